@@ -1,0 +1,148 @@
+"""Oracle Measure/Modify restatement vs independent numpy (float64) formulas.
+
+The reference has no asserting tests for these: parity is unpinned, so the
+restatement is cross-checked against textbook formulas evaluated in float64.
+"""
+import numpy as np
+import pytest
+
+from molar_amd import synth
+from oracle.oracle import PBC_FULL, MeasureError
+
+
+def kabsch_numpy(p1, p2, m):
+    c1 = (p1 * m[:, None]).sum(0) / m.sum()
+    c2 = (p2 * m[:, None]).sum(0) / m.sum()
+    q1, q2 = p1 - c1, p2 - c2
+    cov = (q2[:, :, None] * q1[:, None, :] * m[:, None, None]).sum(0)
+    U, S, Vt = np.linalg.svd(cov)
+    d = -1.0 if np.linalg.det(U @ Vt) < 0 else 1.0
+    R = U @ np.diag([1, 1, d]) @ Vt
+    return R, c2 - R @ c1
+
+
+@pytest.fixture(scope="module")
+def system():
+    n = 5000
+    box = synth.box_a(n)
+    xyz = synth.frame(n, box, 0)
+    rng = np.random.default_rng(3)
+    ang = 0.7
+    axis = np.array([0.3, -0.5, 0.8]); axis /= np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    Rtrue = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    xyz2 = (xyz.astype(np.float64) @ Rtrue.T + np.array([1.5, -2.0, 0.7]) + rng.normal(0, 0.05, xyz.shape)).astype(np.float32)
+    return dict(n=n, box=box, xyz=xyz, xyz2=xyz2, mass=synth.masses(n), idx=np.arange(0, n, 10))
+
+
+@pytest.mark.parametrize("prec,rtol", [("f32", 2e-4), ("f64", 1e-9)])
+def test_reductions(orc32, orc64, system, prec, rtol):
+    o = orc32 if prec == "f32" else orc64
+    s = system
+    idx = s["idx"]
+    p = s["xyz"][idx].astype(np.float64); m = s["mass"][idx].astype(np.float64)
+    assert np.allclose(o.center_of_geometry(s["xyz"], idx), p.mean(0), rtol=rtol)
+    com = (p * m[:, None]).sum(0) / m.sum()
+    assert np.allclose(o.center_of_mass(s["xyz"], s["mass"], idx), com, rtol=rtol)
+    rg = np.sqrt((m * ((p - com) ** 2).sum(1)).sum() / m.sum())
+    assert o.gyration(s["xyz"], s["mass"], idx) == pytest.approx(rg, rel=rtol)
+    lo, up = o.min_max(s["xyz"], idx)
+    assert np.array_equal(lo, s["xyz"][idx].min(0).astype(o.real)) and np.array_equal(up, s["xyz"][idx].max(0).astype(o.real))
+    p2 = s["xyz2"][idx].astype(np.float64)
+    assert o.rmsd(s["xyz"], s["xyz2"], idx, idx) == pytest.approx(np.sqrt(((p2 - p) ** 2).sum(1).mean()), rel=rtol)
+    assert o.rmsd_mw(s["xyz"], s["mass"], s["xyz2"], idx, idx) == pytest.approx(
+        np.sqrt((m * ((p2 - p) ** 2).sum(1)).sum() / m.sum()), rel=rtol)
+    d = p - com
+    T = np.zeros((3, 3))
+    T[0, 0] = (m * (d[:, 1] ** 2 + d[:, 2] ** 2)).sum(); T[1, 1] = (m * (d[:, 0] ** 2 + d[:, 2] ** 2)).sum()
+    T[2, 2] = (m * (d[:, 0] ** 2 + d[:, 1] ** 2)).sum()
+    T[0, 1] = T[1, 0] = -(m * d[:, 0] * d[:, 1]).sum(); T[0, 2] = T[2, 0] = -(m * d[:, 0] * d[:, 2]).sum()
+    T[1, 2] = T[2, 1] = -(m * d[:, 1] * d[:, 2]).sum()
+    assert np.allclose(o.inertia_tensor(s["xyz"], s["mass"], idx), T, rtol=10 * rtol, atol=10 * rtol * abs(T).max())
+    mom, axes = o.inertia(s["xyz"], s["mass"], idx)
+    w, v = np.linalg.eigh(T)
+    assert np.allclose(mom, w, rtol=10 * rtol)
+    assert np.allclose(axes.T @ axes, np.eye(3), atol=1e-5)
+    assert np.linalg.det(axes) == pytest.approx(1.0, abs=1e-5)
+    for k in range(2):
+        assert abs(abs(axes[:, k] @ v[:, k]) - 1) < 1e-3
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("f64", 1e-9)])
+def test_fit_transform(orc32, orc64, system, prec, tol):
+    o = orc32 if prec == "f32" else orc64
+    s = system
+    idx = s["idx"]
+    R, t = o.fit_transform(s["xyz"], s["mass"], s["xyz2"], s["mass"], idx, idx)
+    Rn, tn = kabsch_numpy(s["xyz"][idx].astype(np.float64), s["xyz2"][idx].astype(np.float64),
+                          s["mass"][idx].astype(np.float64))
+    assert np.allclose(R, Rn, atol=tol)
+    assert np.allclose(t, tn, atol=tol * 50)
+    moved = o.apply_transform(s["xyz"], R, t, idx)
+    assert o.rmsd(moved, s["xyz2"], idx, idx) < 0.1          # jitter sigma 0.05 * sqrt(3)
+    untouched = np.setdiff1d(np.arange(s["n"]), idx)
+    assert np.array_equal(moved[untouched], s["xyz"][untouched].astype(o.real))
+
+
+def test_errors(orc32, system):
+    s = system
+    with pytest.raises(MeasureError) as e:
+        orc32.rmsd(s["xyz"], s["xyz2"], s["idx"], s["idx"][:-1])
+    assert e.value.code == 1
+    with pytest.raises(MeasureError) as e:
+        orc32.center_of_mass(s["xyz"], np.zeros(s["n"], np.float32), s["idx"])
+    assert e.value.code == 2
+
+
+def test_pbc_centers_and_unwrap(orc32, orc64, system):
+    """A compact blob straddling the box corner: PBC centre == plain centre of the unwrapped blob."""
+    o = orc64
+    box = synth.box_a(20000)
+    b = o.box_from_matrix(box)
+    rng = np.random.default_rng(5)
+    blob = rng.normal(0, 0.4, (200, 3))                 # centred on the origin = box corner
+    wrapped = np.array([o.wrap_point(b, p) if (p @ np.linalg.inv(box).T >= 0).all() else
+                        (p @ np.linalg.inv(box).T % 1.0) @ box.T for p in blob])
+    m = rng.uniform(1, 16, 200)
+    un = o.unwrap_simple_dim(wrapped, b, PBC_FULL)
+    # all unwrapped atoms are within the blob radius of atom 0 again
+    assert np.linalg.norm(un - un[0], axis=1).max() < 4.0
+    # reference quirk (measure.rs:180-182): cm starts at UNWEIGHTED p0 with mass m0
+    imgs = un.copy()
+    cm = imgs[0] + (imgs[1:] * m[1:, None]).sum(0)
+    expect = cm / m.sum()
+    got = o.center_of_mass_pbc_dims(wrapped, m, b, PBC_FULL)
+    assert np.allclose(got, expect, rtol=1e-9, atol=1e-9)
+    assert np.allclose(o.center_of_geometry_pbc_dims(wrapped, b, PBC_FULL), imgs.mean(0), atol=1e-9)
+    got32 = orc32.center_of_mass_pbc_dims(wrapped, m, orc32.box_from_matrix(box), PBC_FULL)
+    assert np.allclose(got32, expect, atol=1e-4)
+    assert o.gyration_pbc(wrapped, m, b) > 0
+
+
+def test_lipid_tail_order_sz_known_geometry(orc64):
+    # all-trans zig-zag chain along z, normal = z: every C(k-1)->C(k+1) vector is parallel to z => Sz = 1
+    n = 8
+    xyz = np.array([[0.05 * (k % 2), 0.0, 0.127 * k] for k in range(n)])
+    sz = orc64.lipid_tail_order(xyz, 0, [[0, 0, 1.0]], np.ones(n - 1, np.uint8))
+    assert np.allclose(sz, 1.0, atol=1e-12)
+    # normal perpendicular => Sz = -0.5
+    sz = orc64.lipid_tail_order(xyz, 0, [[0, 1.0, 0]], np.ones(n - 1, np.uint8))
+    assert np.allclose(sz, -0.5, atol=1e-12)
+    # Scd of an all-trans chain along the normal: ideal value -0.5 for every CH2
+    scd = orc64.lipid_tail_order(xyz, 1, [[0, 0, 1.0]], np.ones(n - 1, np.uint8))
+    assert np.allclose(scd, 0.5, atol=1e-9) or np.allclose(scd, -0.5, atol=1e-9)
+    with pytest.raises(MeasureError) as e:
+        orc64.lipid_tail_order(xyz[:2], 0, [[0, 0, 1.0]], np.ones(1, np.uint8))
+    assert e.value.code == 7
+    with pytest.raises(MeasureError) as e:
+        orc64.lipid_tail_order(xyz, 0, [[0, 0, 1.0]] * 3, np.ones(n - 1, np.uint8))
+    assert e.value.code == 8
+    with pytest.raises(MeasureError) as e:
+        orc64.lipid_tail_order(xyz, 0, [[0, 0, 1.0]], np.ones(n, np.uint8))
+    assert e.value.code == 9
+
+
+def test_histogram(orc32):
+    vals = np.array([0.0, 0.0005, 0.001, 1.1999, 1.2, -0.1, 0.6], np.float32)
+    bins = orc32.histogram_add(0.0, 1.2, 1200, vals)
+    assert bins.sum() == 5 and bins[0] == 2 and bins[1] == 1 and bins[1199] == 1 and bins[600] + bins[599] == 1
