@@ -1,0 +1,226 @@
+/*
+ * molar_hip.h — C ABI of libmolar_hip.so, the MI355X (gfx950) engine for MolAR's per-frame
+ * hot path: distance_search, PeriodicBox, Measure (COM/COG/gyration/inertia/rmsd/fit) and
+ * Modify (apply_transform/unwrap_simple).
+ *
+ * This is the drop-in boundary.  It follows the reference's own runtime-plugin
+ * convention (molar_gromacs/gromacs/wrapper.hpp:34-81): opaque handle + open/close,
+ * thread-local last_error string, caller-owned output buffers filled after a count call,
+ * plain C types only.  Each entry point names the reference interface it replaces
+ * (paths relative to /root/reference/).
+ *
+ * Data layout handed over by MolAR (providers.rs:96-136, state.rs:22-28, atom_storage.rs:272):
+ *   xyz   : whole frame, AoS float[3*natoms] (Vec<Pos>, Pos = Point3<f32>)
+ *   idx   : sorted selection index slice (usize -> uint64_t), NULL = identity 0..natoms
+ *   mass  : full-length column float[natoms], gathered through idx
+ *   box9  : column-major float[9], COLUMNS are the box vectors a,b,c (periodic_box.rs:7-13)
+ *   pbc   : PbcDims bit mask, bit d <=> dimension d (periodic_box.rs:81-114)
+ *
+ * Every pointer argument may be a HOST pointer or a DEVICE (HIP) pointer; the library detects
+ * which (hipPointerGetAttributes) and stages host buffers through its own device buffers.
+ * Device-resident inputs/outputs are used in place: no copy, kernels read/write them directly.
+ *
+ * Threading: a context is owned by one thread at a time (MolAR calls the search from one
+ * thread, distance_search.rs:949); use one context per thread / per GPU.
+ */
+#ifndef MOLAR_HIP_H
+#define MOLAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes: MeasureError (molar/src/measure.rs:732-762), PeriodicBoxError
+ * (periodic_box.rs:131-144), LipidOrderError (measure.rs:718-729) */
+enum {
+    MOLAR_HIP_OK = 0,
+    MOLAR_HIP_ERR_SIZES = 1,
+    MOLAR_HIP_ERR_ZERO_MASS = 2,
+    MOLAR_HIP_ERR_SVD = 3,
+    MOLAR_HIP_ERR_NO_PBC = 4,
+    MOLAR_HIP_ERR_ZERO_LENGTH_VECTOR = 5,
+    MOLAR_HIP_ERR_INVERSE_FAILED = 6,
+    MOLAR_HIP_ERR_LIPID_TAIL_TOO_SHORT = 7,
+    MOLAR_HIP_ERR_LIPID_NORMALS_COUNT = 8,
+    MOLAR_HIP_ERR_LIPID_BOND_ORDER_COUNT = 9,
+    MOLAR_HIP_ERR_ANGLE_TOO_SMALL = 10,
+    MOLAR_HIP_ERR_INVALID_ARGUMENT = 50,
+    MOLAR_HIP_ERR_TOO_LARGE = 51,
+    MOLAR_HIP_ERR_NO_SEARCH = 52,
+    MOLAR_HIP_ERR_HIP = 100       /* HIP runtime failure, text in molar_hip_last_error() */
+};
+
+#define MOLAR_HIP_PBC_FULL 7u     /* periodic_box.rs:126 */
+#define MOLAR_HIP_PBC_NONE 0u     /* periodic_box.rs:128 */
+
+/* ------------------------------------------------------------------ lifecycle */
+
+typedef struct molar_hip_ctx molar_hip_ctx;   /* opaque, like TprHandle (wrapper.hpp:34-36) */
+
+/* Create an engine bound to HIP device `device`.  NULL on error (no GPU, bad ordinal);
+ * message via molar_hip_last_error().  Mirrors tpr_open/tpr_close (wrapper.hpp:42-44). */
+molar_hip_ctx *molar_hip_create(int device);
+void molar_hip_destroy(molar_hip_ctx *ctx);
+/* Thread-local text of the last failure on this thread; mirrors tpr_last_error (wrapper.hpp:46). */
+const char *molar_hip_last_error(void);
+const char *molar_hip_version(void);
+/* Number of visible HIP devices, 0 if none / no driver (never fails). */
+int molar_hip_device_count(void);
+/* Run this context's kernels on an existing hipStream_t (e.g. torch's current stream). */
+int molar_hip_set_stream(molar_hip_ctx *ctx, void *hip_stream);
+int molar_hip_synchronize(molar_hip_ctx *ctx);
+
+/* Per-kernel-class timing with HIP events recorded on the context's stream (what bench.py's
+ * roofline line is computed from).  Classes: 0 grid build (bin/scan/scatter/place), 1 pair count
+ * kernel, 2 offset scan, 3 pair fill kernel, 4 measure/fit kernels.  read() synchronises the
+ * stream, returns the accumulated milliseconds and launch counts since the last read, and resets. */
+#define MOLAR_HIP_PROFILE_CLASSES 8
+int molar_hip_profile_enable(molar_hip_ctx *ctx, int on);
+int molar_hip_profile_read(molar_hip_ctx *ctx, float ms[MOLAR_HIP_PROFILE_CLASSES],
+                           uint64_t launches[MOLAR_HIP_PROFILE_CLASSES]);
+
+/* ------------------------------------------------------------------ PeriodicBox (periodic_box.rs:15-23) */
+
+typedef struct {
+    float m[9];          /* column-major, columns a,b,c */
+    float inv[9];        /* nalgebra try_inverse */
+    int32_t nshift;      /* tric_corrections.len(), 0 for orthogonal boxes */
+    float shifts[26 * 3];
+} molar_hip_box;
+
+/* PeriodicBox::from_matrix (periodic_box.rs:156-176): ERR_ZERO_LENGTH_VECTOR / ERR_INVERSE_FAILED. */
+int molar_hip_box_from_matrix(const float m9[9], molar_hip_box *out);
+/* PeriodicBox::from_vectors_angles (periodic_box.rs:188-235), angles in degrees. */
+int molar_hip_box_from_vectors_angles(float a, float b, float c, float alpha, float beta, float gamma,
+                                      molar_hip_box *out);
+/* shortest_vector_dims (periodic_box.rs:286-318), host arithmetic identical to the device code. */
+void molar_hip_box_shortest_vector(const molar_hip_box *box, const float v[3], uint8_t pbc, float out[3]);
+/* get_lab_extents (periodic_box.rs:369-375): row sums, what sizes the search grid. */
+void molar_hip_box_lab_extents(const molar_hip_box *box, float out[3]);
+
+/* ------------------------------------------------------------------ distance search (distance_search.rs) */
+
+enum {
+    MOLAR_HIP_SEARCH_SINGLE = 0,      /* distance_search_single(_pbc)      :892-954 */
+    MOLAR_HIP_SEARCH_DOUBLE = 1,      /* distance_search_double(_pbc)      :659-754 */
+    MOLAR_HIP_SEARCH_WITHIN = 2,      /* distance_search_within(_pbc)      :519-598 */
+    MOLAR_HIP_SEARCH_DOUBLE_VDW = 3   /* distance_search_double_vdw(_pbc)  :767-879 */
+};
+
+/* One search request.  Set 1 = (xyz1, natoms1, idx1, n1); set 2 likewise (unused for SINGLE).
+ * The reference takes iterators of &Pos and of ids; here positions are gathered through idx
+ * and the emitted ids are idx values (ids_local=0: iter_index(), molar_python/src/lib.rs:296-302)
+ * or 0..n-1 (ids_local=1: modify.rs:78, all vdw drivers :791-792).
+ * box9 == NULL selects the non-periodic driver, otherwise the *_pbc driver with `pbc`.
+ * WITHIN without a box needs lower/upper (selection/ast.rs:597-612 computes them from min_max). */
+typedef struct {
+    int32_t kind;
+    float cutoff;              /* ignored for DOUBLE_VDW (derived from the radii, :781-783) */
+    const float *xyz1;
+    size_t natoms1;
+    const uint64_t *idx1;
+    size_t n1;
+    const float *xyz2;
+    size_t natoms2;
+    const uint64_t *idx2;
+    size_t n2;
+    const float *vdw1;         /* DOUBLE_VDW: radii per SELECTED atom, length n1 / n2 */
+    const float *vdw2;
+    int32_t ids_local;
+    const float *box9;
+    uint8_t pbc;
+    const float *lower3;       /* WITHIN non-periodic only */
+    const float *upper3;
+} molar_hip_search_desc;
+
+/* Phase 1 (count): builds the cell grid on the GPU, evaluates every cell pair of the
+ * reference's search plan, returns the number of results in reference order.  The request
+ * stays cached in ctx for the fill calls (tpr_n* then tpr_fill_*, wrapper.hpp:48-61). */
+int molar_hip_search_count(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_count);
+/* Phase 2 (fill), results in exactly the reference's order (plan order, then i-major, j-minor;
+ * distance_search.rs:949-953).  pairs: uint32 [count][2] (i,j); dist: float[count] = sqrt(d2)
+ * (DistanceSearchOutput for (usize,usize,Float), :22-26).  Either may be NULL to skip it. */
+int molar_hip_search_fill(molar_hip_ctx *ctx, uint32_t *pairs, float *dist);
+/* Same, widened to MolAR's usize: separate i[], j[] arrays of uint64. */
+int molar_hip_search_fill_usize(molar_hip_ctx *ctx, uint64_t *i, uint64_t *j, float *dist);
+/* WITHIN results (DistanceSearchOutput for usize, :10-14): ids of set-1 atoms, duplicates kept
+ * exactly as the reference emits them (callers sort+dedup, selection_expr.rs:112). */
+int molar_hip_search_fill_ids(molar_hip_ctx *ctx, uint64_t *ids);
+/* Grid dims of the cached search (Grid::get_dims, :212-214). */
+int molar_hip_search_grid_dims(molar_hip_ctx *ctx, uint64_t dims[3]);
+/* Device-resident result of the cached search: fills ctx-owned buffers (reused across frames)
+ * and returns their device addresses; valid until the next search on this ctx. */
+int molar_hip_search_fill_device(molar_hip_ctx *ctx, const uint32_t **d_pairs, const float **d_dist);
+/* Consumer-fused variant: never materialises pairs; every emitted distance d goes through
+ * Histogram1D::add_one (molar_membrane/src/stats.rs:29-35): b=floor(n*(d-min)/(max-min)),
+ * counted in integers (bins: uint64[nbins], accumulated INTO, so frames can be summed). */
+int molar_hip_search_histogram(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, float hmin,
+                               float hmax, size_t nbins, uint64_t *bins, uint64_t *out_count);
+
+/* ------------------------------------------------------------------ Measure (measure.rs) */
+
+/* min_max :22-36 */
+int molar_hip_min_max(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                      float lower[3], float upper[3]);
+/* center_of_geometry :39-47 */
+int molar_hip_center_of_geometry(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx,
+                                 size_t n, float out[3]);
+/* center_of_mass :60-75 (ERR_ZERO_MASS) */
+int molar_hip_center_of_mass(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                             const float *mass, float out[3]);
+/* center_of_geometry_pbc_dims :156-168 / center_of_mass_pbc_dims :197-220 (ERR_NO_PBC if box9==NULL) */
+int molar_hip_center_of_geometry_pbc(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx,
+                                     size_t n, const float *box9, uint8_t pbc, float out[3]);
+int molar_hip_center_of_mass_pbc(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx,
+                                 size_t n, const float *mass, const float *box9, uint8_t pbc, float out[3]);
+/* gyration :78-87, gyration_pbc :222-232 (box9 != NULL) */
+int molar_hip_gyration(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                       const float *mass, const float *box9, float *out);
+/* inertia :90-99 / inertia_pbc :234-244: moments ascending, axes column-major (cols = axes);
+ * tensor9 (optional) receives the raw tensor (column-major). */
+int molar_hip_inertia(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                      const float *mass, const float *box9, float moments[3], float axes9[9], float tensor9[9]);
+/* rmsd :485-504 (ERR_SIZES), rmsd_mw :538-558 (masses of selection 1) */
+int molar_hip_rmsd(molar_hip_ctx *ctx, const float *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                   const float *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2, float *out);
+int molar_hip_rmsd_mw(molar_hip_ctx *ctx, const float *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                      const float *mass1, const float *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2,
+                      float *out);
+/* fit_transform :507-522 / fit_transform_at_origin :525-535 (at_origin != 0):
+ * IsometryMatrix3 as R (column-major) and t, p -> R p + t. */
+int molar_hip_fit_transform(molar_hip_ctx *ctx, const float *xyz1, size_t natoms1, const uint64_t *idx1,
+                            size_t n1, const float *mass1, const float *xyz2, size_t natoms2,
+                            const uint64_t *idx2, size_t n2, const float *mass2, int at_origin, float R9[9],
+                            float t3[3]);
+
+/* ------------------------------------------------------------------ Modify (modify.rs) */
+
+/* apply_transform :32-36 — in place on xyz (host buffers are copied back). */
+int molar_hip_apply_transform(molar_hip_ctx *ctx, float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                              const float R9[9], const float t3[3]);
+/* unwrap_simple_dim :40-54 */
+int molar_hip_unwrap_simple(molar_hip_ctx *ctx, float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                            const float *box9, uint8_t pbc);
+
+/* ------------------------------------------------------------------ batched per-frame analysis */
+
+/* The per-frame align+RMSD loop of the reference's benchmark (benches/comparison_small.rs:14-25,
+ * SURVEY.md §3.4) for `nframes` frames resident in one buffer frames[nframes][natoms][3]:
+ *   tr = fit_transform(cur, ref); apply_transform(cur, tr); rmsd(cur, ref);
+ *   center_of_mass(cur); gyration(cur)
+ * Selection idx/mass are shared by all frames (topology-side arrays).  `frames` is modified in
+ * place when apply != 0.  Outputs are per frame; any of them may be NULL.
+ * Replaces the serial frame loop of AnalysisTask::run (analysis_task.rs:202-252) for this task. */
+int molar_hip_fit_rmsd_batch(molar_hip_ctx *ctx, float *frames, size_t nframes, size_t natoms,
+                             const uint64_t *idx, size_t n, const float *mass, const float *ref_xyz,
+                             size_t ref_natoms, const uint64_t *ref_idx, int apply, float *rmsd_out,
+                             float *R_out /*[nframes][9]*/, float *t_out /*[nframes][3]*/,
+                             float *com_out /*[nframes][3]*/, float *gyr_out /*[nframes]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOLAR_HIP_H */

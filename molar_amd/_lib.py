@@ -1,0 +1,113 @@
+"""Loader for libmolar_hip.so (the C-ABI engine).
+
+Search order mirrors MolAR's own plugin loader (molar_gromacs/src/lib.rs:95-116):
+  1. MOLAR_HIP_PLUGIN environment variable (user override),
+  2. the in-tree build next to this file (molar_amd/libmolar_hip.so).
+There is deliberately NO CPU fallback: if the library is missing or no GPU is visible the
+product path raises — a silent eager path would void every parity claim.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libmolar_hip.so")
+
+_lib = None
+
+
+class MolarHipError(RuntimeError):
+    """Status code + molar_hip_last_error() text.  Codes: include/molar_hip.h."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[molar_hip status {code}] {msg}")
+        self.code = code
+
+
+class Box(C.Structure):
+    """molar_hip_box (include/molar_hip.h) == PeriodicBox (periodic_box.rs:15-23)."""
+    _fields_ = [("m", C.c_float * 9), ("inv", C.c_float * 9), ("nshift", C.c_int32), ("shifts", C.c_float * 78)]
+
+
+class SearchDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("cutoff", C.c_float),
+        ("xyz1", C.c_void_p), ("natoms1", C.c_size_t), ("idx1", C.c_void_p), ("n1", C.c_size_t),
+        ("xyz2", C.c_void_p), ("natoms2", C.c_size_t), ("idx2", C.c_void_p), ("n2", C.c_size_t),
+        ("vdw1", C.c_void_p), ("vdw2", C.c_void_p),
+        ("ids_local", C.c_int32),
+        ("box9", C.c_void_p), ("pbc", C.c_uint8),
+        ("lower3", C.c_void_p), ("upper3", C.c_void_p),
+    ]
+
+
+# every symbol include/molar_hip.h declares: name -> (restype, argtypes)
+_P, _SZ, _F, _I, _U8 = C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_uint8
+SYMBOLS = {
+    "molar_hip_create": (C.c_void_p, [_I]),
+    "molar_hip_destroy": (None, [_P]),
+    "molar_hip_last_error": (C.c_char_p, []),
+    "molar_hip_version": (C.c_char_p, []),
+    "molar_hip_device_count": (_I, []),
+    "molar_hip_set_stream": (_I, [_P, _P]),
+    "molar_hip_synchronize": (_I, [_P]),
+    "molar_hip_profile_enable": (_I, [_P, _I]),
+    "molar_hip_profile_read": (_I, [_P, _P, _P]),
+    "molar_hip_box_from_matrix": (_I, [_P, _P]),
+    "molar_hip_box_from_vectors_angles": (_I, [_F, _F, _F, _F, _F, _F, _P]),
+    "molar_hip_box_shortest_vector": (None, [_P, _P, _U8, _P]),
+    "molar_hip_box_lab_extents": (None, [_P, _P]),
+    "molar_hip_search_count": (_I, [_P, _P, _P]),
+    "molar_hip_search_fill": (_I, [_P, _P, _P]),
+    "molar_hip_search_fill_usize": (_I, [_P, _P, _P, _P]),
+    "molar_hip_search_fill_ids": (_I, [_P, _P]),
+    "molar_hip_search_grid_dims": (_I, [_P, _P]),
+    "molar_hip_search_fill_device": (_I, [_P, _P, _P]),
+    "molar_hip_search_histogram": (_I, [_P, _P, _F, _F, _SZ, _P, _P]),
+    "molar_hip_min_max": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
+    "molar_hip_center_of_geometry": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
+    "molar_hip_center_of_mass": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
+    "molar_hip_center_of_geometry_pbc": (_I, [_P, _P, _SZ, _P, _SZ, _P, _U8, _P]),
+    "molar_hip_center_of_mass_pbc": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _U8, _P]),
+    "molar_hip_gyration": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _P]),
+    "molar_hip_inertia": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _P, _P, _P]),
+    "molar_hip_rmsd": (_I, [_P, _P, _SZ, _P, _SZ, _P, _SZ, _P, _SZ, _P]),
+    "molar_hip_rmsd_mw": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P]),
+    "molar_hip_fit_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P, _I, _P, _P]),
+    "molar_hip_apply_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
+    "molar_hip_unwrap_simple": (_I, [_P, _P, _SZ, _P, _SZ, _P, _U8]),
+    "molar_hip_fit_rmsd_batch": (_I, [_P, _P, _SZ, _SZ, _P, _SZ, _P, _P, _SZ, _P, _I, _P, _P, _P, _P, _P]),
+}
+
+
+def lib_path() -> str:
+    return os.environ.get("MOLAR_HIP_PLUGIN", DEFAULT_LIB)
+
+
+def load():
+    """dlopen the engine and bind every symbol of the header; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"libmolar_hip.so not found at {path}: build it with `python -m molar_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().molar_hip_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise MolarHipError(rc, last_error())

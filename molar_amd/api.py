@@ -1,0 +1,512 @@
+"""Host-side mirror of the pymolar surface for the accelerated path, over the C ABI.
+
+Mirrors (same names, argument meaning, error behaviour) the Python front-end of the reference
+for this path — molar_python/python/pymolar/molar.pyi:130-213 and molar_python/src/lib.rs:
+    distance_search(cutoff | "vdw", sel1, sel2=None, dims=None) -> (pairs[N,2], dist[N])
+    fit_transform(sel1, sel2), fit_transform_at_origin, rmsd(sel1, sel2) [rmsd_py], rmsd_mw
+    Sel.com(dims) / cog(dims) / gyration() / inertia() / min_max() / apply_transform / unwrap_simple
+    PeriodicBox(vectors, angles) / PeriodicBox.from_matrix, shortest_vector, ...
+Only the numeric path is here: no selection language, no file IO (out of scope).
+Arrays may be numpy (host) or torch CUDA tensors (device-resident, used in place).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Box, MolarHipError, SearchDesc, check
+
+PBC_FULL = 7
+PBC_NONE = 0
+
+SEARCH_SINGLE, SEARCH_DOUBLE, SEARCH_WITHIN, SEARCH_DOUBLE_VDW = 0, 1, 2, 3
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _addr(x):
+    """(address, keepalive) of a numpy array or a torch tensor; None -> (None, None)."""
+    if x is None:
+        return None, None
+    if _is_torch(x):
+        assert x.is_contiguous()
+        return x.data_ptr(), x
+    return x.ctypes.data, x
+
+
+def _f32(x, shape=None):
+    if x is None:
+        return None
+    if _is_torch(x):
+        import torch
+        assert x.dtype == torch.float32
+        return x.contiguous()
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    return a.reshape(shape) if shape is not None else a
+
+
+def _u64(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        import torch
+        if x.dtype == torch.int64:
+            return x.contiguous()     # non-negative int64 has the same bits as uint64
+        raise TypeError("index tensors must be int64")
+    return np.ascontiguousarray(x, dtype=np.uint64)
+
+
+def pbc_mask(dims) -> int:
+    """PbcDims::new (periodic_box.rs:101-107); None -> all False like the Python front-end."""
+    if dims is None:
+        return 0
+    if isinstance(dims, (int, np.integer)):
+        return int(dims) & 7
+    return (1 if dims[0] else 0) | (2 if dims[1] else 0) | (4 if dims[2] else 0)
+
+
+class PeriodicBox:
+    """periodic_box.rs:146-435 (host arithmetic of the engine, identical to its device code)."""
+
+    def __init__(self, vectors=None, angles=None, _box=None):
+        lib = _lib.load()
+        self._b = Box()
+        if _box is not None:
+            self._b = _box
+        else:
+            v, a = vectors, angles
+            check(lib.molar_hip_box_from_vectors_angles(v[0], v[1], v[2], a[0], a[1], a[2], C.byref(self._b)))
+
+    @classmethod
+    def from_matrix(cls, m):
+        """m: 3x3 with COLUMNS = box vectors a,b,c (periodic_box.rs:7-13)."""
+        lib = _lib.load()
+        m = np.asarray(m, dtype=np.float32).reshape(3, 3)
+        flat = np.ascontiguousarray(m.T).reshape(9)
+        b = Box()
+        check(lib.molar_hip_box_from_matrix(flat.ctypes.data, C.byref(b)))
+        return cls(_box=b)
+
+    def get_matrix(self):
+        return np.array(self._b.m, dtype=np.float32).reshape(3, 3).T.copy()
+
+    def colmajor9(self):
+        return np.array(self._b.m, dtype=np.float32)
+
+    def shortest_vector(self, v, dims=PBC_FULL):
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        out = np.zeros(3, np.float32)
+        _lib.load().molar_hip_box_shortest_vector(C.byref(self._b), v.ctypes.data, pbc_mask(dims), out.ctypes.data)
+        return out
+
+    def closest_image(self, point, target, dims=PBC_FULL):
+        point = np.asarray(point, np.float32); target = np.asarray(target, np.float32)
+        return target + self.shortest_vector(point - target, dims)
+
+    def distance(self, p1, p2, dims=PBC_FULL):
+        p1 = np.asarray(p1, np.float32); p2 = np.asarray(p2, np.float32)
+        s = self.shortest_vector(p2 - p1, dims)
+        return float(np.sqrt(np.float32(s[0] * s[0] + s[1] * s[1]) + np.float32(s[2] * s[2])))
+
+    def get_lab_extents(self):
+        out = np.zeros(3, np.float32)
+        _lib.load().molar_hip_box_lab_extents(C.byref(self._b), out.ctypes.data)
+        return out
+
+    @property
+    def n_tric_corrections(self):
+        return int(self._b.nshift)
+
+
+class Engine:
+    """One molar_hip_ctx: a GPU, a stream and reusable device buffers."""
+
+    def __init__(self, device: int = 0, stream=None):
+        self.lib = _lib.load()
+        self.ctx = self.lib.molar_hip_create(device)
+        if not self.ctx:
+            raise MolarHipError(100, _lib.last_error())
+        self.device = device
+        if stream is not None:
+            check(self.lib.molar_hip_set_stream(self.ctx, C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.molar_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.molar_hip_synchronize(self.ctx))
+
+    PROFILE_CLASSES = ("grid_build", "pair_count", "offset_scan", "pair_fill", "measure")
+
+    def profile_enable(self, on=True):
+        check(self.lib.molar_hip_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_read(self):
+        """{class: (milliseconds, launches)} accumulated since the last read (HIP events)."""
+        ms = (C.c_float * 8)(); ln = (C.c_uint64 * 8)()
+        check(self.lib.molar_hip_profile_read(self.ctx, ms, ln))
+        return {name: (float(ms[k]), int(ln[k])) for k, name in enumerate(self.PROFILE_CLASSES)}
+
+    # ------------------------------------------------------------ search
+    def search_count(self, kind, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, vdw1=None,
+                     vdw2=None, ids_local=False, lower=None, upper=None) -> int:
+        xyz1 = _f32(xyz1); xyz2 = _f32(xyz2); idx1 = _u64(idx1); idx2 = _u64(idx2)
+        vdw1 = _f32(vdw1); vdw2 = _f32(vdw2)
+        d = SearchDesc()
+        d.kind = kind
+        d.cutoff = float(cutoff) if cutoff is not None else 0.0
+        keep = []
+        for name, arr in (("xyz1", xyz1), ("idx1", idx1), ("xyz2", xyz2), ("idx2", idx2), ("vdw1", vdw1),
+                          ("vdw2", vdw2)):
+            a, k = _addr(arr)
+            setattr(d, name, a)
+            keep.append(k)
+        d.natoms1 = 0 if xyz1 is None else xyz1.shape[0] if xyz1.ndim == 2 else xyz1.shape[0] // 3
+        d.natoms2 = 0 if xyz2 is None else xyz2.shape[0] if xyz2.ndim == 2 else xyz2.shape[0] // 3
+        d.n1 = 0 if idx1 is None else idx1.shape[0]
+        d.n2 = 0 if idx2 is None else idx2.shape[0]
+        d.ids_local = 1 if ids_local else 0
+        if box is not None:
+            b9 = box.colmajor9() if isinstance(box, PeriodicBox) else np.ascontiguousarray(
+                np.asarray(box, np.float32).reshape(3, 3).T).reshape(9)
+            keep.append(b9)
+            d.box9 = b9.ctypes.data
+        d.pbc = pbc_mask(pbc)
+        if lower is not None:
+            lo = np.ascontiguousarray(lower, np.float32); up = np.ascontiguousarray(upper, np.float32)
+            keep += [lo, up]
+            d.lower3 = lo.ctypes.data
+            d.upper3 = up.ctypes.data
+        cnt = C.c_uint64(0)
+        check(self.lib.molar_hip_search_count(self.ctx, C.byref(d), C.byref(cnt)))
+        self._keep = keep
+        return int(cnt.value)
+
+    def search_fill(self, count):
+        pairs = np.empty((count, 2), np.uint32)
+        dist = np.empty(count, np.float32)
+        check(self.lib.molar_hip_search_fill(self.ctx, pairs.ctypes.data, dist.ctypes.data))
+        return pairs, dist
+
+    def search_fill_usize(self, count):
+        i = np.empty(count, np.uint64); j = np.empty(count, np.uint64); d = np.empty(count, np.float32)
+        check(self.lib.molar_hip_search_fill_usize(self.ctx, i.ctypes.data, j.ctypes.data, d.ctypes.data))
+        return i, j, d
+
+    def search_fill_ids(self, count):
+        ids = np.empty(count, np.uint64)
+        check(self.lib.molar_hip_search_fill_ids(self.ctx, ids.ctypes.data))
+        return ids
+
+    def search_fill_device(self):
+        """Fill ctx-owned device buffers; returns (pairs_ptr, dist_ptr) device addresses."""
+        p = C.c_void_p(); d = C.c_void_p()
+        check(self.lib.molar_hip_search_fill_device(self.ctx, C.byref(p), C.byref(d)))
+        return p.value, d.value
+
+    def search_fill_into(self, pairs_t, dist_t):
+        """Fill caller-owned torch CUDA tensors (uint32/int32 [N,2], float32 [N]) in place."""
+        pa, _ = _addr(pairs_t); da, _ = _addr(dist_t)
+        check(self.lib.molar_hip_search_fill(self.ctx, pa, da))
+
+    def grid_dims(self):
+        dims = (C.c_uint64 * 3)()
+        check(self.lib.molar_hip_search_grid_dims(self.ctx, dims))
+        return tuple(int(x) for x in dims)
+
+    def search_histogram(self, kind, cutoff, hmin, hmax, nbins, xyz1, bins=None, **kw):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------ measure
+    def _sel_args(self, xyz, idx):
+        xyz = _f32(xyz); idx = _u64(idx)
+        xa, k1 = _addr(xyz); ia, k2 = _addr(idx)
+        natoms = xyz.shape[0] if xyz.ndim == 2 else xyz.shape[0] // 3
+        n = 0 if idx is None else idx.shape[0]
+        return xa, natoms, ia, n, (k1, k2)
+
+    @staticmethod
+    def _box9(box):
+        if box is None:
+            return None, None
+        b9 = box.colmajor9() if isinstance(box, PeriodicBox) else np.ascontiguousarray(
+            np.asarray(box, np.float32).reshape(3, 3).T).reshape(9)
+        return b9.ctypes.data, b9
+
+    def min_max(self, xyz, idx=None):
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        lo = np.zeros(3, np.float32); up = np.zeros(3, np.float32)
+        check(self.lib.molar_hip_min_max(self.ctx, xa, na, ia, n, lo.ctypes.data, up.ctypes.data))
+        return lo, up
+
+    def center_of_geometry(self, xyz, idx=None):
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        out = np.zeros(3, np.float32)
+        check(self.lib.molar_hip_center_of_geometry(self.ctx, xa, na, ia, n, out.ctypes.data))
+        return out
+
+    def center_of_mass(self, xyz, mass, idx=None):
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        mass = _f32(mass); ma, km = _addr(mass)
+        out = np.zeros(3, np.float32)
+        check(self.lib.molar_hip_center_of_mass(self.ctx, xa, na, ia, n, ma, out.ctypes.data))
+        return out
+
+    def center_of_geometry_pbc(self, xyz, box, dims=PBC_FULL, idx=None):
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        ba, kb = self._box9(box)
+        out = np.zeros(3, np.float32)
+        check(self.lib.molar_hip_center_of_geometry_pbc(self.ctx, xa, na, ia, n, ba, pbc_mask(dims), out.ctypes.data))
+        return out
+
+    def center_of_mass_pbc(self, xyz, mass, box, dims=PBC_FULL, idx=None):
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        mass = _f32(mass); ma, km = _addr(mass)
+        ba, kb = self._box9(box)
+        out = np.zeros(3, np.float32)
+        check(self.lib.molar_hip_center_of_mass_pbc(self.ctx, xa, na, ia, n, ma, ba, pbc_mask(dims), out.ctypes.data))
+        return out
+
+    def gyration(self, xyz, mass, idx=None, box=None):
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        mass = _f32(mass); ma, km = _addr(mass)
+        ba, kb = self._box9(box)
+        out = C.c_float(0)
+        check(self.lib.molar_hip_gyration(self.ctx, xa, na, ia, n, ma, ba, C.byref(out)))
+        return float(out.value)
+
+    def inertia(self, xyz, mass, idx=None, box=None):
+        """(moments[3] ascending, axes 3x3 with axes as columns, raw tensor 3x3)."""
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        mass = _f32(mass); ma, km = _addr(mass)
+        ba, kb = self._box9(box)
+        mom = np.zeros(3, np.float32); axes = np.zeros(9, np.float32); tens = np.zeros(9, np.float32)
+        check(self.lib.molar_hip_inertia(self.ctx, xa, na, ia, n, ma, ba, mom.ctypes.data, axes.ctypes.data,
+                                         tens.ctypes.data))
+        return mom, axes.reshape(3, 3).T.copy(), tens.reshape(3, 3).T.copy()
+
+    def rmsd(self, xyz1, xyz2, idx1=None, idx2=None):
+        a1 = self._sel_args(xyz1, idx1); a2 = self._sel_args(xyz2, idx2)
+        out = C.c_float(0)
+        check(self.lib.molar_hip_rmsd(self.ctx, *a1[:4], *a2[:4], C.byref(out)))
+        return float(out.value)
+
+    def rmsd_mw(self, xyz1, mass1, xyz2, idx1=None, idx2=None):
+        a1 = self._sel_args(xyz1, idx1); a2 = self._sel_args(xyz2, idx2)
+        mass1 = _f32(mass1); ma, km = _addr(mass1)
+        out = C.c_float(0)
+        check(self.lib.molar_hip_rmsd_mw(self.ctx, *a1[:4], ma, *a2[:4], C.byref(out)))
+        return float(out.value)
+
+    def fit_transform(self, xyz1, mass1, xyz2, mass2, idx1=None, idx2=None, at_origin=False):
+        """(R, t) with p -> R @ p + t  (IsometryMatrix3, measure.rs:507-535)."""
+        a1 = self._sel_args(xyz1, idx1); a2 = self._sel_args(xyz2, idx2)
+        mass1 = _f32(mass1); m1, k1 = _addr(mass1)
+        mass2 = _f32(mass2); m2, k2 = _addr(mass2)
+        R = np.zeros(9, np.float32); t = np.zeros(3, np.float32)
+        check(self.lib.molar_hip_fit_transform(self.ctx, *a1[:4], m1, *a2[:4], m2, 1 if at_origin else 0,
+                                               R.ctypes.data, t.ctypes.data))
+        return R.reshape(3, 3).T.copy(), t
+
+    def apply_transform(self, xyz, R, t, idx=None):
+        """In place on xyz (numpy float32 C-contiguous array or torch CUDA tensor)."""
+        if not _is_torch(xyz):
+            assert xyz.dtype == np.float32 and xyz.flags.c_contiguous, "apply_transform works in place"
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        Rf = np.ascontiguousarray(np.asarray(R, np.float32).T).reshape(9)
+        tf = np.ascontiguousarray(t, np.float32)
+        check(self.lib.molar_hip_apply_transform(self.ctx, xa, na, ia, n, Rf.ctypes.data, tf.ctypes.data))
+        return xyz
+
+    def unwrap_simple(self, xyz, box, dims=PBC_FULL, idx=None):
+        if not _is_torch(xyz):
+            assert xyz.dtype == np.float32 and xyz.flags.c_contiguous, "unwrap_simple works in place"
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        ba, kb = self._box9(box)
+        check(self.lib.molar_hip_unwrap_simple(self.ctx, xa, na, ia, n, ba, pbc_mask(dims)))
+        return xyz
+
+    def fit_rmsd_batch(self, frames, mass, ref_xyz, idx=None, ref_idx=None, apply=True):
+        """frames: [F, natoms, 3] (numpy, modified in place if apply; or torch CUDA tensor).
+        Returns dict(rmsd[F], R[F,3,3], t[F,3], com[F,3], gyration[F])."""
+        if _is_torch(frames):
+            F, natoms = frames.shape[0], frames.shape[1]
+            fa, kf = _addr(frames.contiguous())
+        else:
+            assert frames.dtype == np.float32 and frames.flags.c_contiguous
+            F, natoms = frames.shape[0], frames.shape[1]
+            fa, kf = _addr(frames)
+        idx = _u64(idx); ref_idx = _u64(ref_idx) if ref_idx is not None else idx
+        ia, ki = _addr(idx); ra, kr = _addr(ref_idx)
+        n = 0 if idx is None else idx.shape[0]
+        mass = _f32(mass); ma, km = _addr(mass)
+        ref_xyz = _f32(ref_xyz); xa, kx = _addr(ref_xyz)
+        ref_natoms = ref_xyz.shape[0] if ref_xyz.ndim == 2 else ref_xyz.shape[0] // 3
+        rm = np.zeros(F, np.float32); R = np.zeros((F, 9), np.float32); t = np.zeros((F, 3), np.float32)
+        com = np.zeros((F, 3), np.float32); gy = np.zeros(F, np.float32)
+        check(self.lib.molar_hip_fit_rmsd_batch(self.ctx, fa, F, natoms, ia, n, ma, xa, ref_natoms, ra,
+                                                1 if apply else 0, rm.ctypes.data, R.ctypes.data, t.ctypes.data,
+                                                com.ctypes.data, gy.ctypes.data))
+        return dict(rmsd=rm, R=R.reshape(F, 3, 3).transpose(0, 2, 1).copy(), t=t, com=com, gyration=gy)
+
+
+# ---------------------------------------------------------------- pymolar-style front-end
+
+_default_engine = None
+
+
+def default_engine() -> Engine:
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine(0)
+    return _default_engine
+
+
+class State:
+    """Coordinates + box of one frame (state.rs:22-28)."""
+
+    def __init__(self, coords, box: PeriodicBox | None = None, time: float = 0.0):
+        self.coords = _f32(coords)
+        self.pbox = box
+        self.time = time
+
+    def __len__(self):
+        return self.coords.shape[0]
+
+
+class Topology:
+    """Only the per-atom columns the path reads: masses and vdW radii (atom_storage.rs:272)."""
+
+    def __init__(self, masses, vdw=None):
+        self.masses = _f32(masses)
+        self.vdw = _f32(vdw)
+
+
+class Sel:
+    """A bound selection: sorted, non-empty index set over (Topology, State) (sel.rs:10-31)."""
+
+    def __init__(self, top: Topology, state: State, index=None, engine: Engine | None = None):
+        n = len(state)
+        if index is None:
+            index = np.arange(n, dtype=np.uint64)
+        index = np.unique(np.asarray(index, dtype=np.uint64))     # SVec: sorted + dedup
+        if len(index) == 0:
+            raise ValueError("selection is empty")                 # sel.rs:13-19
+        self.top, self.state, self.index = top, state, index
+        self.engine = engine or default_engine()
+
+    def __len__(self):
+        return len(self.index)
+
+    def require_box(self) -> PeriodicBox:
+        if self.state.pbox is None:
+            raise MolarHipError(4, "pbc operation without periodic box")
+        return self.state.pbox
+
+    # molar_python/src/selection.rs:816-829 — com(dims) always goes through the pbc variant
+    def com(self, dims=None):
+        if dims is None or pbc_mask(dims) == 0:
+            return self.engine.center_of_mass(self.state.coords, self.top.masses, self.index)
+        return self.engine.center_of_mass_pbc(self.state.coords, self.top.masses, self.require_box(), dims, self.index)
+
+    def cog(self, dims=None):
+        if dims is None or pbc_mask(dims) == 0:
+            return self.engine.center_of_geometry(self.state.coords, self.index)
+        return self.engine.center_of_geometry_pbc(self.state.coords, self.require_box(), dims, self.index)
+
+    def center_of_mass(self):
+        return self.engine.center_of_mass(self.state.coords, self.top.masses, self.index)
+
+    def center_of_geometry(self):
+        return self.engine.center_of_geometry(self.state.coords, self.index)
+
+    def gyration(self):
+        return self.engine.gyration(self.state.coords, self.top.masses, self.index)
+
+    def gyration_pbc(self):
+        return self.engine.gyration(self.state.coords, self.top.masses, self.index, self.require_box())
+
+    def inertia(self):
+        m, a, _ = self.engine.inertia(self.state.coords, self.top.masses, self.index)
+        return m, a
+
+    def inertia_pbc(self):
+        m, a, _ = self.engine.inertia(self.state.coords, self.top.masses, self.index, self.require_box())
+        return m, a
+
+    def min_max(self):
+        return self.engine.min_max(self.state.coords, self.index)
+
+    def apply_transform(self, tr):
+        R, t = tr
+        self.engine.apply_transform(self.state.coords, R, t, self.index)
+
+    def unwrap_simple(self, dims=PBC_FULL):
+        self.engine.unwrap_simple(self.state.coords, self.require_box(), dims, self.index)
+
+
+def distance_search(cutoff, data1: Sel, data2: Sel | None = None, dims=None):
+    """molar_python/src/lib.rs:259-376 — same dispatch table:
+    float & data2 & any dim -> double_pbc; float & data2 -> double; float & any dim -> single_pbc;
+    float -> single; "vdw" needs data2 (local ids converted to global, :348-354);
+    "vdw" with one selection -> NotImplementedError (:355-358)."""
+    eng = data1.engine
+    pbc = pbc_mask(dims)
+    if isinstance(cutoff, str):
+        if cutoff != "vdw":
+            raise TypeError(f"Unknown cutoff type {cutoff}")
+        if data2 is None:
+            raise NotImplementedError("VdW distance search is not yet supported for single selection")
+        v1 = data1.top.vdw[data1.index.astype(np.int64)]
+        v2 = data2.top.vdw[data2.index.astype(np.int64)]
+        box = data1.require_box() if pbc else None
+        n = eng.search_count(SEARCH_DOUBLE_VDW, None, data1.state.coords, data1.index, data2.state.coords,
+                             data2.index, box=box, pbc=pbc, vdw1=v1, vdw2=v2, ids_local=True)
+        i, j, d = eng.search_fill_usize(n)
+        i = data1.index[i.astype(np.int64)]
+        j = data2.index[j.astype(np.int64)]
+        return np.stack([i, j], 1), d
+    if not isinstance(cutoff, (float, int, np.floating, np.integer)):
+        raise TypeError("cutoff must be a float or 'vdw'")
+    if data2 is not None:
+        box = data1.require_box() if pbc else None
+        n = eng.search_count(SEARCH_DOUBLE, cutoff, data1.state.coords, data1.index, data2.state.coords, data2.index,
+                             box=box, pbc=pbc)
+    else:
+        box = data1.require_box() if pbc else None
+        n = eng.search_count(SEARCH_SINGLE, cutoff, data1.state.coords, data1.index, box=box, pbc=pbc)
+    i, j, d = eng.search_fill_usize(n)
+    return np.stack([i, j], 1), d
+
+
+def fit_transform(sel1: Sel, sel2: Sel):
+    return sel1.engine.fit_transform(sel1.state.coords, sel1.top.masses, sel2.state.coords, sel2.top.masses,
+                                     sel1.index, sel2.index)
+
+
+def fit_transform_at_origin(sel1: Sel, sel2: Sel):
+    return sel1.engine.fit_transform(sel1.state.coords, sel1.top.masses, sel2.state.coords, sel2.top.masses,
+                                     sel1.index, sel2.index, at_origin=True)
+
+
+def rmsd(sel1: Sel, sel2: Sel) -> float:
+    return sel1.engine.rmsd(sel1.state.coords, sel2.state.coords, sel1.index, sel2.index)
+
+
+rmsd_py = rmsd
+
+
+def rmsd_mw(sel1: Sel, sel2: Sel) -> float:
+    return sel1.engine.rmsd_mw(sel1.state.coords, sel1.top.masses, sel2.state.coords, sel1.index, sel2.index)

@@ -1,0 +1,229 @@
+// api.hip — context lifecycle and the host-side PeriodicBox constructors of libmolar_hip.so.
+#include "boxmath.hpp"
+#include "common.hpp"
+
+using namespace mh;
+
+extern "C" {
+
+const char *molar_hip_last_error(void) { return last_error().c_str(); }
+
+const char *molar_hip_version(void) { return "molar_hip 0.1 (gfx950)"; }
+
+int molar_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+molar_hip_ctx *molar_hip_create(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        fail(MOLAR_HIP_ERR_HIP, "molar_hip_create: no HIP device visible (%s)",
+             e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "molar_hip_create: device %d out of range [0,%d)", device, n);
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        fail(MOLAR_HIP_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        fail(MOLAR_HIP_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    auto *c = new molar_hip_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        fail(MOLAR_HIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        delete c;
+        return nullptr;
+    }
+    c->own_stream = true;
+    if (ensure_pinned(c, 1 << 16)) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void molar_hip_destroy(molar_hip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->set) {
+        for (DevBuf *b : {&s.xyz_stage, &s.idx_stage, &s.vdw_stage, &s.key, &s.cell_count, &s.cursor, &s.tmp_key,
+                          &s.tmp_cell, &s.sorted, &s.sorted_vdw})
+            b->release();
+    }
+    for (DevBuf *b : {&c->task_total, &c->task_base, &c->scan_tmp, &c->out_pairs, &c->out_dist, &c->out_ids,
+                      &c->wide_i, &c->wide_j, &c->hist, &c->m_xyz1, &c->m_xyz2, &c->m_idx1, &c->m_idx2,
+                      &c->m_mass1, &c->m_mass2, &c->m_partials, &c->m_results, &c->m_out})
+        b->release();
+    for (auto &s : c->spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int molar_hip_set_stream(molar_hip_ctx *c, void *hip_stream) {
+    if (!c) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "null context");
+    MH_HIP(hipSetDevice(c->device));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_synchronize(molar_hip_ctx *c) {
+    if (!c) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "null context");
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_profile_enable(molar_hip_ctx *c, int on) {
+    if (!c) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "null context");
+    c->profiling = on != 0;
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_profile_read(molar_hip_ctx *c, float ms[MOLAR_HIP_PROFILE_CLASSES],
+                           uint64_t launches[MOLAR_HIP_PROFILE_CLASSES]) {
+    if (!c) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "null context");
+    MH_HIP(hipSetDevice(c->device));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < MOLAR_HIP_PROFILE_CLASSES; ++k) {
+        if (ms) ms[k] = 0.f;
+        if (launches) launches[k] = 0;
+    }
+    for (auto &s : c->spans) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess && s.cls >= 0 && s.cls < MOLAR_HIP_PROFILE_CLASSES) {
+            if (ms) ms[s.cls] += t;
+            if (launches) launches[s.cls] += 1;
+        }
+        c->event_pool.push_back(s.a);
+        c->event_pool.push_back(s.b);
+    }
+    c->spans.clear();
+    return MOLAR_HIP_OK;
+}
+
+// ---------------------------------------------------------------- PeriodicBox constructors (host)
+
+// nalgebra try_inverse, 3x3 closed form (called at periodic_box.rs:167-169)
+static bool invert3(const float *m, float *o) {
+    const float a = m[0], d = m[1], g = m[2];   // column 0 : (0,0) (1,0) (2,0)
+    const float b = m[3], e = m[4], h = m[5];   // column 1
+    const float c = m[6], f = m[7], i = m[8];   // column 2
+    // row-major names: [a b c; d e f; g h i]
+    const float minor_bf = e * i - h * f;
+    const float minor_af = d * i - g * f;
+    const float minor_ae = d * h - g * e;
+    const float det = (a * minor_bf - b * minor_af) + c * minor_ae;
+    if (det == 0.0f) return false;
+    o[0] = minor_bf / det;             // (0,0)
+    o[3] = (c * h - i * b) / det;      // (0,1)
+    o[6] = (b * f - e * c) / det;      // (0,2)
+    o[1] = -minor_af / det;            // (1,0)
+    o[4] = (a * i - g * c) / det;      // (1,1)
+    o[7] = (c * d - f * a) / det;      // (1,2)
+    o[2] = minor_ae / det;             // (2,0)
+    o[5] = (b * g - h * a) / det;      // (2,1)
+    o[8] = (a * e - d * b) / det;      // (2,2)
+    return true;
+}
+
+static float len3(V3 v) { return std::sqrt(norm2(v)); }
+
+int molar_hip_box_from_matrix(const float m9[9], molar_hip_box *out) {
+    if (!m9 || !out) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "box_from_matrix: null argument");
+    V3 col[3];
+    for (int k = 0; k < 3; ++k) {
+        col[k] = v3(m9[3 * k], m9[3 * k + 1], m9[3 * k + 2]);
+        if (len3(col[k]) == 0.0f) return fail(MOLAR_HIP_ERR_ZERO_LENGTH_VECTOR, "zero length box vector");
+    }
+    std::memcpy(out->m, m9, sizeof out->m);
+    if (!invert3(out->m, out->inv)) return fail(MOLAR_HIP_ERR_INVERSE_FAILED, "box matrix inverse failed");
+    out->nshift = 0;
+    // build_tric_corrections (periodic_box.rs:25-66)
+    const bool ortho = m9[3] == 0.f && m9[6] == 0.f && m9[1] == 0.f && m9[7] == 0.f && m9[2] == 0.f && m9[5] == 0.f;
+    if (ortho) return MOLAR_HIP_OK;
+    const V3 a = col[0], b = col[1], c = col[2];
+    const V3 na = v3(-a.x, -a.y, -a.z);
+    float longest = std::fmax(std::fmax(std::fmax(len3((a + b) + c), len3((a + b) - c)), len3((a - b) + c)),
+                              len3((na + b) + c));
+    const float half_diag = 0.5f * longest;
+    const float two = 2.0f * half_diag;
+    const float bound2 = two * two;
+    for (int i = -1; i <= 1; ++i)
+        for (int j = -1; j <= 1; ++j)
+            for (int k = -1; k <= 1; ++k) {
+                if (!i && !j && !k) continue;
+                const float fi = (float)i, fj = (float)j, fk = (float)k;
+                V3 s = (v3(fi * a.x, fi * a.y, fi * a.z) + v3(fj * b.x, fj * b.y, fj * b.z)) +
+                       v3(fk * c.x, fk * c.y, fk * c.z);
+                if (norm2(s) < bound2) {
+                    float *dst = out->shifts + 3 * out->nshift++;
+                    dst[0] = s.x; dst[1] = s.y; dst[2] = s.z;
+                }
+            }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_box_from_vectors_angles(float a, float b, float c, float alpha, float beta, float gamma,
+                                      molar_hip_box *out) {
+    if (a == 0.f || b == 0.f || c == 0.f) return fail(MOLAR_HIP_ERR_ZERO_LENGTH_VECTOR, "zero length box vector");
+    if (alpha < 60.f || beta < 60.f || gamma < 60.f) return fail(MOLAR_HIP_ERR_ANGLE_TOO_SMALL, "box angle is <60 deg");
+    float m[9] = {0};
+    m[0] = a;
+    if (alpha != 90.f || beta != 90.f || gamma != 90.f) {
+        const float d2r = 3.14159265358979323846f / 180.0f;
+        const float cosa = alpha != 90.f ? std::cos(alpha * d2r) : 0.f;
+        const float cosb = beta != 90.f ? std::cos(beta * d2r) : 0.f;
+        float sing = 1.f, cosg = 0.f;
+        if (gamma != 90.f) {
+            sing = std::sin(gamma * d2r);
+            cosg = std::cos(gamma * d2r);
+        }
+        m[3] = b * cosg;                        // (0,1)
+        m[4] = b * sing;                        // (1,1)
+        m[6] = c * cosb;                        // (0,2)
+        m[7] = c * (cosa - cosb * cosg) / sing; // (1,2)
+        m[8] = std::sqrt(c * c - m[6] * m[6] - m[7] * m[7]);
+    } else {
+        m[4] = b;
+        m[8] = c;
+    }
+    return molar_hip_box_from_matrix(m, out);
+}
+
+void molar_hip_box_shortest_vector(const molar_hip_box *box, const float v[3], uint8_t pbc, float out[3]) {
+    V3 r = shortest_vector(*box, v3(v[0], v[1], v[2]), pbc);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+void molar_hip_box_lab_extents(const molar_hip_box *box, float out[3]) {
+    const float *m = box->m;
+    out[0] = (m[0] + m[3]) + m[6];
+    out[1] = (m[1] + m[4]) + m[7];
+    out[2] = (m[2] + m[5]) + m[8];
+}
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+// common.hpp — context, device buffers and error plumbing of libmolar_hip.so.
+// gfx950 only; host side is plain C++17 over the HIP runtime (no torch, no third-party libs).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/molar_hip.h"
+
+namespace mh {
+
+// ---------------------------------------------------------------- errors (tpr_last_error idiom, wrapper.cpp:32,156)
+
+inline std::string &last_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+inline int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+#define MH_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return ::mh::fail(MOLAR_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                              __FILE__, __LINE__);                                                     \
+    } while (0)
+
+#define MH_TRY(expr)          \
+    do {                      \
+        int _rc = (expr);     \
+        if (_rc) return _rc;  \
+    } while (0)
+
+// ---------------------------------------------------------------- grow-only device buffer
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) {
+            MH_HIP(hipFree(p));
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + bytes / 8 + 256;   // headroom: frames of one trajectory vary a little
+        MH_HIP(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// true if `p` is device-accessible HIP memory (device or managed); false for ordinary host memory
+inline bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // unregistered host memory reports an error on some ROCm versions
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeArray;
+}
+
+// ---------------------------------------------------------------- per-set grid state of the cached search
+
+struct GridSet {
+    uint32_t n = 0;            // selected atoms handed in
+    DevBuf xyz_stage;          // host xyz staged here
+    DevBuf idx_stage;          // host idx staged here (uint64)
+    DevBuf vdw_stage;
+    const float *d_xyz = nullptr;
+    const uint64_t *d_idx = nullptr;
+    const float *d_vdw = nullptr;
+    DevBuf key;                // u32 per atom: cell<<1 | wrapped, 0xFFFFFFFF = dropped
+    DevBuf cell_count;         // u32 [ncells+1] -> scanned in place into cell_start
+    DevBuf cursor;             // u32 [ncells]
+    DevBuf tmp_key;            // u32 per kept atom (unsorted inside the cell)
+    DevBuf tmp_cell;           // u32 per kept atom
+    DevBuf sorted;             // float4 {x,y,z,id-bits} in reference cell order
+    DevBuf sorted_vdw;         // float per sorted atom (vdw searches)
+};
+
+}  // namespace mh
+
+struct molar_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+
+    // pinned host scratch for small read-backs
+    void *h_pinned = nullptr;
+    size_t h_pinned_cap = 0;
+
+    // ---- cached search (count -> fill)
+    bool have_search = false;
+    int kind = 0;
+    bool use_box = false;
+    uint8_t pbc = 0;
+    float cutoff = 0.f;
+    molar_hip_box box{};
+    float lower[3]{}, upper[3]{};
+    uint32_t dims[3]{1, 1, 1};
+    uint64_t ntasks = 0;
+    uint64_t total = 0;
+    mh::GridSet set[2];
+    mh::DevBuf task_total;     // u32 per task
+    mh::DevBuf task_base;      // u64 per task (+1 grand total)
+    mh::DevBuf scan_tmp;       // block sums for the scans
+    mh::DevBuf out_pairs;      // ctx-owned result buffers (device-resident results / host staging)
+    mh::DevBuf out_dist;
+    mh::DevBuf out_ids;
+    mh::DevBuf wide_i, wide_j; // usize widening
+    mh::DevBuf hist;           // u64 bins
+
+    // ---- profiling (HIP events on `stream`)
+    bool profiling = false;
+    struct Span { int cls; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+
+    // ---- measure scratch
+    mh::DevBuf m_xyz1, m_xyz2, m_idx1, m_idx2, m_mass1, m_mass2, m_partials, m_results, m_out;
+};
+
+namespace mh {
+
+// RAII span: records an event pair around a group of launches when profiling is on
+struct Prof {
+    molar_hip_ctx *c;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t get(molar_hip_ctx *c) {
+        if (!c->event_pool.empty()) {
+            hipEvent_t e = c->event_pool.back();
+            c->event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    Prof(molar_hip_ctx *ctx, int k) : c(ctx), cls(k) {
+        if (!c->profiling) return;
+        a = get(c);
+        b = get(c);
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~Prof() {
+        if (!c->profiling || !a) return;
+        (void)hipEventRecord(b, c->stream);
+        c->spans.push_back({cls, a, b});
+    }
+};
+
+inline int ensure_pinned(molar_hip_ctx *c, size_t bytes) {
+    if (bytes <= c->h_pinned_cap) return 0;
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    c->h_pinned = nullptr;
+    c->h_pinned_cap = 0;
+    MH_HIP(hipHostMalloc(&c->h_pinned, bytes + 4096, hipHostMallocDefault));
+    c->h_pinned_cap = bytes + 4096;
+    return 0;
+}
+
+// Make `src` (host or device, `bytes` long) readable by kernels: device pointers are used in
+// place, host buffers are copied into `stage` on the context's stream.
+template <class T>
+inline int to_device(molar_hip_ctx *c, const T *src, size_t count, DevBuf &stage, const T **out) {
+    if (!src || count == 0) {
+        *out = nullptr;
+        return 0;
+    }
+    if (is_device_ptr(src)) {
+        *out = src;
+        return 0;
+    }
+    MH_TRY(stage.reserve(count * sizeof(T)));
+    MH_HIP(hipMemcpyAsync(stage.p, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *out = stage.as<T>();
+    return 0;
+}
+
+}  // namespace mh

@@ -1,0 +1,724 @@
+// measure.hip — MolAR's Measure / Modify numeric methods (molar/src/measure.rs, modify.rs) for gfx950.
+//
+// Every reduction gathers through the selection index (providers.rs:103-106), forms each
+// per-atom term in f32 with the reference's operation order (p - c, shortest_vector, R*p + t)
+// and accumulates the terms in f64: per-thread -> wave shuffle -> one partial per workgroup,
+// summed in a fixed order by the finalize step, so results are deterministic and agree with the
+// reference's serial f32 sums to better than the f32 roundoff those sums carry themselves.
+// These passes move 12-44 bytes per atom and a handful of flops: HBM-bound, no MFMA.
+#include "boxmath.hpp"
+#include "common.hpp"
+#include "linalg3.hpp"
+
+using namespace mh;
+
+namespace {
+
+constexpr int RB = 256;   // reduction block
+
+struct Sel {
+    const float *xyz;
+    const uint64_t *idx;
+    const float *mass;   // full-length column, gathered through idx
+    uint32_t n;
+    size_t frame_stride; // floats between consecutive frames (batched calls), 0 otherwise
+};
+
+__device__ __forceinline__ uint64_t atom_of(const Sel &s, uint32_t k) { return s.idx ? s.idx[k] : (uint64_t)k; }
+__device__ __forceinline__ V3 pos_of(const Sel &s, uint32_t frame, uint64_t a) {
+    const float *q = s.xyz + (size_t)frame * s.frame_stride + 3 * a;
+    return v3(q[0], q[1], q[2]);
+}
+
+// block-wide sum of NV doubles; lanes 0..NV-1 of wave 0 write partials[(frame*gridDim.x+block)*NV + v]
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(double *acc, double *partials) {
+    __shared__ double sh[RB / 64][NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double x = acc[v];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+        if (lane == 0) sh[wave][v] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+        for (int w = 0; w < RB / 64; ++w) s += sh[w][threadIdx.x];
+        partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NV + threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------- pass kernels
+
+// [0]=sum m, [1..3]=sum p*m, [4..6]=sum p   (center_of_mass :60-75, center_of_geometry :39-47)
+__global__ void __launch_bounds__(RB) k_sums(Sel s, double *partials) {
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const V3 p = pos_of(s, blockIdx.y, a);
+        const float m = s.mass ? s.mass[a] : 1.0f;
+        acc[0] += (double)m;
+        acc[1] += (double)(p.x * m);
+        acc[2] += (double)(p.y * m);
+        acc[3] += (double)(p.z * m);
+        acc[4] += (double)p.x;
+        acc[5] += (double)p.y;
+        acc[6] += (double)p.z;
+    }
+    block_reduce_store<7>(acc, partials);
+}
+
+// images relative to the first selected atom (center_of_*_pbc_dims :156-168, :197-220):
+// [0]=sum m (k>=1), [1..3]=sum img*m (k>=1), [4..6]=sum img (k>=1)
+__global__ void __launch_bounds__(RB) k_sums_pbc(Sel s, molar_hip_box box, uint32_t pbc, double *partials) {
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    const V3 p0 = pos_of(s, blockIdx.y, atom_of(s, 0));
+    for (uint32_t k = 1 + blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const V3 im = closest_image(box, pos_of(s, blockIdx.y, a), p0, pbc);
+        const float m = s.mass ? s.mass[a] : 1.0f;
+        acc[0] += (double)m;
+        acc[1] += (double)(im.x * m);
+        acc[2] += (double)(im.y * m);
+        acc[3] += (double)(im.z * m);
+        acc[4] += (double)im.x;
+        acc[5] += (double)im.y;
+        acc[6] += (double)im.z;
+    }
+    block_reduce_store<7>(acc, partials);
+}
+
+// central moments about c (do_gyration :561-570, do_inertia :573-586); d = p - c, or
+// shortest_vector(p - c) for the *_pbc variants (:229, :241).
+// [0]=sum m, [1]=sum |d|^2 m, [2..4]=T00,T11,T22, [5..7]=T01,T02,T12 (already negated)
+__global__ void __launch_bounds__(RB) k_central(Sel s, const float *center, int use_box, molar_hip_box box,
+                                                double *partials) {
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const V3 c = v3(center[3 * blockIdx.y], center[3 * blockIdx.y + 1], center[3 * blockIdx.y + 2]);
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        V3 d = pos_of(s, blockIdx.y, a) - c;
+        if (use_box) d = shortest_vector(box, d, MOLAR_HIP_PBC_FULL);
+        const float m = s.mass[a];
+        acc[0] += (double)m;
+        acc[1] += (double)(norm2(d) * m);
+        acc[2] += (double)(m * (d.y * d.y + d.z * d.z));
+        acc[3] += (double)(m * (d.x * d.x + d.z * d.z));
+        acc[4] += (double)(m * (d.x * d.x + d.y * d.y));
+        acc[5] -= (double)(m * d.x * d.y);
+        acc[6] -= (double)(m * d.x * d.z);
+        acc[7] -= (double)(m * d.y * d.z);
+    }
+    block_reduce_store<8>(acc, partials);
+}
+
+// two selections: [0]=sum |p2-p1|^2 (rmsd :499-501), [1]=sum |p2-p1|^2 m, [2]=sum m (rmsd_mw :548-551)
+__global__ void __launch_bounds__(RB) k_rmsd(Sel s1, Sel s2, double *partials) {
+    double acc[3] = {0, 0, 0};
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s1.n; k += gridDim.x * RB) {
+        const uint64_t a1 = atom_of(s1, k), a2 = atom_of(s2, k);
+        const V3 v = pos_of(s2, 0, a2) - pos_of(s1, blockIdx.y, a1);
+        const float d2 = norm2(v);
+        const float m = s1.mass ? s1.mass[a1] : 1.0f;
+        acc[0] += (double)d2;
+        acc[1] += (double)(d2 * m);
+        acc[2] += (double)m;
+    }
+    block_reduce_store<3>(acc, partials);
+}
+
+// rot_transform accumulation (:619-623): cov(r,c) += (q2[r]*q1[c])*m, q = p - centre, m from sel1.
+// centres: c1[frame] and c2 (shared reference).  partial layout column-major cov[c*3+r].
+__global__ void __launch_bounds__(RB) k_cov(Sel s1, Sel s2, const float *c1v, const float *c2v, double *partials) {
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const V3 c1 = v3(c1v[3 * blockIdx.y], c1v[3 * blockIdx.y + 1], c1v[3 * blockIdx.y + 2]);
+    const V3 c2 = v3(c2v[0], c2v[1], c2v[2]);
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s1.n; k += gridDim.x * RB) {
+        const uint64_t a1 = atom_of(s1, k), a2 = atom_of(s2, k);
+        const V3 q1 = pos_of(s1, blockIdx.y, a1) - c1;
+        const V3 q2 = pos_of(s2, 0, a2) - c2;
+        const float m = s1.mass[a1];
+        acc[0] += (double)((q2.x * q1.x) * m);
+        acc[1] += (double)((q2.y * q1.x) * m);
+        acc[2] += (double)((q2.z * q1.x) * m);
+        acc[3] += (double)((q2.x * q1.y) * m);
+        acc[4] += (double)((q2.y * q1.y) * m);
+        acc[5] += (double)((q2.z * q1.y) * m);
+        acc[6] += (double)((q2.x * q1.z) * m);
+        acc[7] += (double)((q2.y * q1.z) * m);
+        acc[8] += (double)((q2.z * q1.z) * m);
+    }
+    block_reduce_store<9>(acc, partials);
+}
+
+// apply_transform (modify.rs:32-36): p <- R*p + t in f32 (written back when `write`), fused with the
+// sums the per-frame loop needs afterwards: [0]=sum |ref-p'|^2, [1]=sum m, [2..4]=sum p'*m,
+// [5]=sum m |p'|^2 (gyration about the new COM by the parallel-axis identity, in f64).
+__global__ void __launch_bounds__(RB) k_apply(Sel s1, Sel s2, float *xyz_rw, const float *Rt /*[frame][12]*/,
+                                              int write, double *partials) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const float *R = Rt + 12 * blockIdx.y;
+    const V3 t = v3(R[9], R[10], R[11]);
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s1.n; k += gridDim.x * RB) {
+        const uint64_t a1 = atom_of(s1, k);
+        const V3 rp = mat_vec(R, pos_of(s1, blockIdx.y, a1));
+        const V3 pn = rp + t;
+        if (write) {
+            float *q = xyz_rw + (size_t)blockIdx.y * s1.frame_stride + 3 * a1;
+            q[0] = pn.x; q[1] = pn.y; q[2] = pn.z;
+        }
+        if (s2.xyz) {
+            const V3 v = pos_of(s2, 0, atom_of(s2, k)) - pn;
+            acc[0] += (double)norm2(v);
+        }
+        const float m = s1.mass ? s1.mass[a1] : 1.0f;
+        acc[1] += (double)m;
+        acc[2] += (double)(pn.x * m);
+        acc[3] += (double)(pn.y * m);
+        acc[4] += (double)(pn.z * m);
+        acc[5] += (double)m * ((double)pn.x * pn.x + (double)pn.y * pn.y + (double)pn.z * pn.z);
+    }
+    block_reduce_store<6>(acc, partials);
+}
+
+// unwrap_simple_dim (modify.rs:40-54): p_k <- closest_image(p_k, p_0) for k >= 1
+__global__ void __launch_bounds__(RB) k_unwrap(Sel s, float *xyz_rw, molar_hip_box box, uint32_t pbc) {
+    const V3 p0 = pos_of(s, 0, atom_of(s, 0));
+    for (uint32_t k = 1 + blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const V3 im = closest_image(box, pos_of(s, 0, a), p0, pbc);
+        float *q = xyz_rw + 3 * a;
+        q[0] = im.x; q[1] = im.y; q[2] = im.z;
+    }
+}
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// min_max (:22-36), exact: mm[0..2]=min, mm[3..5]=max as order-preserving uints
+__global__ void __launch_bounds__(RB) k_minmax(Sel s, uint32_t *mm) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const V3 p = pos_of(s, 0, atom_of(s, k));
+        const float q[3] = {p.x, p.y, p.z};
+        for (int d = 0; d < 3; ++d) {
+            if (q[d] < lo[d]) lo[d] = q[d];
+            if (q[d] > hi[d]) hi[d] = q[d];
+        }
+    }
+    for (int d = 0; d < 3; ++d)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int d = 0; d < 3; ++d) {
+            if (lo[d] != INFINITY) atomicMin(&mm[d], f2ord(lo[d]));
+            if (hi[d] != -INFINITY) atomicMax(&mm[3 + d], f2ord(hi[d]));
+        }
+}
+
+// ---------------------------------------------------------------- finalize kernels (one thread per frame)
+
+__device__ __forceinline__ void sum_partials(const double *partials, uint32_t frame, uint32_t nblk, int nv,
+                                             double *out) {
+    for (int v = 0; v < nv; ++v) out[v] = 0.0;
+    const double *p = partials + (size_t)frame * nblk * nv;
+    for (uint32_t b = 0; b < nblk; ++b)
+        for (int v = 0; v < nv; ++v) out[v] += p[(size_t)b * nv + v];
+}
+
+// COM per frame from k_sums partials -> centers[frame][3] (f32, as the reference's Pos) + status
+__global__ void k_fin_com(const double *partials, uint32_t nblk, uint32_t nframes, float *centers, int *status) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    double s[7];
+    sum_partials(partials, f, nblk, 7, s);
+    if (s[0] == 0.0) {
+        atomicMax(status, MOLAR_HIP_ERR_ZERO_MASS);
+        centers[3 * f] = centers[3 * f + 1] = centers[3 * f + 2] = 0.f;
+        return;
+    }
+    centers[3 * f] = (float)(s[1] / s[0]);
+    centers[3 * f + 1] = (float)(s[2] / s[0]);
+    centers[3 * f + 2] = (float)(s[3] / s[0]);
+}
+
+// Kabsch rotation + translation per frame: Rt[frame] = {R (9, column-major), t (3)}
+// fit_transform (:507-522): t = cm2 + R*(-cm1)
+__global__ void k_fin_fit(const double *partials, uint32_t nblk, uint32_t nframes, const float *c1, const float *c2,
+                          float *Rt, int *status) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    double cov[9], R[9];
+    sum_partials(partials, f, nblk, 9, cov);
+    if (!rotation_from_cov(cov, R)) {
+        atomicMax(status, MOLAR_HIP_ERR_SVD);
+        for (int i = 0; i < 12; ++i) Rt[12 * f + i] = 0.f;
+        return;
+    }
+    float Rf[9];
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)R[i];
+    const V3 neg = v3(-c1[3 * f], -c1[3 * f + 1], -c1[3 * f + 2]);
+    const V3 rv = mat_vec(Rf, neg);
+    for (int i = 0; i < 9; ++i) Rt[12 * f + i] = Rf[i];
+    Rt[12 * f + 9] = c2[0] + rv.x;
+    Rt[12 * f + 10] = c2[1] + rv.y;
+    Rt[12 * f + 11] = c2[2] + rv.z;
+}
+
+// per-frame scalars after k_apply: out[frame] = {rmsd, com.x, com.y, com.z, gyration}
+__global__ void k_fin_apply(const double *partials, uint32_t nblk, uint32_t nframes, uint32_t n, float *out) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    double s[6];
+    sum_partials(partials, f, nblk, 6, s);
+    const double cx = s[2] / s[1], cy = s[3] / s[1], cz = s[4] / s[1];
+    double rg2 = s[5] / s[1] - (cx * cx + cy * cy + cz * cz);
+    if (rg2 < 0.0) rg2 = 0.0;
+    out[5 * f] = (float)sqrt(s[0] / (double)n);
+    out[5 * f + 1] = (float)cx;
+    out[5 * f + 2] = (float)cy;
+    out[5 * f + 3] = (float)cz;
+    out[5 * f + 4] = (float)sqrt(rg2);
+}
+
+// generic: total the partials of frame 0 into results[0..nv)
+__global__ void k_fin_sum(const double *partials, uint32_t nblk, int nv, double *results) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sum_partials(partials, 0, nblk, nv, results);
+}
+
+// ---------------------------------------------------------------- host helpers
+
+uint32_t blocks_for(const molar_hip_ctx *c, uint32_t n, uint32_t nframes) {
+    uint32_t nb = (n + RB * 8 - 1) / (RB * 8);   // >= 8 atoms per thread
+    if (nb < 1) nb = 1;
+    uint32_t cap = nframes >= 64 ? 16u : (uint32_t)c->num_cus * 4u;
+    if (nb > cap) nb = cap;
+    return nb;
+}
+
+int stage_sel(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, size_t n, const float *mass,
+              DevBuf &bx, DevBuf &bi, DevBuf &bm, Sel *out, size_t nframes = 1) {
+    if (!xyz) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "measure: xyz pointer is null");
+    const size_t nsel = idx ? n : natoms;
+    if (nsel >= 0xFFFFFFFFull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "measure: selection too large");
+    out->n = (uint32_t)nsel;
+    out->frame_stride = nframes > 1 ? natoms * 3 : 0;
+    MH_TRY(to_device(c, xyz, natoms * 3 * nframes, bx, &out->xyz));
+    MH_TRY(to_device(c, idx, idx ? n : 0, bi, &out->idx));
+    out->mass = nullptr;
+    if (mass) MH_TRY(to_device(c, mass, natoms, bm, &out->mass));
+    return 0;
+}
+
+int pull(molar_hip_ctx *c, void *dst, const void *src_dev, size_t bytes) {
+    MH_TRY(ensure_pinned(c, bytes));
+    MH_HIP(hipMemcpyAsync(c->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(dst, c->h_pinned, bytes);
+    return 0;
+}
+
+// run a reduction for one frame and fetch its NV totals
+template <class Launch>
+int reduce1(molar_hip_ctx *c, uint32_t n, int nv, double *host_out, Launch launch) {
+    const uint32_t nb = blocks_for(c, n, 1);
+    MH_TRY(c->m_partials.reserve((size_t)nb * nv * 8));
+    MH_TRY(c->m_results.reserve(64 * 8));
+    launch(nb, c->m_partials.as<double>());
+    hipLaunchKernelGGL(k_fin_sum, dim3(1), dim3(64), 0, c->stream, c->m_partials.as<double>(), nb, nv,
+                       c->m_results.as<double>());
+    MH_HIP(hipGetLastError());
+    return pull(c, host_out, c->m_results.p, (size_t)nv * 8);
+}
+
+int box_or_err(const float *box9, molar_hip_box *b) {
+    if (!box9) return fail(MOLAR_HIP_ERR_NO_PBC, "pbc operation without periodic box");
+    return molar_hip_box_from_matrix(box9, b);
+}
+
+int com_host(molar_hip_ctx *c, const Sel &s, float out[3]) {
+    double r[7];
+    MH_TRY(reduce1(c, s.n, 7, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k_sums, dim3(nb, 1), dim3(RB), 0, c->stream, s, part);
+    }));
+    if (r[0] == 0.0) return fail(MOLAR_HIP_ERR_ZERO_MASS, "zero mass");
+    for (int d = 0; d < 3; ++d) out[d] = (float)(r[1 + d] / r[0]);
+    return 0;
+}
+
+// center_of_mass_pbc_dims (:197-220): cm starts at the UNWEIGHTED first position, mass at m0
+int com_pbc_host(molar_hip_ctx *c, const Sel &s, const molar_hip_box &box, uint8_t pbc, bool weighted, float out[3]) {
+    double r[7];
+    MH_TRY(reduce1(c, s.n, 7, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k_sums_pbc, dim3(nb, 1), dim3(RB), 0, c->stream, s, box, (uint32_t)pbc, part);
+    }));
+    // first atom: position and mass
+    float p0[3], m0 = 1.0f;
+    {
+        MH_TRY(c->m_out.reserve(64));
+        uint64_t a0 = 0;
+        if (s.idx) MH_TRY(pull(c, &a0, s.idx, 8));
+        MH_TRY(pull(c, p0, s.xyz + 3 * a0, 12));
+        if (s.mass) MH_TRY(pull(c, &m0, s.mass + a0, 4));
+    }
+    if (weighted) {
+        const double mass = (double)m0 + r[0];
+        if (mass == 0.0) return fail(MOLAR_HIP_ERR_ZERO_MASS, "zero mass");
+        for (int d = 0; d < 3; ++d) out[d] = (float)(((double)p0[d] + r[1 + d]) / mass);
+    } else {
+        for (int d = 0; d < 3; ++d) out[d] = (float)(((double)p0[d] + r[4 + d]) / (double)s.n);
+    }
+    return 0;
+}
+
+int central_host(molar_hip_ctx *c, const Sel &s, const float center[3], const molar_hip_box *box, double r[8]) {
+    MH_TRY(c->m_out.reserve(64));
+    MH_HIP(hipMemcpyAsync(c->m_out.p, center, 12, hipMemcpyHostToDevice, c->stream));
+    molar_hip_box b{};
+    if (box) b = *box;
+    return reduce1(c, s.n, 8, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k_central, dim3(nb, 1), dim3(RB), 0, c->stream, s, c->m_out.as<float>(), box ? 1 : 0, b, part);
+    });
+}
+
+#define MH_CTX(c)                                                              \
+    do {                                                                       \
+        if (!(c)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "null context"); \
+        MH_HIP(hipSetDevice((c)->device));                                     \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int molar_hip_min_max(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, size_t n, float lower[3],
+                      float upper[3]) {
+    MH_CTX(c);
+    Sel s;
+    MH_TRY(stage_sel(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    MH_TRY(c->m_out.reserve(64));
+    uint32_t seed[6];
+    const float fmaxv = 3.40282347e+38f;   // Pos::max_value() / min_value() (:23-24)
+    for (int d = 0; d < 3; ++d) {
+        uint32_t u;
+        std::memcpy(&u, &fmaxv, 4);
+        seed[d] = u | 0x80000000u;          // ord(+MAX)
+        seed[3 + d] = ~(u | 0x80000000u);   // ord(-MAX)
+    }
+    MH_HIP(hipMemcpyAsync(c->m_out.p, seed, sizeof seed, hipMemcpyHostToDevice, c->stream));
+    if (s.n) {
+        uint32_t nb = blocks_for(c, s.n, 1);
+        hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(RB), 0, c->stream, s, c->m_out.as<uint32_t>());
+        MH_HIP(hipGetLastError());
+    }
+    uint32_t mm[6];
+    MH_TRY(pull(c, mm, c->m_out.p, sizeof mm));
+    for (int d = 0; d < 6; ++d) {
+        const uint32_t o = mm[d];
+        const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+        float f;
+        std::memcpy(&f, &u, 4);
+        (d < 3 ? lower[d] : upper[d - 3]) = f;
+    }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_center_of_geometry(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                 float out[3]) {
+    MH_CTX(c);
+    Sel s;
+    MH_TRY(stage_sel(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    double r[7];
+    MH_TRY(reduce1(c, s.n, 7, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k_sums, dim3(nb, 1), dim3(RB), 0, c->stream, s, part);
+    }));
+    for (int d = 0; d < 3; ++d) out[d] = (float)(r[4 + d] / (double)s.n);
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_center_of_mass(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                             const float *mass, float out[3]) {
+    MH_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "center_of_mass: mass pointer is null");
+    Sel s;
+    MH_TRY(stage_sel(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    return com_host(c, s, out);
+}
+
+int molar_hip_center_of_geometry_pbc(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                     const float *box9, uint8_t pbc, float out[3]) {
+    MH_CTX(c);
+    molar_hip_box b;
+    MH_TRY(box_or_err(box9, &b));
+    Sel s;
+    MH_TRY(stage_sel(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    return com_pbc_host(c, s, b, pbc & 7u, false, out);
+}
+
+int molar_hip_center_of_mass_pbc(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                 const float *mass, const float *box9, uint8_t pbc, float out[3]) {
+    MH_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "center_of_mass_pbc: mass pointer is null");
+    molar_hip_box b;
+    MH_TRY(box_or_err(box9, &b));
+    Sel s;
+    MH_TRY(stage_sel(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    return com_pbc_host(c, s, b, pbc & 7u, true, out);
+}
+
+int molar_hip_gyration(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                       const float *mass, const float *box9, float *out) {
+    MH_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "gyration: mass pointer is null");
+    Sel s;
+    MH_TRY(stage_sel(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    float cm[3];
+    molar_hip_box b;
+    if (box9) {
+        MH_TRY(molar_hip_box_from_matrix(box9, &b));
+        MH_TRY(com_pbc_host(c, s, b, MOLAR_HIP_PBC_FULL, true, cm));   // center_of_mass_pbc (:227)
+    } else {
+        MH_TRY(com_host(c, s, cm));                                   // (:82)
+    }
+    double r[8];
+    MH_TRY(central_host(c, s, cm, box9 ? &b : nullptr, r));
+    *out = (float)std::sqrt(r[1] / r[0]);
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_inertia(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                      const float *mass, const float *box9, float moments[3], float axes9[9], float tensor9[9]) {
+    MH_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "inertia: mass pointer is null");
+    Sel s;
+    MH_TRY(stage_sel(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    float cm[3];
+    molar_hip_box b;
+    if (box9) {
+        MH_TRY(molar_hip_box_from_matrix(box9, &b));
+        MH_TRY(com_pbc_host(c, s, b, MOLAR_HIP_PBC_FULL, true, cm));
+    } else {
+        MH_TRY(com_host(c, s, cm));
+    }
+    double r[8];
+    MH_TRY(central_host(c, s, cm, box9 ? &b : nullptr, r));
+    // symmetric tensor (:580-589); stored as f32 like the reference's Matrix3f before the eigen solve
+    const float T00 = (float)r[2], T11 = (float)r[3], T22 = (float)r[4];
+    const float T01 = (float)r[5], T02 = (float)r[6], T12 = (float)r[7];
+    if (tensor9) {
+        const float t[9] = {T00, T01, T02, T01, T11, T12, T02, T12, T22};
+        std::memcpy(tensor9, t, sizeof t);
+    }
+    double A[9] = {T00, T01, T02, T01, T11, T12, T02, T12, T22}, w[3], V[9];
+    jacobi_sym<3>(A, w, V);
+    int ord[3] = {0, 1, 2};   // ascending moments (:594-601)
+    for (int a = 0; a < 2; ++a)
+        for (int q = a + 1; q < 3; ++q)
+            if (w[ord[q]] < w[ord[a]]) std::swap(ord[a], ord[q]);
+    for (int k = 0; k < 3; ++k) moments[k] = (float)w[ord[k]];
+    // col0, col1 normalised, col2 = col0 x col1 (:603-607)
+    float e[2][3];
+    for (int k = 0; k < 2; ++k) {
+        float v[3] = {(float)V[0 * 3 + ord[k]], (float)V[1 * 3 + ord[k]], (float)V[2 * 3 + ord[k]]};
+        const float nn = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+        for (int d = 0; d < 3; ++d) e[k][d] = v[d] / nn;
+    }
+    const float c2[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2],
+                         e[0][0] * e[1][1] - e[0][1] * e[1][0]};
+    for (int d = 0; d < 3; ++d) {
+        axes9[0 * 3 + d] = e[0][d];
+        axes9[1 * 3 + d] = e[1][d];
+        axes9[2 * 3 + d] = c2[d];
+    }
+    return MOLAR_HIP_OK;
+}
+
+static int rmsd_common(molar_hip_ctx *c, const float *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                       const float *mass1, const float *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2,
+                       bool weighted, float *out) {
+    const size_t s1n = idx1 ? n1 : natoms1, s2n = idx2 ? n2 : natoms2;
+    if (s1n != s2n) return fail(MOLAR_HIP_ERR_SIZES, "incompatible sizes: %zu and %zu", s1n, s2n);
+    Sel s1, s2;
+    MH_TRY(stage_sel(c, xyz1, natoms1, idx1, n1, mass1, c->m_xyz1, c->m_idx1, c->m_mass1, &s1));
+    MH_TRY(stage_sel(c, xyz2, natoms2, idx2, n2, nullptr, c->m_xyz2, c->m_idx2, c->m_mass2, &s2));
+    double r[3];
+    MH_TRY(reduce1(c, s1.n, 3, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k_rmsd, dim3(nb, 1), dim3(RB), 0, c->stream, s1, s2, part);
+    }));
+    if (weighted) {
+        if (r[2] == 0.0) return fail(MOLAR_HIP_ERR_ZERO_MASS, "zero mass");
+        *out = (float)std::sqrt(r[1] / r[2]);
+    } else {
+        *out = (float)std::sqrt(r[0] / (double)s1.n);
+    }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_rmsd(molar_hip_ctx *c, const float *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                   const float *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2, float *out) {
+    MH_CTX(c);
+    return rmsd_common(c, xyz1, natoms1, idx1, n1, nullptr, xyz2, natoms2, idx2, n2, false, out);
+}
+
+int molar_hip_rmsd_mw(molar_hip_ctx *c, const float *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                      const float *mass1, const float *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2,
+                      float *out) {
+    MH_CTX(c);
+    if (!mass1) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "rmsd_mw: mass pointer is null");
+    return rmsd_common(c, xyz1, natoms1, idx1, n1, mass1, xyz2, natoms2, idx2, n2, true, out);
+}
+
+int molar_hip_fit_transform(molar_hip_ctx *c, const float *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                            const float *mass1, const float *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2,
+                            const float *mass2, int at_origin, float R9[9], float t3[3]) {
+    MH_CTX(c);
+    if (!mass1 || (!at_origin && !mass2)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_transform: mass pointer is null");
+    Sel s1, s2;
+    MH_TRY(stage_sel(c, xyz1, natoms1, idx1, n1, mass1, c->m_xyz1, c->m_idx1, c->m_mass1, &s1));
+    MH_TRY(stage_sel(c, xyz2, natoms2, idx2, n2, at_origin ? nullptr : mass2, c->m_xyz2, c->m_idx2, c->m_mass2, &s2));
+    float cm[6] = {0, 0, 0, 0, 0, 0};
+    if (!at_origin) {
+        MH_TRY(com_host(c, s1, cm));        // cm1 (:511)
+        MH_TRY(com_host(c, s2, cm + 3));    // cm2 (:512)
+    }
+    // izip! stops at the shorter selection (:621)
+    Sel a = s1, b = s2;
+    a.n = b.n = s1.n < s2.n ? s1.n : s2.n;
+    MH_TRY(c->m_out.reserve(64));
+    MH_HIP(hipMemcpyAsync(c->m_out.p, cm, sizeof cm, hipMemcpyHostToDevice, c->stream));
+    double cov[9];
+    MH_TRY(reduce1(c, a.n, 9, cov, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k_cov, dim3(nb, 1), dim3(RB), 0, c->stream, a, b, c->m_out.as<float>(),
+                           c->m_out.as<float>() + 3, part);
+    }));
+    double R[9];
+    if (!rotation_from_cov(cov, R)) return fail(MOLAR_HIP_ERR_SVD, "SVD failed");
+    for (int i = 0; i < 9; ++i) R9[i] = (float)R[i];
+    if (at_origin) {
+        t3[0] = t3[1] = t3[2] = 0.f;
+    } else {
+        const V3 rv = mat_vec(R9, v3(-cm[0], -cm[1], -cm[2]));   // Translation(cm2)*rot*Translation(-cm1) (:521)
+        t3[0] = cm[3] + rv.x;
+        t3[1] = cm[4] + rv.y;
+        t3[2] = cm[5] + rv.z;
+    }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_apply_transform(molar_hip_ctx *c, float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                              const float R9[9], const float t3[3]) {
+    MH_CTX(c);
+    Sel s;
+    MH_TRY(stage_sel(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    float Rt[12];
+    std::memcpy(Rt, R9, 36);
+    std::memcpy(Rt + 9, t3, 12);
+    MH_TRY(c->m_out.reserve(64));
+    MH_HIP(hipMemcpyAsync(c->m_out.p, Rt, sizeof Rt, hipMemcpyHostToDevice, c->stream));
+    const uint32_t nb = blocks_for(c, s.n, 1);
+    MH_TRY(c->m_partials.reserve((size_t)nb * 6 * 8));
+    Sel none{};
+    hipLaunchKernelGGL(k_apply, dim3(nb, 1), dim3(RB), 0, c->stream, s, none, const_cast<float *>(s.xyz),
+                       c->m_out.as<float>(), 1, c->m_partials.as<double>());
+    MH_HIP(hipGetLastError());
+    if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, s.xyz, natoms * 12, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_unwrap_simple(molar_hip_ctx *c, float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                            const float *box9, uint8_t pbc) {
+    MH_CTX(c);
+    molar_hip_box b;
+    MH_TRY(box_or_err(box9, &b));
+    Sel s;
+    MH_TRY(stage_sel(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    if (s.n > 1) {
+        const uint32_t nb = blocks_for(c, s.n, 1);
+        hipLaunchKernelGGL(k_unwrap, dim3(nb), dim3(RB), 0, c->stream, s, const_cast<float *>(s.xyz), b,
+                           (uint32_t)(pbc & 7u));
+        MH_HIP(hipGetLastError());
+    }
+    if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, s.xyz, natoms * 12, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_fit_rmsd_batch(molar_hip_ctx *c, float *frames, size_t nframes, size_t natoms, const uint64_t *idx,
+                             size_t n, const float *mass, const float *ref_xyz, size_t ref_natoms,
+                             const uint64_t *ref_idx, int apply, float *rmsd_out, float *R_out, float *t_out,
+                             float *com_out, float *gyr_out) {
+    MH_CTX(c);
+    if (!frames || !mass || !ref_xyz) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_rmsd_batch: null argument");
+    if (nframes == 0) return MOLAR_HIP_OK;
+    if (nframes > 65535) return fail(MOLAR_HIP_ERR_TOO_LARGE, "fit_rmsd_batch: at most 65535 frames per call");
+    const size_t nsel = idx ? n : natoms, nref = ref_idx ? n : ref_natoms;
+    if (nsel != nref) return fail(MOLAR_HIP_ERR_SIZES, "incompatible sizes: %zu and %zu", nsel, nref);
+    Sel cur, ref;
+    MH_TRY(stage_sel(c, frames, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &cur, nframes));
+    cur.frame_stride = natoms * 3;
+    // masses of the reference selection: fit_transform takes sel2's own masses for cm2 (:512); the
+    // per-frame loop fits a selection onto the same atoms of the reference frame, i.e. same column
+    MH_TRY(stage_sel(c, ref_xyz, ref_natoms, ref_idx, n, nullptr, c->m_xyz2, c->m_idx2, c->m_mass2, &ref));
+    ref.mass = cur.mass;
+    const uint32_t F = (uint32_t)nframes;
+    const uint32_t nb = blocks_for(c, cur.n, F);
+    const uint32_t nbr = blocks_for(c, ref.n, 1);
+    MH_TRY(c->m_partials.reserve((size_t)std::max(nb * F, nbr) * 9 * 8));
+    // m_out layout: c1[F][3] | c2[3] | Rt[F][12] | scal[F][5] | status
+    const size_t off_c2 = (size_t)F * 3, off_rt = off_c2 + 4, off_sc = off_rt + (size_t)F * 12,
+                 off_st = off_sc + (size_t)F * 5;
+    MH_TRY(c->m_out.reserve((off_st + 4) * 4));
+    float *o = c->m_out.as<float>();
+    int *status = reinterpret_cast<int *>(o + off_st);
+    double *part = c->m_partials.as<double>();
+    MH_HIP(hipMemsetAsync(status, 0, 4, c->stream));
+    const unsigned fb = (F + 63) / 64;
+    Prof *prof = new Prof(c, 4);
+    // reference COM (once)
+    hipLaunchKernelGGL(k_sums, dim3(nbr, 1), dim3(RB), 0, c->stream, ref, part);
+    hipLaunchKernelGGL(k_fin_com, dim3(1), dim3(64), 0, c->stream, part, nbr, 1u, o + off_c2, status);
+    // pass 1: COM of every frame
+    hipLaunchKernelGGL(k_sums, dim3(nb, F), dim3(RB), 0, c->stream, cur, part);
+    hipLaunchKernelGGL(k_fin_com, dim3(fb), dim3(64), 0, c->stream, part, nb, F, o, status);
+    // pass 2: covariance -> rotation + translation
+    hipLaunchKernelGGL(k_cov, dim3(nb, F), dim3(RB), 0, c->stream, cur, ref, o, o + off_c2, part);
+    hipLaunchKernelGGL(k_fin_fit, dim3(fb), dim3(64), 0, c->stream, part, nb, F, o, o + off_c2, o + off_rt, status);
+    // pass 3: apply + rmsd + COM/gyration of the fitted selection
+    hipLaunchKernelGGL(k_apply, dim3(nb, F), dim3(RB), 0, c->stream, cur, ref, const_cast<float *>(cur.xyz),
+                       o + off_rt, apply ? 1 : 0, part);
+    hipLaunchKernelGGL(k_fin_apply, dim3(fb), dim3(64), 0, c->stream, part, nb, F, cur.n, o + off_sc);
+    delete prof;
+    MH_HIP(hipGetLastError());
+    // results
+    std::vector<float> h((off_st + 1) - off_rt);
+    MH_TRY(pull(c, h.data(), o + off_rt, h.size() * 4));
+    int st;
+    std::memcpy(&st, &h[off_st - off_rt], 4);
+    if (st) return fail(st, st == MOLAR_HIP_ERR_ZERO_MASS ? "zero mass" : "SVD failed");
+    auto emit = [&](float *dst, size_t count, auto getter) -> int {
+        if (!dst) return 0;
+        std::vector<float> tmp(count);
+        for (size_t k = 0; k < count; ++k) tmp[k] = getter(k);
+        if (is_device_ptr(dst)) MH_HIP(hipMemcpyAsync(dst, tmp.data(), count * 4, hipMemcpyHostToDevice, c->stream));
+        else std::memcpy(dst, tmp.data(), count * 4);
+        return 0;
+    };
+    const float *rt = h.data(), *sc = h.data() + (off_sc - off_rt);
+    MH_TRY(emit(rmsd_out, F, [&](size_t k) { return sc[5 * k]; }));
+    MH_TRY(emit(gyr_out, F, [&](size_t k) { return sc[5 * k + 4]; }));
+    MH_TRY(emit(com_out, (size_t)F * 3, [&](size_t k) { return sc[5 * (k / 3) + 1 + (k % 3)]; }));
+    MH_TRY(emit(R_out, (size_t)F * 9, [&](size_t k) { return rt[12 * (k / 9) + (k % 9)]; }));
+    MH_TRY(emit(t_out, (size_t)F * 3, [&](size_t k) { return rt[12 * (k / 3) + 9 + (k % 3)]; }));
+    if (apply && !is_device_ptr(frames))
+        MH_HIP(hipMemcpyAsync(frames, cur.xyz, nframes * natoms * 12, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+}  // extern "C"

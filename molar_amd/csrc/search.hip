@@ -1,0 +1,999 @@
+// search.hip — MolAR's cell-list distance search (molar/src/distance_search.rs) for gfx950.
+//
+// Pipeline per search (all on ctx->stream, no host round trip except the scalar result count
+// and, for non-periodic drivers, the bounding box):
+//   bin      one thread per atom: fractional coords -> cell, wrap/drop decision      (:120-199)
+//   scan     cell counts -> cell_start
+//   scatter  unordered placement into the cell's segment
+//   place    rank inside the segment by (wrapped, input index) -> reference cell order
+//            (in-box atoms in input order, then wrapped atoms, :180,:203-209); writes the
+//            cell-sorted float4 {x,y,z,id} array the pair kernels read
+//   count    one 64-lane wave per plan entry (x,y,z outer..inner, 14 masks, :217-269): lanes hold
+//            the atoms of the second cell in registers, the first cell's atoms arrive through
+//            scalar loads; v_cmp masks are popcounted -> hits per task
+//   scan     task counts -> 64-bit output offsets (reference order = plan order, :949-953)
+//   fill     same traversal; hits are compacted with mbcnt prefix ranks into a per-wave LDS
+//            FIFO (i-major, j-minor = the reference's inner loop order) and flushed 64 at a
+//            time as fully coalesced (u32,u32) + f32 stores
+//
+// All f32 arithmetic follows boxmath.hpp (reference operation order, no FMA contraction).
+#include "boxmath.hpp"
+#include "common.hpp"
+
+using namespace mh;
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
+constexpr uint32_t DROPPED = 0xFFFFFFFFu;
+constexpr int KREG = 8;            // B-cell chunks (of 64 atoms) a lane keeps in registers
+constexpr int FIFO_CAP = 128;      // per-wave LDS FIFO entries (flush threshold 64, push <= 64)
+constexpr float F32_EPS = 1.1920929e-07f;
+
+// distance_search.rs:39-60
+__constant__ uint8_t MASKS[14][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {0, 0, 0, 1, 0, 0}, {0, 0, 0, 0, 1, 0}, {0, 0, 0, 0, 0, 1},
+    {0, 0, 0, 1, 1, 0}, {0, 0, 0, 1, 0, 1}, {0, 0, 0, 0, 1, 1},
+    {0, 0, 0, 1, 1, 1},
+    {1, 0, 0, 0, 1, 0}, {1, 0, 0, 0, 0, 1}, {0, 1, 0, 0, 0, 1},
+    {1, 1, 0, 0, 0, 1}, {1, 0, 1, 0, 1, 0}, {0, 1, 1, 1, 0, 0},
+};
+
+// ================================================================= grid build
+
+struct BinParams {
+    const float *xyz;
+    const uint64_t *idx;
+    uint32_t n;
+    uint32_t dx, dy, dz;
+    uint32_t pbc;
+    uint32_t use_box;
+    float lower[3], upper[3];
+    molar_hip_box box;
+};
+
+struct CellOfAtom {
+    uint32_t key;   // cell<<1 | wrapped, or DROPPED
+    V3 pos;         // position stored in the grid (original or wrapped image)
+};
+
+// Grid::populate_pbc (distance_search.rs:144-210) / Grid::populate (:120-142) for one atom.
+__device__ __forceinline__ CellOfAtom classify(const BinParams &P, V3 p) {
+    CellOfAtom r;
+    r.pos = p;
+    if (P.use_box) {
+        V3 rel = mat_vec(P.box.inv, p);
+        float rl[3] = {rel.x, rel.y, rel.z};
+        bool wrap = false;
+        for (int d = 0; d < 3; ++d) {
+            if (rl[d] < 0.0f || rl[d] >= 1.0f) {
+                if (!((P.pbc >> d) & 1u)) {
+                    r.key = DROPPED;
+                    return r;
+                }
+                wrap = true;
+                break;
+            }
+        }
+        const uint32_t dims[3] = {P.dx, P.dy, P.dz};
+        uint32_t loc[3];
+        if (!wrap) {
+            for (int d = 0; d < 3; ++d) loc[d] = floor_to_cell(rl[d] * (float)dims[d], dims[d]);
+        } else {
+            for (int d = 0; d < 3; ++d) {
+                if ((P.pbc >> d) & 1u) {
+                    rl[d] = fract_rs(rl[d]);
+                    if (rl[d] < 0.0f) rl[d] = 1.0f + rl[d];
+                }
+                loc[d] = floor_to_cell(rl[d] * (float)dims[d], dims[d]);
+            }
+            r.pos = mat_vec(P.box.m, v3(rl[0], rl[1], rl[2]));
+        }
+        r.key = ((loc[0] + loc[1] * P.dx + loc[2] * P.dx * P.dy) << 1) | (wrap ? 1u : 0u);
+        return r;
+    }
+    const float pp[3] = {p.x, p.y, p.z};
+    const uint32_t dims[3] = {P.dx, P.dy, P.dz};
+    uint32_t loc[3];
+    for (int d = 0; d < 3; ++d) {
+        const float dim_sz = P.upper[d] - P.lower[d];
+        const float f = __builtin_floorf((float)dims[d] * (pp[d] - P.lower[d]) / dim_sz);
+        if (f != f) {               // NaN as isize == 0
+            loc[d] = 0;
+            continue;
+        }
+        if (f < 0.0f || f >= (float)dims[d]) {
+            r.key = DROPPED;
+            return r;
+        }
+        loc[d] = (uint32_t)f;
+    }
+    r.key = (loc[0] + loc[1] * P.dx + loc[2] * P.dx * P.dy) << 1;
+    return r;
+}
+
+__device__ __forceinline__ V3 load_pos(const float *xyz, uint64_t a) {
+    const float *q = xyz + 3 * a;
+    return v3(q[0], q[1], q[2]);
+}
+
+__global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restrict__ key,
+                                                  uint32_t *__restrict__ cell_count) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= P.n) return;
+    const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
+    const CellOfAtom c = classify(P, load_pos(P.xyz, a));
+    key[k] = c.key;
+    if (c.key != DROPPED) atomicAdd(&cell_count[c.key >> 1], 1u);
+}
+
+__global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t *__restrict__ key,
+                                                      const uint32_t *__restrict__ cell_start,
+                                                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ tmp_key,
+                                                      uint32_t *__restrict__ tmp_cell) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t ky = key[k];
+    if (ky == DROPPED) return;
+    const uint32_t cell = ky >> 1;
+    const uint32_t pos = cell_start[cell] + atomicAdd(&cursor[cell], 1u);
+    tmp_key[pos] = ((ky & 1u) << 31) | k;     // sort key inside the cell: in-box first, then input order
+    tmp_cell[pos] = cell;
+}
+
+__global__ void __launch_bounds__(256) place_kernel(BinParams P, uint32_t ncells, int ids_local,
+                                                    const uint32_t *__restrict__ cell_start,
+                                                    const uint32_t *__restrict__ tmp_key,
+                                                    const uint32_t *__restrict__ tmp_cell,
+                                                    const float *__restrict__ vdw, float4 *__restrict__ sorted,
+                                                    float *__restrict__ sorted_vdw) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= cell_start[ncells]) return;
+    const uint32_t mine = tmp_key[t];
+    const uint32_t cell = tmp_cell[t];
+    const uint32_t s = cell_start[cell], e = cell_start[cell + 1];
+    uint32_t rank = 0;
+    for (uint32_t q = s; q < e; ++q) rank += tmp_key[q] < mine ? 1u : 0u;
+    const uint32_t k = mine & 0x7FFFFFFFu;
+    const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
+    const CellOfAtom c = classify(P, load_pos(P.xyz, a));   // same arithmetic as bin_kernel
+    const uint32_t id = ids_local ? k : (uint32_t)a;
+    sorted[s + rank] = make_float4(c.pos.x, c.pos.y, c.pos.z, __uint_as_float(id));
+    if (vdw) sorted_vdw[s + rank] = vdw[k];
+}
+
+// ================================================================= scans (exclusive, n elements)
+
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
+
+template <class T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *total) {
+    __shared__ T wave_sums[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        T o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) base += wave_sums[w];
+        tot += wave_sums[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+template <class TIn, class TOut>
+__global__ void __launch_bounds__(256) scan_tile_kernel(const TIn *in, TOut *out, TOut *block_sums, uint64_t n) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    TOut item[SCAN_ITEMS];
+    TOut sum = 0;
+    for (int q = 0; q < SCAN_ITEMS; ++q) {
+        item[q] = base + q < n ? (TOut)in[base + q] : (TOut)0;
+        sum += item[q];
+    }
+    TOut tot;
+    TOut run = block_exclusive_scan<TOut>(sum, &tot);
+    for (int q = 0; q < SCAN_ITEMS; ++q) {
+        if (base + q < n) out[base + q] = run;
+        run += item[q];
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) scan_sums_kernel(T *sums, uint64_t nb) {
+    __shared__ T carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t start = 0; start < nb; start += 256) {
+        const uint64_t i = start + threadIdx.x;
+        const T v = i < nb ? sums[i] : (T)0;
+        T tot;
+        const T ex = block_exclusive_scan<T>(v, &tot);
+        const T carry = carry_s;
+        if (i < nb) sums[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) scan_add_kernel(T *out, const T *sums, uint64_t n) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    const T add = sums[blockIdx.x];
+    for (int q = 0; q < SCAN_ITEMS; ++q)
+        if (base + q < n) out[base + q] += add;
+}
+
+template <class TIn, class TOut>
+int exclusive_scan(molar_hip_ctx *c, const TIn *in, TOut *out, uint64_t n) {
+    if (n == 0) return 0;
+    const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    MH_TRY(c->scan_tmp.reserve(nb * sizeof(TOut)));
+    TOut *sums = c->scan_tmp.as<TOut>();
+    hipLaunchKernelGGL((scan_tile_kernel<TIn, TOut>), dim3((unsigned)nb), dim3(256), 0, c->stream, in, out, sums, n);
+    if (nb > 1) {
+        hipLaunchKernelGGL((scan_sums_kernel<TOut>), dim3(1), dim3(256), 0, c->stream, sums, nb);
+        hipLaunchKernelGGL((scan_add_kernel<TOut>), dim3((unsigned)nb), dim3(256), 0, c->stream, out, sums, n);
+    }
+    MH_HIP(hipGetLastError());
+    return 0;
+}
+
+// ================================================================= bounding box / max reductions
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+inline float ord2f(uint32_t o) {
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+inline uint32_t f2ord_host(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// compute_min_max (distance_search.rs:602-616): mm[0..2] = min, mm[3..5] = max, as ordered uints,
+// pre-seeded by the host with 0.0 (the reference seeds with zeros, so the box contains the origin).
+__global__ void __launch_bounds__(256) minmax_kernel(const float *__restrict__ xyz, const uint64_t *__restrict__ idx,
+                                                     uint32_t n, uint32_t *__restrict__ mm) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+        const uint64_t a = idx ? idx[k] : (uint64_t)k;
+        const float *q = xyz + 3 * a;
+        for (int d = 0; d < 3; ++d) {
+            const float v = q[d];
+            if (v < lo[d]) lo[d] = v;      // NaN never compares true, as in the reference
+            if (v > hi[d]) hi[d] = v;
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int d = 0; d < 3; ++d) {
+            if (lo[d] != INFINITY) atomicMin(&mm[d], f2ord(lo[d]));
+            if (hi[d] != -INFINITY) atomicMax(&mm[3 + d], f2ord(hi[d]));
+        }
+    }
+}
+
+// vdw.iter().cloned().reduce(Float::max) (distance_search.rs:781-782)
+__global__ void __launch_bounds__(256) fmax_kernel(const float *__restrict__ v, uint32_t n, uint32_t *__restrict__ out) {
+    float m = -INFINITY;
+    bool any = false;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+        const float x = v[k];
+        if (x == x) {
+            m = fmaxf(m, x);
+            any = true;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const bool wave_any = __ballot(any) != 0ull;
+    if ((threadIdx.x & 63) == 0 && wave_any) atomicMax(out, f2ord(m));
+}
+
+// ================================================================= pair kernels
+
+struct SearchParams {
+    const float4 *sa;        // cell-sorted atoms of set 1
+    const float4 *sb;        // cell-sorted atoms of set 2 (== sa for SINGLE)
+    const uint32_t *csa;     // cell_start of set 1
+    const uint32_t *csb;     // cell_start of set 2
+    const float *vdwa;
+    const float *vdwb;
+    uint32_t dx, dy, dz;
+    uint32_t pbc;            // PbcDims of the plan (0 for the non-periodic drivers)
+    uint32_t use_box;
+    uint32_t nblocks;        // launch grid (for the XCD remap)
+    float cutoff2;
+    uint64_t ntasks;
+    molar_hip_box box;
+};
+
+struct Task {
+    uint32_t a0, n1, b0, n2;
+    uint32_t wrap;
+    bool tri;
+    bool valid;
+};
+
+// search_plan (distance_search.rs:217-269).  Task index == position in the reference's plan
+// enumeration (x outer, z inner, 14 masks; for two-grid searches each entry is two tasks:
+// (c1,c2) then (c2,c1), :686-693).  Entries the reference filters out because a cell is empty
+// produce zero results here, so no compaction of the plan is needed.
+template <int KIND>
+__device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
+    Task T;
+    T.valid = false;
+    T.tri = false;
+    T.a0 = T.b0 = T.n1 = T.n2 = 0;
+    T.wrap = 0;
+    uint32_t half = 0;
+    uint64_t e = t;
+    if (KIND != MOLAR_HIP_SEARCH_SINGLE) {
+        half = (uint32_t)(t & 1ull);
+        e = t >> 1;
+    }
+    const uint32_t m = (uint32_t)(e % 14ull);
+    const uint64_t cidx = e / 14ull;
+    const uint32_t z = (uint32_t)(cidx % P.dz);
+    const uint64_t r = cidx / P.dz;
+    const uint32_t y = (uint32_t)(r % P.dy);
+    const uint32_t x = (uint32_t)(r / P.dy);
+    const uint32_t dims[3] = {P.dx, P.dy, P.dz};
+    uint32_t c[2][3] = {{x + MASKS[m][0], y + MASKS[m][1], z + MASKS[m][2]},
+                        {x + MASKS[m][3], y + MASKS[m][4], z + MASKS[m][5]}};
+    uint32_t wrap = 0;
+    for (int i = 0; i < 2; ++i)
+        for (int d = 0; d < 3; ++d)
+            if (c[i][d] == dims[d]) {
+                if ((P.pbc >> d) & 1u) {
+                    c[i][d] = 0;
+                    wrap |= 1u << d;
+                } else {
+                    return T;   // non-periodic dimension: entry dropped (:241-244)
+                }
+            }
+    const uint32_t i1 = c[0][0] + c[0][1] * P.dx + c[0][2] * P.dx * P.dy;
+    const uint32_t i2 = c[1][0] + c[1][1] * P.dx + c[1][2] * P.dx * P.dy;
+    uint32_t ca = i1, cb = i2;
+    if (KIND == MOLAR_HIP_SEARCH_SINGLE) {
+        T.tri = (i1 == i2);
+    } else if (half) {
+        ca = i2;
+        cb = i1;
+    }
+    T.a0 = P.csa[ca];
+    T.n1 = P.csa[ca + 1] - T.a0;
+    T.b0 = P.csb[cb];
+    T.n2 = P.csb[cb + 1] - T.b0;
+    T.wrap = wrap;
+    T.valid = T.n1 > 0 && T.n2 > 0 && !(T.tri && T.n1 < 2);
+    return T;
+}
+
+// |p2-p1|^2 for a plain pair (:488) or PeriodicBox::distance_squared with the entry's wrap flags (:485-486)
+template <bool WRAPPED>
+__device__ __forceinline__ float pair_d2(const molar_hip_box &box, uint32_t wrap, float x1, float y1, float z1,
+                                         float x2, float y2, float z2) {
+    const V3 v = v3(x2 - x1, y2 - y1, z2 - z1);
+    if (!WRAPPED) return norm2(v);
+    return norm2(shortest_vector(box, v, wrap));
+}
+
+// Per-wave output FIFO of the fill pass.
+struct Fifo {
+    uint32_t *fi, *fj, *fd;     // LDS, FIFO_CAP entries each
+    uint32_t head, tail;        // monotonically increasing, wave-uniform
+    uint64_t base;              // output offset of this task
+    uint2 *pairs;
+    float *dist;
+    uint32_t *ids;              // WITHIN output
+};
+
+template <int KIND>
+__device__ __forceinline__ void fifo_flush(Fifo &F, uint32_t count, uint32_t lane) {
+    if (lane < count) {
+        const uint32_t s = (F.head + lane) & (FIFO_CAP - 1);
+        const uint64_t pos = F.base + F.head + lane;
+        if (KIND == MOLAR_HIP_SEARCH_WITHIN) {
+            F.ids[pos] = F.fi[s];
+        } else {
+            if (F.pairs) F.pairs[pos] = make_uint2(F.fi[s], F.fj[s]);
+            if (F.dist) F.dist[pos] = __fsqrt_rn(__uint_as_float(F.fd[s]));   // d2.sqrt(), correctly rounded
+        }
+    }
+    F.head += count;
+}
+
+// One task = one ordered block of the reference's output:
+//   search_cell_pair_single(_pbc) :432-517, _double(_pbc) :324-373, _vdw(_pbc) :375-430,
+//   _within(_pbc) :271-322.  i runs over the first cell (scalar loads, wave-uniform),
+//   j over the second cell (one atom per lane per 64-chunk).
+template <int KIND, bool FILL, bool WRAPPED, bool STREAM>
+__device__ __forceinline__ uint64_t run_task(const SearchParams &P, const Task &T, Fifo &F, uint32_t lane) {
+    constexpr bool VDW = KIND == MOLAR_HIP_SEARCH_DOUBLE_VDW;
+    constexpr bool WITHIN = KIND == MOLAR_HIP_SEARCH_WITHIN;
+    uint64_t total = 0;
+
+    float bx[KREG], by[KREG], bz[KREG], bv[KREG];
+    uint32_t bid[KREG];
+    if (!STREAM) {
+#pragma unroll
+        for (int k = 0; k < KREG; ++k) {
+            const uint32_t jj = (uint32_t)k * 64u + lane;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            float rv = 0.f;
+            if (jj < T.n2) {
+                q = P.sb[T.b0 + jj];
+                if (VDW) rv = P.vdwb[T.b0 + jj];
+            }
+            bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bid[k] = __float_as_uint(q.w); bv[k] = rv;
+        }
+    }
+    const uint32_t nchunks = (T.n2 + 63u) >> 6;
+
+    for (uint32_t i = 0; i < T.n1; ++i) {
+        const float4 p = P.sa[T.a0 + i];
+        const uint32_t id_i = __float_as_uint(p.w);
+        float r1 = 0.f;
+        if (VDW) r1 = P.vdwa[T.a0 + i];
+        bool found = false;   // WITHIN
+
+        auto body = [&](uint32_t jj, float qx, float qy, float qz, uint32_t qid, float qv) {
+            const float d2 = pair_d2<WRAPPED>(P.box, T.wrap, p.x, p.y, p.z, qx, qy, qz);
+            bool hit;
+            if (VDW) {
+                const float cut = (r1 + qv) + F32_EPS;                 // :392, :423
+                hit = d2 <= cut * cut;
+            } else {
+                hit = d2 <= P.cutoff2;
+            }
+            hit = hit && (jj < T.n2);
+            if (T.tri) hit = hit && (jj > i);                          // j in i+1..n (:443, :482)
+            const unsigned long long mask = __ballot(hit);
+            if (WITHIN) {
+                if (mask) found = true;
+                return;
+            }
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            if (!FILL) {
+                total += cnt;
+                return;
+            }
+            if (cnt) {
+                if (hit) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    const uint32_t s = (F.tail + rank) & (FIFO_CAP - 1);
+                    F.fi[s] = id_i;
+                    F.fj[s] = qid;
+                    F.fd[s] = __float_as_uint(d2);
+                }
+                F.tail += cnt;
+                total += cnt;
+                if (F.tail - F.head >= 64u) {
+                    __builtin_amdgcn_wave_barrier();
+                    fifo_flush<KIND>(F, 64u, lane);
+                }
+            }
+        };
+
+        if (!STREAM) {
+#pragma unroll
+            for (int k = 0; k < KREG; ++k) {
+                if ((uint32_t)k >= nchunks) break;
+                if (T.tri && (uint32_t)k * 64u + 63u <= i) continue;   // whole chunk has j <= i
+                if (WITHIN && found) break;                          // `break` at the first hit (:289, :318)
+                body((uint32_t)k * 64u + lane, bx[k], by[k], bz[k], bid[k], bv[k]);
+            }
+        } else {
+            for (uint32_t c0 = 0; c0 < T.n2; c0 += 64u) {
+                if (T.tri && c0 + 63u <= i) continue;
+                if (WITHIN && found) break;
+                const uint32_t jj = c0 + lane;
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                float rv = 0.f;
+                if (jj < T.n2) {
+                    q = P.sb[T.b0 + jj];
+                    if (VDW) rv = P.vdwb[T.b0 + jj];
+                }
+                body(jj, q.x, q.y, q.z, __float_as_uint(q.w), rv);
+            }
+        }
+
+        if (WITHIN && found) {
+            if (FILL) {
+                if (lane == 0) F.fi[F.tail & (FIFO_CAP - 1)] = id_i;
+                F.tail += 1;
+                if (F.tail - F.head >= 64u) {
+                    __builtin_amdgcn_wave_barrier();
+                    fifo_flush<KIND>(F, 64u, lane);
+                }
+            }
+            total += 1;
+        }
+    }
+    if (FILL && F.tail != F.head) {
+        __builtin_amdgcn_wave_barrier();
+        fifo_flush<KIND>(F, F.tail - F.head, lane);
+    }
+    return total;
+}
+
+// block b of the launch -> task block, so that each XCD (blocks b%8) walks a contiguous range of
+// the plan and neighbouring cells stay in its own L2 (bijective form, guide §5 "XCD swizzle").
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
+    const uint32_t xcd = b & 7u, q = nb >> 3, r = nb & 7u;
+    const uint32_t start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return start + (b >> 3);
+}
+
+template <int KIND, bool FILL>
+__global__ void __launch_bounds__(BLOCK) pair_kernel(SearchParams P, unsigned long long *__restrict__ task_total,
+                                                     const unsigned long long *__restrict__ task_base,
+                                                     uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
+                                                     uint32_t *__restrict__ out_ids) {
+    __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t blk = xcd_remap(blockIdx.x, P.nblocks);
+    const uint64_t t = (uint64_t)blk * WAVES_PER_BLOCK + wave;
+    if (t >= P.ntasks) return;
+    const Task T = decode_task<KIND>(P, t);
+    Fifo F;
+    F.fi = lds[wave][0];
+    F.fj = lds[wave][1];
+    F.fd = lds[wave][2];
+    F.head = F.tail = 0;
+    F.pairs = out_pairs;
+    F.dist = out_dist;
+    F.ids = out_ids;
+    F.base = 0;
+    uint64_t total = 0;
+    if (T.valid) {
+        if (FILL) {
+            F.base = task_base[t];
+            if (task_base[t + 1] == F.base) return;     // nothing to emit: skip the traversal
+        }
+        const bool wrapped = P.use_box && T.wrap != 0;
+        const bool stream = T.n2 > (uint32_t)KREG * 64u;
+        if (!stream) {
+            total = wrapped ? run_task<KIND, FILL, true, false>(P, T, F, lane)
+                            : run_task<KIND, FILL, false, false>(P, T, F, lane);
+        } else {
+            total = wrapped ? run_task<KIND, FILL, true, true>(P, T, F, lane)
+                            : run_task<KIND, FILL, false, true>(P, T, F, lane);
+        }
+    }
+    if (!FILL && lane == 0) task_total[t] = total;
+}
+
+// u32 (i,j) pairs -> separate usize arrays (Vec<(usize,usize,Float)> split by field)
+__global__ void __launch_bounds__(256) widen_pairs_kernel(const uint2 *__restrict__ pairs, uint64_t n,
+                                                          unsigned long long *__restrict__ oi,
+                                                          unsigned long long *__restrict__ oj) {
+    for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256u) {
+        const uint2 p = pairs[k];
+        if (oi) oi[k] = p.x;
+        if (oj) oj[k] = p.y;
+    }
+}
+
+__global__ void __launch_bounds__(256) widen_ids_kernel(const uint32_t *__restrict__ ids, uint64_t n,
+                                                        unsigned long long *__restrict__ out) {
+    for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256u)
+        out[k] = ids[k];
+}
+
+// ================================================================= host orchestration
+
+// Grid::from_cutoff_and_extents (distance_search.rs:103-110)
+int dims_from_extents(molar_hip_ctx *c, float cutoff, const float ext[3]) {
+    double cells = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        const float q = std::floor(ext[d] / cutoff);
+        uint64_t s = (q > 0.0f) ? (q >= 4.0e9f ? 4000000000ull : (uint64_t)q) : 0ull;   // `as usize` saturates
+        if (s < 1) s = 1;
+        c->dims[d] = (uint32_t)s;
+        cells *= (double)s;
+    }
+    if (cells > 1.0e8)
+        return fail(MOLAR_HIP_ERR_TOO_LARGE, "search grid %u x %u x %u has too many cells (cutoff %g)", c->dims[0],
+                    c->dims[1], c->dims[2], (double)cutoff);
+    return 0;
+}
+
+int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
+    Prof prof(c, 0);
+    const uint32_t ncells = c->dims[0] * c->dims[1] * c->dims[2];
+    BinParams P{};
+    P.xyz = S.d_xyz;
+    P.idx = S.d_idx;
+    P.n = S.n;
+    P.dx = c->dims[0];
+    P.dy = c->dims[1];
+    P.dz = c->dims[2];
+    P.pbc = c->pbc;
+    P.use_box = c->use_box ? 1u : 0u;
+    for (int d = 0; d < 3; ++d) {
+        P.lower[d] = c->lower[d];
+        P.upper[d] = c->upper[d];
+    }
+    P.box = c->box;
+    MH_TRY(S.key.reserve((size_t)(S.n ? S.n : 1) * 4));
+    MH_TRY(S.cell_count.reserve((size_t)(ncells + 1) * 4));
+    MH_TRY(S.cursor.reserve((size_t)ncells * 4));
+    MH_TRY(S.tmp_key.reserve((size_t)(S.n ? S.n : 1) * 4));
+    MH_TRY(S.tmp_cell.reserve((size_t)(S.n ? S.n : 1) * 4));
+    MH_TRY(S.sorted.reserve((size_t)(S.n ? S.n : 1) * sizeof(float4)));
+    if (S.d_vdw) MH_TRY(S.sorted_vdw.reserve((size_t)(S.n ? S.n : 1) * 4));
+    MH_HIP(hipMemsetAsync(S.cell_count.p, 0, (size_t)(ncells + 1) * 4, c->stream));
+    MH_HIP(hipMemsetAsync(S.cursor.p, 0, (size_t)ncells * 4, c->stream));
+    if (S.n) {
+        const unsigned nb = (S.n + 255u) / 256u;
+        hipLaunchKernelGGL(bin_kernel, dim3(nb), dim3(256), 0, c->stream, P, S.key.as<uint32_t>(),
+                           S.cell_count.as<uint32_t>());
+        MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, S.cell_count.as<uint32_t>(), S.cell_count.as<uint32_t>(),
+                                                   (uint64_t)ncells + 1)));
+        hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, c->stream, S.n, S.key.as<uint32_t>(),
+                           S.cell_count.as<uint32_t>(), S.cursor.as<uint32_t>(), S.tmp_key.as<uint32_t>(),
+                           S.tmp_cell.as<uint32_t>());
+        hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), 0, c->stream, P, ncells, ids_local,
+                           S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.tmp_cell.as<uint32_t>(), S.d_vdw,
+                           S.sorted.as<float4>(), S.d_vdw ? S.sorted_vdw.as<float>() : nullptr);
+        MH_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int stage_set(molar_hip_ctx *c, GridSet &S, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+              const float *vdw, bool want_vdw) {
+    if (!xyz) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: xyz pointer is null");
+    const size_t nsel = idx ? n : natoms;
+    if (nsel >= 0x7FFFFFFFull || natoms >= 0xFFFFFFFFull)
+        return fail(MOLAR_HIP_ERR_TOO_LARGE, "search: %zu atoms exceed the 2^31 limit of the 32-bit device ids", nsel);
+    S.n = (uint32_t)nsel;
+    MH_TRY(to_device(c, xyz, natoms * 3, S.xyz_stage, &S.d_xyz));
+    MH_TRY(to_device(c, idx, idx ? n : 0, S.idx_stage, &S.d_idx));
+    S.d_vdw = nullptr;
+    if (want_vdw) {
+        if (!vdw) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "vdw search: radii pointer is null");
+        MH_TRY(to_device(c, vdw, nsel, S.vdw_stage, &S.d_vdw));
+    }
+    return 0;
+}
+
+SearchParams make_params(molar_hip_ctx *c) {
+    SearchParams P{};
+    const bool two = c->kind != MOLAR_HIP_SEARCH_SINGLE;
+    P.sa = c->set[0].sorted.as<float4>();
+    P.csa = c->set[0].cell_count.as<uint32_t>();
+    P.sb = two ? c->set[1].sorted.as<float4>() : P.sa;
+    P.csb = two ? c->set[1].cell_count.as<uint32_t>() : P.csa;
+    P.vdwa = c->set[0].sorted_vdw.as<float>();
+    P.vdwb = c->set[1].sorted_vdw.as<float>();
+    P.dx = c->dims[0];
+    P.dy = c->dims[1];
+    P.dz = c->dims[2];
+    P.pbc = c->use_box ? c->pbc : 0u;
+    P.use_box = c->use_box ? 1u : 0u;
+    P.cutoff2 = c->cutoff * c->cutoff;
+    P.ntasks = c->ntasks;
+    P.nblocks = (uint32_t)((c->ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    P.box = c->box;
+    return P;
+}
+
+template <bool FILL>
+int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids) {
+    Prof prof(c, FILL ? 3 : 1);
+    const SearchParams P = make_params(c);
+    if (P.nblocks == 0) return 0;
+    auto *tt = c->task_total.as<unsigned long long>();
+    auto *tb = c->task_base.as<unsigned long long>();
+    const dim3 g(P.nblocks), b(BLOCK);
+    switch (c->kind) {
+        case MOLAR_HIP_SEARCH_SINGLE:
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_SINGLE, FILL>), g, b, 0, c->stream, P, tt, tb, pairs, dist, ids);
+            break;
+        case MOLAR_HIP_SEARCH_DOUBLE:
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_DOUBLE, FILL>), g, b, 0, c->stream, P, tt, tb, pairs, dist, ids);
+            break;
+        case MOLAR_HIP_SEARCH_WITHIN:
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_WITHIN, FILL>), g, b, 0, c->stream, P, tt, tb, pairs, dist, ids);
+            break;
+        default:
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_DOUBLE_VDW, FILL>), g, b, 0, c->stream, P, tt, tb, pairs, dist, ids);
+            break;
+    }
+    MH_HIP(hipGetLastError());
+    return 0;
+}
+
+int read_back(molar_hip_ctx *c, void *dst_host, const void *src_dev, size_t bytes) {
+    MH_TRY(ensure_pinned(c, bytes));
+    MH_HIP(hipMemcpyAsync(c->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(dst_host, c->h_pinned, bytes);
+    return 0;
+}
+
+// zero-seeded bounding box of one set, accumulated into c->scan_tmp-independent 6-word buffer
+int bbox_accumulate(molar_hip_ctx *c, uint32_t *d_mm, const GridSet &S) {
+    if (!S.n) return 0;
+    unsigned nb = (S.n + 255u) / 256u;
+    if (nb > 2048u) nb = 2048u;
+    hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, c->stream, S.d_xyz, S.d_idx, S.n, d_mm);
+    MH_HIP(hipGetLastError());
+    return 0;
+}
+
+int device_fmax(molar_hip_ctx *c, const float *d_v, uint32_t n, float *out) {
+    MH_TRY(c->hist.reserve(64));
+    uint32_t *d = c->hist.as<uint32_t>();
+    const uint32_t seed = 0u;   // below every ordered float
+    MH_HIP(hipMemcpyAsync(d, &seed, 4, hipMemcpyHostToDevice, c->stream));
+    unsigned nb = (n + 255u) / 256u;
+    if (nb > 1024u) nb = 1024u;
+    hipLaunchKernelGGL(fmax_kernel, dim3(nb), dim3(256), 0, c->stream, d_v, n, d);
+    MH_HIP(hipGetLastError());
+    uint32_t o;
+    MH_TRY(read_back(c, &o, d, 4));
+    *out = ord2f(o);
+    return 0;
+}
+
+int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q) {
+    if (!c || !q) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: null argument");
+    if (q->kind < 0 || q->kind > 3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: unknown kind %d", q->kind);
+    MH_HIP(hipSetDevice(c->device));
+    c->have_search = false;
+    c->kind = q->kind;
+    const bool two = q->kind != MOLAR_HIP_SEARCH_SINGLE;
+    const bool vdw = q->kind == MOLAR_HIP_SEARCH_DOUBLE_VDW;
+    c->use_box = q->box9 != nullptr;
+    c->pbc = q->pbc & 7u;
+    if (c->use_box) MH_TRY(molar_hip_box_from_matrix(q->box9, &c->box));
+    MH_TRY(stage_set(c, c->set[0], q->xyz1, q->natoms1, q->idx1, q->n1, q->vdw1, vdw));
+    if (two) MH_TRY(stage_set(c, c->set[1], q->xyz2, q->natoms2, q->idx2, q->n2, q->vdw2, vdw));
+    else c->set[1].n = 0;
+
+    float cutoff = q->cutoff;
+    if (vdw) {
+        // cutoff = max(vdw1) + max(vdw2) + EPSILON (:781-783); the reference panics on empty input
+        if (c->set[0].n == 0 || c->set[1].n == 0) {
+            c->dims[0] = c->dims[1] = c->dims[2] = 1;
+            c->ntasks = 0;
+            c->total = 0;
+            c->have_search = true;
+            return 0;
+        }
+        float m1, m2;
+        MH_TRY(device_fmax(c, c->set[0].d_vdw, c->set[0].n, &m1));
+        MH_TRY(device_fmax(c, c->set[1].d_vdw, c->set[1].n, &m2));
+        cutoff = (m1 + m2) + F32_EPS;
+    }
+    if (!(cutoff > 0.0f)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: cutoff must be positive (got %g)", (double)cutoff);
+    c->cutoff = cutoff;
+
+    float ext[3];
+    if (c->use_box) {
+        molar_hip_box_lab_extents(&c->box, ext);                       // Grid::from_cutoff_and_box :116-118
+    } else {
+        if (q->kind == MOLAR_HIP_SEARCH_WITHIN) {
+            if (!q->lower3 || !q->upper3)
+                return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "non-periodic within search needs lower3/upper3");
+            for (int d = 0; d < 3; ++d) {
+                c->lower[d] = q->lower3[d];
+                c->upper[d] = q->upper3[d];
+            }
+        } else {
+            // compute_bounding_box_single/double (:618-646), min/max seeded with zeros (:602-616)
+            MH_TRY(c->hist.reserve(64));
+            uint32_t *d_mm = c->hist.as<uint32_t>();
+            uint32_t seed[6];
+            for (int d = 0; d < 6; ++d) seed[d] = f2ord_host(0.0f);
+            MH_HIP(hipMemcpyAsync(d_mm, seed, sizeof seed, hipMemcpyHostToDevice, c->stream));
+            MH_TRY(bbox_accumulate(c, d_mm, c->set[0]));
+            if (two) MH_TRY(bbox_accumulate(c, d_mm, c->set[1]));
+            uint32_t mm[6];
+            MH_TRY(read_back(c, mm, d_mm, sizeof mm));
+            for (int d = 0; d < 3; ++d) {
+                c->lower[d] = ord2f(mm[d]) + (-cutoff - F32_EPS);
+                c->upper[d] = ord2f(mm[3 + d]) + (cutoff + F32_EPS);
+            }
+        }
+        for (int d = 0; d < 3; ++d) ext[d] = c->upper[d] - c->lower[d];   // from_cutoff_and_min_max :112-114
+    }
+    MH_TRY(dims_from_extents(c, cutoff, ext));
+    MH_TRY(build_grid(c, c->set[0], q->ids_local || vdw));
+    if (two) MH_TRY(build_grid(c, c->set[1], q->ids_local || vdw));
+
+    const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
+    c->ntasks = ncells * 14ull * (two ? 2ull : 1ull);
+    MH_TRY(c->task_total.reserve((c->ntasks + 1) * 8));
+    MH_TRY(c->task_base.reserve((c->ntasks + 1) * 8));
+    MH_HIP(hipMemsetAsync(c->task_total.p, 0, (c->ntasks + 1) * 8, c->stream));
+    return 0;
+}
+
+int finish_count(molar_hip_ctx *c) {
+    Prof *prof = new Prof(c, 2);
+    int rc = (exclusive_scan<unsigned long long, unsigned long long>(c, c->task_total.as<unsigned long long>(),
+                                                                   c->task_base.as<unsigned long long>(),
+                                                                   c->ntasks + 1));
+    delete prof;
+    MH_TRY(rc);
+    unsigned long long tot = 0;
+    MH_TRY(read_back(c, &tot, c->task_base.as<unsigned long long>() + c->ntasks, 8));
+    c->total = tot;
+    c->have_search = true;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int molar_hip_search_count(molar_hip_ctx *c, const molar_hip_search_desc *q, uint64_t *out_count) {
+    MH_TRY(prepare_search(c, q));
+    if (c->have_search) {   // degenerate (empty vdw input)
+        if (out_count) *out_count = 0;
+        return MOLAR_HIP_OK;
+    }
+    MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr));
+    MH_TRY(finish_count(c));
+    if (out_count) *out_count = c->total;
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_search_grid_dims(molar_hip_ctx *c, uint64_t dims[3]) {
+    if (!c || !c->have_search) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached search: call molar_hip_search_count first");
+    for (int d = 0; d < 3; ++d) dims[d] = c->dims[d];
+    return MOLAR_HIP_OK;
+}
+
+static int fill_common(molar_hip_ctx *c, uint2 *d_pairs, float *d_dist, uint32_t *d_ids) {
+    if (!c || !c->have_search) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached search: call molar_hip_search_count first");
+    MH_HIP(hipSetDevice(c->device));
+    if (c->total == 0 || c->ntasks == 0) return 0;
+    return launch_pairs<true>(c, d_pairs, d_dist, d_ids);
+}
+
+int molar_hip_search_fill(molar_hip_ctx *c, uint32_t *pairs, float *dist) {
+    if (!c || !c->have_search) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached search: call molar_hip_search_count first");
+    if (c->kind == MOLAR_HIP_SEARCH_WITHIN)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within search yields ids: use molar_hip_search_fill_ids");
+    const bool pd = is_device_ptr(pairs), dd = is_device_ptr(dist);
+    uint2 *dp = nullptr;
+    float *ddist = nullptr;
+    if (pairs) {
+        if (pd) dp = reinterpret_cast<uint2 *>(pairs);
+        else {
+            MH_TRY(c->out_pairs.reserve((size_t)(c->total ? c->total : 1) * 8));
+            dp = c->out_pairs.as<uint2>();
+        }
+    }
+    if (dist) {
+        if (dd) ddist = dist;
+        else {
+            MH_TRY(c->out_dist.reserve((size_t)(c->total ? c->total : 1) * 4));
+            ddist = c->out_dist.as<float>();
+        }
+    }
+    MH_TRY(fill_common(c, dp, ddist, nullptr));
+    if (pairs && !pd && c->total) MH_HIP(hipMemcpyAsync(pairs, dp, c->total * 8, hipMemcpyDeviceToHost, c->stream));
+    if (dist && !dd && c->total) MH_HIP(hipMemcpyAsync(dist, ddist, c->total * 4, hipMemcpyDeviceToHost, c->stream));
+    if ((pairs && !pd) || (dist && !dd)) MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_search_fill_device(molar_hip_ctx *c, const uint32_t **d_pairs, const float **d_dist) {
+    if (!c || !c->have_search) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached search: call molar_hip_search_count first");
+    if (c->kind == MOLAR_HIP_SEARCH_WITHIN)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within search yields ids: use molar_hip_search_fill_ids");
+    MH_TRY(c->out_pairs.reserve((size_t)(c->total ? c->total : 1) * 8));
+    MH_TRY(c->out_dist.reserve((size_t)(c->total ? c->total : 1) * 4));
+    MH_TRY(fill_common(c, c->out_pairs.as<uint2>(), c->out_dist.as<float>(), nullptr));
+    if (d_pairs) *d_pairs = c->out_pairs.as<uint32_t>();
+    if (d_dist) *d_dist = c->out_dist.as<float>();
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_search_fill_usize(molar_hip_ctx *c, uint64_t *oi, uint64_t *oj, float *dist) {
+    if (!c || !c->have_search) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached search: call molar_hip_search_count first");
+    if (c->kind == MOLAR_HIP_SEARCH_WITHIN)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within search yields ids: use molar_hip_search_fill_ids");
+    const size_t n = (size_t)c->total;
+    MH_TRY(c->out_pairs.reserve((n ? n : 1) * 8));
+    const bool dd = is_device_ptr(dist);
+    float *ddist = nullptr;
+    if (dist) {
+        if (dd) ddist = dist;
+        else {
+            MH_TRY(c->out_dist.reserve((n ? n : 1) * 4));
+            ddist = c->out_dist.as<float>();
+        }
+    }
+    MH_TRY(fill_common(c, c->out_pairs.as<uint2>(), ddist, nullptr));
+    if (n == 0) return MOLAR_HIP_OK;
+    const bool di = is_device_ptr(oi), dj = is_device_ptr(oj);
+    unsigned long long *wi = nullptr, *wj = nullptr;
+    if (oi) {
+        if (di) wi = reinterpret_cast<unsigned long long *>(oi);
+        else {
+            MH_TRY(c->wide_i.reserve(n * 8));
+            wi = c->wide_i.as<unsigned long long>();
+        }
+    }
+    if (oj) {
+        if (dj) wj = reinterpret_cast<unsigned long long *>(oj);
+        else {
+            MH_TRY(c->wide_j.reserve(n * 8));
+            wj = c->wide_j.as<unsigned long long>();
+        }
+    }
+    unsigned nb = (unsigned)((n + 255) / 256);
+    if (nb > 8192u) nb = 8192u;
+    hipLaunchKernelGGL(widen_pairs_kernel, dim3(nb), dim3(256), 0, c->stream, c->out_pairs.as<uint2>(), (uint64_t)n, wi, wj);
+    MH_HIP(hipGetLastError());
+    if (oi && !di) MH_HIP(hipMemcpyAsync(oi, wi, n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (oj && !dj) MH_HIP(hipMemcpyAsync(oj, wj, n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (dist && !dd) MH_HIP(hipMemcpyAsync(dist, ddist, n * 4, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_search_fill_ids(molar_hip_ctx *c, uint64_t *ids) {
+    if (!c || !c->have_search) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached search: call molar_hip_search_count first");
+    if (c->kind != MOLAR_HIP_SEARCH_WITHIN)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fill_ids is for within searches");
+    const size_t n = (size_t)c->total;
+    if (n == 0 || !ids) return MOLAR_HIP_OK;
+    MH_TRY(c->out_ids.reserve(n * 4));
+    MH_TRY(fill_common(c, nullptr, nullptr, c->out_ids.as<uint32_t>()));
+    const bool dv = is_device_ptr(ids);
+    unsigned long long *w;
+    if (dv) w = reinterpret_cast<unsigned long long *>(ids);
+    else {
+        MH_TRY(c->wide_i.reserve(n * 8));
+        w = c->wide_i.as<unsigned long long>();
+    }
+    unsigned nb = (unsigned)((n + 255) / 256);
+    if (nb > 8192u) nb = 8192u;
+    hipLaunchKernelGGL(widen_ids_kernel, dim3(nb), dim3(256), 0, c->stream, c->out_ids.as<uint32_t>(), (uint64_t)n, w);
+    MH_HIP(hipGetLastError());
+    if (!dv) {
+        MH_HIP(hipMemcpyAsync(ids, w, n * 8, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q, float hmin, float hmax, size_t nbins,
+                               uint64_t *bins, uint64_t *out_count) {
+    (void)c; (void)q; (void)hmin; (void)hmax; (void)nbins; (void)bins; (void)out_count;
+    return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "molar_hip_search_histogram: not implemented yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/molar_hip.h
+declares, its host-side PeriodicBox arithmetic equals the oracle bit for bit, and the product
+path fails loudly when no GPU is present (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from molar_amd import _lib, build
+    build.build_library()
+    return _lib.load()
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "molar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(molar_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from molar_amd import _lib
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/molar_hip.h but not exported"
+    assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
+
+
+def test_version_and_device_count(lib):
+    assert b"gfx950" in lib.molar_hip_version()
+    assert lib.molar_hip_device_count() >= 0
+
+
+def test_box_matches_oracle_bitwise(lib, orc32):
+    from molar_amd.api import PeriodicBox
+    rng = np.random.default_rng(0)
+    mats = [
+        np.diag([10.0, 20.0, 30.0]),
+        np.array([[10.0, 4.0, -4.0], [0, 10.0, 0], [0, 0, 10.0]]),
+        np.array([[21.544, 0, -3.0], [0, 21.544, -3.0], [0, 0, 21.544]]),
+        np.array([[6.0, 0, 3.0], [0, 6.0, 3.0], [0, 0, 6.0]]),
+        np.array([[8.0, 4.0, 0], [0, 6.9282, 0], [0, 0, 9.0]]),
+    ]
+    for m in mats:
+        pb = PeriodicBox.from_matrix(m)
+        ob = orc32.box_from_matrix(m)
+        assert np.array_equal(np.array(pb._b.m), np.array(ob.m))
+        assert np.array_equal(np.array(pb._b.inv), np.array(ob.inv))
+        assert pb._b.nshift == ob.nshift
+        assert np.array_equal(np.array(pb._b.shifts)[: 3 * ob.nshift], np.array(ob.shifts)[: 3 * ob.nshift])
+        assert np.array_equal(pb.get_lab_extents(), orc32.lab_extents(ob))
+        for _ in range(200):
+            v = rng.uniform(-60, 60, 3).astype(np.float32)
+            for dims in (7, 0, 1, 3, 5):
+                assert np.array_equal(pb.shortest_vector(v, dims), orc32.shortest_vector_dims(ob, v, dims))
+
+
+def test_box_known_answers(lib):
+    """periodic_box.rs:559-575 and test_2.py:233-245 through the product's host arithmetic."""
+    from molar_amd.api import PeriodicBox
+    pb = PeriodicBox.from_matrix([[10.0, 4.0, -4.0], [0, 10.0, 0], [0, 0, 10.0]])
+    assert abs(pb.distance([38.9214, 40.0078, -34.0795], [-26.6187, 40.8926, 30.9709]) - 5.353627) < 1e-3
+    b = PeriodicBox([1, 2, 3], [90, 90, 90])
+    v = b.shortest_vector([0.9, 0.5, 0.6])
+    assert np.allclose(v, [-0.1, 0.5, 0.6], atol=1e-6)
+    assert PeriodicBox.from_matrix(np.diag([10.0, 20.0, 30.0])).n_tric_corrections == 0
+
+
+def test_box_errors(lib):
+    from molar_amd.api import PeriodicBox
+    from molar_amd._lib import MolarHipError
+    with pytest.raises(MolarHipError) as e:
+        PeriodicBox.from_matrix(np.zeros((3, 3)))
+    assert e.value.code == 5
+    with pytest.raises(MolarHipError) as e:
+        PeriodicBox.from_matrix([[1, 1, 0], [1, 1, 0], [0, 0, 1]])
+    assert e.value.code == 6
+    with pytest.raises(MolarHipError) as e:
+        PeriodicBox([10.0, 0.2, 15.0], [90.0, 9.0, 90.0])       # periodic_box.rs:448-454
+    assert e.value.code == 10
+
+
+def test_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from molar_amd.api import Engine
+    from molar_amd._lib import MolarHipError
+    with pytest.raises(MolarHipError):
+        Engine(0)
+    assert "HIP device" in lib.molar_hip_last_error().decode() or "no HIP" in lib.molar_hip_last_error().decode()
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under molar_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "molar_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no CPU fallback", ""), f"{f} mentions the oracle"

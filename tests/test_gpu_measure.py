@@ -1,0 +1,142 @@
+"""GPU parity of the Measure / Modify entry points against the CPU oracle.
+
+Tolerance (north_star): 1e-5 relative against the reference arithmetic.  The reference sums
+1e4-1e5 f32 terms serially, which itself carries ~1e-5..1e-4 relative noise, so
+floats are compared with the oracle's f64 build (MolAR's own `f64` feature) at 1e-5, and with
+the f32-faithful build at a stated looser bound."""
+import numpy as np
+import pytest
+
+from molar_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL64 = 1e-5     # vs the f64 oracle
+RTOL32 = 3e-4     # vs the serial-f32 oracle (its own summation noise)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from molar_amd import build
+    from molar_amd.api import Engine
+    build.build_library()
+    return Engine(0)
+
+
+@pytest.fixture(scope="module")
+def system():
+    n = 50_000
+    box = synth.box_a(n)
+    xyz = synth.frame(n, box, 0)
+    rng = np.random.default_rng(3)
+    ang = 0.9
+    axis = np.array([0.3, -0.5, 0.8]); axis /= np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    Rtrue = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    xyz2 = (xyz.astype(np.float64) @ Rtrue.T + np.array([1.5, -2.0, 0.7]) + rng.normal(0, 0.05, xyz.shape)).astype(np.float32)
+    return dict(n=n, box=box, xyz=xyz, xyz2=xyz2, mass=synth.masses(n), idx=np.arange(0, n, 10, dtype=np.uint64))
+
+
+def test_reductions(eng, orc32, orc64, system):
+    s = system
+    for idx in (s["idx"], None):
+        for o, rtol in ((orc64, RTOL64), (orc32, RTOL32)):
+            assert np.allclose(eng.center_of_geometry(s["xyz"], idx), o.center_of_geometry(s["xyz"], idx), rtol=rtol)
+            assert np.allclose(eng.center_of_mass(s["xyz"], s["mass"], idx), o.center_of_mass(s["xyz"], s["mass"], idx), rtol=rtol)
+            assert eng.gyration(s["xyz"], s["mass"], idx) == pytest.approx(o.gyration(s["xyz"], s["mass"], idx), rel=rtol)
+            assert eng.rmsd(s["xyz"], s["xyz2"], idx, idx) == pytest.approx(o.rmsd(s["xyz"], s["xyz2"], idx, idx), rel=rtol)
+            assert eng.rmsd_mw(s["xyz"], s["mass"], s["xyz2"], idx, idx) == pytest.approx(
+                o.rmsd_mw(s["xyz"], s["mass"], s["xyz2"], idx, idx), rel=rtol)
+        lo, up = eng.min_max(s["xyz"], idx)
+        rlo, rup = orc32.min_max(s["xyz"], idx)
+        assert np.array_equal(lo, rlo) and np.array_equal(up, rup)          # exact
+
+
+def test_inertia(eng, orc64, system):
+    s = system
+    mom, axes, tens = eng.inertia(s["xyz"], s["mass"], s["idx"])
+    rmom, raxes = orc64.inertia(s["xyz"], s["mass"], s["idx"])
+    rt = orc64.inertia_tensor(s["xyz"], s["mass"], s["idx"])
+    assert np.allclose(tens, rt, rtol=RTOL64, atol=RTOL64 * np.abs(rt).max())
+    assert np.allclose(mom, rmom, rtol=1e-4)
+    assert np.allclose(axes.T @ axes, np.eye(3), atol=1e-5) and np.linalg.det(axes) == pytest.approx(1.0, abs=1e-5)
+    # near-degenerate moments of a uniform box: compare the invariant A diag(m) A^T instead of axis signs
+    assert np.allclose(axes @ np.diag(mom) @ axes.T, rt, rtol=1e-4, atol=1e-4 * np.abs(rt).max())
+
+
+def test_fit_transform_and_apply(eng, orc32, orc64, system):
+    s = system
+    idx = s["idx"]
+    R, t = eng.fit_transform(s["xyz"], s["mass"], s["xyz2"], s["mass"], idx, idx)
+    R64, t64 = orc64.fit_transform(s["xyz"], s["mass"], s["xyz2"], s["mass"], idx, idx)
+    assert np.allclose(R, R64, atol=1e-5)
+    assert np.allclose(t, t64, rtol=1e-5, atol=2e-4)
+    R0, t0 = eng.fit_transform(s["xyz"], s["mass"], s["xyz2"], s["mass"], idx, idx, at_origin=True)
+    Ro, to = orc64.fit_transform_at_origin(s["xyz"], s["mass"], s["xyz2"], idx, idx)
+    assert np.allclose(R0, Ro, atol=1e-5) and not t0.any()
+    # apply_transform: same f32 arithmetic as the reference -> bit-identical coordinates
+    moved = s["xyz"].copy()
+    eng.apply_transform(moved, R, t, idx)
+    ref = orc32.apply_transform(s["xyz"], R, t, idx)
+    assert np.array_equal(moved, ref)
+    assert eng.rmsd(moved, s["xyz2"], idx, idx) < 0.1
+
+
+def test_pbc_centres_gyration_unwrap(eng, orc32, orc64):
+    box = synth.box_a(20000)
+    rng = np.random.default_rng(5)
+    blob = rng.normal(0, 0.4, (3000, 3))
+    inv = np.linalg.inv(box.astype(np.float64))
+    wrapped = (((blob @ inv.T) % 1.0) @ box.astype(np.float64).T).astype(np.float32)
+    m = rng.uniform(1, 16, 3000).astype(np.float32)
+    b64 = orc64.box_from_matrix(box); b32 = orc32.box_from_matrix(box)
+    for dims in (7, 3):
+        assert np.allclose(eng.center_of_mass_pbc(wrapped, m, box, dims),
+                           orc64.center_of_mass_pbc_dims(wrapped, m, b64, dims), rtol=RTOL64, atol=1e-5)
+        assert np.allclose(eng.center_of_geometry_pbc(wrapped, box, dims),
+                           orc64.center_of_geometry_pbc_dims(wrapped, b64, dims), rtol=RTOL64, atol=1e-5)
+    assert eng.gyration(wrapped, m, None, box) == pytest.approx(orc64.gyration_pbc(wrapped, m, b64), rel=1e-4)
+    un = wrapped.copy()
+    eng.unwrap_simple(un, box, 7)
+    assert np.array_equal(un, orc32.unwrap_simple_dim(wrapped, b32, 7))       # same f32 arithmetic: exact
+
+
+def test_errors(eng, system):
+    from molar_amd._lib import MolarHipError
+    s = system
+    with pytest.raises(MolarHipError) as e:
+        eng.rmsd(s["xyz"], s["xyz2"], s["idx"], s["idx"][:-1])
+    assert e.value.code == 1                                               # MeasureError::Sizes
+    with pytest.raises(MolarHipError) as e:
+        eng.center_of_mass(s["xyz"], np.zeros(s["n"], np.float32), s["idx"])
+    assert e.value.code == 2                                               # MeasureError::ZeroMass
+    with pytest.raises(MolarHipError) as e:
+        eng.center_of_mass_pbc(s["xyz"], s["mass"], None, 7, s["idx"])
+    assert e.value.code == 4                                               # PeriodicBoxError::NoPbc
+
+
+def test_fit_rmsd_batch(eng, orc32, orc64):
+    """Per-frame loop of benches/comparison_small.rs:14-25 batched over frames."""
+    n, F = 20000, 6
+    box = synth.box_a(n)
+    ref = synth.frame(n, box, 0)
+    frames = np.stack([synth.frame(n, box, f + 1) for f in range(F)])
+    # rotate/translate each frame differently so the fit is not the identity
+    for f in range(F):
+        a = 0.3 * (f + 1)
+        Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        frames[f] = (frames[f].astype(np.float64) @ Rz.T + [0.5 * f, -1.0, 2.0]).astype(np.float32)
+    mass = synth.masses(n)
+    idx = np.arange(0, n, 10, dtype=np.uint64)
+    work = frames.copy()
+    out = eng.fit_rmsd_batch(work, mass, ref, idx=idx, apply=True)
+    for f in range(F):
+        R64, t64 = orc64.fit_transform(frames[f], mass, ref, mass, idx, idx)
+        assert np.allclose(out["R"][f], R64, atol=1e-5)
+        assert np.allclose(out["t"][f], t64, rtol=1e-5, atol=2e-4)
+        moved = orc32.apply_transform(frames[f], out["R"][f], out["t"][f], idx)
+        assert np.array_equal(work[f], moved)                              # apply: exact f32 arithmetic
+        assert out["rmsd"][f] == pytest.approx(orc64.rmsd(moved, ref, idx, idx), rel=RTOL64)
+        assert np.allclose(out["com"][f], orc64.center_of_mass(moved, mass, idx), rtol=RTOL64)
+        assert out["gyration"][f] == pytest.approx(orc64.gyration(moved, mass, idx), rel=RTOL64)
+        assert out["rmsd"][f] < 0.2
