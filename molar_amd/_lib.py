@@ -85,11 +85,32 @@ def lib_path() -> str:
     return os.environ.get("MOLAR_HIP_PLUGIN", DEFAULT_LIB)
 
 
+def _preload_torch_hip_runtime():
+    """torch wheels bundle their own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Whichever
+    copy is dlopen'ed first serves the whole process; torch does not find its GPUs behind the
+    system copy, so when torch is installed load its runtime first.  (A non-Python host simply
+    uses the system runtime the library is linked against.)"""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen the engine and bind every symbol of the header; raises if anything is missing."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip_runtime()
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError(

@@ -127,8 +127,11 @@ struct molar_hip_ctx {
     uint64_t ntasks = 0;
     uint64_t total = 0;
     mh::GridSet set[2];
-    mh::DevBuf task_total;     // u32 per task
-    mh::DevBuf task_base;      // u64 per task (+1 grand total)
+    uint64_t nslots_bound = 0; // host-side upper bound of the slot count (sizes the launches)
+    mh::DevBuf task_nb;        // u32 per task (+1): 64-row blocks of the task, scanned in place -> first slot
+    mh::DevBuf slot_task;      // u32 per slot: owning task
+    mh::DevBuf slot_cnt;       // u32 per slot (+1): results of the slot
+    mh::DevBuf slot_base;      // u64 per slot (+1): output offset (last = grand total)
     mh::DevBuf scan_tmp;       // block sums for the scans
     mh::DevBuf out_pairs;      // ctx-owned result buffers (device-resident results / host staging)
     mh::DevBuf out_dist;

@@ -323,7 +323,8 @@ struct SearchParams {
     uint32_t dx, dy, dz;
     uint32_t pbc;            // PbcDims of the plan (0 for the non-periodic drivers)
     uint32_t use_box;
-    uint32_t nblocks;        // launch grid (for the XCD remap)
+    uint32_t nblocks;        // launch grid
+    uint32_t wrap_kind;      // WK_* of the box matrix (zero pattern of m and inv)
     float cutoff2;
     uint64_t ntasks;
     molar_hip_box box;
@@ -391,13 +392,70 @@ __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     return T;
 }
 
-// |p2-p1|^2 for a plain pair (:488) or PeriodicBox::distance_squared with the entry's wrap flags (:485-486)
-template <bool WRAPPED>
-__device__ __forceinline__ float pair_d2(const molar_hip_box &box, uint32_t wrap, float x1, float y1, float z1,
-                                         float x2, float y2, float z2) {
-    const V3 v = v3(x2 - x1, y2 - y1, z2 - z1);
-    if (!WRAPPED) return norm2(v);
-    return norm2(shortest_vector(box, v, wrap));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// How a wrapped cell pair evaluates PeriodicBox::distance_squared (periodic_box.rs:286-318,379-381).
+// The matrix kinds only skip products with entries that are exactly 0.0 in BOTH the box matrix
+// and its inverse: x + (0*y) == x in IEEE arithmetic (up to the sign of a zero result, which the
+// final sum of squares cannot see), so every kind yields the same d2 bits as the general form.
+enum { WK_NONE = 0, WK_DIAG = 1, WK_UPPER = 2, WK_GENERAL = 3 };
+
+__device__ __forceinline__ v2f round_away2(v2f f) { return v2f{__builtin_roundf(f.x), __builtin_roundf(f.y)}; }
+
+// squared distances from the broadcast atom p (SGPR operands) to TWO second-cell atoms per lane
+// (one of each 64-chunk of a chunk pair): packed f32 math, two candidates per VALU instruction.
+//   plain   : |p2-p1|^2 = ((dx*dx)+(dy*dy))+(dz*dz)                                   (:488)
+//   wrapped : f = inv*v; f[d] -= round(f[d]) for the entry's wrap dims; s = M*f;
+//             triclinic candidate loop only if shifts exist and all three dims wrap (:304)
+template <int WK>
+__device__ __forceinline__ v2f pair_d2x2(const SearchParams &P, uint32_t wrap, float px, float py, float pz, v2f qx,
+                                         v2f qy, v2f qz) {
+    const v2f vx = qx - px, vy = qy - py, vz = qz - pz;
+    if (WK == WK_NONE) return (vx * vx + vy * vy) + vz * vz;
+    const float *I = P.box.inv, *M = P.box.m;
+    v2f fx, fy, fz;
+    if (WK == WK_DIAG) {
+        fx = I[0] * vx;
+        fy = I[4] * vy;
+        fz = I[8] * vz;
+    } else if (WK == WK_UPPER) {
+        fx = (I[0] * vx + I[3] * vy) + I[6] * vz;
+        fy = I[4] * vy + I[7] * vz;
+        fz = I[8] * vz;
+    } else {
+        fx = (I[0] * vx + I[3] * vy) + I[6] * vz;
+        fy = (I[1] * vx + I[4] * vy) + I[7] * vz;
+        fz = (I[2] * vx + I[5] * vy) + I[8] * vz;
+    }
+    if (wrap & 1u) fx -= round_away2(fx);
+    if (wrap & 2u) fy -= round_away2(fy);
+    if (wrap & 4u) fz -= round_away2(fz);
+    v2f sx, sy, sz;
+    if (WK == WK_DIAG) {
+        sx = M[0] * fx;
+        sy = M[4] * fy;
+        sz = M[8] * fz;
+    } else if (WK == WK_UPPER) {
+        sx = (M[0] * fx + M[3] * fy) + M[6] * fz;
+        sy = M[4] * fy + M[7] * fz;
+        sz = M[8] * fz;
+    } else {
+        sx = (M[0] * fx + M[3] * fy) + M[6] * fz;
+        sy = (M[1] * fx + M[4] * fy) + M[7] * fz;
+        sz = (M[2] * fx + M[5] * fy) + M[8] * fz;
+    }
+    v2f best2 = (sx * sx + sy * sy) + sz * sz;
+    if (WK != WK_DIAG && P.box.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {
+        for (int k = 0; k < P.box.nshift; ++k) {
+            const v2f cx = sx + P.box.shifts[3 * k], cy = sy + P.box.shifts[3 * k + 1], cz = sz + P.box.shifts[3 * k + 2];
+            const v2f n2 = (cx * cx + cy * cy) + cz * cz;
+            // `best` itself is only needed through its norm: cand = start + s is always formed from
+            // `start`, not from the running best (:310), so tracking best2 is enough
+            best2.x = n2.x < best2.x ? n2.x : best2.x;
+            best2.y = n2.y < best2.y ? n2.y : best2.y;
+        }
+    }
+    return best2;
 }
 
 // Per-wave output FIFO of the fill pass.
@@ -419,7 +477,8 @@ __device__ __forceinline__ void fifo_flush(Fifo &F, uint32_t count, uint32_t lan
             F.ids[pos] = F.fi[s];
         } else {
             if (F.pairs) F.pairs[pos] = make_uint2(F.fi[s], F.fj[s]);
-            if (F.dist) F.dist[pos] = __fsqrt_rn(__uint_as_float(F.fd[s]));   // d2.sqrt(), correctly rounded
+            // d2.sqrt() (:448): llvm.sqrt.f32 without fpmath metadata = IEEE correctly rounded
+            if (F.dist) F.dist[pos] = __builtin_sqrtf(__uint_as_float(F.fd[s]));
         }
     }
     F.head += count;
@@ -427,110 +486,162 @@ __device__ __forceinline__ void fifo_flush(Fifo &F, uint32_t count, uint32_t lan
 
 // One task = one ordered block of the reference's output:
 //   search_cell_pair_single(_pbc) :432-517, _double(_pbc) :324-373, _vdw(_pbc) :375-430,
-//   _within(_pbc) :271-322.  i runs over the first cell (scalar loads, wave-uniform),
-//   j over the second cell (one atom per lane per 64-chunk).
-template <int KIND, bool FILL, bool WRAPPED, bool STREAM>
-__device__ __forceinline__ uint64_t run_task(const SearchParams &P, const Task &T, Fifo &F, uint32_t lane) {
+//   _within(_pbc) :271-322.
+// j (second cell): one atom per lane per 64-chunk, NCH chunks resident in registers as packed
+// pairs (NCH = 0: cells larger than KREG*64 atoms are re-read from memory per row).
+// i (first cell): 64 atoms at a time are loaded one-per-lane and each row's atom is broadcast
+// with v_readlane into SGPRs, so the distance arithmetic takes scalar operands and no per-row
+// memory access sits on the critical path.
+// RUNTIME_NCH: the chunk count is checked at run time (triangular tasks, which skip chunks).
+template <int KIND, bool FILL, int WK, bool TRI, int NCH, bool RUNTIME_NCH>
+__device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, uint32_t lane) {
     constexpr bool VDW = KIND == MOLAR_HIP_SEARCH_DOUBLE_VDW;
     constexpr bool WITHIN = KIND == MOLAR_HIP_SEARCH_WITHIN;
-    uint64_t total = 0;
+    constexpr bool STREAM = NCH == 0;
+    constexpr int NPAIR = STREAM ? 1 : (NCH + 1) / 2;
+    uint32_t total = 0;
 
-    float bx[KREG], by[KREG], bz[KREG], bv[KREG];
-    uint32_t bid[KREG];
+    v2f bx[NPAIR], by[NPAIR], bz[NPAIR], bv[NPAIR];
+    uint32_t bid[2 * NPAIR];
+    auto load_b = [&](uint32_t jj, float &x, float &y, float &z, float &v, uint32_t &id) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        float rv = 0.f;
+        if (jj < T.n2) {
+            q = P.sb[T.b0 + jj];
+            if (VDW) rv = P.vdwb[T.b0 + jj];
+        }
+        x = q.x; y = q.y; z = q.z; v = rv; id = __float_as_uint(q.w);
+    };
     if (!STREAM) {
 #pragma unroll
-        for (int k = 0; k < KREG; ++k) {
-            const uint32_t jj = (uint32_t)k * 64u + lane;
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            float rv = 0.f;
-            if (jj < T.n2) {
-                q = P.sb[T.b0 + jj];
-                if (VDW) rv = P.vdwb[T.b0 + jj];
-            }
-            bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bid[k] = __float_as_uint(q.w); bv[k] = rv;
+        for (int h = 0; h < NPAIR; ++h) {
+            float x0, y0, z0, v0, x1, y1, z1, v1;
+            load_b((uint32_t)(2 * h) * 64u + lane, x0, y0, z0, v0, bid[2 * h]);
+            load_b((uint32_t)(2 * h + 1) * 64u + lane, x1, y1, z1, v1, bid[2 * h + 1]);
+            bx[h] = v2f{x0, x1}; by[h] = v2f{y0, y1}; bz[h] = v2f{z0, z1}; bv[h] = v2f{v0, v1};
         }
     }
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
 
-    for (uint32_t i = 0; i < T.n1; ++i) {
-        const float4 p = P.sa[T.a0 + i];
-        const uint32_t id_i = __float_as_uint(p.w);
-        float r1 = 0.f;
-        if (VDW) r1 = P.vdwa[T.a0 + i];
-        bool found = false;   // WITHIN
-
-        auto body = [&](uint32_t jj, float qx, float qy, float qz, uint32_t qid, float qv) {
-            const float d2 = pair_d2<WRAPPED>(P.box, T.wrap, p.x, p.y, p.z, qx, qy, qz);
-            bool hit;
-            if (VDW) {
-                const float cut = (r1 + qv) + F32_EPS;                 // :392, :423
-                hit = d2 <= cut * cut;
-            } else {
-                hit = d2 <= P.cutoff2;
-            }
-            hit = hit && (jj < T.n2);
-            if (T.tri) hit = hit && (jj > i);                          // j in i+1..n (:443, :482)
-            const unsigned long long mask = __ballot(hit);
-            if (WITHIN) {
-                if (mask) found = true;
-                return;
-            }
-            const uint32_t cnt = (uint32_t)__popcll(mask);
-            if (!FILL) {
-                total += cnt;
-                return;
-            }
-            if (cnt) {
-                if (hit) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    const uint32_t s = (F.tail + rank) & (FIFO_CAP - 1);
-                    F.fi[s] = id_i;
-                    F.fj[s] = qid;
-                    F.fd[s] = __float_as_uint(d2);
-                }
-                F.tail += cnt;
-                total += cnt;
-                if (F.tail - F.head >= 64u) {
-                    __builtin_amdgcn_wave_barrier();
-                    fifo_flush<KIND>(F, 64u, lane);
-                }
-            }
-        };
-
-        if (!STREAM) {
-#pragma unroll
-            for (int k = 0; k < KREG; ++k) {
-                if ((uint32_t)k >= nchunks) break;
-                if (T.tri && (uint32_t)k * 64u + 63u <= i) continue;   // whole chunk has j <= i
-                if (WITHIN && found) break;                          // `break` at the first hit (:289, :318)
-                body((uint32_t)k * 64u + lane, bx[k], by[k], bz[k], bid[k], bv[k]);
-            }
-        } else {
-            for (uint32_t c0 = 0; c0 < T.n2; c0 += 64u) {
-                if (T.tri && c0 + 63u <= i) continue;
-                if (WITHIN && found) break;
-                const uint32_t jj = c0 + lane;
-                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                float rv = 0.f;
-                if (jj < T.n2) {
-                    q = P.sb[T.b0 + jj];
-                    if (VDW) rv = P.vdwb[T.b0 + jj];
-                }
-                body(jj, q.x, q.y, q.z, __float_as_uint(q.w), rv);
-            }
+    {   // one slot = rows [i0, i0+64) of the first cell
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ra = 0.f;
+        if (i0 + lane < T.n1) {
+            a = P.sa[T.a0 + i0 + lane];
+            if (VDW) ra = P.vdwa[T.a0 + i0 + lane];
         }
+        const uint32_t rows = T.n1 - i0 < 64u ? T.n1 - i0 : 64u;
+        for (uint32_t r = 0; r < rows; ++r) {
+            const uint32_t i = i0 + r;
+            const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.x), r));
+            const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.y), r));
+            const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.z), r));
+            const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(a.w), r);
+            float r1 = 0.f;
+            if (VDW) r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra), r));
+            bool found = false;   // WITHIN
 
-        if (WITHIN && found) {
-            if (FILL) {
-                if (lane == 0) F.fi[F.tail & (FIFO_CAP - 1)] = id_i;
-                F.tail += 1;
-                if (F.tail - F.head >= 64u) {
-                    __builtin_amdgcn_wave_barrier();
-                    fifo_flush<KIND>(F, 64u, lane);
+            // consume the hits of one 64-chunk, in j order
+            auto emit = [&](bool hit, float d2, uint32_t qid) {
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (WITHIN) {
+                    if (mask) found = true;
+                    return;
+                }
+                const uint32_t cnt = (uint32_t)__popcll(mask);
+                if (!FILL) {
+                    total += cnt;
+                    return;
+                }
+                if (cnt) {
+                    if (hit) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        const uint32_t s = (F.tail + rank) & (FIFO_CAP - 1);
+                        F.fi[s] = id_i;
+                        F.fj[s] = qid;
+                        F.fd[s] = __float_as_uint(d2);
+                    }
+                    F.tail += cnt;
+                    total += cnt;
+                    if (F.tail - F.head >= 64u) {
+                        __builtin_amdgcn_wave_barrier();
+                        fifo_flush<KIND>(F, 64u, lane);
+                    }
+                }
+            };
+            // two chunks (c0 = first chunk index) against row i; use0/use1: chunk is live
+            auto pair_body = [&](uint32_t c0, bool use0, bool use1, bool rag0, bool rag1, v2f qx, v2f qy, v2f qz, v2f qv,
+                                 uint32_t id0, uint32_t id1) {
+                const v2f d2 = pair_d2x2<WK>(P, T.wrap, px, py, pz, qx, qy, qz);
+                bool h0, h1;
+                if (VDW) {
+                    const v2f cut = (r1 + qv) + F32_EPS;                   // :392, :423
+                    const v2f c2 = cut * cut;
+                    h0 = d2.x <= c2.x;
+                    h1 = d2.y <= c2.y;
+                } else {
+                    h0 = d2.x <= P.cutoff2;
+                    h1 = d2.y <= P.cutoff2;
+                }
+                const uint32_t j0 = c0 * 64u + lane, j1 = j0 + 64u;
+                if (rag0) h0 = h0 && (j0 < T.n2);                          // only the last chunk is ragged
+                if (rag1) h1 = h1 && (j1 < T.n2);
+                if (TRI) {                                                 // j in i+1..n (:443, :482)
+                    h0 = h0 && (j0 > i);
+                    h1 = h1 && (j1 > i);
+                }
+                if (use0 && !(WITHIN && found)) emit(h0, d2.x, id0);
+                if (use1 && !(WITHIN && found)) emit(h1, d2.y, id1);      // `break` at the first hit (:289, :318)
+            };
+
+            if (!STREAM) {
+#pragma unroll
+                for (int h = 0; h < NPAIR; ++h) {
+                    const uint32_t c0 = 2u * (uint32_t)h, c1 = c0 + 1u;
+                    bool use0 = true, use1 = (int)c1 < NCH;
+                    if (RUNTIME_NCH) {
+                        use0 = c0 < nchunks;
+                        use1 = c1 < nchunks;
+                    }
+                    if (TRI) {                                             // whole chunk has j <= i
+                        use0 = use0 && !(c0 * 64u + 63u <= i);
+                        use1 = use1 && !(c1 * 64u + 63u <= i);
+                    }
+                    if (WITHIN && found) break;
+                    if (!use0 && !use1) continue;
+                    const bool rag0 = RUNTIME_NCH ? (c0 + 1u == nchunks) : ((int)c0 == NCH - 1);
+                    const bool rag1 = RUNTIME_NCH ? (c1 + 1u == nchunks) : ((int)c1 == NCH - 1);
+                    pair_body(c0, use0, use1, rag0, rag1, bx[h], by[h], bz[h], bv[h], bid[2 * h], bid[2 * h + 1]);
+                }
+            } else {
+                for (uint32_t c0 = 0; c0 < nchunks; c0 += 2u) {
+                    bool use0 = true, use1 = c0 + 1u < nchunks;
+                    if (TRI) {
+                        use0 = !(c0 * 64u + 63u <= i);
+                        use1 = use1 && !((c0 + 1u) * 64u + 63u <= i);
+                    }
+                    if (WITHIN && found) break;
+                    if (!use0 && !use1) continue;
+                    float x0, y0, z0, v0, x1, y1, z1, v1;
+                    uint32_t id0, id1;
+                    load_b(c0 * 64u + lane, x0, y0, z0, v0, id0);
+                    load_b((c0 + 1u) * 64u + lane, x1, y1, z1, v1, id1);
+                    pair_body(c0, use0, use1, true, true, v2f{x0, x1}, v2f{y0, y1}, v2f{z0, z1}, v2f{v0, v1}, id0, id1);
                 }
             }
-            total += 1;
+
+            if (WITHIN && found) {
+                if (FILL) {
+                    if (lane == 0) F.fi[F.tail & (FIFO_CAP - 1)] = id_i;
+                    F.tail += 1;
+                    if (F.tail - F.head >= 64u) {
+                        __builtin_amdgcn_wave_barrier();
+                        fifo_flush<KIND>(F, 64u, lane);
+                    }
+                }
+                total += 1;
+            }
         }
     }
     if (FILL && F.tail != F.head) {
@@ -540,25 +651,72 @@ __device__ __forceinline__ uint64_t run_task(const SearchParams &P, const Task &
     return total;
 }
 
-// block b of the launch -> task block, so that each XCD (blocks b%8) walks a contiguous range of
-// the plan and neighbouring cells stay in its own L2 (bijective form, guide §5 "XCD swizzle").
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
-    const uint32_t xcd = b & 7u, q = nb >> 3, r = nb & 7u;
-    const uint32_t start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-    return start + (b >> 3);
+// chunk-count dispatch: for the single-set search the non-triangular tasks get a fully unrolled,
+// branch-free row body per chunk count; everything else checks the chunk count at run time
+template <int KIND, bool FILL, int WK>
+__device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, uint32_t lane) {
+    const uint32_t nchunks = (T.n2 + 63u) >> 6;
+    if (nchunks > (uint32_t)KREG) {
+        if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) return run_task<KIND, FILL, WK, true, 0, false>(P, T, i0, F, lane);
+        return run_task<KIND, FILL, WK, false, 0, false>(P, T, i0, F, lane);
+    }
+    if (KIND == MOLAR_HIP_SEARCH_SINGLE) {
+        if (T.tri) return run_task<KIND, FILL, WK, true, KREG, true>(P, T, i0, F, lane);
+        switch (nchunks) {
+            case 1: return run_task<KIND, FILL, WK, false, 1, false>(P, T, i0, F, lane);
+            case 2: return run_task<KIND, FILL, WK, false, 2, false>(P, T, i0, F, lane);
+            case 3: return run_task<KIND, FILL, WK, false, 3, false>(P, T, i0, F, lane);
+            case 4: return run_task<KIND, FILL, WK, false, 4, false>(P, T, i0, F, lane);
+            case 5: return run_task<KIND, FILL, WK, false, 5, false>(P, T, i0, F, lane);
+            case 6: return run_task<KIND, FILL, WK, false, 6, false>(P, T, i0, F, lane);
+            case 7: return run_task<KIND, FILL, WK, false, 7, false>(P, T, i0, F, lane);
+            default: return run_task<KIND, FILL, WK, false, 8, false>(P, T, i0, F, lane);
+        }
+    }
+    return run_task<KIND, FILL, WK, false, KREG, true>(P, T, i0, F, lane);
+}
+
+// Slots.  A plan entry ("task") is cut into blocks of 64 rows of its first cell; one wave processes
+// one slot.  This bounds the work of a wave (the corner entries that run the triclinic candidate
+// loop are ~50x a plain entry) and gives small systems enough waves to fill the chip.  Slots are
+// numbered in plan order, then row order, so an exclusive scan of the per-slot counts is the
+// reference's output order.
+template <int KIND>
+__global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__restrict__ task_nb) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.ntasks) return;
+    const Task T = decode_task<KIND>(P, t);
+    task_nb[t] = T.valid ? (T.n1 + 63u) >> 6 : 0u;
+}
+
+__global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, const uint32_t *__restrict__ task_first,
+                                                      uint32_t *__restrict__ slot_task) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= ntasks) return;
+    const uint32_t s0 = task_first[t], s1 = task_first[t + 1];
+    for (uint32_t s = s0; s < s1; ++s) slot_task[s] = (uint32_t)t;
 }
 
 template <int KIND, bool FILL>
-__global__ void __launch_bounds__(BLOCK) pair_kernel(SearchParams P, unsigned long long *__restrict__ task_total,
-                                                     const unsigned long long *__restrict__ task_base,
+__global__ void __launch_bounds__(BLOCK) pair_kernel(SearchParams P, const uint32_t *__restrict__ task_first,
+                                                     const uint32_t *__restrict__ slot_task,
+                                                     uint32_t *__restrict__ slot_cnt,
+                                                     const unsigned long long *__restrict__ slot_base,
                                                      uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
                                                      uint32_t *__restrict__ out_ids) {
     __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t blk = xcd_remap(blockIdx.x, P.nblocks);
-    const uint64_t t = (uint64_t)blk * WAVES_PER_BLOCK + wave;
-    if (t >= P.ntasks) return;
+    const uint32_t nslots = task_first[P.ntasks];
+    const uint32_t w = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (w >= nslots) return;
+    // Blocks are handed out in launch order: walk the plan BACKWARDS so the cells at the far x edge,
+    // whose entries wrap (several times the arithmetic per candidate), start first and the cheap
+    // entries fill the tail; consecutive blocks land on different XCDs, which spreads that band
+    // over the whole chip.
+    const uint32_t slot = nslots - 1u - w;
+    const uint32_t t = slot_task[slot];
+    const uint32_t i0 = (slot - task_first[t]) * 64u;
     const Task T = decode_task<KIND>(P, t);
     Fifo F;
     F.fi = lds[wave][0];
@@ -569,23 +727,19 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(SearchParams P, unsigned lo
     F.dist = out_dist;
     F.ids = out_ids;
     F.base = 0;
-    uint64_t total = 0;
-    if (T.valid) {
-        if (FILL) {
-            F.base = task_base[t];
-            if (task_base[t + 1] == F.base) return;     // nothing to emit: skip the traversal
-        }
-        const bool wrapped = P.use_box && T.wrap != 0;
-        const bool stream = T.n2 > (uint32_t)KREG * 64u;
-        if (!stream) {
-            total = wrapped ? run_task<KIND, FILL, true, false>(P, T, F, lane)
-                            : run_task<KIND, FILL, false, false>(P, T, F, lane);
-        } else {
-            total = wrapped ? run_task<KIND, FILL, true, true>(P, T, F, lane)
-                            : run_task<KIND, FILL, false, true>(P, T, F, lane);
-        }
+    if (FILL) {
+        F.base = slot_base[slot];
+        if (slot_base[slot + 1] == F.base) return;     // nothing to emit: skip the traversal
     }
-    if (!FILL && lane == 0) task_total[t] = total;
+    uint32_t total = 0;
+    const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
+    switch (wk) {
+        case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE>(P, T, i0, F, lane); break;
+        case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG>(P, T, i0, F, lane); break;
+        case WK_UPPER: total = run_task_nch<KIND, FILL, WK_UPPER>(P, T, i0, F, lane); break;
+        default: total = run_task_nch<KIND, FILL, WK_GENERAL>(P, T, i0, F, lane); break;
+    }
+    if (!FILL && lane == 0) slot_cnt[slot] = total;
 }
 
 // u32 (i,j) pairs -> separate usize arrays (Vec<(usize,usize,Float)> split by field)
@@ -699,8 +853,18 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.use_box = c->use_box ? 1u : 0u;
     P.cutoff2 = c->cutoff * c->cutoff;
     P.ntasks = c->ntasks;
-    P.nblocks = (uint32_t)((c->ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    P.nblocks = (uint32_t)((c->nslots_bound + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     P.box = c->box;
+    // zero pattern shared by the matrix and its inverse -> which products a wrapped pair may skip
+    P.wrap_kind = 3u;   // WK_GENERAL
+    if (c->use_box) {
+        const float *m = c->box.m, *iv = c->box.inv;
+        auto z = [&](int k) { return m[k] == 0.0f && iv[k] == 0.0f; };
+        const bool lower_zero = z(1) && z(2) && z(5);            // (1,0) (2,0) (2,1)
+        const bool upper_zero = z(3) && z(6) && z(7);            // (0,1) (0,2) (1,2)
+        if (lower_zero && upper_zero) P.wrap_kind = 1u;          // WK_DIAG
+        else if (lower_zero) P.wrap_kind = 2u;                   // WK_UPPER (GROMACS-style boxes)
+    }
     return P;
 }
 
@@ -709,21 +873,23 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids) {
     Prof prof(c, FILL ? 3 : 1);
     const SearchParams P = make_params(c);
     if (P.nblocks == 0) return 0;
-    auto *tt = c->task_total.as<unsigned long long>();
-    auto *tb = c->task_base.as<unsigned long long>();
+    const uint32_t *tf = c->task_nb.as<uint32_t>();
+    const uint32_t *st = c->slot_task.as<uint32_t>();
+    uint32_t *sc = c->slot_cnt.as<uint32_t>();
+    auto *sb = c->slot_base.as<unsigned long long>();
     const dim3 g(P.nblocks), b(BLOCK);
     switch (c->kind) {
         case MOLAR_HIP_SEARCH_SINGLE:
-            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_SINGLE, FILL>), g, b, 0, c->stream, P, tt, tb, pairs, dist, ids);
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_SINGLE, FILL>), g, b, 0, c->stream, P, tf, st, sc, sb, pairs, dist, ids);
             break;
         case MOLAR_HIP_SEARCH_DOUBLE:
-            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_DOUBLE, FILL>), g, b, 0, c->stream, P, tt, tb, pairs, dist, ids);
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_DOUBLE, FILL>), g, b, 0, c->stream, P, tf, st, sc, sb, pairs, dist, ids);
             break;
         case MOLAR_HIP_SEARCH_WITHIN:
-            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_WITHIN, FILL>), g, b, 0, c->stream, P, tt, tb, pairs, dist, ids);
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_WITHIN, FILL>), g, b, 0, c->stream, P, tf, st, sc, sb, pairs, dist, ids);
             break;
         default:
-            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_DOUBLE_VDW, FILL>), g, b, 0, c->stream, P, tt, tb, pairs, dist, ids);
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_DOUBLE_VDW, FILL>), g, b, 0, c->stream, P, tf, st, sc, sb, pairs, dist, ids);
             break;
     }
     MH_HIP(hipGetLastError());
@@ -831,21 +997,45 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q) {
 
     const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
     c->ntasks = ncells * 14ull * (two ? 2ull : 1ull);
-    MH_TRY(c->task_total.reserve((c->ntasks + 1) * 8));
-    MH_TRY(c->task_base.reserve((c->ntasks + 1) * 8));
-    MH_HIP(hipMemsetAsync(c->task_total.p, 0, (c->ntasks + 1) * 8, c->stream));
+    // every set-1 cell is the first cell of at most 14 (two grids: 28) tasks, so
+    // sum_t ceil(n1(t)/64) <= mult*N1/64 + ntasks
+    c->nslots_bound = (two ? 28ull : 14ull) * (((uint64_t)c->set[0].n + 63ull) / 64ull) + c->ntasks;
+    if (c->ntasks >= 0xFFFFFFF0ull || c->nslots_bound >= 0xFFFFFFF0ull)
+        return fail(MOLAR_HIP_ERR_TOO_LARGE, "search plan too large (%llu entries)", (unsigned long long)c->ntasks);
+    MH_TRY(c->task_nb.reserve((c->ntasks + 1) * 4));
+    MH_TRY(c->slot_task.reserve((c->nslots_bound + 1) * 4));
+    MH_TRY(c->slot_cnt.reserve((c->nslots_bound + 1) * 4));
+    MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
+    {
+        Prof prof(c, 0);
+        MH_HIP(hipMemsetAsync(c->task_nb.p, 0, (c->ntasks + 1) * 4, c->stream));
+        MH_HIP(hipMemsetAsync(c->slot_cnt.p, 0, (c->nslots_bound + 1) * 4, c->stream));
+        const SearchParams P = make_params(c);
+        const unsigned nb = (unsigned)((c->ntasks + 255) / 256);
+        switch (c->kind) {
+            case MOLAR_HIP_SEARCH_SINGLE:
+                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>());
+                break;
+            default:   // the three two-grid kinds decode tasks identically
+                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>());
+                break;
+        }
+        MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), c->ntasks + 1)));
+        hipLaunchKernelGGL(slotmap_kernel, dim3(nb), dim3(256), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
+                           c->slot_task.as<uint32_t>());
+        MH_HIP(hipGetLastError());
+    }
     return 0;
 }
 
 int finish_count(molar_hip_ctx *c) {
     Prof *prof = new Prof(c, 2);
-    int rc = (exclusive_scan<unsigned long long, unsigned long long>(c, c->task_total.as<unsigned long long>(),
-                                                                   c->task_base.as<unsigned long long>(),
-                                                                   c->ntasks + 1));
+    int rc = (exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(),
+                                                           c->slot_base.as<unsigned long long>(), c->nslots_bound + 1));
     delete prof;
     MH_TRY(rc);
     unsigned long long tot = 0;
-    MH_TRY(read_back(c, &tot, c->task_base.as<unsigned long long>() + c->ntasks, 8));
+    MH_TRY(read_back(c, &tot, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8));
     c->total = tot;
     c->have_search = true;
     return 0;

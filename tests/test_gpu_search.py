@@ -285,7 +285,7 @@ def test_full_size_properties(eng):
     assert cnt == eng.search_count(a.SEARCH_SINGLE, 1.2, dpos, box=box, pbc=7)     # idempotent
     i = pairs[:, 0].long(); j = pairs[:, 1].long()
     assert int((i == j).sum()) == 0
-    assert float(dist.max()) <= 1.2 and float(dist.min()) >= 0.0
+    assert float(dist.max()) <= float(np.float32(1.2)) and float(dist.min()) >= 0.0      # sqrt(d2 <= rc*rc) in f32
     # no duplicate pairs: the (min,max) keys are unique
     key = torch.minimum(i, j) * n + torch.maximum(i, j)
     assert int(torch.unique(key).numel()) == cnt
