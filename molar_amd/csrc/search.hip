@@ -407,12 +407,17 @@ __device__ __forceinline__ v2f round_away2(v2f f) { return v2f{__builtin_roundf(
 //   plain   : |p2-p1|^2 = ((dx*dx)+(dy*dy))+(dz*dz)                                   (:488)
 //   wrapped : f = inv*v; f[d] -= round(f[d]) for the entry's wrap dims; s = M*f;
 //             triclinic candidate loop only if shifts exist and all three dims wrap (:304)
+struct BoxRegs {
+    float I[9], M[9];   // inverse and matrix, column-major, held in SGPRs (statically indexed only)
+    int nshift;
+};
+
 template <int WK>
-__device__ __forceinline__ v2f pair_d2x2(const SearchParams &P, uint32_t wrap, float px, float py, float pz, v2f qx,
-                                         v2f qy, v2f qz) {
+__device__ __forceinline__ v2f pair_d2x2(const SearchParams &P, const BoxRegs &B, uint32_t wrap, float px, float py,
+                                         float pz, v2f qx, v2f qy, v2f qz) {
     const v2f vx = qx - px, vy = qy - py, vz = qz - pz;
     if (WK == WK_NONE) return (vx * vx + vy * vy) + vz * vz;
-    const float *I = P.box.inv, *M = P.box.m;
+    const float *I = B.I, *M = B.M;
     v2f fx, fy, fz;
     if (WK == WK_DIAG) {
         fx = I[0] * vx;
@@ -445,8 +450,8 @@ __device__ __forceinline__ v2f pair_d2x2(const SearchParams &P, uint32_t wrap, f
         sz = (M[2] * fx + M[5] * fy) + M[8] * fz;
     }
     v2f best2 = (sx * sx + sy * sy) + sz * sz;
-    if (WK != WK_DIAG && P.box.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {
-        for (int k = 0; k < P.box.nshift; ++k) {
+    if (WK != WK_DIAG && B.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {
+        for (int k = 0; k < B.nshift; ++k) {
             const v2f cx = sx + P.box.shifts[3 * k], cy = sy + P.box.shifts[3 * k + 1], cz = sz + P.box.shifts[3 * k + 2];
             const v2f n2 = (cx * cx + cy * cy) + cz * cz;
             // `best` itself is only needed through its norm: cand = start + s is always formed from
@@ -500,6 +505,17 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
     constexpr bool STREAM = NCH == 0;
     constexpr int NPAIR = STREAM ? 1 : (NCH + 1) / 2;
     uint32_t total = 0;
+    BoxRegs B;
+    B.nshift = 0;
+    if (WK != WK_NONE) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            B.I[k] = P.box.inv[k];
+            B.M[k] = P.box.m[k];
+        }
+        B.nshift = P.box.nshift;
+    }
+    const float cutoff2 = P.cutoff2;
 
     v2f bx[NPAIR], by[NPAIR], bz[NPAIR], bv[NPAIR];
     uint32_t bid[2 * NPAIR];
@@ -573,7 +589,7 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
             // two chunks (c0 = first chunk index) against row i; use0/use1: chunk is live
             auto pair_body = [&](uint32_t c0, bool use0, bool use1, bool rag0, bool rag1, v2f qx, v2f qy, v2f qz, v2f qv,
                                  uint32_t id0, uint32_t id1) {
-                const v2f d2 = pair_d2x2<WK>(P, T.wrap, px, py, pz, qx, qy, qz);
+                const v2f d2 = pair_d2x2<WK>(P, B, T.wrap, px, py, pz, qx, qy, qz);
                 bool h0, h1;
                 if (VDW) {
                     const v2f cut = (r1 + qv) + F32_EPS;                   // :392, :423
@@ -581,8 +597,8 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
                     h0 = d2.x <= c2.x;
                     h1 = d2.y <= c2.y;
                 } else {
-                    h0 = d2.x <= P.cutoff2;
-                    h1 = d2.y <= P.cutoff2;
+                    h0 = d2.x <= cutoff2;
+                    h1 = d2.y <= cutoff2;
                 }
                 const uint32_t j0 = c0 * 64u + lane, j1 = j0 + 64u;
                 if (rag0) h0 = h0 && (j0 < T.n2);                          // only the last chunk is ragged
@@ -698,13 +714,17 @@ __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, const uin
 }
 
 template <int KIND, bool FILL>
-__global__ void __launch_bounds__(BLOCK) pair_kernel(SearchParams P, const uint32_t *__restrict__ task_first,
+__global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restrict__ Pp,
+                                                     const uint32_t *__restrict__ task_first,
                                                      const uint32_t *__restrict__ slot_task,
                                                      uint32_t *__restrict__ slot_cnt,
                                                      const unsigned long long *__restrict__ slot_base,
                                                      uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
                                                      uint32_t *__restrict__ out_ids) {
     __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
+    // The parameter block lives in device memory: a by-value struct this large, indexed dynamically
+    // (box.shifts[k]), gets copied to scratch by the compiler and drags every field into VGPRs.
+    const SearchParams &P = *Pp;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nslots = task_first[P.ntasks];
@@ -873,6 +893,9 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids) {
     Prof prof(c, FILL ? 3 : 1);
     const SearchParams P = make_params(c);
     if (P.nblocks == 0) return 0;
+    MH_TRY(c->params.reserve(sizeof(SearchParams)));
+    MH_HIP(hipMemcpyAsync(c->params.p, &P, sizeof(SearchParams), hipMemcpyHostToDevice, c->stream));
+    const SearchParams *dP = c->params.as<SearchParams>();
     const uint32_t *tf = c->task_nb.as<uint32_t>();
     const uint32_t *st = c->slot_task.as<uint32_t>();
     uint32_t *sc = c->slot_cnt.as<uint32_t>();
@@ -880,16 +903,16 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids) {
     const dim3 g(P.nblocks), b(BLOCK);
     switch (c->kind) {
         case MOLAR_HIP_SEARCH_SINGLE:
-            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_SINGLE, FILL>), g, b, 0, c->stream, P, tf, st, sc, sb, pairs, dist, ids);
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_SINGLE, FILL>), g, b, 0, c->stream, dP, tf, st, sc, sb, pairs, dist, ids);
             break;
         case MOLAR_HIP_SEARCH_DOUBLE:
-            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_DOUBLE, FILL>), g, b, 0, c->stream, P, tf, st, sc, sb, pairs, dist, ids);
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_DOUBLE, FILL>), g, b, 0, c->stream, dP, tf, st, sc, sb, pairs, dist, ids);
             break;
         case MOLAR_HIP_SEARCH_WITHIN:
-            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_WITHIN, FILL>), g, b, 0, c->stream, P, tf, st, sc, sb, pairs, dist, ids);
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_WITHIN, FILL>), g, b, 0, c->stream, dP, tf, st, sc, sb, pairs, dist, ids);
             break;
         default:
-            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_DOUBLE_VDW, FILL>), g, b, 0, c->stream, P, tf, st, sc, sb, pairs, dist, ids);
+            hipLaunchKernelGGL((pair_kernel<MOLAR_HIP_SEARCH_DOUBLE_VDW, FILL>), g, b, 0, c->stream, dP, tf, st, sc, sb, pairs, dist, ids);
             break;
     }
     MH_HIP(hipGetLastError());
