@@ -164,13 +164,10 @@ def main():
     prof = eng.profile_read()
     eng.profile_enable(False)
 
-    tot = torch.tensor([float(pairs), rsum, elapsed], device=device, dtype=torch.float64)
-    tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)        # end-of-run reduction of counts / RMSD sum (RCCL)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_pairs = float(tot[0])
-    t = float(tmax[0])
+    # end-of-run reductions (RCCL when world > 1): integer pair count, max-over-ranks wall time
+    from molar_amd.distributed import max_over_ranks, reduce_counts
+    total_pairs = float(reduce_counts([pairs], device=device)[0])
+    t = max_over_ranks(elapsed, device=device)
 
     if rank == 0:
         frames_total = K * world

@@ -1,0 +1,73 @@
+"""Frame sharding and end-of-run reductions for multi-GPU runs (one process per GPU).
+
+Frames of a trajectory are independent (analysis_task.rs:202-267 keeps no cross-frame state
+apart from the task's own accumulators), so ranks own contiguous blocks of frames and never
+exchange data on the hot path.  The only collectives run once, at the end: an integer
+all_reduce of histogram bins / pair counts and a gather of the per-frame scalar series.
+`torch.distributed` is the transport: backend "nccl" is RCCL over xGMI on the GPU box, "gloo"
+in the CPU tests.  Payloads are tens of bytes to ~10 KB: latency-bound, bucket sizes irrelevant.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_frames(nframes: int, rank: int, world: int) -> range:
+    """Contiguous block of frame indices owned by `rank` (blocks differ by at most one frame)."""
+    base, rem = divmod(nframes, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def reduce_counts(local, device=None):
+    """Element-wise SUM of an integer array over ranks (histogram bins, pair counts).  Integer
+    arithmetic, so the result is bit-identical to a single-rank run over all frames."""
+    import torch
+    dist = _dist()
+    t = torch.as_tensor(np.asarray(local, dtype=np.int64))
+    if device is not None:
+        t = t.to(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def gather_series(local, nframes: int, device=None):
+    """Concatenate per-frame float series from all ranks in frame order (ranks own the blocks of
+    shard_frames).  Returns the full series on every rank."""
+    import torch
+    dist = _dist()
+    local = np.asarray(local, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    width = int(np.prod(local.shape[1:])) if local.ndim > 1 else 1
+    maxlen = (nframes + world - 1) // world
+    buf = torch.zeros((maxlen, width), dtype=torch.float64)
+    buf[: len(local)] = torch.as_tensor(local.reshape(len(local), width))
+    if device is not None:
+        buf = buf.to(device)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out = []
+    for r, p in enumerate(parts):
+        k = len(shard_frames(nframes, r, world))
+        out.append(p[:k].cpu().numpy())
+    full = np.concatenate(out, 0)
+    return full.reshape((nframes,) + local.shape[1:]) if local.ndim > 1 else full.reshape(nframes)
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    import torch
+    dist = _dist()
+    t = torch.tensor([value], dtype=torch.float64)
+    if device is not None:
+        t = t.to(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
