@@ -101,6 +101,7 @@ struct GridSet {
     DevBuf tmp_cell;           // u32 per kept atom
     DevBuf sorted;             // float4 {x,y,z,id-bits} in reference cell order
     DevBuf sorted_vdw;         // float per sorted atom (vdw searches)
+    DevBuf aabb;               // float4 lo/hi per cell
 };
 
 }  // namespace mh

@@ -164,6 +164,32 @@ __global__ void __launch_bounds__(256) place_kernel(BinParams P, uint32_t ncells
     if (vdw) sorted_vdw[s + rank] = vdw[k];
 }
 
+// Axis-aligned bounding box of the positions stored in each cell (lab frame): aabb[2c] = lo,
+// aabb[2c+1] = hi.  One wave per cell.  Lets a row of the pair kernels prove "no atom of the other
+// cell can be within the cutoff" and skip its candidates (see run_plain).
+__global__ void __launch_bounds__(256) cell_aabb_kernel(uint32_t ncells, const uint32_t *__restrict__ cell_start,
+                                                        const float4 *__restrict__ sorted, float4 *__restrict__ aabb) {
+    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (c >= ncells) return;
+    const uint32_t s = cell_start[c], e = cell_start[c + 1];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t q = s + lane; q < e; q += 64u) {
+        const float4 p = sorted[q];
+        lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+        lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+        lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+    }
+    for (int d = 0; d < 3; ++d)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+    if (lane == 0) {
+        aabb[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        aabb[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+}
+
 // ================================================================= scans (exclusive, n elements)
 
 constexpr int SCAN_ITEMS = 8;
@@ -320,6 +346,7 @@ struct SearchParams {
     const uint32_t *csb;     // cell_start of set 2
     const float *vdwa;
     const float *vdwb;
+    const float4 *aabb_b;    // per-cell bounding boxes of set 2 (== set 1 for SINGLE)
     uint32_t dx, dy, dz;
     uint32_t pbc;            // PbcDims of the plan (0 for the non-periodic drivers)
     uint32_t use_box;
@@ -332,6 +359,7 @@ struct SearchParams {
 
 struct Task {
     uint32_t a0, n1, b0, n2;
+    uint32_t cb;              // second cell (for its bounding box)
     uint32_t wrap;
     bool tri;
     bool valid;
@@ -341,12 +369,13 @@ struct Task {
 // enumeration (x outer, z inner, 14 masks; for two-grid searches each entry is two tasks:
 // (c1,c2) then (c2,c1), :686-693).  Entries the reference filters out because a cell is empty
 // produce zero results here, so no compaction of the plan is needed.
-template <int KIND>
+template <int KIND, bool UNIFORM>
 __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     Task T;
     T.valid = false;
     T.tri = false;
     T.a0 = T.b0 = T.n1 = T.n2 = 0;
+    T.cb = 0;
     T.wrap = 0;
     uint32_t half = 0;
     uint64_t e = t;
@@ -388,6 +417,15 @@ __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     T.b0 = P.csb[cb];
     T.n2 = P.csb[cb + 1] - T.b0;
     T.wrap = wrap;
+    T.cb = cb;
+    if (UNIFORM) {
+        T.cb = __builtin_amdgcn_readfirstlane(T.cb);   // one task per wave: keep the descriptor in SGPRs
+        T.a0 = __builtin_amdgcn_readfirstlane(T.a0);
+        T.n1 = __builtin_amdgcn_readfirstlane(T.n1);
+        T.b0 = __builtin_amdgcn_readfirstlane(T.b0);
+        T.n2 = __builtin_amdgcn_readfirstlane(T.n2);
+        T.wrap = __builtin_amdgcn_readfirstlane(T.wrap);
+    }
     T.valid = T.n1 > 0 && T.n2 > 0 && !(T.tri && T.n1 < 2);
     return T;
 }
@@ -667,11 +705,118 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
     return total;
 }
 
+// Fast path for the bulk of the work: plain (unwrapped) Euclidean cell pairs with a fixed cutoff,
+// non-triangular, second cell resident in registers (NCH <= 8 chunks).
+//  * the slot's 64 first-cell atoms are staged in LDS and each row is fetched with ONE broadcast
+//    ds_read_b128, so the arithmetic runs on VGPR operands only (an SGPR source halves the issue
+//    rate of f32 VALU ops on gfx950: 4.4 vs 2.4-2.7 cycles, profiles/microbench/valu_rate.hip)
+//    and no v_readlane sits in the row loop;
+//  * the count pass never leaves the VALU: hits are added per lane through the carry of the
+//    compare and reduced across the wave once per slot (a v_cmp -> s_bcnt1 -> s_add chain costs
+//    ~14 cycles per chunk because of the VALU->SALU hazard);
+//  * lanes past the end of the second cell hold a coordinate so large that d2 overflows to +inf
+//    and the compare fails by itself - no separate validity mask.
+template <int KIND, bool FILL, int NCH>
+__device__ __forceinline__ uint32_t run_plain(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
+                                              uint32_t lane) {
+    float bx[NCH], by[NCH], bz[NCH];
+    uint32_t bid[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const uint32_t jj = (uint32_t)k * 64u + lane;
+        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+        if (jj < T.n2) q = P.sb[T.b0 + jj];
+        bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bid[k] = __float_as_uint(q.w);
+    }
+    const float cutoff2 = P.cutoff2;
+    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < 64u ? T.n1 - i0 : 64u);
+    unsigned long long live;   // rows of this slot that can have a hit at all
+    {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < rows) a = P.sa[T.a0 + i0 + lane];
+        la[lane] = a;
+        // Row pruning.  Every B position lies inside the cell's bounding box [lo,hi], and each f32
+        // operation of d2 = ((dx*dx)+(dy*dy))+(dz*dz) is monotone in |dx|,|dy|,|dz|, so the same
+        // expression evaluated on the box distances (ex,ey,ez) is a lower bound of every d2 of the
+        // row IN f32 ARITHMETIC: if it already exceeds cutoff2 the reference finds no hit in this
+        // row either, and skipping the row changes nothing in the output.
+        const float4 lo = P.aabb_b[2 * T.cb], hi = P.aabb_b[2 * T.cb + 1];
+        const float ex = fmaxf(fmaxf(lo.x - a.x, a.x - hi.x), 0.f);
+        const float ey = fmaxf(fmaxf(lo.y - a.y, a.y - hi.y), 0.f);
+        const float ez = fmaxf(fmaxf(lo.z - a.z, a.z - hi.z), 0.f);
+        const float e2 = (ex * ex + ey * ey) + ez * ez;
+        live = __builtin_amdgcn_ballot_w64(lane < rows && !(e2 > cutoff2));
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t acc = 0;      // per-lane hit counter (count pass)
+    uint32_t total = 0;
+    while (live) {
+        const uint32_t r = (uint32_t)__builtin_ctzll(live);
+        live &= live - 1ull;
+        const float4 p = la[r];                      // one broadcast ds_read per row
+        const uint32_t id_i = __float_as_uint(p.w);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;          // |p2-p1|^2 (:446, :460)
+            if (!FILL) {
+                // acc += (d2 <= cutoff2): the compare's carry is added per lane, no SALU involved
+                asm volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"
+                             : "+v"(acc)
+                             : "v"(d2), "s"(cutoff2)
+                             : "vcc");
+            } else {
+                const bool hit = d2 <= cutoff2;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (mask) {
+                    const uint32_t cnt = (uint32_t)__popcll(mask);
+                    if (hit) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        const uint32_t s = (F.tail + rank) & (FIFO_CAP - 1);
+                        F.fi[s] = id_i;
+                        F.fj[s] = bid[k];
+                        F.fd[s] = __float_as_uint(d2);
+                    }
+                    F.tail += cnt;
+                    total += cnt;
+                    if (F.tail - F.head >= 64u) {
+                        __builtin_amdgcn_wave_barrier();
+                        fifo_flush<KIND>(F, 64u, lane);
+                    }
+                }
+            }
+        }
+    }
+    if (!FILL) {
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        total = acc;
+    } else if (F.tail != F.head) {
+        __builtin_amdgcn_wave_barrier();
+        fifo_flush<KIND>(F, F.tail - F.head, lane);
+    }
+    return total;
+}
+
 // chunk-count dispatch: for the single-set search the non-triangular tasks get a fully unrolled,
 // branch-free row body per chunk count; everything else checks the chunk count at run time
 template <int KIND, bool FILL, int WK>
-__device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, uint32_t lane) {
+__device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
+                                                 uint32_t lane) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
+    if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && WK == WK_NONE && !T.tri &&
+        nchunks <= (uint32_t)KREG) {
+        switch (nchunks) {
+            case 1: return run_plain<KIND, FILL, 1>(P, T, i0, F, la, lane);
+            case 2: return run_plain<KIND, FILL, 2>(P, T, i0, F, la, lane);
+            case 3: return run_plain<KIND, FILL, 3>(P, T, i0, F, la, lane);
+            case 4: return run_plain<KIND, FILL, 4>(P, T, i0, F, la, lane);
+            case 5: return run_plain<KIND, FILL, 5>(P, T, i0, F, la, lane);
+            case 6: return run_plain<KIND, FILL, 6>(P, T, i0, F, la, lane);
+            case 7: return run_plain<KIND, FILL, 7>(P, T, i0, F, la, lane);
+            default: return run_plain<KIND, FILL, 8>(P, T, i0, F, la, lane);
+        }
+    }
     if (nchunks > (uint32_t)KREG) {
         if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) return run_task<KIND, FILL, WK, true, 0, false>(P, T, i0, F, lane);
         return run_task<KIND, FILL, WK, false, 0, false>(P, T, i0, F, lane);
@@ -701,7 +846,7 @@ template <int KIND>
 __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__restrict__ task_nb) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= P.ntasks) return;
-    const Task T = decode_task<KIND>(P, t);
+    const Task T = decode_task<KIND, false>(P, t);
     task_nb[t] = T.valid ? (T.n1 + 63u) >> 6 : 0u;
 }
 
@@ -722,6 +867,7 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
                                                      uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
                                                      uint32_t *__restrict__ out_ids) {
     __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
+    __shared__ float4 lds_a[WAVES_PER_BLOCK][64];
     // The parameter block lives in device memory: a by-value struct this large, indexed dynamically
     // (box.shifts[k]), gets copied to scratch by the compiler and drags every field into VGPRs.
     const SearchParams &P = *Pp;
@@ -737,7 +883,7 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
     const uint32_t slot = nslots - 1u - w;
     const uint32_t t = slot_task[slot];
     const uint32_t i0 = (slot - task_first[t]) * 64u;
-    const Task T = decode_task<KIND>(P, t);
+    const Task T = decode_task<KIND, true>(P, t);
     Fifo F;
     F.fi = lds[wave][0];
     F.fj = lds[wave][1];
@@ -754,10 +900,10 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
     uint32_t total = 0;
     const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
     switch (wk) {
-        case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE>(P, T, i0, F, lane); break;
-        case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG>(P, T, i0, F, lane); break;
-        case WK_UPPER: total = run_task_nch<KIND, FILL, WK_UPPER>(P, T, i0, F, lane); break;
-        default: total = run_task_nch<KIND, FILL, WK_GENERAL>(P, T, i0, F, lane); break;
+        case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE>(P, T, i0, F, lds_a[wave], lane); break;
+        case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG>(P, T, i0, F, lds_a[wave], lane); break;
+        case WK_UPPER: total = run_task_nch<KIND, FILL, WK_UPPER>(P, T, i0, F, lds_a[wave], lane); break;
+        default: total = run_task_nch<KIND, FILL, WK_GENERAL>(P, T, i0, F, lds_a[wave], lane); break;
     }
     if (!FILL && lane == 0) slot_cnt[slot] = total;
 }
@@ -821,6 +967,7 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     MH_TRY(S.tmp_cell.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.sorted.reserve((size_t)(S.n ? S.n : 1) * sizeof(float4)));
     if (S.d_vdw) MH_TRY(S.sorted_vdw.reserve((size_t)(S.n ? S.n : 1) * 4));
+    MH_TRY(S.aabb.reserve((size_t)ncells * 2 * sizeof(float4)));
     MH_HIP(hipMemsetAsync(S.cell_count.p, 0, (size_t)(ncells + 1) * 4, c->stream));
     MH_HIP(hipMemsetAsync(S.cursor.p, 0, (size_t)ncells * 4, c->stream));
     if (S.n) {
@@ -835,6 +982,8 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.tmp_cell.as<uint32_t>(), S.d_vdw,
                            S.sorted.as<float4>(), S.d_vdw ? S.sorted_vdw.as<float>() : nullptr);
+        hipLaunchKernelGGL(cell_aabb_kernel, dim3((ncells + 3u) / 4u), dim3(256), 0, c->stream, ncells,
+                           S.cell_count.as<uint32_t>(), S.sorted.as<float4>(), S.aabb.as<float4>());
         MH_HIP(hipGetLastError());
     }
     return 0;
@@ -866,6 +1015,7 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.csb = two ? c->set[1].cell_count.as<uint32_t>() : P.csa;
     P.vdwa = c->set[0].sorted_vdw.as<float>();
     P.vdwb = c->set[1].sorted_vdw.as<float>();
+    P.aabb_b = two ? c->set[1].aabb.as<float4>() : c->set[0].aabb.as<float4>();
     P.dx = c->dims[0];
     P.dy = c->dims[1];
     P.dz = c->dims[2];
