@@ -17,6 +17,8 @@
 //            time as fully coalesced (u32,u32) + f32 stores
 //
 // All f32 arithmetic follows boxmath.hpp (reference operation order, no FMA contraction).
+#include <cstdlib>
+
 #include "boxmath.hpp"
 #include "common.hpp"
 
@@ -352,6 +354,9 @@ struct SearchParams {
     uint32_t use_box;
     uint32_t nblocks;        // launch grid
     uint32_t wrap_kind;      // WK_* of the box matrix (zero pattern of m and inv)
+    uint32_t prune_wrapped;  // wrapped entries may use the image-box row pruning (all periodic dims >= 3 cells)
+    float prune_limit2;      // (cutoff + margin)^2 for that pruning
+    uint32_t debug_skip;     // profiling aid (env MOLAR_HIP_DEBUG_SKIP): bit0 plain, bit1 wrapped, bit2 triangular slots do nothing
     float cutoff2;
     uint64_t ntasks;
     molar_hip_box box;
@@ -359,6 +364,8 @@ struct SearchParams {
 
 struct Task {
     uint32_t a0, n1, b0, n2;
+    uint32_t rps;             // rows of the first cell per slot: 64, or 8 for entries that run the
+                              // triclinic candidate loop (~50x the arithmetic per candidate)
     uint32_t cb;              // second cell (for its bounding box)
     uint32_t wrap;
     bool tri;
@@ -376,6 +383,7 @@ __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     T.tri = false;
     T.a0 = T.b0 = T.n1 = T.n2 = 0;
     T.cb = 0;
+    T.rps = 64u;
     T.wrap = 0;
     uint32_t half = 0;
     uint64_t e = t;
@@ -417,9 +425,12 @@ __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     T.b0 = P.csb[cb];
     T.n2 = P.csb[cb + 1] - T.b0;
     T.wrap = wrap;
+    // only the entries of the single home cell (dx-1,dy-1,dz-1) can wrap in all three dims: <= 28 tasks
+    T.rps = (P.use_box && wrap == MOLAR_HIP_PBC_FULL && P.box.nshift != 0 && T.n1 <= 4096u) ? 8u : 64u;
     T.cb = cb;
     if (UNIFORM) {
-        T.cb = __builtin_amdgcn_readfirstlane(T.cb);   // one task per wave: keep the descriptor in SGPRs
+        T.cb = __builtin_amdgcn_readfirstlane(T.cb);
+        T.rps = __builtin_amdgcn_readfirstlane(T.rps);   // one task per wave: keep the descriptor in SGPRs
         T.a0 = __builtin_amdgcn_readfirstlane(T.a0);
         T.n1 = __builtin_amdgcn_readfirstlane(T.n1);
         T.b0 = __builtin_amdgcn_readfirstlane(T.b0);
@@ -584,7 +595,7 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
             a = P.sa[T.a0 + i0 + lane];
             if (VDW) ra = P.vdwa[T.a0 + i0 + lane];
         }
-        const uint32_t rows = T.n1 - i0 < 64u ? T.n1 - i0 : 64u;
+        const uint32_t rows = T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps;
         for (uint32_t r = 0; r < rows; ++r) {
             const uint32_t i = i0 + r;
             const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.x), r));
@@ -705,20 +716,86 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
     return total;
 }
 
-// Fast path for the bulk of the work: plain (unwrapped) Euclidean cell pairs with a fixed cutoff,
-// non-triangular, second cell resident in registers (NCH <= 8 chunks).
+// Box matrices copied into VGPRs: an SGPR source operand halves the issue rate of f32 VALU ops on
+// gfx950 (4.4 vs 2.4-2.7 cycles per wave instruction, profiles/microbench/valu_rate.hip).
+struct BoxV {
+    float I[9], M[9];
+};
+
+__device__ __forceinline__ float to_vgpr(float s) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+
+// PeriodicBox::distance_squared for ONE candidate (periodic_box.rs:286-318, 379-381), plain f32 ops.
+// The grid stores every atom inside the primary cell along periodic dimensions (populate_pbc wraps
+// them, distance_search.rs:183-196), so |f[d]| < 1.5 for a wrapped dimension and f32::round reduces
+// to "copysign(1, f) if |f| >= 0.5 else 0" - the same value, three instructions instead of six.
+template <int WK>
+__device__ __forceinline__ float wrapped_d2(const SearchParams &P, const BoxV &B, uint32_t wrap, int nshift, float vx,
+                                            float vy, float vz) {
+    float fx, fy, fz;
+    if (WK == WK_DIAG) {
+        fx = B.I[0] * vx; fy = B.I[4] * vy; fz = B.I[8] * vz;
+    } else if (WK == WK_UPPER) {
+        fx = (B.I[0] * vx + B.I[3] * vy) + B.I[6] * vz;
+        fy = B.I[4] * vy + B.I[7] * vz;
+        fz = B.I[8] * vz;
+    } else {
+        fx = (B.I[0] * vx + B.I[3] * vy) + B.I[6] * vz;
+        fy = (B.I[1] * vx + B.I[4] * vy) + B.I[7] * vz;
+        fz = (B.I[2] * vx + B.I[5] * vy) + B.I[8] * vz;
+    }
+    if (wrap & 1u) fx -= (fabsf(fx) >= 0.5f ? copysignf(1.0f, fx) : 0.0f);
+    if (wrap & 2u) fy -= (fabsf(fy) >= 0.5f ? copysignf(1.0f, fy) : 0.0f);
+    if (wrap & 4u) fz -= (fabsf(fz) >= 0.5f ? copysignf(1.0f, fz) : 0.0f);
+    float sx, sy, sz;
+    if (WK == WK_DIAG) {
+        sx = B.M[0] * fx; sy = B.M[4] * fy; sz = B.M[8] * fz;
+    } else if (WK == WK_UPPER) {
+        sx = (B.M[0] * fx + B.M[3] * fy) + B.M[6] * fz;
+        sy = B.M[4] * fy + B.M[7] * fz;
+        sz = B.M[8] * fz;
+    } else {
+        sx = (B.M[0] * fx + B.M[3] * fy) + B.M[6] * fz;
+        sy = (B.M[1] * fx + B.M[4] * fy) + B.M[7] * fz;
+        sz = (B.M[2] * fx + B.M[5] * fy) + B.M[8] * fz;
+    }
+    float best2 = (sx * sx + sy * sy) + sz * sz;
+    if (WK != WK_DIAG && nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {   // triclinic candidates (:304-317)
+        for (int k = 0; k < nshift; ++k) {
+            const float cx = sx + P.box.shifts[3 * k], cy = sy + P.box.shifts[3 * k + 1], cz = sz + P.box.shifts[3 * k + 2];
+            const float n2 = (cx * cx + cy * cy) + cz * cz;
+            best2 = n2 < best2 ? n2 : best2;
+        }
+    }
+    return best2;
+}
+
+// squared distance from a point to an axis-aligned box, same f32 expression as a pair distance
+__device__ __forceinline__ float aabb_d2(float ax, float ay, float az, float lx, float ly, float lz, float hx, float hy,
+                                         float hz) {
+    const float ex = fmaxf(fmaxf(lx - ax, ax - hx), 0.f);
+    const float ey = fmaxf(fmaxf(ly - ay, ay - hy), 0.f);
+    const float ez = fmaxf(fmaxf(lz - az, az - hz), 0.f);
+    return (ex * ex + ey * ey) + ez * ez;
+}
+
+// Fast path for the bulk of the work: fixed-cutoff, non-triangular cell pairs whose second cell
+// fits in registers (NCH <= 8 chunks of 64), plain (WK_NONE) or wrapped (WK_DIAG/UPPER/GENERAL).
 //  * the slot's 64 first-cell atoms are staged in LDS and each row is fetched with ONE broadcast
-//    ds_read_b128, so the arithmetic runs on VGPR operands only (an SGPR source halves the issue
-//    rate of f32 VALU ops on gfx950: 4.4 vs 2.4-2.7 cycles, profiles/microbench/valu_rate.hip)
-//    and no v_readlane sits in the row loop;
+//    ds_read_b128, so the arithmetic runs on VGPR operands only and no v_readlane sits in the row
+//    loop;
 //  * the count pass never leaves the VALU: hits are added per lane through the carry of the
 //    compare and reduced across the wave once per slot (a v_cmp -> s_bcnt1 -> s_add chain costs
 //    ~14 cycles per chunk because of the VALU->SALU hazard);
 //  * lanes past the end of the second cell hold a coordinate so large that d2 overflows to +inf
-//    and the compare fails by itself - no separate validity mask.
-template <int KIND, bool FILL, int NCH>
-__device__ __forceinline__ uint32_t run_plain(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
-                                              uint32_t lane) {
+//    (or NaN) and the compare fails by itself - no separate validity mask;
+//  * rows that provably cannot have a hit are skipped (see `live` below).
+template <int KIND, bool FILL, int WK, int NCH, bool TRI>
+__device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
+                                             uint32_t lane) {
     float bx[NCH], by[NCH], bz[NCH];
     uint32_t bid[NCH];
 #pragma unroll
@@ -728,24 +805,60 @@ __device__ __forceinline__ uint32_t run_plain(const SearchParams &P, const Task 
         if (jj < T.n2) q = P.sb[T.b0 + jj];
         bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bid[k] = __float_as_uint(q.w);
     }
+    BoxV B;
+    int nshift = 0;
+    if (WK != WK_NONE) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            B.I[k] = to_vgpr(P.box.inv[k]);
+            B.M[k] = to_vgpr(P.box.m[k]);
+        }
+        nshift = P.box.nshift;
+    }
     const float cutoff2 = P.cutoff2;
-    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < 64u ? T.n1 - i0 : 64u);
+    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
     unsigned long long live;   // rows of this slot that can have a hit at all
     {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane < rows) a = P.sa[T.a0 + i0 + lane];
         la[lane] = a;
-        // Row pruning.  Every B position lies inside the cell's bounding box [lo,hi], and each f32
-        // operation of d2 = ((dx*dx)+(dy*dy))+(dz*dz) is monotone in |dx|,|dy|,|dz|, so the same
-        // expression evaluated on the box distances (ex,ey,ez) is a lower bound of every d2 of the
-        // row IN f32 ARITHMETIC: if it already exceeds cutoff2 the reference finds no hit in this
-        // row either, and skipping the row changes nothing in the output.
         const float4 lo = P.aabb_b[2 * T.cb], hi = P.aabb_b[2 * T.cb + 1];
-        const float ex = fmaxf(fmaxf(lo.x - a.x, a.x - hi.x), 0.f);
-        const float ey = fmaxf(fmaxf(lo.y - a.y, a.y - hi.y), 0.f);
-        const float ez = fmaxf(fmaxf(lo.z - a.z, a.z - hi.z), 0.f);
-        const float e2 = (ex * ex + ey * ey) + ez * ez;
-        live = __builtin_amdgcn_ballot_w64(lane < rows && !(e2 > cutoff2));
+        bool need = true;
+        if (TRI) {
+            // same cell (i < j triangle, :439-451): the atom lies inside its own cell's box, nothing to prune
+        } else if (WK == WK_NONE) {
+            // Exact row pruning.  Every B position lies inside the cell's bounding box [lo,hi], and each
+            // f32 operation of d2 = ((dx*dx)+(dy*dy))+(dz*dz) is monotone in |dx|,|dy|,|dz|, so the same
+            // expression on the box distances is a lower bound of every d2 of the row IN f32 ARITHMETIC:
+            // if it already exceeds cutoff2 the reference finds no hit in this row either.
+            need = !(aabb_d2(a.x, a.y, a.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > cutoff2);
+        } else if (P.prune_wrapped && !(nshift != 0 && T.wrap == MOLAR_HIP_PBC_FULL)) {
+            // Conservative row pruning for wrapped entries.  In exact arithmetic the reference's vector
+            // is (b - a) - sum_d n_d*col_d with n_d = round(f_d) in {-1,0,1} for the wrapped dims (atoms
+            // are stored inside the primary cell).  The row is skipped only if for EVERY such image the
+            // box distance exceeds cutoff + margin; the margin (1e-3 nm, >100x the f32 evaluation error
+            // of inv*v / M*f at MD box sizes) absorbs the difference between the reference's f32
+            // arithmetic and this geometric bound.
+            const float lim = P.prune_limit2;
+            need = false;
+            for (int nx = -1; nx <= 1; ++nx) {
+                if (!(T.wrap & 1u) && nx != 0) continue;
+                for (int ny = -1; ny <= 1; ++ny) {
+                    if (!(T.wrap & 2u) && ny != 0) continue;
+                    for (int nz = -1; nz <= 1; ++nz) {
+                        if (!(T.wrap & 4u) && nz != 0) continue;
+                        const float fx = (float)nx, fy = (float)ny, fz = (float)nz;
+                        const float tx = (fx * P.box.m[0] + fy * P.box.m[3]) + fz * P.box.m[6];
+                        const float ty = (fx * P.box.m[1] + fy * P.box.m[4]) + fz * P.box.m[7];
+                        const float tz = (fx * P.box.m[2] + fy * P.box.m[5]) + fz * P.box.m[8];
+                        // (b - n*cols) - a  ==  b - (a + n*cols): shift the point instead of the box
+                        const float e2 = aabb_d2(a.x + tx, a.y + ty, a.z + tz, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+                        need = need || !(e2 > lim);
+                    }
+                }
+            }
+        }
+        live = __builtin_amdgcn_ballot_w64(lane < rows && need);
     }
     __builtin_amdgcn_wave_barrier();
     uint32_t acc = 0;      // per-lane hit counter (count pass)
@@ -755,10 +868,16 @@ __device__ __forceinline__ uint32_t run_plain(const SearchParams &P, const Task 
         live &= live - 1ull;
         const float4 p = la[r];                      // one broadcast ds_read per row
         const uint32_t id_i = __float_as_uint(p.w);
+        const uint32_t i = i0 + r;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;          // |p2-p1|^2 (:446, :460)
+            if (TRI && (uint32_t)k * 64u + 63u <= i) continue;                   // whole chunk has j <= i
+            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1
+            float d2;
+            if (WK == WK_NONE) d2 = (dx * dx + dy * dy) + dz * dz;               // |p2-p1|^2 (:446, :460)
+            else d2 = wrapped_d2<WK>(P, B, T.wrap, nshift, dx, dy, dz);          // (:485-486)
+            if (TRI && (uint32_t)k * 64u <= i)                                   // diagonal chunk: j in i+1..n (:443)
+                d2 = ((uint32_t)k * 64u + lane > i) ? d2 : INFINITY;
             if (!FILL) {
                 // acc += (d2 <= cutoff2): the compare's carry is added per lane, no SALU involved
                 asm volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"
@@ -804,36 +923,35 @@ template <int KIND, bool FILL, int WK>
 __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                                  uint32_t lane) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
-    if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && WK == WK_NONE && !T.tri &&
-        nchunks <= (uint32_t)KREG) {
+    if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && !T.tri && nchunks <= (uint32_t)KREG) {
         switch (nchunks) {
-            case 1: return run_plain<KIND, FILL, 1>(P, T, i0, F, la, lane);
-            case 2: return run_plain<KIND, FILL, 2>(P, T, i0, F, la, lane);
-            case 3: return run_plain<KIND, FILL, 3>(P, T, i0, F, la, lane);
-            case 4: return run_plain<KIND, FILL, 4>(P, T, i0, F, la, lane);
-            case 5: return run_plain<KIND, FILL, 5>(P, T, i0, F, la, lane);
-            case 6: return run_plain<KIND, FILL, 6>(P, T, i0, F, la, lane);
-            case 7: return run_plain<KIND, FILL, 7>(P, T, i0, F, la, lane);
-            default: return run_plain<KIND, FILL, 8>(P, T, i0, F, la, lane);
+            case 1: return run_fast<KIND, FILL, WK, 1, false>(P, T, i0, F, la, lane);
+            case 2: return run_fast<KIND, FILL, WK, 2, false>(P, T, i0, F, la, lane);
+            case 3: return run_fast<KIND, FILL, WK, 3, false>(P, T, i0, F, la, lane);
+            case 4: return run_fast<KIND, FILL, WK, 4, false>(P, T, i0, F, la, lane);
+            case 5: return run_fast<KIND, FILL, WK, 5, false>(P, T, i0, F, la, lane);
+            case 6: return run_fast<KIND, FILL, WK, 6, false>(P, T, i0, F, la, lane);
+            case 7: return run_fast<KIND, FILL, WK, 7, false>(P, T, i0, F, la, lane);
+            default: return run_fast<KIND, FILL, WK, 8, false>(P, T, i0, F, la, lane);
+        }
+    }
+    if (KIND == MOLAR_HIP_SEARCH_SINGLE && WK == WK_NONE && T.tri && nchunks <= (uint32_t)KREG) {
+        switch (nchunks) {
+            case 1: return run_fast<KIND, FILL, WK_NONE, 1, true>(P, T, i0, F, la, lane);
+            case 2: return run_fast<KIND, FILL, WK_NONE, 2, true>(P, T, i0, F, la, lane);
+            case 3: return run_fast<KIND, FILL, WK_NONE, 3, true>(P, T, i0, F, la, lane);
+            case 4: return run_fast<KIND, FILL, WK_NONE, 4, true>(P, T, i0, F, la, lane);
+            case 5: return run_fast<KIND, FILL, WK_NONE, 5, true>(P, T, i0, F, la, lane);
+            case 6: return run_fast<KIND, FILL, WK_NONE, 6, true>(P, T, i0, F, la, lane);
+            case 7: return run_fast<KIND, FILL, WK_NONE, 7, true>(P, T, i0, F, la, lane);
+            default: return run_fast<KIND, FILL, WK_NONE, 8, true>(P, T, i0, F, la, lane);
         }
     }
     if (nchunks > (uint32_t)KREG) {
         if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) return run_task<KIND, FILL, WK, true, 0, false>(P, T, i0, F, lane);
         return run_task<KIND, FILL, WK, false, 0, false>(P, T, i0, F, lane);
     }
-    if (KIND == MOLAR_HIP_SEARCH_SINGLE) {
-        if (T.tri) return run_task<KIND, FILL, WK, true, KREG, true>(P, T, i0, F, lane);
-        switch (nchunks) {
-            case 1: return run_task<KIND, FILL, WK, false, 1, false>(P, T, i0, F, lane);
-            case 2: return run_task<KIND, FILL, WK, false, 2, false>(P, T, i0, F, lane);
-            case 3: return run_task<KIND, FILL, WK, false, 3, false>(P, T, i0, F, lane);
-            case 4: return run_task<KIND, FILL, WK, false, 4, false>(P, T, i0, F, lane);
-            case 5: return run_task<KIND, FILL, WK, false, 5, false>(P, T, i0, F, lane);
-            case 6: return run_task<KIND, FILL, WK, false, 6, false>(P, T, i0, F, lane);
-            case 7: return run_task<KIND, FILL, WK, false, 7, false>(P, T, i0, F, lane);
-            default: return run_task<KIND, FILL, WK, false, 8, false>(P, T, i0, F, lane);
-        }
-    }
+    if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) return run_task<KIND, FILL, WK, true, KREG, true>(P, T, i0, F, lane);
     return run_task<KIND, FILL, WK, false, KREG, true>(P, T, i0, F, lane);
 }
 
@@ -847,7 +965,7 @@ __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__r
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= P.ntasks) return;
     const Task T = decode_task<KIND, false>(P, t);
-    task_nb[t] = T.valid ? (T.n1 + 63u) >> 6 : 0u;
+    task_nb[t] = T.valid ? (T.n1 + T.rps - 1u) / T.rps : 0u;
 }
 
 __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, const uint32_t *__restrict__ task_first,
@@ -882,8 +1000,8 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
     // over the whole chip.
     const uint32_t slot = nslots - 1u - w;
     const uint32_t t = slot_task[slot];
-    const uint32_t i0 = (slot - task_first[t]) * 64u;
     const Task T = decode_task<KIND, true>(P, t);
+    const uint32_t i0 = (slot - task_first[t]) * T.rps;
     Fifo F;
     F.fi = lds[wave][0];
     F.fj = lds[wave][1];
@@ -899,6 +1017,10 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
     }
     uint32_t total = 0;
     const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
+    if (P.debug_skip) {
+        const uint32_t kind_bit = T.tri ? 4u : (wk != WK_NONE ? 2u : 1u);
+        if (P.debug_skip & kind_bit) return;
+    }
     switch (wk) {
         case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE>(P, T, i0, F, lds_a[wave], lane); break;
         case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG>(P, T, i0, F, lds_a[wave], lane); break;
@@ -1035,6 +1157,19 @@ SearchParams make_params(molar_hip_ctx *c) {
         if (lower_zero && upper_zero) P.wrap_kind = 1u;          // WK_DIAG
         else if (lower_zero) P.wrap_kind = 2u;                   // WK_UPPER (GROMACS-style boxes)
     }
+    // image-box pruning of wrapped entries argues with n_d = round(f_d) in {-1,0,1}; keep the exhaustive
+    // path on degenerate grids (a periodic dimension with fewer than 3 cells): they are tiny anyway
+    P.prune_wrapped = 0u;
+    if (c->use_box) {
+        bool ok = true;
+        for (int d = 0; d < 3; ++d)
+            if (((c->pbc >> d) & 1u) && c->dims[d] < 3u) ok = false;
+        P.prune_wrapped = ok ? 1u : 0u;
+    }
+    const float lim = c->cutoff + 1.0e-3f;
+    P.prune_limit2 = lim * lim;
+    const char *dbg = std::getenv("MOLAR_HIP_DEBUG_SKIP");
+    P.debug_skip = dbg ? (uint32_t)std::atoi(dbg) : 0u;
     return P;
 }
 
@@ -1173,6 +1308,8 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q) {
     // every set-1 cell is the first cell of at most 14 (two grids: 28) tasks, so
     // sum_t ceil(n1(t)/64) <= mult*N1/64 + ntasks
     c->nslots_bound = (two ? 28ull : 14ull) * (((uint64_t)c->set[0].n + 63ull) / 64ull) + c->ntasks;
+    // entries wrapping in all three dims of a triclinic box use 8-row slots: <= 28 tasks of <= 4096 rows
+    c->nslots_bound += 28ull * 512ull;
     if (c->ntasks >= 0xFFFFFFF0ull || c->nslots_bound >= 0xFFFFFFF0ull)
         return fail(MOLAR_HIP_ERR_TOO_LARGE, "search plan too large (%llu entries)", (unsigned long long)c->ntasks);
     MH_TRY(c->task_nb.reserve((c->ntasks + 1) * 4));
