@@ -122,25 +122,26 @@ __device__ __forceinline__ V3 load_pos(const float *xyz, uint64_t a) {
 }
 
 __global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restrict__ key,
-                                                  uint32_t *__restrict__ cell_count) {
+                                                  uint32_t *__restrict__ arrival, uint32_t *__restrict__ cell_count) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= P.n) return;
     const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
     const CellOfAtom c = classify(P, load_pos(P.xyz, a));
     key[k] = c.key;
-    if (c.key != DROPPED) atomicAdd(&cell_count[c.key >> 1], 1u);
+    // arrival order inside the cell (arbitrary): lets scatter place the atom without a second atomic
+    if (c.key != DROPPED) arrival[k] = atomicAdd(&cell_count[c.key >> 1], 1u);
 }
 
 __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t *__restrict__ key,
                                                       const uint32_t *__restrict__ cell_start,
-                                                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ tmp_key,
-                                                      uint32_t *__restrict__ tmp_cell) {
+                                                      const uint32_t *__restrict__ arrival,
+                                                      uint32_t *__restrict__ tmp_key, uint32_t *__restrict__ tmp_cell) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= n) return;
     const uint32_t ky = key[k];
     if (ky == DROPPED) return;
     const uint32_t cell = ky >> 1;
-    const uint32_t pos = cell_start[cell] + atomicAdd(&cursor[cell], 1u);
+    const uint32_t pos = cell_start[cell] + arrival[k];
     tmp_key[pos] = ((ky & 1u) << 31) | k;     // sort key inside the cell: in-box first, then input order
     tmp_cell[pos] = cell;
 }
@@ -157,7 +158,8 @@ __global__ void __launch_bounds__(256) place_kernel(BinParams P, uint32_t ncells
     const uint32_t cell = tmp_cell[t];
     const uint32_t s = cell_start[cell], e = cell_start[cell + 1];
     uint32_t rank = 0;
-    for (uint32_t q = s; q < e; ++q) rank += tmp_key[q] < mine ? 1u : 0u;
+#pragma unroll 8
+    for (uint32_t q = s; q < e; ++q) rank += tmp_key[q] < mine ? 1u : 0u;   // 8 loads in flight per thread
     const uint32_t k = mine & 0x7FFFFFFFu;
     const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
     const CellOfAtom c = classify(P, load_pos(P.xyz, a));   // same arithmetic as bin_kernel
@@ -262,9 +264,39 @@ __global__ void __launch_bounds__(256) scan_add_kernel(T *out, const T *sums, ui
         if (base + q < n) out[base + q] += add;
 }
 
+// small n: one workgroup walks the array in 1024-element steps (a single launch instead of three)
+template <class TIn, class TOut>
+__global__ void __launch_bounds__(256) scan_small_kernel(const TIn *in, TOut *out, uint32_t n) {
+    __shared__ TOut carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < n; start += 1024u) {
+        const uint32_t base = start + threadIdx.x * 4u;
+        TOut item[4], sum = 0;
+        for (int q = 0; q < 4; ++q) {
+            item[q] = base + q < n ? (TOut)in[base + q] : (TOut)0;
+            sum += item[q];
+        }
+        TOut tot;
+        TOut run = carry_s + block_exclusive_scan<TOut>(sum, &tot);
+        for (int q = 0; q < 4; ++q) {
+            if (base + q < n) out[base + q] = run;
+            run += item[q];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tot;
+        __syncthreads();
+    }
+}
+
 template <class TIn, class TOut>
 int exclusive_scan(molar_hip_ctx *c, const TIn *in, TOut *out, uint64_t n) {
     if (n == 0) return 0;
+    if (n <= 8192ull) {
+        hipLaunchKernelGGL((scan_small_kernel<TIn, TOut>), dim3(1), dim3(256), 0, c->stream, in, out, (uint32_t)n);
+        MH_HIP(hipGetLastError());
+        return 0;
+    }
     const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     MH_TRY(c->scan_tmp.reserve(nb * sizeof(TOut)));
     TOut *sums = c->scan_tmp.as<TOut>();
@@ -1084,18 +1116,17 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     P.box = c->box;
     MH_TRY(S.key.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.cell_count.reserve((size_t)(ncells + 1) * 4));
-    MH_TRY(S.cursor.reserve((size_t)ncells * 4));
+    MH_TRY(S.cursor.reserve((size_t)(S.n ? S.n : 1) * 4));   // arrival order of each atom in its cell
     MH_TRY(S.tmp_key.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.tmp_cell.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.sorted.reserve((size_t)(S.n ? S.n : 1) * sizeof(float4)));
     if (S.d_vdw) MH_TRY(S.sorted_vdw.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.aabb.reserve((size_t)ncells * 2 * sizeof(float4)));
     MH_HIP(hipMemsetAsync(S.cell_count.p, 0, (size_t)(ncells + 1) * 4, c->stream));
-    MH_HIP(hipMemsetAsync(S.cursor.p, 0, (size_t)ncells * 4, c->stream));
     if (S.n) {
         const unsigned nb = (S.n + 255u) / 256u;
         hipLaunchKernelGGL(bin_kernel, dim3(nb), dim3(256), 0, c->stream, P, S.key.as<uint32_t>(),
-                           S.cell_count.as<uint32_t>());
+                           S.cursor.as<uint32_t>(), S.cell_count.as<uint32_t>());
         MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, S.cell_count.as<uint32_t>(), S.cell_count.as<uint32_t>(),
                                                    (uint64_t)ncells + 1)));
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, c->stream, S.n, S.key.as<uint32_t>(),
