@@ -226,8 +226,37 @@ class Engine:
         check(self.lib.molar_hip_search_grid_dims(self.ctx, dims))
         return tuple(int(x) for x in dims)
 
-    def search_histogram(self, kind, cutoff, hmin, hmax, nbins, xyz1, bins=None, **kw):
-        raise NotImplementedError
+    def search_histogram(self, kind, cutoff, hmin, hmax, nbins, xyz1, idx1=None, xyz2=None, idx2=None, box=None,
+                         pbc=0, vdw1=None, vdw2=None, bins=None):
+        """Consumer-fused search: every emitted distance goes through Histogram1D::add_one
+        (molar_membrane/src/stats.rs:29-35); pairs are never materialised.  `bins` (uint64[nbins]) is
+        accumulated into, so frames can be summed.  Returns (bins, number_of_pairs)."""
+        xyz1 = _f32(xyz1); xyz2 = _f32(xyz2); idx1 = _u64(idx1); idx2 = _u64(idx2)
+        vdw1 = _f32(vdw1); vdw2 = _f32(vdw2)
+        d = SearchDesc()
+        d.kind = kind
+        d.cutoff = float(cutoff) if cutoff is not None else 0.0
+        keep = []
+        for name, arr in (("xyz1", xyz1), ("idx1", idx1), ("xyz2", xyz2), ("idx2", idx2), ("vdw1", vdw1),
+                          ("vdw2", vdw2)):
+            a, k = _addr(arr)
+            setattr(d, name, a)
+            keep.append(k)
+        d.natoms1 = 0 if xyz1 is None else xyz1.shape[0]
+        d.natoms2 = 0 if xyz2 is None else xyz2.shape[0]
+        d.n1 = 0 if idx1 is None else idx1.shape[0]
+        d.n2 = 0 if idx2 is None else idx2.shape[0]
+        if box is not None:
+            ba, kb = self._box9(box)
+            keep.append(kb)
+            d.box9 = ba
+        d.pbc = pbc_mask(pbc)
+        if bins is None:
+            bins = np.zeros(nbins, np.uint64)
+        cnt = C.c_uint64(0)
+        check(self.lib.molar_hip_search_histogram(self.ctx, C.byref(d), float(hmin), float(hmax), nbins,
+                                                  bins.ctypes.data, C.byref(cnt)))
+        return bins, int(cnt.value)
 
     # ------------------------------------------------------------ measure
     def _sel_args(self, xyz, idx):

@@ -1,0 +1,788 @@
+// pair_kernels.hpp - the cell-pair kernels of the distance search (device code) and their launcher.
+// Included by search.hip (parameter structs, plan kernels) and by one translation unit per search
+// kind (pair_k0..3.hip), so the heavy template instantiations compile in parallel.
+#pragma once
+
+#include "boxmath.hpp"
+#include "common.hpp"
+
+namespace mh {
+namespace pairk {
+
+enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2 };
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
+constexpr int KREG = 8;            // B-cell chunks (of 64 atoms) a lane keeps in registers
+constexpr int FIFO_CAP = 128;      // per-wave LDS FIFO entries (flush threshold 64, push <= 64)
+constexpr float F32_EPS = 1.1920929e-07f;
+
+// distance_search.rs:39-60
+static __constant__ uint8_t MASKS[14][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {0, 0, 0, 1, 0, 0}, {0, 0, 0, 0, 1, 0}, {0, 0, 0, 0, 0, 1},
+    {0, 0, 0, 1, 1, 0}, {0, 0, 0, 1, 0, 1}, {0, 0, 0, 0, 1, 1},
+    {0, 0, 0, 1, 1, 1},
+    {1, 0, 0, 0, 1, 0}, {1, 0, 0, 0, 0, 1}, {0, 1, 0, 0, 0, 1},
+    {1, 1, 0, 0, 0, 1}, {1, 0, 1, 0, 1, 0}, {0, 1, 1, 1, 0, 0},
+};
+
+// ================================================================= pair kernels
+
+struct SearchParams {
+    const float4 *sa;        // cell-sorted atoms of set 1
+    const float4 *sb;        // cell-sorted atoms of set 2 (== sa for SINGLE)
+    const uint32_t *csa;     // cell_start of set 1
+    const uint32_t *csb;     // cell_start of set 2
+    const float *vdwa;
+    const float *vdwb;
+    const float4 *aabb_b;    // per-cell bounding boxes of set 2 (== set 1 for SINGLE)
+    uint32_t dx, dy, dz;
+    uint32_t pbc;            // PbcDims of the plan (0 for the non-periodic drivers)
+    uint32_t use_box;
+    uint32_t nblocks;        // launch grid
+    uint32_t wrap_kind;      // WK_* of the box matrix (zero pattern of m and inv)
+    uint32_t prune_wrapped;  // wrapped entries may use the image-box row pruning (all periodic dims >= 3 cells)
+    float prune_limit2;      // (cutoff + margin)^2 for that pruning
+    uint32_t hist_nbins;     // != 0: the fill traversal feeds a histogram instead of writing pairs
+    float hist_min, hist_max;
+    unsigned long long *hist_bins;    // [nbins] + [1] total
+    uint32_t debug_skip;     // profiling aid (env MOLAR_HIP_DEBUG_SKIP): bit0 plain, bit1 wrapped, bit2 triangular slots do nothing
+    float cutoff2;
+    uint64_t ntasks;
+    molar_hip_box box;
+};
+
+struct Task {
+    uint32_t a0, n1, b0, n2;
+    uint32_t rps;             // rows of the first cell per slot: 64, or 8 for entries that run the
+                              // triclinic candidate loop (~50x the arithmetic per candidate)
+    uint32_t cb;              // second cell (for its bounding box)
+    uint32_t wrap;
+    bool tri;
+    bool valid;
+};
+
+// search_plan (distance_search.rs:217-269).  Task index == position in the reference's plan
+// enumeration (x outer, z inner, 14 masks; for two-grid searches each entry is two tasks:
+// (c1,c2) then (c2,c1), :686-693).  Entries the reference filters out because a cell is empty
+// produce zero results here, so no compaction of the plan is needed.
+template <int KIND, bool UNIFORM>
+__device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
+    Task T;
+    T.valid = false;
+    T.tri = false;
+    T.a0 = T.b0 = T.n1 = T.n2 = 0;
+    T.cb = 0;
+    T.rps = 64u;
+    T.wrap = 0;
+    uint32_t half = 0;
+    uint64_t e = t;
+    if (KIND != MOLAR_HIP_SEARCH_SINGLE) {
+        half = (uint32_t)(t & 1ull);
+        e = t >> 1;
+    }
+    const uint32_t m = (uint32_t)(e % 14ull);
+    const uint64_t cidx = e / 14ull;
+    const uint32_t z = (uint32_t)(cidx % P.dz);
+    const uint64_t r = cidx / P.dz;
+    const uint32_t y = (uint32_t)(r % P.dy);
+    const uint32_t x = (uint32_t)(r / P.dy);
+    const uint32_t dims[3] = {P.dx, P.dy, P.dz};
+    uint32_t c[2][3] = {{x + MASKS[m][0], y + MASKS[m][1], z + MASKS[m][2]},
+                        {x + MASKS[m][3], y + MASKS[m][4], z + MASKS[m][5]}};
+    uint32_t wrap = 0;
+    for (int i = 0; i < 2; ++i)
+        for (int d = 0; d < 3; ++d)
+            if (c[i][d] == dims[d]) {
+                if ((P.pbc >> d) & 1u) {
+                    c[i][d] = 0;
+                    wrap |= 1u << d;
+                } else {
+                    return T;   // non-periodic dimension: entry dropped (:241-244)
+                }
+            }
+    const uint32_t i1 = c[0][0] + c[0][1] * P.dx + c[0][2] * P.dx * P.dy;
+    const uint32_t i2 = c[1][0] + c[1][1] * P.dx + c[1][2] * P.dx * P.dy;
+    uint32_t ca = i1, cb = i2;
+    if (KIND == MOLAR_HIP_SEARCH_SINGLE) {
+        T.tri = (i1 == i2);
+    } else if (half) {
+        ca = i2;
+        cb = i1;
+    }
+    T.a0 = P.csa[ca];
+    T.n1 = P.csa[ca + 1] - T.a0;
+    T.b0 = P.csb[cb];
+    T.n2 = P.csb[cb + 1] - T.b0;
+    T.wrap = wrap;
+    // only the entries of the single home cell (dx-1,dy-1,dz-1) can wrap in all three dims: <= 28 tasks
+    T.rps = (P.use_box && wrap == MOLAR_HIP_PBC_FULL && P.box.nshift != 0 && T.n1 <= 4096u) ? 8u : 64u;
+    T.cb = cb;
+    if (UNIFORM) {
+        T.cb = __builtin_amdgcn_readfirstlane(T.cb);
+        T.rps = __builtin_amdgcn_readfirstlane(T.rps);   // one task per wave: keep the descriptor in SGPRs
+        T.a0 = __builtin_amdgcn_readfirstlane(T.a0);
+        T.n1 = __builtin_amdgcn_readfirstlane(T.n1);
+        T.b0 = __builtin_amdgcn_readfirstlane(T.b0);
+        T.n2 = __builtin_amdgcn_readfirstlane(T.n2);
+        T.wrap = __builtin_amdgcn_readfirstlane(T.wrap);
+    }
+    T.valid = T.n1 > 0 && T.n2 > 0 && !(T.tri && T.n1 < 2);
+    return T;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// How a wrapped cell pair evaluates PeriodicBox::distance_squared (periodic_box.rs:286-318,379-381).
+// The matrix kinds only skip products with entries that are exactly 0.0 in BOTH the box matrix
+// and its inverse: x + (0*y) == x in IEEE arithmetic (up to the sign of a zero result, which the
+// final sum of squares cannot see), so every kind yields the same d2 bits as the general form.
+enum { WK_NONE = 0, WK_DIAG = 1, WK_UPPER = 2, WK_GENERAL = 3 };
+
+__device__ __forceinline__ v2f round_away2(v2f f) { return v2f{__builtin_roundf(f.x), __builtin_roundf(f.y)}; }
+
+// squared distances from the broadcast atom p (SGPR operands) to TWO second-cell atoms per lane
+// (one of each 64-chunk of a chunk pair): packed f32 math, two candidates per VALU instruction.
+//   plain   : |p2-p1|^2 = ((dx*dx)+(dy*dy))+(dz*dz)                                   (:488)
+//   wrapped : f = inv*v; f[d] -= round(f[d]) for the entry's wrap dims; s = M*f;
+//             triclinic candidate loop only if shifts exist and all three dims wrap (:304)
+struct BoxRegs {
+    float I[9], M[9];   // inverse and matrix, column-major, held in SGPRs (statically indexed only)
+    int nshift;
+};
+
+template <int WK>
+__device__ __forceinline__ v2f pair_d2x2(const SearchParams &P, const BoxRegs &B, uint32_t wrap, float px, float py,
+                                         float pz, v2f qx, v2f qy, v2f qz) {
+    const v2f vx = qx - px, vy = qy - py, vz = qz - pz;
+    if (WK == WK_NONE) return (vx * vx + vy * vy) + vz * vz;
+    const float *I = B.I, *M = B.M;
+    v2f fx, fy, fz;
+    if (WK == WK_DIAG) {
+        fx = I[0] * vx;
+        fy = I[4] * vy;
+        fz = I[8] * vz;
+    } else if (WK == WK_UPPER) {
+        fx = (I[0] * vx + I[3] * vy) + I[6] * vz;
+        fy = I[4] * vy + I[7] * vz;
+        fz = I[8] * vz;
+    } else {
+        fx = (I[0] * vx + I[3] * vy) + I[6] * vz;
+        fy = (I[1] * vx + I[4] * vy) + I[7] * vz;
+        fz = (I[2] * vx + I[5] * vy) + I[8] * vz;
+    }
+    if (wrap & 1u) fx -= round_away2(fx);
+    if (wrap & 2u) fy -= round_away2(fy);
+    if (wrap & 4u) fz -= round_away2(fz);
+    v2f sx, sy, sz;
+    if (WK == WK_DIAG) {
+        sx = M[0] * fx;
+        sy = M[4] * fy;
+        sz = M[8] * fz;
+    } else if (WK == WK_UPPER) {
+        sx = (M[0] * fx + M[3] * fy) + M[6] * fz;
+        sy = M[4] * fy + M[7] * fz;
+        sz = M[8] * fz;
+    } else {
+        sx = (M[0] * fx + M[3] * fy) + M[6] * fz;
+        sy = (M[1] * fx + M[4] * fy) + M[7] * fz;
+        sz = (M[2] * fx + M[5] * fy) + M[8] * fz;
+    }
+    v2f best2 = (sx * sx + sy * sy) + sz * sz;
+    if (WK != WK_DIAG && B.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {
+        for (int k = 0; k < B.nshift; ++k) {
+            const v2f cx = sx + P.box.shifts[3 * k], cy = sy + P.box.shifts[3 * k + 1], cz = sz + P.box.shifts[3 * k + 2];
+            const v2f n2 = (cx * cx + cy * cy) + cz * cz;
+            // `best` itself is only needed through its norm: cand = start + s is always formed from
+            // `start`, not from the running best (:310), so tracking best2 is enough
+            best2.x = n2.x < best2.x ? n2.x : best2.x;
+            best2.y = n2.y < best2.y ? n2.y : best2.y;
+        }
+    }
+    return best2;
+}
+
+// Per-wave output FIFO of the fill pass.
+struct Fifo {
+    uint32_t *fi, *fj, *fd;     // LDS, FIFO_CAP entries each
+    uint32_t head, tail;        // monotonically increasing, wave-uniform
+    uint64_t base;              // output offset of this task
+    uint2 *pairs;
+    float *dist;
+    uint32_t *ids;              // WITHIN output
+    uint32_t *hist;             // consumer-fused mode: workgroup histogram in LDS (NULL otherwise)
+    float hmin, hmax, hn;
+};
+
+template <int KIND>
+__device__ __forceinline__ void fifo_flush(Fifo &F, uint32_t count, uint32_t lane) {
+    if (lane < count) {
+        const uint32_t s = (F.head + lane) & (FIFO_CAP - 1);
+        const uint64_t pos = F.base + F.head + lane;
+        if (KIND == MOLAR_HIP_SEARCH_WITHIN) {
+            F.ids[pos] = F.fi[s];
+        } else if (F.hist) {
+            // Histogram1D::add_one (molar_membrane/src/stats.rs:29-35) on d = sqrt(d2):
+            //   b = (n as Float * (val - min) / (max - min)).floor() as isize;  if 0 <= b < n: bins[b] += 1
+            const float d = __builtin_sqrtf(__uint_as_float(F.fd[s]));
+            float fb = __builtin_floorf(F.hn * (d - F.hmin) / (F.hmax - F.hmin));
+            if (fb != fb) fb = 0.0f;                                    // NaN as isize == 0
+            if (fb >= 0.0f && fb < F.hn) atomicAdd(&F.hist[(uint32_t)fb], 1u);
+        } else {
+            if (F.pairs) F.pairs[pos] = make_uint2(F.fi[s], F.fj[s]);
+            // d2.sqrt() (:448): llvm.sqrt.f32 without fpmath metadata = IEEE correctly rounded
+            if (F.dist) F.dist[pos] = __builtin_sqrtf(__uint_as_float(F.fd[s]));
+        }
+    }
+    F.head += count;
+}
+
+// One task = one ordered block of the reference's output:
+//   search_cell_pair_single(_pbc) :432-517, _double(_pbc) :324-373, _vdw(_pbc) :375-430,
+//   _within(_pbc) :271-322.
+// j (second cell): one atom per lane per 64-chunk, NCH chunks resident in registers as packed
+// pairs (NCH = 0: cells larger than KREG*64 atoms are re-read from memory per row).
+// i (first cell): 64 atoms at a time are loaded one-per-lane and each row's atom is broadcast
+// with v_readlane into SGPRs, so the distance arithmetic takes scalar operands and no per-row
+// memory access sits on the critical path.
+// RUNTIME_NCH: the chunk count is checked at run time (triangular tasks, which skip chunks).
+template <int KIND, bool FILL, int WK, bool TRI, int NCH, bool RUNTIME_NCH>
+__device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, uint32_t lane) {
+    constexpr bool VDW = KIND == MOLAR_HIP_SEARCH_DOUBLE_VDW;
+    constexpr bool WITHIN = KIND == MOLAR_HIP_SEARCH_WITHIN;
+    constexpr bool STREAM = NCH == 0;
+    constexpr int NPAIR = STREAM ? 1 : (NCH + 1) / 2;
+    uint32_t total = 0;
+    BoxRegs B;
+    B.nshift = 0;
+    if (WK != WK_NONE) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            B.I[k] = P.box.inv[k];
+            B.M[k] = P.box.m[k];
+        }
+        B.nshift = P.box.nshift;
+    }
+    const float cutoff2 = P.cutoff2;
+
+    v2f bx[NPAIR], by[NPAIR], bz[NPAIR], bv[NPAIR];
+    uint32_t bid[2 * NPAIR];
+    auto load_b = [&](uint32_t jj, float &x, float &y, float &z, float &v, uint32_t &id) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        float rv = 0.f;
+        if (jj < T.n2) {
+            q = P.sb[T.b0 + jj];
+            if (VDW) rv = P.vdwb[T.b0 + jj];
+        }
+        x = q.x; y = q.y; z = q.z; v = rv; id = __float_as_uint(q.w);
+    };
+    if (!STREAM) {
+#pragma unroll
+        for (int h = 0; h < NPAIR; ++h) {
+            float x0, y0, z0, v0, x1, y1, z1, v1;
+            load_b((uint32_t)(2 * h) * 64u + lane, x0, y0, z0, v0, bid[2 * h]);
+            load_b((uint32_t)(2 * h + 1) * 64u + lane, x1, y1, z1, v1, bid[2 * h + 1]);
+            bx[h] = v2f{x0, x1}; by[h] = v2f{y0, y1}; bz[h] = v2f{z0, z1}; bv[h] = v2f{v0, v1};
+        }
+    }
+    const uint32_t nchunks = (T.n2 + 63u) >> 6;
+
+    {   // one slot = rows [i0, i0+64) of the first cell
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ra = 0.f;
+        if (i0 + lane < T.n1) {
+            a = P.sa[T.a0 + i0 + lane];
+            if (VDW) ra = P.vdwa[T.a0 + i0 + lane];
+        }
+        const uint32_t rows = T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps;
+        for (uint32_t r = 0; r < rows; ++r) {
+            const uint32_t i = i0 + r;
+            const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.x), r));
+            const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.y), r));
+            const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.z), r));
+            const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(a.w), r);
+            float r1 = 0.f;
+            if (VDW) r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra), r));
+            bool found = false;   // WITHIN
+
+            // consume the hits of one 64-chunk, in j order
+            auto emit = [&](bool hit, float d2, uint32_t qid) {
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (WITHIN) {
+                    if (mask) found = true;
+                    return;
+                }
+                const uint32_t cnt = (uint32_t)__popcll(mask);
+                if (!FILL) {
+                    total += cnt;
+                    return;
+                }
+                if (cnt) {
+                    if (hit) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        const uint32_t s = (F.tail + rank) & (FIFO_CAP - 1);
+                        F.fi[s] = id_i;
+                        F.fj[s] = qid;
+                        F.fd[s] = __float_as_uint(d2);
+                    }
+                    F.tail += cnt;
+                    total += cnt;
+                    if (F.tail - F.head >= 64u) {
+                        __builtin_amdgcn_wave_barrier();
+                        fifo_flush<KIND>(F, 64u, lane);
+                    }
+                }
+            };
+            // two chunks (c0 = first chunk index) against row i; use0/use1: chunk is live
+            auto pair_body = [&](uint32_t c0, bool use0, bool use1, bool rag0, bool rag1, v2f qx, v2f qy, v2f qz, v2f qv,
+                                 uint32_t id0, uint32_t id1) {
+                const v2f d2 = pair_d2x2<WK>(P, B, T.wrap, px, py, pz, qx, qy, qz);
+                bool h0, h1;
+                if (VDW) {
+                    const v2f cut = (r1 + qv) + F32_EPS;                   // :392, :423
+                    const v2f c2 = cut * cut;
+                    h0 = d2.x <= c2.x;
+                    h1 = d2.y <= c2.y;
+                } else {
+                    h0 = d2.x <= cutoff2;
+                    h1 = d2.y <= cutoff2;
+                }
+                const uint32_t j0 = c0 * 64u + lane, j1 = j0 + 64u;
+                if (rag0) h0 = h0 && (j0 < T.n2);                          // only the last chunk is ragged
+                if (rag1) h1 = h1 && (j1 < T.n2);
+                if (TRI) {                                                 // j in i+1..n (:443, :482)
+                    h0 = h0 && (j0 > i);
+                    h1 = h1 && (j1 > i);
+                }
+                if (use0 && !(WITHIN && found)) emit(h0, d2.x, id0);
+                if (use1 && !(WITHIN && found)) emit(h1, d2.y, id1);      // `break` at the first hit (:289, :318)
+            };
+
+            if (!STREAM) {
+#pragma unroll
+                for (int h = 0; h < NPAIR; ++h) {
+                    const uint32_t c0 = 2u * (uint32_t)h, c1 = c0 + 1u;
+                    bool use0 = true, use1 = (int)c1 < NCH;
+                    if (RUNTIME_NCH) {
+                        use0 = c0 < nchunks;
+                        use1 = c1 < nchunks;
+                    }
+                    if (TRI) {                                             // whole chunk has j <= i
+                        use0 = use0 && !(c0 * 64u + 63u <= i);
+                        use1 = use1 && !(c1 * 64u + 63u <= i);
+                    }
+                    if (WITHIN && found) break;
+                    if (!use0 && !use1) continue;
+                    const bool rag0 = RUNTIME_NCH ? (c0 + 1u == nchunks) : ((int)c0 == NCH - 1);
+                    const bool rag1 = RUNTIME_NCH ? (c1 + 1u == nchunks) : ((int)c1 == NCH - 1);
+                    pair_body(c0, use0, use1, rag0, rag1, bx[h], by[h], bz[h], bv[h], bid[2 * h], bid[2 * h + 1]);
+                }
+            } else {
+                for (uint32_t c0 = 0; c0 < nchunks; c0 += 2u) {
+                    bool use0 = true, use1 = c0 + 1u < nchunks;
+                    if (TRI) {
+                        use0 = !(c0 * 64u + 63u <= i);
+                        use1 = use1 && !((c0 + 1u) * 64u + 63u <= i);
+                    }
+                    if (WITHIN && found) break;
+                    if (!use0 && !use1) continue;
+                    float x0, y0, z0, v0, x1, y1, z1, v1;
+                    uint32_t id0, id1;
+                    load_b(c0 * 64u + lane, x0, y0, z0, v0, id0);
+                    load_b((c0 + 1u) * 64u + lane, x1, y1, z1, v1, id1);
+                    pair_body(c0, use0, use1, true, true, v2f{x0, x1}, v2f{y0, y1}, v2f{z0, z1}, v2f{v0, v1}, id0, id1);
+                }
+            }
+
+            if (WITHIN && found) {
+                if (FILL) {
+                    if (lane == 0) F.fi[F.tail & (FIFO_CAP - 1)] = id_i;
+                    F.tail += 1;
+                    if (F.tail - F.head >= 64u) {
+                        __builtin_amdgcn_wave_barrier();
+                        fifo_flush<KIND>(F, 64u, lane);
+                    }
+                }
+                total += 1;
+            }
+        }
+    }
+    if (FILL && F.tail != F.head) {
+        __builtin_amdgcn_wave_barrier();
+        fifo_flush<KIND>(F, F.tail - F.head, lane);
+    }
+    return total;
+}
+
+// Box matrices copied into VGPRs: an SGPR source operand halves the issue rate of f32 VALU ops on
+// gfx950 (4.4 vs 2.4-2.7 cycles per wave instruction, profiles/microbench/valu_rate.hip).
+struct BoxV {
+    float I[9], M[9];
+};
+
+__device__ __forceinline__ float to_vgpr(float s) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+
+// PeriodicBox::distance_squared for ONE candidate (periodic_box.rs:286-318, 379-381), plain f32 ops.
+// The grid stores every atom inside the primary cell along periodic dimensions (populate_pbc wraps
+// them, distance_search.rs:183-196), so |f[d]| < 1.5 for a wrapped dimension and f32::round reduces
+// to "copysign(1, f) if |f| >= 0.5 else 0" - the same value, three instructions instead of six.
+template <int WK>
+__device__ __forceinline__ float wrapped_d2(const SearchParams &P, const BoxV &B, uint32_t wrap, int nshift, float vx,
+                                            float vy, float vz) {
+    float fx, fy, fz;
+    if (WK == WK_DIAG) {
+        fx = B.I[0] * vx; fy = B.I[4] * vy; fz = B.I[8] * vz;
+    } else if (WK == WK_UPPER) {
+        fx = (B.I[0] * vx + B.I[3] * vy) + B.I[6] * vz;
+        fy = B.I[4] * vy + B.I[7] * vz;
+        fz = B.I[8] * vz;
+    } else {
+        fx = (B.I[0] * vx + B.I[3] * vy) + B.I[6] * vz;
+        fy = (B.I[1] * vx + B.I[4] * vy) + B.I[7] * vz;
+        fz = (B.I[2] * vx + B.I[5] * vy) + B.I[8] * vz;
+    }
+    if (wrap & 1u) fx -= (fabsf(fx) >= 0.5f ? copysignf(1.0f, fx) : 0.0f);
+    if (wrap & 2u) fy -= (fabsf(fy) >= 0.5f ? copysignf(1.0f, fy) : 0.0f);
+    if (wrap & 4u) fz -= (fabsf(fz) >= 0.5f ? copysignf(1.0f, fz) : 0.0f);
+    float sx, sy, sz;
+    if (WK == WK_DIAG) {
+        sx = B.M[0] * fx; sy = B.M[4] * fy; sz = B.M[8] * fz;
+    } else if (WK == WK_UPPER) {
+        sx = (B.M[0] * fx + B.M[3] * fy) + B.M[6] * fz;
+        sy = B.M[4] * fy + B.M[7] * fz;
+        sz = B.M[8] * fz;
+    } else {
+        sx = (B.M[0] * fx + B.M[3] * fy) + B.M[6] * fz;
+        sy = (B.M[1] * fx + B.M[4] * fy) + B.M[7] * fz;
+        sz = (B.M[2] * fx + B.M[5] * fy) + B.M[8] * fz;
+    }
+    float best2 = (sx * sx + sy * sy) + sz * sz;
+    if (WK != WK_DIAG && nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {   // triclinic candidates (:304-317)
+        for (int k = 0; k < nshift; ++k) {
+            const float cx = sx + P.box.shifts[3 * k], cy = sy + P.box.shifts[3 * k + 1], cz = sz + P.box.shifts[3 * k + 2];
+            const float n2 = (cx * cx + cy * cy) + cz * cz;
+            best2 = n2 < best2 ? n2 : best2;
+        }
+    }
+    return best2;
+}
+
+// squared distance from a point to an axis-aligned box, same f32 expression as a pair distance
+__device__ __forceinline__ float aabb_d2(float ax, float ay, float az, float lx, float ly, float lz, float hx, float hy,
+                                         float hz) {
+    const float ex = fmaxf(fmaxf(lx - ax, ax - hx), 0.f);
+    const float ey = fmaxf(fmaxf(ly - ay, ay - hy), 0.f);
+    const float ez = fmaxf(fmaxf(lz - az, az - hz), 0.f);
+    return (ex * ex + ey * ey) + ez * ez;
+}
+
+// Fast path for the bulk of the work: fixed-cutoff, non-triangular cell pairs whose second cell
+// fits in registers (NCH <= 8 chunks of 64), plain (WK_NONE) or wrapped (WK_DIAG/UPPER/GENERAL).
+//  * the slot's 64 first-cell atoms are staged in LDS and each row is fetched with ONE broadcast
+//    ds_read_b128, so the arithmetic runs on VGPR operands only and no v_readlane sits in the row
+//    loop;
+//  * the count pass never leaves the VALU: hits are added per lane through the carry of the
+//    compare and reduced across the wave once per slot (a v_cmp -> s_bcnt1 -> s_add chain costs
+//    ~14 cycles per chunk because of the VALU->SALU hazard);
+//  * lanes past the end of the second cell hold a coordinate so large that d2 overflows to +inf
+//    (or NaN) and the compare fails by itself - no separate validity mask;
+//  * rows that provably cannot have a hit are skipped (see `live` below).
+template <int KIND, bool FILL, int WK, int NCH, bool TRI>
+__device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
+                                             uint32_t lane) {
+    float bx[NCH], by[NCH], bz[NCH];
+    uint32_t bid[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const uint32_t jj = (uint32_t)k * 64u + lane;
+        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+        if (jj < T.n2) q = P.sb[T.b0 + jj];
+        bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bid[k] = __float_as_uint(q.w);
+    }
+    BoxV B;
+    int nshift = 0;
+    if (WK != WK_NONE) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            B.I[k] = to_vgpr(P.box.inv[k]);
+            B.M[k] = to_vgpr(P.box.m[k]);
+        }
+        nshift = P.box.nshift;
+    }
+    const float cutoff2 = P.cutoff2;
+    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
+    unsigned long long live;   // rows of this slot that can have a hit at all
+    {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < rows) a = P.sa[T.a0 + i0 + lane];
+        la[lane] = a;
+        const float4 lo = P.aabb_b[2 * T.cb], hi = P.aabb_b[2 * T.cb + 1];
+        bool need = true;
+        if (TRI) {
+            // same cell (i < j triangle, :439-451): the atom lies inside its own cell's box, nothing to prune
+        } else if (WK == WK_NONE) {
+            // Exact row pruning.  Every B position lies inside the cell's bounding box [lo,hi], and each
+            // f32 operation of d2 = ((dx*dx)+(dy*dy))+(dz*dz) is monotone in |dx|,|dy|,|dz|, so the same
+            // expression on the box distances is a lower bound of every d2 of the row IN f32 ARITHMETIC:
+            // if it already exceeds cutoff2 the reference finds no hit in this row either.
+            need = !(aabb_d2(a.x, a.y, a.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > cutoff2);
+        } else if (P.prune_wrapped && !(nshift != 0 && T.wrap == MOLAR_HIP_PBC_FULL)) {
+            // Conservative row pruning for wrapped entries.  In exact arithmetic the reference's vector
+            // is (b - a) - sum_d n_d*col_d with n_d = round(f_d) in {-1,0,1} for the wrapped dims (atoms
+            // are stored inside the primary cell).  The row is skipped only if for EVERY such image the
+            // box distance exceeds cutoff + margin; the margin (1e-3 nm, >100x the f32 evaluation error
+            // of inv*v / M*f at MD box sizes) absorbs the difference between the reference's f32
+            // arithmetic and this geometric bound.
+            const float lim = P.prune_limit2;
+            need = false;
+            for (int nx = -1; nx <= 1; ++nx) {
+                if (!(T.wrap & 1u) && nx != 0) continue;
+                for (int ny = -1; ny <= 1; ++ny) {
+                    if (!(T.wrap & 2u) && ny != 0) continue;
+                    for (int nz = -1; nz <= 1; ++nz) {
+                        if (!(T.wrap & 4u) && nz != 0) continue;
+                        const float fx = (float)nx, fy = (float)ny, fz = (float)nz;
+                        const float tx = (fx * P.box.m[0] + fy * P.box.m[3]) + fz * P.box.m[6];
+                        const float ty = (fx * P.box.m[1] + fy * P.box.m[4]) + fz * P.box.m[7];
+                        const float tz = (fx * P.box.m[2] + fy * P.box.m[5]) + fz * P.box.m[8];
+                        // (b - n*cols) - a  ==  b - (a + n*cols): shift the point instead of the box
+                        const float e2 = aabb_d2(a.x + tx, a.y + ty, a.z + tz, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+                        need = need || !(e2 > lim);
+                    }
+                }
+            }
+        }
+        live = __builtin_amdgcn_ballot_w64(lane < rows && need);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t acc = 0;      // per-lane hit counter (count pass)
+    uint32_t total = 0;
+    while (live) {
+        const uint32_t r = (uint32_t)__builtin_ctzll(live);
+        live &= live - 1ull;
+        const float4 p = la[r];                      // one broadcast ds_read per row
+        const uint32_t id_i = __float_as_uint(p.w);
+        const uint32_t i = i0 + r;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (TRI && (uint32_t)k * 64u + 63u <= i) continue;                   // whole chunk has j <= i
+            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1
+            float d2;
+            if (WK == WK_NONE) d2 = (dx * dx + dy * dy) + dz * dz;               // |p2-p1|^2 (:446, :460)
+            else d2 = wrapped_d2<WK>(P, B, T.wrap, nshift, dx, dy, dz);          // (:485-486)
+            if (TRI && (uint32_t)k * 64u <= i)                                   // diagonal chunk: j in i+1..n (:443)
+                d2 = ((uint32_t)k * 64u + lane > i) ? d2 : INFINITY;
+            if (!FILL) {
+                // acc += (d2 <= cutoff2): the compare's carry is added per lane, no SALU involved
+                asm volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"
+                             : "+v"(acc)
+                             : "v"(d2), "s"(cutoff2)
+                             : "vcc");
+            } else {
+                const bool hit = d2 <= cutoff2;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (mask) {
+                    const uint32_t cnt = (uint32_t)__popcll(mask);
+                    if (hit) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        const uint32_t s = (F.tail + rank) & (FIFO_CAP - 1);
+                        F.fi[s] = id_i;
+                        F.fj[s] = bid[k];
+                        F.fd[s] = __float_as_uint(d2);
+                    }
+                    F.tail += cnt;
+                    total += cnt;
+                    if (F.tail - F.head >= 64u) {
+                        __builtin_amdgcn_wave_barrier();
+                        fifo_flush<KIND>(F, 64u, lane);
+                    }
+                }
+            }
+        }
+    }
+    if (!FILL) {
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        total = acc;
+    } else if (F.tail != F.head) {
+        __builtin_amdgcn_wave_barrier();
+        fifo_flush<KIND>(F, F.tail - F.head, lane);
+    }
+    return total;
+}
+
+// chunk-count dispatch: for the single-set search the non-triangular tasks get a fully unrolled,
+// branch-free row body per chunk count; everything else checks the chunk count at run time
+template <int KIND, bool FILL, int WK>
+__device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
+                                                 uint32_t lane) {
+    const uint32_t nchunks = (T.n2 + 63u) >> 6;
+    if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && !T.tri && nchunks <= (uint32_t)KREG) {
+        switch (nchunks) {
+            case 1: return run_fast<KIND, FILL, WK, 1, false>(P, T, i0, F, la, lane);
+            case 2: return run_fast<KIND, FILL, WK, 2, false>(P, T, i0, F, la, lane);
+            case 3: return run_fast<KIND, FILL, WK, 3, false>(P, T, i0, F, la, lane);
+            case 4: return run_fast<KIND, FILL, WK, 4, false>(P, T, i0, F, la, lane);
+            case 5: return run_fast<KIND, FILL, WK, 5, false>(P, T, i0, F, la, lane);
+            case 6: return run_fast<KIND, FILL, WK, 6, false>(P, T, i0, F, la, lane);
+            case 7: return run_fast<KIND, FILL, WK, 7, false>(P, T, i0, F, la, lane);
+            default: return run_fast<KIND, FILL, WK, 8, false>(P, T, i0, F, la, lane);
+        }
+    }
+    if (KIND == MOLAR_HIP_SEARCH_SINGLE && WK == WK_NONE && T.tri && nchunks <= (uint32_t)KREG) {
+        switch (nchunks) {
+            case 1: return run_fast<KIND, FILL, WK_NONE, 1, true>(P, T, i0, F, la, lane);
+            case 2: return run_fast<KIND, FILL, WK_NONE, 2, true>(P, T, i0, F, la, lane);
+            case 3: return run_fast<KIND, FILL, WK_NONE, 3, true>(P, T, i0, F, la, lane);
+            case 4: return run_fast<KIND, FILL, WK_NONE, 4, true>(P, T, i0, F, la, lane);
+            case 5: return run_fast<KIND, FILL, WK_NONE, 5, true>(P, T, i0, F, la, lane);
+            case 6: return run_fast<KIND, FILL, WK_NONE, 6, true>(P, T, i0, F, la, lane);
+            case 7: return run_fast<KIND, FILL, WK_NONE, 7, true>(P, T, i0, F, la, lane);
+            default: return run_fast<KIND, FILL, WK_NONE, 8, true>(P, T, i0, F, la, lane);
+        }
+    }
+    if (nchunks > (uint32_t)KREG) {
+        if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) return run_task<KIND, FILL, WK, true, 0, false>(P, T, i0, F, lane);
+        return run_task<KIND, FILL, WK, false, 0, false>(P, T, i0, F, lane);
+    }
+    if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) return run_task<KIND, FILL, WK, true, KREG, true>(P, T, i0, F, lane);
+    return run_task<KIND, FILL, WK, false, KREG, true>(P, T, i0, F, lane);
+}
+
+// Slots.  A plan entry ("task") is cut into blocks of 64 rows of its first cell; one wave processes
+// one slot.  This bounds the work of a wave (the corner entries that run the triclinic candidate
+// loop are ~50x a plain entry) and gives small systems enough waves to fill the chip.  Slots are
+// numbered in plan order, then row order, so an exclusive scan of the per-slot counts is the
+// reference's output order.
+template <int KIND>
+__global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__restrict__ task_nb) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.ntasks) return;
+    const Task T = decode_task<KIND, false>(P, t);
+    task_nb[t] = T.valid ? (T.n1 + T.rps - 1u) / T.rps : 0u;
+}
+
+static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, const uint32_t *__restrict__ task_first,
+                                                      uint32_t *__restrict__ slot_task) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= ntasks) return;
+    const uint32_t s0 = task_first[t], s1 = task_first[t + 1];
+    for (uint32_t s = s0; s < s1; ++s) slot_task[s] = (uint32_t)t;
+}
+
+template <int KIND, int MODE>
+__global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restrict__ Pp,
+                                                     const uint32_t *__restrict__ task_first,
+                                                     const uint32_t *__restrict__ slot_task,
+                                                     uint32_t *__restrict__ slot_cnt,
+                                                     const unsigned long long *__restrict__ slot_base,
+                                                     uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
+                                                     uint32_t *__restrict__ out_ids) {
+    __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
+    __shared__ float4 lds_a[WAVES_PER_BLOCK][64];
+    constexpr bool FILL = MODE != MODE_COUNT;
+    extern __shared__ uint32_t lds_hist[];     // histogram mode only (hist_nbins counters)
+    // The parameter block lives in device memory: a by-value struct this large, indexed dynamically
+    // (box.shifts[k]), gets copied to scratch by the compiler and drags every field into VGPRs.
+    const SearchParams &P = *Pp;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nslots = task_first[P.ntasks];
+    constexpr bool hist = MODE == MODE_HIST;
+    if (hist) {
+        for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += BLOCK) lds_hist[b] = 0u;
+        __syncthreads();
+    }
+    unsigned long long wave_total = 0;
+    auto process_slot = [&](uint32_t w) __attribute__((always_inline)) {
+        // Blocks are handed out in launch order: walk the plan BACKWARDS so the cells at the far x edge,
+        // whose entries wrap (several times the arithmetic per candidate), start first and the cheap
+        // entries fill the tail; consecutive blocks land on different XCDs, which spreads that band
+        // over the whole chip.
+        const uint32_t slot = nslots - 1u - w;
+        const uint32_t t = slot_task[slot];
+        const Task T = decode_task<KIND, true>(P, t);
+        const uint32_t i0 = (slot - task_first[t]) * T.rps;
+        Fifo F;
+        F.fi = lds[wave][0];
+        F.fj = lds[wave][1];
+        F.fd = lds[wave][2];
+        F.head = F.tail = 0;
+        F.pairs = out_pairs;
+        F.dist = out_dist;
+        F.ids = out_ids;
+        F.base = 0;
+        F.hist = hist ? lds_hist : nullptr;
+        F.hmin = P.hist_min;
+        F.hmax = P.hist_max;
+        F.hn = (float)P.hist_nbins;
+        if (FILL && !hist) {
+            F.base = slot_base[slot];
+            if (slot_base[slot + 1] == F.base) return;     // nothing to emit: skip the traversal
+        }
+        uint32_t total = 0;
+        const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
+        if (P.debug_skip) {
+            const uint32_t kind_bit = T.tri ? 4u : (wk != WK_NONE ? 2u : 1u);
+            if (P.debug_skip & kind_bit) return;
+        }
+        switch (wk) {
+            case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE>(P, T, i0, F, lds_a[wave], lane); break;
+            case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG>(P, T, i0, F, lds_a[wave], lane); break;
+            case WK_UPPER: total = run_task_nch<KIND, FILL, WK_UPPER>(P, T, i0, F, lds_a[wave], lane); break;
+            default: total = run_task_nch<KIND, FILL, WK_GENERAL>(P, T, i0, F, lds_a[wave], lane); break;
+        }
+        if (!FILL && lane == 0) slot_cnt[slot] = total;
+        wave_total += total;
+    };
+    const uint32_t w0 = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (!hist) {
+        // COUNT / FILL: one wave per slot (nothing is live across slots -> fewer registers, more waves)
+        if (w0 < nslots) process_slot(w0);
+    } else {
+        // histogram mode: capped grid, strided slots, so each workgroup flushes its LDS histogram once
+        for (uint32_t w = w0; w < nslots; w += gridDim.x * WAVES_PER_BLOCK) process_slot(w);
+    }
+    if (hist) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += BLOCK) {
+            const uint32_t v = lds_hist[b];
+            if (v) atomicAdd(&P.hist_bins[b], (unsigned long long)v);
+        }
+        if (lane == 0 && wave_total) atomicAdd(&P.hist_bins[P.hist_nbins], wave_total);
+    }
+}
+
+
+// one launch of the pair kernel for a search kind / mode
+template <int KIND, int MODE>
+inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t stream, const SearchParams *dP,
+                               const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                               const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids) {
+    hipLaunchKernelGGL((pair_kernel<KIND, MODE>), dim3(nblocks), dim3(BLOCK), dyn_lds, stream, dP, task_first, slot_task,
+                       slot_cnt, slot_base, pairs, dist, ids);
+}
+
+}  // namespace pairk
+
+// defined in pair_k0.hip .. pair_k3.hip (one search kind each)
+void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
+                        const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                        const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);
+void launch_pair_double(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
+                        const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                        const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);
+void launch_pair_within(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
+                        const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                        const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);
+void launch_pair_vdw(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
+                     const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                     const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);
+
+}  // namespace mh

@@ -308,3 +308,38 @@ def test_full_size_properties(eng):
     deg = torch.bincount(i, minlength=n) + torch.bincount(j, minlength=n)
     assert abs(float(deg.float().mean()) - 2.0 * cnt / n) < 1e-3
     assert 600 < float(deg.float().mean()) < 800
+
+
+@pytest.mark.parametrize("n,cutoff,nbins", [(20000, 0.8, 400), (250_000, 1.2, 1200)])
+def test_fused_histogram_bit_identical(eng, orc32, n, cutoff, nbins):
+    """Config 4's consumer: radial distance histogram without materialising pairs.  Integer bins must
+    equal Histogram1D::add_one (stats.rs:29-35) applied to the reference's distance stream."""
+    a = api()
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 3)
+    ob = orc32.box_from_matrix(box)
+    ref = orc32.search_single_pbc(cutoff, pos, ob, 7, nthreads=8)
+    want = orc32.histogram_add(0.0, cutoff, nbins, ref["d"]).astype(np.uint64)
+    bins, cnt = eng.search_histogram(a.SEARCH_SINGLE, cutoff, 0.0, cutoff, nbins, pos, box=box, pbc=7)
+    assert cnt == len(ref["i"])
+    assert np.array_equal(bins, want)
+    # accumulation over frames: a second call adds into the same bins
+    bins2, cnt2 = eng.search_histogram(a.SEARCH_SINGLE, cutoff, 0.0, cutoff, nbins, pos, box=box, pbc=7, bins=bins)
+    assert np.array_equal(bins2, 2 * want) and cnt2 == cnt
+    # out-of-range distances are dropped (b >= n): histogram over half the range
+    half, _ = eng.search_histogram(a.SEARCH_SINGLE, cutoff, 0.0, cutoff / 2, nbins, pos, box=box, pbc=7)
+    want_half = orc32.histogram_add(0.0, cutoff / 2, nbins, ref["d"]).astype(np.uint64)
+    assert np.array_equal(half, want_half)
+
+
+def test_fused_histogram_two_sets(eng, orc32):
+    a = api()
+    n = 12000
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 1)
+    idx1 = np.arange(0, n, 2, dtype=np.uint64); idx2 = np.arange(1, n, 2, dtype=np.uint64)
+    ob = orc32.box_from_matrix(box)
+    ref = orc32.search_double_pbc(0.7, pos[idx1.astype(int)], pos[idx2.astype(int)], ob, 7, idx1, idx2)
+    want = orc32.histogram_add(0.0, 0.7, 350, ref["d"]).astype(np.uint64)
+    bins, cnt = eng.search_histogram(a.SEARCH_DOUBLE, 0.7, 0.0, 0.7, 350, pos, idx1, pos, idx2, box=box, pbc=7)
+    assert cnt == len(ref["i"]) and np.array_equal(bins, want)     # includes the reference's same-cell duplicates
