@@ -196,6 +196,18 @@ int molar_hip_fit_transform(molar_hip_ctx *ctx, const float *xyz1, size_t natoms
                             const uint64_t *idx2, size_t n2, const float *mass2, int at_origin, float R9[9],
                             float t3[3]);
 
+/* Measure::lipid_tail_order (measure.rs:270-422), batched over `ntails` tails given as CSR:
+ * tail t holds the carbons idx[tail_offsets[t] .. tail_offsets[t+1]) (n_t atoms), its normals are
+ * normals[3*normal_offsets[t] .. 3*normal_offsets[t+1]) (1 or n_t-2 vectors), its n_t-1 bond orders
+ * start at bond_orders[tail_offsets[t]-t], its n_t-2 results go to out[tail_offsets[t]-2t ..).
+ * order_type: 0 Sz, 1 Scd, 2 ScdCorr (measure.rs:708-716).  Size violations of any tail return
+ * ERR_LIPID_TAIL_TOO_SHORT / _NORMALS_COUNT / _BOND_ORDER_COUNT (measure.rs:281-291); bond order
+ * counts are implied by the layout, so the third can only come from a NULL bond_orders.
+ * Replaces the per-lipid rayon loop of molar_membrane (lib.rs:435-443, lipid_molecule.rs:48-59). */
+int molar_hip_lipid_tail_order(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx,
+                               const uint64_t *tail_offsets, size_t ntails, int order_type, const float *normals,
+                               const uint64_t *normal_offsets, const uint8_t *bond_orders, float *out);
+
 /* ------------------------------------------------------------------ Modify (modify.rs) */
 
 /* apply_transform :32-36 — in place on xyz (host buffers are copied back). */

@@ -367,6 +367,33 @@ class Engine:
         check(self.lib.molar_hip_unwrap_simple(self.ctx, xa, na, ia, n, ba, pbc_mask(dims)))
         return xyz
 
+    def lipid_tail_order(self, xyz, tails, order_type, normals, bond_orders):
+        """Batched Measure::lipid_tail_order (measure.rs:270-422).  tails: list of index arrays (the
+        tail carbons, in chain order); normals: list of [1,3] or [n-2,3] arrays; bond_orders: list of
+        n-1 arrays of 1/2.  order_type: 0 Sz, 1 Scd, 2 ScdCorr.  Returns a list of n-2 arrays."""
+        xyz = _f32(xyz)
+        xa, kx = _addr(xyz)
+        natoms = xyz.shape[0]
+        lens = np.array([len(t) for t in tails], dtype=np.uint64)
+        toff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(t, np.uint64) for t in tails]))
+        nl = [np.asarray(n, np.float32).reshape(-1, 3) for n in normals]
+        noff = np.concatenate([[0], np.cumsum([len(n) for n in nl])]).astype(np.uint64)
+        nrm = np.ascontiguousarray(np.concatenate(nl))
+        bo = np.ascontiguousarray(np.concatenate([np.asarray(b, np.uint8) for b in bond_orders])) if bond_orders is not None else None
+        if bo is not None and len(bo) != int(toff[-1]) - len(tails):
+            raise MolarHipError(9, "for N tail carbons # of bond orders should be N-1")       # LipidOrderError::BondOrderCount
+        nout = max(int(toff[-1]) - 2 * len(tails), 0)
+        out = np.zeros(max(nout, 1), np.float32)
+        check(self.lib.molar_hip_lipid_tail_order(self.ctx, xa, natoms, idx.ctypes.data, toff.ctypes.data, len(tails),
+                                                  int(order_type), nrm.ctypes.data, noff.ctypes.data,
+                                                  None if bo is None else bo.ctypes.data, out.ctypes.data))
+        res, pos = [], 0
+        for n in lens:
+            res.append(out[pos:pos + int(n) - 2].copy())
+            pos += int(n) - 2
+        return res
+
     def fit_rmsd_batch(self, frames, mass, ref_xyz, idx=None, ref_idx=None, apply=True):
         """frames: [F, natoms, 3] (numpy, modified in place if apply; or torch CUDA tensor).
         Returns dict(rmsd[F], R[F,3,3], t[F,3], com[F,3], gyration[F])."""

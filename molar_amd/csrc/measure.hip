@@ -221,6 +221,107 @@ __global__ void __launch_bounds__(RB) k_minmax(Sel s, uint32_t *mm) {
         }
 }
 
+// ---------------------------------------------------------------- lipid tail order (measure.rs:270-422)
+
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3sub(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ float f3dot(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float f3norm(F3 a) { return __builtin_sqrtf(f3dot(a, a)); }
+__device__ __forceinline__ F3 f3cross(F3 a, F3 b) {
+    return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ F3 f3unit(F3 a) {
+    const float n = f3norm(a);
+    return F3{a.x / n, a.y / n, a.z / n};
+}
+// nalgebra Vector::angle: acos(clamp(a.b / (|a||b|), -1, 1)), 0 if either vector is zero
+__device__ __forceinline__ float f3angle(F3 a, F3 b) {
+    const float n1 = f3norm(a), n2 = f3norm(b);
+    if (n1 == 0.0f || n2 == 0.0f) return 0.0f;
+    float c = f3dot(a, b) / (n1 * n2);
+    c = c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c);
+    return acosf(c);
+}
+
+// One thread per tail: the reference's loop writes order[i-1] and order[i] from a double bond at i, so
+// bonds are walked sequentially to keep its last-writer-wins behaviour for any bond pattern.
+__global__ void __launch_bounds__(64) k_lipid_order(const float *__restrict__ xyz, const uint64_t *__restrict__ idx,
+                                                    const uint64_t *__restrict__ toff, uint32_t ntails, int order_type,
+                                                    const float *__restrict__ normals, const uint64_t *__restrict__ noff,
+                                                    const uint8_t *__restrict__ bonds, float *__restrict__ out,
+                                                    int *__restrict__ status) {
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    if (t >= ntails) return;
+    const uint64_t a0 = toff[t];
+    const uint32_t n = (uint32_t)(toff[t + 1] - a0);
+    const uint32_t nn = (uint32_t)(noff[t + 1] - noff[t]);
+    if (n < 3) {
+        atomicMax(status, MOLAR_HIP_ERR_LIPID_TAIL_TOO_SHORT);
+        return;
+    }
+    if (nn != 1 && nn != n - 2) {
+        atomicMax(status, MOLAR_HIP_ERR_LIPID_NORMALS_COUNT);
+        return;
+    }
+    const uint8_t *bo = bonds + (a0 - t);
+    float *order = out + (a0 - 2ull * t);
+    auto P = [&](uint32_t k) {
+        const float *q = xyz + 3 * idx[a0 + k];
+        return F3{q[0], q[1], q[2]};
+    };
+    auto N = [&](uint32_t k) {
+        const float *q = normals + 3 * (noff[t] + (nn == 1 ? 0 : k));
+        return F3{q[0], q[1], q[2]};
+    };
+    for (uint32_t k = 0; k < n - 2; ++k) order[k] = 0.0f;
+    if (order_type == 0) {
+        for (uint32_t at = 1; at + 1 < n; ++at) {
+            const float c = cosf(f3angle(f3sub(P(at + 1), P(at - 1)), N(at - 1)));
+            order[at - 1] = 1.5f * (c * c) - 0.5f;
+        }
+        return;
+    }
+    const float sqrt3 = __builtin_sqrtf(3.0f), pi = 3.14159265358979323846f;
+    for (uint32_t i = 0; i + 2 < n; ++i) {
+        if (bo[i] == 1) {
+            if (bo[i + 1] == 1) {
+                const F3 p1 = P(i), p2 = P(i + 1), p3 = P(i + 2);
+                const F3 lz = f3unit(f3sub(p3, p1));
+                const F3 lx = f3unit(f3cross(f3sub(p1, p2), f3sub(p3, p2)));
+                const F3 ly = f3cross(lx, lz);
+                const F3 nv = N(i);
+                const float cx = cosf(f3angle(lx, nv)), cy = cosf(f3angle(ly, nv));
+                const float sxx = 0.5f * (3.0f * (cx * cx) - 1.0f), syy = 0.5f * (3.0f * (cy * cy) - 1.0f);
+                order[i] = -(2.0f * sxx + syy) / 3.0f;
+            }
+        } else {
+            const F3 p1 = P(i - 1), p2 = P(i), p3 = P(i + 1), p4 = P(i + 2);
+            const float a1 = 0.5f * (pi - f3angle(f3sub(p1, p2), f3sub(p3, p2)));
+            const float a2 = 0.5f * (pi - f3angle(f3sub(p2, p3), f3sub(p4, p3)));
+            const F3 lz = f3unit(f3sub(p3, p2));
+            for (int side = 0; side < 2; ++side) {
+                const F3 lx = f3unit(f3cross(side == 0 ? f3sub(p1, p2) : f3sub(p3, p4), lz));
+                const F3 ly = f3cross(lx, lz);
+                const F3 nv = N(side == 0 ? i : i + 1);
+                const float cy = cosf(f3angle(ly, nv)), cz = cosf(f3angle(lz, nv));
+                const float szz = 0.5f * (3.0f * (cz * cz) - 1.0f), syy = 0.5f * (3.0f * (cy * cy) - 1.0f);
+                const float syz = 1.5f * cy * cz;
+                const float a = side == 0 ? a1 : a2, sgn = side == 0 ? -1.0f : 1.0f;
+                float v;
+                if (order_type == 2) {
+                    const float ca = cosf(a), sa = sinf(a);
+                    v = -(((ca * ca) * syy + (sa * sa) * szz) + sgn * (2.0f * ca * sa * syz));
+                } else {
+                    v = -((szz / 4.0f + 3.0f * syy / 4.0f) + sgn * (sqrt3 * syz / 2.0f));
+                }
+                order[side == 0 ? i - 1 : i] = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- finalize kernels (one thread per frame)
 
 __device__ __forceinline__ void sum_partials(const double *partials, uint32_t frame, uint32_t nblk, int nv,
@@ -606,6 +707,54 @@ int molar_hip_fit_transform(molar_hip_ctx *c, const float *xyz1, size_t natoms1,
         t3[0] = cm[3] + rv.x;
         t3[1] = cm[4] + rv.y;
         t3[2] = cm[5] + rv.z;
+    }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_lipid_tail_order(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx,
+                               const uint64_t *tail_offsets, size_t ntails, int order_type, const float *normals,
+                               const uint64_t *normal_offsets, const uint8_t *bond_orders, float *out) {
+    MH_CTX(c);
+    if (!xyz || !idx || !tail_offsets || !normals || !normal_offsets || !out)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "lipid_tail_order: null argument");
+    if (order_type < 0 || order_type > 2) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "lipid_tail_order: order_type %d", order_type);
+    if (!bond_orders && order_type != 0) return fail(MOLAR_HIP_ERR_LIPID_BOND_ORDER_COUNT, "bond orders missing");
+    if (ntails == 0) return MOLAR_HIP_OK;
+    // the CSR offsets are needed on the host to size the transfers
+    std::vector<uint64_t> toff(ntails + 1), noff(ntails + 1);
+    if (is_device_ptr(tail_offsets)) MH_HIP(hipMemcpy(toff.data(), tail_offsets, (ntails + 1) * 8, hipMemcpyDeviceToHost));
+    else std::memcpy(toff.data(), tail_offsets, (ntails + 1) * 8);
+    if (is_device_ptr(normal_offsets)) MH_HIP(hipMemcpy(noff.data(), normal_offsets, (ntails + 1) * 8, hipMemcpyDeviceToHost));
+    else std::memcpy(noff.data(), normal_offsets, (ntails + 1) * 8);
+    const size_t nidx = toff[ntails], nnorm = noff[ntails];
+    if (nidx < 2 * ntails) return fail(MOLAR_HIP_ERR_LIPID_TAIL_TOO_SHORT, "tail should have at least 3 carbons");
+    const size_t nout = nidx - 2 * ntails, nbond = nidx - ntails;
+    const float *d_xyz, *d_norm;
+    const uint64_t *d_idx, *d_toff, *d_noff;
+    const uint8_t *d_bo = nullptr;
+    MH_TRY(to_device(c, xyz, natoms * 3, c->m_xyz1, &d_xyz));
+    MH_TRY(to_device(c, idx, nidx, c->m_idx1, &d_idx));
+    MH_TRY(to_device(c, normals, nnorm * 3, c->m_xyz2, &d_norm));
+    MH_TRY(to_device(c, toff.data(), ntails + 1, c->m_idx2, &d_toff));
+    MH_TRY(to_device(c, noff.data(), ntails + 1, c->m_mass2, &d_noff));
+    static const uint8_t dummy = 1;
+    if (bond_orders) MH_TRY(to_device(c, bond_orders, nbond, c->m_mass1, &d_bo));
+    else MH_TRY(to_device(c, &dummy, 1, c->m_mass1, &d_bo));
+    const bool out_dev = is_device_ptr(out);
+    MH_TRY(c->m_out.reserve((nout + 4) * 4));
+    float *d_out = out_dev ? out : c->m_out.as<float>();
+    MH_TRY(c->m_results.reserve(64));
+    int *status = c->m_results.as<int>();
+    MH_HIP(hipMemsetAsync(status, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_lipid_order, dim3((unsigned)((ntails + 63) / 64)), dim3(64), 0, c->stream, d_xyz, d_idx, d_toff,
+                       (uint32_t)ntails, order_type, d_norm, d_noff, d_bo, d_out, status);
+    MH_HIP(hipGetLastError());
+    int st = 0;
+    MH_TRY(pull(c, &st, status, 4));
+    if (st) return fail(st, "lipid order error (status %d)", st);
+    if (!out_dev && nout) {
+        MH_HIP(hipMemcpyAsync(out, d_out, nout * 4, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
     }
     return MOLAR_HIP_OK;
 }

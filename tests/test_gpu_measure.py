@@ -140,3 +140,61 @@ def test_fit_rmsd_batch(eng, orc32, orc64):
         assert np.allclose(out["com"][f], orc64.center_of_mass(moved, mass, idx), rtol=RTOL64)
         assert out["gyration"][f] == pytest.approx(orc64.gyration(moved, mass, idx), rel=RTOL64)
         assert out["rmsd"][f] < 0.2
+
+
+def _random_tails(rng, ntails, natoms):
+    """Random-walk 'lipid tails' of 14-18 carbons with C-C ~0.153 nm and bond angle ~112 deg."""
+    xyz = rng.uniform(0, 10, (natoms, 3)).astype(np.float32)
+    tails, bonds, normals1, normalsN = [], [], [], []
+    used = 0
+    for t in range(ntails):
+        n = int(rng.integers(14, 19))
+        idx = np.arange(used, used + n)
+        used += n
+        p = np.zeros((n, 3))
+        p[0] = rng.uniform(1, 9, 3)
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        for k in range(1, n):
+            d = d + 0.9 * rng.normal(size=3); d /= np.linalg.norm(d)
+            p[k] = p[k - 1] + 0.153 * d
+        xyz[idx] = p.astype(np.float32)
+        bo = np.ones(n - 1, np.uint8)
+        if n > 8 and t % 2 == 0:
+            bo[int(rng.integers(2, n - 4))] = 2          # one double bond, not at the ends
+        tails.append(idx.astype(np.uint64)); bonds.append(bo)
+        nv = rng.normal(size=3); nv /= np.linalg.norm(nv)
+        normals1.append(nv[None, :].astype(np.float32))
+        nn = rng.normal(size=(n - 2, 3)); nn /= np.linalg.norm(nn, axis=1)[:, None]
+        normalsN.append(nn.astype(np.float32))
+    return xyz, tails, bonds, normals1, normalsN
+
+
+@pytest.mark.parametrize("order_type", [0, 1, 2])
+def test_lipid_tail_order_batched(eng, orc32, orc64, order_type):
+    rng = np.random.default_rng(11)
+    xyz, tails, bonds, n1, nN = _random_tails(rng, 300, 6000)
+    for normals in (n1, nN):
+        got = eng.lipid_tail_order(xyz, tails, order_type, normals, bonds)
+        for t in range(len(tails)):
+            want = orc64.lipid_tail_order(xyz, order_type, normals[t], bonds[t], idx=tails[t])
+            want32 = orc32.lipid_tail_order(xyz, order_type, normals[t], bonds[t], idx=tails[t])
+            assert got[t].shape == want.shape
+            # f32 trig (acos/cos) on both sides: agreement with the f32 oracle to a few ulp of O(1) values,
+            # with the f64 oracle to f32 roundoff amplified by the acos near |c|=1
+            assert np.allclose(got[t], want32, atol=2e-5), (t, got[t], want32)
+            assert np.allclose(got[t], want, atol=2e-4)
+
+
+def test_lipid_tail_order_errors(eng):
+    from molar_amd._lib import MolarHipError
+    rng = np.random.default_rng(12)
+    xyz, tails, bonds, n1, nN = _random_tails(rng, 4, 200)
+    with pytest.raises(MolarHipError) as e:
+        eng.lipid_tail_order(xyz, [tails[0][:2]], 0, [n1[0]], [bonds[0][:1]])
+    assert e.value.code == 7                                       # TailTooShort (measure.rs:281-283)
+    with pytest.raises(MolarHipError) as e:
+        eng.lipid_tail_order(xyz, [tails[0]], 0, [nN[0][:3]], [bonds[0]])
+    assert e.value.code == 8                                       # NormalsCount (:285-287)
+    with pytest.raises(MolarHipError) as e:
+        eng.lipid_tail_order(xyz, [tails[0]], 1, [n1[0]], [bonds[0][:-1]])
+    assert e.value.code == 9                                       # BondOrderCount (:289-291)
