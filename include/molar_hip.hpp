@@ -1,0 +1,621 @@
+// molar_hip.hpp — C++17 host side of the engine, above the C ABI (molar_hip.h).
+//
+// The reference's host code is Rust; this image has no Rust toolchain, so the compiled-language
+// mirror of MolAR's interface for the accelerated path is this header.  Names, argument meaning
+// and error behaviour follow the reference (paths under /root/reference/):
+//   PbcDims, PBC_FULL/PBC_NONE, PeriodicBox            molar/src/periodic_box.rs:68-435
+//   distance_search_{single,double,double_vdw}(_pbc),
+//   distance_search_within(_pbc), DistanceSearchOutput molar/src/distance_search.rs:6-26,519-954
+//   Measure / Modify methods on a bound selection      molar/src/measure.rs:20-482, modify.rs:15-63
+//   rmsd, rmsd_mw, fit_transform(_at_origin)           molar/src/measure.rs:485-558
+//   MeasureError / PeriodicBoxError / LipidOrderError  measure.rs:718-762, periodic_box.rs:131-144
+//   AnalysisTask, AnalysisContext, TrajAnalysisArgs,
+//   process_suffix, run()                              molar/src/analysis_task.rs:12-313
+// File formats and the selection language are out of scope: frames come from a FrameSource.
+// Header-only; link with -lmolar_hip (or dlopen it and pass the handle — see INTEGRATION.md).
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "molar_hip.h"
+
+namespace molar {
+
+using Float = float;          // aliases.rs:10-13
+using usize = uint64_t;
+
+struct Vector3f {
+    Float x = 0, y = 0, z = 0;
+    Float &operator[](int d) { return d == 0 ? x : (d == 1 ? y : z); }
+    Float operator[](int d) const { return d == 0 ? x : (d == 1 ? y : z); }
+};
+using Pos = Vector3f;         // Point3<Float>, bit-compatible with xyzxyz... (io/xtc_handler.rs:89-92)
+static_assert(sizeof(Pos) == 12, "Pos must be three packed floats");
+
+// column-major 3x3 like nalgebra::Matrix3
+struct Matrix3f {
+    std::array<Float, 9> m{};
+    Float &operator()(int r, int c) { return m[c * 3 + r]; }
+    Float operator()(int r, int c) const { return m[c * 3 + r]; }
+};
+
+// ---------------------------------------------------------------- errors
+
+struct MolarError : std::runtime_error {
+    int code;
+    MolarError(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+struct MeasureError : MolarError {          // measure.rs:732-762
+    enum Kind { Sizes = 1, ZeroMass = 2, Svd = 3, Pbc = 4, LipidOrder = 7 };
+    using MolarError::MolarError;
+};
+struct PeriodicBoxError : MolarError {      // periodic_box.rs:131-144
+    enum Kind { NoPbc = 4, ZeroLengthVector = 5, InverseFailed = 6, AngleTooSmall = 10 };
+    using MolarError::MolarError;
+};
+struct LipidOrderError : MolarError {       // measure.rs:718-729
+    enum Kind { TailTooShort = 7, NormalsCount = 8, BondOrderCount = 9 };
+    using MolarError::MolarError;
+};
+
+inline void check(int rc) {
+    if (rc == MOLAR_HIP_OK) return;
+    const std::string msg = molar_hip_last_error();
+    if (rc >= 7 && rc <= 9) throw LipidOrderError(rc, msg);
+    if (rc == 4 || rc == 5 || rc == 6 || rc == 10) throw PeriodicBoxError(rc, msg);
+    if (rc >= 1 && rc <= 3) throw MeasureError(rc, msg);
+    throw MolarError(rc, msg);
+}
+
+// ---------------------------------------------------------------- PbcDims / PeriodicBox
+
+class PbcDims {                              // periodic_box.rs:68-123
+    uint8_t v_ = 0;
+
+   public:
+    PbcDims() = default;
+    explicit constexpr PbcDims(uint8_t raw) : v_(raw) {}
+    static PbcDims make(bool x, bool y, bool z) {   // PbcDims::new
+        PbcDims p;
+        p.set_dim(0, x); p.set_dim(1, y); p.set_dim(2, z);
+        return p;
+    }
+    void set_dim(size_t n, bool val) {
+        if (n > 2) throw std::out_of_range("pbc has only 3 dimentions");
+        if (val) v_ |= (uint8_t)(1u << n); else v_ &= (uint8_t)~(1u << n);
+    }
+    bool get_dim(size_t n) const {
+        if (n > 2) throw std::out_of_range("pbc has only 3 dimentions");
+        return (v_ & (1u << n)) != 0;
+    }
+    bool any() const { return (v_ & 7u) != 0; }
+    uint8_t raw() const { return v_; }
+    bool operator==(const PbcDims &o) const { return v_ == o.v_; }
+    bool operator!=(const PbcDims &o) const { return v_ != o.v_; }
+};
+constexpr PbcDims PBC_FULL{7};               // periodic_box.rs:126
+constexpr PbcDims PBC_NONE{0};               // periodic_box.rs:128
+
+class PeriodicBox {                          // periodic_box.rs:15-23,146-435
+    molar_hip_box b_{};
+
+   public:
+    static PeriodicBox from_matrix(const Matrix3f &m) {
+        PeriodicBox p;
+        check(molar_hip_box_from_matrix(m.m.data(), &p.b_));
+        return p;
+    }
+    static PeriodicBox from_vectors_angles(Float a, Float b, Float c, Float alpha, Float beta, Float gamma) {
+        PeriodicBox p;
+        check(molar_hip_box_from_vectors_angles(a, b, c, alpha, beta, gamma, &p.b_));
+        return p;
+    }
+    Matrix3f get_matrix() const {
+        Matrix3f m;
+        for (int k = 0; k < 9; ++k) m.m[k] = b_.m[k];
+        return m;
+    }
+    const float *colmajor9() const { return b_.m; }
+    size_t n_tric_corrections() const { return (size_t)b_.nshift; }
+    Vector3f shortest_vector_dims(const Vector3f &v, PbcDims dims) const {
+        Vector3f o;
+        molar_hip_box_shortest_vector(&b_, &v.x, dims.raw(), &o.x);
+        return o;
+    }
+    Vector3f shortest_vector(const Vector3f &v) const { return shortest_vector_dims(v, PBC_FULL); }
+    Pos closest_image_dims(const Pos &p, const Pos &target, PbcDims dims) const {
+        const Vector3f s = shortest_vector_dims({p.x - target.x, p.y - target.y, p.z - target.z}, dims);
+        return {target.x + s.x, target.y + s.y, target.z + s.z};
+    }
+    Pos closest_image(const Pos &p, const Pos &target) const { return closest_image_dims(p, target, PBC_FULL); }
+    Float distance_squared(const Pos &p1, const Pos &p2, PbcDims dims) const {
+        const Vector3f s = shortest_vector_dims({p2.x - p1.x, p2.y - p1.y, p2.z - p1.z}, dims);
+        return (s.x * s.x + s.y * s.y) + s.z * s.z;
+    }
+    Float distance(const Pos &p1, const Pos &p2, PbcDims dims) const { return std::sqrt(distance_squared(p1, p2, dims)); }
+    Vector3f get_lab_extents() const {
+        Vector3f o;
+        molar_hip_box_lab_extents(&b_, &o.x);
+        return o;
+    }
+    bool is_triclinic() const {
+        return b_.m[3] != 0 || b_.m[6] != 0 || b_.m[1] != 0 || b_.m[7] != 0 || b_.m[2] != 0 || b_.m[5] != 0;
+    }
+};
+
+// ---------------------------------------------------------------- engine handle
+
+class Engine {                               // molar_hip_ctx, one per thread / GPU
+    molar_hip_ctx *ctx_;
+
+   public:
+    explicit Engine(int device = 0) : ctx_(molar_hip_create(device)) {
+        if (!ctx_) throw MolarError(MOLAR_HIP_ERR_HIP, molar_hip_last_error());
+    }
+    ~Engine() { molar_hip_destroy(ctx_); }
+    Engine(const Engine &) = delete;
+    Engine &operator=(const Engine &) = delete;
+    molar_hip_ctx *ctx() const { return ctx_; }
+    static Engine &global() {                // process-wide default, like TprPlugin::get_cached
+        static Engine e(0);
+        return e;
+    }
+};
+
+// ---------------------------------------------------------------- data model (only what the path reads)
+
+struct State {                               // state.rs:22-28
+    std::vector<Pos> coords;
+    std::optional<PeriodicBox> pbox;
+    Float time = 0;
+    Float get_time() const { return time; }
+};
+struct Topology {                            // atom_storage.rs: SoA columns
+    std::vector<Float> masses;
+    std::vector<Float> vdw;
+};
+struct IsometryMatrix3 {                     // p -> R p + t
+    Matrix3f R;
+    Vector3f t;
+};
+enum class OrderType { Sz = 0, Scd = 1, ScdCorr = 2 };   // measure.rs:708-716
+
+class System {                               // selection/system.rs: topology + current state
+   public:
+    Topology top;
+    State state;
+    System(Topology t, State s) : top(std::move(t)), state(std::move(s)) {
+        if (top.masses.size() != state.coords.size())
+            throw MolarError(MOLAR_HIP_ERR_INVALID_ARGUMENT, "topology and state sizes differ");
+    }
+    size_t len() const { return state.coords.size(); }
+    void set_state(State s) {                // system.rs:230-236 (mem::replace, size checked)
+        if (s.coords.size() != state.coords.size())
+            throw MolarError(MOLAR_HIP_ERR_INVALID_ARGUMENT, "incompatible state size");
+        state = std::move(s);
+    }
+};
+
+// A selection bound to a System: sorted, non-empty index set (sel.rs:10-31) + Measure/Modify.
+class SelBound {
+    System *sys_;
+    std::vector<usize> index_;
+    Engine *eng_;
+
+   public:
+    SelBound(System &sys, std::vector<usize> index, Engine &eng = Engine::global()) : sys_(&sys), index_(std::move(index)), eng_(&eng) {
+        if (index_.empty()) throw MolarError(MOLAR_HIP_ERR_INVALID_ARGUMENT, "selection is empty");   // sel.rs:13-19
+    }
+    static SelBound all(System &sys, Engine &eng = Engine::global()) {
+        std::vector<usize> idx(sys.len());
+        for (size_t k = 0; k < idx.size(); ++k) idx[k] = k;
+        return SelBound(sys, std::move(idx), eng);
+    }
+    size_t len() const { return index_.size(); }
+    const std::vector<usize> &get_index_slice() const { return index_; }   // IndexSliceProvider
+    const float *coords_ptr() const { return &sys_->state.coords[0].x; }   // PosProvider (whole frame)
+    float *coords_ptr_mut() { return &sys_->state.coords[0].x; }
+    size_t natoms() const { return sys_->len(); }
+    const float *masses() const { return sys_->top.masses.data(); }
+    const PeriodicBox &require_box() const {                               // BoxProvider::require_box
+        if (!sys_->state.pbox) throw PeriodicBoxError(PeriodicBoxError::NoPbc, "pbc operation withon periodic box");
+        return *sys_->state.pbox;
+    }
+    System &system() const { return *sys_; }
+    molar_hip_ctx *ctx() const { return eng_->ctx(); }
+
+    // ---- Measure (measure.rs:20-482)
+    std::pair<Pos, Pos> min_max() const {
+        Pos lo, hi;
+        check(molar_hip_min_max(ctx(), coords_ptr(), natoms(), index_.data(), index_.size(), &lo.x, &hi.x));
+        return {lo, hi};
+    }
+    Pos center_of_geometry() const {
+        Pos o;
+        check(molar_hip_center_of_geometry(ctx(), coords_ptr(), natoms(), index_.data(), index_.size(), &o.x));
+        return o;
+    }
+    Pos center_of_mass() const {
+        Pos o;
+        check(molar_hip_center_of_mass(ctx(), coords_ptr(), natoms(), index_.data(), index_.size(), masses(), &o.x));
+        return o;
+    }
+    Pos center_of_geometry_pbc_dims(PbcDims dims) const {
+        Pos o;
+        check(molar_hip_center_of_geometry_pbc(ctx(), coords_ptr(), natoms(), index_.data(), index_.size(),
+                                               require_box().colmajor9(), dims.raw(), &o.x));
+        return o;
+    }
+    Pos center_of_geometry_pbc() const { return center_of_geometry_pbc_dims(PBC_FULL); }
+    Pos center_of_mass_pbc_dims(PbcDims dims) const {
+        Pos o;
+        check(molar_hip_center_of_mass_pbc(ctx(), coords_ptr(), natoms(), index_.data(), index_.size(), masses(),
+                                           require_box().colmajor9(), dims.raw(), &o.x));
+        return o;
+    }
+    Pos center_of_mass_pbc() const { return center_of_mass_pbc_dims(PBC_FULL); }
+    Float gyration() const {
+        Float o;
+        check(molar_hip_gyration(ctx(), coords_ptr(), natoms(), index_.data(), index_.size(), masses(), nullptr, &o));
+        return o;
+    }
+    Float gyration_pbc() const {
+        Float o;
+        check(molar_hip_gyration(ctx(), coords_ptr(), natoms(), index_.data(), index_.size(), masses(),
+                                 require_box().colmajor9(), &o));
+        return o;
+    }
+    std::pair<Vector3f, Matrix3f> inertia() const {
+        Vector3f m; Matrix3f a;
+        check(molar_hip_inertia(ctx(), coords_ptr(), natoms(), index_.data(), index_.size(), masses(), nullptr, &m.x,
+                                a.m.data(), nullptr));
+        return {m, a};
+    }
+    std::pair<Vector3f, Matrix3f> inertia_pbc() const {
+        Vector3f m; Matrix3f a;
+        check(molar_hip_inertia(ctx(), coords_ptr(), natoms(), index_.data(), index_.size(), masses(),
+                                require_box().colmajor9(), &m.x, a.m.data(), nullptr));
+        return {m, a};
+    }
+    Float rmsd(const SelBound &other) const;
+    std::vector<Float> lipid_tail_order(OrderType ot, const std::vector<Vector3f> &normals,
+                                        const std::vector<uint8_t> &bond_orders) const {
+        // size checks of measure.rs:281-291, same order, same errors
+        if (len() < 3) throw LipidOrderError(LipidOrderError::TailTooShort, "tail should have at least 3 carbons");
+        if (normals.size() != 1 && normals.size() != len() - 2)
+            throw LipidOrderError(LipidOrderError::NormalsCount, "wrong number of normals");
+        if (bond_orders.size() != len() - 1)
+            throw LipidOrderError(LipidOrderError::BondOrderCount, "wrong number of bond orders");
+        const uint64_t toff[2] = {0, len()}, noff[2] = {0, normals.size()};
+        std::vector<Float> out(len() - 2);
+        check(molar_hip_lipid_tail_order(ctx(), coords_ptr(), natoms(), index_.data(), toff, 1, (int)ot, &normals[0].x, noff,
+                                         bond_orders.data(), out.data()));
+        return out;
+    }
+
+    // ---- Modify (modify.rs:15-63)
+    void apply_transform(const IsometryMatrix3 &tr) {
+        check(molar_hip_apply_transform(ctx(), coords_ptr_mut(), natoms(), index_.data(), index_.size(), tr.R.m.data(), &tr.t.x));
+    }
+    void unwrap_simple_dim(PbcDims dims) {
+        check(molar_hip_unwrap_simple(ctx(), coords_ptr_mut(), natoms(), index_.data(), index_.size(),
+                                      require_box().colmajor9(), dims.raw()));
+    }
+    void unwrap_simple() { unwrap_simple_dim(PBC_FULL); }
+};
+
+// ---- free functions of measure.rs:485-558
+inline Float rmsd(const SelBound &s1, const SelBound &s2) {
+    Float o;
+    check(molar_hip_rmsd(s1.ctx(), s1.coords_ptr(), s1.natoms(), s1.get_index_slice().data(), s1.len(), s2.coords_ptr(),
+                         s2.natoms(), s2.get_index_slice().data(), s2.len(), &o));
+    return o;
+}
+inline Float SelBound::rmsd(const SelBound &other) const { return molar::rmsd(*this, other); }
+inline Float rmsd_mw(const SelBound &s1, const SelBound &s2) {
+    Float o;
+    check(molar_hip_rmsd_mw(s1.ctx(), s1.coords_ptr(), s1.natoms(), s1.get_index_slice().data(), s1.len(), s1.masses(),
+                            s2.coords_ptr(), s2.natoms(), s2.get_index_slice().data(), s2.len(), &o));
+    return o;
+}
+inline IsometryMatrix3 fit_transform(const SelBound &s1, const SelBound &s2) {
+    IsometryMatrix3 tr;
+    check(molar_hip_fit_transform(s1.ctx(), s1.coords_ptr(), s1.natoms(), s1.get_index_slice().data(), s1.len(), s1.masses(),
+                                  s2.coords_ptr(), s2.natoms(), s2.get_index_slice().data(), s2.len(), s2.masses(), 0,
+                                  tr.R.m.data(), &tr.t.x));
+    return tr;
+}
+inline IsometryMatrix3 fit_transform_at_origin(const SelBound &s1, const SelBound &s2) {
+    IsometryMatrix3 tr;
+    check(molar_hip_fit_transform(s1.ctx(), s1.coords_ptr(), s1.natoms(), s1.get_index_slice().data(), s1.len(), s1.masses(),
+                                  s2.coords_ptr(), s2.natoms(), s2.get_index_slice().data(), s2.len(), s2.masses(), 1,
+                                  tr.R.m.data(), &tr.t.x));
+    return tr;
+}
+
+// ---------------------------------------------------------------- distance search (distance_search.rs)
+
+// DistanceSearchOutput (:6-26): usize | (usize,usize) | (usize,usize,Float)
+template <class T> struct DistanceSearchOutput;
+template <> struct DistanceSearchOutput<usize> {
+    static usize from_ijd(usize i, usize, Float) { return i; }
+};
+template <> struct DistanceSearchOutput<std::pair<usize, usize>> {
+    static std::pair<usize, usize> from_ijd(usize i, usize j, Float) { return {i, j}; }
+};
+template <> struct DistanceSearchOutput<std::tuple<usize, usize, Float>> {
+    static std::tuple<usize, usize, Float> from_ijd(usize i, usize j, Float d) { return {i, j, d}; }
+};
+
+namespace detail {
+template <class T>
+std::vector<T> run_search(molar_hip_ctx *ctx, const molar_hip_search_desc &d) {
+    uint64_t n = 0;
+    check(molar_hip_search_count(ctx, &d, &n));
+    std::vector<T> out;
+    out.reserve(n);
+    if (d.kind == MOLAR_HIP_SEARCH_WITHIN) {
+        std::vector<uint64_t> ids(n);
+        check(molar_hip_search_fill_ids(ctx, ids.data()));
+        for (uint64_t k = 0; k < n; ++k) out.push_back(DistanceSearchOutput<T>::from_ijd(ids[k], 0, 0));
+        return out;
+    }
+    std::vector<uint64_t> i(n), j(n);
+    std::vector<float> dist(n);
+    check(molar_hip_search_fill_usize(ctx, i.data(), j.data(), dist.data()));
+    for (uint64_t k = 0; k < n; ++k) out.push_back(DistanceSearchOutput<T>::from_ijd(i[k], j[k], dist[k]));
+    return out;
+}
+inline molar_hip_search_desc desc(int kind, Float cutoff, const SelBound &s1, const SelBound *s2, bool ids_local,
+                                  const PeriodicBox *box, PbcDims dims) {
+    molar_hip_search_desc d{};
+    d.kind = kind;
+    d.cutoff = cutoff;
+    d.xyz1 = s1.coords_ptr(); d.natoms1 = s1.natoms(); d.idx1 = s1.get_index_slice().data(); d.n1 = s1.len();
+    if (s2) { d.xyz2 = s2->coords_ptr(); d.natoms2 = s2->natoms(); d.idx2 = s2->get_index_slice().data(); d.n2 = s2->len(); }
+    d.ids_local = ids_local ? 1 : 0;
+    d.box9 = box ? box->colmajor9() : nullptr;
+    d.pbc = dims.raw();
+    return d;
+}
+}  // namespace detail
+
+// ids: the reference takes an iterator; the two uses are the selection's own indices
+// (sel.iter_index(), ids_local = false) and 0..n (modify.rs:78, ids_local = true).
+template <class T>
+std::vector<T> distance_search_single(Float cutoff, const SelBound &data, bool ids_local = false) {            // :892-915
+    return detail::run_search<T>(data.ctx(), detail::desc(MOLAR_HIP_SEARCH_SINGLE, cutoff, data, nullptr, ids_local, nullptr, PBC_NONE));
+}
+template <class T>
+std::vector<T> distance_search_single_pbc(Float cutoff, const SelBound &data, const PeriodicBox &pbox, PbcDims pbc_dims,
+                                          bool ids_local = false) {                                            // :928-954
+    return detail::run_search<T>(data.ctx(), detail::desc(MOLAR_HIP_SEARCH_SINGLE, cutoff, data, nullptr, ids_local, &pbox, pbc_dims));
+}
+template <class T>
+std::vector<T> distance_search_double(Float cutoff, const SelBound &d1, const SelBound &d2, bool ids_local = false) {   // :659-698
+    return detail::run_search<T>(d1.ctx(), detail::desc(MOLAR_HIP_SEARCH_DOUBLE, cutoff, d1, &d2, ids_local, nullptr, PBC_NONE));
+}
+template <class T>
+std::vector<T> distance_search_double_pbc(Float cutoff, const SelBound &d1, const SelBound &d2, const PeriodicBox &pbox,
+                                          PbcDims pbc_dims, bool ids_local = false) {                          // :713-754
+    return detail::run_search<T>(d1.ctx(), detail::desc(MOLAR_HIP_SEARCH_DOUBLE, cutoff, d1, &d2, ids_local, &pbox, pbc_dims));
+}
+template <class T>
+std::vector<T> distance_search_double_vdw(const SelBound &d1, const SelBound &d2, const std::vector<Float> &vdw1,
+                                          const std::vector<Float> &vdw2) {                                    // :767-814 (local ids)
+    auto d = detail::desc(MOLAR_HIP_SEARCH_DOUBLE_VDW, 0, d1, &d2, true, nullptr, PBC_NONE);
+    d.vdw1 = vdw1.data(); d.vdw2 = vdw2.data();
+    return detail::run_search<T>(d1.ctx(), d);
+}
+template <class T>
+std::vector<T> distance_search_double_vdw_pbc(const SelBound &d1, const SelBound &d2, const std::vector<Float> &vdw1,
+                                              const std::vector<Float> &vdw2, const PeriodicBox &pbox, PbcDims pbc_dims) {   // :829-879
+    auto d = detail::desc(MOLAR_HIP_SEARCH_DOUBLE_VDW, 0, d1, &d2, true, &pbox, pbc_dims);
+    d.vdw1 = vdw1.data(); d.vdw2 = vdw2.data();
+    return detail::run_search<T>(d1.ctx(), d);
+}
+inline std::vector<usize> distance_search_within(Float cutoff, const SelBound &d1, const SelBound &d2, const Vector3f &lower,
+                                                 const Vector3f &upper) {                                      // :519-558
+    auto d = detail::desc(MOLAR_HIP_SEARCH_WITHIN, cutoff, d1, &d2, false, nullptr, PBC_NONE);
+    d.lower3 = &lower.x; d.upper3 = &upper.x;
+    return detail::run_search<usize>(d1.ctx(), d);
+}
+inline std::vector<usize> distance_search_within_pbc(Float cutoff, const SelBound &d1, const SelBound &d2,
+                                                     const PeriodicBox &pbox, PbcDims pbc_dims) {              // :560-598
+    return detail::run_search<usize>(d1.ctx(), detail::desc(MOLAR_HIP_SEARCH_WITHIN, cutoff, d1, &d2, false, &pbox, pbc_dims));
+}
+
+// ---------------------------------------------------------------- analysis task driver (analysis_task.rs)
+
+struct AnalysisError : MolarError {          // analysis_task.rs:40-75
+    enum Kind { ParseFloat = 201, ParseInt = 202, InvalidSuffix = 203, NoFramesConsumed = 204, PreProcess = 205,
+                ProcessFrame = 206, PostProcess = 207, Arg = 208, NoTraj = 209 };
+    using MolarError::MolarError;
+};
+
+struct TrajAnalysisArgs {                    // analysis_task.rs:12-38
+    std::vector<std::string> files;
+    size_t log = 100;
+    std::string begin = "0";
+    std::string end = "";
+    size_t skip = 1;
+    bool use_struct_file = false;
+    std::vector<std::string> rest;           // arguments the task itself consumes (A::augment_args)
+
+    static TrajAnalysisArgs parse(const std::vector<std::string> &argv) {
+        TrajAnalysisArgs a;
+        bool have_files = false;
+        auto need = [&](size_t k) -> const std::string & {
+            if (k >= argv.size()) throw AnalysisError(AnalysisError::Arg, "argument parsing: missing value for " + argv[k - 1]);
+            return argv[k];
+        };
+        for (size_t k = 0; k < argv.size(); ++k) {
+            const std::string &s = argv[k];
+            if (s == "-f" || s == "--files") {
+                have_files = true;
+                while (k + 1 < argv.size() && argv[k + 1].rfind("-", 0) != 0) a.files.push_back(argv[++k]);
+            } else if (s == "--log") {
+                a.log = std::stoull(need(++k));
+            } else if (s == "-b" || s == "--begin") {
+                a.begin = need(++k);
+            } else if (s == "-e" || s == "--end") {
+                a.end = need(++k);
+            } else if (s == "--skip") {
+                a.skip = std::stoull(need(++k));
+                if (a.skip < 1) throw AnalysisError(AnalysisError::Arg, "argument parsing: --skip must be >= 1");
+            } else if (s == "--use_struct_file") {
+                a.use_struct_file = true;
+            } else {
+                a.rest.push_back(s);
+            }
+        }
+        if (!have_files || a.files.empty()) throw AnalysisError(AnalysisError::Arg, "argument parsing: -f/--files is required");
+        return a;
+    }
+};
+
+// process_suffix (analysis_task.rs:82-110): "" -> no limit; bare number / "fr" -> frame; ps/ns/us -> time in ps
+inline std::pair<std::optional<size_t>, std::optional<Float>> process_suffix(const std::string &in) {
+    const auto b = in.find_first_not_of(" \t\n\r");
+    if (b == std::string::npos) return {std::nullopt, std::nullopt};
+    const std::string s = in.substr(b, in.find_last_not_of(" \t\n\r") - b + 1);
+    auto trim = [](std::string t) {
+        const auto x = t.find_first_not_of(" \t");
+        if (x == std::string::npos) return std::string();
+        return t.substr(x, t.find_last_not_of(" \t") - x + 1);
+    };
+    auto parse_usize = [](const std::string &t, size_t &out) {
+        if (t.empty()) return false;
+        for (char ch : t)
+            if (ch < '0' || ch > '9') return false;
+        try { out = std::stoull(t); } catch (...) { return false; }
+        return true;
+    };
+    auto ends_with = [&](const char *suf) { const std::string u(suf); return s.size() >= u.size() && s.compare(s.size() - u.size(), u.size(), u) == 0; };
+    size_t fr;
+    if (parse_usize(s, fr)) return {fr, std::nullopt};
+    if (ends_with("fr")) {
+        if (!parse_usize(trim(s.substr(0, s.size() - 2)), fr)) throw AnalysisError(AnalysisError::ParseInt, "invalid digit found in string");
+        return {fr, std::nullopt};
+    }
+    const std::pair<const char *, Float> units[] = {{"ps", 1.0f}, {"ns", 1000.0f}, {"us", 1000000.0f}};
+    for (const auto &u : units)
+        if (ends_with(u.first)) {
+            const std::string num = trim(s.substr(0, s.size() - 2));
+            size_t used = 0;
+            Float v;
+            try { v = std::stof(num, &used); } catch (...) { throw AnalysisError(AnalysisError::ParseFloat, "invalid float literal"); }
+            if (used != num.size()) throw AnalysisError(AnalysisError::ParseFloat, "invalid float literal");
+            return {std::nullopt, v * u.second};
+        }
+    throw AnalysisError(AnalysisError::InvalidSuffix, "invalid time suffix, 'fr', 'ps', 'ns', 'us' allowed");
+}
+
+// Where frames come from (the reference opens files; IO formats are out of scope here).
+struct FrameSource {
+    virtual ~FrameSource() = default;
+    virtual Topology read_topology(const std::string &structure_file) = 0;
+    virtual State read_structure_state(const std::string &structure_file) = 0;
+    // Opens trajectory `file`; the returned callable yields frames until it returns nullopt.
+    // `skip_to_frame` / `skip_to_time` (io.rs random access) are applied before the first call.
+    virtual std::function<std::optional<State>()> open(const std::string &file, std::optional<size_t> skip_to_frame,
+                                                       std::optional<Float> skip_to_time) = 0;
+};
+
+template <class A>
+struct AnalysisContext {                     // analysis_task.rs:309-313
+    System sys;
+    size_t consumed_frames = 0;
+    A args;
+};
+
+// AnalysisTask<A> (analysis_task.rs:113-123).  A must be constructible from the unconsumed arguments.
+template <class Derived, class A>
+class AnalysisTask {
+   public:
+    // Derived provides:  explicit Derived(AnalysisContext<A>&);   [fn new]
+    //                    void process_frame(AnalysisContext<A>&); void post_process(AnalysisContext<A>&);
+    //                    static std::string task_name();
+    static void run(const std::vector<std::string> &argv, FrameSource &src) {          // :124-280
+        const TrajAnalysisArgs traj_args = TrajAnalysisArgs::parse(argv);
+        if (!traj_args.use_struct_file && traj_args.files.size() < 2)
+            throw AnalysisError(AnalysisError::NoTraj, "at least one trajectory required if 'use_struct_file' is not set");
+        std::unique_ptr<Derived> inst;
+        std::unique_ptr<AnalysisContext<A>> context;
+        const auto [begin_frame, begin_time] = process_suffix(traj_args.begin);
+        const auto [end_frame, end_time] = process_suffix(traj_args.end);
+        size_t consumed_frames = 0, global_frame = 0, phase = 0;
+        const bool random_access_begin = traj_args.files.size() - 1 == 1;
+
+        auto init = [&](Topology top, State state) {                                   // :282-306
+            context.reset(new AnalysisContext<A>{System(std::move(top), std::move(state)), 0, A(traj_args.rest)});
+            try { inst.reset(new Derived(*context)); }
+            catch (const AnalysisError &) { throw; }
+            catch (const std::exception &e) { throw AnalysisError(AnalysisError::PreProcess, std::string("in task pre_process: ") + e.what()); }
+            try { inst->process_frame(*context); }
+            catch (const std::exception &e) { throw AnalysisError(AnalysisError::ProcessFrame, std::string("in task process_frame: ") + e.what()); }
+        };
+
+        if (traj_args.use_struct_file) {                                               // :168-179
+            init(src.read_topology(traj_args.files[0]), src.read_structure_state(traj_args.files[0]));
+            consumed_frames += 1;
+        }
+        bool stop = false;
+        for (size_t fidx = 1; fidx < traj_args.files.size() && !stop; ++fidx) {         // :184
+            std::optional<size_t> sk_fr;
+            std::optional<Float> sk_t;
+            if (random_access_begin) {                                                  // :189-198
+                if (begin_frame) {
+                    if (*begin_frame > 0) { sk_fr = begin_frame; global_frame = *begin_frame; }
+                } else if (begin_time) {
+                    sk_t = begin_time;
+                }
+            }
+            auto next = src.open(traj_args.files[fidx], sk_fr, sk_t);
+            while (auto st = next()) {                                                 // :202
+                State &state = *st;
+                if (!random_access_begin) {                                            // :205-215
+                    bool before_begin = false;
+                    if (begin_frame) before_begin = global_frame < *begin_frame;
+                    else if (begin_time) before_begin = state.get_time() < *begin_time;
+                    if (before_begin) { global_frame += 1; continue; }
+                }
+                if ((end_frame && global_frame >= *end_frame) || (end_time && state.get_time() > *end_time)) {   // :219-223
+                    stop = true;
+                    break;
+                }
+                const bool keep = phase % traj_args.skip == 0;                          // :229-234
+                phase += 1;
+                global_frame += 1;
+                if (!keep) continue;
+                if (context) {                                                         // :245-252
+                    context->sys.set_state(std::move(state));
+                    try { inst->process_frame(*context); }
+                    catch (const std::exception &e) { throw AnalysisError(AnalysisError::ProcessFrame, std::string("in task process_frame: ") + e.what()); }
+                } else {                                                               // :253-262
+                    init(src.read_topology(traj_args.files[0]), std::move(state));
+                }
+                consumed_frames += 1;
+                context->consumed_frames += 1;
+            }
+        }
+        if (inst) {                                                                    // :270-277
+            try { inst->post_process(*context); }
+            catch (const std::exception &e) { throw AnalysisError(AnalysisError::PostProcess, std::string("in task post_process: ") + e.what()); }
+        } else {
+            throw AnalysisError(AnalysisError::NoFramesConsumed, "no frames consumed");
+        }
+    }
+};
+
+}  // namespace molar

@@ -1,0 +1,164 @@
+// CPU-only tests of the C++ host mirror: process_suffix (the reference's five tests,
+// molar/src/analysis_task.rs:329-366, restated value for value) and the frame-window logic of
+// AnalysisTask::run (analysis_task.rs:124-280) driven by a mock FrameSource.  No GPU calls.
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "molar_hip.hpp"
+
+using namespace molar;
+
+static int failures = 0;
+#define EXPECT(cond)                                                         \
+    do {                                                                     \
+        if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+template <class F>
+static bool throws_kind(F f, int kind) {
+    try { f(); } catch (const AnalysisError &e) { return e.code == kind; } catch (...) { return false; }
+    return false;
+}
+
+static void suffix_tests() {
+    using R = std::pair<std::optional<size_t>, std::optional<Float>>;
+    // suffix_empty_is_no_limit
+    EXPECT(process_suffix("") == R(std::nullopt, std::nullopt));
+    EXPECT(process_suffix("   ") == R(std::nullopt, std::nullopt));
+    // suffix_bare_number_is_frame
+    EXPECT(process_suffix("0") == R(0, std::nullopt));
+    EXPECT(process_suffix("5") == R(5, std::nullopt));
+    EXPECT(process_suffix("42") == R(42, std::nullopt));
+    EXPECT(process_suffix("100") == R(100, std::nullopt));
+    // suffix_explicit_frame
+    EXPECT(process_suffix("5fr") == R(5, std::nullopt));
+    EXPECT(process_suffix("100fr") == R(100, std::nullopt));
+    // suffix_time_units_convert_to_ps
+    EXPECT(process_suffix("5ps") == R(std::nullopt, 5.0f));
+    EXPECT(process_suffix("2ns") == R(std::nullopt, 2000.0f));
+    EXPECT(process_suffix("1us") == R(std::nullopt, 1000000.0f));
+    EXPECT(process_suffix("1.5ns") == R(std::nullopt, 1500.0f));
+    // suffix_invalid
+    EXPECT(throws_kind([] { process_suffix("5km"); }, AnalysisError::InvalidSuffix));
+    bool threw = false;
+    try { process_suffix("fr"); } catch (const AnalysisError &) { threw = true; }
+    EXPECT(threw);
+}
+
+// ---- mock trajectory: file "tA" has frames with times 0,10,20,...; "tB" continues
+struct MockSource : FrameSource {
+    size_t natoms = 4;
+    std::vector<std::pair<std::string, std::vector<Float>>> files{{"tA", {0, 10, 20, 30, 40}}, {"tB", {50, 60, 70}}};
+    int topology_reads = 0;
+    Topology read_topology(const std::string &) override {
+        ++topology_reads;
+        return Topology{std::vector<Float>(natoms, 1.0f), {}};
+    }
+    State read_structure_state(const std::string &) override {
+        State s;
+        s.coords.assign(natoms, Pos{});
+        s.time = -1.0f;
+        return s;
+    }
+    std::function<std::optional<State>()> open(const std::string &file, std::optional<size_t> skip_to_frame,
+                                               std::optional<Float> skip_to_time) override {
+        const std::vector<Float> *times = nullptr;
+        for (auto &f : files)
+            if (f.first == file) times = &f.second;
+        auto pos = std::make_shared<size_t>(0);
+        if (skip_to_frame) *pos = *skip_to_frame;
+        if (skip_to_time)
+            while (*pos < times->size() && (*times)[*pos] < *skip_to_time) ++*pos;
+        const size_t n = natoms;
+        return [times, pos, n]() -> std::optional<State> {
+            if (!times || *pos >= times->size()) return std::nullopt;
+            State s;
+            s.coords.assign(n, Pos{});
+            s.time = (*times)[(*pos)++];
+            return s;
+        };
+    }
+};
+
+struct NoArgs {
+    explicit NoArgs(const std::vector<std::string> &) {}
+};
+
+static std::vector<Float> seen;
+static std::vector<size_t> seen_consumed;
+static int post_calls = 0;
+
+struct Recorder : AnalysisTask<Recorder, NoArgs> {
+    explicit Recorder(AnalysisContext<NoArgs> &) {}
+    void process_frame(AnalysisContext<NoArgs> &ctx) {
+        seen.push_back(ctx.sys.state.get_time());
+        seen_consumed.push_back(ctx.consumed_frames);
+    }
+    void post_process(AnalysisContext<NoArgs> &) { ++post_calls; }
+    static std::string task_name() { return "recorder"; }
+};
+
+static std::vector<Float> run_with(std::vector<std::string> argv, MockSource &src) {
+    seen.clear(); seen_consumed.clear(); post_calls = 0;
+    Recorder::run(argv, src);
+    return seen;
+}
+
+static void window_tests() {
+    using V = std::vector<Float>;
+    MockSource src;
+    // single trajectory: random-access begin (:189-198), absolute exclusive end (:219-223)
+    EXPECT(run_with({"-f", "top", "tA"}, src) == (V{0, 10, 20, 30, 40}));
+    EXPECT(post_calls == 1 && src.topology_reads == 1);
+    EXPECT((seen_consumed == std::vector<size_t>{0, 1, 2, 3, 4}));
+    EXPECT(run_with({"-f", "top", "tA", "-b", "2"}, src) == (V{20, 30, 40}));
+    EXPECT(run_with({"-f", "top", "tA", "-b", "1", "-e", "4"}, src) == (V{10, 20, 30}));
+    EXPECT(run_with({"-f", "top", "tA", "-b", "15ps"}, src) == (V{20, 30, 40}));
+    EXPECT(run_with({"-f", "top", "tA", "-e", "25ps"}, src) == (V{0, 10, 20}));
+    // --skip counts from `begin`, the begin frame is always processed (:225-234)
+    EXPECT(run_with({"-f", "top", "tA", "--skip", "2"}, src) == (V{0, 20, 40}));
+    EXPECT(run_with({"-f", "top", "tA", "-b", "1", "--skip", "2"}, src) == (V{10, 30}));
+    // several files = one continuous stream; begin filtered serially (:205-215), cadence continuous
+    EXPECT(run_with({"-f", "top", "tA", "tB"}, src) == (V{0, 10, 20, 30, 40, 50, 60, 70}));
+    EXPECT(run_with({"-f", "top", "tA", "tB", "-b", "3", "-e", "7"}, src) == (V{30, 40, 50, 60}));
+    EXPECT(run_with({"-f", "top", "tA", "tB", "--skip", "3"}, src) == (V{0, 30, 60}));
+    EXPECT(run_with({"-f", "top", "tA", "tB", "-b", "45ps"}, src) == (V{50, 60, 70}));
+    // --use_struct_file: the structure's own state is frame one (:168-179)
+    EXPECT(run_with({"-f", "top", "tA", "--use_struct_file", "-e", "2"}, src) == (V{-1, 0, 10}));
+    EXPECT(run_with({"-f", "top", "--use_struct_file"}, src) == (V{-1}));
+    // errors
+    EXPECT(throws_kind([&] { run_with({"-f", "top"}, src); }, AnalysisError::NoTraj));                       // :139-141
+    EXPECT(throws_kind([&] { run_with({"-f", "top", "tA", "-b", "99"}, src); }, AnalysisError::NoFramesConsumed));   // :275-277
+    EXPECT(throws_kind([&] { run_with({"-f", "top", "tA", "-b", "5km"}, src); }, AnalysisError::InvalidSuffix));
+    EXPECT(throws_kind([&] { run_with({"--skip", "2"}, src); }, AnalysisError::Arg));
+    EXPECT(throws_kind([&] { run_with({"-f", "top", "tA", "--skip", "0"}, src); }, AnalysisError::Arg));
+}
+
+static void pbcdims_tests() {
+    PbcDims d = PbcDims::make(true, false, true);
+    EXPECT(d.get_dim(0) && !d.get_dim(1) && d.get_dim(2) && d.any());
+    EXPECT(d != PBC_FULL && PbcDims::make(true, true, true) == PBC_FULL && !PBC_NONE.any());
+    bool threw = false;
+    try { d.get_dim(3); } catch (const std::out_of_range &) { threw = true; }
+    EXPECT(threw);
+    // periodic_box.rs:559-575 through the C++ PeriodicBox (host arithmetic of the engine)
+    Matrix3f m;
+    m(0, 0) = 10; m(0, 1) = 4; m(0, 2) = -4; m(1, 1) = 10; m(2, 2) = 10;
+    const PeriodicBox pb = PeriodicBox::from_matrix(m);
+    const Float dd = pb.distance({38.9214f, 40.0078f, -34.0795f}, {-26.6187f, 40.8926f, 30.9709f}, PBC_FULL);
+    EXPECT(std::fabs(dd - 5.353627f) < 1e-3f);
+    EXPECT(pb.is_triclinic() && pb.n_tric_corrections() > 0);
+    threw = false;
+    try { PeriodicBox::from_vectors_angles(10.0f, 0.2f, 15.0f, 90.0f, 9.0f, 90.0f); } catch (const PeriodicBoxError &e) { threw = e.code == PeriodicBoxError::AngleTooSmall; }
+    EXPECT(threw);
+}
+
+int main() {
+    suffix_tests();
+    window_tests();
+    pbcdims_tests();
+    if (failures) { std::printf("%d failure(s)\n", failures); return 1; }
+    std::printf("all host-mirror CPU tests passed\n");
+    return 0;
+}

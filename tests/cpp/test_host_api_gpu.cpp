@@ -1,0 +1,249 @@
+// GPU parity of the C++ host mirror (include/molar_hip.hpp -> libmolar_hip.so) against the CPU oracle
+// (oracle/molar_oracle.h, f32 build).  The tests read like the reference's own usage: bound
+// selections, distance_search_*<T>, fit_transform / apply_transform / rmsd, an AnalysisTask.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <tuple>
+#include <vector>
+
+#include "molar_hip.hpp"
+extern "C" {
+#include "molar_oracle.h"
+}
+
+using namespace molar;
+
+static int failures = 0;
+#define EXPECT(cond)                                                         \
+    do {                                                                     \
+        if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+static uint64_t rng_state = 20240607ull;
+static double urand() {                       // SplitMix64
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) / 9007199254740992.0;
+}
+
+static State make_state(size_t n, const Matrix3f &box, double jitter, float time = 0) {
+    State s;
+    s.coords.resize(n);
+    for (size_t k = 0; k < n; ++k) {
+        const double f[3] = {urand(), urand(), urand()};
+        for (int r = 0; r < 3; ++r)
+            s.coords[k][r] = (float)(box(r, 0) * f[0] + box(r, 1) * f[1] + box(r, 2) * f[2] + jitter * (urand() - 0.5));
+    }
+    s.pbox = PeriodicBox::from_matrix(box);
+    s.time = time;
+    return s;
+}
+
+static bool close_rel(double a, double b, double rel) { return std::fabs(a - b) <= rel * std::fmax(std::fabs(a), std::fabs(b)) + 1e-7; }
+
+static void search_tests() {
+    const size_t n = 6000;
+    Matrix3f box;                              // triclinic, columns a,b,c (negative shear: reference grid complete)
+    box(0, 0) = 3.9f; box(1, 1) = 3.9f; box(2, 2) = 3.9f; box(0, 2) = -0.5f; box(1, 2) = -0.5f;
+    System sys(Topology{std::vector<Float>(n, 12.011f), std::vector<Float>(n, 0.17f)}, make_state(n, box, 0.3));
+    SelBound all = SelBound::all(sys);
+    std::vector<usize> ev, od;
+    for (usize k = 0; k < n; ++k) (k % 2 ? od : ev).push_back(k);
+    SelBound s_ev(sys, ev), s_od(sys, od);
+    const PeriodicBox &pb = all.require_box();
+    orc_box ob;
+    orc_box_from_matrix(box.m.data(), &ob);
+
+    // distance_search_single_pbc -> Vec<(usize,usize,Float)>: identical elements in identical order
+    {
+        auto got = distance_search_single_pbc<std::tuple<usize, usize, Float>>(0.6f, all, pb, PBC_FULL);
+        std::vector<uint64_t> ids(n);
+        for (size_t k = 0; k < n; ++k) ids[k] = k;
+        orc_pairs *ref = orc_search_single_pbc(0.6f, all.coords_ptr(), ids.data(), n, &ob, 7, 4);
+        EXPECT(got.size() == ref->n && ref->n > 1000);
+        bool same = got.size() == ref->n;
+        for (size_t k = 0; same && k < ref->n; ++k)
+            same = std::get<0>(got[k]) == ref->i[k] && std::get<1>(got[k]) == ref->j[k] && std::get<2>(got[k]) == ref->d[k];
+        EXPECT(same);
+        orc_pairs_free(ref);
+        // (usize,usize) projection and local ids (modify.rs:78)
+        auto pr = distance_search_single_pbc<std::pair<usize, usize>>(0.6f, s_ev, pb, PBC_FULL, true);
+        std::vector<float> pos_ev(3 * ev.size());
+        for (size_t k = 0; k < ev.size(); ++k) std::memcpy(&pos_ev[3 * k], &sys.state.coords[ev[k]].x, 12);
+        orc_pairs *rl = orc_search_single_pbc(0.6f, pos_ev.data(), nullptr, ev.size(), &ob, 7, 4);
+        bool ok = pr.size() == rl->n;
+        for (size_t k = 0; ok && k < rl->n; ++k) ok = pr[k].first == rl->i[k] && pr[k].second == rl->j[k];
+        EXPECT(ok);
+        orc_pairs_free(rl);
+    }
+    // distance_search_double (non-periodic) with global ids
+    {
+        auto got = distance_search_double<std::tuple<usize, usize, Float>>(0.5f, s_ev, s_od);
+        std::vector<float> p1(3 * ev.size()), p2(3 * od.size());
+        for (size_t k = 0; k < ev.size(); ++k) std::memcpy(&p1[3 * k], &sys.state.coords[ev[k]].x, 12);
+        for (size_t k = 0; k < od.size(); ++k) std::memcpy(&p2[3 * k], &sys.state.coords[od[k]].x, 12);
+        orc_pairs *ref = orc_search_double(0.5f, p1.data(), ev.data(), ev.size(), p2.data(), od.data(), od.size(), 4);
+        bool same = got.size() == ref->n && ref->n > 100;
+        for (size_t k = 0; same && k < ref->n; ++k)
+            same = std::get<0>(got[k]) == ref->i[k] && std::get<1>(got[k]) == ref->j[k] && std::get<2>(got[k]) == ref->d[k];
+        EXPECT(same);
+        orc_pairs_free(ref);
+        // within_pbc: usize stream with the reference's duplicates
+        auto w = distance_search_within_pbc(0.5f, s_ev, s_od, pb, PBC_FULL);
+        orc_pairs *rw = orc_search_within_pbc(0.5f, p1.data(), ev.data(), ev.size(), p2.data(), od.data(), od.size(), &ob, 7, 4);
+        bool okw = w.size() == rw->n;
+        for (size_t k = 0; okw && k < rw->n; ++k) okw = w[k] == rw->i[k];
+        EXPECT(okw);
+        orc_pairs_free(rw);
+        // vdw: local ids (:791-792)
+        std::vector<Float> v1(ev.size(), 0.17f), v2(od.size(), 0.15f);
+        auto gv = distance_search_double_vdw_pbc<std::pair<usize, usize>>(s_ev, s_od, v1, v2, pb, PBC_FULL);
+        orc_pairs *rv = orc_search_double_vdw_pbc(p1.data(), ev.size(), p2.data(), od.size(), v1.data(), v2.data(), &ob, 7, 4);
+        bool okv = gv.size() == rv->n && rv->n > 10;
+        for (size_t k = 0; okv && k < rv->n; ++k) okv = gv[k].first == rv->i[k] && gv[k].second == rv->j[k];
+        EXPECT(okv);
+        orc_pairs_free(rv);
+    }
+}
+
+static void measure_tests() {
+    const size_t n = 20000;
+    Matrix3f box;
+    box(0, 0) = 5.8f; box(1, 1) = 5.8f; box(2, 2) = 5.8f; box(0, 2) = -0.8f; box(1, 2) = -0.8f;
+    Topology top;
+    top.masses.resize(n);
+    const float cyc[4] = {1.008f, 12.011f, 14.007f, 15.999f};
+    for (size_t k = 0; k < n; ++k) top.masses[k] = cyc[k % 4];
+    System ref_sys(top, make_state(n, box, 0.0));
+    System cur_sys(top, ref_sys.state);
+    // rotate + translate + perturb the current frame
+    const double a = 0.8, ca = std::cos(a), sa = std::sin(a);
+    for (auto &p : cur_sys.state.coords) {
+        const double x = p.x, y = p.y;
+        p.x = (float)(ca * x - sa * y + 1.5 + 0.02 * (urand() - 0.5));
+        p.y = (float)(sa * x + ca * y - 2.0 + 0.02 * (urand() - 0.5));
+        p.z = (float)(p.z + 0.7 + 0.02 * (urand() - 0.5));
+    }
+    std::vector<usize> idx;
+    for (usize k = 0; k < n; k += 10) idx.push_back(k);
+    SelBound cur(cur_sys, idx), ref(ref_sys, idx);
+    const float *cx = cur.coords_ptr(), *rx = ref.coords_ptr();
+    float want3[3], wantf;
+
+    orc_center_of_mass(cx, idx.data(), idx.size(), top.masses.data(), want3);
+    const Pos com = cur.center_of_mass();
+    EXPECT(close_rel(com.x, want3[0], 3e-4) && close_rel(com.y, want3[1], 3e-4) && close_rel(com.z, want3[2], 3e-4));
+    orc_center_of_geometry(cx, idx.data(), idx.size(), want3);
+    const Pos cog = cur.center_of_geometry();
+    EXPECT(close_rel(cog.x, want3[0], 3e-4) && close_rel(cog.z, want3[2], 3e-4));
+    orc_gyration(cx, idx.data(), idx.size(), top.masses.data(), &wantf);
+    EXPECT(close_rel(cur.gyration(), wantf, 3e-4));
+    orc_rmsd(cx, idx.data(), idx.size(), rx, idx.data(), idx.size(), &wantf);
+    EXPECT(close_rel(rmsd(cur, ref), wantf, 3e-4));
+    orc_rmsd_mw(cx, idx.data(), idx.size(), top.masses.data(), rx, idx.data(), idx.size(), &wantf);
+    EXPECT(close_rel(rmsd_mw(cur, ref), wantf, 3e-4));
+    float lo[3], hi[3];
+    orc_min_max(cx, idx.data(), idx.size(), lo, hi);
+    const auto mm = cur.min_max();
+    EXPECT(mm.first.x == lo[0] && mm.first.y == lo[1] && mm.second.z == hi[2]);
+
+    // the align + RMSD loop body of benches/comparison_small.rs:17-24
+    float R[9], t[3];
+    orc_fit_transform(cx, idx.data(), idx.size(), top.masses.data(), rx, idx.data(), idx.size(), top.masses.data(), R, t);
+    const IsometryMatrix3 tr = fit_transform(cur, ref);
+    bool okR = true;
+    for (int k = 0; k < 9; ++k) okR = okR && std::fabs(tr.R.m[k] - R[k]) < 1e-4;
+    EXPECT(okR && std::fabs(tr.t.x - t[0]) < 2e-3 && std::fabs(tr.t.y - t[1]) < 2e-3 && std::fabs(tr.t.z - t[2]) < 2e-3);
+    std::vector<float> moved(cx, cx + 3 * n);
+    orc_apply_transform(moved.data(), idx.data(), idx.size(), tr.R.m.data(), &tr.t.x);
+    cur.apply_transform(tr);
+    EXPECT(std::memcmp(moved.data(), cur.coords_ptr(), 12 * n) == 0);           // bit-identical coordinates
+    EXPECT(rmsd(cur, ref) < 0.05f);
+
+    // error mapping (measure.rs:732-762)
+    bool threw = false;
+    std::vector<usize> shorter(idx.begin(), idx.end() - 1);
+    SelBound sh(ref_sys, shorter);
+    try { rmsd(cur, sh); } catch (const MeasureError &e) { threw = e.code == MeasureError::Sizes; }
+    EXPECT(threw);
+    threw = false;
+    System nobox(top, State{ref_sys.state.coords, std::nullopt, 0});
+    try { SelBound::all(nobox).center_of_mass_pbc(); } catch (const PeriodicBoxError &e) { threw = e.code == PeriodicBoxError::NoPbc; }
+    EXPECT(threw);
+}
+
+// ---- an AnalysisTask written against the mirror: per-frame fit + RMSD to the first frame
+struct Frames : FrameSource {
+    size_t n = 5000;
+    Matrix3f box;
+    Topology top;
+    std::vector<State> traj;
+    Frames() {
+        box(0, 0) = 3.7f; box(1, 1) = 3.7f; box(2, 2) = 3.7f;
+        top.masses.assign(n, 12.011f);
+        State base = make_state(n, box, 0.0);
+        for (int f = 0; f < 6; ++f) {
+            State s = base;
+            s.time = 10.0f * f;
+            for (auto &p : s.coords) { p.x += (float)(0.05 * f + 0.03 * (urand() - 0.5)); p.y += (float)(0.03 * (urand() - 0.5)); }
+            traj.push_back(s);
+        }
+    }
+    Topology read_topology(const std::string &) override { return top; }
+    State read_structure_state(const std::string &) override { return traj[0]; }
+    std::function<std::optional<State>()> open(const std::string &, std::optional<size_t> skip, std::optional<Float>) override {
+        auto pos = std::make_shared<size_t>(skip ? *skip : 0);
+        return [this, pos]() -> std::optional<State> {
+            if (*pos >= traj.size()) return std::nullopt;
+            return traj[(*pos)++];
+        };
+    }
+};
+struct NoArgs { explicit NoArgs(const std::vector<std::string> &) {} };
+static std::vector<float> task_rmsd;
+struct AlignTask : AnalysisTask<AlignTask, NoArgs> {
+    std::unique_ptr<System> ref;
+    explicit AlignTask(AnalysisContext<NoArgs> &ctx) : ref(new System(ctx.sys.top, ctx.sys.state)) {}
+    void process_frame(AnalysisContext<NoArgs> &ctx) {
+        SelBound cur = SelBound::all(ctx.sys), r = SelBound::all(*ref);
+        cur.apply_transform(fit_transform(cur, r));
+        task_rmsd.push_back(rmsd(cur, r));
+    }
+    void post_process(AnalysisContext<NoArgs> &) {}
+    static std::string task_name() { return "align"; }
+};
+
+static void task_tests() {
+    Frames src;
+    AlignTask::run({"-f", "top", "traj", "-b", "1", "--skip", "2"}, src);       // frames 1, 3, 5
+    EXPECT(task_rmsd.size() == 3);
+    const std::vector<size_t> which{1, 3, 5};
+    std::vector<float> m(src.top.masses);
+    for (size_t q = 0; q < which.size() && q < task_rmsd.size(); ++q) {
+        // reference = first processed frame (frame 1), as T::new sees it
+        const State &cur = src.traj[which[q]], &ref = src.traj[1];
+        float R[9], t[3], want;
+        orc_fit_transform(&cur.coords[0].x, nullptr, src.n, m.data(), &ref.coords[0].x, nullptr, src.n, m.data(), R, t);
+        std::vector<float> moved(&cur.coords[0].x, &cur.coords[0].x + 3 * src.n);
+        orc_apply_transform(moved.data(), nullptr, src.n, R, t);
+        orc_rmsd(moved.data(), nullptr, src.n, &ref.coords[0].x, nullptr, src.n, &want);
+        EXPECT(std::fabs(task_rmsd[q] - want) < 2e-5f + 3e-4f * want);
+    }
+}
+
+int main() {
+    try {
+        search_tests();
+        measure_tests();
+        task_tests();
+    } catch (const std::exception &e) {
+        std::printf("exception: %s\n", e.what());
+        return 2;
+    }
+    if (failures) { std::printf("%d failure(s)\n", failures); return 1; }
+    std::printf("all host-mirror GPU tests passed\n");
+    return 0;
+}
