@@ -512,6 +512,74 @@ class Sel:
     def unwrap_simple(self, dims=PBC_FULL):
         self.engine.unwrap_simple(self.state.coords, self.require_box(), dims, self.index)
 
+    def within(self, cutoff, inner: "Sel", pbc=None, include_inner=False):
+        """`within <cutoff> [pbc xyz] [self] of <inner>` evaluated inside this selection
+        (LogicalNode::Within, selection/ast.rs:589-631): atoms of `self` closer than cutoff to any atom
+        of `inner`; the raw search stream is sorted + de-duplicated like SVec::from_unsorted
+        (selection_expr.rs:112); `include_inner` is the `self` keyword (:627-629)."""
+        mask = pbc_mask(pbc)
+        eng = self.engine
+        if mask == 0:
+            lo, up = self.min_max()                                   # ast.rs:600-602
+            lo = lo + (np.float32(-cutoff) - np.float32(1.1920929e-07))
+            up = up + (np.float32(cutoff) + np.float32(1.1920929e-07))
+            n = eng.search_count(SEARCH_WITHIN, cutoff, self.state.coords, self.index, inner.state.coords, inner.index,
+                                 lower=lo, upper=up)
+        else:
+            n = eng.search_count(SEARCH_WITHIN, cutoff, self.state.coords, self.index, inner.state.coords, inner.index,
+                                 box=self.require_box(), pbc=mask)
+        ids = eng.search_fill_ids(n)
+        if include_inner:
+            ids = np.concatenate([ids, inner.index])
+        return np.unique(ids)
+
+    def unwrap_connectivity(self, cutoff, dims=PBC_FULL):
+        """Modify::unwrap_connectivity_dim (modify.rs:72-131): neighbour search with LOCAL ids under full
+        PBC (:77-78), adjacency in pair order (SearchConnectivity, connectivity.rs:19-35), then the
+        reference's stack walk that pulls every connected atom to the closest image of the atom it was
+        reached from.  Coordinates are modified in place; returns the list of local-index groups the
+        reference returns as selections."""
+        box = self.require_box()
+        eng = self.engine
+        n = len(self.index)
+        cnt = eng.search_count(SEARCH_SINGLE, cutoff, self.state.coords, self.index, box=box, pbc=PBC_FULL,
+                               ids_local=True)
+        pairs, _ = eng.search_fill(cnt)
+        conn = [[] for _ in range(n)]
+        for i, j in pairs.tolist():                                   # from_iter: push j to i, then i to j
+            conn[i].append(j)
+            conn[j].append(i)
+        coords = self.state.coords
+        gidx = self.index.astype(np.int64)
+        used = np.zeros(n, bool)
+        todo = [0]
+        used[0] = True
+        sel_vec, res = [], []
+        mask = pbc_mask(dims)
+        while True:
+            while todo:
+                c = todo.pop()
+                p0 = coords[gidx[c]].copy()
+                for ind in conn[c]:
+                    if not used[ind]:
+                        coords[gidx[ind]] = box.closest_image(coords[gidx[ind]], p0, mask)
+                        todo.append(ind)
+                        used[ind] = True
+                        sel_vec.append(ind)
+            rest = np.nonzero(~used)[0]
+            if len(rest):
+                i = int(rest[0])
+                todo.append(i)
+                used[i] = True
+                if sel_vec:
+                    res.append(np.array(sorted(set(sel_vec)), dtype=np.uint64))
+                sel_vec = []
+            else:
+                if sel_vec:
+                    res.append(np.array(sorted(set(sel_vec)), dtype=np.uint64))
+                break
+        return res
+
 
 def distance_search(cutoff, data1: Sel, data2: Sel | None = None, dims=None):
     """molar_python/src/lib.rs:259-376 — same dispatch table:

@@ -343,3 +343,71 @@ def test_fused_histogram_two_sets(eng, orc32):
     want = orc32.histogram_add(0.0, 0.7, 350, ref["d"]).astype(np.uint64)
     bins, cnt = eng.search_histogram(a.SEARCH_DOUBLE, 0.7, 0.0, 0.7, 350, pos, idx1, pos, idx2, box=box, pbc=7)
     assert cnt == len(ref["i"]) and np.array_equal(bins, want)     # includes the reference's same-cell duplicates
+
+
+def test_within_selection_end_to_end(eng, orc32):
+    """`within 0.6 [pbc] [self] of <inner>` (selection/ast.rs:589-631) = search stream + sort/dedup."""
+    a = api()
+    n = 9000
+    box = synth.box_a(n)
+    pos = synth.frame(n, box)
+    top = a.Topology(synth.masses(n))
+    st = a.State(pos, a.PeriodicBox.from_matrix(box))
+    outer = a.Sel(top, st, np.arange(0, n, 1), engine=eng)
+    inner = a.Sel(top, st, np.arange(2000, 2300), engine=eng)
+    ob = orc32.box_from_matrix(box)
+    # periodic
+    got = outer.within(0.6, inner, pbc=[True, True, True])
+    ref = orc32.search_within_pbc(0.6, pos, pos[2000:2300], ob, 7, np.arange(n), np.arange(2000, 2300))
+    assert np.array_equal(got, np.unique(ref["i"]))
+    # brute-force meaning of the selection: min-image distance to any inner atom <= cutoff
+    bf = orc32.brute_double(0.6, pos, pos[2000:2300], ob, 7, np.arange(n), np.arange(2000, 2300))
+    assert np.array_equal(got, np.unique(bf["i"]))
+    # non-periodic + `self`
+    got = outer.within(0.6, inner, include_inner=True)
+    bf = orc32.brute_double(0.6, pos, pos[2000:2300], None, ids1=np.arange(n), ids2=np.arange(2000, 2300))
+    assert np.array_equal(got, np.unique(np.concatenate([bf["i"], np.arange(2000, 2300)])))
+
+
+def test_unwrap_connectivity(eng, orc32):
+    """modify.rs:72-131: chains broken across the box are made whole again."""
+    a = api()
+    rng = np.random.default_rng(4)
+    box = np.diag([4.0, 4.0, 4.0]).astype(np.float32)
+    chains = []
+    for c in range(12):                                    # 12 random-walk chains of 40 beads, bond 0.15 nm
+        p = np.zeros((40, 3)); p[0] = rng.uniform(0, 4, 3)
+        for k in range(1, 40):
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            p[k] = p[k - 1] + 0.15 * d
+        chains.append(p)
+    whole = np.concatenate(chains)
+    wrapped = (whole % 4.0).astype(np.float32)
+    top = a.Topology(np.ones(len(wrapped), np.float32))
+    st = a.State(wrapped.copy(), a.PeriodicBox.from_matrix(box))
+    sel = a.Sel(top, st, engine=eng)
+    groups = sel.unwrap_connectivity(0.2)
+    un = st.coords
+    # every bond is restored to its length, whatever image the chain ended up in
+    for c in range(12):
+        seg = un[40 * c: 40 * (c + 1)].astype(np.float64)
+        assert np.allclose(np.linalg.norm(np.diff(seg, axis=0), axis=1), 0.15, atol=1e-4)
+    assert sum(len(g) for g in groups) <= len(wrapped) and len(groups) >= 1
+    # same walk with the oracle's primitives gives the same coordinates
+    ob = orc32.box_from_matrix(box)
+    r = orc32.search_single_pbc(0.2, wrapped, ob, 7)
+    conn = [[] for _ in range(len(wrapped))]
+    for i, j in zip(r["i"].tolist(), r["j"].tolist()):
+        conn[i].append(j); conn[j].append(i)
+    ref = wrapped.copy(); used = np.zeros(len(ref), bool); todo = [0]; used[0] = True
+    while True:
+        while todo:
+            c = todo.pop(); p0 = ref[c].copy()
+            for ind in conn[c]:
+                if not used[ind]:
+                    ref[ind] = orc32.closest_image_dims(ob, ref[ind], p0, 7); todo.append(ind); used[ind] = True
+        rest = np.nonzero(~used)[0]
+        if not len(rest):
+            break
+        todo.append(int(rest[0])); used[int(rest[0])] = True
+    assert np.array_equal(un, ref)
