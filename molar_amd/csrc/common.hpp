@@ -130,6 +130,7 @@ struct molar_hip_ctx {
     mh::GridSet set[2];
     uint64_t nslots_bound = 0; // host-side upper bound of the slot count (sizes the launches)
     mh::DevBuf params;         // SearchParams block read by the pair kernels
+    mh::DevBuf task_desc;      // TaskDesc per task (plan entry)
     mh::DevBuf task_nb;        // u32 per task (+1): 64-row blocks of the task, scanned in place -> first slot
     mh::DevBuf slot_task;      // u32 per slot: owning task
     mh::DevBuf slot_cnt;       // u32 per slot (+1): results of the slot

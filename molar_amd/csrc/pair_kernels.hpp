@@ -37,6 +37,7 @@ struct SearchParams {
     const float *vdwa;
     const float *vdwb;
     const float4 *aabb_b;    // per-cell bounding boxes of set 2 (== set 1 for SINGLE)
+    const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
     uint32_t dx, dy, dz;
     uint32_t pbc;            // PbcDims of the plan (0 for the non-periodic drivers)
     uint32_t use_box;
@@ -51,6 +52,11 @@ struct SearchParams {
     float cutoff2;
     uint64_t ntasks;
     molar_hip_box box;
+};
+
+// what plan_kernel stores per plan entry and the pair kernels read back with one 32-byte load
+struct TaskDesc {
+    uint32_t a0, n1, b0, n2, cb, flags, pad0, pad1;   // flags: wrap | tri<<8 | valid<<9 | rps<<16
 };
 
 struct Task {
@@ -661,11 +667,17 @@ __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Ta
 // numbered in plan order, then row order, so an exclusive scan of the per-slot counts is the
 // reference's output order.
 template <int KIND>
-__global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__restrict__ task_nb) {
+__global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__restrict__ task_nb,
+                                                   TaskDesc *__restrict__ task_desc) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= P.ntasks) return;
     const Task T = decode_task<KIND, false>(P, t);
     task_nb[t] = T.valid ? (T.n1 + T.rps - 1u) / T.rps : 0u;
+    TaskDesc d;
+    d.a0 = T.a0; d.n1 = T.n1; d.b0 = T.b0; d.n2 = T.n2; d.cb = T.cb;
+    d.flags = T.wrap | (T.tri ? 0x100u : 0u) | (T.valid ? 0x200u : 0u) | (T.rps << 16);
+    d.pad0 = d.pad1 = 0;
+    task_desc[t] = d;
 }
 
 static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, const uint32_t *__restrict__ task_first,
@@ -707,7 +719,21 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
         // over the whole chip.
         const uint32_t slot = nslots - 1u - w;
         const uint32_t t = slot_task[slot];
-        const Task T = decode_task<KIND, true>(P, t);
+        Task T;   // descriptor precomputed by plan_kernel: no per-slot replay of the plan arithmetic
+        {
+            const uint4 lo = reinterpret_cast<const uint4 *>(P.task_desc + t)[0];
+            const uint2 hi = reinterpret_cast<const uint2 *>(P.task_desc + t)[2];
+            T.a0 = __builtin_amdgcn_readfirstlane(lo.x);
+            T.n1 = __builtin_amdgcn_readfirstlane(lo.y);
+            T.b0 = __builtin_amdgcn_readfirstlane(lo.z);
+            T.n2 = __builtin_amdgcn_readfirstlane(lo.w);
+            T.cb = __builtin_amdgcn_readfirstlane(hi.x);
+            const uint32_t fl = __builtin_amdgcn_readfirstlane(hi.y);
+            T.wrap = fl & 7u;
+            T.tri = (fl & 0x100u) != 0u;
+            T.valid = (fl & 0x200u) != 0u;
+            T.rps = fl >> 16;
+        }
         const uint32_t i0 = (slot - task_first[t]) * T.rps;
         Fifo F;
         F.fi = lds[wave][0];

@@ -465,6 +465,7 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.vdwa = c->set[0].sorted_vdw.as<float>();
     P.vdwb = c->set[1].sorted_vdw.as<float>();
     P.aabb_b = two ? c->set[1].aabb.as<float4>() : c->set[0].aabb.as<float4>();
+    P.task_desc = c->task_desc.as<TaskDesc>();
     P.dx = c->dims[0];
     P.dy = c->dims[1];
     P.dz = c->dims[2];
@@ -646,6 +647,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q) {
     if (c->ntasks >= 0xFFFFFFF0ull || c->nslots_bound >= 0xFFFFFFF0ull)
         return fail(MOLAR_HIP_ERR_TOO_LARGE, "search plan too large (%llu entries)", (unsigned long long)c->ntasks);
     MH_TRY(c->task_nb.reserve((c->ntasks + 1) * 4));
+    MH_TRY(c->task_desc.reserve((c->ntasks + 1) * sizeof(TaskDesc)));
     MH_TRY(c->slot_task.reserve((c->nslots_bound + 1) * 4));
     MH_TRY(c->slot_cnt.reserve((c->nslots_bound + 1) * 4));
     MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
@@ -657,10 +659,10 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q) {
         const unsigned nb = (unsigned)((c->ntasks + 255) / 256);
         switch (c->kind) {
             case MOLAR_HIP_SEARCH_SINGLE:
-                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>());
+                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>());
                 break;
             default:   // the three two-grid kinds decode tasks identically
-                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>());
+                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>());
                 break;
         }
         MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), c->ntasks + 1)));
