@@ -196,6 +196,23 @@ int molar_hip_fit_transform(molar_hip_ctx *ctx, const float *xyz1, size_t natoms
                             const uint64_t *idx2, size_t n2, const float *mass2, int at_origin, float R9[9],
                             float t3[3]);
 
+/* Batched selections (CSR): selection k = idx[offsets[k] .. offsets[k+1]).  Replaces the rayon loops over
+ * ParSplit sub-selections / per-lipid selections (selection/system.rs:193-213, molar_membrane/src/lib.rs:
+ * 135-137, lipid_molecule.rs:65-99) where one GPU launch per ~100-atom selection would be slower than the
+ * serial loop.  out: float[K][3].  mass == NULL => center_of_geometry, else center_of_mass (ERR_ZERO_MASS if
+ * any selection has zero total mass). */
+int molar_hip_center_batch(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx,
+                           const uint64_t *offsets, size_t nsel, const float *mass, float *out);
+/* Modify::unwrap_simple_dim (modify.rs:40-54) applied to every selection of the CSR list, in place. */
+int molar_hip_unwrap_simple_batch(molar_hip_ctx *ctx, float *xyz, size_t natoms, const uint64_t *idx,
+                                  const uint64_t *offsets, size_t nsel, const float *box9, uint8_t pbc);
+/* Membrane::compute_initial_normals (molar_membrane/src/lib.rs:456-505), host arithmetic: tail->head unit
+ * vectors, then two neighbour-averaging passes over the patches (CSR patch_offsets/patch_ids; the second
+ * pass updates normals in place, in lipid order, exactly like the reference loop).  valid may be NULL. */
+int molar_hip_membrane_initial_normals(size_t nlipids, const float *head_markers, const float *tail_markers,
+                                       const uint64_t *patch_offsets, const uint64_t *patch_ids,
+                                       const uint8_t *valid, float *normals_out);
+
 /* Measure::lipid_tail_order (measure.rs:270-422), batched over `ntails` tails given as CSR:
  * tail t holds the carbons idx[tail_offsets[t] .. tail_offsets[t+1]) (n_t atoms), its normals are
  * normals[3*normal_offsets[t] .. 3*normal_offsets[t+1]) (1 or n_t-2 vectors), its n_t-1 bond orders

@@ -367,6 +367,41 @@ class Engine:
         check(self.lib.molar_hip_unwrap_simple(self.ctx, xa, na, ia, n, ba, pbc_mask(dims)))
         return xyz
 
+    def center_batch(self, xyz, idx, offsets, mass=None):
+        """Centres of K selections given as CSR (idx, offsets[K+1]): center_of_mass if `mass` is given,
+        else center_of_geometry.  One wave per selection; returns float32 [K,3]."""
+        xyz = _f32(xyz); idx = _u64(idx); offsets = _u64(offsets); mass = _f32(mass)
+        xa, k1 = _addr(xyz); ia, k2 = _addr(idx); oa, k3 = _addr(offsets); ma, k4 = _addr(mass)
+        K = offsets.shape[0] - 1
+        out = np.zeros((K, 3), np.float32)
+        check(self.lib.molar_hip_center_batch(self.ctx, xa, xyz.shape[0], ia, oa, K, ma, out.ctypes.data))
+        return out
+
+    def unwrap_simple_batch(self, xyz, idx, offsets, box, dims=PBC_FULL):
+        """unwrap_simple on each of K CSR selections, in place."""
+        if not _is_torch(xyz):
+            assert xyz.dtype == np.float32 and xyz.flags.c_contiguous
+        idx = _u64(idx); offsets = _u64(offsets)
+        xa, k1 = _addr(xyz); ia, k2 = _addr(idx); oa, k3 = _addr(offsets)
+        ba, kb = self._box9(box)
+        check(self.lib.molar_hip_unwrap_simple_batch(self.ctx, xa, xyz.shape[0], ia, oa, offsets.shape[0] - 1, ba,
+                                                     pbc_mask(dims)))
+        return xyz
+
+    def lipid_tail_order_csr(self, xyz, idx, tail_offsets, order_type, normals, normal_offsets, bond_orders):
+        """Same as lipid_tail_order with the CSR arrays prepared by the caller (no per-call Python loops)."""
+        xyz = _f32(xyz)
+        xa, kx = _addr(xyz)
+        idx = _u64(idx); tail_offsets = _u64(tail_offsets); normal_offsets = _u64(normal_offsets)
+        normals = np.ascontiguousarray(normals, np.float32); bond_orders = np.ascontiguousarray(bond_orders, np.uint8)
+        K = len(tail_offsets) - 1
+        nout = int(tail_offsets[-1]) - 2 * K
+        out = np.zeros(max(nout, 1), np.float32)
+        check(self.lib.molar_hip_lipid_tail_order(self.ctx, xa, xyz.shape[0], idx.ctypes.data, tail_offsets.ctypes.data, K,
+                                                  int(order_type), normals.ctypes.data, normal_offsets.ctypes.data,
+                                                  bond_orders.ctypes.data, out.ctypes.data))
+        return out[:nout]
+
     def lipid_tail_order(self, xyz, tails, order_type, normals, bond_orders):
         """Batched Measure::lipid_tail_order (measure.rs:270-422).  tails: list of index arrays (the
         tail carbons, in chain order); normals: list of [1,3] or [n-2,3] arrays; bond_orders: list of
@@ -416,6 +451,20 @@ class Engine:
                                                 1 if apply else 0, rm.ctypes.data, R.ctypes.data, t.ctypes.data,
                                                 com.ctypes.data, gy.ctypes.data))
         return dict(rmsd=rm, R=R.reshape(F, 3, 3).transpose(0, 2, 1).copy(), t=t, com=com, gyration=gy)
+
+
+def membrane_initial_normals(head_markers, tail_markers, patch_offsets, patch_ids, valid=None, normals=None):
+    """Membrane::compute_initial_normals (molar_membrane/src/lib.rs:456-505); host arithmetic of the engine."""
+    lib = _lib.load()
+    head = np.ascontiguousarray(head_markers, np.float32); tail = np.ascontiguousarray(tail_markers, np.float32)
+    po = np.ascontiguousarray(patch_offsets, np.uint64); pi = np.ascontiguousarray(patch_ids, np.uint64)
+    K = len(head)
+    out = np.zeros((K, 3), np.float32) if normals is None else np.ascontiguousarray(normals, np.float32)
+    v = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+    check(lib.molar_hip_membrane_initial_normals(K, head.ctypes.data, tail.ctypes.data, po.ctypes.data,
+                                                 pi.ctypes.data if len(pi) else None, None if v is None else v.ctypes.data,
+                                                 out.ctypes.data))
+    return out
 
 
 # ---------------------------------------------------------------- pymolar-style front-end

@@ -221,6 +221,60 @@ __global__ void __launch_bounds__(RB) k_minmax(Sel s, uint32_t *mm) {
         }
 }
 
+// ---------------------------------------------------------------- batched (CSR) selections: one wave each
+
+__global__ void __launch_bounds__(256) k_center_batch(const float *__restrict__ xyz, const uint64_t *__restrict__ idx,
+                                                      const uint64_t *__restrict__ off, uint32_t nsel,
+                                                      const float *__restrict__ mass, float *__restrict__ out,
+                                                      int *__restrict__ status) {
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (k >= nsel) return;
+    const uint64_t s = off[k], e = off[k + 1];
+    double sm = 0, sx = 0, sy = 0, sz = 0;
+    for (uint64_t q = s + lane; q < e; q += 64) {
+        const uint64_t a = idx[q];
+        const float *p = xyz + 3 * a;
+        const float m = mass ? mass[a] : 1.0f;
+        sm += (double)m;
+        sx += (double)(p[0] * m);
+        sy += (double)(p[1] * m);
+        sz += (double)(p[2] * m);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sm += __shfl_xor(sm, o, 64);
+        sx += __shfl_xor(sx, o, 64);
+        sy += __shfl_xor(sy, o, 64);
+        sz += __shfl_xor(sz, o, 64);
+    }
+    if (lane == 0) {
+        const double den = mass ? sm : (double)(e - s);
+        if (den == 0.0) {
+            atomicMax(status, MOLAR_HIP_ERR_ZERO_MASS);
+            out[3 * k] = out[3 * k + 1] = out[3 * k + 2] = 0.f;
+        } else {
+            out[3 * k] = (float)(sx / den);
+            out[3 * k + 1] = (float)(sy / den);
+            out[3 * k + 2] = (float)(sz / den);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_unwrap_batch(float *__restrict__ xyz, const uint64_t *__restrict__ idx,
+                                                      const uint64_t *__restrict__ off, uint32_t nsel, molar_hip_box box,
+                                                      uint32_t pbc) {
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (k >= nsel) return;
+    const uint64_t s = off[k], e = off[k + 1];
+    if (e - s < 2) return;
+    const float *q0 = xyz + 3 * idx[s];
+    const V3 p0 = v3(q0[0], q0[1], q0[2]);
+    for (uint64_t q = s + 1 + lane; q < e; q += 64) {
+        float *p = xyz + 3 * idx[q];
+        const V3 im = closest_image(box, v3(p[0], p[1], p[2]), p0, pbc);
+        p[0] = im.x; p[1] = im.y; p[2] = im.z;
+    }
+}
+
 // ---------------------------------------------------------------- lipid tail order (measure.rs:270-422)
 
 struct F3 {
@@ -707,6 +761,104 @@ int molar_hip_fit_transform(molar_hip_ctx *c, const float *xyz1, size_t natoms1,
         t3[0] = cm[3] + rv.x;
         t3[1] = cm[4] + rv.y;
         t3[2] = cm[5] + rv.z;
+    }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_center_batch(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx,
+                           const uint64_t *offsets, size_t nsel, const float *mass, float *out) {
+    MH_CTX(c);
+    if (!xyz || !idx || !offsets || !out) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "center_batch: null argument");
+    if (nsel == 0) return MOLAR_HIP_OK;
+    uint64_t last = 0;
+    if (is_device_ptr(offsets)) MH_HIP(hipMemcpy(&last, offsets + nsel, 8, hipMemcpyDeviceToHost));
+    else last = offsets[nsel];
+    const float *d_xyz, *d_mass = nullptr;
+    const uint64_t *d_idx, *d_off;
+    MH_TRY(to_device(c, xyz, natoms * 3, c->m_xyz1, &d_xyz));
+    MH_TRY(to_device(c, idx, (size_t)last, c->m_idx1, &d_idx));
+    MH_TRY(to_device(c, offsets, nsel + 1, c->m_idx2, &d_off));
+    if (mass) MH_TRY(to_device(c, mass, natoms, c->m_mass1, &d_mass));
+    const bool out_dev = is_device_ptr(out);
+    MH_TRY(c->m_out.reserve(nsel * 12 + 16));
+    float *d_out = out_dev ? out : c->m_out.as<float>();
+    MH_TRY(c->m_results.reserve(64));
+    int *status = c->m_results.as<int>();
+    MH_HIP(hipMemsetAsync(status, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_center_batch, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, c->stream, d_xyz, d_idx, d_off,
+                       (uint32_t)nsel, d_mass, d_out, status);
+    MH_HIP(hipGetLastError());
+    int st = 0;
+    MH_TRY(pull(c, &st, status, 4));
+    if (st) return fail(st, "zero mass");
+    if (!out_dev) {
+        MH_HIP(hipMemcpyAsync(out, d_out, nsel * 12, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_unwrap_simple_batch(molar_hip_ctx *c, float *xyz, size_t natoms, const uint64_t *idx,
+                                  const uint64_t *offsets, size_t nsel, const float *box9, uint8_t pbc) {
+    MH_CTX(c);
+    if (!xyz || !idx || !offsets) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "unwrap_simple_batch: null argument");
+    molar_hip_box b;
+    MH_TRY(box_or_err(box9, &b));
+    if (nsel == 0) return MOLAR_HIP_OK;
+    uint64_t last = 0;
+    if (is_device_ptr(offsets)) MH_HIP(hipMemcpy(&last, offsets + nsel, 8, hipMemcpyDeviceToHost));
+    else last = offsets[nsel];
+    const float *d_xyz;
+    const uint64_t *d_idx, *d_off;
+    MH_TRY(to_device(c, (const float *)xyz, natoms * 3, c->m_xyz1, &d_xyz));
+    MH_TRY(to_device(c, idx, (size_t)last, c->m_idx1, &d_idx));
+    MH_TRY(to_device(c, offsets, nsel + 1, c->m_idx2, &d_off));
+    hipLaunchKernelGGL(k_unwrap_batch, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, c->stream, const_cast<float *>(d_xyz),
+                       d_idx, d_off, (uint32_t)nsel, b, (uint32_t)(pbc & 7u));
+    MH_HIP(hipGetLastError());
+    if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, d_xyz, natoms * 12, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+// host-only: f32, the reference's loop order (molar_membrane/src/lib.rs:456-505)
+int molar_hip_membrane_initial_normals(size_t K, const float *head, const float *tail, const uint64_t *poff,
+                                       const uint64_t *pids, const uint8_t *valid, float *normals) {
+    if (!head || !tail || !poff || !normals) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "initial_normals: null argument");
+    struct V { float x, y, z; };
+    auto nrm = [](V a) { return std::sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); };
+    auto unit = [&](V a) { const float n = nrm(a); return V{a.x / n, a.y / n, a.z / n}; };
+    auto angle = [&](V a, V b) {
+        const float n1 = nrm(a), n2 = nrm(b);
+        if (n1 == 0.0f || n2 == 0.0f) return 0.0f;
+        float cc = ((a.x * b.x + a.y * b.y) + a.z * b.z) / (n1 * n2);
+        cc = cc < -1.0f ? -1.0f : (cc > 1.0f ? 1.0f : cc);
+        return std::acos(cc);
+    };
+    const float half_pi = 1.57079632679489661923f;
+    std::vector<V> thv(K), nv(K);
+    auto ok = [&](size_t i) { return !valid || valid[i]; };
+    for (size_t i = 0; i < K; ++i) {
+        thv[i] = V{0, 0, 0};
+        nv[i] = V{normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]};
+        if (ok(i)) thv[i] = unit(V{head[3 * i] - tail[3 * i], head[3 * i + 1] - tail[3 * i + 1], head[3 * i + 2] - tail[3 * i + 2]});
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        for (size_t i = 0; i < K; ++i) {
+            if (!ok(i)) continue;
+            const std::vector<V> &src = pass == 0 ? thv : nv;   // pass 2 reads normals already updated for l < i
+            const V self = src[i];
+            V sum{0, 0, 0};
+            for (uint64_t q = poff[i]; q < poff[i + 1]; ++q) {
+                const V o = src[pids[q]];
+                if (angle(o, self) <= half_pi) { sum.x += o.x; sum.y += o.y; sum.z += o.z; }
+            }
+            sum.x += self.x; sum.y += self.y; sum.z += self.z;   // .chain(once(central))
+            nv[i] = unit(sum);
+        }
+    }
+    for (size_t i = 0; i < K; ++i) {
+        normals[3 * i] = nv[i].x; normals[3 * i + 1] = nv[i].y; normals[3 * i + 2] = nv[i].z;
     }
     return MOLAR_HIP_OK;
 }

@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Secondary workloads of BASELINE.json (configs[2], [3]) on one GPU — informational numbers for
+DESIGN.md; the headline metric stays bench.py.  Prints one JSON object per workload."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    from molar_amd import api, build, synth
+    build.build_library()
+    eng = api.Engine(0)
+    dev = torch.device("cuda", 0)
+
+    # ---- C3: 1M-atom frames, 100k-atom selection: Kabsch fit + apply + rmsd + COM + gyration, batched
+    n, F = 1_000_000, 64
+    box = synth.box_a(n)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    base = (torch.rand((n, 3), generator=g, device=dev, dtype=torch.float64) @ torch.from_numpy(box.astype(np.float64)).to(dev).T)
+    frames = (base[None] + 0.05 * torch.randn((F, n, 3), generator=g, device=dev, dtype=torch.float32).double()).float().contiguous()
+    ref = base.float().contiguous()
+    mass = torch.from_numpy(synth.masses(n)).to(dev)
+    idx = torch.arange(0, n, 10, device=dev, dtype=torch.int64)
+    for batch in (1, 64):
+        eng.fit_rmsd_batch(frames[:batch], mass, ref, idx=idx, apply=False)
+        eng.synchronize(); torch.cuda.synchronize()
+        reps = 20 if batch == 1 else 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for s in range(0, F, batch):
+                eng.fit_rmsd_batch(frames[s:s + batch], mass, ref, idx=idx, apply=False)
+        eng.synchronize(); torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / (reps * F)
+        print(json.dumps({"workload": "C3 fit+rmsd+COM+gyration, M=1e5 of N=1e6, frames resident", "frames_per_call": batch,
+                          "frames_per_s": 1.0 / dt, "us_per_frame": dt * 1e6,
+                          "algorithmic_GBps": 44.0 * 1e5 / dt / 1e9}))
+    # streamed from host (PCIe): one 12 MB frame per call
+    hframe = frames[0].cpu().numpy(); href = ref.cpu().numpy(); hmass = mass.cpu().numpy(); hidx = idx.cpu().numpy().astype(np.uint64)
+    eng.fit_rmsd_batch(hframe[None].copy(), hmass, href, idx=hidx, apply=False)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        eng.fit_rmsd_batch(hframe[None], hmass, href, idx=hidx, apply=False)
+    dt = (time.perf_counter() - t0) / 10
+    print(json.dumps({"workload": "C3 streamed from pageable host memory (frame + reference + mass + idx per call)",
+                      "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3}))
+    del frames
+
+    # ---- C4: 250k atoms, RDF 0..1.2 nm in 1200 bins, fused histogram (no pair list)
+    n = 250_000
+    box = synth.box_a(n)
+    pos = [torch.from_numpy(synth.frame(n, box, f)).to(dev) for f in range(8)]
+    bins = np.zeros(1200, np.uint64)
+    eng.search_histogram(api.SEARCH_SINGLE, 1.2, 0.0, 1.2, 1200, pos[0], box=box, pbc=7)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    pairs = 0
+    K = 40
+    for s in range(K):
+        bins, c = eng.search_histogram(api.SEARCH_SINGLE, 1.2, 0.0, 1.2, 1200, pos[s % 8], box=box, pbc=7, bins=bins)
+        pairs += c
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    print(json.dumps({"workload": "C4 250k-atom frame, radial histogram 1200 bins, fused (single pass, no pairs)",
+                      "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "matom_pairs_per_s": pairs / K / dt / 1e6}))
+
+    # ---- host round trip of the headline search (PCIe-inclusive, never the bench value)
+    n = 1_000_000
+    box = synth.box_a(n)
+    hpos = synth.frame(n, box, 0)
+    cnt = eng.search_count(api.SEARCH_SINGLE, 1.2, hpos, box=box, pbc=7)
+    t0 = time.perf_counter()
+    cnt = eng.search_count(api.SEARCH_SINGLE, 1.2, hpos, box=box, pbc=7)
+    pairs_h, dist_h = eng.search_fill(cnt)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"workload": "C2 with host buffers: 12 MB frame in, 4.3 GB pair list out to pageable host memory",
+                      "s_per_frame": dt, "pairs": cnt, "host_GBps": cnt * 12 / dt / 1e9}))
+
+
+if __name__ == "__main__":
+    main()
