@@ -45,6 +45,8 @@ struct SearchParams {
     uint32_t wrap_kind;      // WK_* of the box matrix (zero pattern of m and inv)
     uint32_t prune_wrapped;  // wrapped entries may use the image-box row pruning (all periodic dims >= 3 cells)
     float prune_limit2;      // (cutoff + margin)^2 for that pruning
+    uint32_t approx_wrapped; // wrapped entries may be classified with the plain distance to the image cell
+    float band_lo, band_hi;  // band around cutoff^2 inside which the exact formula decides
     uint32_t hist_nbins;     // != 0: the fill traversal feeds a histogram instead of writing pairs
     float hist_min, hist_max;
     unsigned long long *hist_bins;    // [nbins] + [1] total
@@ -56,7 +58,7 @@ struct SearchParams {
 
 // what plan_kernel stores per plan entry and the pair kernels read back with one 32-byte load
 struct TaskDesc {
-    uint32_t a0, n1, b0, n2, cb, flags, pad0, pad1;   // flags: wrap | tri<<8 | valid<<9 | rps<<16
+    uint32_t a0, n1, b0, n2, cb, flags, pad0, pad1;   // flags: wrap | tri<<8 | valid<<9 | wrap_b<<12 | rps<<16
 };
 
 struct Task {
@@ -64,6 +66,7 @@ struct Task {
     uint32_t rps;             // rows of the first cell per slot: 64, or 8 for entries that run the
                               // triclinic candidate loop (~50x the arithmetic per candidate)
     uint32_t cb;              // second cell (for its bounding box)
+    uint32_t wrap_b;          // dims in which the SECOND cell is the one that wrapped (subset of wrap)
     uint32_t wrap;
     bool tri;
     bool valid;
@@ -80,6 +83,7 @@ __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     T.tri = false;
     T.a0 = T.b0 = T.n1 = T.n2 = 0;
     T.cb = 0;
+    T.wrap_b = 0;
     T.rps = 64u;
     T.wrap = 0;
     uint32_t half = 0;
@@ -97,13 +101,14 @@ __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     const uint32_t dims[3] = {P.dx, P.dy, P.dz};
     uint32_t c[2][3] = {{x + MASKS[m][0], y + MASKS[m][1], z + MASKS[m][2]},
                         {x + MASKS[m][3], y + MASKS[m][4], z + MASKS[m][5]}};
-    uint32_t wrap = 0;
+    uint32_t wrap = 0, wrap_c2 = 0;
     for (int i = 0; i < 2; ++i)
         for (int d = 0; d < 3; ++d)
             if (c[i][d] == dims[d]) {
                 if ((P.pbc >> d) & 1u) {
                     c[i][d] = 0;
                     wrap |= 1u << d;
+                    if (i == 1) wrap_c2 |= 1u << d;
                 } else {
                     return T;   // non-periodic dimension: entry dropped (:241-244)
                 }
@@ -122,6 +127,8 @@ __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     T.b0 = P.csb[cb];
     T.n2 = P.csb[cb + 1] - T.b0;
     T.wrap = wrap;
+    // second cell of the task: c2, or c1 for the swapped half of a two-grid entry
+    T.wrap_b = (KIND != MOLAR_HIP_SEARCH_SINGLE && half) ? (wrap & ~wrap_c2) : wrap_c2;
     // only the entries of the single home cell (dx-1,dy-1,dz-1) can wrap in all three dims: <= 28 tasks
     T.rps = (P.use_box && wrap == MOLAR_HIP_PBC_FULL && P.box.nshift != 0 && T.n1 <= 4096u) ? 8u : 64u;
     T.cb = cb;
@@ -219,10 +226,24 @@ struct Fifo {
     uint32_t *ids;              // WITHIN output
     uint32_t *hist;             // consumer-fused mode: workgroup histogram in LDS (NULL otherwise)
     float hmin, hmax, hn;
+    bool recompute;             // entries carry (row<<26 | sorted position) instead of d2 (wrapped fast path)
+    const float4 *la;           // the slot's first-cell atoms in LDS
+    uint32_t wrap;
 };
 
+__device__ __forceinline__ float wrapped_d2_exact(const SearchParams &P, uint32_t wrap, float vx, float vy, float vz);
+
+// d2 of a queued hit: stored directly, or recomputed with the exact wrapped formula from the two atoms
+__device__ __forceinline__ float fifo_d2(const SearchParams &P, const Fifo &F, uint32_t s) {
+    const uint32_t w = F.fd[s];
+    if (!F.recompute) return __uint_as_float(w);
+    const float4 a = F.la[w >> 26];
+    const float4 b = P.sb[w & 0x3FFFFFFu];
+    return wrapped_d2_exact(P, F.wrap, b.x - a.x, b.y - a.y, b.z - a.z);
+}
+
 template <int KIND>
-__device__ __forceinline__ void fifo_flush(Fifo &F, uint32_t count, uint32_t lane) {
+__device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint32_t count, uint32_t lane) {
     if (lane < count) {
         const uint32_t s = (F.head + lane) & (FIFO_CAP - 1);
         const uint64_t pos = F.base + F.head + lane;
@@ -231,14 +252,14 @@ __device__ __forceinline__ void fifo_flush(Fifo &F, uint32_t count, uint32_t lan
         } else if (F.hist) {
             // Histogram1D::add_one (molar_membrane/src/stats.rs:29-35) on d = sqrt(d2):
             //   b = (n as Float * (val - min) / (max - min)).floor() as isize;  if 0 <= b < n: bins[b] += 1
-            const float d = __builtin_sqrtf(__uint_as_float(F.fd[s]));
+            const float d = __builtin_sqrtf(fifo_d2(P, F, s));
             float fb = __builtin_floorf(F.hn * (d - F.hmin) / (F.hmax - F.hmin));
             if (fb != fb) fb = 0.0f;                                    // NaN as isize == 0
             if (fb >= 0.0f && fb < F.hn) atomicAdd(&F.hist[(uint32_t)fb], 1u);
         } else {
             if (F.pairs) F.pairs[pos] = make_uint2(F.fi[s], F.fj[s]);
             // d2.sqrt() (:448): llvm.sqrt.f32 without fpmath metadata = IEEE correctly rounded
-            if (F.dist) F.dist[pos] = __builtin_sqrtf(__uint_as_float(F.fd[s]));
+            if (F.dist) F.dist[pos] = __builtin_sqrtf(fifo_d2(P, F, s));
         }
     }
     F.head += count;
@@ -337,7 +358,7 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
                     total += cnt;
                     if (F.tail - F.head >= 64u) {
                         __builtin_amdgcn_wave_barrier();
-                        fifo_flush<KIND>(F, 64u, lane);
+                        fifo_flush<KIND>(P, F, 64u, lane);
                     }
                 }
             };
@@ -408,7 +429,7 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
                     F.tail += 1;
                     if (F.tail - F.head >= 64u) {
                         __builtin_amdgcn_wave_barrier();
-                        fifo_flush<KIND>(F, 64u, lane);
+                        fifo_flush<KIND>(P, F, 64u, lane);
                     }
                 }
                 total += 1;
@@ -417,60 +438,32 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
     }
     if (FILL && F.tail != F.head) {
         __builtin_amdgcn_wave_barrier();
-        fifo_flush<KIND>(F, F.tail - F.head, lane);
+        fifo_flush<KIND>(P, F, F.tail - F.head, lane);
     }
     return total;
 }
 
-// Box matrices copied into VGPRs: an SGPR source operand halves the issue rate of f32 VALU ops on
-// gfx950 (4.4 vs 2.4-2.7 cycles per wave instruction, profiles/microbench/valu_rate.hip).
-struct BoxV {
-    float I[9], M[9];
-};
-
-__device__ __forceinline__ float to_vgpr(float s) {
-    float v;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
-    return v;
-}
-
-// PeriodicBox::distance_squared for ONE candidate (periodic_box.rs:286-318, 379-381), plain f32 ops.
+// Exact PeriodicBox::distance_squared for ONE candidate (periodic_box.rs:286-318, 379-381) in the general
+// matrix form; the kernel library is built without FMA contraction, and products with matrix entries
+// that are exactly zero do not change an IEEE sum (up to the sign of a zero the squares cannot see), so
+// this equals the reference for diagonal, triangular and full boxes alike.
 // The grid stores every atom inside the primary cell along periodic dimensions (populate_pbc wraps
 // them, distance_search.rs:183-196), so |f[d]| < 1.5 for a wrapped dimension and f32::round reduces
 // to "copysign(1, f) if |f| >= 0.5 else 0" - the same value, three instructions instead of six.
-template <int WK>
-__device__ __forceinline__ float wrapped_d2(const SearchParams &P, const BoxV &B, uint32_t wrap, int nshift, float vx,
-                                            float vy, float vz) {
-    float fx, fy, fz;
-    if (WK == WK_DIAG) {
-        fx = B.I[0] * vx; fy = B.I[4] * vy; fz = B.I[8] * vz;
-    } else if (WK == WK_UPPER) {
-        fx = (B.I[0] * vx + B.I[3] * vy) + B.I[6] * vz;
-        fy = B.I[4] * vy + B.I[7] * vz;
-        fz = B.I[8] * vz;
-    } else {
-        fx = (B.I[0] * vx + B.I[3] * vy) + B.I[6] * vz;
-        fy = (B.I[1] * vx + B.I[4] * vy) + B.I[7] * vz;
-        fz = (B.I[2] * vx + B.I[5] * vy) + B.I[8] * vz;
-    }
+__device__ __forceinline__ float wrapped_d2_exact(const SearchParams &P, uint32_t wrap, float vx, float vy, float vz) {
+    const float *I = P.box.inv, *M = P.box.m;
+    float fx = (I[0] * vx + I[3] * vy) + I[6] * vz;
+    float fy = (I[1] * vx + I[4] * vy) + I[7] * vz;
+    float fz = (I[2] * vx + I[5] * vy) + I[8] * vz;
     if (wrap & 1u) fx -= (fabsf(fx) >= 0.5f ? copysignf(1.0f, fx) : 0.0f);
     if (wrap & 2u) fy -= (fabsf(fy) >= 0.5f ? copysignf(1.0f, fy) : 0.0f);
     if (wrap & 4u) fz -= (fabsf(fz) >= 0.5f ? copysignf(1.0f, fz) : 0.0f);
-    float sx, sy, sz;
-    if (WK == WK_DIAG) {
-        sx = B.M[0] * fx; sy = B.M[4] * fy; sz = B.M[8] * fz;
-    } else if (WK == WK_UPPER) {
-        sx = (B.M[0] * fx + B.M[3] * fy) + B.M[6] * fz;
-        sy = B.M[4] * fy + B.M[7] * fz;
-        sz = B.M[8] * fz;
-    } else {
-        sx = (B.M[0] * fx + B.M[3] * fy) + B.M[6] * fz;
-        sy = (B.M[1] * fx + B.M[4] * fy) + B.M[7] * fz;
-        sz = (B.M[2] * fx + B.M[5] * fy) + B.M[8] * fz;
-    }
+    const float sx = (M[0] * fx + M[3] * fy) + M[6] * fz;
+    const float sy = (M[1] * fx + M[4] * fy) + M[7] * fz;
+    const float sz = (M[2] * fx + M[5] * fy) + M[8] * fz;
     float best2 = (sx * sx + sy * sy) + sz * sz;
-    if (WK != WK_DIAG && nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {   // triclinic candidates (:304-317)
-        for (int k = 0; k < nshift; ++k) {
+    if (P.box.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {   // triclinic candidates (:304-317)
+        for (int k = 0; k < P.box.nshift; ++k) {
             const float cx = sx + P.box.shifts[3 * k], cy = sy + P.box.shifts[3 * k + 1], cz = sz + P.box.shifts[3 * k + 2];
             const float n2 = (cx * cx + cy * cy) + cz * cz;
             best2 = n2 < best2 ? n2 : best2;
@@ -488,40 +481,55 @@ __device__ __forceinline__ float aabb_d2(float ax, float ay, float az, float lx,
     return (ex * ex + ey * ey) + ez * ez;
 }
 
-// Fast path for the bulk of the work: fixed-cutoff, non-triangular cell pairs whose second cell
-// fits in registers (NCH <= 8 chunks of 64), plain (WK_NONE) or wrapped (WK_DIAG/UPPER/GENERAL).
-//  * the slot's 64 first-cell atoms are staged in LDS and each row is fetched with ONE broadcast
-//    ds_read_b128, so the arithmetic runs on VGPR operands only and no v_readlane sits in the row
-//    loop;
-//  * the count pass never leaves the VALU: hits are added per lane through the carry of the
-//    compare and reduced across the wave once per slot (a v_cmp -> s_bcnt1 -> s_add chain costs
-//    ~14 cycles per chunk because of the VALU->SALU hazard);
-//  * lanes past the end of the second cell hold a coordinate so large that d2 overflows to +inf
-//    (or NaN) and the compare fails by itself - no separate validity mask;
-//  * rows that provably cannot have a hit are skipped (see `live` below).
-template <int KIND, bool FILL, int WK, int NCH, bool TRI>
+// Fast path for the bulk of the work: fixed-cutoff cell pairs whose second cell fits in registers
+// (NCH <= 8 chunks of 64): plain, triangular (same cell) or wrapped.
+//  * the slot's first-cell atoms are staged in LDS and each row is fetched with ONE broadcast
+//    ds_read_b128, so the arithmetic runs on VGPR operands only (an SGPR source halves the issue rate
+//    of f32 VALU ops on gfx950, profiles/microbench/valu_rate.hip) and no v_readlane sits in the loop;
+//  * the count pass never leaves the VALU: hits are added per lane through the carry of the compare
+//    and reduced across the wave once per slot (v_cmp -> s_bcnt1 -> s_add costs ~14 cycles per chunk);
+//  * lanes past the end of the second cell hold a coordinate so large that d2 overflows and the
+//    compare fails by itself - no separate validity mask;
+//  * rows that provably cannot have a hit are skipped (`live`);
+//  * WRAPPED entries (a cell pair across the periodic boundary) need PeriodicBox::distance_squared:
+//    inv*v, round, M*v - 4x the arithmetic of a plain pair.  Only the DECISION d2 <= cutoff^2 and the
+//    d2 of actual hits must equal the reference's, so the row loop classifies candidates with the
+//    plain distance to the image of the second cell (b + S, S = the lattice vector of the wrap):
+//    below the band [lo,hi] around cutoff^2 it is a hit, above it a miss, and only candidates INSIDE the
+//    band (a fraction of a percent of the chunks) are evaluated with the exact formula.  Hits carry
+//    (row, atom position) through the FIFO and their exact d2 is recomputed densely at flush time.
+//    The band is >10x the worst-case disagreement between the two evaluations (make_params()).
+template <int KIND, bool FILL, bool WRAPPED, int NCH, bool TRI>
 __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                              uint32_t lane) {
+    static_assert(!(WRAPPED && TRI), "a triangular (same-cell) entry never wraps on the fast path");
+    // approximate classification allowed?  (needs n_d = round(f_d) = +-1 for every wrapped pair: >= 4 cells
+    // per periodic dimension; the corner entries of triclinic boxes run the candidate loop: always exact)
+    const bool approx = WRAPPED && P.approx_wrapped != 0u && !(P.box.nshift != 0 && T.wrap == MOLAR_HIP_PBC_FULL);
+    float Sx = 0.f, Sy = 0.f, Sz = 0.f;      // b + S is the image of the second cell next to the first one
+    if (WRAPPED && approx) {
+        for (int d = 0; d < 3; ++d) {
+            if (!((T.wrap >> d) & 1u)) continue;
+            const float sgn = ((T.wrap_b >> d) & 1u) ? 1.0f : -1.0f;   // second cell wrapped: +col, first cell: -col
+            Sx += sgn * P.box.m[3 * d];
+            Sy += sgn * P.box.m[3 * d + 1];
+            Sz += sgn * P.box.m[3 * d + 2];
+        }
+    }
     float bx[NCH], by[NCH], bz[NCH];
     uint32_t bid[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const uint32_t jj = (uint32_t)k * 64u + lane;
         float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
-        if (jj < T.n2) q = P.sb[T.b0 + jj];
+        if (jj < T.n2) {
+            q = P.sb[T.b0 + jj];
+            if (WRAPPED) { q.x += Sx; q.y += Sy; q.z += Sz; }       // S == 0 when the slot is evaluated exactly
+        }
         bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bid[k] = __float_as_uint(q.w);
     }
-    BoxV B;
-    int nshift = 0;
-    if (WK != WK_NONE) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            B.I[k] = to_vgpr(P.box.inv[k]);
-            B.M[k] = to_vgpr(P.box.m[k]);
-        }
-        nshift = P.box.nshift;
-    }
     const float cutoff2 = P.cutoff2;
+    const float band_lo = P.band_lo, band_hi = P.band_hi;
     const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
     unsigned long long live;   // rows of this slot that can have a hit at all
     {
@@ -532,43 +540,34 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
         bool need = true;
         if (TRI) {
             // same cell (i < j triangle, :439-451): the atom lies inside its own cell's box, nothing to prune
-        } else if (WK == WK_NONE) {
+        } else if (!WRAPPED) {
             // Exact row pruning.  Every B position lies inside the cell's bounding box [lo,hi], and each
             // f32 operation of d2 = ((dx*dx)+(dy*dy))+(dz*dz) is monotone in |dx|,|dy|,|dz|, so the same
             // expression on the box distances is a lower bound of every d2 of the row IN f32 ARITHMETIC:
             // if it already exceeds cutoff2 the reference finds no hit in this row either.
             need = !(aabb_d2(a.x, a.y, a.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > cutoff2);
-        } else if (P.prune_wrapped && !(nshift != 0 && T.wrap == MOLAR_HIP_PBC_FULL)) {
-            // Conservative row pruning for wrapped entries.  In exact arithmetic the reference's vector
-            // is (b - a) - sum_d n_d*col_d with n_d = round(f_d) in {-1,0,1} for the wrapped dims (atoms
-            // are stored inside the primary cell).  The row is skipped only if for EVERY such image the
-            // box distance exceeds cutoff + margin; the margin (1e-3 nm, >100x the f32 evaluation error
-            // of inv*v / M*f at MD box sizes) absorbs the difference between the reference's f32
-            // arithmetic and this geometric bound.
-            const float lim = P.prune_limit2;
-            need = false;
-            for (int nx = -1; nx <= 1; ++nx) {
-                if (!(T.wrap & 1u) && nx != 0) continue;
-                for (int ny = -1; ny <= 1; ++ny) {
-                    if (!(T.wrap & 2u) && ny != 0) continue;
-                    for (int nz = -1; nz <= 1; ++nz) {
-                        if (!(T.wrap & 4u) && nz != 0) continue;
-                        const float fx = (float)nx, fy = (float)ny, fz = (float)nz;
-                        const float tx = (fx * P.box.m[0] + fy * P.box.m[3]) + fz * P.box.m[6];
-                        const float ty = (fx * P.box.m[1] + fy * P.box.m[4]) + fz * P.box.m[7];
-                        const float tz = (fx * P.box.m[2] + fy * P.box.m[5]) + fz * P.box.m[8];
-                        // (b - n*cols) - a  ==  b - (a + n*cols): shift the point instead of the box
-                        const float e2 = aabb_d2(a.x + tx, a.y + ty, a.z + tz, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
-                        need = need || !(e2 > lim);
-                    }
-                }
-            }
+        } else if (approx) {
+            // Conservative pruning against the image box [lo+S, hi+S] with a 1e-3 nm margin (>100x the f32
+            // evaluation error of the reference's inv*v / M*f at MD box sizes).
+            need = !(aabb_d2(a.x - Sx, a.y - Sy, a.z - Sz, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > P.prune_limit2);
         }
         live = __builtin_amdgcn_ballot_w64(lane < rows && need);
     }
     __builtin_amdgcn_wave_barrier();
-    uint32_t acc = 0;      // per-lane hit counter (count pass)
+    if (FILL) {
+        F.recompute = WRAPPED && approx;
+        F.la = la;
+        F.wrap = T.wrap;
+    }
+    uint32_t acc = 0;       // per-lane hit counter (count pass); wrapped+approx: hits that are certain
+    uint32_t acc_hi = 0;    // wrapped+approx: candidates at or below the upper edge of the band
     uint32_t total = 0;
+    // exact d2 of (row atom p, atom jj of the second cell), second cell re-read unshifted
+    auto exact_d2 = [&](const float4 &p, uint32_t jj) -> float {
+        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+        if (jj < T.n2) q = P.sb[T.b0 + jj];
+        return wrapped_d2_exact(P, T.wrap, q.x - p.x, q.y - p.y, q.z - p.z);
+    };
     while (live) {
         const uint32_t r = (uint32_t)__builtin_ctzll(live);
         live &= live - 1ull;
@@ -578,20 +577,30 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             if (TRI && (uint32_t)k * 64u + 63u <= i) continue;                   // whole chunk has j <= i
-            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1
-            float d2;
-            if (WK == WK_NONE) d2 = (dx * dx + dy * dy) + dz * dz;               // |p2-p1|^2 (:446, :460)
-            else d2 = wrapped_d2<WK>(P, B, T.wrap, nshift, dx, dy, dz);          // (:485-486)
-            if (TRI && (uint32_t)k * 64u <= i)                                   // diagonal chunk: j in i+1..n (:443)
-                d2 = ((uint32_t)k * 64u + lane > i) ? d2 : INFINITY;
+            const uint32_t jj = (uint32_t)k * 64u + lane;
+            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1 (image of p2 if WRAPPED)
+            float d2 = (dx * dx + dy * dy) + dz * dz;                            // |p2-p1|^2 (:446, :460)
+            if (WRAPPED && !approx) d2 = wrapped_d2_exact(P, T.wrap, dx, dy, dz); // S == 0: dx is the raw difference (:485-486)
+            if (TRI && (uint32_t)k * 64u <= i) d2 = (jj > i) ? d2 : INFINITY;    // diagonal chunk: j in i+1..n (:443)
             if (!FILL) {
-                // acc += (d2 <= cutoff2): the compare's carry is added per lane, no SALU involved
-                asm volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"
-                             : "+v"(acc)
-                             : "v"(d2), "s"(cutoff2)
-                             : "vcc");
+                if (WRAPPED && approx) {
+                    asm volatile("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(acc) : "v"(d2), "s"(band_lo) : "vcc");
+                    asm volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(acc_hi) : "v"(d2), "s"(band_hi) : "vcc");
+                } else {
+                    // acc += (d2 <= cutoff2): the compare's carry is added per lane, no SALU involved
+                    asm volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(acc) : "v"(d2), "s"(cutoff2) : "vcc");
+                }
             } else {
-                const bool hit = d2 <= cutoff2;
+                bool hit;
+                uint32_t third = __float_as_uint(d2);
+                if (WRAPPED && approx) {
+                    const bool sure = d2 < band_lo, maybe = d2 <= band_hi;
+                    hit = sure;
+                    if (__builtin_amdgcn_ballot_w64(maybe && !sure)) hit = sure || (maybe && exact_d2(p, jj) <= cutoff2);
+                    third = (r << 26) | (T.b0 + jj);          // exact d2 is recomputed at flush time
+                } else {
+                    hit = d2 <= cutoff2;
+                }
                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
                 if (mask) {
                     const uint32_t cnt = (uint32_t)__popcll(mask);
@@ -601,15 +610,30 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
                         const uint32_t s = (F.tail + rank) & (FIFO_CAP - 1);
                         F.fi[s] = id_i;
                         F.fj[s] = bid[k];
-                        F.fd[s] = __float_as_uint(d2);
+                        F.fd[s] = third;
                     }
                     F.tail += cnt;
                     total += cnt;
                     if (F.tail - F.head >= 64u) {
                         __builtin_amdgcn_wave_barrier();
-                        fifo_flush<KIND>(F, 64u, lane);
+                        fifo_flush<KIND>(P, F, 64u, lane);
                     }
                 }
+            }
+        }
+        if (!FILL && WRAPPED && approx) {
+            // some candidate of this row fell inside the band: settle those (and only those) exactly
+            if (__builtin_amdgcn_ballot_w64(acc != acc_hi)) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    const bool amb = d2 <= band_hi && !(d2 < band_lo);
+                    if (__builtin_amdgcn_ballot_w64(amb)) {
+                        if (amb && exact_d2(p, (uint32_t)k * 64u + lane) <= cutoff2) acc += 1u;
+                    }
+                }
+                acc_hi = acc;
             }
         }
     }
@@ -618,8 +642,9 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
         total = acc;
     } else if (F.tail != F.head) {
         __builtin_amdgcn_wave_barrier();
-        fifo_flush<KIND>(F, F.tail - F.head, lane);
+        fifo_flush<KIND>(P, F, F.tail - F.head, lane);
     }
+    if (FILL) F.recompute = false;
     return total;
 }
 
@@ -630,27 +655,28 @@ __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Ta
                                                  uint32_t lane) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
     if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && !T.tri && nchunks <= (uint32_t)KREG) {
+        constexpr bool WR = WK != WK_NONE;
         switch (nchunks) {
-            case 1: return run_fast<KIND, FILL, WK, 1, false>(P, T, i0, F, la, lane);
-            case 2: return run_fast<KIND, FILL, WK, 2, false>(P, T, i0, F, la, lane);
-            case 3: return run_fast<KIND, FILL, WK, 3, false>(P, T, i0, F, la, lane);
-            case 4: return run_fast<KIND, FILL, WK, 4, false>(P, T, i0, F, la, lane);
-            case 5: return run_fast<KIND, FILL, WK, 5, false>(P, T, i0, F, la, lane);
-            case 6: return run_fast<KIND, FILL, WK, 6, false>(P, T, i0, F, la, lane);
-            case 7: return run_fast<KIND, FILL, WK, 7, false>(P, T, i0, F, la, lane);
-            default: return run_fast<KIND, FILL, WK, 8, false>(P, T, i0, F, la, lane);
+            case 1: return run_fast<KIND, FILL, WR, 1, false>(P, T, i0, F, la, lane);
+            case 2: return run_fast<KIND, FILL, WR, 2, false>(P, T, i0, F, la, lane);
+            case 3: return run_fast<KIND, FILL, WR, 3, false>(P, T, i0, F, la, lane);
+            case 4: return run_fast<KIND, FILL, WR, 4, false>(P, T, i0, F, la, lane);
+            case 5: return run_fast<KIND, FILL, WR, 5, false>(P, T, i0, F, la, lane);
+            case 6: return run_fast<KIND, FILL, WR, 6, false>(P, T, i0, F, la, lane);
+            case 7: return run_fast<KIND, FILL, WR, 7, false>(P, T, i0, F, la, lane);
+            default: return run_fast<KIND, FILL, WR, 8, false>(P, T, i0, F, la, lane);
         }
     }
     if (KIND == MOLAR_HIP_SEARCH_SINGLE && WK == WK_NONE && T.tri && nchunks <= (uint32_t)KREG) {
         switch (nchunks) {
-            case 1: return run_fast<KIND, FILL, WK_NONE, 1, true>(P, T, i0, F, la, lane);
-            case 2: return run_fast<KIND, FILL, WK_NONE, 2, true>(P, T, i0, F, la, lane);
-            case 3: return run_fast<KIND, FILL, WK_NONE, 3, true>(P, T, i0, F, la, lane);
-            case 4: return run_fast<KIND, FILL, WK_NONE, 4, true>(P, T, i0, F, la, lane);
-            case 5: return run_fast<KIND, FILL, WK_NONE, 5, true>(P, T, i0, F, la, lane);
-            case 6: return run_fast<KIND, FILL, WK_NONE, 6, true>(P, T, i0, F, la, lane);
-            case 7: return run_fast<KIND, FILL, WK_NONE, 7, true>(P, T, i0, F, la, lane);
-            default: return run_fast<KIND, FILL, WK_NONE, 8, true>(P, T, i0, F, la, lane);
+            case 1: return run_fast<KIND, FILL, false, 1, true>(P, T, i0, F, la, lane);
+            case 2: return run_fast<KIND, FILL, false, 2, true>(P, T, i0, F, la, lane);
+            case 3: return run_fast<KIND, FILL, false, 3, true>(P, T, i0, F, la, lane);
+            case 4: return run_fast<KIND, FILL, false, 4, true>(P, T, i0, F, la, lane);
+            case 5: return run_fast<KIND, FILL, false, 5, true>(P, T, i0, F, la, lane);
+            case 6: return run_fast<KIND, FILL, false, 6, true>(P, T, i0, F, la, lane);
+            case 7: return run_fast<KIND, FILL, false, 7, true>(P, T, i0, F, la, lane);
+            default: return run_fast<KIND, FILL, false, 8, true>(P, T, i0, F, la, lane);
         }
     }
     if (nchunks > (uint32_t)KREG) {
@@ -675,7 +701,7 @@ __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__r
     task_nb[t] = T.valid ? (T.n1 + T.rps - 1u) / T.rps : 0u;
     TaskDesc d;
     d.a0 = T.a0; d.n1 = T.n1; d.b0 = T.b0; d.n2 = T.n2; d.cb = T.cb;
-    d.flags = T.wrap | (T.tri ? 0x100u : 0u) | (T.valid ? 0x200u : 0u) | (T.rps << 16);
+    d.flags = T.wrap | (T.tri ? 0x100u : 0u) | (T.valid ? 0x200u : 0u) | (T.wrap_b << 12) | (T.rps << 16);
     d.pad0 = d.pad1 = 0;
     task_desc[t] = d;
 }
@@ -732,6 +758,7 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
             T.wrap = fl & 7u;
             T.tri = (fl & 0x100u) != 0u;
             T.valid = (fl & 0x200u) != 0u;
+            T.wrap_b = (fl >> 12) & 7u;
             T.rps = fl >> 16;
         }
         const uint32_t i0 = (slot - task_first[t]) * T.rps;
@@ -745,6 +772,9 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
         F.ids = out_ids;
         F.base = 0;
         F.hist = hist ? lds_hist : nullptr;
+        F.recompute = false;
+        F.la = lds_a[wave];
+        F.wrap = 0;
         F.hmin = P.hist_min;
         F.hmax = P.hist_max;
         F.hn = (float)P.hist_nbins;

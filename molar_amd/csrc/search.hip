@@ -499,6 +499,28 @@ SearchParams make_params(molar_hip_ctx *c) {
     }
     const float lim = c->cutoff + 1.0e-3f;
     P.prune_limit2 = lim * lim;
+    // Wrapped entries: classify with the plain distance to the image cell, decide exactly inside a band
+    // around cutoff^2.  Both evaluations carry a few ulp(L) of absolute error in each component of the
+    // difference vector (L = largest lab extent), i.e. <= ~2*sqrt(3)*rc*8*ulp(L) in d2, which relative to
+    // rc^2 is ~1.7e-6 * L/rc; the band is 2e-4 + 1e-5 * L/rc, more than 10x that for any box.
+    P.approx_wrapped = 0u;
+    P.band_lo = P.band_hi = P.cutoff2;
+    if (c->use_box) {
+        bool ok = (uint64_t)c->set[0].n + (uint64_t)c->set[1].n < (1ull << 26);   // (row<<26 | position) packing
+        float ext[3], lmax = 0.f;
+        molar_hip_box_lab_extents(&c->box, ext);
+        for (int d = 0; d < 3; ++d) {
+            if (((c->pbc >> d) & 1u) && c->dims[d] < 4u) ok = false;   // round(f_d) must be +-1 for wrapped pairs
+            lmax = std::fmax(lmax, std::fabs(ext[d]));
+            for (int k = 0; k < 3; ++k) lmax = std::fmax(lmax, std::fabs(c->box.m[3 * k + d]));
+        }
+        const float rel = 2.0e-4f + 1.0e-5f * (lmax / c->cutoff);
+        if (ok && rel < 0.05f) {
+            P.approx_wrapped = 1u;
+            P.band_lo = P.cutoff2 * (1.0f - rel);
+            P.band_hi = P.cutoff2 * (1.0f + rel);
+        }
+    }
     const char *dbg = std::getenv("MOLAR_HIP_DEBUG_SKIP");
     P.debug_skip = dbg ? (uint32_t)std::atoi(dbg) : 0u;
     return P;

@@ -411,3 +411,49 @@ def test_unwrap_connectivity(eng, orc32):
             break
         todo.append(int(rest[0])); used[int(rest[0])] = True
     assert np.array_equal(un, ref)
+
+
+@pytest.mark.parametrize("boxkind", ["ortho", "tric"])
+def test_wrapped_pairs_at_the_cutoff_edge(eng, orc32, boxkind):
+    """Wrapped cell pairs are classified with a cheap distance and decided exactly only inside a narrow band
+    around cutoff^2 (pair_kernels.hpp, run_fast).  Stress exactly that band: thousands of pairs straddling the
+    periodic boundary whose distance is cutoff*(1 +- 3e-4), where one ulp decides membership."""
+    rng = np.random.default_rng(21)
+    L = 9.0
+    box = np.diag([L, L, L]).astype(np.float32)
+    if boxkind == "tric":
+        box[0, 2] = -1.5; box[1, 2] = -1.5; box[0, 1] = 0.7
+    rc = 1.0
+    npairs = 6000
+    M = box.astype(np.float64)
+    pts = []
+    for k in range(npairs):
+        # a near the far face of a random periodic dim, b = a + u*d mapped back into the box
+        fa = rng.random(3)
+        dim = int(rng.integers(0, 3))
+        fa[dim] = 1.0 - 0.04 * rng.random()
+        a = M @ fa
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        d = rc * (1.0 + rng.uniform(-3e-4, 3e-4))
+        b = a + d * u
+        fb = np.linalg.solve(M, b)
+        if not ((fb < 0) | (fb >= 1)).any():
+            continue                                   # keep only pairs that really cross the boundary
+        fb = fb % 1.0
+        pts.append(a); pts.append(M @ fb)
+    pos = np.array(pts, np.float32)
+    # background atoms so that cells are populated like a real system
+    pos = np.concatenate([pos, synth.frame(4000, box, 5)])
+    ob = orc32.box_from_matrix(box)
+    ref = orc32.search_single_pbc(rc, pos, ob, 7, nthreads=4)
+    assert min(ref["dims"]) >= 4                        # the approximate classification is active
+    gi, gj, gd, cnt = run_single(eng, rc, pos, box, 7)
+    assert cnt == len(ref["i"])
+    assert_same_pairs(gi, gj, gd, ref)
+    # the band really was exercised: many reference distances lie within 3e-4 of the cutoff
+    assert (np.abs(ref["d"] / rc - 1.0) < 3e-4).sum() > 1000
+    # and the fused histogram agrees too (flush-time recomputation of wrapped d2)
+    a = api()
+    want = orc32.histogram_add(0.0, rc, 500, ref["d"]).astype(np.uint64)
+    bins, c2 = eng.search_histogram(a.SEARCH_SINGLE, rc, 0.0, rc, 500, pos, box=box, pbc=7)
+    assert c2 == cnt and np.array_equal(bins, want)
