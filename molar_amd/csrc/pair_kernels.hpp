@@ -605,9 +605,10 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
                 if (mask) {
                     const uint32_t cnt = (uint32_t)__popcll(mask);
                     if (hit) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                        const uint32_t s = (F.tail + rank) & (FIFO_CAP - 1);
+                        // FIFO slot = tail + rank among the hit lanes (mbcnt accumulates onto tail)
+                        const uint32_t s = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, F.tail)) &
+                                           (FIFO_CAP - 1);
                         F.fi[s] = id_i;
                         F.fj[s] = bid[k];
                         F.fd[s] = third;
