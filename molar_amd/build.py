@@ -2,6 +2,8 @@
 file so that it travels with the repo snapshot to the GPU box."""
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import subprocess
 
@@ -15,17 +17,44 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function"]
 
 
+HASH_FILE = LIB + ".srchash"
+
+
+def _source_hash() -> str:
+    """Content hash of everything the library is built from (file mtimes do not survive a repo snapshot)."""
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HASH_FILE):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        return open(HASH_FILE).read().strip() != _source_hash()
+    except OSError:
+        return True
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
+    # several ranks of one node may get here at once (torch.distributed.run): build under a lock
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
@@ -46,6 +75,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed: {' '.join(cmd)}\n{r.stdout}{r.stderr}")
+    with open(HASH_FILE, "w") as f:
+        f.write(_source_hash())
     return LIB
 
 

@@ -457,3 +457,35 @@ def test_wrapped_pairs_at_the_cutoff_edge(eng, orc32, boxkind):
     want = orc32.histogram_add(0.0, rc, 500, ref["d"]).astype(np.uint64)
     bins, c2 = eng.search_histogram(a.SEARCH_SINGLE, rc, 0.0, rc, 500, pos, box=box, pbc=7)
     assert c2 == cnt and np.array_equal(bins, want)
+
+
+def test_non_finite_coordinates_and_degenerate_inputs(eng, orc32):
+    """NaN / inf coordinates never compare as hits in the reference (and land in cell 0 through the
+    saturating `as usize` cast); the engine must agree and must not fault.  Also: coincident atoms (d = 0)."""
+    a = api()
+    n = 3000
+    box = synth.box_a(n)
+    pos = synth.frame(n, box)
+    pos[10] = [np.nan, 1.0, 1.0]
+    pos[11] = [np.inf, 1.0, 1.0]
+    pos[12] = [1.0, -np.inf, np.nan]
+    pos[500] = pos[499]                      # coincident pair: d2 == 0, sqrt(0) == 0 exactly
+    ob = orc32.box_from_matrix(box)
+    ref = orc32.search_single_pbc(0.5, pos, ob, 7)
+    gi, gj, gd, cnt = run_single(eng, 0.5, pos, box, 7)
+    assert cnt == len(ref["i"])
+    assert_same_pairs(gi, gj, gd, ref)
+    assert not np.isin([10, 11, 12], np.concatenate([gi, gj])).any()
+    hit = (gi == 499) & (gj == 500)
+    assert hit.sum() == 1 and gd[hit][0] == 0.0
+    # non-periodic driver: NaN only (an infinite coordinate makes the reference's zero-seeded bounding box,
+    # hence its grid, infinite - it cannot run there either)
+    pos2 = pos.copy()
+    pos2[11] = [2.0, 1.0, 1.0]
+    pos2[12] = [1.0, 2.0, np.nan]
+    ref = orc32.search_single(0.5, pos2)
+    gi, gj, gd, cnt = run_single(eng, 0.5, pos2)
+    assert_same_pairs(gi, gj, gd, ref)
+    # an empty second set
+    cnt = eng.search_count(a.SEARCH_DOUBLE, 0.5, pos, np.arange(100, dtype=np.uint64), pos, np.zeros(0, np.uint64), box=box, pbc=7)
+    assert cnt == 0
