@@ -100,6 +100,15 @@ int molar_hip_box_from_vectors_angles(float a, float b, float c, float alpha, fl
 void molar_hip_box_shortest_vector(const molar_hip_box *box, const float v[3], uint8_t pbc, float out[3]);
 /* get_lab_extents (periodic_box.rs:369-375): row sums, what sizes the search grid. */
 void molar_hip_box_lab_extents(const molar_hip_box *box, float out[3]);
+/* get_box_extents (:364-366): lengths of the box vectors. */
+void molar_hip_box_extents(const molar_hip_box *box, float out[3]);
+/* to_box_coords (:340-344) = inv*v, to_lab_coords (:356-360) = M*v. */
+void molar_hip_box_to_box_coords(const molar_hip_box *box, const float v[3], float out[3]);
+void molar_hip_box_to_lab_coords(const molar_hip_box *box, const float v[3], float out[3]);
+/* is_inside (:348-352): all fractional coordinates in [0,1). */
+int molar_hip_box_is_inside(const molar_hip_box *box, const float p[3]);
+/* wrap_point / wrap_vec (:409-434), including the reference's `1.0 - bv` for negative fractions. */
+void molar_hip_box_wrap_point(const molar_hip_box *box, const float p[3], float out[3]);
 
 /* ------------------------------------------------------------------ distance search (distance_search.rs) */
 

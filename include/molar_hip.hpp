@@ -148,6 +148,28 @@ class PeriodicBox {                          // periodic_box.rs:15-23,146-435
         molar_hip_box_lab_extents(&b_, &o.x);
         return o;
     }
+    Vector3f get_box_extents() const {
+        Vector3f o;
+        molar_hip_box_extents(&b_, &o.x);
+        return o;
+    }
+    Vector3f to_box_coords(const Vector3f &v) const {
+        Vector3f o;
+        molar_hip_box_to_box_coords(&b_, &v.x, &o.x);
+        return o;
+    }
+    Vector3f to_lab_coords(const Vector3f &v) const {
+        Vector3f o;
+        molar_hip_box_to_lab_coords(&b_, &v.x, &o.x);
+        return o;
+    }
+    bool is_inside(const Pos &p) const { return molar_hip_box_is_inside(&b_, &p.x) != 0; }
+    Pos wrap_point(const Pos &p) const {
+        Pos o;
+        molar_hip_box_wrap_point(&b_, &p.x, &o.x);
+        return o;
+    }
+    Vector3f wrap_vec(const Vector3f &v) const { return wrap_point(v); }
     bool is_triclinic() const {
         return b_.m[3] != 0 || b_.m[6] != 0 || b_.m[1] != 0 || b_.m[7] != 0 || b_.m[2] != 0 || b_.m[5] != 0;
     }

@@ -58,6 +58,11 @@ SYMBOLS = {
     "molar_hip_box_from_vectors_angles": (_I, [_F, _F, _F, _F, _F, _F, _P]),
     "molar_hip_box_shortest_vector": (None, [_P, _P, _U8, _P]),
     "molar_hip_box_lab_extents": (None, [_P, _P]),
+    "molar_hip_box_extents": (None, [_P, _P]),
+    "molar_hip_box_to_box_coords": (None, [_P, _P, _P]),
+    "molar_hip_box_to_lab_coords": (None, [_P, _P, _P]),
+    "molar_hip_box_is_inside": (_I, [_P, _P]),
+    "molar_hip_box_wrap_point": (None, [_P, _P, _P]),
     "molar_hip_search_count": (_I, [_P, _P, _P]),
     "molar_hip_search_fill": (_I, [_P, _P, _P]),
     "molar_hip_search_fill_usize": (_I, [_P, _P, _P, _P]),

@@ -117,6 +117,34 @@ class PeriodicBox:
         _lib.load().molar_hip_box_lab_extents(C.byref(self._b), out.ctypes.data)
         return out
 
+    def _v3(self, fn, v):
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        out = np.zeros(3, np.float32)
+        getattr(_lib.load(), fn)(C.byref(self._b), v.ctypes.data, out.ctypes.data)
+        return out
+
+    def to_box_coords(self, v):
+        return self._v3("molar_hip_box_to_box_coords", v)
+
+    def to_lab_coords(self, v):
+        return self._v3("molar_hip_box_to_lab_coords", v)
+
+    def wrap_point(self, p):
+        return self._v3("molar_hip_box_wrap_point", p)
+
+    def is_inside(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float32)
+        return bool(_lib.load().molar_hip_box_is_inside(C.byref(self._b), p.ctypes.data))
+
+    def get_box_extents(self):
+        out = np.zeros(3, np.float32)
+        _lib.load().molar_hip_box_extents(C.byref(self._b), out.ctypes.data)
+        return out
+
+    def is_triclinic(self):
+        m = self._b.m
+        return any(m[k] != 0.0 for k in (1, 2, 3, 5, 6, 7))
+
     @property
     def n_tric_corrections(self):
         return int(self._b.nshift)

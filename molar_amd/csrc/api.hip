@@ -219,6 +219,36 @@ void molar_hip_box_shortest_vector(const molar_hip_box *box, const float v[3], u
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 
+void molar_hip_box_extents(const molar_hip_box *box, float out[3]) {
+    for (int c = 0; c < 3; ++c) out[c] = len3(v3(box->m[3 * c], box->m[3 * c + 1], box->m[3 * c + 2]));
+}
+
+void molar_hip_box_to_box_coords(const molar_hip_box *box, const float v[3], float out[3]) {
+    const V3 r = mat_vec(box->inv, v3(v[0], v[1], v[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+void molar_hip_box_to_lab_coords(const molar_hip_box *box, const float v[3], float out[3]) {
+    const V3 r = mat_vec(box->m, v3(v[0], v[1], v[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+int molar_hip_box_is_inside(const molar_hip_box *box, const float p[3]) {
+    const V3 v = mat_vec(box->inv, v3(p[0], p[1], p[2]));
+    return (v.x < 1.0f && v.y < 1.0f && v.z < 1.0f && v.x >= 0.0f && v.y >= 0.0f && v.z >= 0.0f) ? 1 : 0;
+}
+
+void molar_hip_box_wrap_point(const molar_hip_box *box, const float p[3], float out[3]) {
+    const V3 f = mat_vec(box->inv, v3(p[0], p[1], p[2]));
+    float bv[3] = {f.x, f.y, f.z};
+    for (int i = 0; i < 3; ++i) {
+        bv[i] = fract_rs(bv[i]);
+        if (bv[i] < 0.0f) bv[i] = 1.0f - bv[i];     // sic (periodic_box.rs:414-416)
+    }
+    const V3 r = mat_vec(box->m, v3(bv[0], bv[1], bv[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
 void molar_hip_box_lab_extents(const molar_hip_box *box, float out[3]) {
     const float *m = box->m;
     out[0] = (m[0] + m[3]) + m[6];

@@ -56,6 +56,11 @@ def test_box_matches_oracle_bitwise(lib, orc32):
         assert pb._b.nshift == ob.nshift
         assert np.array_equal(np.array(pb._b.shifts)[: 3 * ob.nshift], np.array(ob.shifts)[: 3 * ob.nshift])
         assert np.array_equal(pb.get_lab_extents(), orc32.lab_extents(ob))
+        assert np.array_equal(pb.get_box_extents(), orc32.box_extents(ob))
+        for _ in range(50):
+            q = rng.uniform(-30, 30, 3).astype(np.float32)
+            assert np.array_equal(pb.wrap_point(q), orc32.wrap_point(ob, q))
+            assert pb.is_inside(q) == orc32.is_inside(ob, q)
         for _ in range(200):
             v = rng.uniform(-60, 60, 3).astype(np.float32)
             for dims in (7, 0, 1, 3, 5):
