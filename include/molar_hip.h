@@ -222,6 +222,39 @@ int molar_hip_membrane_initial_normals(size_t nlipids, const float *head_markers
                                        const uint64_t *patch_offsets, const uint64_t *patch_ids,
                                        const uint8_t *valid, float *normals_out);
 
+/* One iteration of Membrane::smooth (molar_membrane/src/lib.rs:661-812) for all lipids on the GPU: local
+ * frame from the lipid's normal (lipid_molecule.rs:190-196), patch markers into that frame through
+ * PeriodicBox::shortest_vector, quadric fit (get_quad_coefs :844-863), Voronoi cell of the marker among its patch
+ * (molar/src/voronoi_cell.rs:62-211), curvatures + fitted normal (lipid_molecule.rs:102-188), cell area, fitted
+ * patch points, then the scatter-average of the markers (:781-809).  Replaces the rayon par_iter over lipids.
+ * Host pointers.  Patches are CSR over lipid ids (compute_patches :539-558).  The state arrays are IN/OUT exactly
+ * like the fields of LipidMolecule: a lipid that is (or becomes) invalid keeps its previous values; optional
+ * outputs may be NULL.  Lipid i owns slots [patch_offsets[i] + 4*i, patch_offsets[i+1] + 4*(i+1)) of neib_ids
+ * and voro_vertexes and fills the first nvert[i] of them (a cell has at most patch_len + 4 vertices).
+ * Eigenpairs: nalgebra's symmetric_eigen leaves order and sign open; here princ_curvs are descending and each
+ * direction has a positive first non-zero local component. */
+typedef struct {
+    size_t nlipids;
+    const uint64_t *patch_offsets;   /* [nlipids+1] */
+    const uint64_t *patch_ids;       /* [patch_offsets[nlipids]] */
+} molar_hip_membrane_patches;
+typedef struct {
+    float *head_markers;             /* [K][3]  required */
+    float *normals;                  /* [K][3]  required: in = normal defining the local frame, out = fitted normal */
+    uint8_t *valid;                  /* [K]     required */
+    float *quad_coefs;               /* [K][6]  a,b,c,d,e,f of z = a x^2 + b y^2 + c xy + d x + e y + f */
+    float *mean_curv, *gauss_curv;   /* [K] */
+    float *princ_curvs;              /* [K][2] */
+    float *princ_dirs;               /* [K][2][3] */
+    float *area;                     /* [K] */
+    uint32_t *nvert;                 /* [K] */
+    uint64_t *neib_ids;              /* [E + 4K] slotted, see above */
+    float *voro_vertexes;            /* [E + 4K][3] slotted */
+    float *fitted_patch_points;      /* [E][3] aligned with patch_ids */
+} molar_hip_membrane_state;
+int molar_hip_membrane_smooth(molar_hip_ctx *ctx, const molar_hip_membrane_patches *patches, const float *box9,
+                              molar_hip_membrane_state *state);
+
 /* Measure::lipid_tail_order (measure.rs:270-422), batched over `ntails` tails given as CSR:
  * tail t holds the carbons idx[tail_offsets[t] .. tail_offsets[t+1]) (n_t atoms), its normals are
  * normals[3*normal_offsets[t] .. 3*normal_offsets[t+1]) (1 or n_t-2 vectors), its n_t-1 bond orders

@@ -83,6 +83,7 @@ SYMBOLS = {
     "molar_hip_center_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _P]),
     "molar_hip_unwrap_simple_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _U8]),
     "molar_hip_membrane_initial_normals": (_I, [_SZ, _P, _P, _P, _P, _P, _P]),
+    "molar_hip_membrane_smooth": (_I, [_P, _P, _P, _P]),
     "molar_hip_lipid_tail_order": (_I, [_P, _P, _SZ, _P, _P, _SZ, _I, _P, _P, _P, _P]),
     "molar_hip_apply_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
     "molar_hip_unwrap_simple": (_I, [_P, _P, _SZ, _P, _SZ, _P, _U8]),

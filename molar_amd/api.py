@@ -430,6 +430,26 @@ class Engine:
                                                   bond_orders.ctypes.data, out.ctypes.data))
         return out[:nout]
 
+    def membrane_smooth(self, box, state, patch_offsets, patch_ids):
+        """One iteration of Membrane::smooth (molar_membrane/src/lib.rs:661-812) on the GPU.  `state` is a dict of
+        per-lipid arrays updated IN PLACE (see new_membrane_state); a lipid that turns invalid keeps its old
+        values, like the fields of the reference's LipidMolecule."""
+        pb = box if isinstance(box, PeriodicBox) else PeriodicBox.from_matrix(box)
+        po = _u64(patch_offsets); pi = _u64(patch_ids)
+        K = len(po) - 1
+        E = int(po[-1]); slots = E + 4 * K
+        st = state
+        if st["neib_ids"].shape[0] != max(slots, 1):                       # patch structure changed: re-slot
+            st["neib_ids"] = np.zeros(max(slots, 1), np.uint64)
+            st["voro_vertexes"] = np.zeros((max(slots, 1), 3), np.float32)
+            st["fitted_patch_points"] = np.zeros((max(E, 1), 3), np.float32)
+            st["nvert"][:] = 0
+        P = _MembranePatches(K, po.ctypes.data, pi.ctypes.data if E else None)
+        S = _MembraneState(*[st[k].ctypes.data for k in _MEMBRANE_FIELDS])
+        m9 = pb.colmajor9()
+        check(self.lib.molar_hip_membrane_smooth(self.ctx, C.byref(P), m9.ctypes.data, C.byref(S)))
+        return st
+
     def lipid_tail_order(self, xyz, tails, order_type, normals, bond_orders):
         """Batched Measure::lipid_tail_order (measure.rs:270-422).  tails: list of index arrays (the
         tail carbons, in chain order); normals: list of [1,3] or [n-2,3] arrays; bond_orders: list of
@@ -479,6 +499,33 @@ class Engine:
                                                 1 if apply else 0, rm.ctypes.data, R.ctypes.data, t.ctypes.data,
                                                 com.ctypes.data, gy.ctypes.data))
         return dict(rmsd=rm, R=R.reshape(F, 3, 3).transpose(0, 2, 1).copy(), t=t, com=com, gyration=gy)
+
+
+_MEMBRANE_FIELDS = ("head_markers", "normals", "valid", "quad_coefs", "mean_curv", "gauss_curv", "princ_curvs",
+                    "princ_dirs", "area", "nvert", "neib_ids", "voro_vertexes", "fitted_patch_points")
+
+
+class _MembranePatches(C.Structure):     # molar_hip_membrane_patches
+    _fields_ = [("nlipids", C.c_size_t), ("patch_offsets", C.c_void_p), ("patch_ids", C.c_void_p)]
+
+
+class _MembraneState(C.Structure):       # molar_hip_membrane_state
+    _fields_ = [(k, C.c_void_p) for k in _MEMBRANE_FIELDS]
+
+
+def new_membrane_state(head_markers, normals, valid=None, npatch_entries=0):
+    """Per-lipid state with the defaults of Membrane::new (molar_membrane/src/lib.rs:152-177)."""
+    head = np.array(head_markers, np.float32, order="C").reshape(-1, 3)
+    K = len(head)
+    slots = max(npatch_entries + 4 * K, 1)
+    return dict(
+        head_markers=head, normals=np.array(normals, np.float32, order="C").reshape(K, 3),
+        valid=np.ones(K, np.uint8) if valid is None else np.array(valid, np.uint8, order="C"),
+        quad_coefs=np.zeros((K, 6), np.float32), mean_curv=np.full(K, -100.0, np.float32),
+        gauss_curv=np.full(K, -100.0, np.float32), princ_curvs=np.zeros((K, 2), np.float32),
+        princ_dirs=np.zeros((K, 2, 3), np.float32), area=np.zeros(K, np.float32), nvert=np.zeros(K, np.uint32),
+        neib_ids=np.zeros(slots, np.uint64), voro_vertexes=np.zeros((slots, 3), np.float32),
+        fitted_patch_points=np.zeros((max(npatch_entries, 1), 3), np.float32))
 
 
 def membrane_initial_normals(head_markers, tail_markers, patch_offsets, patch_ids, valid=None, normals=None):

@@ -4,10 +4,15 @@
     markers      head / mid / tail-end centres of mass per lipid       lipid_molecule.rs:65-99, lib.rs:135-137
     patches      PBC neighbour search among head markers               lib.rs:539-558
     normals      tail->head vectors, two neighbour-averaging passes    lib.rs:456-505
+    smoothing    quadric fit, Voronoi cell, curvature, marker update   lib.rs:661-812, voronoi_cell.rs, lipid_molecule.rs:102-196
+    n-th shell   patches / curvature averaging over neighbour shells    lib.rs:562-621
     order        lipid_tail_order per tail with the lipid's normal     lib.rs:435-443, lipid_molecule.rs:48-59
 
-The iterative surface smoothing (quadric fit, Voronoi cells, curvature: lib.rs:661-812) is NOT implemented;
-see DESIGN.md.  All per-lipid loops are batched: one launch per stage for all lipids of a frame.
+All per-lipid loops are batched: one launch per stage for all lipids of a frame.  The reference computes the
+markers once in Membrane::new and its per-frame refresh is commented out (lipid_molecule.rs:65-99); this class
+refreshes them every frame, which is what the commented code does.  Where the reference iterates a HashSet
+(n-th shell patches, curvature averaging) the order is unspecified there; here it is ascending lipid id.
+Group statistics and file output (stats.rs, lipid_group.rs) are host bookkeeping and out of scope.
 """
 from __future__ import annotations
 
@@ -32,7 +37,11 @@ class LipidTemplate:
 @dataclass
 class MembraneOptions:          # molar_membrane/src/lib.rs:53-85 (subset)
     cutoff: float = 2.5
-    order_type: int = 1         # 0 Sz, 1 Scd, 2 ScdCorr
+    order_type: int = 2         # 0 Sz, 1 Scd, 2 ScdCorr (the reference's default)
+    max_smooth_iter: int = 1
+    n_shells_patch: int = 0     # >0: re-define patches as the n-th Voronoi neighbour shell after a first pass
+    n_shells_smoothing: int = 0 # >0: average curvatures over the n-th neighbour shell
+    global_normal: object = None
     unwrap: bool = True
 
 
@@ -120,33 +129,99 @@ class Membrane:
         self.tail_bonds = np.ascontiguousarray(np.tile(np.concatenate(template.bond_orders), self.K))
         self.ntails = len(tl)
         self.tail_lens = [len(t) for t in tl]
+        self.valid = np.ones(self.K, np.uint8)                                  # LipidMolecule::valid, sticky across frames
+
+    def reset_valid_lipids(self):                                               # lib.rs:269-273
+        self.valid[:] = 1
+
+    @staticmethod
+    def _patch_csr(K, i, j):
+        """patch_ids[i].push(j); patch_ids[j].push(i) in pair order (lib.rs:553-556)."""
+        src = np.stack([i, j], 1).reshape(-1); dst = np.stack([j, i], 1).reshape(-1)
+        order = np.argsort(src, kind="stable")
+        return (np.concatenate([[0], np.cumsum(np.bincount(src, minlength=K))]).astype(np.uint64),
+                dst[order].astype(np.uint64))
+
+    def _neighbour_matrix(self, st, patch_off):
+        """Voronoi neighbours of the valid lipids as a K x K boolean CSR matrix."""
+        from scipy import sparse
+        K = self.K
+        ok = st["valid"].astype(bool)
+        cnt = np.where(ok, st["nvert"], 0).astype(np.int64)
+        slot0 = patch_off[:-1].astype(np.int64) + 4 * np.arange(K)
+        indptr = np.concatenate([[0], np.cumsum(cnt)])
+        pos = np.arange(indptr[-1]) - np.repeat(indptr[:-1], cnt) + np.repeat(slot0, cnt)
+        cols = st["neib_ids"][pos].astype(np.int64)
+        return sparse.csr_matrix((np.ones(len(cols), np.int32), cols, indptr), shape=(K, K))
+
+    @staticmethod
+    def _nth_shell(A, n):
+        """lib.rs:572-578 / 597-603: start from the direct neighbours, extend (n-2) times."""
+        R = A.copy()
+        for _ in range(2, n):
+            R = R + R @ A
+            R.data[:] = 1
+        R.sum_duplicates(); R.sort_indices()
+        return R
 
     def compute(self, xyz, box):
-        """One frame.  xyz: float32 [N,3] (numpy; unwrapped in place when options.unwrap).  Returns dict with
-        head/mid/tail markers [K,3], patch CSR, normals [K,3], order: list over tails of [K, n_t-2]."""
-        e, K = self.eng, self.K
+        """One frame (Membrane::compute, lib.rs:410-454).  xyz: float32 [N,3] (numpy; unwrapped in place when
+        options.unwrap).  Returns a dict: markers, patch CSR, per-lipid state (valid, normals, curvatures, area,
+        Voronoi neighbours/vertices) and order: list over tails of [K, n_t-2]."""
+        e, K, opt = self.eng, self.K, self.opt
         pb = box if isinstance(box, api.PeriodicBox) else api.PeriodicBox.from_matrix(box)
-        if self.opt.unwrap:                                                     # lipid_molecule.rs:75-76
+        if opt.unwrap:                                                          # lipid_molecule.rs:75-76
             e.unwrap_simple_batch(xyz, self.lipid_idx, self.lipid_off, pb)
         mk = e.center_batch(xyz, self.marker_idx, self.marker_off, self.masses).reshape(K, 3, 3)
         head, mid, tail = mk[:, 0].copy(), mk[:, 1].copy(), mk[:, 2].copy()
-        # compute_patches (lib.rs:539-558): ids are lipid ids -> local ids of the marker array
-        n = e.search_count(api.SEARCH_SINGLE, self.opt.cutoff, head, box=pb, pbc=api.PBC_FULL, ids_local=True)
+        # compute_patches (lib.rs:539-558): search among the valid lipids' head markers, ids = lipid ids
+        vidx = np.flatnonzero(self.valid).astype(np.uint64)
+        n = e.search_count(api.SEARCH_SINGLE, opt.cutoff, head, idx1=vidx, box=pb, pbc=api.PBC_FULL, ids_local=False)
         pairs, _ = e.search_fill(n)
-        i = pairs[:, 0].astype(np.int64); j = pairs[:, 1].astype(np.int64)
-        # patch_ids[i].push(j); patch_ids[j].push(i) in pair order
-        src = np.stack([i, j], 1).reshape(-1); dst = np.stack([j, i], 1).reshape(-1)
-        order = np.argsort(src, kind="stable")
-        patch_ids = dst[order].astype(np.uint64)
-        patch_off = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=K))]).astype(np.uint64)
-        normals = api.membrane_initial_normals(head, tail, patch_off, patch_ids)
-        # compute_order (lib.rs:435-443): one normal per lipid, shared by its tails
-        nrm = np.repeat(normals, self.ntails, axis=0)
+        patch_off, patch_ids = self._patch_csr(K, pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64))
+        normals = api.membrane_initial_normals(head, tail, patch_off, patch_ids, valid=self.valid)
+        st = api.new_membrane_state(head, normals, self.valid, len(patch_ids))
+        it = 0
+        while True:                                                             # lib.rs:417-432 (at least one pass)
+            if opt.n_shells_patch > 0 and it == 0:
+                e.membrane_smooth(pb, st, patch_off, patch_ids)
+                R = self._nth_shell(self._neighbour_matrix(st, patch_off), opt.n_shells_patch)
+                ok = st["valid"].astype(bool)
+                keep_off, keep_ids = patch_off, patch_ids                       # invalid lipids keep their patch
+                cnt = np.where(ok, np.diff(R.indptr), np.diff(keep_off.astype(np.int64)))
+                new_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+                new_ids = np.empty(int(new_off[-1]), np.uint64)
+                for k in range(K):                                              # host bookkeeping, once per frame
+                    a, b = int(new_off[k]), int(new_off[k + 1])
+                    new_ids[a:b] = R.indices[R.indptr[k]:R.indptr[k + 1]] if ok[k] else keep_ids[int(keep_off[k]):int(keep_off[k + 1])]
+                patch_off, patch_ids = new_off, new_ids
+            e.membrane_smooth(pb, st, patch_off, patch_ids)
+            it += 1
+            if it >= opt.max_smooth_iter:
+                break
+        self.valid[:] = st["valid"]
+        # compute_order (lib.rs:435-443): one normal per lipid (or the global one), shared by its tails
+        nl = st["normals"] if opt.global_normal is None else np.tile(np.asarray(opt.global_normal, np.float32), (K, 1))
+        nrm = np.repeat(nl, self.ntails, axis=0)
         noff = np.arange(K * self.ntails + 1, dtype=np.uint64)
-        flat = e.lipid_tail_order_csr(xyz, self.tail_idx, self.tail_off, self.opt.order_type, nrm, noff, self.tail_bonds)
+        flat = e.lipid_tail_order_csr(xyz, self.tail_idx, self.tail_off, opt.order_type, nrm, noff, self.tail_bonds)
         per_lipid = sum(l - 2 for l in self.tail_lens)
         flat = flat.reshape(K, per_lipid)
         out, pos = [], 0
         for l in self.tail_lens:
             out.append(flat[:, pos:pos + l - 2].copy()); pos += l - 2
-        return dict(head=head, mid=mid, tail=tail, patch_off=patch_off, patch_ids=patch_ids, normals=normals, order=out)
+        if opt.n_shells_smoothing > 0:              # smooth_curvature (lib.rs:584-621)
+            R = self._nth_shell(self._neighbour_matrix(st, patch_off), opt.n_shells_smoothing)
+            ok = st["valid"].astype(np.float32)
+            Rv = R.multiply(ok[None, :]).tocsr()
+            nval = np.asarray(Rv.sum(1)).reshape(-1).astype(np.float32)
+            for key in ("mean_curv", "gauss_curv"):
+                v = st[key].copy()
+                sm = (v + Rv @ v) / (nval + 1.0)
+                st[key] = np.where(ok > 0, sm, v).astype(np.float32)
+        res = dict(head=head, mid=mid, tail=tail, patch_off=patch_off, patch_ids=patch_ids, normals=st["normals"],
+                   initial_normals=normals, order=out, valid=st["valid"].copy(), smoothed_head=st["head_markers"])
+        for k in ("quad_coefs", "mean_curv", "gauss_curv", "princ_curvs", "princ_dirs", "area", "nvert", "neib_ids",
+                  "voro_vertexes", "fitted_patch_points"):
+            res[k] = st[k]
+        return res

@@ -24,6 +24,7 @@
 #ifdef ORACLE_F64
 #define R_SQRT sqrt
 #define R_FLOOR floor
+#define R_ABS fabs
 #define R_ROUND round
 #define R_TRUNC trunc
 #define R_ACOS acos
@@ -35,6 +36,7 @@
 #else
 #define R_SQRT sqrtf
 #define R_FLOOR floorf
+#define R_ABS fabsf
 #define R_ROUND roundf
 #define R_TRUNC truncf
 #define R_ACOS acosf
@@ -1312,4 +1314,267 @@ void orc_histogram_add(REAL minv, REAL maxv, size_t nbins, const REAL *vals, siz
         int64_t b = as_isize(R_FLOOR((REAL)n * (vals[k] - minv) / (maxv - minv)));
         if (b >= 0 && b < n) bins[b] += (REAL)1.0;
     }
+}
+
+/* ------------------------------------------------------------------ molar_membrane: Membrane::smooth
+ *
+ * One iteration of the surface smoothing (molar_membrane/src/lib.rs:661-812) for all lipids, with
+ *   get_to_lab_transform          lipid_molecule.rs:190-196
+ *   get_quad_coefs                lib.rs:844-863      (normal equations, nalgebra Cholesky + solve)
+ *   VoronoiCell::new / add_point  molar/src/voronoi_cell.rs:62-211 (TOL 1e-10)
+ *   compute_curvature_and_normal  lipid_molecule.rs:102-188
+ *   z_surf / project_to_surf      lib.rs:865-879
+ * PARITY UNPINNED: the reference holds no asserting test for this path (test_curvature_sphere only prints).
+ * nalgebra's symmetric_eigen does not define the order or sign of the 2x2 eigenpairs; here: descending
+ * eigenvalues, eigenvector with non-negative first non-zero component.
+ */
+
+/* nalgebra Cholesky::new (column-by-column, lower factor) then solve: L y = b, L^T x = y. */
+static int chol6_solve(REAL m[36] /* column-major */, REAL b[6]) {
+#define A(r, c) m[(c) * 6 + (r)]
+    for (int j = 0; j < 6; ++j) {
+        for (int k = 0; k < j; ++k) {
+            const REAL factor = -A(j, k);
+            for (int r = j; r < 6; ++r) A(r, j) = factor * A(r, k) + A(r, j);
+        }
+        const REAL diag = A(j, j);
+        if (!(diag > 0)) return 0;           /* zero, negative or NaN pivot: not positive definite */
+        const REAL denom = R_SQRT(diag);
+        A(j, j) = denom;
+        for (int r = j + 1; r < 6; ++r) A(r, j) /= denom;
+    }
+    for (int i = 0; i < 6; ++i) {            /* solve_lower_triangular_mut */
+        const REAL coeff = b[i] / A(i, i);
+        b[i] = coeff;
+        for (int r = i + 1; r < 6; ++r) b[r] = (-coeff) * A(r, i) + b[r];
+    }
+    for (int i = 5; i >= 0; --i) {           /* ad_solve_lower_triangular_mut */
+        REAL dot = 0;
+        for (int r = i + 1; r < 6; ++r) dot += A(r, i) * b[r];
+        b[i] = (b[i] - dot) / A(i, i);
+    }
+#undef A
+    return 1;
+}
+
+static inline REAL z_surf(REAL x, REAL y, const REAL c[6]) {       /* lib.rs:870-879 */
+    return ((((c[0] * x * x + c[1] * y * y) + c[2] * x * y) + c[3] * x) + c[4] * y) + c[5];
+}
+
+typedef struct { REAL x, y; int64_t next; int64_t id; } vvert;
+
+static inline REAL vdist(const vvert *v, REAL lx, REAL ly, REAL r2) { return (lx * v->x + ly * v->y) - r2; }
+
+/* voronoi_cell.rs:107-205; returns -1 if a loop would not terminate (the reference would hang) */
+static int voro_add_point(vvert *vert, int64_t *nvert, int64_t *init, REAL px, REAL py, int64_t id) {
+    const REAL TOL = (REAL)1e-10;
+    const REAL lx = (REAL)0.5 * px, ly = (REAL)0.5 * py;
+    const REAL r2 = lx * lx + ly * ly;
+    int64_t cur = *init, guard = 0;
+    REAL cur_d = vdist(&vert[cur], lx, ly, r2);
+    while (cur_d >= TOL) {
+        cur = vert[cur].next;
+        cur_d = vdist(&vert[cur], lx, ly, r2);
+        if (++guard > *nvert) return -1;
+    }
+    *init = cur;
+    int64_t c1_in, c1_out, c2_in, c2_out;
+    REAL c1_ind, c1_outd, c2_ind, c2_outd;
+    for (;;) {
+        const int64_t nx = vert[cur].next;
+        if (nx == *init) return 0;
+        const REAL nd = vdist(&vert[nx], lx, ly, r2);
+        if (nd >= TOL) {
+            c1_in = cur; c1_ind = cur_d; c1_out = nx; c1_outd = nd;
+            cur = nx; cur_d = nd;
+            break;
+        }
+        cur = nx; cur_d = nd;
+    }
+    guard = 0;
+    for (;;) {
+        const int64_t nx = vert[cur].next;
+        const REAL nd = vdist(&vert[nx], lx, ly, r2);
+        if (nd < TOL) {
+            c2_out = cur; c2_outd = cur_d; c2_in = nx; c2_ind = nd;
+            break;
+        }
+        cur = nx; cur_d = nd;
+        if (++guard > *nvert) return -1;
+    }
+    {   /* cut 2 */
+        const REAL frac = c2_outd / (R_ABS(c2_ind) + c2_outd);
+        const REAL x = ((REAL)1.0 - frac) * vert[c2_out].x + frac * vert[c2_in].x;
+        const REAL y = ((REAL)1.0 - frac) * vert[c2_out].y + frac * vert[c2_in].y;
+        if (c1_out != c2_out) {
+            vert[c2_out].x = x; vert[c2_out].y = y;
+            vert[c1_out].next = c2_out;
+        } else {
+            vvert nv = {x, y, c2_in, vert[c2_out].id};
+            vert[*nvert] = nv;
+            vert[c1_out].next = *nvert;
+            *nvert += 1;
+        }
+    }
+    {   /* cut 1 */
+        const REAL frac = c1_outd / (R_ABS(c1_ind) + c1_outd);
+        const REAL x = ((REAL)1.0 - frac) * vert[c1_out].x + frac * vert[c1_in].x;
+        const REAL y = ((REAL)1.0 - frac) * vert[c1_out].y + frac * vert[c1_in].y;
+        vert[c1_out].x = x; vert[c1_out].y = y;
+        vert[c1_out].id = id;
+    }
+    return 1;
+}
+
+/* 2x2 symmetric eigenproblem of [[a, b], [b, c]] (b = lower element, the one nalgebra reads) */
+static void eig2_sym(REAL a, REAL b, REAL c, REAL w[2], REAL v[4] /* column-major 2x2 */) {
+    const REAL half = (REAL)0.5;
+    const REAL t = half * (a - c), m = half * (a + c);
+    const REAL h = R_SQRT(t * t + b * b);
+    w[0] = m + h; w[1] = m - h;
+    REAL x, y;
+    if (b == 0) {
+        if (a >= c) { x = 1; y = 0; } else { x = 0; y = 1; }
+    } else {
+        /* (A - w1 I) v = 0 -> v = (b, w0 - a) or (w0 - c, b); take the better conditioned one */
+        if (t >= 0) { x = t + h; y = b; } else { x = b; y = h - t; }
+        const REAL n = R_SQRT(x * x + y * y);
+        x /= n; y /= n;
+        if (x < 0 || (x == 0 && y < 0)) { x = -x; y = -y; }
+    }
+    v[0] = x; v[1] = y;
+    /* second eigenvector: perpendicular, same sign convention */
+    REAL x2 = -y, y2 = x;
+    if (x2 < 0 || (x2 == 0 && y2 < 0)) { x2 = -x2; y2 = -y2; }
+    v[2] = x2; v[3] = y2;
+}
+
+int orc_membrane_smooth(const orc_box *box, size_t K, REAL *head, REAL *normals, uint8_t *valid,
+                        const uint64_t *poff, const uint64_t *pids, REAL *coefs, REAL *mean_curv,
+                        REAL *gauss_curv, REAL *princ_curvs, REAL *princ_dirs, REAL *area, uint32_t *nvert_out,
+                        uint64_t *neib_ids, REAL *voro, REAL *fitted) {
+    REAL *saved = (REAL *)malloc(sizeof(REAL) * 3 * (K ? K : 1));
+    memcpy(saved, head, sizeof(REAL) * 3 * K);
+    for (size_t i = 0; i < K; ++i) {
+        if (!valid[i]) continue;
+        const size_t p0 = poff[i], np = poff[i + 1] - poff[i], slot = p0 + 4 * i;
+        const REAL *nrm = normals + 3 * i;
+        REAL to_lab[9], to_local[9];
+        {   /* lipid_molecule.rs:190-196 */
+            const REAL ex[3] = {1, 0, 0};
+            REAL c0[3], c1[3];
+            cross3(nrm, ex, c0);
+            cross3(nrm, c0, c1);
+            for (int r = 0; r < 3; ++r) { to_lab[r] = c0[r]; to_lab[3 + r] = c1[r]; to_lab[6 + r] = -nrm[r]; }
+        }
+        if (!inverse3(to_lab, to_local)) { valid[i] = 0; continue; }
+        REAL *lp = (REAL *)malloc(sizeof(REAL) * 3 * (np ? np : 1));
+        for (size_t q = 0; q < np; ++q) {
+            const REAL *s = saved + 3 * pids[p0 + q];
+            REAL d[3] = {s[0] - saved[3 * i], s[1] - saved[3 * i + 1], s[2] - saved[3 * i + 2]}, sv[3];
+            orc_shortest_vector_dims(box, d, ORC_PBC_FULL, sv);
+            matvec(to_local, sv, lp + 3 * q);
+        }
+        REAL m[36], c[6] = {0, 0, 0, 0, 0, 0};
+        memset(m, 0, sizeof m);
+        for (size_t q = 0; q < np; ++q) {
+            const REAL x = lp[3 * q], y = lp[3 * q + 1], z = lp[3 * q + 2];
+            const REAL pw[6] = {x * x, y * y, x * y, x, y, (REAL)1.0};
+            for (int cc = 0; cc < 6; ++cc)
+                for (int r = 0; r < 6; ++r) m[cc * 6 + r] += pw[r] * pw[cc];
+            for (int r = 0; r < 6; ++r) c[r] += pw[r] * z;
+        }
+        if (!chol6_solve(m, c)) { valid[i] = 0; free(lp); continue; }
+        vvert *vert = (vvert *)malloc(sizeof(vvert) * (np + 4));
+        const vvert w0 = {-10, -10, 1, -1}, w1 = {10, -10, 2, -2}, w2 = {10, 10, 3, -3}, w3 = {-10, 10, 0, -4};
+        vert[0] = w0; vert[1] = w1; vert[2] = w2; vert[3] = w3;
+        int64_t nv = 4, init = 0;
+        int hang = 0;
+        for (size_t q = 0; q < np && !hang; ++q)
+            hang = voro_add_point(vert, &nv, &init, lp[3 * q], lp[3 * q + 1], (int64_t)pids[p0 + q]) < 0;
+        /* direct neighbours (lib.rs:706-726) */
+        uint32_t n_vert = 0, n_neib = 0;
+        if (!hang) {
+            int64_t cur = init;
+            do {
+                if (vert[cur].id >= 0) neib_ids[slot + n_neib++] = (uint64_t)vert[cur].id;
+                n_vert++;
+                cur = vert[cur].next;
+            } while (cur != init);
+        }
+        if (hang || n_neib < n_vert) { valid[i] = 0; free(vert); free(lp); continue; }
+        nvert_out[i] = n_vert;
+        memcpy(coefs + 6 * i, c, sizeof c);
+        {   /* lipid_molecule.rs:134-187 */
+            const REAL a = c[0], b = c[1], cq = c[2], d = c[3], e = c[4];
+            const REAL E = (REAL)1.0 + d * d, F = d * e, G = (REAL)1.0 + e * e;
+            const REAL L = (REAL)2.0 * a, Mm = cq, N = (REAL)2.0 * b;
+            const REAL Z = E * G - F * F;
+            gauss_curv[i] = (L * N - Mm * Mm) / Z;
+            mean_curv[i] = (REAL)0.5 * ((E * N - (REAL)2.0 * F * Mm) + G * L) / Z;
+            const REAL g[3] = {d, e, (REAL)-1.0};
+            REAL gn[3];
+            normalize3(g, gn);
+            matvec(to_lab, gn, normals + 3 * i);
+            const REAL W00 = (E * L - F * Mm) / Z, W10 = (G * Mm - F * L) / Z, W11 = (G * N - F * Mm) / Z;
+            REAL w[2], ev[4];
+            eig2_sym(W00, W10, W11, w, ev);
+            princ_curvs[2 * i] = w[0]; princ_curvs[2 * i + 1] = w[1];
+            for (int k = 0; k < 2; ++k) {
+                const REAL v3[3] = {ev[2 * k], ev[2 * k + 1], 0};
+                matvec(to_lab, v3, princ_dirs + 6 * i + 3 * k);
+            }
+        }
+        {   /* vertices projected to the surface, lab frame; triangle-fan area (lib.rs:731-752) */
+            int64_t cur = init;
+            for (uint32_t k = 0; k < n_vert; ++k) {
+                const REAL pv[3] = {vert[cur].x, vert[cur].y, z_surf(vert[cur].x, vert[cur].y, c)};
+                matvec(to_lab, pv, voro + 3 * (slot + k));
+                cur = vert[cur].next;
+            }
+            REAL ar = 0;
+            for (uint32_t k = 0; k < n_vert; ++k) {
+                REAL cr[3];
+                cross3(voro + 3 * (slot + k), voro + 3 * (slot + (k + 1) % n_vert), cr);
+                ar += (REAL)0.5 * norm3(cr);
+            }
+            area[i] = ar;
+        }
+        for (size_t q = 0; q < np; ++q) {   /* fitted patch points (lib.rs:760-768) */
+            const REAL dz[3] = {0, 0, z_surf(lp[3 * q], lp[3 * q + 1], c) - lp[3 * q + 2]};
+            REAL t[3];
+            matvec(to_lab, dz, t);
+            const REAL *s = saved + 3 * pids[p0 + q];
+            for (int r = 0; r < 3; ++r) fitted[3 * (p0 + q) + r] = s[r] + t[r];
+        }
+        free(vert); free(lp);
+        if (R_ABS(c[5]) > (REAL)0.5) { valid[i] = 0; continue; }
+        {
+            const REAL dz[3] = {0, 0, c[5]};
+            REAL t[3];
+            matvec(to_lab, dz, t);
+            for (int r = 0; r < 3; ++r) head[3 * i + r] += t[r];
+        }
+    }
+    /* serial scatter-average (lib.rs:781-801) */
+    REAL *sn = (REAL *)malloc(sizeof(REAL) * (K ? K : 1)), *sp = (REAL *)malloc(sizeof(REAL) * 3 * (K ? K : 1));
+    for (size_t i = 0; i < K; ++i) sn[i] = 1;
+    memcpy(sp, head, sizeof(REAL) * 3 * K);
+    for (size_t i = 0; i < K; ++i) {
+        if (!valid[i]) continue;
+        for (uint64_t q = poff[i]; q < poff[i + 1]; ++q) {
+            const uint64_t id = pids[q];
+            sn[id] += (REAL)1.0;
+            for (int r = 0; r < 3; ++r) sp[3 * id + r] += fitted[3 * q + r];
+        }
+    }
+    for (size_t i = 0; i < K; ++i) {
+        if (!valid[i]) continue;
+        for (int r = 0; r < 3; ++r) head[3 * i + r] = sp[3 * i + r] / sn[i];
+        const size_t slot = poff[i] + 4 * i;
+        for (uint32_t k = 0; k < nvert_out[i]; ++k)
+            for (int r = 0; r < 3; ++r) voro[3 * (slot + k) + r] += head[3 * i + r];
+    }
+    free(sn); free(sp); free(saved);
+    return ORC_OK;
 }

@@ -177,6 +177,17 @@ int  orc_lipid_tail_order(const REAL *xyz, const uint64_t *idx, size_t n, int or
 void orc_histogram_add(REAL minv, REAL maxv, size_t nbins, const REAL *vals, size_t nvals,
                        REAL *bins);
 
+/* One iteration of molar_membrane's Membrane::smooth (lib.rs:661-812): per valid lipid a local frame from
+ * its normal, quadric fit of the patch markers, Voronoi cell, curvatures, fitted normal, area; then the serial
+ * scatter-average of the markers.  head [K][3], normals [K][3] and valid [K] are updated in place; lipids that
+ * stay valid get coefs [K][6], mean/gauss [K], princ_curvs [K][2], princ_dirs [K][2][3], area [K], nvert [K];
+ * lipid i owns slots [poff[i]+4i, poff[i+1]+4(i+1)) of neib_ids / voro ([..][3]) and uses nvert[i] of them;
+ * fitted [E][3] is aligned with pids. */
+int orc_membrane_smooth(const orc_box *box, size_t K, REAL *head, REAL *normals, uint8_t *valid,
+                        const uint64_t *poff, const uint64_t *pids, REAL *coefs, REAL *mean_curv,
+                        REAL *gauss_curv, REAL *princ_curvs, REAL *princ_dirs, REAL *area, uint32_t *nvert,
+                        uint64_t *neib_ids, REAL *voro, REAL *fitted);
+
 #ifdef __cplusplus
 }
 #endif

@@ -387,6 +387,27 @@ class Oracle:
             C.c_size_t(len(normals)), self._p(bo), C.c_size_t(len(bo)), self._p(out)))
         return out[: n - 2]
 
+    def membrane_smooth(self, box, head, normals, valid, patch_off, patch_ids):
+        """One Membrane::smooth iteration (molar_membrane/src/lib.rs:661-812).  Returns a dict; inputs are
+        copied, not modified."""
+        head = self.arr(head, (-1, 3)).copy(); normals = self.arr(normals, (-1, 3)).copy()
+        K = len(head)
+        valid = np.ascontiguousarray(valid, dtype=np.uint8).copy()
+        poff = np.ascontiguousarray(patch_off, dtype=np.uint64); pids = np.ascontiguousarray(patch_ids, dtype=np.uint64)
+        E = int(poff[-1]); S = E + 4 * K
+        r = self.real
+        out = dict(coefs=np.zeros((K, 6), r), mean_curv=np.full(K, -100.0, r), gauss_curv=np.full(K, -100.0, r),
+                   princ_curvs=np.zeros((K, 2), r), princ_dirs=np.zeros((K, 2, 3), r), area=np.zeros(K, r),
+                   nvert=np.zeros(K, np.uint32), neib_ids=np.zeros(max(S, 1), np.uint64),
+                   voro=np.zeros((max(S, 1), 3), r), fitted=np.zeros((max(E, 1), 3), r))
+        self._chk(self.lib.orc_membrane_smooth(
+            C.byref(box), C.c_size_t(K), self._p(head), self._p(normals), self._p(valid), self._p(poff), self._p(pids),
+            self._p(out["coefs"]), self._p(out["mean_curv"]), self._p(out["gauss_curv"]), self._p(out["princ_curvs"]),
+            self._p(out["princ_dirs"]), self._p(out["area"]), self._p(out["nvert"]), self._p(out["neib_ids"]),
+            self._p(out["voro"]), self._p(out["fitted"])))
+        out.update(head=head, normals=normals, valid=valid)
+        return out
+
     def histogram_add(self, minv, maxv, nbins, vals):
         vals = self.arr(vals)
         bins = np.zeros(nbins, self.real)

@@ -42,6 +42,25 @@ def oracle_normals(o, head, tail, patch):
     return nv
 
 
+def check_smooth(got, want, patch_off, K, tol=2e-5):
+    """GPU state vs the oracle's: validity, Voronoi neighbour ids and vertex counts exactly; floats to `tol`
+    (both sides evaluate the same f32 expressions; libm/rounding of sqrt and division are IEEE on both)."""
+    assert np.array_equal(got["valid"], want["valid"])
+    ok = want["valid"].astype(bool)
+    assert np.array_equal(got["nvert"][ok], want["nvert"][ok])
+    for k in np.flatnonzero(ok):
+        s0 = int(patch_off[k]) + 4 * k
+        nv = int(want["nvert"][k])
+        assert np.array_equal(got["neib_ids"][s0:s0 + nv], want["neib_ids"][s0:s0 + nv])
+        assert np.allclose(got["voro_vertexes"][s0:s0 + nv], want["voro"][s0:s0 + nv], rtol=tol, atol=tol)
+        a, b = int(patch_off[k]), int(patch_off[k + 1])
+        assert np.allclose(got["fitted_patch_points"][a:b], want["fitted"][a:b], rtol=tol, atol=tol)
+    for g, w in (("quad_coefs", "coefs"), ("mean_curv", "mean_curv"), ("gauss_curv", "gauss_curv"),
+                 ("princ_curvs", "princ_curvs"), ("princ_dirs", "princ_dirs"), ("area", "area"), ("normals", "normals"),
+                 ("smoothed_head", "head")):
+        assert np.allclose(got[g][ok], want[w][ok], rtol=tol, atol=tol), g
+
+
 def test_membrane_pipeline_matches_oracle(eng, orc32):
     from molar_amd import membrane as mb
     xyz, box, first, tpl, masses = mb.build_bilayer(200, 40000)
@@ -71,15 +90,124 @@ def test_membrane_pipeline_matches_oracle(eng, orc32):
     assert np.mean([len(p) for p in patch]) > 4
     # normals
     want_n = oracle_normals(orc32, res["head"], res["tail"], patch)
-    assert np.allclose(res["normals"], want_n, atol=2e-6)
-    assert np.allclose(np.linalg.norm(res["normals"], axis=1), 1.0, atol=1e-5)
+    assert np.allclose(res["initial_normals"], want_n, atol=2e-6)
+    assert np.allclose(np.linalg.norm(res["initial_normals"], axis=1), 1.0, atol=1e-5)
     # upper leaflet normals point up, lower down (tails towards the mid-plane)
-    assert (res["normals"][:200, 2] > 0.8).all() and (res["normals"][200:, 2] < -0.8).all()
+    assert (res["initial_normals"][:200, 2] > 0.8).all() and (res["initial_normals"][200:, 2] < -0.8).all()
+    # one smoothing pass (lib.rs:661-812) against the oracle's restatement on the same inputs
+    so = orc32.membrane_smooth(ob, res["head"], res["initial_normals"], np.ones(K, np.uint8), res["patch_off"], res["patch_ids"])
+    check_smooth(res, so, res["patch_off"], K)
     # order parameters per tail with the lipid normal
     for t, carbons in enumerate(tpl.tails):
         for k in range(0, K, 7):
+            if not res["valid"][k]:
+                continue
             want = orc32.lipid_tail_order(ref_xyz, 1, res["normals"][k][None, :], tpl.bond_orders[t],
                                           idx=first[k] + carbons.astype(np.uint64))
             assert np.allclose(res["order"][t][k], want, atol=3e-5)
     # roughly ordered chains along the normal: mean |Scd| in a sensible range
     assert 0.05 < np.abs(np.concatenate([o.reshape(-1) for o in res["order"]])).mean() < 0.6
+
+
+def _patches_from_oracle(o, ob, head, cutoff):
+    r = o.search_single_pbc(cutoff, head, ob, 7)
+    K = len(head)
+    i = r["i"].astype(np.int64); j = r["j"].astype(np.int64)
+    src = np.stack([i, j], 1).reshape(-1); dst = np.stack([j, i], 1).reshape(-1)
+    order = np.argsort(src, kind="stable")
+    return (np.concatenate([[0], np.cumsum(np.bincount(src, minlength=K))]).astype(np.uint64), dst[order].astype(np.uint64))
+
+
+@pytest.mark.parametrize("tric", [False, True])
+def test_smooth_sheet_parity_and_geometry(eng, orc32, orc64, tric):
+    """A jittered undulating sheet crossing the periodic boundaries: the GPU pass against the f32 oracle (ids
+    exact, floats 2e-5) and the f64 oracle (conditioning of the 6x6 normal equations: 2e-3), plus what the
+    geometry must give: six-ish neighbours, cell areas tiling the box."""
+    from molar_amd import api
+    rng = np.random.default_rng(5)
+    side = 40
+    L = side * 0.8
+    g = (np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 2) + 0.5
+         + 0.2 * rng.normal(size=(side * side, 2))) * L / side
+    z = 5.0 + 0.3 * np.sin(2 * np.pi * g[:, 0] / L) * np.cos(2 * np.pi * g[:, 1] / L) + 0.02 * rng.normal(size=len(g))
+    head = np.concatenate([g, z[:, None]], 1).astype(np.float32)
+    box = np.diag([L, L, 12.0]).astype(np.float32)
+    if tric:
+        box[0, 1] = 0.3 * L          # b = (0.3L, L, 0): sheared in-plane periodicity
+        head[:, 0] += 0.3 * head[:, 1]
+    K = len(head)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (K, 1))
+    nrm += 0.05 * rng.normal(size=nrm.shape).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    ob = orc32.box_from_matrix(box)
+    poff, pids = _patches_from_oracle(orc32, ob, head, 2.0)
+    st = api.new_membrane_state(head, nrm, None, len(pids))
+    eng.membrane_smooth(box, st, poff, pids)
+    st["smoothed_head"] = st["head_markers"]
+    w32 = orc32.membrane_smooth(ob, head, nrm, np.ones(K, np.uint8), poff, pids)
+    check_smooth(st, w32, poff, K)
+    w64 = orc64.membrane_smooth(orc64.box_from_matrix(box), head, nrm, np.ones(K, np.uint8), poff, pids)
+    ok = st["valid"].astype(bool) & w64["valid"].astype(bool)
+    assert ok.sum() == K
+    for gk, wk in (("mean_curv", "mean_curv"), ("gauss_curv", "gauss_curv"), ("area", "area"), ("normals", "normals"),
+                   ("smoothed_head", "head"), ("quad_coefs", "coefs")):
+        assert np.allclose(st[gk][ok], w64[wk][ok], rtol=2e-3, atol=2e-3), gk
+    assert 5.5 < st["nvert"].mean() < 6.5
+    assert abs(st["area"].sum() - L * L) < 0.02 * L * L
+    # smoothing pulls the markers towards the underlying surface: jitter in z shrinks
+    zs = 5.0 + 0.3 * np.sin(2 * np.pi * g[:, 0] / L) * np.cos(2 * np.pi * g[:, 1] / L)
+    assert np.abs(st["head_markers"][:, 2] - zs).mean() < np.abs(head[:, 2] - zs).mean()
+
+
+def test_smooth_sphere_curvature_and_invalidation(eng, orc32):
+    """Markers on a sphere cap (the reference's test_curvature_sphere geometry, lib.rs:1097-1134, with enough
+    points for a patch): curvatures ~ 1/R; rim lipids have open Voronoi cells and turn invalid; lipids that were
+    invalid on entry are left untouched."""
+    from molar_amd import api
+    rng = np.random.default_rng(11)
+    R, n = 10.0, 800
+    th = np.arccos(1 - rng.random(n) * (1 - np.cos(0.6))); ph = rng.random(n) * 2 * np.pi
+    c = np.array([25.0, 25.0, 10.0])
+    pts = (np.stack([R * np.sin(th) * np.cos(ph), R * np.sin(th) * np.sin(ph), R * np.cos(th)], 1) + c).astype(np.float32)
+    box = np.diag([50.0, 50.0, 50.0]).astype(np.float32)
+    nrm = ((pts - c) / R).astype(np.float32)
+    ob = orc32.box_from_matrix(box)
+    poff, pids = _patches_from_oracle(orc32, ob, pts, 2.5)
+    valid = np.ones(n, np.uint8); valid[::17] = 0
+    st = api.new_membrane_state(pts, nrm, valid, len(pids))
+    eng.membrane_smooth(box, st, poff, pids)
+    st["smoothed_head"] = st["head_markers"]
+    want = orc32.membrane_smooth(ob, pts, nrm, valid, poff, pids)
+    check_smooth(st, want, poff, n)
+    ok = st["valid"].astype(bool)
+    assert 0.5 * n < ok.sum() < n - n // 17          # interior valid, rim invalid
+    assert abs(st["mean_curv"][ok].mean() - 1 / R) < 0.015
+    assert np.all(st["princ_curvs"][ok, 0] >= st["princ_curvs"][ok, 1])
+    assert np.allclose(st["princ_curvs"][ok].sum(1) / 2, st["mean_curv"][ok], atol=1e-3)
+    assert np.allclose(st["princ_curvs"][ok].prod(1), st["gauss_curv"][ok], atol=1e-3)
+    off = valid == 0
+    assert np.array_equal(st["head_markers"][off], pts[off]) and np.all(st["mean_curv"][off] == -100.0)
+    # degenerate normal along x: to_lab is singular (normal x X = 0) -> invalid (lib.rs:675-679)
+    nrm2 = nrm.copy(); nrm2[5] = [1, 0, 0]
+    st2 = api.new_membrane_state(pts, nrm2, None, len(pids))
+    eng.membrane_smooth(box, st2, poff, pids)
+    assert st2["valid"][5] == 0
+
+
+def test_membrane_shells_and_iterations(eng, orc32):
+    """n-th shell patches + two smoothing iterations + curvature averaging run end to end and keep the bilayer
+    geometry: normals stay aligned with the leaflet, areas near the lattice area per lipid."""
+    from molar_amd import membrane as mb
+    xyz, box, first, tpl, masses = mb.build_bilayer(400, 60000)
+    K = len(first)
+    m = mb.Membrane(eng, len(xyz), first, tpl, masses,
+                    mb.MembraneOptions(cutoff=2.0, max_smooth_iter=2, n_shells_patch=3, n_shells_smoothing=2))
+    res = m.compute(xyz.copy(), box)
+    ok = res["valid"].astype(bool)
+    assert ok.sum() > 0.95 * K
+    up = np.arange(K) < 400
+    assert (res["normals"][ok & up, 2] > 0.8).all() and (res["normals"][ok & ~up, 2] < -0.8).all()
+    assert abs(res["area"][ok].mean() - 0.62) < 0.05
+    assert np.abs(res["mean_curv"][ok]).mean() < 0.2
+    # patches are now Voronoi shells: symmetric-ish, much smaller than the 2 nm disc
+    assert np.diff(res["patch_off"].astype(np.int64))[ok].mean() < 30
