@@ -574,6 +574,20 @@ class Topology:
         self.vdw = _f32(vdw)
 
 
+def rotation_from_axis_angle(axis, angle):
+    """nalgebra Rotation3::from_axis_angle (Rodrigues), f32; `axis` is normalised like Unit::new_normalize."""
+    f = np.float32
+    u = np.asarray(axis, f)
+    u = (u / f(np.sqrt(f(f(u[0] * u[0] + u[1] * u[1]) + u[2] * u[2])))).astype(f)
+    ux, uy, uz = u
+    s, c = f(np.sin(f(angle))), f(np.cos(f(angle)))
+    k = f(1) - c
+    sqx, sqy, sqz = ux * ux, uy * uy, uz * uz
+    return np.array([[sqx + (f(1) - sqx) * c, ux * uy * k - uz * s, ux * uz * k + uy * s],
+                     [ux * uy * k + uz * s, sqy + (f(1) - sqy) * c, uy * uz * k - ux * s],
+                     [ux * uz * k - uy * s, uy * uz * k + ux * s, sqz + (f(1) - sqz) * c]], dtype=f)
+
+
 class Sel:
     """A bound selection: sorted, non-empty index set over (Topology, State) (sel.rs:10-31)."""
 
@@ -628,6 +642,29 @@ class Sel:
 
     def min_max(self):
         return self.engine.min_max(self.state.coords, self.index)
+
+    # measure.rs:100-109, 246-257, 646-649: T(cm) * inverse(axes) * T(-cm), returned as (R, t) of p -> R p + t
+    def _principal(self, cm, axes):
+        f = np.float32
+        R = np.linalg.inv(np.asarray(axes, np.float64)).astype(f)          # axes is orthonormal: inverse = transpose to f32 roundoff
+        cm = np.asarray(cm, f)
+        return R, (cm + (R @ (-cm)).astype(f)).astype(f)
+
+    def principal_transform(self):
+        _, axes = self.inertia()
+        return self._principal(self.center_of_mass(), axes)
+
+    def principal_transform_pbc(self):
+        _, axes = self.inertia_pbc()
+        return self._principal(self.com(PBC_FULL), axes)
+
+    # modify.rs:16-30
+    def translate(self, shift):
+        self.engine.apply_transform(self.state.coords, np.eye(3, dtype=np.float32), np.asarray(shift, np.float32), self.index)
+
+    def rotate(self, axis, angle):
+        """Rotation3::from_axis_angle about a unit axis through the origin (modify.rs:25-30)."""
+        self.engine.apply_transform(self.state.coords, rotation_from_axis_angle(axis, angle), np.zeros(3, np.float32), self.index)
 
     def apply_transform(self, tr):
         R, t = tr

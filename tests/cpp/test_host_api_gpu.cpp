@@ -163,6 +163,26 @@ static void measure_tests() {
     EXPECT(std::memcmp(moved.data(), cur.coords_ptr(), 12 * n) == 0);           // bit-identical coordinates
     EXPECT(rmsd(cur, ref) < 0.05f);
 
+    // translate / rotate / principal_transform (modify.rs:16-30, measure.rs:100-109)
+    {
+        const Pos c0 = cur.center_of_mass();
+        cur.translate({0.5f, -1.0f, 0.25f});
+        const Pos c1 = cur.center_of_mass();
+        EXPECT(std::fabs(c1.x - c0.x - 0.5f) < 1e-4 && std::fabs(c1.y - c0.y + 1.0f) < 1e-4 && std::fabs(c1.z - c0.z - 0.25f) < 1e-4);
+        const Float g0 = cur.gyration();
+        cur.rotate({0.0f, 0.0f, 1.0f}, 1.5707963f);             // (x, y) -> (-y, x)
+        const Pos c2 = cur.center_of_mass();
+        EXPECT(std::fabs(c2.x + c1.y) < 2e-4 && std::fabs(c2.y - c1.x) < 2e-4 && std::fabs(c2.z - c1.z) < 1e-4);
+        EXPECT(std::fabs(cur.gyration() - g0) < 1e-4);
+        const IsometryMatrix3 pt = cur.principal_transform();
+        cur.apply_transform(pt);
+        const auto in = cur.inertia();                          // axes of the aligned cloud = identity up to sign
+        EXPECT(in.first.x <= in.first.y && in.first.y <= in.first.z);
+        EXPECT(std::fabs(std::fabs(in.second(0, 0)) - 1.0f) < 1e-3 && std::fabs(std::fabs(in.second(1, 1)) - 1.0f) < 1e-3);
+        const Pos c3 = cur.center_of_mass();
+        EXPECT(std::fabs(c3.x - c2.x) < 2e-4 && std::fabs(c3.y - c2.y) < 2e-4 && std::fabs(c3.z - c2.z) < 2e-4);
+    }
+
     // error mapping (measure.rs:732-762)
     bool threw = false;
     std::vector<usize> shorter(idx.begin(), idx.end() - 1);

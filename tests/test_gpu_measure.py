@@ -198,3 +198,44 @@ def test_lipid_tail_order_errors(eng):
     with pytest.raises(MolarHipError) as e:
         eng.lipid_tail_order(xyz, [tails[0]], 1, [n1[0]], [bonds[0][:-1]])
     assert e.value.code == 9                                       # BondOrderCount (:289-291)
+
+
+def test_principal_transform_translate_rotate(eng, orc64):
+    """measure.rs:100-109,646-649 and modify.rs:16-30 on the host mirror: after principal_transform the inertia
+    tensor is diagonal with ascending moments and the centre of mass has not moved; translate/rotate equal the
+    float64 formulas."""
+    from molar_amd import api, synth
+    n = 5000
+    box = synth.box_ortho(n)
+    xyz = (synth.frame(n, box, 3) * np.array([1.0, 0.6, 0.3], np.float32)).astype(np.float32)
+    # skew the cloud so the principal axes are not the lab axes
+    Rz = api.rotation_from_axis_angle([0.3, -0.5, 0.8], 0.7)
+    xyz = (xyz @ Rz.T).astype(np.float32)
+    top = api.Topology(synth.masses(n))
+    st = api.State(xyz.copy(), api.PeriodicBox.from_matrix(box))
+    sel = api.Sel(top, st, np.arange(0, n, 2), engine=eng)
+    cm0 = sel.center_of_mass()
+    R, t = sel.principal_transform()
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-5) and np.isclose(np.linalg.det(R), 1.0, atol=1e-5)
+    sel.apply_transform((R, t))
+    assert np.allclose(sel.center_of_mass(), cm0, atol=2e-4)
+    mom, axes = sel.inertia()
+    ii = sel.index.astype(np.int64)
+    d = st.coords[ii].astype(np.float64) - np.asarray(sel.center_of_mass(), np.float64)
+    mm = top.masses[ii].astype(np.float64)
+    tens = np.einsum("k,kij->ij", mm, (d * d).sum(1)[:, None, None] * np.eye(3) - d[:, :, None] * d[:, None, :])
+    off = tens - np.diag(np.diag(tens))
+    assert np.abs(off).max() < 2e-4 * np.abs(np.diag(tens)).max()
+    assert np.all(np.diff(np.diag(tens)) >= 0)          # ascending moments along x, y, z
+    # translate / rotate
+    before = st.coords[sel.index.astype(np.int64)].astype(np.float64)
+    untouched = st.coords[1::2].copy()
+    sel.translate([0.5, -1.25, 2.0])
+    assert np.allclose(st.coords[sel.index.astype(np.int64)], before + [0.5, -1.25, 2.0], atol=1e-5)
+    before = st.coords[sel.index.astype(np.int64)].astype(np.float64)
+    ax = np.array([1.0, 2.0, -0.5]); ax /= np.linalg.norm(ax)
+    sel.rotate(ax, 0.9)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    Rr = np.eye(3) + np.sin(0.9) * K + (1 - np.cos(0.9)) * (K @ K)
+    assert np.allclose(st.coords[sel.index.astype(np.int64)], before @ Rr.T, atol=2e-5)
+    assert np.array_equal(st.coords[1::2], untouched)
