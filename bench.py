@@ -210,6 +210,7 @@ def main():
                 traffic = json.load(open(tp)).get("pair_fill_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        copy_peak = eng.copy_bandwidth(1 << 30, 10)                # float4 copy kernel, same run
         line = {
             "metric": "frames/sec + Matom-pairs/sec, 1M-atom PBC neighbor search + RMSD fit",
             "value": frames_total / t,
@@ -237,6 +238,7 @@ def main():
                 "kernel": "pair_kernel<SINGLE,FILL>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fill_avg_ms,
+                "copy_peak_measured": copy_peak, "frac_of_copy_peak": achieved / copy_peak if copy_peak > 0 else None,
             },
         }
         if not args.no_cpu_baseline and world == 1:

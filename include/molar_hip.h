@@ -50,6 +50,7 @@ enum {
     MOLAR_HIP_ERR_INVALID_ARGUMENT = 50,
     MOLAR_HIP_ERR_TOO_LARGE = 51,
     MOLAR_HIP_ERR_NO_SEARCH = 52,
+    MOLAR_HIP_ERR_IO = 53,        /* trajectory file: open/seek failure, truncated or corrupt frame */
     MOLAR_HIP_ERR_HIP = 100       /* HIP runtime failure, text in molar_hip_last_error() */
 };
 
@@ -81,6 +82,11 @@ int molar_hip_synchronize(molar_hip_ctx *ctx);
 int molar_hip_profile_enable(molar_hip_ctx *ctx, int on);
 int molar_hip_profile_read(molar_hip_ctx *ctx, float ms[MOLAR_HIP_PROFILE_CLASSES],
                            uint64_t launches[MOLAR_HIP_PROFILE_CLASSES]);
+
+/* Device-copy ceiling of this GPU (SURVEY.md §8d "measured device-copy ceiling from a trivial float4 copy
+ * kernel in the same run"): copies `bytes` device-to-device `reps` times with a grid-stride float4 kernel on the
+ * context's stream and returns (read + written bytes) / time in GB/s.  Diagnostic, not part of the reference. */
+int molar_hip_copy_bandwidth(molar_hip_ctx *ctx, size_t bytes, int reps, float *gb_per_s);
 
 /* ------------------------------------------------------------------ PeriodicBox (periodic_box.rs:15-23) */
 
@@ -266,6 +272,29 @@ int molar_hip_membrane_smooth(molar_hip_ctx *ctx, const molar_hip_membrane_patch
 int molar_hip_lipid_tail_order(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx,
                                const uint64_t *tail_offsets, size_t ntails, int order_type, const float *normals,
                                const uint64_t *normal_offsets, const uint8_t *bond_orders, float *out);
+
+/* ------------------------------------------------------------------ XTC frames (molar/src/io/xtc_handler.rs)
+ *
+ * Feeds the path with trajectory frames: MolAR's XtcFileHandler over the un-vendored `molly` crate
+ * (read_state :64-112 -> State{coords, time, pbox}; seek_frame :200-218; seek_time :220-229 = first frame with
+ * time >= t, :282-297).  GROMACS XTC, magic 1995 and 2023.  The file is indexed once at open (headers only);
+ * molar_hip_xtc_read decodes `count` consecutive frames on `nthreads` host threads (0 = all cores; a frame's bit
+ * stream is serial, frames are independent) into xyz[count][natoms][3] (nm), which may be host memory or device
+ * memory (then through pinned staging and async copies on the context's stream; ctx may be NULL for host output).
+ * box9 of a frame is column-major with columns a,b,c (Matrix3f::from_iterator(boxvec), :100).  A truncated last
+ * frame ends the index (the reference reports Eof there, :325-332).  Returns ERR_IO / ERR_SIZES (frames of
+ * different atom counts in one read). */
+typedef struct molar_hip_xtc molar_hip_xtc;
+molar_hip_xtc *molar_hip_xtc_open(const char *path);
+molar_hip_xtc *molar_hip_xtc_open_memory(const void *data, size_t bytes);   /* borrowed, must outlive the handle */
+void molar_hip_xtc_close(molar_hip_xtc *x);
+size_t molar_hip_xtc_nframes(const molar_hip_xtc *x);
+size_t molar_hip_xtc_natoms(const molar_hip_xtc *x);
+int molar_hip_xtc_frame_info(const molar_hip_xtc *x, size_t frame, int32_t *natoms, int32_t *step, float *time,
+                             float box9[9], float *precision);
+int molar_hip_xtc_seek_time(const molar_hip_xtc *x, float t, size_t *frame);
+int molar_hip_xtc_read(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t first, size_t count, float *xyz,
+                       int nthreads);
 
 /* ------------------------------------------------------------------ Modify (modify.rs) */
 

@@ -57,6 +57,7 @@ SYMBOLS = {
     "molar_hip_box_from_matrix": (_I, [_P, _P]),
     "molar_hip_box_from_vectors_angles": (_I, [_F, _F, _F, _F, _F, _F, _P]),
     "molar_hip_box_shortest_vector": (None, [_P, _P, _U8, _P]),
+    "molar_hip_copy_bandwidth": (_I, [_P, _SZ, _I, _P]),
     "molar_hip_box_lab_extents": (None, [_P, _P]),
     "molar_hip_box_extents": (None, [_P, _P]),
     "molar_hip_box_to_box_coords": (None, [_P, _P, _P]),
@@ -84,6 +85,14 @@ SYMBOLS = {
     "molar_hip_unwrap_simple_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _U8]),
     "molar_hip_membrane_initial_normals": (_I, [_SZ, _P, _P, _P, _P, _P, _P]),
     "molar_hip_membrane_smooth": (_I, [_P, _P, _P, _P]),
+    "molar_hip_xtc_open": (_P, [C.c_char_p]),
+    "molar_hip_xtc_open_memory": (_P, [_P, _SZ]),
+    "molar_hip_xtc_close": (None, [_P]),
+    "molar_hip_xtc_nframes": (_SZ, [_P]),
+    "molar_hip_xtc_natoms": (_SZ, [_P]),
+    "molar_hip_xtc_frame_info": (_I, [_P, _SZ, _P, _P, _P, _P, _P]),
+    "molar_hip_xtc_seek_time": (_I, [_P, C.c_float, _P]),
+    "molar_hip_xtc_read": (_I, [_P, _P, _SZ, _SZ, _P, _I]),
     "molar_hip_lipid_tail_order": (_I, [_P, _P, _SZ, _P, _P, _SZ, _I, _P, _P, _P, _P]),
     "molar_hip_apply_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
     "molar_hip_unwrap_simple": (_I, [_P, _P, _SZ, _P, _SZ, _P, _U8]),

@@ -430,6 +430,12 @@ class Engine:
                                                   bond_orders.ctypes.data, out.ctypes.data))
         return out[:nout]
 
+    def copy_bandwidth(self, nbytes=1 << 30, reps=10) -> float:
+        """Measured device-to-device copy rate in GB/s (read + write) of a float4 grid-stride kernel."""
+        out = C.c_float(0)
+        check(self.lib.molar_hip_copy_bandwidth(self.ctx, int(nbytes), int(reps), C.byref(out)))
+        return float(out.value)
+
     def membrane_smooth(self, box, state, patch_offsets, patch_ids):
         """One iteration of Membrane::smooth (molar_membrane/src/lib.rs:661-812) on the GPU.  `state` is a dict of
         per-lipid arrays updated IN PLACE (see new_membrane_state); a lipid that turns invalid keeps its old

@@ -1,5 +1,7 @@
 // api.hip — context lifecycle and the host-side PeriodicBox constructors of libmolar_hip.so.
 #include "boxmath.hpp"
+#include <algorithm>
+
 #include "common.hpp"
 
 using namespace mh;
@@ -122,6 +124,41 @@ int molar_hip_profile_read(molar_hip_ctx *c, float ms[MOLAR_HIP_PROFILE_CLASSES]
         c->event_pool.push_back(s.b);
     }
     c->spans.clear();
+    return MOLAR_HIP_OK;
+}
+
+__global__ __launch_bounds__(256) void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+}
+
+int molar_hip_copy_bandwidth(molar_hip_ctx *c, size_t bytes, int reps, float *gbs) {
+    if (!c || !gbs || reps < 1 || bytes < 16) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "copy_bandwidth: bad argument");
+    MH_HIP(hipSetDevice(c->device));
+    const size_t n = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    MH_HIP(hipMalloc((void **)&a, n * 16));
+    if (hipMalloc((void **)&b, n * 16) != hipSuccess) {
+        (void)hipFree(a);
+        return fail(MOLAR_HIP_ERR_HIP, "copy_bandwidth: out of device memory");
+    }
+    (void)hipMemsetAsync(a, 0, n * 16, c->stream);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->num_cus * 32);
+    hipLaunchKernelGGL(k_copy_f4, dim3(grid), dim3(256), 0, c->stream, a, b, n);   // warm-up
+    (void)hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy_f4, dim3(grid), dim3(256), 0, c->stream, a, b, n);
+    (void)hipEventRecord(e1, c->stream);
+    hipError_t err = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    if (err != hipSuccess || !(ms > 0.f)) return fail(MOLAR_HIP_ERR_HIP, "copy_bandwidth: %s", hipGetErrorString(err));
+    *gbs = (float)(2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9);
     return MOLAR_HIP_OK;
 }
 

@@ -408,6 +408,47 @@ class Oracle:
         out.update(head=head, normals=normals, valid=valid)
         return out
 
+    # ------------------------------------------------------------------ XTC codec (xtc_oracle.c)
+    def xtc_index(self, data: bytes):
+        buf = np.frombuffer(data, np.uint8)
+        self.lib.orc_xtc_index.restype = C.c_size_t
+        n = self.lib.orc_xtc_index(self._p(buf), C.c_size_t(len(buf)), None, C.c_size_t(0))
+        off = np.zeros(max(n, 1), np.uint64)
+        self.lib.orc_xtc_index(self._p(buf), C.c_size_t(len(buf)), self._p(off), C.c_size_t(n))
+        return off[:n]
+
+    def xtc_header(self, data: bytes, offset=0):
+        buf = np.frombuffer(data, np.uint8)[int(offset):]
+        self.lib.orc_xtc_frame_header.restype = C.c_size_t
+        nat, step, t, prec = C.c_int32(0), C.c_int32(0), C.c_float(0), C.c_float(0)
+        box = np.zeros(9, np.float32)
+        ln = self.lib.orc_xtc_frame_header(self._p(buf), C.c_size_t(len(buf)), C.byref(nat), C.byref(step), C.byref(t),
+                                           self._p(box), C.byref(prec))
+        if not ln:
+            raise ValueError("not an XTC frame header")
+        return dict(natoms=nat.value, step=step.value, time=t.value, box9=box, precision=prec.value, length=int(ln))
+
+    def xtc_decode(self, data: bytes, offset=0):
+        h = self.xtc_header(data, offset)
+        buf = np.frombuffer(data, np.uint8)[int(offset):]
+        xyz = np.zeros((h["natoms"], 3), np.float32)
+        rc = self.lib.orc_xtc_decode_frame(self._p(buf), C.c_size_t(len(buf)), self._p(xyz))
+        if rc:
+            raise ValueError(f"xtc decode failed: {rc}")
+        return xyz, h
+
+    def xtc_encode(self, xyz, box9, step=0, time=0.0, precision=1000.0, magic=1995) -> bytes:
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        box9 = np.ascontiguousarray(box9, np.float32).reshape(9)
+        cap = 128 + 16 * len(xyz)
+        out = np.zeros(cap, np.uint8)
+        self.lib.orc_xtc_encode_frame.restype = C.c_size_t
+        n = self.lib.orc_xtc_encode_frame(self._p(xyz), C.c_int32(len(xyz)), self._p(box9), C.c_int32(step), C.c_float(time),
+                                          C.c_float(precision), C.c_uint32(magic), self._p(out), C.c_size_t(cap))
+        if not n:
+            raise ValueError("xtc encode failed")
+        return out[:n].tobytes()
+
     def histogram_add(self, minv, maxv, nbins, vals):
         vals = self.arr(vals)
         bins = np.zeros(nbins, self.real)
