@@ -594,6 +594,58 @@ struct FrameSource {
                                                        std::optional<Float> skip_to_time) = 0;
 };
 
+// XTC trajectory through the engine's decoder (molar/src/io/xtc_handler.rs:64-112, 200-229): read_state,
+// seek_frame, seek_time; `open_as_source` adapts it to FrameSource::open.
+class XtcReader {
+    molar_hip_xtc *h_;
+    size_t cur_fr_ = 0;
+
+   public:
+    explicit XtcReader(const std::string &path) : h_(molar_hip_xtc_open(path.c_str())) {
+        if (!h_) throw MolarError(MOLAR_HIP_ERR_IO, molar_hip_last_error());
+    }
+    XtcReader(const void *data, size_t bytes) : h_(molar_hip_xtc_open_memory(data, bytes)) {
+        if (!h_) throw MolarError(MOLAR_HIP_ERR_IO, molar_hip_last_error());
+    }
+    XtcReader(const XtcReader &) = delete;
+    XtcReader &operator=(const XtcReader &) = delete;
+    ~XtcReader() { molar_hip_xtc_close(h_); }
+    size_t nframes() const { return molar_hip_xtc_nframes(h_); }
+    size_t natoms() const { return molar_hip_xtc_natoms(h_); }
+    size_t current_frame() const { return cur_fr_; }
+    void seek_frame(size_t fr) {
+        if (fr > nframes()) throw MolarError(MOLAR_HIP_ERR_IO, "seek to frame failed");
+        cur_fr_ = fr;
+    }
+    void seek_time(Float t) { check(molar_hip_xtc_seek_time(h_, t, &cur_fr_)); }
+    std::optional<State> read_state() {      // nullopt = FileFormatError::Eof
+        if (cur_fr_ >= nframes()) return std::nullopt;
+        int32_t nat = 0;
+        float time = 0, box9[9];
+        check(molar_hip_xtc_frame_info(h_, cur_fr_, &nat, nullptr, &time, box9, nullptr));
+        State st;
+        st.coords.resize((size_t)nat);
+        check(molar_hip_xtc_read(nullptr, h_, cur_fr_, 1, &st.coords[0].x, 1));
+        Matrix3f m;
+        for (int k = 0; k < 9; ++k) m.m[k] = box9[k];
+        st.pbox = PeriodicBox::from_matrix(m);
+        st.time = time;
+        ++cur_fr_;
+        return st;
+    }
+    // `count` consecutive frames decoded on `nthreads` host threads into xyz (host or device memory)
+    void read_frames(size_t first, size_t count, float *xyz, Engine *eng = nullptr, int nthreads = 0) {
+        check(molar_hip_xtc_read(eng ? eng->ctx() : nullptr, h_, first, count, xyz, nthreads));
+    }
+    static std::function<std::optional<State>()> open_as_source(const std::string &file, std::optional<size_t> skip_to_frame,
+                                                                std::optional<Float> skip_to_time) {
+        auto r = std::make_shared<XtcReader>(file);
+        if (skip_to_frame) r->seek_frame(*skip_to_frame);
+        if (skip_to_time) r->seek_time(*skip_to_time);
+        return [r]() { return r->read_state(); };
+    }
+};
+
 template <class A>
 struct AnalysisContext {                     // analysis_task.rs:309-313
     System sys;

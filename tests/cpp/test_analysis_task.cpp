@@ -154,10 +154,43 @@ static void pbcdims_tests() {
     EXPECT(threw);
 }
 
-int main() {
+// XtcReader on the reference's benzene.xtc (copy under tests/golden): 5 frames of 12 atoms, times 4032..4040
+// (tests/test_netcdf.rs:37-80); handler semantics of xtc_handler.rs:200-229.
+static void xtc_tests(const char *path) {
+    XtcReader r(path);
+    EXPECT(r.nframes() == 5 && r.natoms() == 12);
+    int n = 0;
+    Float last = 0;
+    while (auto st = r.read_state()) {
+        EXPECT(st->coords.size() == 12 && st->pbox.has_value());
+        EXPECT(st->coords[0].x > 1.6f && st->coords[0].x < 1.7f);      // 1.659 nm in frame 0
+        last = st->time;
+        ++n;
+    }
+    EXPECT(n == 5 && last == 4040.0f);
+    EXPECT(!r.read_state().has_value());                               // Eof stays Eof
+    r.seek_frame(3);
+    EXPECT(r.read_state()->time == 4038.0f);
+    r.seek_time(4035.0f);                                              // first frame with time >= t
+    EXPECT(r.read_state()->time == 4036.0f);
+    bool threw = false;
+    try { r.seek_time(1.0e6f); } catch (const MolarError &e) { threw = e.code == MOLAR_HIP_ERR_IO; }
+    EXPECT(threw);
+    threw = false;
+    try { XtcReader bad("/nonexistent.xtc"); } catch (const MolarError &e) { threw = e.code == MOLAR_HIP_ERR_IO; }
+    EXPECT(threw);
+    auto next = XtcReader::open_as_source(path, std::optional<size_t>(4), std::nullopt);
+    EXPECT(next()->time == 4040.0f && !next().has_value());
+    std::vector<float> all(5 * 12 * 3);
+    r.read_frames(0, 5, all.data(), nullptr, 2);
+    EXPECT(std::fabs(all[0] - 1.659f) < 1e-6f);
+}
+
+int main(int argc, char **argv) {
     suffix_tests();
     window_tests();
     pbcdims_tests();
+    if (argc > 1) xtc_tests(argv[1]);
     if (failures) { std::printf("%d failure(s)\n", failures); return 1; }
     std::printf("all host-mirror CPU tests passed\n");
     return 0;

@@ -22,7 +22,7 @@ def _compile(src, exe, extra=()):
 
 def test_analysis_task_and_suffix_cpu():
     exe = _compile("test_analysis_task.cpp", "test_analysis_task")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "benzene.xtc")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all host-mirror CPU tests passed" in r.stdout
 
