@@ -141,6 +141,10 @@ struct molar_hip_ctx {
     mh::DevBuf out_ids;
     mh::DevBuf wide_i, wide_j; // usize widening
     mh::DevBuf hist;           // u64 bins
+    mh::DevBuf task_mu;        // u32 per task (+1): 64-word hit-history units of the task's slots
+    mh::DevBuf task_moff;      // u64 per task (+1): exclusive scan of task_mu
+    mh::DevBuf maskbuf;        // hit bits recorded by the count pass, replayed by the fill pass
+    uint64_t mask_units = 0;
 
     // ---- profiling (HIP events on `stream`)
     bool profiling = false;

@@ -38,6 +38,8 @@ struct SearchParams {
     const float *vdwb;
     const float4 *aabb_b;    // per-cell bounding boxes of set 2 (== set 1 for SINGLE)
     const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
+    uint32_t *maskbuf;       // fast-path slots: hit bits found by the count pass, replayed by the fill pass
+    const unsigned long long *task_moff;   // per task: first 64-word unit of its slots in maskbuf (a slot owns 2*nch units)
     uint32_t dx, dy, dz;
     uint32_t pbc;            // PbcDims of the plan (0 for the non-periodic drivers)
     uint32_t use_box;
@@ -226,20 +228,29 @@ struct Fifo {
     uint32_t *ids;              // WITHIN output
     uint32_t *hist;             // consumer-fused mode: workgroup histogram in LDS (NULL otherwise)
     float hmin, hmax, hn;
-    bool recompute;             // entries carry (row<<26 | sorted position) instead of d2 (wrapped fast path)
+    uint32_t recompute;         // 0: entries carry ids + d2;  1 / 2: entries are (row<<26 | sorted position) only and ids,
+                                // d2 are rebuilt at flush time with the exact wrapped (1) or the plain (2) formula
     const float4 *la;           // the slot's first-cell atoms in LDS
+    float4 *fq_store;           // LDS backing of fq (fill kernels)
+    float4 *fq;                 // replay mode: FIFO of the hits' second atoms {x,y,z,id}; fd then holds the row
     uint32_t wrap;
 };
 
 __device__ __forceinline__ float wrapped_d2_exact(const SearchParams &P, uint32_t wrap, float vx, float vy, float vz);
 
-// d2 of a queued hit: stored directly, or recomputed with the exact wrapped formula from the two atoms
-__device__ __forceinline__ float fifo_d2(const SearchParams &P, const Fifo &F, uint32_t s) {
+// One queued hit, resolved at flush time: ids and squared distance
+struct Hit {
+    uint32_t i, j;
+    float d2;
+};
+__device__ __forceinline__ Hit fifo_hit(const SearchParams &P, const Fifo &F, uint32_t s) {
     const uint32_t w = F.fd[s];
-    if (!F.recompute) return __uint_as_float(w);
-    const float4 a = F.la[w >> 26];
-    const float4 b = P.sb[w & 0x3FFFFFFu];
-    return wrapped_d2_exact(P, F.wrap, b.x - a.x, b.y - a.y, b.z - a.z);
+    if (F.recompute == 0u) return Hit{F.fi[s], F.fj[s], __uint_as_float(w)};
+    const float4 a = F.la[F.fq ? w : (w >> 26)];
+    const float4 b = F.fq ? F.fq[s] : P.sb[w & 0x3FFFFFFu];
+    const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;               // p2 - p1
+    const float d2 = F.recompute == 1u ? wrapped_d2_exact(P, F.wrap, dx, dy, dz) : (dx * dx + dy * dy) + dz * dz;
+    return Hit{__float_as_uint(a.w), __float_as_uint(b.w), d2};
 }
 
 template <int KIND>
@@ -252,14 +263,15 @@ __device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint3
         } else if (F.hist) {
             // Histogram1D::add_one (molar_membrane/src/stats.rs:29-35) on d = sqrt(d2):
             //   b = (n as Float * (val - min) / (max - min)).floor() as isize;  if 0 <= b < n: bins[b] += 1
-            const float d = __builtin_sqrtf(fifo_d2(P, F, s));
+            const float d = __builtin_sqrtf(fifo_hit(P, F, s).d2);
             float fb = __builtin_floorf(F.hn * (d - F.hmin) / (F.hmax - F.hmin));
             if (fb != fb) fb = 0.0f;                                    // NaN as isize == 0
             if (fb >= 0.0f && fb < F.hn) atomicAdd(&F.hist[(uint32_t)fb], 1u);
         } else {
-            if (F.pairs) F.pairs[pos] = make_uint2(F.fi[s], F.fj[s]);
+            const Hit h = fifo_hit(P, F, s);
+            if (F.pairs) F.pairs[pos] = make_uint2(h.i, h.j);
             // d2.sqrt() (:448): llvm.sqrt.f32 without fpmath metadata = IEEE correctly rounded
-            if (F.dist) F.dist[pos] = __builtin_sqrtf(fifo_d2(P, F, s));
+            if (F.dist) F.dist[pos] = __builtin_sqrtf(h.d2);
         }
     }
     F.head += count;
@@ -499,9 +511,9 @@ __device__ __forceinline__ float aabb_d2(float ax, float ay, float az, float lx,
 //    band (a fraction of a percent of the chunks) are evaluated with the exact formula.  Hits carry
 //    (row, atom position) through the FIFO and their exact d2 is recomputed densely at flush time.
 //    The band is >10x the worst-case disagreement between the two evaluations (make_params()).
-template <int KIND, bool FILL, bool WRAPPED, int NCH, bool TRI>
+template <int KIND, bool FILL, bool WRAPPED, int NCH, bool TRI, bool MASKED>
 __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
-                                             uint32_t lane) {
+                                             uint32_t lane, uint32_t *mwords) {
     static_assert(!(WRAPPED && TRI), "a triangular (same-cell) entry never wraps on the fast path");
     // approximate classification allowed?  (needs n_d = round(f_d) = +-1 for every wrapped pair: >= 4 cells
     // per periodic dimension; the corner entries of triclinic boxes run the candidate loop: always exact)
@@ -516,22 +528,25 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
             Sz += sgn * P.box.m[3 * d + 2];
         }
     }
+    constexpr bool REPLAY = FILL && MASKED;   // the fill pass replays the hit bits of the count pass: no distances
     float bx[NCH], by[NCH], bz[NCH];
     uint32_t bid[NCH];
+    if (!REPLAY) {
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const uint32_t jj = (uint32_t)k * 64u + lane;
-        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
-        if (jj < T.n2) {
-            q = P.sb[T.b0 + jj];
-            if (WRAPPED) { q.x += Sx; q.y += Sy; q.z += Sz; }       // S == 0 when the slot is evaluated exactly
+        for (int k = 0; k < NCH; ++k) {
+            const uint32_t jj = (uint32_t)k * 64u + lane;
+            float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+            if (jj < T.n2) {
+                q = P.sb[T.b0 + jj];
+                if (WRAPPED) { q.x += Sx; q.y += Sy; q.z += Sz; }       // S == 0 when the slot is evaluated exactly
+            }
+            bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bid[k] = __float_as_uint(q.w);
         }
-        bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bid[k] = __float_as_uint(q.w);
     }
     const float cutoff2 = P.cutoff2;
     const float band_lo = P.band_lo, band_hi = P.band_hi;
     const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
-    unsigned long long live;   // rows of this slot that can have a hit at all
+    unsigned long long live;   // rows of this slot that can have a hit at all (same value in both passes)
     {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane < rows) a = P.sa[T.a0 + i0 + lane];
@@ -554,14 +569,88 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
         live = __builtin_amdgcn_ballot_w64(lane < rows && need);
     }
     __builtin_amdgcn_wave_barrier();
+    uint32_t total = 0;
+
+    if (REPLAY) {
+        // ---- fill pass over recorded hit bits.  Word (g, k) of lane l holds, MSB first, the hit bits of
+        // (live row, atom k*64+l) for the g-th group of 32 live rows.  A queued hit is (row, sorted position);
+        // ids and the exact d2 are rebuilt densely at flush time (fifo_hit).
+        F.recompute = WRAPPED ? 1u : 2u;
+        F.la = la;
+        F.wrap = T.wrap;
+        F.fq = F.fq_store;
+        float4 q[NCH];                         // second-cell atoms of this lane, unshifted
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const uint32_t jj = (uint32_t)k * 64u + lane;
+            q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jj < T.n2) q[k] = P.sb[T.b0 + jj];
+        }
+        uint32_t w[NCH];
+        uint32_t nrow = 0;
+        while (live) {
+            if ((nrow & 31u) == 0u) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) w[k] = mwords[((nrow >> 5) * NCH + k) * 64u + lane];
+            }
+            ++nrow;
+            const uint32_t r = (uint32_t)__builtin_ctzll(live);
+            live &= live - 1ull;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const bool hit = (int32_t)w[k] < 0;
+                w[k] += w[k];
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (mask) {
+                    const uint32_t cnt = (uint32_t)__popcll(mask);
+                    if (hit) {
+                        const uint32_t s = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, F.tail)) &
+                                           (FIFO_CAP - 1);
+                        F.fq[s] = q[k];
+                        F.fd[s] = r;
+                    }
+                    F.tail += cnt;
+                    total += cnt;
+                    if (F.tail - F.head >= 64u) {
+                        __builtin_amdgcn_wave_barrier();
+                        fifo_flush<KIND>(P, F, 64u, lane);
+                    }
+                }
+            }
+        }
+        if (F.tail != F.head) {
+            __builtin_amdgcn_wave_barrier();
+            fifo_flush<KIND>(P, F, F.tail - F.head, lane);
+        }
+        F.recompute = 0u;
+        F.fq = nullptr;
+        return total;
+    }
+
     if (FILL) {
-        F.recompute = WRAPPED && approx;
+        F.recompute = (WRAPPED && approx) ? 1u : 0u;
         F.la = la;
         F.wrap = T.wrap;
     }
-    uint32_t acc = 0;       // per-lane hit counter (count pass); wrapped+approx: hits that are certain
-    uint32_t acc_hi = 0;    // wrapped+approx: candidates at or below the upper edge of the band
-    uint32_t total = 0;
+    uint32_t acc = 0;       // count pass.  !MASKED: per-lane hit counter (wrapped+approx: hits that are certain)
+    uint32_t acc_hi = 0;    //              wrapped+approx: candidates at or below the upper edge of the band
+    uint32_t hw[NCH];       // MASKED: per chunk, the hit bits of the rows done so far
+    uint32_t su = 0, mu = 0;   // MASKED wrapped+approx: per-row summaries, one bit per chunk (certain / at or below the band)
+    uint32_t nrow = 0;
+    if (MASKED) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) hw[k] = 0u;
+    }
+    // store the history words of a finished group (n rows, left-aligned) and count its hits
+    auto store_group = [&](uint32_t g, uint32_t n) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            acc += (uint32_t)__popc(hw[k]);
+            mwords[(g * NCH + k) * 64u + lane] = hw[k] << (32u - n);
+            hw[k] = 0u;
+        }
+    };
     // exact d2 of (row atom p, atom jj of the second cell), second cell re-read unshifted
     auto exact_d2 = [&](const float4 &p, uint32_t jj) -> float {
         float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
@@ -576,14 +665,32 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
         const uint32_t i = i0 + r;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            if (TRI && (uint32_t)k * 64u + 63u <= i) continue;                   // whole chunk has j <= i
+            if (TRI && (uint32_t)k * 64u + 63u <= i) {                           // whole chunk has j <= i
+                if (MASKED && !FILL) hw[k] += hw[k];                             // ... its bit of this row is 0
+                continue;
+            }
             const uint32_t jj = (uint32_t)k * 64u + lane;
             const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1 (image of p2 if WRAPPED)
             float d2 = (dx * dx + dy * dy) + dz * dz;                            // |p2-p1|^2 (:446, :460)
             if (WRAPPED && !approx) d2 = wrapped_d2_exact(P, T.wrap, dx, dy, dz); // S == 0: dx is the raw difference (:485-486)
             if (TRI && (uint32_t)k * 64u <= i) d2 = (jj > i) ? d2 : INFINITY;    // diagonal chunk: j in i+1..n (:443)
             if (!FILL) {
-                if (WRAPPED && approx) {
+                if (MASKED) {
+                    // h = 2*h + (d2 <= cutoff2): the compare's carry shifts into the per-lane history, VALU only
+                    if (WRAPPED && approx) {
+                        // sure = d2 < band_lo goes into the chunk's history AND into the row summary `su`;
+                        // maybe = d2 <= band_hi into the row summary `mu`: the row has an undecided candidate
+                        // iff the two summaries differ in their low NCH bits
+                        unsigned long long scr;
+                        asm volatile("v_cmp_gt_f32 vcc, %4, %3\n\t"
+                                     "v_addc_co_u32 %0, %2, %0, %0, vcc\n\t"
+                                     "v_addc_co_u32 %1, %2, %1, %1, vcc"
+                                     : "+v"(hw[k]), "+v"(su), "=&s"(scr) : "v"(d2), "s"(band_lo) : "vcc");
+                        asm volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mu) : "v"(d2), "s"(band_hi) : "vcc");
+                    } else {
+                        asm volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hw[k]) : "v"(d2), "s"(cutoff2) : "vcc");
+                    }
+                } else if (WRAPPED && approx) {
                     asm volatile("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(acc) : "v"(d2), "s"(band_lo) : "vcc");
                     asm volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(acc_hi) : "v"(d2), "s"(band_hi) : "vcc");
                 } else {
@@ -624,60 +731,73 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
         }
         if (!FILL && WRAPPED && approx) {
             // some candidate of this row fell inside the band: settle those (and only those) exactly
-            if (__builtin_amdgcn_ballot_w64(acc != acc_hi)) {
+            bool any_amb;
+            if (MASKED) {
+                any_amb = __builtin_amdgcn_ballot_w64(((su ^ mu) & ((1u << NCH) - 1u)) != 0u) != 0ull;
+            } else {
+                any_amb = __builtin_amdgcn_ballot_w64(acc != acc_hi) != 0ull;
+            }
+            if (any_amb) {
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
                     const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;
                     const float d2 = (dx * dx + dy * dy) + dz * dz;
                     const bool amb = d2 <= band_hi && !(d2 < band_lo);
                     if (__builtin_amdgcn_ballot_w64(amb)) {
-                        if (amb && exact_d2(p, (uint32_t)k * 64u + lane) <= cutoff2) acc += 1u;
+                        if (amb && exact_d2(p, (uint32_t)k * 64u + lane) <= cutoff2) {
+                            if (MASKED) hw[k] |= 1u;
+                            else acc += 1u;
+                        }
                     }
                 }
                 acc_hi = acc;
             }
         }
+        if (!FILL && MASKED) {
+            if ((++nrow & 31u) == 0u) store_group((nrow >> 5) - 1u, 32u);
+        }
     }
     if (!FILL) {
+        if (MASKED && (nrow & 31u) != 0u) store_group(nrow >> 5, nrow & 31u);
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
         total = acc;
     } else if (F.tail != F.head) {
         __builtin_amdgcn_wave_barrier();
         fifo_flush<KIND>(P, F, F.tail - F.head, lane);
     }
-    if (FILL) F.recompute = false;
+    if (FILL) F.recompute = 0u;
     return total;
 }
 
 // chunk-count dispatch: for the single-set search the non-triangular tasks get a fully unrolled,
 // branch-free row body per chunk count; everything else checks the chunk count at run time
-template <int KIND, bool FILL, int WK>
+template <int KIND, bool FILL, int WK, bool MASKED>
 __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
-                                                 uint32_t lane) {
+                                                 uint32_t lane, uint32_t *mwords) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
     if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && !T.tri && nchunks <= (uint32_t)KREG) {
         constexpr bool WR = WK != WK_NONE;
         switch (nchunks) {
-            case 1: return run_fast<KIND, FILL, WR, 1, false>(P, T, i0, F, la, lane);
-            case 2: return run_fast<KIND, FILL, WR, 2, false>(P, T, i0, F, la, lane);
-            case 3: return run_fast<KIND, FILL, WR, 3, false>(P, T, i0, F, la, lane);
-            case 4: return run_fast<KIND, FILL, WR, 4, false>(P, T, i0, F, la, lane);
-            case 5: return run_fast<KIND, FILL, WR, 5, false>(P, T, i0, F, la, lane);
-            case 6: return run_fast<KIND, FILL, WR, 6, false>(P, T, i0, F, la, lane);
-            case 7: return run_fast<KIND, FILL, WR, 7, false>(P, T, i0, F, la, lane);
-            default: return run_fast<KIND, FILL, WR, 8, false>(P, T, i0, F, la, lane);
+            case 1: return run_fast<KIND, FILL, WR, 1, false, MASKED && WR>(P, T, i0, F, la, lane, mwords);
+            case 2: return run_fast<KIND, FILL, WR, 2, false, MASKED && WR>(P, T, i0, F, la, lane, mwords);
+            case 3: return run_fast<KIND, FILL, WR, 3, false, MASKED && WR>(P, T, i0, F, la, lane, mwords);
+            case 4: return run_fast<KIND, FILL, WR, 4, false, MASKED && WR>(P, T, i0, F, la, lane, mwords);
+            case 5: return run_fast<KIND, FILL, WR, 5, false, MASKED && WR>(P, T, i0, F, la, lane, mwords);
+            case 6: return run_fast<KIND, FILL, WR, 6, false, MASKED && WR>(P, T, i0, F, la, lane, mwords);
+            case 7: return run_fast<KIND, FILL, WR, 7, false, MASKED && WR>(P, T, i0, F, la, lane, mwords);
+            default: return run_fast<KIND, FILL, WR, 8, false, MASKED && WR>(P, T, i0, F, la, lane, mwords);
         }
     }
     if (KIND == MOLAR_HIP_SEARCH_SINGLE && WK == WK_NONE && T.tri && nchunks <= (uint32_t)KREG) {
         switch (nchunks) {
-            case 1: return run_fast<KIND, FILL, false, 1, true>(P, T, i0, F, la, lane);
-            case 2: return run_fast<KIND, FILL, false, 2, true>(P, T, i0, F, la, lane);
-            case 3: return run_fast<KIND, FILL, false, 3, true>(P, T, i0, F, la, lane);
-            case 4: return run_fast<KIND, FILL, false, 4, true>(P, T, i0, F, la, lane);
-            case 5: return run_fast<KIND, FILL, false, 5, true>(P, T, i0, F, la, lane);
-            case 6: return run_fast<KIND, FILL, false, 6, true>(P, T, i0, F, la, lane);
-            case 7: return run_fast<KIND, FILL, false, 7, true>(P, T, i0, F, la, lane);
-            default: return run_fast<KIND, FILL, false, 8, true>(P, T, i0, F, la, lane);
+            case 1: return run_fast<KIND, FILL, false, 1, true, false>(P, T, i0, F, la, lane, mwords);
+            case 2: return run_fast<KIND, FILL, false, 2, true, false>(P, T, i0, F, la, lane, mwords);
+            case 3: return run_fast<KIND, FILL, false, 3, true, false>(P, T, i0, F, la, lane, mwords);
+            case 4: return run_fast<KIND, FILL, false, 4, true, false>(P, T, i0, F, la, lane, mwords);
+            case 5: return run_fast<KIND, FILL, false, 5, true, false>(P, T, i0, F, la, lane, mwords);
+            case 6: return run_fast<KIND, FILL, false, 6, true, false>(P, T, i0, F, la, lane, mwords);
+            case 7: return run_fast<KIND, FILL, false, 7, true, false>(P, T, i0, F, la, lane, mwords);
+            default: return run_fast<KIND, FILL, false, 8, true, false>(P, T, i0, F, la, lane, mwords);
         }
     }
     if (nchunks > (uint32_t)KREG) {
@@ -695,11 +815,19 @@ __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Ta
 // reference's output order.
 template <int KIND>
 __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__restrict__ task_nb,
-                                                   TaskDesc *__restrict__ task_desc) {
+                                                   TaskDesc *__restrict__ task_desc, uint32_t *__restrict__ task_mu,
+                                                   uint32_t fast_kind) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= P.ntasks) return;
     const Task T = decode_task<KIND, false>(P, t);
-    task_nb[t] = T.valid ? (T.n1 + T.rps - 1u) / T.rps : 0u;
+    const uint32_t nb = T.valid ? (T.n1 + T.rps - 1u) / T.rps : 0u;
+    task_nb[t] = nb;
+    // hit-history units (64 words) of the task's slots: two 32-row groups x nch chunks per slot, for the WRAPPED
+    // tasks run_task_nch sends down the register-resident fast path (same condition as there).  Recording the hit
+    // bits in the count pass and replaying them in the fill pass pays where a candidate is expensive (the wrapped
+    // distance); for plain and same-cell entries re-evaluating d2 is cheaper than the replay (measured).
+    const uint32_t nch = (T.n2 + 63u) >> 6;
+    task_mu[t] = (fast_kind && P.use_box && T.wrap != 0u && nch <= (uint32_t)KREG) ? nb * 2u * nch : 0u;
     TaskDesc d;
     d.a0 = T.a0; d.n1 = T.n1; d.b0 = T.b0; d.n2 = T.n2; d.cb = T.cb;
     d.flags = T.wrap | (T.tri ? 0x100u : 0u) | (T.valid ? 0x200u : 0u) | (T.wrap_b << 12) | (T.rps << 16);
@@ -716,7 +844,7 @@ static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, co
 }
 
 template <int KIND, int MODE>
-__global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restrict__ Pp,
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : 7))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const uint32_t *__restrict__ task_first,
                                                      const uint32_t *__restrict__ slot_task,
                                                      uint32_t *__restrict__ slot_cnt,
@@ -725,6 +853,7 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
                                                      uint32_t *__restrict__ out_ids) {
     __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
     __shared__ float4 lds_a[WAVES_PER_BLOCK][64];
+    __shared__ float4 lds_q[MODE == MODE_FILL ? WAVES_PER_BLOCK : 1][MODE == MODE_FILL ? FIFO_CAP : 1];   // replayed hits' second atoms
     constexpr bool FILL = MODE != MODE_COUNT;
     extern __shared__ uint32_t lds_hist[];     // histogram mode only (hist_nbins counters)
     // The parameter block lives in device memory: a by-value struct this large, indexed dynamically
@@ -773,8 +902,10 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
         F.ids = out_ids;
         F.base = 0;
         F.hist = hist ? lds_hist : nullptr;
-        F.recompute = false;
+        F.recompute = 0u;
         F.la = lds_a[wave];
+        F.fq = nullptr;
+        F.fq_store = MODE == MODE_FILL ? lds_q[wave] : nullptr;
         F.wrap = 0;
         F.hmin = P.hist_min;
         F.hmax = P.hist_max;
@@ -789,11 +920,18 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(const SearchParams *__restr
             const uint32_t kind_bit = T.tri ? 4u : (wk != WK_NONE ? 2u : 1u);
             if (P.debug_skip & kind_bit) return;
         }
+        // count/fill pair: the count pass records the hit bits of the fast-path slots, the fill pass replays them
+        constexpr bool MASKED = MODE != MODE_HIST;
+        uint32_t *mwords = nullptr;
+        if (MASKED) {
+            const uint32_t nch = (T.n2 + 63u) >> 6;
+            mwords = P.maskbuf + (P.task_moff[t] + (unsigned long long)(slot - task_first[t]) * 2u * nch) * 64u;
+        }
         switch (wk) {
-            case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE>(P, T, i0, F, lds_a[wave], lane); break;
-            case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG>(P, T, i0, F, lds_a[wave], lane); break;
-            case WK_UPPER: total = run_task_nch<KIND, FILL, WK_UPPER>(P, T, i0, F, lds_a[wave], lane); break;
-            default: total = run_task_nch<KIND, FILL, WK_GENERAL>(P, T, i0, F, lds_a[wave], lane); break;
+            case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
+            case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
+            case WK_UPPER: total = run_task_nch<KIND, FILL, WK_UPPER, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
+            default: total = run_task_nch<KIND, FILL, WK_GENERAL, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
         }
         if (!FILL && lane == 0) slot_cnt[slot] = total;
         wave_total += total;

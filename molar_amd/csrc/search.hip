@@ -466,6 +466,8 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.vdwb = c->set[1].sorted_vdw.as<float>();
     P.aabb_b = two ? c->set[1].aabb.as<float4>() : c->set[0].aabb.as<float4>();
     P.task_desc = c->task_desc.as<TaskDesc>();
+    P.maskbuf = c->maskbuf.as<uint32_t>();
+    P.task_moff = c->task_moff.as<unsigned long long>();
     P.dx = c->dims[0];
     P.dy = c->dims[1];
     P.dz = c->dims[2];
@@ -673,24 +675,41 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q) {
     MH_TRY(c->slot_task.reserve((c->nslots_bound + 1) * 4));
     MH_TRY(c->slot_cnt.reserve((c->nslots_bound + 1) * 4));
     MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
+    MH_TRY(c->task_mu.reserve((c->ntasks + 1) * 4));
+    MH_TRY(c->task_moff.reserve((c->ntasks + 1) * 8));
+    const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
     {
         Prof prof(c, 0);
         MH_HIP(hipMemsetAsync(c->task_nb.p, 0, (c->ntasks + 1) * 4, c->stream));
+        MH_HIP(hipMemsetAsync(c->task_mu.p, 0, (c->ntasks + 1) * 4, c->stream));
         MH_HIP(hipMemsetAsync(c->slot_cnt.p, 0, (c->nslots_bound + 1) * 4, c->stream));
         const SearchParams P = make_params(c);
         const unsigned nb = (unsigned)((c->ntasks + 255) / 256);
         switch (c->kind) {
             case MOLAR_HIP_SEARCH_SINGLE:
-                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>());
+                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
+                                   c->task_mu.as<uint32_t>(), fast_kind);
                 break;
             default:   // the three two-grid kinds decode tasks identically
-                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>());
+                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
+                                   c->task_mu.as<uint32_t>(), fast_kind);
                 break;
         }
+        if (fast_kind)
+            MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->task_mu.as<uint32_t>(), c->task_moff.as<unsigned long long>(), c->ntasks + 1)));
         MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), c->ntasks + 1)));
         hipLaunchKernelGGL(slotmap_kernel, dim3(nb), dim3(256), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
                            c->slot_task.as<uint32_t>());
         MH_HIP(hipGetLastError());
+    }
+    // hit-history buffer of the count -> fill pair: sized exactly (one small read-back; the fused histogram
+    // mode does not use it, but sizing it here keeps a later count/fill on the same cached search valid)
+    c->mask_units = 0;
+    if (fast_kind) {
+        unsigned long long units = 0;
+        MH_TRY(read_back(c, &units, c->task_moff.as<unsigned long long>() + c->ntasks, 8));
+        c->mask_units = units;
+        MH_TRY(c->maskbuf.reserve((size_t)units * 256u + 256u));
     }
     return 0;
 }

@@ -46,6 +46,7 @@ def test_reference_benzene_states_on_device(eng):
     from molar_amd.xtc import XtcReader
     r = XtcReader(os.path.join(G, "benzene.xtc"), engine=eng)
     dev = torch.zeros((5, 12, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()             # the engine copies on ITS stream: torch's fill kernel must be done first
     r.read_frames(0, 5, out=dev)
     host = r.read_frames(0, 5)
     assert np.array_equal(dev.cpu().numpy(), host)
