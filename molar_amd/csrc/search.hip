@@ -475,7 +475,7 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.use_box = c->use_box ? 1u : 0u;
     P.cutoff2 = c->cutoff * c->cutoff;
     P.ntasks = c->ntasks;
-    P.nblocks = (uint32_t)((c->nslots_bound + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    P.nblocks = (uint32_t)c->nslots_bound;      // count / fill: one wave per workgroup (launch_pairs adjusts the histogram mode)
     P.box = c->box;
     P.hist_nbins = 0u;
     P.hist_min = P.hist_max = 0.f;
@@ -541,6 +541,8 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     size_t dyn_lds = 0;
     if (hist_nbins) {
         dyn_lds = (size_t)hist_nbins * 4;
+        const uint32_t wpb = (uint32_t)waves_per_block(MODE_HIST);
+        P.nblocks = (P.nblocks + wpb - 1u) / wpb;
         const uint32_t cap = (uint32_t)c->num_cus * 8u;
         if (P.nblocks > cap) P.nblocks = cap;
     }
