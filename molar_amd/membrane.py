@@ -12,7 +12,7 @@ All per-lipid loops are batched: one launch per stage for all lipids of a frame.
 markers once in Membrane::new and its per-frame refresh is commented out (lipid_molecule.rs:65-99); this class
 refreshes them every frame, which is what the commented code does.  Where the reference iterates a HashSet
 (n-th shell patches, curvature averaging) the order is unspecified there; here it is ascending lipid id.
-Group statistics and file output (stats.rs, lipid_group.rs) are host bookkeeping and out of scope.
+Group statistics and their text output (stats.rs, lipid_group.rs) are host bookkeeping: membrane_stats.py.
 """
 from __future__ import annotations
 
@@ -130,6 +130,27 @@ class Membrane:
         self.ntails = len(tl)
         self.tail_lens = [len(t) for t in tl]
         self.valid = np.ones(self.K, np.uint8)                                  # LipidMolecule::valid, sticky across frames
+        self.species_names = ["LIP"]                                            # one template = one species
+        self.species_of_lipid = np.zeros(self.K, np.int64)
+        self.groups = {}
+
+    # ---- groups (lib.rs:261-345, lipid_group.rs)
+    def add_ids_to_group(self, name, ids):
+        from .membrane_stats import LipidGroup
+        ids = np.asarray(ids, np.int64)
+        if len(ids) and (ids.min() < 0 or ids.max() >= self.K):
+            raise ValueError(f"lipid id out of bounds 0:{self.K}")                # lib.rs:303-309
+        if name not in self.groups:
+            self.groups[name] = LipidGroup(self.species_names, {sp: self.tail_lens for sp in self.species_names})
+        self.groups[name].lipid_ids = np.concatenate([self.groups[name].lipid_ids, ids])
+
+    def reset_groups(self):                                                     # lib.rs:261-267
+        for g in self.groups.values():
+            g.lipid_ids = np.zeros(0, np.int64)
+
+    def finalize(self, output_dir="."):                                         # lib.rs:517-537
+        for name, g in self.groups.items():
+            g.save(output_dir, name)
 
     def reset_valid_lipids(self):                                               # lib.rs:269-273
         self.valid[:] = 1
@@ -224,4 +245,9 @@ class Membrane:
         for k in ("quad_coefs", "mean_curv", "gauss_curv", "princ_curvs", "princ_dirs", "area", "nvert", "neib_ids",
                   "voro_vertexes", "fitted_patch_points"):
             res[k] = st[k]
+        if self.groups:                                                         # lib.rs:448-451
+            d = (head - tail).astype(np.float32)
+            thv = d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]        # tail_head_vec (lib.rs:459-461)
+            for g in self.groups.values():
+                g.frame_update(res, self.species_of_lipid, thv)
         return res

@@ -211,3 +211,31 @@ def test_membrane_shells_and_iterations(eng, orc32):
     assert np.abs(res["mean_curv"][ok]).mean() < 0.2
     # patches are now Voronoi shells: symmetric-ish, much smaller than the 2 nm disc
     assert np.diff(res["patch_off"].astype(np.int64))[ok].mean() < 30
+
+
+def test_membrane_groups_accumulate(eng, tmp_path):
+    """Groups + per-frame statistics over two frames (lib.rs:448-451, lipid_group.rs, stats.rs)."""
+    from molar_amd import membrane as mb
+    xyz, box, first, tpl, masses = mb.build_bilayer(300, 50000)
+    K = len(first)
+    m = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(cutoff=2.0))
+    m.add_ids_to_group("upper", np.arange(300))
+    m.add_ids_to_group("lower", np.arange(300, 600))
+    with pytest.raises(ValueError):
+        m.add_ids_to_group("upper", [K])
+    rng = np.random.default_rng(3)
+    areas = []
+    for f in range(2):
+        res = m.compute((xyz + rng.normal(0, 0.01, xyz.shape)).astype(np.float32), box)
+        ok = res["valid"].astype(bool)
+        areas.append(res["area"][:300][ok[:300]])
+    g = m.groups["upper"].per_species["LIP"]
+    allarea = np.concatenate(areas)
+    mean, std = g.area.compute()
+    assert np.isclose(mean, allarea.mean(), rtol=1e-4) and np.isclose(std, allarea.std(), rtol=2e-2)
+    assert 250 < g.num_lip.compute()[0] <= 300 and 5 < g.num_neib.compute()[0] < 7
+    assert g.tilt.compute()[0] < 25.0                      # normals roughly along the tail-head vectors
+    assert np.isclose(g.neib_species["LIP"].compute()[0], g.num_neib.compute()[0], rtol=1e-3)
+    m.finalize(tmp_path)
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["gr_lower_neib_stats.dat", "gr_lower_order_LIP.dat", "gr_lower_stats.dat",
+                                                          "gr_upper_neib_stats.dat", "gr_upper_order_LIP.dat", "gr_upper_stats.dat"]
