@@ -278,6 +278,7 @@ int build_index(molar_hip_xtc *x) {
             f.nbytes = magic == 2023 ? (((uint64_t)be32(p + 88) << 32) | be32(p + 92)) : be32(p + 88);
             f.data_off = off + hdr;
             len = hdr + ((f.nbytes + 3) & ~(uint64_t)3);
+            if (f.nbytes * 8 < (uint64_t)f.natoms) break;   // every atom costs at least its flag bit: hostile header
         }
         if (off + len > x->size) break;       // truncated last frame: stop like an UnexpectedEof (xtc_handler.rs:325-332)
         x->frames.push_back(f);

@@ -137,3 +137,37 @@ def test_reference_trajectories_product_equals_oracle(reader_cls, orc32, rel, nf
     # consecutive frames of an MD trajectory are close
     d = np.abs(got[1:] - got[:-1])
     assert np.median(d) < 0.3
+
+
+def test_corrupt_streams_do_not_crash(reader_cls, orc32):
+    """Bit flips, truncations and hostile header fields: the decoder reports an error or returns numbers, it never
+    reads outside the buffer (the reader bounds every fetch by the block length of the index)."""
+    from molar_amd._lib import MolarHipError
+    frames, box9 = synthetic_frames(600, 2)
+    good = b"".join(orc32.xtc_encode(f, box9, step=k, time=float(k)) for k, f in enumerate(frames))
+    rng = np.random.default_rng(7)
+    outcomes = {"ok": 0, "error": 0, "short": 0}
+    for trial in range(300):
+        b = bytearray(good)
+        kind = trial % 3
+        if kind == 0:                                   # random bit flips in the compressed block
+            for _ in range(int(rng.integers(1, 6))):
+                pos = int(rng.integers(92, len(b)))
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:                                 # hostile header words (natoms, sizes, smallidx, byte count)
+            pos = int(rng.choice([4, 52, 60, 64, 68, 72, 76, 80, 84, 88]))
+            b[pos:pos + 4] = rng.integers(0, 256, 4, dtype=np.uint8).tobytes()
+        else:                                           # truncation
+            b = b[: int(rng.integers(1, len(b)))]
+        r = reader_cls(bytes(b), nthreads=1)
+        n = len(r)
+        if n < 2:
+            outcomes["short"] += 1
+        try:
+            if n:
+                r.read_frames(0, n)
+            outcomes["ok"] += 1
+        except MolarHipError:
+            outcomes["error"] += 1
+        r.close()
+    assert outcomes["error"] > 0 and outcomes["ok"] > 0 and outcomes["short"] > 0
