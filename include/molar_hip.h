@@ -169,6 +169,13 @@ int molar_hip_search_grid_dims(molar_hip_ctx *ctx, uint64_t dims[3]);
 /* Device-resident result of the cached search: fills ctx-owned buffers (reused across frames)
  * and returns their device addresses; valid until the next search on this ctx. */
 int molar_hip_search_fill_device(molar_hip_ctx *ctx, const uint32_t **d_pairs, const float **d_dist);
+/* The resident path in one call and ONE host round trip: count, offset scan and fill are enqueued back to back
+ * into ctx-owned buffers sized by earlier frames of the trajectory; if a buffer turns out too small (first
+ * frame) it grows and the affected pass repeats.  Same result, order and validity rules as
+ * molar_hip_search_count + molar_hip_search_fill_device; the cached search stays available to the other fill
+ * variants.  Not for WITHIN (ids, not pairs). */
+int molar_hip_search_resident(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_count,
+                              const uint32_t **d_pairs, const float **d_dist);
 /* Consumer-fused variant: never materialises pairs; every emitted distance d goes through
  * Histogram1D::add_one (molar_membrane/src/stats.rs:29-35): b=floor(n*(d-min)/(max-min)),
  * counted in integers (bins: uint64[nbins], accumulated INTO, so frames can be summed). */

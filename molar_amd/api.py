@@ -188,8 +188,8 @@ class Engine:
         return {name: (float(ms[k]), int(ln[k])) for k, name in enumerate(self.PROFILE_CLASSES)}
 
     # ------------------------------------------------------------ search
-    def search_count(self, kind, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, vdw1=None,
-                     vdw2=None, ids_local=False, lower=None, upper=None) -> int:
+    def _search_desc(self, kind, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, vdw1=None,
+                     vdw2=None, ids_local=False, lower=None, upper=None):
         xyz1 = _f32(xyz1); xyz2 = _f32(xyz2); idx1 = _u64(idx1); idx2 = _u64(idx2)
         vdw1 = _f32(vdw1); vdw2 = _f32(vdw2)
         d = SearchDesc()
@@ -217,10 +217,25 @@ class Engine:
             keep += [lo, up]
             d.lower3 = lo.ctypes.data
             d.upper3 = up.ctypes.data
+        return d, keep
+
+    def search_count(self, kind, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, vdw1=None,
+                     vdw2=None, ids_local=False, lower=None, upper=None) -> int:
+        d, keep = self._search_desc(kind, cutoff, xyz1, idx1, xyz2, idx2, box, pbc, vdw1, vdw2, ids_local, lower, upper)
         cnt = C.c_uint64(0)
         check(self.lib.molar_hip_search_count(self.ctx, C.byref(d), C.byref(cnt)))
         self._keep = keep
         return int(cnt.value)
+
+    def search_resident(self, kind, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, vdw1=None,
+                        vdw2=None, ids_local=False, lower=None, upper=None):
+        """Count + fill into engine-owned device buffers with a single host round trip
+        (molar_hip_search_resident).  Returns (count, pairs_device_address, dist_device_address)."""
+        d, keep = self._search_desc(kind, cutoff, xyz1, idx1, xyz2, idx2, box, pbc, vdw1, vdw2, ids_local, lower, upper)
+        cnt = C.c_uint64(0); p = C.c_void_p(); dd = C.c_void_p()
+        check(self.lib.molar_hip_search_resident(self.ctx, C.byref(d), C.byref(cnt), C.byref(p), C.byref(dd)))
+        self._keep = keep
+        return int(cnt.value), p.value, dd.value
 
     def search_fill(self, count):
         pairs = np.empty((count, 2), np.uint32)

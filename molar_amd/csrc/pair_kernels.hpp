@@ -42,6 +42,9 @@ struct SearchParams {
     const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
     uint32_t *maskbuf;       // fast-path slots: hit bits found by the count pass, replayed by the fill pass
     const unsigned long long *task_moff;   // per task: first 64-word unit of its slots in maskbuf (a slot owns 2*nch units)
+    unsigned long long mask_cap_units;     // units maskbuf can hold; a slot beyond it records / replays nothing (the host
+                                           // grows the buffer and repeats the pass - single-sync resident path)
+    unsigned long long out_cap;            // result entries the output buffers can hold; slots beyond it write nothing
     uint32_t dx, dy, dz;
     uint32_t pbc;            // PbcDims of the plan (0 for the non-periodic drivers)
     uint32_t use_box;
@@ -574,6 +577,7 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
     uint32_t total = 0;
 
     if (REPLAY) {
+        if (!mwords) return 0u;                // the bits of this slot were not recorded (buffer too small)
         // ---- fill pass over recorded hit bits.  Word (g, k) of lane l holds, MSB first, the hit bits of
         // (live row, atom k*64+l) for the g-th group of 32 live rows.  A queued hit is (row, sorted position);
         // ids and the exact d2 are rebuilt densely at flush time (fifo_hit).
@@ -649,7 +653,7 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             acc += (uint32_t)__popc(hw[k]);
-            mwords[(g * NCH + k) * 64u + lane] = hw[k] << (32u - n);
+            if (mwords) mwords[(g * NCH + k) * 64u + lane] = hw[k] << (32u - n);
             hw[k] = 0u;
         }
     };
@@ -915,7 +919,8 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
         F.hn = (float)P.hist_nbins;
         if (FILL && !hist) {
             F.base = slot_base[slot];
-            if (slot_base[slot + 1] == F.base) return;     // nothing to emit: skip the traversal
+            const unsigned long long end = slot_base[slot + 1];
+            if (end == F.base || end > P.out_cap) return;  // nothing to emit / no room (the host grows and repeats)
         }
         uint32_t total = 0;
         const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
@@ -928,7 +933,8 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
         uint32_t *mwords = nullptr;
         if (MASKED) {
             const uint32_t nch = (T.n2 + 63u) >> 6;
-            mwords = P.maskbuf + (P.task_moff[t] + (unsigned long long)(slot - task_first[t]) * 2u * nch) * 64u;
+            const unsigned long long mu = P.task_moff[t] + (unsigned long long)(slot - task_first[t]) * 2u * nch;
+            if (mu + 2u * nch <= P.mask_cap_units) mwords = P.maskbuf + mu * 64u;
         }
         switch (wk) {
             case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;

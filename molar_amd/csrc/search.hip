@@ -468,6 +468,8 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.task_desc = c->task_desc.as<TaskDesc>();
     P.maskbuf = c->maskbuf.as<uint32_t>();
     P.task_moff = c->task_moff.as<unsigned long long>();
+    P.mask_cap_units = c->maskbuf.cap / 256u;
+    P.out_cap = ~0ull;
     P.dx = c->dims[0];
     P.dy = c->dims[1];
     P.dz = c->dims[2];
@@ -530,10 +532,11 @@ SearchParams make_params(molar_hip_ctx *c) {
 
 template <bool FILL>
 int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uint32_t hist_nbins = 0, float hmin = 0.f,
-                 float hmax = 0.f, unsigned long long *hist_bins = nullptr) {
+                 float hmax = 0.f, unsigned long long *hist_bins = nullptr, unsigned long long out_cap = ~0ull) {
     Prof prof(c, FILL ? 3 : 1);
     SearchParams P = make_params(c);
     if (P.nblocks == 0) return 0;
+    P.out_cap = out_cap;
     P.hist_nbins = hist_nbins;
     P.hist_min = hmin;
     P.hist_max = hmax;
@@ -597,7 +600,7 @@ int device_fmax(molar_hip_ctx *c, const float *d_v, uint32_t n, float *out) {
     return 0;
 }
 
-int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q) {
+int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_masks = true) {
     if (!c || !q) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: null argument");
     if (q->kind < 0 || q->kind > 3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: unknown kind %d", q->kind);
     MH_HIP(hipSetDevice(c->device));
@@ -707,7 +710,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q) {
     // hit-history buffer of the count -> fill pair: sized exactly (one small read-back; the fused histogram
     // mode does not use it, but sizing it here keeps a later count/fill on the same cached search valid)
     c->mask_units = 0;
-    if (fast_kind) {
+    if (fast_kind && size_masks) {
         unsigned long long units = 0;
         MH_TRY(read_back(c, &units, c->task_moff.as<unsigned long long>() + c->ntasks, 8));
         c->mask_units = units;
@@ -793,6 +796,61 @@ int molar_hip_search_fill_device(molar_hip_ctx *c, const uint32_t **d_pairs, con
     MH_TRY(c->out_pairs.reserve((size_t)(c->total ? c->total : 1) * 8));
     MH_TRY(c->out_dist.reserve((size_t)(c->total ? c->total : 1) * 4));
     MH_TRY(fill_common(c, c->out_pairs.as<uint2>(), c->out_dist.as<float>(), nullptr));
+    if (d_pairs) *d_pairs = c->out_pairs.as<uint32_t>();
+    if (d_dist) *d_dist = c->out_dist.as<float>();
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_search_resident(molar_hip_ctx *c, const molar_hip_search_desc *q, uint64_t *out_count,
+                              const uint32_t **d_pairs, const float **d_dist) {
+    if (q && q->kind == MOLAR_HIP_SEARCH_WITHIN)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within search yields ids: use molar_hip_search_count + fill_ids");
+    MH_TRY(prepare_search(c, q, /*size_masks=*/false));
+    if (c->have_search) {   // degenerate (empty vdw input)
+        if (out_count) *out_count = 0;
+        if (d_pairs) *d_pairs = c->out_pairs.as<uint32_t>();
+        if (d_dist) *d_dist = c->out_dist.as<float>();
+        return MOLAR_HIP_OK;
+    }
+    // Count, scan and fill are enqueued back to back against the capacities left by earlier frames; one
+    // read-back tells whether the hit-bit buffer or the result buffers were too small, in which case they grow
+    // and the affected passes run again (first frame of a trajectory; later frames are the same size +- noise).
+    const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
+    auto out_cap = [&]() -> unsigned long long {
+        const unsigned long long a = c->out_pairs.cap / 8u, b = c->out_dist.cap / 4u;
+        return a < b ? a : b;
+    };
+    MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr));
+    {
+        Prof prof(c, 2);
+        MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(),
+                                                             c->nslots_bound + 1)));
+    }
+    unsigned long long cap0 = out_cap();
+    if (cap0) MH_TRY(launch_pairs<true>(c, c->out_pairs.as<uint2>(), c->out_dist.as<float>(), nullptr, 0, 0.f, 0.f, nullptr, cap0));
+    unsigned long long res[2] = {0, 0};
+    MH_TRY(ensure_pinned(c, 16));
+    MH_HIP(hipMemcpyAsync(c->h_pinned, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8, hipMemcpyDeviceToHost, c->stream));
+    if (fast_kind)
+        MH_HIP(hipMemcpyAsync((char *)c->h_pinned + 8, c->task_moff.as<unsigned long long>() + c->ntasks, 8, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(res, c->h_pinned, 16);
+    c->total = res[0];
+    c->mask_units = fast_kind ? res[1] : 0;
+    c->have_search = true;
+    bool refill = cap0 == 0 && c->total != 0;
+    if (c->mask_units > c->maskbuf.cap / 256u) {        // hit bits did not fit: grow, record them, fill again
+        MH_TRY(c->maskbuf.reserve((size_t)(c->mask_units + c->mask_units / 4u) * 256u + 256u));
+        MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr));
+        refill = true;
+    }
+    if (c->total > cap0) {
+        MH_TRY(c->out_pairs.reserve((size_t)(c->total + c->total / 16u) * 8));
+        MH_TRY(c->out_dist.reserve((size_t)(c->total + c->total / 16u) * 4));
+        refill = true;
+    }
+    if (refill && c->total) MH_TRY(launch_pairs<true>(c, c->out_pairs.as<uint2>(), c->out_dist.as<float>(), nullptr));
+    if (out_count) *out_count = c->total;
     if (d_pairs) *d_pairs = c->out_pairs.as<uint32_t>();
     if (d_dist) *d_dist = c->out_dist.as<float>();
     return MOLAR_HIP_OK;

@@ -489,3 +489,50 @@ def test_non_finite_coordinates_and_degenerate_inputs(eng, orc32):
     # an empty second set
     cnt = eng.search_count(a.SEARCH_DOUBLE, 0.5, pos, np.arange(100, dtype=np.uint64), pos, np.zeros(0, np.uint64), box=box, pbc=7)
     assert cnt == 0
+
+
+def test_resident_single_round_trip_matches_count_then_fill():
+    """molar_hip_search_resident: same ordered result as count + fill, through the grow-and-repeat logic (fresh
+    context: every buffer starts empty; then larger and smaller systems on the same context)."""
+    import torch
+    a = api()
+    from molar_amd.api import Engine
+    e1, e2 = Engine(0), Engine(0)
+    for n, boxfn, rc in ((3000, synth.box_a, 0.5), (20000, synth.box_a, 0.7), (5000, synth.box_b, 0.6), (20000, synth.box_a, 0.7),
+                         (4000, synth.box_ortho, 0.45)):
+        box = boxfn(n)
+        pos = synth.frame(n, box, sigma=0.08)
+        want_n = e1.search_count(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+        want_p, want_d = e1.search_fill(want_n)
+        cnt, pp, dp = e2.search_resident(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+        assert cnt == want_n > 0
+        # the engine-owned device buffers hold the ordered result
+        class Dev:
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+        e2.synchronize()
+        got_pairs = torch.as_tensor(Dev(pp, cnt * 2, "<i4"), device="cuda").cpu().numpy().view(np.uint32).reshape(-1, 2)
+        got_dist = torch.as_tensor(Dev(dp, cnt, "<f4"), device="cuda").cpu().numpy()
+        assert np.array_equal(got_pairs, want_p) and np.array_equal(got_dist, want_d)
+        # the cached search of the resident call serves the host fill too
+        got_p, got_d = e2.search_fill(cnt)
+        assert np.array_equal(got_p, want_p) and np.array_equal(got_d, want_d)
+    # two-set search and vdw through the same entry
+    n = 6000
+    box = synth.box_ortho(n, density=60.0)
+    pos = synth.frame(n, box)
+    i1 = np.arange(0, n // 2, dtype=np.uint64); i2 = np.arange(n // 2, n, dtype=np.uint64)
+    want_n = e1.search_count(a.SEARCH_DOUBLE, 0.6, pos, i1, pos, i2, box=box, pbc=7)
+    want = e1.search_fill(want_n)
+    cnt, _, _ = e2.search_resident(a.SEARCH_DOUBLE, 0.6, pos, i1, pos, i2, box=box, pbc=7)
+    got = e2.search_fill(cnt)
+    assert cnt == want_n and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    v = np.random.default_rng(2).uniform(0.1, 0.2, n // 2).astype(np.float32)
+    want_n = e1.search_count(a.SEARCH_DOUBLE_VDW, None, pos, i1, pos, i2, vdw1=v, vdw2=v)
+    want = e1.search_fill(want_n)
+    cnt, _, _ = e2.search_resident(a.SEARCH_DOUBLE_VDW, None, pos, i1, pos, i2, vdw1=v, vdw2=v)
+    got = e2.search_fill(cnt)
+    assert cnt == want_n and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    from molar_amd._lib import MolarHipError
+    with pytest.raises(MolarHipError):
+        e2.search_resident(a.SEARCH_WITHIN, 0.5, pos, i1, pos, i2, box=box, pbc=7)
