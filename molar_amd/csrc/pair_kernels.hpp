@@ -31,6 +31,25 @@ static __constant__ uint8_t MASKS[14][6] = {
 
 // ================================================================= pair kernels
 
+// Pointers read out of the parameter block in memory have no address space the compiler can see, so plain
+// dereferences become FLAT accesses (aperture check, both wait counters).  These helpers state the space:
+// global_load with an SGPR base, ds_read for LDS.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload4(const float4 *p, size_t i) {
+    const v4f_t v = ((const __attribute__((address_space(1))) v4f_t *)p)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t gload_u32(const uint32_t *p, size_t i) {
+    return ((const __attribute__((address_space(1))) uint32_t *)p)[i];
+}
+__device__ __forceinline__ void gstore_u32(uint32_t *p, size_t i, uint32_t v) {
+    ((__attribute__((address_space(1))) uint32_t *)p)[i] = v;
+}
+__device__ __forceinline__ float4 lload4(const float4 *p, uint32_t i) {
+    const v4f_t v = ((const __attribute__((address_space(3))) v4f_t *)p)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct SearchParams {
     const float4 *sa;        // cell-sorted atoms of set 1
     const float4 *sb;        // cell-sorted atoms of set 2 (== sa for SINGLE)
@@ -251,8 +270,14 @@ struct Hit {
 __device__ __forceinline__ Hit fifo_hit(const SearchParams &P, const Fifo &F, uint32_t s) {
     const uint32_t w = F.fd[s];
     if (F.recompute == 0u) return Hit{F.fi[s], F.fj[s], __uint_as_float(w)};
-    const float4 a = F.la[F.fq ? w : (w >> 26)];
-    const float4 b = F.fq ? F.fq[s] : P.sb[w & 0x3FFFFFFu];
+    float4 a, b;
+    if (F.fq) {                 // replay: two LDS reads
+        a = lload4(F.la, w);
+        b = lload4(F.fq, s);
+    } else {
+        a = lload4(F.la, w >> 26);
+        b = gload4(P.sb, w & 0x3FFFFFFu);
+    }
     const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;               // p2 - p1
     const float d2 = F.recompute == 1u ? wrapped_d2_exact(P, F.wrap, dx, dy, dz) : (dx * dx + dy * dy) + dz * dz;
     return Hit{__float_as_uint(a.w), __float_as_uint(b.w), d2};
@@ -542,7 +567,7 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
             const uint32_t jj = (uint32_t)k * 64u + lane;
             float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
             if (jj < T.n2) {
-                q = P.sb[T.b0 + jj];
+                q = gload4(P.sb, T.b0 + jj);
                 if (WRAPPED) { q.x += Sx; q.y += Sy; q.z += Sz; }       // S == 0 when the slot is evaluated exactly
             }
             bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bid[k] = __float_as_uint(q.w);
@@ -554,9 +579,9 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
     unsigned long long live;   // rows of this slot that can have a hit at all (same value in both passes)
     {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < rows) a = P.sa[T.a0 + i0 + lane];
+        if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
         la[lane] = a;
-        const float4 lo = P.aabb_b[2 * T.cb], hi = P.aabb_b[2 * T.cb + 1];
+        const float4 lo = gload4(P.aabb_b, 2 * T.cb), hi = gload4(P.aabb_b, 2 * T.cb + 1);
         bool need = true;
         if (TRI) {
             // same cell (i < j triangle, :439-451): the atom lies inside its own cell's box, nothing to prune
@@ -590,14 +615,14 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
         for (int k = 0; k < NCH; ++k) {
             const uint32_t jj = (uint32_t)k * 64u + lane;
             q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (jj < T.n2) q[k] = P.sb[T.b0 + jj];
+            if (jj < T.n2) q[k] = gload4(P.sb, T.b0 + jj);
         }
         uint32_t w[NCH];
         uint32_t nrow = 0;
         while (live) {
             if ((nrow & 31u) == 0u) {
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) w[k] = mwords[((nrow >> 5) * NCH + k) * 64u + lane];
+                for (int k = 0; k < NCH; ++k) w[k] = gload_u32(mwords, ((nrow >> 5) * NCH + k) * 64u + lane);
             }
             ++nrow;
             const uint32_t r = (uint32_t)__builtin_ctzll(live);
@@ -653,20 +678,20 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             acc += (uint32_t)__popc(hw[k]);
-            if (mwords) mwords[(g * NCH + k) * 64u + lane] = hw[k] << (32u - n);
+            if (mwords) gstore_u32(mwords, (g * NCH + k) * 64u + lane, hw[k] << (32u - n));
             hw[k] = 0u;
         }
     };
     // exact d2 of (row atom p, atom jj of the second cell), second cell re-read unshifted
     auto exact_d2 = [&](const float4 &p, uint32_t jj) -> float {
         float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
-        if (jj < T.n2) q = P.sb[T.b0 + jj];
+        if (jj < T.n2) q = gload4(P.sb, T.b0 + jj);
         return wrapped_d2_exact(P, T.wrap, q.x - p.x, q.y - p.y, q.z - p.z);
     };
     while (live) {
         const uint32_t r = (uint32_t)__builtin_ctzll(live);
         live &= live - 1ull;
-        const float4 p = la[r];                      // one broadcast ds_read per row
+        const float4 p = lload4(la, r);              // one broadcast ds_read per row
         const uint32_t id_i = __float_as_uint(p.w);
         const uint32_t i = i0 + r;
 #pragma unroll
