@@ -18,6 +18,7 @@ constexpr int waves_per_block(int mode) { return mode == MODE_HIST ? 4 : 1; }
 constexpr int KREG = 8;            // B-cell chunks (of 64 atoms) a lane keeps in registers
 constexpr int FIFO_CAP = 128;      // per-wave LDS FIFO entries (flush threshold 64, push <= 64)
 constexpr float F32_EPS = 1.1920929e-07f;
+constexpr bool MASKED_COUNT_SORTED = true;   // count pass of plain / same-cell entries walks the spatial order
 
 // distance_search.rs:39-60
 static __constant__ uint8_t MASKS[14][6] = {
@@ -58,6 +59,8 @@ struct SearchParams {
     const float *vdwa;
     const float *vdwb;
     const float4 *aabb_b;    // per-cell bounding boxes of set 2 (== set 1 for SINGLE)
+    const uint32_t *perm_b;  // set 2: Morton order inside each cell (cells of <= 512 atoms), see cell_order_kernel
+    const float4 *chunk_aabb_b;   // set 2: bounding boxes of the 64-atom Morton chunks, slot (cell_start >> 6) + cell + k
     const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
     uint32_t *maskbuf;       // fast-path slots: hit bits found by the count pass, replayed by the fill pass
     const unsigned long long *task_moff;   // per task: first 64-word unit of its slots in maskbuf (a slot owns 2*nch units)
@@ -541,10 +544,69 @@ __device__ __forceinline__ float aabb_d2(float ax, float ay, float az, float lx,
 //    band (a fraction of a percent of the chunks) are evaluated with the exact formula.  Hits carry
 //    (row, atom position) through the FIFO and their exact d2 is recomputed densely at flush time.
 //    The band is >10x the worst-case disagreement between the two evaluations (make_params()).
+// Count pass of plain and same-cell entries.  A count does not depend on the order in which candidates are
+// visited, so the second cell is walked in the SPATIAL order prepared by cell_order_kernel: its 64-atom chunks are
+// compact, and a (row, chunk) pair is skipped when the row's atom is farther than the cutoff from the chunk's
+// bounding box - the same exact f32 lower-bound argument as the row pruning of run_fast.  In the reference's
+// order a chunk spans the whole cell and nothing could be skipped; here ~43 % of the candidate evaluations of
+// the 13 neighbour entries go away.  Row-outer loop (one LDS broadcast per row), a scalar test per chunk,
+// VALU-only counting as in run_fast.
+template <int KIND, int NCH, bool TRI>
+__device__ __forceinline__ uint32_t run_count_sorted(const SearchParams &P, const Task &T, uint32_t i0, float4 *la,
+                                                     uint32_t lane) {
+    const float cutoff2 = P.cutoff2;
+    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
+    la[lane] = a;
+    float bx[NCH], by[NCH], bz[NCH];
+    uint32_t bpos[NCH];          // position of the atom in the reference's cell order (same-cell entries: j > i)
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const uint32_t jj = (uint32_t)k * 64u + lane;
+        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+        uint32_t pj = 0u;
+        if (jj < T.n2) {
+            pj = gload_u32(P.perm_b, T.b0 + jj);
+            q = gload4(P.sb, T.b0 + pj);
+        }
+        bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bpos[k] = pj;
+    }
+    const uint32_t ubase = (T.b0 >> 6) + T.cb;
+    unsigned long long livek[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const float4 lo = gload4(P.chunk_aabb_b, 2u * (ubase + k)), hi = gload4(P.chunk_aabb_b, 2u * (ubase + k) + 1u);
+        const bool need = lane < rows && !(aabb_d2(a.x, a.y, a.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > cutoff2);
+        livek[k] = __builtin_amdgcn_ballot_w64(need);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t acc = 0;
+    unsigned long long live = 0ull;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) live |= livek[k];
+    while (live) {
+        const uint32_t r = (uint32_t)__builtin_ctzll(live);
+        live &= live - 1ull;
+        const float4 p = lload4(la, r);              // one broadcast ds_read per row
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (!((livek[k] >> r) & 1ull)) continue;                              // wave-uniform: scalar branch
+            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1
+            float d2 = (dx * dx + dy * dy) + dz * dz;                            // |p2-p1|^2 (:446, :460)
+            if (TRI) d2 = (bpos[k] > i0 + r) ? d2 : INFINITY;                    // same cell: j in i+1..n (:443)
+            asm volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(acc) : "v"(d2), "s"(cutoff2) : "vcc");
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    return acc;
+}
+
 template <int KIND, bool FILL, bool WRAPPED, int NCH, bool TRI, bool MASKED>
 __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                              uint32_t lane, uint32_t *mwords) {
     static_assert(!(WRAPPED && TRI), "a triangular (same-cell) entry never wraps on the fast path");
+    if constexpr (!FILL && !WRAPPED && MASKED_COUNT_SORTED) return run_count_sorted<KIND, NCH, TRI>(P, T, i0, la, lane);
     // approximate classification allowed?  (needs n_d = round(f_d) = +-1 for every wrapped pair: >= 4 cells
     // per periodic dimension; the corner entries of triclinic boxes run the candidate loop: always exact)
     const bool approx = WRAPPED && P.approx_wrapped != 0u && !(P.box.nshift != 0 && T.wrap == MOLAR_HIP_PBC_FULL);

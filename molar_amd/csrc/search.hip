@@ -155,14 +155,26 @@ __global__ void __launch_bounds__(256) place_kernel(BinParams P, uint32_t ncells
     if (vdw) sorted_vdw[s + rank] = vdw[k];
 }
 
-// Axis-aligned bounding box of the positions stored in each cell (lab frame): aabb[2c] = lo,
-// aabb[2c+1] = hi.  One wave per cell.  Lets a row of the pair kernels prove "no atom of the other
-// cell can be within the cutoff" and skip its candidates (see run_plain).
-__global__ void __launch_bounds__(256) cell_aabb_kernel(uint32_t ncells, const uint32_t *__restrict__ cell_start,
-                                                        const float4 *__restrict__ sorted, float4 *__restrict__ aabb) {
-    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+// Per cell (one wave each): the axis-aligned bounding box of the stored positions (aabb[2c] = lo, aabb[2c+1] =
+// hi; lets a row of the pair kernels prove "no atom of the other cell can be within the cutoff"), and for cells
+// that fit the register-resident fast path (<= 512 atoms) a SPATIAL order of their atoms for the count pass:
+//   perm[cell_start[c] + m]  = position inside the cell of the m-th atom in Morton order (3 bits per axis of the
+//                              cell's bounding box; LDS counting sort, order inside a key irrelevant),
+//   chunk_aabb[2*u], [2*u+1] = bounding box of the 64 atoms of Morton chunk k, u = (cell_start[c] >> 6) + c + k
+//                              (distinct for all chunks of all cells: a cell owns floor(n/64)+1 >= ceil(n/64) slots).
+// Counting does not depend on the order in which candidates are visited, so the count pass walks compact
+// chunks and skips (row, chunk) pairs by bounding box; the fill pass keeps the reference's order.
+constexpr uint32_t ORDER_MAX = 512;   // = KREG * 64 of the pair kernels
+__global__ void __launch_bounds__(256) cell_order_kernel(uint32_t ncells, const uint32_t *__restrict__ cell_start,
+                                                         const float4 *__restrict__ sorted, float4 *__restrict__ aabb,
+                                                         uint32_t *__restrict__ perm, float4 *__restrict__ chunk_aabb) {
+    __shared__ uint32_t hist_s[4][ORDER_MAX];
+    __shared__ uint32_t kr_s[4][ORDER_MAX];
+    __shared__ uint16_t perm_s[4][ORDER_MAX];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t c = blockIdx.x * 4u + w;
     if (c >= ncells) return;
-    const uint32_t s = cell_start[c], e = cell_start[c + 1];
+    const uint32_t s = cell_start[c], e = cell_start[c + 1], n = e - s;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t q = s + lane; q < e; q += 64u) {
         const float4 p = sorted[q];
@@ -178,6 +190,63 @@ __global__ void __launch_bounds__(256) cell_aabb_kernel(uint32_t ncells, const u
     if (lane == 0) {
         aabb[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f);
         aabb[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+    if (n == 0 || n > ORDER_MAX || !perm) return;
+    uint32_t *hist = hist_s[w], *kr = kr_s[w];
+    uint16_t *pl = perm_s[w];
+    for (uint32_t b = lane; b < ORDER_MAX; b += 64u) hist[b] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    float sc[3];
+    for (int d = 0; d < 3; ++d) sc[d] = hi[d] > lo[d] ? 8.0f / (hi[d] - lo[d]) : 0.0f;
+    auto cell3 = [&](float v, int d) -> uint32_t {
+        const float f = (v - lo[d]) * sc[d];
+        return f >= 7.0f ? 7u : (f > 0.0f ? (uint32_t)f : 0u);      // NaN -> 0
+    };
+    for (uint32_t t = lane; t < n; t += 64u) {
+        const float4 p = sorted[s + t];
+        const uint32_t x = cell3(p.x, 0), y = cell3(p.y, 1), z = cell3(p.z, 2);
+        uint32_t key = 0;
+        for (int b = 0; b < 3; ++b) key |= (((x >> b) & 1u) << (3 * b)) | (((y >> b) & 1u) << (3 * b + 1)) | (((z >> b) & 1u) << (3 * b + 2));
+        const uint32_t rank = atomicAdd(&hist[key], 1u);
+        kr[t] = key | (rank << 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // exclusive prefix over the 512 bins: 8 consecutive bins per lane
+        uint32_t loc[8], sum = 0;
+        for (int b = 0; b < 8; ++b) { loc[b] = hist[lane * 8u + b]; sum += loc[b]; }
+        uint32_t inc = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if ((int)lane >= off) inc += o;
+        }
+        uint32_t run = inc - sum;
+        for (int b = 0; b < 8; ++b) { hist[lane * 8u + b] = run; run += loc[b]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = lane; t < n; t += 64u) {
+        const uint32_t v = kr[t];
+        pl[hist[v & 0xFFFFu] + (v >> 16)] = (uint16_t)t;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t ubase = (s >> 6) + c;
+    for (uint32_t k = 0; k * 64u < n; ++k) {
+        const uint32_t m = k * 64u + lane;
+        float l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (m < n) {
+            const uint32_t t = pl[m];
+            perm[s + m] = t;
+            const float4 p = sorted[s + t];
+            l3[0] = h3[0] = p.x; l3[1] = h3[1] = p.y; l3[2] = h3[2] = p.z;
+        }
+        for (int d = 0; d < 3; ++d)
+            for (int off = 32; off > 0; off >>= 1) {
+                l3[d] = fminf(l3[d], __shfl_xor(l3[d], off, 64));
+                h3[d] = fmaxf(h3[d], __shfl_xor(h3[d], off, 64));
+            }
+        if (lane == 0) {
+            chunk_aabb[2 * (ubase + k)] = make_float4(l3[0], l3[1], l3[2], 0.f);
+            chunk_aabb[2 * (ubase + k) + 1] = make_float4(h3[0], h3[1], h3[2], 0.f);
+        }
     }
 }
 
@@ -418,6 +487,8 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     MH_TRY(S.sorted.reserve((size_t)(S.n ? S.n : 1) * sizeof(float4)));
     if (S.d_vdw) MH_TRY(S.sorted_vdw.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.aabb.reserve((size_t)ncells * 2 * sizeof(float4)));
+    MH_TRY(S.perm.reserve((size_t)(S.n ? S.n : 1) * 4));
+    MH_TRY(S.chunk_aabb.reserve(((size_t)S.n / 64 + ncells + 1) * 2 * sizeof(float4)));
     MH_HIP(hipMemsetAsync(S.cell_count.p, 0, (size_t)(ncells + 1) * 4, c->stream));
     if (S.n) {
         const unsigned nb = (S.n + 255u) / 256u;
@@ -431,8 +502,9 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.tmp_cell.as<uint32_t>(), S.d_vdw,
                            S.sorted.as<float4>(), S.d_vdw ? S.sorted_vdw.as<float>() : nullptr);
-        hipLaunchKernelGGL(cell_aabb_kernel, dim3((ncells + 3u) / 4u), dim3(256), 0, c->stream, ncells,
-                           S.cell_count.as<uint32_t>(), S.sorted.as<float4>(), S.aabb.as<float4>());
+        hipLaunchKernelGGL(cell_order_kernel, dim3((ncells + 3u) / 4u), dim3(256), 0, c->stream, ncells,
+                           S.cell_count.as<uint32_t>(), S.sorted.as<float4>(), S.aabb.as<float4>(), S.perm.as<uint32_t>(),
+                           S.chunk_aabb.as<float4>());
         MH_HIP(hipGetLastError());
     }
     return 0;
@@ -465,6 +537,8 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.vdwa = c->set[0].sorted_vdw.as<float>();
     P.vdwb = c->set[1].sorted_vdw.as<float>();
     P.aabb_b = two ? c->set[1].aabb.as<float4>() : c->set[0].aabb.as<float4>();
+    P.perm_b = two ? c->set[1].perm.as<uint32_t>() : c->set[0].perm.as<uint32_t>();
+    P.chunk_aabb_b = two ? c->set[1].chunk_aabb.as<float4>() : c->set[0].chunk_aabb.as<float4>();
     P.task_desc = c->task_desc.as<TaskDesc>();
     P.maskbuf = c->maskbuf.as<uint32_t>();
     P.task_moff = c->task_moff.as<unsigned long long>();
