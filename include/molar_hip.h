@@ -235,6 +235,11 @@ int molar_hip_membrane_initial_normals(size_t nlipids, const float *head_markers
                                        const uint64_t *patch_offsets, const uint64_t *patch_ids,
                                        const uint8_t *valid, float *normals_out);
 
+/* Membrane::compute_patches' list building (molar_membrane/src/lib.rs:548-557) from the (i, j) pairs of the
+ * marker search, in pair order: patch_ids[i].push(j); patch_ids[j].push(i).  Host arrays; patch_offsets[K+1],
+ * patch_ids[2*npairs]. */
+int molar_hip_membrane_patches_from_pairs(const uint32_t *pairs, size_t npairs, size_t nlipids,
+                                          uint64_t *patch_offsets, uint64_t *patch_ids);
 /* One iteration of Membrane::smooth (molar_membrane/src/lib.rs:661-812) for all lipids on the GPU: local
  * frame from the lipid's normal (lipid_molecule.rs:190-196), patch markers into that frame through
  * PeriodicBox::shortest_vector, quadric fit (get_quad_coefs :844-863), Voronoi cell of the marker among its patch

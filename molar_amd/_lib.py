@@ -86,6 +86,7 @@ SYMBOLS = {
     "molar_hip_unwrap_simple_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _U8]),
     "molar_hip_membrane_initial_normals": (_I, [_SZ, _P, _P, _P, _P, _P, _P]),
     "molar_hip_membrane_smooth": (_I, [_P, _P, _P, _P]),
+    "molar_hip_membrane_patches_from_pairs": (_I, [_P, _SZ, _SZ, _P, _P]),
     "molar_hip_xtc_open": (_P, [C.c_char_p]),
     "molar_hip_xtc_open_memory": (_P, [_P, _SZ]),
     "molar_hip_xtc_close": (None, [_P]),

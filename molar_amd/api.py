@@ -549,6 +549,15 @@ def new_membrane_state(head_markers, normals, valid=None, npatch_entries=0):
         fitted_patch_points=np.zeros((max(npatch_entries, 1), 3), np.float32))
 
 
+def membrane_patches_from_pairs(pairs, nlipids):
+    """compute_patches' list building (molar_membrane/src/lib.rs:548-557): CSR (offsets, ids) in push order."""
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    off = np.zeros(nlipids + 1, np.uint64)
+    ids = np.zeros(max(2 * len(pairs), 1), np.uint64)
+    check(_lib.load().molar_hip_membrane_patches_from_pairs(pairs.ctypes.data, len(pairs), nlipids, off.ctypes.data, ids.ctypes.data))
+    return off, ids[: 2 * len(pairs)]
+
+
 def membrane_initial_normals(head_markers, tail_markers, patch_offsets, patch_ids, valid=None, normals=None):
     """Membrane::compute_initial_normals (molar_membrane/src/lib.rs:456-505); host arithmetic of the engine."""
     lib = _lib.load()

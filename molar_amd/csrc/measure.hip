@@ -828,15 +828,21 @@ int molar_hip_membrane_initial_normals(size_t K, const float *head, const float 
     struct V { float x, y, z; };
     auto nrm = [](V a) { return std::sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); };
     auto unit = [&](V a) { const float n = nrm(a); return V{a.x / n, a.y / n, a.z / n}; };
-    auto angle = [&](V a, V b) {
-        const float n1 = nrm(a), n2 = nrm(b);
-        if (n1 == 0.0f || n2 == 0.0f) return 0.0f;
-        float cc = ((a.x * b.x + a.y * b.y) + a.z * b.z) / (n1 * n2);
-        cc = cc < -1.0f ? -1.0f : (cc > 1.0f ? 1.0f : cc);
-        return std::acos(cc);
-    };
+    // nalgebra Vector::angle with the two norms handed in: they are functions of one vector each, so computing
+    // them once per lipid instead of once per pair gives the same bits
     const float half_pi = 1.57079632679489661923f;
+    // "angle <= FRAC_PI_2" (lib.rs:472-473, 494).  acos is only evaluated when the cosine is within 1e-6 of zero:
+    // outside that band the comparison cannot depend on how acos rounds (the spacing of f32 near pi/2 is 1.2e-7)
+    auto within_half_pi = [&](V a, float n1, V b, float n2) {
+        if (n1 == 0.0f || n2 == 0.0f) return true;               // Vector::angle returns 0
+        float cc = ((a.x * b.x + a.y * b.y) + a.z * b.z) / (n1 * n2);
+        if (cc > 1.0e-6f) return true;
+        if (cc < -1.0e-6f) return false;
+        cc = cc < -1.0f ? -1.0f : (cc > 1.0f ? 1.0f : cc);       // NaN falls through to acos like the reference
+        return std::acos(cc) <= half_pi;
+    };
     std::vector<V> thv(K), nv(K);
+    std::vector<float> len(K);
     auto ok = [&](size_t i) { return !valid || valid[i]; };
     for (size_t i = 0; i < K; ++i) {
         thv[i] = V{0, 0, 0};
@@ -844,21 +850,45 @@ int molar_hip_membrane_initial_normals(size_t K, const float *head, const float 
         if (ok(i)) thv[i] = unit(V{head[3 * i] - tail[3 * i], head[3 * i + 1] - tail[3 * i + 1], head[3 * i + 2] - tail[3 * i + 2]});
     }
     for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<V> &src = pass == 0 ? thv : nv;   // pass 2 reads normals already updated for l < i
+        for (size_t i = 0; i < K; ++i) len[i] = nrm(src[i]);
         for (size_t i = 0; i < K; ++i) {
             if (!ok(i)) continue;
-            const std::vector<V> &src = pass == 0 ? thv : nv;   // pass 2 reads normals already updated for l < i
             const V self = src[i];
+            const float nself = len[i];
             V sum{0, 0, 0};
             for (uint64_t q = poff[i]; q < poff[i + 1]; ++q) {
                 const V o = src[pids[q]];
-                if (angle(o, self) <= half_pi) { sum.x += o.x; sum.y += o.y; sum.z += o.z; }
+                if (within_half_pi(o, len[pids[q]], self, nself)) { sum.x += o.x; sum.y += o.y; sum.z += o.z; }
             }
             sum.x += self.x; sum.y += self.y; sum.z += self.z;   // .chain(once(central))
             nv[i] = unit(sum);
+            if (pass == 1) len[i] = nrm(nv[i]);                  // src aliases nv in pass 2: keep its norm current
         }
     }
     for (size_t i = 0; i < K; ++i) {
         normals[3 * i] = nv[i].x; normals[3 * i + 1] = nv[i].y; normals[3 * i + 2] = nv[i].z;
+    }
+    return MOLAR_HIP_OK;
+}
+
+// Membrane::compute_patches' list building (molar_membrane/src/lib.rs:548-557): for (i, j) in pair order,
+// patch_ids[i].push(j); patch_ids[j].push(i) - as a CSR over lipid ids (two counting passes, host).
+int molar_hip_membrane_patches_from_pairs(const uint32_t *pairs, size_t npairs, size_t K, uint64_t *patch_offsets,
+                                          uint64_t *patch_ids) {
+    if ((!pairs && npairs) || !patch_offsets || (!patch_ids && npairs))
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "patches_from_pairs: null argument");
+    std::vector<uint64_t> cnt(K + 1, 0);
+    for (size_t p = 0; p < 2 * npairs; ++p) {
+        if (pairs[p] >= K) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "patches_from_pairs: id %u out of range", pairs[p]);
+        cnt[pairs[p] + 1]++;
+    }
+    for (size_t i = 0; i < K; ++i) cnt[i + 1] += cnt[i];
+    std::memcpy(patch_offsets, cnt.data(), (K + 1) * 8);
+    for (size_t p = 0; p < npairs; ++p) {
+        const uint32_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        patch_ids[cnt[i]++] = j;
+        patch_ids[cnt[j]++] = i;
     }
     return MOLAR_HIP_OK;
 }

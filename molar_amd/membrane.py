@@ -199,7 +199,7 @@ class Membrane:
         vidx = np.flatnonzero(self.valid).astype(np.uint64)
         n = e.search_count(api.SEARCH_SINGLE, opt.cutoff, head, idx1=vidx, box=pb, pbc=api.PBC_FULL, ids_local=False)
         pairs, _ = e.search_fill(n)
-        patch_off, patch_ids = self._patch_csr(K, pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64))
+        patch_off, patch_ids = api.membrane_patches_from_pairs(pairs, K)
         normals = api.membrane_initial_normals(head, tail, patch_off, patch_ids, valid=self.valid)
         st = api.new_membrane_state(head, normals, self.valid, len(patch_ids))
         it = 0
