@@ -65,7 +65,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &s : c->set) {
-        for (DevBuf *b : {&s.xyz_stage, &s.idx_stage, &s.vdw_stage, &s.key, &s.cell_count, &s.cursor, &s.tmp_key,
+        for (DevBuf *b : {&s.xyz_stage, &s.idx_stage, &s.vdw_stage, &s.key, &s.cell_count, &s.cnt_pad, &s.cursor, &s.tmp_key,
                           &s.tmp_cell, &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb})
             b->release();
     }

@@ -96,6 +96,7 @@ struct GridSet {
     const float *d_vdw = nullptr;
     DevBuf key;                // u32 per atom: cell<<1 | wrapped, 0xFFFFFFFF = dropped
     DevBuf cell_count;         // u32 [ncells+1] -> scanned in place into cell_start
+    DevBuf cnt_pad;            // cell counters at one per 128-byte line while binning (crowded grids)
     DevBuf cursor;             // u32 per atom: arrival order inside its cell
     DevBuf tmp_key;            // u32 per kept atom (unsorted inside the cell)
     DevBuf tmp_cell;           // u32 per kept atom

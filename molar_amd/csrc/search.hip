@@ -108,15 +108,24 @@ __device__ __forceinline__ V3 load_pos(const float *xyz, uint64_t a) {
     return v3(q[0], q[1], q[2]);
 }
 
+// `counters` holds one counter per cell at stride 1 << pad_shift words: with a few thousand cells and hundreds of
+// atoms per cell, 32 neighbouring counters in one 128-byte line serialise in L2; one counter per line does not.
 __global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restrict__ key,
-                                                  uint32_t *__restrict__ arrival, uint32_t *__restrict__ cell_count) {
+                                                  uint32_t *__restrict__ arrival, uint32_t *__restrict__ counters,
+                                                  uint32_t pad_shift) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= P.n) return;
     const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
     const CellOfAtom c = classify(P, load_pos(P.xyz, a));
     key[k] = c.key;
     // arrival order inside the cell (arbitrary): lets scatter place the atom without a second atomic
-    if (c.key != DROPPED) arrival[k] = atomicAdd(&cell_count[c.key >> 1], 1u);
+    if (c.key != DROPPED) arrival[k] = atomicAdd(&counters[(size_t)(c.key >> 1) << pad_shift], 1u);
+}
+
+__global__ void __launch_bounds__(256) unpad_kernel(uint32_t ncells, const uint32_t *__restrict__ padded, uint32_t pad_shift,
+                                                    uint32_t *__restrict__ cell_count) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c < ncells) cell_count[c] = padded[(size_t)c << pad_shift];
 }
 
 __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t *__restrict__ key,
@@ -492,8 +501,19 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     MH_HIP(hipMemsetAsync(S.cell_count.p, 0, (size_t)(ncells + 1) * 4, c->stream));
     if (S.n) {
         const unsigned nb = (S.n + 255u) / 256u;
+        // one counter per 128-byte line while that stays small (<= 64 MB) and cells are crowded
+        const uint32_t pad_shift = (ncells <= (1u << 19) && (uint64_t)S.n >= 8ull * ncells) ? 5u : 0u;
+        uint32_t *counters = S.cell_count.as<uint32_t>();
+        if (pad_shift) {
+            MH_TRY(S.cnt_pad.reserve(((size_t)ncells << pad_shift) * 4));
+            MH_HIP(hipMemsetAsync(S.cnt_pad.p, 0, ((size_t)ncells << pad_shift) * 4, c->stream));
+            counters = S.cnt_pad.as<uint32_t>();
+        }
         hipLaunchKernelGGL(bin_kernel, dim3(nb), dim3(256), 0, c->stream, P, S.key.as<uint32_t>(),
-                           S.cursor.as<uint32_t>(), S.cell_count.as<uint32_t>());
+                           S.cursor.as<uint32_t>(), counters, pad_shift);
+        if (pad_shift)
+            hipLaunchKernelGGL(unpad_kernel, dim3((ncells + 255u) / 256u), dim3(256), 0, c->stream, ncells, counters, pad_shift,
+                               S.cell_count.as<uint32_t>());
         MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, S.cell_count.as<uint32_t>(), S.cell_count.as<uint32_t>(),
                                                    (uint64_t)ncells + 1)));
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, c->stream, S.n, S.key.as<uint32_t>(),

@@ -1,6 +1,6 @@
 # A/B two builds of the library on the same box: MOLAR_HIP_PLUGIN selects the .so (see molar_amd/_lib.py)
 for i in 1 2 3; do
   for so in "$@"; do
-    MOLAR_HIP_PLUGIN=$so python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_frame']; print('$so', round(d['value'],1), 'count %.3f fill %.3f' % (k['pair_count'], k['pair_fill']))"
+    MOLAR_HIP_PLUGIN=$so python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_frame']; print('$so', round(d['value'],1), 'grid %.3f count %.3f fill %.3f' % (k['grid_build'], k['pair_count'], k['pair_fill']))"
   done
 done
