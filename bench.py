@@ -146,6 +146,7 @@ def main():
     done = [queue.Queue() for _ in range(S)] if overlap else None
 
     def measure_worker(k):
+        torch.cuda.set_device(local_rank)      # the current device is per thread: without this rank r's worker would sync GPU 0
         while True:
             job = jobs[k].get()
             if job is None:
@@ -154,7 +155,7 @@ def main():
                 # the fit moves the selected atoms in place (apply_transform) while the search of the same frame
                 # is reading it on the other stream: work on a copy (12 MB device-to-device)
                 work[k].copy_(job, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
+                torch.cuda.current_stream(device).synchronize()
                 done[k].put(m_engines[k].fit_rmsd_batch(work[k].unsqueeze(0), mass, ref, idx=idx, apply=True))
             except Exception as exc:           # surface failures in the main thread
                 done[k].put(exc)
