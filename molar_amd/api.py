@@ -629,7 +629,14 @@ class Sel:
         if len(index) == 0:
             raise ValueError("selection is empty")                 # sel.rs:13-19
         self.top, self.state, self.index = top, state, index
-        self.engine = engine or default_engine()
+        self._engine = engine
+
+    @property
+    def engine(self):
+        """The GPU context is created on first use, so selections can be built without a device."""
+        if self._engine is None:
+            self._engine = default_engine()
+        return self._engine
 
     def __len__(self):
         return len(self.index)
