@@ -536,3 +536,17 @@ def test_resident_single_round_trip_matches_count_then_fill():
     from molar_amd._lib import MolarHipError
     with pytest.raises(MolarHipError):
         e2.search_resident(a.SEARCH_WITHIN, 0.5, pos, i1, pos, i2, box=box, pbc=7)
+
+
+def test_randomised_differential(monkeypatch):
+    """tools/fuzz_search.py: random boxes / cutoffs / densities / periodicity masks / selections / kinds, count+fill and
+    resident entries, against the oracle - every case bit-identical (9000 cases were run this way in round 1)."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_search.py")
+    spec = importlib.util.spec_from_file_location("fuzz_search", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["fuzz_search.py", "250", "11"])
+    assert mod.main() == 0
