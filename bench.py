@@ -180,12 +180,16 @@ def main():
             th.start()
             workers.append(th)
 
+    # one search description per context, re-pointed at each frame (no per-step argument marshalling)
+    descs = [e.make_search_desc(api.SEARCH_SINGLE, CUTOFF, frames[0], box=box, pbc=7) for e in engines]
+
     def step(e, f):
         k = engines.index(e)
         fr = frames[f % nres]
         if overlap:
             jobs[k].put(fr)
-            cnt, _, _ = e.search_resident(api.SEARCH_SINGLE, CUTOFF, fr, box=box, pbc=7)   # count + scan + fill, one round trip
+            descs[k][0].xyz1 = fr.data_ptr()
+            cnt, _, _ = e.search_resident_desc(descs[k][0])       # count + scan + fill, one round trip
             out = done[k].get()
             if isinstance(out, Exception):
                 raise out

@@ -227,6 +227,17 @@ class Engine:
         self._keep = keep
         return int(cnt.value)
 
+    def make_search_desc(self, kind, cutoff, xyz1, **kw):
+        """A reusable search description for per-frame loops: build once, point `desc.xyz1` (and xyz2) at each new
+        frame (`desc.xyz1 = frame.data_ptr()`), run with search_resident_desc / search_count_desc.  Returns
+        (desc, keepalive)."""
+        return self._search_desc(kind, cutoff, xyz1, **kw)
+
+    def search_resident_desc(self, desc):
+        cnt = C.c_uint64(0); p = C.c_void_p(); dd = C.c_void_p()
+        check(self.lib.molar_hip_search_resident(self.ctx, C.byref(desc), C.byref(cnt), C.byref(p), C.byref(dd)))
+        return int(cnt.value), p.value, dd.value
+
     def search_resident(self, kind, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, vdw1=None,
                         vdw2=None, ids_local=False, lower=None, upper=None):
         """Count + fill into engine-owned device buffers with a single host round trip
