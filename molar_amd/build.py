@@ -14,7 +14,10 @@ SOURCES = ["api.hip", "search.hip", "measure.hip", "membrane.hip", "xtc.hip", "p
 HEADERS = ["common.hpp", "boxmath.hpp", "linalg3.hpp", "pair_kernels.hpp", os.path.join("..", "..", "include", "molar_hip.h")]
 # -ffp-contract=off: MolAR (Rust) never contracts a*b+c; bit-identical neighbour lists need the same
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function",
+         # SLP vectorisation packs the x/z differences of ONE candidate into v_pk_add/v_pk_mul_f32, which issue at
+         # half rate on gfx950 and need extra v_mov to line up their operands
+         "-fno-slp-vectorize"]
 
 
 HASH_FILE = LIB + ".srchash"
