@@ -18,6 +18,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          # SLP vectorisation packs the x/z differences of ONE candidate into v_pk_add/v_pk_mul_f32, which issue at
          # half rate on gfx950 and need extra v_mov to line up their operands
          "-fno-slp-vectorize"]
+# experiments: extra compiler flags, e.g. MOLAR_HIP_EXTRA_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"
+FLAGS += os.environ.get("MOLAR_HIP_EXTRA_FLAGS", "").split()
 
 
 HASH_FILE = LIB + ".srchash"
