@@ -911,6 +911,10 @@ __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__r
                                                    TaskDesc *__restrict__ task_desc, uint32_t *__restrict__ task_mu,
                                                    uint32_t fast_kind) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t == P.ntasks) {                 // terminators of the two exclusive scans (the grid covers ntasks + 1)
+        task_nb[t] = 0u;
+        task_mu[t] = 0u;
+    }
     if (t >= P.ntasks) return;
     const Task T = decode_task<KIND, false>(P, t);
     const uint32_t nb = T.valid ? (T.n1 + T.rps - 1u) / T.rps : 0u;

@@ -779,11 +779,9 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
     {
         Prof prof(c, 0);
-        MH_HIP(hipMemsetAsync(c->task_nb.p, 0, (c->ntasks + 1) * 4, c->stream));
-        MH_HIP(hipMemsetAsync(c->task_mu.p, 0, (c->ntasks + 1) * 4, c->stream));
         MH_HIP(hipMemsetAsync(c->slot_cnt.p, 0, (c->nslots_bound + 1) * 4, c->stream));
         const SearchParams P = make_params(c);
-        const unsigned nb = (unsigned)((c->ntasks + 255) / 256);
+        const unsigned nb = (unsigned)((c->ntasks + 256) / 256);     // ntasks + 1 threads: the last one writes the scan terminators
         switch (c->kind) {
             case MOLAR_HIP_SEARCH_SINGLE:
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
