@@ -122,6 +122,14 @@ __global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restr
     if (c.key != DROPPED) arrival[k] = atomicAdd(&counters[(size_t)(c.key >> 1) << pad_shift], 1u);
 }
 
+// one launch instead of hipMemsetAsync, which splits an unaligned range into up to three fill kernels (~5 us each)
+__global__ void __launch_bounds__(256) zero2_kernel(uint32_t *__restrict__ a, size_t na, uint32_t *__restrict__ b, size_t nb) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * 256u) {
+        if (i < na) a[i] = 0u;
+        else b[i - na] = 0u;
+    }
+}
+
 __global__ void __launch_bounds__(256) unpad_kernel(uint32_t ncells, const uint32_t *__restrict__ padded, uint32_t pad_shift,
                                                     uint32_t *__restrict__ cell_count) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
@@ -498,17 +506,19 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     MH_TRY(S.aabb.reserve((size_t)ncells * 2 * sizeof(float4)));
     MH_TRY(S.perm.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.chunk_aabb.reserve(((size_t)S.n / 64 + ncells + 1) * 2 * sizeof(float4)));
-    MH_HIP(hipMemsetAsync(S.cell_count.p, 0, (size_t)(ncells + 1) * 4, c->stream));
+    // one counter per 128-byte line while that stays small (<= 64 MB) and cells are crowded
+    const uint32_t pad_shift = (S.n && ncells <= (1u << 19) && (uint64_t)S.n >= 8ull * ncells) ? 5u : 0u;
+    const size_t npad = pad_shift ? ((size_t)ncells << pad_shift) : 0;
+    if (pad_shift) MH_TRY(S.cnt_pad.reserve(npad * 4));
+    {
+        const size_t nz = (size_t)ncells + 1 + npad;
+        const unsigned zb = (unsigned)std::min<size_t>((nz + 255) / 256, 2048);
+        hipLaunchKernelGGL(zero2_kernel, dim3(zb), dim3(256), 0, c->stream, S.cell_count.as<uint32_t>(), (size_t)ncells + 1,
+                           S.cnt_pad.as<uint32_t>(), npad);
+    }
     if (S.n) {
         const unsigned nb = (S.n + 255u) / 256u;
-        // one counter per 128-byte line while that stays small (<= 64 MB) and cells are crowded
-        const uint32_t pad_shift = (ncells <= (1u << 19) && (uint64_t)S.n >= 8ull * ncells) ? 5u : 0u;
-        uint32_t *counters = S.cell_count.as<uint32_t>();
-        if (pad_shift) {
-            MH_TRY(S.cnt_pad.reserve(((size_t)ncells << pad_shift) * 4));
-            MH_HIP(hipMemsetAsync(S.cnt_pad.p, 0, ((size_t)ncells << pad_shift) * 4, c->stream));
-            counters = S.cnt_pad.as<uint32_t>();
-        }
+        uint32_t *counters = pad_shift ? S.cnt_pad.as<uint32_t>() : S.cell_count.as<uint32_t>();
         hipLaunchKernelGGL(bin_kernel, dim3(nb), dim3(256), 0, c->stream, P, S.key.as<uint32_t>(),
                            S.cursor.as<uint32_t>(), counters, pad_shift);
         if (pad_shift)
@@ -626,7 +636,8 @@ SearchParams make_params(molar_hip_ctx *c) {
 
 template <bool FILL>
 int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uint32_t hist_nbins = 0, float hmin = 0.f,
-                 float hmax = 0.f, unsigned long long *hist_bins = nullptr, unsigned long long out_cap = ~0ull) {
+                 float hmax = 0.f, unsigned long long *hist_bins = nullptr, unsigned long long out_cap = ~0ull,
+                 bool params_resident = false) {
     Prof prof(c, FILL ? 3 : 1);
     SearchParams P = make_params(c);
     if (P.nblocks == 0) return 0;
@@ -644,7 +655,8 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
         if (P.nblocks > cap) P.nblocks = cap;
     }
     MH_TRY(c->params.reserve(sizeof(SearchParams)));
-    MH_HIP(hipMemcpyAsync(c->params.p, &P, sizeof(SearchParams), hipMemcpyHostToDevice, c->stream));
+    // params_resident: the block uploaded for the previous pass of this search is still valid for this one
+    if (!params_resident) MH_HIP(hipMemcpyAsync(c->params.p, &P, sizeof(SearchParams), hipMemcpyHostToDevice, c->stream));
     const SearchParams *dP = c->params.as<SearchParams>();
     const uint32_t *tf = c->task_nb.as<uint32_t>();
     const uint32_t *st = c->slot_task.as<uint32_t>();
@@ -779,17 +791,18 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
     {
         Prof prof(c, 0);
-        MH_HIP(hipMemsetAsync(c->slot_cnt.p, 0, (c->nslots_bound + 1) * 4, c->stream));
         const SearchParams P = make_params(c);
-        const unsigned nb = (unsigned)((c->ntasks + 256) / 256);     // ntasks + 1 threads: the last one writes the scan terminators
+        // ntasks + 1 threads (the last one writes the scan terminators); the same grid zeroes the slot counters
+        const uint64_t nplan = std::max<uint64_t>(c->ntasks + 1, c->nslots_bound + 1);
+        const unsigned nb = (unsigned)((nplan + 255) / 256);
         switch (c->kind) {
             case MOLAR_HIP_SEARCH_SINGLE:
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
-                                   c->task_mu.as<uint32_t>(), fast_kind);
+                                   c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1);
                 break;
             default:   // the three two-grid kinds decode tasks identically
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
-                                   c->task_mu.as<uint32_t>(), fast_kind);
+                                   c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1);
                 break;
         }
         if (fast_kind)
@@ -912,14 +925,16 @@ int molar_hip_search_resident(molar_hip_ctx *c, const molar_hip_search_desc *q, 
         const unsigned long long a = c->out_pairs.cap / 8u, b = c->out_dist.cap / 4u;
         return a < b ? a : b;
     };
-    MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr));
+    // one parameter block serves both passes: the count pass ignores the output capacity
+    unsigned long long cap0 = out_cap();
+    MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, cap0));
     {
         Prof prof(c, 2);
         MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(),
                                                              c->nslots_bound + 1)));
     }
-    unsigned long long cap0 = out_cap();
-    if (cap0) MH_TRY(launch_pairs<true>(c, c->out_pairs.as<uint2>(), c->out_dist.as<float>(), nullptr, 0, 0.f, 0.f, nullptr, cap0));
+    if (cap0) MH_TRY(launch_pairs<true>(c, c->out_pairs.as<uint2>(), c->out_dist.as<float>(), nullptr, 0, 0.f, 0.f, nullptr, cap0,
+                                        /*params_resident=*/true));
     unsigned long long res[2] = {0, 0};
     MH_TRY(ensure_pinned(c, 16));
     MH_HIP(hipMemcpyAsync(c->h_pinned, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8, hipMemcpyDeviceToHost, c->stream));
