@@ -139,6 +139,7 @@ struct molar_hip_ctx {
     mh::DevBuf slot_cnt;       // u32 per slot (+1): results of the slot
     mh::DevBuf slot_base;      // u64 per slot (+1): output offset (last = grand total)
     mh::DevBuf scan_tmp;       // block sums for the scans
+    mh::DevBuf scan_state;     // ticket + tile descriptors of the single-pass scans (zeroed by the plan kernel)
     mh::DevBuf out_pairs;      // ctx-owned result buffers (device-resident results / host staging)
     mh::DevBuf out_dist;
     mh::DevBuf out_ids;

@@ -909,9 +909,11 @@ __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Ta
 template <int KIND>
 __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__restrict__ task_nb,
                                                    TaskDesc *__restrict__ task_desc, uint32_t *__restrict__ task_mu,
-                                                   uint32_t fast_kind, uint32_t *__restrict__ slot_cnt, uint64_t nslot_cnt) {
+                                                   uint32_t fast_kind, uint32_t *__restrict__ slot_cnt, uint64_t nslot_cnt,
+                                                   unsigned long long *__restrict__ scan_state, uint64_t nstate) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t < nslot_cnt) slot_cnt[t] = 0u;     // the count kernel writes the slots that exist; the scan runs over the bound
+    if (t < nstate) scan_state[t] = 0ull;    // ticket + tile descriptors of this search's look-back scans
     if (t == P.ntasks) {                 // terminators of the two exclusive scans (the grid covers ntasks + 1)
         task_nb[t] = 0u;
         task_mu[t] = 0u;

@@ -311,6 +311,84 @@ __global__ void __launch_bounds__(256) scan_tile_kernel(const TIn *in, TOut *out
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
+// Single-launch exclusive scan (decoupled look-back, Merrill & Garland): tiles take tickets in launch order, publish
+// their aggregate, and resolve their prefix by walking back over the descriptors of earlier tiles.  A descriptor is
+// one 64-bit word: flag in the top two bits (0 not ready, 1 aggregate, 2 inclusive prefix), value below (< 2^62).
+// Scans TWO arrays of the same length at once when in2 != nullptr (task slot counts and task hit-history units).
+// `state` holds 1 ticket word + 2 descriptors per tile and must be zero on entry.
+constexpr unsigned long long LB_MASK = (1ull << 62) - 1ull;
+__device__ __forceinline__ unsigned long long lb_resolve(unsigned long long *desc, uint32_t tile, unsigned long long tot) {
+    if (tile == 0) {
+        __hip_atomic_store(&desc[0], (2ull << 62) | tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return 0ull;
+    }
+    __hip_atomic_store(&desc[tile], (1ull << 62) | tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long run = 0;
+    for (uint32_t t = tile - 1u;; --t) {
+        unsigned long long d;
+        do {
+            d = __hip_atomic_load(&desc[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((d >> 62) == 0ull);
+        run += d & LB_MASK;
+        if ((d >> 62) == 2ull) break;
+    }
+    __hip_atomic_store(&desc[tile], (2ull << 62) | (run + tot), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return run;
+}
+
+template <class TIn1, class TOut1, class TIn2, class TOut2>
+__global__ void __launch_bounds__(256) scan_lookback_kernel(const TIn1 *in1, TOut1 *out1, const TIn2 *in2, TOut2 *out2, uint64_t n,
+                                                            unsigned long long *state, uint32_t ntiles) {
+    __shared__ uint32_t tile_s;
+    __shared__ unsigned long long pre_s[2];
+    if (threadIdx.x == 0) tile_s = atomicAdd(reinterpret_cast<uint32_t *>(state), 1u);
+    __syncthreads();
+    const uint32_t tile = tile_s;
+    unsigned long long *d1 = state + 1, *d2 = state + 1 + ntiles;
+    const uint64_t base = (uint64_t)tile * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    TOut1 a[SCAN_ITEMS];
+    TOut2 b[SCAN_ITEMS];
+    TOut1 sa = 0;
+    TOut2 sb = 0;
+    for (int q = 0; q < SCAN_ITEMS; ++q) {
+        a[q] = base + q < n ? (TOut1)in1[base + q] : (TOut1)0;
+        sa += a[q];
+        b[q] = (in2 && base + q < n) ? (TOut2)in2[base + q] : (TOut2)0;
+        sb += b[q];
+    }
+    TOut1 ta;
+    TOut1 ra = block_exclusive_scan<TOut1>(sa, &ta);
+    TOut2 tb = 0, rb = 0;
+    if (in2) rb = block_exclusive_scan<TOut2>(sb, &tb);
+    if (threadIdx.x == 0) pre_s[0] = lb_resolve(d1, tile, (unsigned long long)ta);
+    if (threadIdx.x == 64 && in2) pre_s[1] = lb_resolve(d2, tile, (unsigned long long)tb);
+    __syncthreads();
+    ra += (TOut1)pre_s[0];
+    if (in2) rb += (TOut2)pre_s[1];
+    for (int q = 0; q < SCAN_ITEMS; ++q) {
+        if (base + q < n) {
+            out1[base + q] = ra;
+            if (in2) out2[base + q] = rb;
+        }
+        ra += a[q];
+        rb += b[q];
+    }
+}
+
+// state words needed by scan_lookback for n elements
+inline size_t lookback_state_words(uint64_t n) { return 1 + 2 * (size_t)((n + SCAN_TILE - 1) / SCAN_TILE); }
+
+template <class TIn1, class TOut1, class TIn2, class TOut2>
+int scan_lookback(molar_hip_ctx *c, const TIn1 *in1, TOut1 *out1, const TIn2 *in2, TOut2 *out2, uint64_t n,
+                  unsigned long long *zeroed_state) {
+    if (n == 0) return 0;
+    const uint32_t ntiles = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL((scan_lookback_kernel<TIn1, TOut1, TIn2, TOut2>), dim3(ntiles), dim3(256), 0, c->stream, in1, out1, in2, out2, n,
+                       zeroed_state, ntiles);
+    MH_HIP(hipGetLastError());
+    return 0;
+}
+
 template <class T>
 __global__ void __launch_bounds__(256) scan_sums_kernel(T *sums, uint64_t nb) {
     __shared__ T carry_s;
@@ -786,28 +864,34 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     MH_TRY(c->slot_task.reserve((c->nslots_bound + 1) * 4));
     MH_TRY(c->slot_cnt.reserve((c->nslots_bound + 1) * 4));
     MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
+    const size_t st_tasks = lookback_state_words(c->ntasks + 1), st_slots = lookback_state_words(c->nslots_bound + 1);
+    MH_TRY(c->scan_state.reserve((st_tasks + st_slots) * 8));
     MH_TRY(c->task_mu.reserve((c->ntasks + 1) * 4));
     MH_TRY(c->task_moff.reserve((c->ntasks + 1) * 8));
     const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
     {
         Prof prof(c, 0);
         const SearchParams P = make_params(c);
-        // ntasks + 1 threads (the last one writes the scan terminators); the same grid zeroes the slot counters
-        const uint64_t nplan = std::max<uint64_t>(c->ntasks + 1, c->nslots_bound + 1);
+        // ntasks + 1 threads (the last one writes the scan terminators); the same grid zeroes the slot counters and the
+        // descriptors of the two look-back scans of this search
+        const uint64_t nplan = std::max<uint64_t>(std::max<uint64_t>(c->ntasks + 1, c->nslots_bound + 1), st_tasks + st_slots);
         const unsigned nb = (unsigned)((nplan + 255) / 256);
         switch (c->kind) {
             case MOLAR_HIP_SEARCH_SINGLE:
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
-                                   c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1);
+                                   c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots));
                 break;
             default:   // the three two-grid kinds decode tasks identically
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
-                                   c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1);
+                                   c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots));
                 break;
         }
-        if (fast_kind)
-            MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->task_mu.as<uint32_t>(), c->task_moff.as<unsigned long long>(), c->ntasks + 1)));
-        MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), c->ntasks + 1)));
+        // slot index of every task and (fast kinds) its first hit-history unit: one single-pass scan over both
+        MH_TRY((scan_lookback<uint32_t, uint32_t, uint32_t, unsigned long long>(
+            c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), fast_kind ? c->task_mu.as<uint32_t>() : nullptr,
+            c->task_moff.as<unsigned long long>(), c->ntasks + 1, c->scan_state.as<unsigned long long>())));
         hipLaunchKernelGGL(slotmap_kernel, dim3(nb), dim3(256), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
                            c->slot_task.as<uint32_t>());
         MH_HIP(hipGetLastError());
@@ -826,8 +910,9 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
 
 int finish_count(molar_hip_ctx *c) {
     Prof *prof = new Prof(c, 2);
-    int rc = (exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(),
-                                                           c->slot_base.as<unsigned long long>(), c->nslots_bound + 1));
+    int rc = (scan_lookback<uint32_t, unsigned long long, uint32_t, unsigned long long>(
+        c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(), nullptr, nullptr, c->nslots_bound + 1,
+        c->scan_state.as<unsigned long long>() + lookback_state_words(c->ntasks + 1)));
     delete prof;
     MH_TRY(rc);
     unsigned long long tot = 0;
@@ -930,8 +1015,9 @@ int molar_hip_search_resident(molar_hip_ctx *c, const molar_hip_search_desc *q, 
     MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, cap0));
     {
         Prof prof(c, 2);
-        MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(),
-                                                             c->nslots_bound + 1)));
+        MH_TRY((scan_lookback<uint32_t, unsigned long long, uint32_t, unsigned long long>(
+            c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(), nullptr, nullptr, c->nslots_bound + 1,
+            c->scan_state.as<unsigned long long>() + lookback_state_words(c->ntasks + 1))));
     }
     if (cap0) MH_TRY(launch_pairs<true>(c, c->out_pairs.as<uint2>(), c->out_dist.as<float>(), nullptr, 0, 0.f, 0.f, nullptr, cap0,
                                         /*params_resident=*/true));
