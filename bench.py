@@ -184,19 +184,28 @@ def main():
     descs = [e.make_search_desc(api.SEARCH_SINGLE, CUTOFF, frames[0], box=box, pbc=7) for e in engines]
 
     def step(e, f):
+        """Enqueue the frame's fit on the measure context, run its search; the fit result is collected by
+        run_steps (it has the whole search to finish in, so nothing waits on it inside the loop)."""
         k = engines.index(e)
         fr = frames[f % nres]
         if overlap:
             jobs[k].put(fr)
             descs[k][0].xyz1 = fr.data_ptr()
             cnt, _, _ = e.search_resident_desc(descs[k][0])       # count + scan + fill, one round trip
+            return cnt, None
+        cnt, _, _ = e.search_resident(api.SEARCH_SINGLE, CUTOFF, fr, box=box, pbc=7)
+        out = e.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
+        return cnt, float(out["rmsd"][0])
+
+    def collect_fits(k, count):
+        """The `count` fit results of context k, in frame order; all of them are part of the timed work."""
+        tot = 0.0
+        for _ in range(count):
             out = done[k].get()
             if isinstance(out, Exception):
                 raise out
-        else:
-            cnt, _, _ = e.search_resident(api.SEARCH_SINGLE, CUTOFF, fr, box=box, pbc=7)
-            out = e.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
-        return cnt, float(out["rmsd"][0])
+            tot += float(out["rmsd"][0])
+        return tot
 
     def barrier():
         if world > 1:
@@ -210,20 +219,25 @@ def main():
         ctypes releases the GIL inside the library)."""
         if S == 1:
             res = [step(eng, first + s) for s in range(count)]
+            rsum = collect_fits(0, count) if overlap else sum(r[1] for r in res)
         else:
             import threading
             res = [None] * count
+            rs = [0.0] * S
 
             def worker(k):
-                for s in range(k, count, S):
+                mine = list(range(k, count, S))
+                for s in mine:
                     res[s] = step(engines[k], first + s)
+                rs[k] = collect_fits(k, len(mine)) if overlap else sum(res[s][1] for s in mine)
 
             th = [threading.Thread(target=worker, args=(k,)) for k in range(S)]
             for t_ in th:
                 t_.start()
             for t_ in th:
                 t_.join()
-        return sum(r[0] for r in res), sum(r[1] for r in res)
+            rsum = sum(rs)
+        return sum(r[0] for r in res), rsum
 
     run_steps(0, W)
     barrier()
