@@ -910,9 +910,9 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
 
 int finish_count(molar_hip_ctx *c) {
     Prof *prof = new Prof(c, 2);
-    int rc = (scan_lookback<uint32_t, unsigned long long, uint32_t, unsigned long long>(
-        c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(), nullptr, nullptr, c->nslots_bound + 1,
-        c->scan_state.as<unsigned long long>() + lookback_state_words(c->ntasks + 1)));
+    // (the look-back scan is slower here: ~140 chained tiles take 43 us against 14 us for the three-kernel scan)
+    int rc = (exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(),
+                                                           c->slot_base.as<unsigned long long>(), c->nslots_bound + 1));
     delete prof;
     MH_TRY(rc);
     unsigned long long tot = 0;
@@ -1015,9 +1015,8 @@ int molar_hip_search_resident(molar_hip_ctx *c, const molar_hip_search_desc *q, 
     MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, cap0));
     {
         Prof prof(c, 2);
-        MH_TRY((scan_lookback<uint32_t, unsigned long long, uint32_t, unsigned long long>(
-            c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(), nullptr, nullptr, c->nslots_bound + 1,
-            c->scan_state.as<unsigned long long>() + lookback_state_words(c->ntasks + 1))));
+        MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(),
+                                                             c->nslots_bound + 1)));
     }
     if (cap0) MH_TRY(launch_pairs<true>(c, c->out_pairs.as<uint2>(), c->out_dist.as<float>(), nullptr, 0, 0.f, 0.f, nullptr, cap0,
                                         /*params_resident=*/true));
