@@ -66,7 +66,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &s : c->set) {
         for (DevBuf *b : {&s.xyz_stage, &s.idx_stage, &s.vdw_stage, &s.key, &s.cell_count, &s.cnt_pad, &s.cursor, &s.tmp_key,
-                          &s.tmp_cell, &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb})
+                          &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb})
             b->release();
     }
     for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_task, &c->slot_cnt, &c->slot_base, &c->scan_tmp, &c->scan_state, &c->out_pairs, &c->out_dist, &c->out_ids,

@@ -99,7 +99,6 @@ struct GridSet {
     DevBuf cnt_pad;            // cell counters at one per 128-byte line while binning (crowded grids)
     DevBuf cursor;             // u32 per atom: arrival order inside its cell
     DevBuf tmp_key;            // u32 per kept atom (unsorted inside the cell)
-    DevBuf tmp_cell;           // u32 per kept atom
     DevBuf sorted;             // float4 {x,y,z,id-bits} in reference cell order
     DevBuf sorted_vdw;         // float per sorted atom (vdw searches)
     DevBuf aabb;               // float4 lo/hi per cell

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) unpad_kernel(uint32_t ncells, const uint3
 __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t *__restrict__ key,
                                                       const uint32_t *__restrict__ cell_start,
                                                       const uint32_t *__restrict__ arrival,
-                                                      uint32_t *__restrict__ tmp_key, uint32_t *__restrict__ tmp_cell) {
+                                                      uint32_t *__restrict__ tmp_key) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= n) return;
     const uint32_t ky = key[k];
@@ -147,57 +147,72 @@ __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t
     const uint32_t cell = ky >> 1;
     const uint32_t pos = cell_start[cell] + arrival[k];
     tmp_key[pos] = ((ky & 1u) << 31) | k;     // sort key inside the cell: in-box first, then input order
-    tmp_cell[pos] = cell;
 }
 
-__global__ void __launch_bounds__(256) place_kernel(BinParams P, uint32_t ncells, int ids_local,
-                                                    const uint32_t *__restrict__ cell_start,
-                                                    const uint32_t *__restrict__ tmp_key,
-                                                    const uint32_t *__restrict__ tmp_cell,
-                                                    const float *__restrict__ vdw, float4 *__restrict__ sorted,
-                                                    float *__restrict__ sorted_vdw) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= cell_start[ncells]) return;
-    const uint32_t mine = tmp_key[t];
-    const uint32_t cell = tmp_cell[t];
-    const uint32_t s = cell_start[cell], e = cell_start[cell + 1];
-    uint32_t rank = 0;
-#pragma unroll 8
-    for (uint32_t q = s; q < e; ++q) rank += tmp_key[q] < mine ? 1u : 0u;   // 8 loads in flight per thread
-    const uint32_t k = mine & 0x7FFFFFFFu;
-    const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
-    const CellOfAtom c = classify(P, load_pos(P.xyz, a));   // same arithmetic as bin_kernel
-    const uint32_t id = ids_local ? k : (uint32_t)a;
-    sorted[s + rank] = make_float4(c.pos.x, c.pos.y, c.pos.z, __uint_as_float(id));
-    if (vdw) sorted_vdw[s + rank] = vdw[k];
-}
-
-// Per cell (one wave each): the axis-aligned bounding box of the stored positions (aabb[2c] = lo, aabb[2c+1] =
-// hi; lets a row of the pair kernels prove "no atom of the other cell can be within the cutoff"), and for cells
-// that fit the register-resident fast path (<= 512 atoms) a SPATIAL order of their atoms for the count pass:
-//   perm[cell_start[c] + m]  = position inside the cell of the m-th atom in Morton order (3 bits per axis of the
-//                              cell's bounding box; LDS counting sort, order inside a key irrelevant),
-//   chunk_aabb[2*u], [2*u+1] = bounding box of the 64 atoms of Morton chunk k, u = (cell_start[c] >> 6) + c + k
-//                              (distinct for all chunks of all cells: a cell owns floor(n/64)+1 >= ceil(n/64) slots).
-// Counting does not depend on the order in which candidates are visited, so the count pass walks compact
-// chunks and skips (row, chunk) pairs by bounding box; the fill pass keeps the reference's order.
+// One wave per cell does everything that depends on the cell's content:
+//  * PLACE: rank of every atom inside the cell segment by (wrapped, input index) - the reference's push order:
+//    in-box atoms in input order, then wrapped atoms (distance_search.rs:180,203-209) - and its record
+//    sorted[s + rank] = {x, y, z, id}.  Cells of <= 512 atoms (everything the register-resident pair path takes)
+//    rank against the keys held in LDS; larger cells loop over global memory.
+//  * the axis-aligned bounding box of the stored positions (aabb[2c] = lo, aabb[2c+1] = hi; lets a row of the pair
+//    kernels prove "no atom of the other cell can be within the cutoff");
+//  * for cells of <= 512 atoms a SPATIAL order of their atoms for the count pass:
+//      perm[cell_start[c] + m]  = position inside the cell of the m-th atom in Morton order (3 bits per axis of
+//                                 the cell's bounding box; LDS counting sort, order inside a key irrelevant),
+//      chunk_aabb[2*u], [2*u+1] = bounding box of the 64 atoms of Morton chunk k, u = (cell_start[c] >> 6) + c + k
+//                                 (distinct for all chunks of all cells: a cell owns floor(n/64)+1 >= ceil(n/64) slots).
+//    Counting does not depend on the order in which candidates are visited, so the count pass walks compact
+//    chunks and skips (row, chunk) pairs by bounding box; the fill pass keeps the reference's order.
 constexpr uint32_t ORDER_MAX = 512;   // = KREG * 64 of the pair kernels
-__global__ void __launch_bounds__(256) cell_order_kernel(uint32_t ncells, const uint32_t *__restrict__ cell_start,
-                                                         const float4 *__restrict__ sorted, float4 *__restrict__ aabb,
-                                                         uint32_t *__restrict__ perm, float4 *__restrict__ chunk_aabb) {
-    __shared__ uint32_t hist_s[4][ORDER_MAX];
+__global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t ncells, int ids_local,
+                                                          const uint32_t *__restrict__ cell_start,
+                                                          const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
+                                                          float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
+                                                          float4 *__restrict__ aabb, uint32_t *__restrict__ perm,
+                                                          float4 *__restrict__ chunk_aabb) {
+    __shared__ uint32_t keys_s[4][ORDER_MAX];     // sort keys of the cell; reused as the Morton histogram
     __shared__ uint32_t kr_s[4][ORDER_MAX];
     __shared__ uint16_t perm_s[4][ORDER_MAX];
+    __shared__ float4 pos_s[4][ORDER_MAX];        // placed records, by rank
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t c = blockIdx.x * 4u + w;
     if (c >= ncells) return;
     const uint32_t s = cell_start[c], e = cell_start[c + 1], n = e - s;
+    const bool small = n <= ORDER_MAX;
+    uint32_t *keys = keys_s[w], *kr = kr_s[w];
+    uint16_t *pl = perm_s[w];
+    float4 *pos = pos_s[w];
+    if (small) {
+        for (uint32_t t = lane; t < n; t += 64u) keys[t] = tmp_key[s + t];
+        __builtin_amdgcn_wave_barrier();
+    }
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t q = s + lane; q < e; q += 64u) {
-        const float4 p = sorted[q];
-        lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
-        lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
-        lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+    for (uint32_t t = lane; t < n; t += 64u) {
+        const uint32_t mine = small ? keys[t] : tmp_key[s + t];
+        uint32_t rank = 0;
+        if (small) {
+            const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+            uint32_t q = 0;
+            for (; q + 4u <= n; q += 4u) {                      // wave-uniform address: one broadcast ds_read_b128
+                const uint4 v = k4[q >> 2];
+                rank += (v.x < mine ? 1u : 0u) + (v.y < mine ? 1u : 0u) + (v.z < mine ? 1u : 0u) + (v.w < mine ? 1u : 0u);
+            }
+            for (; q < n; ++q) rank += keys[q] < mine ? 1u : 0u;
+        } else {
+#pragma unroll 8
+            for (uint32_t q = s; q < e; ++q) rank += tmp_key[q] < mine ? 1u : 0u;
+        }
+        const uint32_t k = mine & 0x7FFFFFFFu;
+        const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
+        const CellOfAtom ca = classify(P, load_pos(P.xyz, a));   // same arithmetic as bin_kernel
+        const uint32_t id = ids_local ? k : (uint32_t)a;
+        const float4 rec = make_float4(ca.pos.x, ca.pos.y, ca.pos.z, __uint_as_float(id));
+        sorted[s + rank] = rec;
+        if (vdw) sorted_vdw[s + rank] = vdw[k];
+        if (small) pos[rank] = rec;
+        lo[0] = fminf(lo[0], rec.x); hi[0] = fmaxf(hi[0], rec.x);
+        lo[1] = fminf(lo[1], rec.y); hi[1] = fmaxf(hi[1], rec.y);
+        lo[2] = fminf(lo[2], rec.z); hi[2] = fmaxf(hi[2], rec.z);
     }
     for (int d = 0; d < 3; ++d)
         for (int off = 32; off > 0; off >>= 1) {
@@ -208,9 +223,9 @@ __global__ void __launch_bounds__(256) cell_order_kernel(uint32_t ncells, const 
         aabb[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f);
         aabb[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
     }
-    if (n == 0 || n > ORDER_MAX || !perm) return;
-    uint32_t *hist = hist_s[w], *kr = kr_s[w];
-    uint16_t *pl = perm_s[w];
+    if (n == 0 || !small) return;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t *hist = keys;                          // the sort keys are no longer needed
     for (uint32_t b = lane; b < ORDER_MAX; b += 64u) hist[b] = 0u;
     __builtin_amdgcn_wave_barrier();
     float sc[3];
@@ -220,7 +235,7 @@ __global__ void __launch_bounds__(256) cell_order_kernel(uint32_t ncells, const 
         return f >= 7.0f ? 7u : (f > 0.0f ? (uint32_t)f : 0u);      // NaN -> 0
     };
     for (uint32_t t = lane; t < n; t += 64u) {
-        const float4 p = sorted[s + t];
+        const float4 p = pos[t];
         const uint32_t x = cell3(p.x, 0), y = cell3(p.y, 1), z = cell3(p.z, 2);
         uint32_t key = 0;
         for (int b = 0; b < 3; ++b) key |= (((x >> b) & 1u) << (3 * b)) | (((y >> b) & 1u) << (3 * b + 1)) | (((z >> b) & 1u) << (3 * b + 2));
@@ -252,7 +267,7 @@ __global__ void __launch_bounds__(256) cell_order_kernel(uint32_t ncells, const 
         if (m < n) {
             const uint32_t t = pl[m];
             perm[s + m] = t;
-            const float4 p = sorted[s + t];
+            const float4 p = pos[t];
             l3[0] = h3[0] = p.x; l3[1] = h3[1] = p.y; l3[2] = h3[2] = p.z;
         }
         for (int d = 0; d < 3; ++d)
@@ -578,7 +593,6 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     MH_TRY(S.cell_count.reserve((size_t)(ncells + 1) * 4));
     MH_TRY(S.cursor.reserve((size_t)(S.n ? S.n : 1) * 4));   // arrival order of each atom in its cell
     MH_TRY(S.tmp_key.reserve((size_t)(S.n ? S.n : 1) * 4));
-    MH_TRY(S.tmp_cell.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.sorted.reserve((size_t)(S.n ? S.n : 1) * sizeof(float4)));
     if (S.d_vdw) MH_TRY(S.sorted_vdw.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.aabb.reserve((size_t)ncells * 2 * sizeof(float4)));
@@ -605,13 +619,10 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, S.cell_count.as<uint32_t>(), S.cell_count.as<uint32_t>(),
                                                    (uint64_t)ncells + 1)));
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, c->stream, S.n, S.key.as<uint32_t>(),
-                           S.cell_count.as<uint32_t>(), S.cursor.as<uint32_t>(), S.tmp_key.as<uint32_t>(),
-                           S.tmp_cell.as<uint32_t>());
-        hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), 0, c->stream, P, ncells, ids_local,
-                           S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.tmp_cell.as<uint32_t>(), S.d_vdw,
-                           S.sorted.as<float4>(), S.d_vdw ? S.sorted_vdw.as<float>() : nullptr);
-        hipLaunchKernelGGL(cell_order_kernel, dim3((ncells + 3u) / 4u), dim3(256), 0, c->stream, ncells,
-                           S.cell_count.as<uint32_t>(), S.sorted.as<float4>(), S.aabb.as<float4>(), S.perm.as<uint32_t>(),
+                           S.cell_count.as<uint32_t>(), S.cursor.as<uint32_t>(), S.tmp_key.as<uint32_t>());
+        hipLaunchKernelGGL(place_order_kernel, dim3((ncells + 3u) / 4u), dim3(256), 0, c->stream, P, ncells, ids_local,
+                           S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
+                           S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<uint32_t>(),
                            S.chunk_aabb.as<float4>());
         MH_HIP(hipGetLastError());
     }
