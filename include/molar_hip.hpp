@@ -452,6 +452,29 @@ inline molar_hip_search_desc desc(int kind, Float cutoff, const SelBound &s1, co
 }
 }  // namespace detail
 
+// Device-resident result of a search (engine extension, no reference counterpart): `count` pairs as (u32 i, u32 j)
+// and f32 distances in engine-owned HIP memory, in the reference's order, valid until the next search on the
+// context; one host round trip per call (molar_hip_search_resident).
+struct ResidentPairs {
+    uint64_t count = 0;
+    const uint32_t *pairs = nullptr;   // device pointer, count x 2
+    const float *dist = nullptr;       // device pointer, count
+};
+inline ResidentPairs distance_search_single_pbc_resident(Float cutoff, const SelBound &data, const PeriodicBox &pbox,
+                                                         PbcDims pbc_dims, bool ids_local = false) {
+    const molar_hip_search_desc d = detail::desc(MOLAR_HIP_SEARCH_SINGLE, cutoff, data, nullptr, ids_local, &pbox, pbc_dims);
+    ResidentPairs r;
+    check(molar_hip_search_resident(data.ctx(), &d, &r.count, &r.pairs, &r.dist));
+    return r;
+}
+inline ResidentPairs distance_search_double_pbc_resident(Float cutoff, const SelBound &d1, const SelBound &d2,
+                                                         const PeriodicBox &pbox, PbcDims pbc_dims, bool ids_local = false) {
+    const molar_hip_search_desc d = detail::desc(MOLAR_HIP_SEARCH_DOUBLE, cutoff, d1, &d2, ids_local, &pbox, pbc_dims);
+    ResidentPairs r;
+    check(molar_hip_search_resident(d1.ctx(), &d, &r.count, &r.pairs, &r.dist));
+    return r;
+}
+
 // ids: the reference takes an iterator; the two uses are the selection's own indices
 // (sel.iter_index(), ids_local = false) and 0..n (modify.rs:78, ids_local = true).
 template <class T>

@@ -163,6 +163,20 @@ static void measure_tests() {
     EXPECT(std::memcmp(moved.data(), cur.coords_ptr(), 12 * n) == 0);           // bit-identical coordinates
     EXPECT(rmsd(cur, ref) < 0.05f);
 
+    // resident result = the host result (one round trip; pairs stay in HBM)
+    {
+        const auto host = distance_search_single_pbc<std::tuple<usize, usize, Float>>(0.6f, cur, cur.require_box(), PBC_FULL);
+        const ResidentPairs rp = distance_search_single_pbc_resident(0.6f, cur, cur.require_box(), PBC_FULL);
+        EXPECT(rp.count == host.size() && rp.pairs != nullptr && rp.dist != nullptr);
+        std::vector<uint32_t> pr(2 * rp.count);
+        std::vector<float> dd(rp.count);
+        EXPECT(molar_hip_search_fill(cur.ctx(), pr.data(), dd.data()) == MOLAR_HIP_OK);     // cached search, host copy
+        bool same = true;
+        for (size_t k = 0; k < host.size(); ++k)
+            same = same && pr[2 * k] == std::get<0>(host[k]) && pr[2 * k + 1] == std::get<1>(host[k]) && dd[k] == std::get<2>(host[k]);
+        EXPECT(same);
+    }
+
     // translate / rotate / principal_transform (modify.rs:16-30, measure.rs:100-109)
     {
         const Pos c0 = cur.center_of_mass();
