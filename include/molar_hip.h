@@ -178,7 +178,9 @@ int molar_hip_search_resident(molar_hip_ctx *ctx, const molar_hip_search_desc *d
                               const uint32_t **d_pairs, const float **d_dist);
 /* Consumer-fused variant: never materialises pairs; every emitted distance d goes through
  * Histogram1D::add_one (molar_membrane/src/stats.rs:29-35): b=floor(n*(d-min)/(max-min)),
- * counted in integers (bins: uint64[nbins], accumulated INTO, so frames can be summed). */
+ * counted in integers (bins: uint64[nbins], accumulated INTO, so frames can be summed).  With `bins` in device
+ * memory the sum stays on the GPU, and with out_count == NULL the call returns without waiting for the kernels
+ * (frames of a trajectory queue up back to back; molar_hip_synchronize before reading the bins). */
 int molar_hip_search_histogram(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, float hmin,
                                float hmax, size_t nbins, uint64_t *bins, uint64_t *out_count);
 

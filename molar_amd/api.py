@@ -281,10 +281,12 @@ class Engine:
         return tuple(int(x) for x in dims)
 
     def search_histogram(self, kind, cutoff, hmin, hmax, nbins, xyz1, idx1=None, xyz2=None, idx2=None, box=None,
-                         pbc=0, vdw1=None, vdw2=None, bins=None):
+                         pbc=0, vdw1=None, vdw2=None, bins=None, want_count=True):
         """Consumer-fused search: every emitted distance goes through Histogram1D::add_one
-        (molar_membrane/src/stats.rs:29-35); pairs are never materialised.  `bins` (uint64[nbins]) is
-        accumulated into, so frames can be summed.  Returns (bins, number_of_pairs)."""
+        (molar_membrane/src/stats.rs:29-35); pairs are never materialised.  `bins` (uint64[nbins], numpy or a torch
+        int64 CUDA tensor) is accumulated into, so frames can be summed.  Returns (bins, number_of_pairs).  With
+        device-resident bins and want_count=False the call does not wait for the GPU (count is returned as None):
+        the frames of a trajectory queue up back to back; synchronize() before reading the bins."""
         xyz1 = _f32(xyz1); xyz2 = _f32(xyz2); idx1 = _u64(idx1); idx2 = _u64(idx2)
         vdw1 = _f32(vdw1); vdw2 = _f32(vdw2)
         d = SearchDesc()
@@ -308,9 +310,11 @@ class Engine:
         if bins is None:
             bins = np.zeros(nbins, np.uint64)
         cnt = C.c_uint64(0)
+        ba_, kb_ = _addr(bins)
         check(self.lib.molar_hip_search_histogram(self.ctx, C.byref(d), float(hmin), float(hmax), nbins,
-                                                  bins.ctypes.data, C.byref(cnt)))
-        return bins, int(cnt.value)
+                                                  ba_, C.byref(cnt) if want_count else None))
+        self._keep = keep
+        return bins, (int(cnt.value) if want_count else None)
 
     # ------------------------------------------------------------ measure
     def _sel_args(self, xyz, idx):

@@ -130,6 +130,12 @@ __global__ void __launch_bounds__(256) zero2_kernel(uint32_t *__restrict__ a, si
     }
 }
 
+__global__ void __launch_bounds__(256) add_u64_kernel(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src,
+                                                      size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 __global__ void __launch_bounds__(256) unpad_kernel(uint32_t ncells, const uint32_t *__restrict__ padded, uint32_t pad_shift,
                                                     uint32_t *__restrict__ cell_count) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
@@ -1135,23 +1141,29 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
     if (q->kind == MOLAR_HIP_SEARCH_WITHIN)
         return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_histogram: a within search has no distances");
     if (nbins == 0 || nbins > 8192) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_histogram: nbins must be in 1..8192");
-    MH_TRY(prepare_search(c, q));
+    MH_TRY(prepare_search(c, q, /*size_masks=*/false));     // the fused pass records no hit bits
     if (out_count) *out_count = 0;
     if (c->have_search) return MOLAR_HIP_OK;     // degenerate (empty vdw input)
     // single pass: no counts, no offsets - every emitted distance goes straight into the histogram
     MH_TRY(c->hist.reserve((nbins + 1) * 8));
-    MH_HIP(hipMemsetAsync(c->hist.p, 0, (nbins + 1) * 8, c->stream));
+    hipLaunchKernelGGL(zero2_kernel, dim3(1), dim3(256), 0, c->stream, c->hist.as<uint32_t>(), (nbins + 1) * 2, (uint32_t *)nullptr,
+                       (size_t)0);
     MH_TRY(launch_pairs<true>(c, nullptr, nullptr, nullptr, (uint32_t)nbins, hmin, hmax, c->hist.as<unsigned long long>()));
+    if (is_device_ptr(bins)) {
+        // device-resident accumulator: added on the GPU; without out_count the call does not wait for the kernels
+        hipLaunchKernelGGL(add_u64_kernel, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, c->stream,
+                           reinterpret_cast<unsigned long long *>(bins), c->hist.as<unsigned long long>(), nbins);
+        MH_HIP(hipGetLastError());
+        if (out_count) {
+            unsigned long long tot = 0;
+            MH_TRY(read_back(c, &tot, c->hist.as<unsigned long long>() + nbins, 8));
+            *out_count = tot;
+        }
+        return MOLAR_HIP_OK;
+    }
     std::vector<unsigned long long> h(nbins + 1);
     MH_TRY(read_back(c, h.data(), c->hist.p, (nbins + 1) * 8));
-    if (is_device_ptr(bins)) {
-        std::vector<unsigned long long> cur(nbins);
-        MH_HIP(hipMemcpy(cur.data(), bins, nbins * 8, hipMemcpyDeviceToHost));
-        for (size_t b = 0; b < nbins; ++b) cur[b] += h[b];
-        MH_HIP(hipMemcpy(bins, cur.data(), nbins * 8, hipMemcpyHostToDevice));
-    } else {
-        for (size_t b = 0; b < nbins; ++b) bins[b] += h[b];
-    }
+    for (size_t b = 0; b < nbins; ++b) bins[b] += h[b];
     if (out_count) *out_count = h[nbins];
     return MOLAR_HIP_OK;
 }

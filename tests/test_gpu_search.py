@@ -550,3 +550,29 @@ def test_randomised_differential(monkeypatch):
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, "argv", ["fuzz_search.py", "250", "11"])
     assert mod.main() == 0
+
+
+def test_histogram_device_bins_async(eng):
+    """Device-resident bins, no per-frame round trip: several frames queued back to back give the same integer bins
+    as the host-bins path."""
+    import torch
+    a = api()
+    n = 20000
+    box = synth.box_a(n)
+    frames = [synth.frame(n, box, f) for f in range(4)]
+    hb = np.zeros(300, np.uint64)
+    tot = 0
+    for f in frames:
+        hb, c = eng.search_histogram(a.SEARCH_SINGLE, 0.9, 0.0, 0.9, 300, f, box=box, pbc=7, bins=hb)
+        tot += c
+    db = torch.zeros(300, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    dev_frames = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+    for f in dev_frames[:-1]:
+        _, c = eng.search_histogram(a.SEARCH_SINGLE, 0.9, 0.0, 0.9, 300, f, box=box, pbc=7, bins=db, want_count=False)
+        assert c is None
+    _, c_last = eng.search_histogram(a.SEARCH_SINGLE, 0.9, 0.0, 0.9, 300, dev_frames[-1], box=box, pbc=7, bins=db)
+    eng.synchronize()
+    assert np.array_equal(db.cpu().numpy().astype(np.uint64), hb)
+    assert 0 < int(hb.sum()) <= tot and c_last > 0          # a distance equal to the upper edge falls outside the last bin
