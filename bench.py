@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MOLAR_BENCH_STREAMS", "1")),
                     help="engine contexts (HIP streams) per GPU working on different frames concurrently; 2 gives ~5 %% more "
                          "frames/s but overlapping launches make the per-kernel event times (roofline) meaningless, so 1 is the default")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one search at a time (molar_hip_search_resident) instead of the begin/end form that keeps two "
+                         "frames queued on the engine's stream (kernels still run one after the other, in order)")
     args = ap.parse_args()
 
     import torch
@@ -181,7 +184,9 @@ def main():
             workers.append(th)
 
     # one search description per context, re-pointed at each frame (no per-step argument marshalling)
-    descs = [e.make_search_desc(api.SEARCH_SINGLE, CUTOFF, frames[0], box=box, pbc=7) for e in engines]
+    # (two per context: the begin/end form keeps the description of a frame alive until its result is collected)
+    descs = [[e.make_search_desc(api.SEARCH_SINGLE, CUTOFF, frames[0], box=box, pbc=7) for _ in range(2)] for e in engines]
+    pipelined = not args.no_pipeline
 
     def step(e, f):
         """Enqueue the frame's fit on the measure context, run its search; the fit result is collected by
@@ -190,8 +195,8 @@ def main():
         fr = frames[f % nres]
         if overlap:
             jobs[k].put(fr)
-            descs[k][0].xyz1 = fr.data_ptr()
-            cnt, _, _ = e.search_resident_desc(descs[k][0])       # count + scan + fill, one round trip
+            descs[k][0][0].xyz1 = fr.data_ptr()
+            cnt, _, _ = e.search_resident_desc(descs[k][0][0])       # count + scan + fill, one round trip
             return cnt, None
         cnt, _, _ = e.search_resident(api.SEARCH_SINGLE, CUTOFF, fr, box=box, pbc=7)
         out = e.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
@@ -214,10 +219,32 @@ def main():
             e.synchronize()
         torch.cuda.synchronize()
 
+    fits = []
+
     def run_steps(first, count):
         """`count` steps starting at frame `first`, dealt round-robin to the S contexts (one host thread each;
         ctypes releases the GIL inside the library)."""
-        if S == 1:
+        if S == 1 and pipelined:
+            # frame s+1 is enqueued (grid, plan, count, scan, fill: ~15 launches) before the result of frame s is
+            # waited for, so the stream never runs dry between frames; every frame is begun AND ended in here
+            res, prev = [], None
+            for s in range(count):
+                fr = frames[(first + s) % nres]
+                if overlap:
+                    jobs[0].put(fr)
+                d = descs[0][s & 1][0]
+                d.xyz1 = fr.data_ptr()
+                t = eng.search_resident_begin(d)
+                if prev is not None:
+                    res.append((eng.search_resident_end(prev)[0], None))
+                prev = t
+                if not overlap:      # the fit of frame s runs behind its search on the same stream
+                    out = eng.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
+                    fits.append(float(out["rmsd"][0]))
+            if prev is not None:
+                res.append((eng.search_resident_end(prev)[0], None))
+            rsum = collect_fits(0, count) if overlap else sum(fits[-count:])
+        elif S == 1:
             res = [step(eng, first + s) for s in range(count)]
             rsum = collect_fits(0, count) if overlap else sum(r[1] for r in res)
         else:
@@ -296,6 +323,7 @@ def main():
                 "selection_atoms": int(len(idx_np)), "frames_per_gpu": K,
                 "parallelism": f"frames sharded over {world} rank(s), no data-path collective",
                 "streams_per_gpu": S * (2 if overlap else 1),
+                "frames_in_flight_per_stream": 2 if (S == 1 and pipelined) else 1,
                 "measure_overlapped_with_search": overlap,
             },
             "kernel_ms_per_frame": {k: v[0] / K for k, v in prof.items()},

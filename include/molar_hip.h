@@ -176,6 +176,18 @@ int molar_hip_search_fill_device(molar_hip_ctx *ctx, const uint32_t **d_pairs, c
  * variants.  Not for WITHIN (ids, not pairs). */
 int molar_hip_search_resident(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_count,
                               const uint32_t **d_pairs, const float **d_dist);
+/* The same search split in two so that a per-frame loop never leaves the GPU idle: _begin enqueues everything for
+ * one frame and returns at once with a ticket (0 or 1); _end waits for that frame only and returns its result.
+ * Two searches may be in flight, each with its own result set, so the loop is
+ *     begin(frame k+1); end(frame k); consume k; ...
+ * and the host work of frame k+1 (and the result round trip of frame k) hides behind the kernels of frame k.
+ * The kernels still run in order on the context's one stream.  A frame that outgrows a buffer is repeated inside
+ * _end (after the younger search has drained), so `desc` and everything it points to must stay valid until _end.
+ * A result set is valid until the second _begin after the one that produced it.  Errors: both sets in flight
+ * (_begin), unknown or already finished ticket (_end). */
+int molar_hip_search_resident_begin(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, int32_t *ticket);
+int molar_hip_search_resident_end(molar_hip_ctx *ctx, int32_t ticket, uint64_t *out_count, const uint32_t **d_pairs,
+                                  const float **d_dist);
 /* Consumer-fused variant: never materialises pairs; every emitted distance d goes through
  * Histogram1D::add_one (molar_membrane/src/stats.rs:29-35): b=floor(n*(d-min)/(max-min)),
  * counted in integers (bins: uint64[nbins], accumulated INTO, so frames can be summed).  With `bins` in device

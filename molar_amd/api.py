@@ -238,6 +238,19 @@ class Engine:
         check(self.lib.molar_hip_search_resident(self.ctx, C.byref(desc), C.byref(cnt), C.byref(p), C.byref(dd)))
         return int(cnt.value), p.value, dd.value
 
+    def search_resident_begin(self, desc):
+        """Enqueue a whole resident search and return its ticket without waiting (molar_hip_search_resident_begin).
+        `desc` (and what it points to) must stay alive and unchanged until search_resident_end(ticket)."""
+        t = C.c_int32(-1)
+        check(self.lib.molar_hip_search_resident_begin(self.ctx, C.byref(desc), C.byref(t)))
+        return int(t.value)
+
+    def search_resident_end(self, ticket):
+        """Wait for the search behind `ticket`; returns (count, pairs_device_address, dist_device_address)."""
+        cnt = C.c_uint64(0); p = C.c_void_p(); dd = C.c_void_p()
+        check(self.lib.molar_hip_search_resident_end(self.ctx, C.c_int32(ticket), C.byref(cnt), C.byref(p), C.byref(dd)))
+        return int(cnt.value), p.value, dd.value
+
     def search_resident(self, kind, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, vdw1=None,
                         vdw2=None, ids_local=False, lower=None, upper=None):
         """Count + fill into engine-owned device buffers with a single host round trip

@@ -139,8 +139,20 @@ struct molar_hip_ctx {
     mh::DevBuf slot_base;      // u64 per slot (+1): output offset (last = grand total)
     mh::DevBuf scan_tmp;       // block sums for the scans
     mh::DevBuf scan_state;     // ticket + tile descriptors of the single-pass scans (zeroed by the plan kernel)
-    mh::DevBuf out_pairs;      // ctx-owned result buffers (device-resident results / host staging)
-    mh::DevBuf out_dist;
+    mh::DevBuf out_pairs_set[2];   // ctx-owned result buffers (device-resident results / host staging); the second
+    mh::DevBuf out_dist_set[2];    // set exists for the pipelined begin/end searches only
+    mh::DevBuf &out_pairs = out_pairs_set[0];
+    mh::DevBuf &out_dist = out_dist_set[0];
+    // pipelined resident searches (molar_hip_search_resident_begin/_end): two result sets, two tickets
+    struct Ticket {
+        bool pending = false, degenerate = false;
+        unsigned long long cap0 = 0, maskcap0 = 0, serial = 0;
+        hipEvent_t done = nullptr;
+        molar_hip_search_desc desc{};
+    } tickets[2];
+    int next_ticket = 0;
+    unsigned long long search_serial = 0;   // counts resident searches enqueued on this context
+    void *h_sizes = nullptr;                // pinned: 16 bytes of result sizes per ticket
     mh::DevBuf out_ids;
     mh::DevBuf wide_i, wide_j; // usize widening
     mh::DevBuf hist;           // u64 bins

@@ -560,6 +560,14 @@ __global__ void __launch_bounds__(256) widen_ids_kernel(const uint32_t *__restri
         out[k] = ids[k];
 }
 
+// The parameter block of the pair kernels travels as a kernel argument and is written to device memory by the
+// GPU itself (read straight from the kernarg segment: no by-value struct indexing, no scratch copy).
+__global__ void upload_params_kernel(SearchParams P, SearchParams *dst) {
+    const uint32_t *src = (const uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t *d = (uint32_t *)dst;
+    for (uint32_t t = threadIdx.x; t < (uint32_t)(sizeof(SearchParams) / 4u); t += blockDim.x) d[t] = src[t];
+}
+
 // ================================================================= host orchestration
 
 // Grid::from_cutoff_and_extents (distance_search.rs:103-110)
@@ -751,7 +759,10 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     }
     MH_TRY(c->params.reserve(sizeof(SearchParams)));
     // params_resident: the block uploaded for the previous pass of this search is still valid for this one
-    if (!params_resident) MH_HIP(hipMemcpyAsync(c->params.p, &P, sizeof(SearchParams), hipMemcpyHostToDevice, c->stream));
+    // (a kernel argument, not a copy from pageable memory: the latter makes the host wait for the stream to drain,
+    // which would serialise the begin/end pipelining of molar_hip_search_resident_begin)
+    if (!params_resident)
+        hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, c->stream, P, c->params.as<SearchParams>());
     const SearchParams *dP = c->params.as<SearchParams>();
     const uint32_t *tf = c->task_nb.as<uint32_t>();
     const uint32_t *st = c->slot_task.as<uint32_t>();
@@ -1008,60 +1019,154 @@ int molar_hip_search_fill_device(molar_hip_ctx *c, const uint32_t **d_pairs, con
     return MOLAR_HIP_OK;
 }
 
-int molar_hip_search_resident(molar_hip_ctx *c, const molar_hip_search_desc *q, uint64_t *out_count,
-                              const uint32_t **d_pairs, const float **d_dist) {
+// Enqueue one whole resident search (grid, plan, count, offset scan, fill into outP/outD against their present
+// capacity) and the async read-back of its two sizes into `sizes` (pinned, 16 bytes).  No host wait.
+struct ResidentLaunch {
+    unsigned long long cap0 = 0;      // result capacity the fill pass was launched with (0: the fill was skipped)
+    unsigned long long maskcap0 = 0;  // hit-history units the count pass could record
+    bool degenerate = false;          // empty vdw input: nothing was enqueued, the result is empty
+};
+
+static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::DevBuf &outP, mh::DevBuf &outD,
+                            void *sizes, ResidentLaunch *L) {
     if (q && q->kind == MOLAR_HIP_SEARCH_WITHIN)
         return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within search yields ids: use molar_hip_search_count + fill_ids");
     MH_TRY(prepare_search(c, q, /*size_masks=*/false));
-    if (c->have_search) {   // degenerate (empty vdw input)
-        if (out_count) *out_count = 0;
-        if (d_pairs) *d_pairs = c->out_pairs.as<uint32_t>();
-        if (d_dist) *d_dist = c->out_dist.as<float>();
-        return MOLAR_HIP_OK;
-    }
-    // Count, scan and fill are enqueued back to back against the capacities left by earlier frames; one
-    // read-back tells whether the hit-bit buffer or the result buffers were too small, in which case they grow
-    // and the affected passes run again (first frame of a trajectory; later frames are the same size +- noise).
+    ++c->search_serial;
+    *L = ResidentLaunch{};
+    L->degenerate = c->have_search;
+    if (L->degenerate) return 0;
     const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
-    auto out_cap = [&]() -> unsigned long long {
-        const unsigned long long a = c->out_pairs.cap / 8u, b = c->out_dist.cap / 4u;
-        return a < b ? a : b;
-    };
+    const unsigned long long a = outP.cap / 8u, b = outD.cap / 4u;
+    const unsigned long long cap0 = a < b ? a : b;
+    L->maskcap0 = c->maskbuf.cap / 256u;
     // one parameter block serves both passes: the count pass ignores the output capacity
-    unsigned long long cap0 = out_cap();
     MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, cap0));
     {
         Prof prof(c, 2);
         MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(),
                                                              c->nslots_bound + 1)));
     }
-    if (cap0) MH_TRY(launch_pairs<true>(c, c->out_pairs.as<uint2>(), c->out_dist.as<float>(), nullptr, 0, 0.f, 0.f, nullptr, cap0,
+    if (cap0) MH_TRY(launch_pairs<true>(c, outP.as<uint2>(), outD.as<float>(), nullptr, 0, 0.f, 0.f, nullptr, cap0,
                                         /*params_resident=*/true));
-    unsigned long long res[2] = {0, 0};
-    MH_TRY(ensure_pinned(c, 16));
-    MH_HIP(hipMemcpyAsync(c->h_pinned, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipMemcpyAsync(sizes, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8, hipMemcpyDeviceToHost, c->stream));
     if (fast_kind)
-        MH_HIP(hipMemcpyAsync((char *)c->h_pinned + 8, c->task_moff.as<unsigned long long>() + c->ntasks, 8, hipMemcpyDeviceToHost, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
-    std::memcpy(res, c->h_pinned, 16);
+        MH_HIP(hipMemcpyAsync((char *)sizes + 8, c->task_moff.as<unsigned long long>() + c->ntasks, 8, hipMemcpyDeviceToHost, c->stream));
+    L->cap0 = cap0;
+    return 0;
+}
+
+// With `sizes` delivered and the search still the context's cached one: grow what was too small and repeat the
+// affected passes (first frame of a trajectory; later frames are the same size +- noise).
+static int resident_settle(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD, const void *sizes, const ResidentLaunch &L) {
+    const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
+    unsigned long long res[2] = {0, 0};
+    std::memcpy(res, sizes, 16);
     c->total = res[0];
     c->mask_units = fast_kind ? res[1] : 0;
     c->have_search = true;
-    bool refill = cap0 == 0 && c->total != 0;
-    if (c->mask_units > c->maskbuf.cap / 256u) {        // hit bits did not fit: grow, record them, fill again
-        MH_TRY(c->maskbuf.reserve((size_t)(c->mask_units + c->mask_units / 4u) * 256u + 256u));
+    bool refill = L.cap0 == 0 && c->total != 0;
+    if (c->mask_units > L.maskcap0) {        // hit bits did not fit: grow, record them, fill again
+        if (c->mask_units > c->maskbuf.cap / 256u)
+            MH_TRY(c->maskbuf.reserve((size_t)(c->mask_units + c->mask_units / 4u) * 256u + 256u));
         MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr));
         refill = true;
     }
-    if (c->total > cap0) {
-        MH_TRY(c->out_pairs.reserve((size_t)(c->total + c->total / 16u) * 8));
-        MH_TRY(c->out_dist.reserve((size_t)(c->total + c->total / 16u) * 4));
+    if (c->total > L.cap0) {
+        MH_TRY(outP.reserve((size_t)(c->total + c->total / 16u) * 8));
+        MH_TRY(outD.reserve((size_t)(c->total + c->total / 16u) * 4));
         refill = true;
     }
-    if (refill && c->total) MH_TRY(launch_pairs<true>(c, c->out_pairs.as<uint2>(), c->out_dist.as<float>(), nullptr));
+    if (refill && c->total) MH_TRY(launch_pairs<true>(c, outP.as<uint2>(), outD.as<float>(), nullptr));
+    return 0;
+}
+
+int molar_hip_search_resident(molar_hip_ctx *c, const molar_hip_search_desc *q, uint64_t *out_count,
+                              const uint32_t **d_pairs, const float **d_dist) {
+    if (!c) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: null argument");
+    // Count, scan and fill are enqueued back to back against the capacities left by earlier frames; one
+    // read-back tells whether the hit-bit buffer or the result buffers were too small.
+    MH_TRY(ensure_pinned(c, 64));
+    ResidentLaunch L;
+    MH_TRY(resident_enqueue(c, q, c->out_pairs, c->out_dist, c->h_pinned, &L));
+    if (!L.degenerate) {
+        MH_HIP(hipStreamSynchronize(c->stream));
+        MH_TRY(resident_settle(c, c->out_pairs, c->out_dist, c->h_pinned, L));
+    }
     if (out_count) *out_count = c->total;
     if (d_pairs) *d_pairs = c->out_pairs.as<uint32_t>();
     if (d_dist) *d_dist = c->out_dist.as<float>();
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_desc *q, int32_t *ticket) {
+    if (!c || !q || !ticket) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: null argument");
+    const int slot = c->next_ticket & 1;
+    molar_hip_ctx::Ticket &T = c->tickets[slot];
+    if (T.pending)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "both result sets are in flight: call molar_hip_search_resident_end first");
+    MH_HIP(hipSetDevice(c->device));
+    if (!c->h_sizes) MH_HIP(hipHostMalloc(&c->h_sizes, 64, hipHostMallocDefault));
+    if (!T.done) MH_HIP(hipEventCreateWithFlags(&T.done, hipEventDisableTiming));
+    T.desc = *q;
+    ResidentLaunch L;
+    MH_TRY(resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 16 * slot, &L));
+    MH_HIP(hipEventRecord(T.done, c->stream));
+    T.cap0 = L.cap0;
+    T.maskcap0 = L.maskcap0;
+    T.degenerate = L.degenerate;
+    T.serial = c->search_serial;
+    T.pending = true;
+    c->next_ticket ^= 1;
+    *ticket = slot;
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *out_count, const uint32_t **d_pairs,
+                                  const float **d_dist) {
+    if (!c || ticket < 0 || ticket > 1 || !c->tickets[ticket].pending)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: no pipelined search with ticket %d", (int)ticket);
+    molar_hip_ctx::Ticket &T = c->tickets[ticket];
+    mh::DevBuf &outP = c->out_pairs_set[ticket];
+    mh::DevBuf &outD = c->out_dist_set[ticket];
+    T.pending = false;
+    MH_HIP(hipSetDevice(c->device));
+    uint64_t total = 0;
+    if (!T.degenerate) {
+        MH_HIP(hipEventSynchronize(T.done));
+        const void *sizes = (const char *)c->h_sizes + 16 * ticket;
+        unsigned long long res[2];
+        std::memcpy(res, sizes, 16);
+        const bool fast_kind = T.desc.kind == MOLAR_HIP_SEARCH_SINGLE || T.desc.kind == MOLAR_HIP_SEARCH_DOUBLE;
+        total = res[0];
+        if (res[0] > T.cap0 || (fast_kind && res[1] > T.maskcap0)) {
+            // A buffer was too small (first frames of a trajectory).  Let everything in flight finish - a younger
+            // search owns the context's intermediate buffers by now, its results sit in the other result set - then
+            // grow and repeat: the affected passes if this is still the context's cached search, else the frame.
+            MH_HIP(hipStreamSynchronize(c->stream));
+            ResidentLaunch L;
+            L.cap0 = T.cap0;
+            L.maskcap0 = T.maskcap0;
+            if (T.serial != c->search_serial) {
+                if (fast_kind && res[1] > c->maskbuf.cap / 256u)
+                    MH_TRY(c->maskbuf.reserve((size_t)(res[1] + res[1] / 4u) * 256u + 256u));
+                if (res[0] > T.cap0) {
+                    MH_TRY(outP.reserve((size_t)(res[0] + res[0] / 16u) * 8));
+                    MH_TRY(outD.reserve((size_t)(res[0] + res[0] / 16u) * 4));
+                }
+                MH_TRY(ensure_pinned(c, 64));
+                MH_TRY(resident_enqueue(c, &T.desc, outP, outD, c->h_pinned, &L));
+                MH_HIP(hipStreamSynchronize(c->stream));
+                sizes = c->h_pinned;
+            }
+            MH_TRY(resident_settle(c, outP, outD, sizes, L));
+            MH_HIP(hipStreamSynchronize(c->stream));
+            total = c->total;
+        }
+    }
+    if (out_count) *out_count = total;
+    if (d_pairs) *d_pairs = outP.as<uint32_t>();
+    if (d_dist) *d_dist = outD.as<float>();
     return MOLAR_HIP_OK;
 }
 

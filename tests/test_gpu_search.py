@@ -538,6 +538,60 @@ def test_resident_single_round_trip_matches_count_then_fill():
         e2.search_resident(a.SEARCH_WITHIN, 0.5, pos, i1, pos, i2, box=box, pbc=7)
 
 
+def test_resident_pipelined_begin_end_matches_the_plain_call():
+    """molar_hip_search_resident_begin/_end: two frames in flight on one stream, results per ticket equal to
+    count + fill - through the repeat logic (fresh context: the first frames outgrow every buffer while a
+    younger search is already queued), with frames that grow and shrink, and the misuse errors."""
+    import torch
+    a = api()
+    from molar_amd.api import Engine
+    from molar_amd._lib import MolarHipError
+    e1, e2 = Engine(0), Engine(0)
+
+    class Dev:
+        def __init__(self, ptr, n, typestr):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+    cases = [(3000, synth.box_a, 0.5), (3000, synth.box_a, 0.5), (20000, synth.box_a, 0.7), (5000, synth.box_b, 0.6),
+             (20000, synth.box_a, 0.7), (21000, synth.box_a, 0.72), (4000, synth.box_ortho, 0.45), (20000, synth.box_a, 0.7)]
+    frames, want = [], []
+    for k, (n, boxfn, rc) in enumerate(cases):
+        box = boxfn(n)
+        pos = torch.from_numpy(synth.frame(n, box, k, sigma=0.08)).cuda()
+        frames.append((pos, box, rc))
+        wn = e1.search_count(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+        want.append((wn,) + e1.search_fill(wn))
+    descs = [e2.make_search_desc(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7) for pos, box, rc in frames]
+
+    def check(k, res):
+        cnt, pp, dp = res
+        wn, wp, wd = want[k]
+        assert cnt == wn > 0
+        got_pairs = torch.as_tensor(Dev(pp, cnt * 2, "<i4"), device="cuda").cpu().numpy().view(np.uint32).reshape(-1, 2)
+        got_dist = torch.as_tensor(Dev(dp, cnt, "<f4"), device="cuda").cpu().numpy()
+        assert np.array_equal(got_pairs, wp) and np.array_equal(got_dist, wd), f"frame {k}"
+
+    for rounds in range(2):          # second round: every buffer already large enough (no repeats)
+        prev = None
+        for k in range(len(frames)):
+            t = e2.search_resident_begin(descs[k][0])
+            if prev is not None:
+                check(prev[0], e2.search_resident_end(prev[1]))
+            prev = (k, t)
+        check(prev[0], e2.search_resident_end(prev[1]))
+    # both tickets out: a third begin is refused, so is ending a ticket twice; the plain call still works afterwards
+    t0 = e2.search_resident_begin(descs[0][0])
+    t1 = e2.search_resident_begin(descs[2][0])
+    assert {t0, t1} == {0, 1}
+    with pytest.raises(MolarHipError):
+        e2.search_resident_begin(descs[3][0])
+    check(2, e2.search_resident_end(t1))          # out of order is fine
+    check(0, e2.search_resident_end(t0))
+    with pytest.raises(MolarHipError):
+        e2.search_resident_end(t0)
+    check(3, e2.search_resident_desc(descs[3][0]))
+
+
 def test_randomised_differential(monkeypatch):
     """tools/fuzz_search.py: random boxes / cutoffs / densities / periodicity masks / selections / kinds, count+fill and
     resident entries, against the oracle - every case bit-identical (9000 cases were run this way in round 1)."""
