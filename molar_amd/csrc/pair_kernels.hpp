@@ -249,6 +249,8 @@ __device__ __forceinline__ v2f pair_d2x2(const SearchParams &P, const BoxRegs &B
 struct Fifo {
     uint32_t *fi, *fj, *fd;     // LDS, FIFO_CAP entries each
     uint32_t head, tail;        // monotonically increasing, wave-uniform
+    uint32_t quota;             // entries the next full flush writes: 64 - (base % 64) for the first flush of a slot, so
+                                // that every later flush is one naturally aligned 512-byte / 256-byte block; then 64
     uint64_t base;              // output offset of this task
     uint2 *pairs;
     float *dist;
@@ -308,6 +310,19 @@ __device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint3
         }
     }
     F.head += count;
+}
+
+// >= 64 entries are queued: write them out in 64-entry blocks.  A slot's output starts wherever the slots before it
+// end, so its first flush only goes up to the next 64-entry boundary of the output arrays; from then on every
+// flush is a naturally aligned block (unaligned 512-byte stores straddle five cache lines instead of four and
+// reach 3.9 instead of 4.6 TB/s on this chip, profiles/microbench/store_shapes_mi355x.txt).
+template <int KIND>
+__device__ __forceinline__ void fifo_drain(const SearchParams &P, Fifo &F, uint32_t lane) {
+    __builtin_amdgcn_wave_barrier();
+    do {
+        fifo_flush<KIND>(P, F, F.quota, lane);
+        F.quota = 64u;
+    } while (F.tail - F.head >= 64u);
 }
 
 // One task = one ordered block of the reference's output:
@@ -401,10 +416,7 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
                     }
                     F.tail += cnt;
                     total += cnt;
-                    if (F.tail - F.head >= 64u) {
-                        __builtin_amdgcn_wave_barrier();
-                        fifo_flush<KIND>(P, F, 64u, lane);
-                    }
+                    if (F.tail - F.head >= 64u) fifo_drain<KIND>(P, F, lane);
                 }
             };
             // two chunks (c0 = first chunk index) against row i; use0/use1: chunk is live
@@ -472,10 +484,7 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
                 if (FILL) {
                     if (lane == 0) F.fi[F.tail & (FIFO_CAP - 1)] = id_i;
                     F.tail += 1;
-                    if (F.tail - F.head >= 64u) {
-                        __builtin_amdgcn_wave_barrier();
-                        fifo_flush<KIND>(P, F, 64u, lane);
-                    }
+                    if (F.tail - F.head >= 64u) fifo_drain<KIND>(P, F, lane);
                 }
                 total += 1;
             }
@@ -705,10 +714,7 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
                     }
                     F.tail += cnt;
                     total += cnt;
-                    if (F.tail - F.head >= 64u) {
-                        __builtin_amdgcn_wave_barrier();
-                        fifo_flush<KIND>(P, F, 64u, lane);
-                    }
+                    if (F.tail - F.head >= 64u) fifo_drain<KIND>(P, F, lane);
                 }
             }
         }
@@ -815,10 +821,7 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
                     }
                     F.tail += cnt;
                     total += cnt;
-                    if (F.tail - F.head >= 64u) {
-                        __builtin_amdgcn_wave_barrier();
-                        fifo_flush<KIND>(P, F, 64u, lane);
-                    }
+                    if (F.tail - F.head >= 64u) fifo_drain<KIND>(P, F, lane);
                 }
             }
         }
@@ -998,6 +1001,7 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
         F.fj = lds[wave][1];
         F.fd = lds[wave][2];
         F.head = F.tail = 0;
+        F.quota = 64u;
         F.pairs = out_pairs;
         F.dist = out_dist;
         F.ids = out_ids;
@@ -1013,6 +1017,7 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
         F.hn = (float)P.hist_nbins;
         if (FILL && !hist) {
             F.base = slot_base[slot];
+            F.quota = 64u - ((uint32_t)F.base & 63u);
             const unsigned long long end = slot_base[slot + 1];
             if (end == F.base || end > P.out_cap) return;  // nothing to emit / no room (the host grows and repeats)
         }
