@@ -69,7 +69,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
                           &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb})
             b->release();
     }
-    for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_task, &c->slot_cnt, &c->slot_base, &c->scan_tmp, &c->scan_state, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
+    for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->scan_tmp, &c->scan_state, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
                       &c->wide_i, &c->wide_j, &c->hist, &c->task_mu, &c->task_moff, &c->maskbuf, &c->m_xyz1, &c->m_xyz2, &c->m_idx1, &c->m_idx2,
                       &c->m_mass1, &c->m_mass2, &c->m_partials, &c->m_results, &c->m_out})
         b->release();

@@ -134,7 +134,7 @@ struct molar_hip_ctx {
     mh::DevBuf params;         // SearchParams block read by the pair kernels
     mh::DevBuf task_desc;      // TaskDesc per task (plan entry)
     mh::DevBuf task_nb;        // u32 per task (+1): 64-row blocks of the task, scanned in place -> first slot
-    mh::DevBuf slot_task;      // u32 per slot: owning task
+    mh::DevBuf slot_desc;      // SlotDesc per slot (+1): what a wave of the pair kernels needs to start
     mh::DevBuf slot_cnt;       // u32 per slot (+1): results of the slot
     mh::DevBuf slot_base;      // u64 per slot (+1): output offset (last = grand total)
     mh::DevBuf scan_tmp;       // block sums for the scans

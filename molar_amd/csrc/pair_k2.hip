@@ -4,14 +4,14 @@
 namespace mh {
 
 void launch_pair_within(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
-                        const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                        const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                         const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids) {
     using namespace pairk;
     constexpr int KIND = MOLAR_HIP_SEARCH_WITHIN;
     if (mode == MODE_COUNT)
-        launch_pair_kernel<KIND, MODE_COUNT>(nblocks, dyn_lds, stream, dP, task_first, slot_task, slot_cnt, slot_base, pairs, dist, ids);
+        launch_pair_kernel<KIND, MODE_COUNT>(nblocks, dyn_lds, stream, dP, slot_desc, nslots, slot_cnt, slot_base, pairs, dist, ids);
     else
-        launch_pair_kernel<KIND, MODE_FILL>(nblocks, dyn_lds, stream, dP, task_first, slot_task, slot_cnt, slot_base, pairs, dist, ids);
+        launch_pair_kernel<KIND, MODE_FILL>(nblocks, dyn_lds, stream, dP, slot_desc, nslots, slot_cnt, slot_base, pairs, dist, ids);
 }
 
 }  // namespace mh

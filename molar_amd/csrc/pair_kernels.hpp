@@ -90,6 +90,16 @@ struct TaskDesc {
     uint32_t a0, n1, b0, n2, cb, flags, pad0, pad1;   // flags: wrap | tri<<8 | valid<<9 | wrap_b<<12 | rps<<16
 };
 
+// what slotmap_kernel stores per slot: everything a wave needs to start on its slot, so that the chain of dependent
+// loads in front of the first atom is kernel arguments -> this record -> atoms (it used to be parameter block ->
+// slot count -> slot's task -> task descriptor -> atoms).  Slots in [number of slots, host-side bound] have flags == 0.
+struct SlotDesc {
+    uint32_t a0, n1, b0, n2;          // as TaskDesc
+    uint32_t cb, flags, i0, pad0;     // i0: first row of the slot inside the first cell
+    unsigned long long moff, pad1;    // first 64-word unit of the slot in maskbuf
+};
+static_assert(sizeof(SlotDesc) == 48, "SlotDesc is read with three 16-byte loads");
+
 struct Task {
     uint32_t a0, n1, b0, n2;
     uint32_t rps;             // rows of the first cell per slot: 64, or 8 for entries that run the
@@ -939,17 +949,41 @@ __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__r
 }
 
 static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, const uint32_t *__restrict__ task_first,
-                                                      uint32_t *__restrict__ slot_task) {
+                                                      const TaskDesc *__restrict__ task_desc,
+                                                      const unsigned long long *__restrict__ task_moff,   // NULL: no hit history
+                                                      SlotDesc *__restrict__ slot_desc, uint64_t nslots_bound) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (t >= ntasks) return;
+    if (t >= ntasks) {
+        // slots between the real count and the host's bound: waves launched for them leave at once
+        const uint64_t s = (uint64_t)task_first[ntasks] + (t - ntasks);
+        if (s <= nslots_bound) {
+            SlotDesc z;
+            z.a0 = z.n1 = z.b0 = z.n2 = z.cb = z.flags = z.i0 = z.pad0 = 0u;
+            z.moff = ~0ull >> 1;
+            z.pad1 = 0ull;
+            slot_desc[s] = z;
+        }
+        return;
+    }
     const uint32_t s0 = task_first[t], s1 = task_first[t + 1];
-    for (uint32_t s = s0; s < s1; ++s) slot_task[s] = (uint32_t)t;
+    if (s1 == s0) return;
+    const TaskDesc d = task_desc[t];
+    const uint32_t rps = d.flags >> 16, nch = (d.n2 + 63u) >> 6;
+    const unsigned long long m0 = task_moff ? task_moff[t] : (~0ull >> 1);
+    for (uint32_t s = s0; s < s1; ++s) {
+        SlotDesc o;
+        o.a0 = d.a0; o.n1 = d.n1; o.b0 = d.b0; o.n2 = d.n2;
+        o.cb = d.cb; o.flags = d.flags; o.i0 = (s - s0) * rps; o.pad0 = 0u;
+        o.moff = task_moff ? m0 + (unsigned long long)(s - s0) * 2u * nch : m0;
+        o.pad1 = 0ull;
+        slot_desc[s] = o;
+    }
 }
 
 template <int KIND, int MODE>
 __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : 7))) pair_kernel(const SearchParams *__restrict__ Pp,
-                                                     const uint32_t *__restrict__ task_first,
-                                                     const uint32_t *__restrict__ slot_task,
+                                                     const SlotDesc *__restrict__ slot_desc,
+                                                     const uint32_t nslots,      // the host's bound: slots past the real count are empty
                                                      uint32_t *__restrict__ slot_cnt,
                                                      const unsigned long long *__restrict__ slot_base,
                                                      uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
@@ -965,7 +999,6 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
     const SearchParams &P = *Pp;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t nslots = task_first[P.ntasks];
     constexpr bool hist = MODE == MODE_HIST;
     if (hist) {
         for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += BLOCK) lds_hist[b] = 0u;
@@ -978,24 +1011,28 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
         // entries fill the tail; consecutive blocks land on different XCDs, which spreads that band
         // over the whole chip.
         const uint32_t slot = nslots - 1u - w;
-        const uint32_t t = slot_task[slot];
-        Task T;   // descriptor precomputed by plan_kernel: no per-slot replay of the plan arithmetic
+        Task T;   // record prepared by slotmap_kernel: one dependent load between the kernel arguments and the atoms
+        uint32_t i0;
+        unsigned long long moff;
         {
-            const uint4 lo = reinterpret_cast<const uint4 *>(P.task_desc + t)[0];
-            const uint2 hi = reinterpret_cast<const uint2 *>(P.task_desc + t)[2];
+            const uint4 lo = reinterpret_cast<const uint4 *>(slot_desc + slot)[0];
+            const uint4 hi = reinterpret_cast<const uint4 *>(slot_desc + slot)[1];
+            const uint2 mo = reinterpret_cast<const uint2 *>(slot_desc + slot)[4];
+            const uint32_t fl = __builtin_amdgcn_readfirstlane(hi.y);
+            if (!(fl & 0x200u)) return;       // past the last slot
             T.a0 = __builtin_amdgcn_readfirstlane(lo.x);
             T.n1 = __builtin_amdgcn_readfirstlane(lo.y);
             T.b0 = __builtin_amdgcn_readfirstlane(lo.z);
             T.n2 = __builtin_amdgcn_readfirstlane(lo.w);
             T.cb = __builtin_amdgcn_readfirstlane(hi.x);
-            const uint32_t fl = __builtin_amdgcn_readfirstlane(hi.y);
+            i0 = __builtin_amdgcn_readfirstlane(hi.z);
+            moff = ((unsigned long long)__builtin_amdgcn_readfirstlane(mo.y) << 32) | __builtin_amdgcn_readfirstlane(mo.x);
             T.wrap = fl & 7u;
             T.tri = (fl & 0x100u) != 0u;
-            T.valid = (fl & 0x200u) != 0u;
+            T.valid = true;
             T.wrap_b = (fl >> 12) & 7u;
             T.rps = fl >> 16;
         }
-        const uint32_t i0 = (slot - task_first[t]) * T.rps;
         Fifo F;
         F.fi = lds[wave][0];
         F.fj = lds[wave][1];
@@ -1032,8 +1069,7 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
         uint32_t *mwords = nullptr;
         if (MASKED) {
             const uint32_t nch = (T.n2 + 63u) >> 6;
-            const unsigned long long mu = P.task_moff[t] + (unsigned long long)(slot - task_first[t]) * 2u * nch;
-            if (mu + 2u * nch <= P.mask_cap_units) mwords = P.maskbuf + mu * 64u;
+            if (moff + 2u * nch <= P.mask_cap_units) mwords = P.maskbuf + moff * 64u;
         }
         switch (wk) {
             case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
@@ -1066,9 +1102,9 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
 // one launch of the pair kernel for a search kind / mode
 template <int KIND, int MODE>
 inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t stream, const SearchParams *dP,
-                               const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                               const SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                                const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids) {
-    hipLaunchKernelGGL((pair_kernel<KIND, MODE>), dim3(nblocks), dim3(64 * waves_per_block(MODE)), dyn_lds, stream, dP, task_first, slot_task,
+    hipLaunchKernelGGL((pair_kernel<KIND, MODE>), dim3(nblocks), dim3(64 * waves_per_block(MODE)), dyn_lds, stream, dP, slot_desc, nslots,
                        slot_cnt, slot_base, pairs, dist, ids);
 }
 
@@ -1076,16 +1112,16 @@ inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t str
 
 // defined in pair_k0.hip .. pair_k3.hip (one search kind each)
 void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
-                        const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                        const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                         const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);
 void launch_pair_double(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
-                        const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                        const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                         const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);
 void launch_pair_within(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
-                        const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                        const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                         const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);
 void launch_pair_vdw(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
-                     const uint32_t *task_first, const uint32_t *slot_task, uint32_t *slot_cnt,
+                     const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                      const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);
 
 }  // namespace mh

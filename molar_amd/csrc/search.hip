@@ -764,8 +764,8 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     if (!params_resident)
         hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, c->stream, P, c->params.as<SearchParams>());
     const SearchParams *dP = c->params.as<SearchParams>();
-    const uint32_t *tf = c->task_nb.as<uint32_t>();
-    const uint32_t *st = c->slot_task.as<uint32_t>();
+    const SlotDesc *tf = c->slot_desc.as<SlotDesc>();
+    const uint32_t st = (uint32_t)c->nslots_bound;
     uint32_t *sc = c->slot_cnt.as<uint32_t>();
     auto *sb = c->slot_base.as<unsigned long long>();
     const int mode = !FILL ? MODE_COUNT : (hist_nbins ? MODE_HIST : MODE_FILL);
@@ -889,7 +889,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         return fail(MOLAR_HIP_ERR_TOO_LARGE, "search plan too large (%llu entries)", (unsigned long long)c->ntasks);
     MH_TRY(c->task_nb.reserve((c->ntasks + 1) * 4));
     MH_TRY(c->task_desc.reserve((c->ntasks + 1) * sizeof(TaskDesc)));
-    MH_TRY(c->slot_task.reserve((c->nslots_bound + 1) * 4));
+    MH_TRY(c->slot_desc.reserve((c->nslots_bound + 1) * sizeof(SlotDesc)));
     MH_TRY(c->slot_cnt.reserve((c->nslots_bound + 1) * 4));
     MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
     const size_t st_tasks = lookback_state_words(c->ntasks + 1), st_slots = lookback_state_words(c->nslots_bound + 1);
@@ -920,8 +920,11 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         MH_TRY((scan_lookback<uint32_t, uint32_t, uint32_t, unsigned long long>(
             c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), fast_kind ? c->task_mu.as<uint32_t>() : nullptr,
             c->task_moff.as<unsigned long long>(), c->ntasks + 1, c->scan_state.as<unsigned long long>())));
-        hipLaunchKernelGGL(slotmap_kernel, dim3(nb), dim3(256), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
-                           c->slot_task.as<uint32_t>());
+        // one record per slot (threads past the tasks blank the slots between the real count and the bound)
+        const unsigned nbs = (unsigned)((c->ntasks + c->nslots_bound + 1 + 255) / 256);
+        hipLaunchKernelGGL(slotmap_kernel, dim3(nbs), dim3(256), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
+                           c->task_desc.as<TaskDesc>(), fast_kind ? c->task_moff.as<unsigned long long>() : nullptr,
+                           c->slot_desc.as<SlotDesc>(), c->nslots_bound);
         MH_HIP(hipGetLastError());
     }
     // hit-history buffer of the count -> fill pair: sized exactly (one small read-back; the fused histogram
