@@ -102,7 +102,7 @@ struct GridSet {
     DevBuf sorted;             // float4 {x,y,z,id-bits} in reference cell order
     DevBuf sorted_vdw;         // float per sorted atom (vdw searches)
     DevBuf aabb;               // float4 lo/hi per cell
-    DevBuf perm;               // u32 per sorted atom: Morton order inside the cell (count pass of the fast path)
+    DevBuf perm;               // float4 per sorted atom: the cell in Morton order, {x,y,z,position} (count pass of the fast path)
     DevBuf chunk_aabb;         // float4 lo/hi per 64-atom Morton chunk, slot (cell_start >> 6) + cell + k
 };
 

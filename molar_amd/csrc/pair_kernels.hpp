@@ -59,7 +59,7 @@ struct SearchParams {
     const float *vdwa;
     const float *vdwb;
     const float4 *aabb_b;    // per-cell bounding boxes of set 2 (== set 1 for SINGLE)
-    const uint32_t *perm_b;  // set 2: Morton order inside each cell (cells of <= 512 atoms), see cell_order_kernel
+    const float4 *perm_b;    // set 2: atoms in Morton order inside each cell, {x,y,z,position in the cell} (cells of <= 512 atoms), see place_order_kernel
     const float4 *chunk_aabb_b;   // set 2: bounding boxes of the 64-atom Morton chunks, slot (cell_start >> 6) + cell + k
     const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
     uint32_t *maskbuf;       // fast-path slots: hit bits found by the count pass, replayed by the fill pass
@@ -586,8 +586,8 @@ __device__ __forceinline__ uint32_t run_count_sorted(const SearchParams &P, cons
         float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
         uint32_t pj = 0u;
         if (jj < T.n2) {
-            pj = gload_u32(P.perm_b, T.b0 + jj);
-            q = gload4(P.sb, T.b0 + pj);
+            q = gload4(P.perm_b, T.b0 + jj);
+            pj = __float_as_uint(q.w);
         }
         bx[k] = q.x; by[k] = q.y; bz[k] = q.z; bpos[k] = pj;
     }

@@ -163,8 +163,9 @@ __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t
 //  * the axis-aligned bounding box of the stored positions (aabb[2c] = lo, aabb[2c+1] = hi; lets a row of the pair
 //    kernels prove "no atom of the other cell can be within the cutoff");
 //  * for cells of <= 512 atoms a SPATIAL order of their atoms for the count pass:
-//      perm[cell_start[c] + m]  = position inside the cell of the m-th atom in Morton order (3 bits per axis of
-//                                 the cell's bounding box; LDS counting sort, order inside a key irrelevant),
+//      perm[cell_start[c] + m]  = {x, y, z, position inside the cell} of the m-th atom in Morton order (3 bits per
+//                                 axis of the cell's bounding box; LDS counting sort, order inside a key irrelevant;
+//                                 a second copy of the coordinates, so the count pass loads them without a gather),
 //      chunk_aabb[2*u], [2*u+1] = bounding box of the 64 atoms of Morton chunk k, u = (cell_start[c] >> 6) + c + k
 //                                 (distinct for all chunks of all cells: a cell owns floor(n/64)+1 >= ceil(n/64) slots).
 //    Counting does not depend on the order in which candidates are visited, so the count pass walks compact
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t 
                                                           const uint32_t *__restrict__ cell_start,
                                                           const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
                                                           float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
-                                                          float4 *__restrict__ aabb, uint32_t *__restrict__ perm,
+                                                          float4 *__restrict__ aabb, float4 *__restrict__ perm,
                                                           float4 *__restrict__ chunk_aabb) {
     __shared__ uint32_t keys_s[4][ORDER_MAX];     // sort keys of the cell; reused as the Morton histogram
     __shared__ uint32_t kr_s[4][ORDER_MAX];
@@ -272,8 +273,8 @@ __global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t 
         float l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
         if (m < n) {
             const uint32_t t = pl[m];
-            perm[s + m] = t;
             const float4 p = pos[t];
+            perm[s + m] = make_float4(p.x, p.y, p.z, __uint_as_float(t));
             l3[0] = h3[0] = p.x; l3[1] = h3[1] = p.y; l3[2] = h3[2] = p.z;
         }
         for (int d = 0; d < 3; ++d)
@@ -610,7 +611,7 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     MH_TRY(S.sorted.reserve((size_t)(S.n ? S.n : 1) * sizeof(float4)));
     if (S.d_vdw) MH_TRY(S.sorted_vdw.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.aabb.reserve((size_t)ncells * 2 * sizeof(float4)));
-    MH_TRY(S.perm.reserve((size_t)(S.n ? S.n : 1) * 4));
+    MH_TRY(S.perm.reserve((size_t)(S.n ? S.n : 1) * 16));
     MH_TRY(S.chunk_aabb.reserve(((size_t)S.n / 64 + ncells + 1) * 2 * sizeof(float4)));
     // one counter per 128-byte line while that stays small (<= 64 MB) and cells are crowded
     const uint32_t pad_shift = (S.n && ncells <= (1u << 19) && (uint64_t)S.n >= 8ull * ncells) ? 5u : 0u;
@@ -636,7 +637,7 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
                            S.cell_count.as<uint32_t>(), S.cursor.as<uint32_t>(), S.tmp_key.as<uint32_t>());
         hipLaunchKernelGGL(place_order_kernel, dim3((ncells + 3u) / 4u), dim3(256), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
-                           S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<uint32_t>(),
+                           S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<float4>(),
                            S.chunk_aabb.as<float4>());
         MH_HIP(hipGetLastError());
     }
@@ -670,7 +671,7 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.vdwa = c->set[0].sorted_vdw.as<float>();
     P.vdwb = c->set[1].sorted_vdw.as<float>();
     P.aabb_b = two ? c->set[1].aabb.as<float4>() : c->set[0].aabb.as<float4>();
-    P.perm_b = two ? c->set[1].perm.as<uint32_t>() : c->set[0].perm.as<uint32_t>();
+    P.perm_b = two ? c->set[1].perm.as<float4>() : c->set[0].perm.as<float4>();
     P.chunk_aabb_b = two ? c->set[1].chunk_aabb.as<float4>() : c->set[0].chunk_aabb.as<float4>();
     P.task_desc = c->task_desc.as<TaskDesc>();
     P.maskbuf = c->maskbuf.as<uint32_t>();
