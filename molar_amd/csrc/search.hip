@@ -180,7 +180,8 @@ __global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t 
     __shared__ uint32_t keys_s[4][ORDER_MAX];     // sort keys of the cell; reused as the Morton histogram
     __shared__ uint32_t kr_s[4][ORDER_MAX];
     __shared__ uint16_t perm_s[4][ORDER_MAX];
-    __shared__ float4 pos_s[4][ORDER_MAX];        // placed records, by rank
+    // (the placed records are read back from `sorted` - written by this wave - rather than kept in LDS: 8 KB per wave
+    // more would hold the kernel at 3 workgroups per CU and make a 1M-atom grid take two rounds)
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t c = blockIdx.x * 4u + w;
     if (c >= ncells) return;
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t 
     const bool small = n <= ORDER_MAX;
     uint32_t *keys = keys_s[w], *kr = kr_s[w];
     uint16_t *pl = perm_s[w];
-    float4 *pos = pos_s[w];
+    const float4 *pos = sorted + s;               // valid once the placement loop's stores are visible (fence below)
     if (small) {
         for (uint32_t t = lane; t < n; t += 64u) keys[t] = tmp_key[s + t];
         __builtin_amdgcn_wave_barrier();
@@ -216,7 +217,6 @@ __global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t 
         const float4 rec = make_float4(ca.pos.x, ca.pos.y, ca.pos.z, __uint_as_float(id));
         sorted[s + rank] = rec;
         if (vdw) sorted_vdw[s + rank] = vdw[k];
-        if (small) pos[rank] = rec;
         lo[0] = fminf(lo[0], rec.x); hi[0] = fmaxf(hi[0], rec.x);
         lo[1] = fminf(lo[1], rec.y); hi[1] = fmaxf(hi[1], rec.y);
         lo[2] = fminf(lo[2], rec.z); hi[2] = fmaxf(hi[2], rec.z);
@@ -231,6 +231,7 @@ __global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t 
         aabb[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
     }
     if (n == 0 || !small) return;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the records placed above are re-read by other lanes of this wave (same CU: no L2 write-back needed)
     __builtin_amdgcn_wave_barrier();
     uint32_t *hist = keys;                          // the sort keys are no longer needed
     for (uint32_t b = lane; b < ORDER_MAX; b += 64u) hist[b] = 0u;
