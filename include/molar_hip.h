@@ -173,7 +173,7 @@ int molar_hip_search_fill_device(molar_hip_ctx *ctx, const uint32_t **d_pairs, c
  * into ctx-owned buffers sized by earlier frames of the trajectory; if a buffer turns out too small (first
  * frame) it grows and the affected pass repeats.  Same result, order and validity rules as
  * molar_hip_search_count + molar_hip_search_fill_device; the cached search stays available to the other fill
- * variants.  Not for WITHIN (ids, not pairs). */
+ * variants.  The result is complete in device memory when the call returns.  Not for WITHIN (ids, not pairs). */
 int molar_hip_search_resident(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_count,
                               const uint32_t **d_pairs, const float **d_dist);
 /* The same search split in two so that a per-frame loop never leaves the GPU idle: _begin enqueues everything for

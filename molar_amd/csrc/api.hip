@@ -64,12 +64,13 @@ void molar_hip_destroy(molar_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (auto &s : c->set) {
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+    for (auto &gen : c->set_store) for (auto &s : gen) {
         for (DevBuf *b : {&s.xyz_stage, &s.idx_stage, &s.vdw_stage, &s.key, &s.cell_count, &s.cnt_pad, &s.cursor, &s.tmp_key,
                           &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb})
             b->release();
     }
-    for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->scan_tmp, &c->scan_state, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
+    for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->scan_tmp, &c->scan_tmp_side, &c->scan_state, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
                       &c->wide_i, &c->wide_j, &c->hist, &c->task_mu, &c->task_moff, &c->maskbuf, &c->m_xyz1, &c->m_xyz2, &c->m_idx1, &c->m_idx2,
                       &c->m_mass1, &c->m_mass2, &c->m_partials, &c->m_results, &c->m_out})
         b->release();
@@ -82,6 +83,8 @@ void molar_hip_destroy(molar_hip_ctx *c) {
     if (c->h_sizes) (void)hipHostFree(c->h_sizes);
     for (auto &t : c->tickets)
         if (t.done) (void)hipEventDestroy(t.done);
+    if (c->grid_done) (void)hipEventDestroy(c->grid_done);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

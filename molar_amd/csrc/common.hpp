@@ -129,7 +129,15 @@ struct molar_hip_ctx {
     uint32_t dims[3]{1, 1, 1};
     uint64_t ntasks = 0;
     uint64_t total = 0;
-    mh::GridSet set[2];
+    // Two generations of the grids: the pipelined resident search (molar_hip_search_resident_begin) builds the grid of
+    // the next frame on `side_stream` while the pair kernels of the frame before it still read theirs.
+    mh::GridSet set_store[2][2];
+    mh::GridSet *set = set_store[0];     // the generation the cached search refers to (set[0], set[1]: first / second set)
+    hipStream_t side_stream = nullptr;   // grid build of a pipelined search (created on first use, highest priority)
+    hipEvent_t grid_done = nullptr;
+    bool want_side = false;              // set by _begin around its enqueue
+    bool on_side = false;                // launches currently go to side_stream (scans then use scan_tmp_side)
+    mh::DevBuf scan_tmp_side;
     uint64_t nslots_bound = 0; // host-side upper bound of the slot count (sizes the launches)
     mh::DevBuf params;         // SearchParams block read by the pair kernels
     mh::DevBuf task_desc;      // TaskDesc per task (plan entry)

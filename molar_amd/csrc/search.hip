@@ -472,8 +472,9 @@ int exclusive_scan(molar_hip_ctx *c, const TIn *in, TOut *out, uint64_t n) {
         return 0;
     }
     const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    MH_TRY(c->scan_tmp.reserve(nb * sizeof(TOut)));
-    TOut *sums = c->scan_tmp.as<TOut>();
+    mh::DevBuf &tmp = c->on_side ? c->scan_tmp_side : c->scan_tmp;   // the two streams may scan at the same time
+    MH_TRY(tmp.reserve(nb * sizeof(TOut)));
+    TOut *sums = tmp.as<TOut>();
     hipLaunchKernelGGL((scan_tile_kernel<TIn, TOut>), dim3((unsigned)nb), dim3(256), 0, c->stream, in, out, sums, n);
     if (nb > 1) {
         hipLaunchKernelGGL((scan_sums_kernel<TOut>), dim3(1), dim3(256), 0, c->stream, sums, nb);
@@ -877,8 +878,34 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         for (int d = 0; d < 3; ++d) ext[d] = c->upper[d] - c->lower[d];   // from_cutoff_and_min_max :112-114
     }
     MH_TRY(dims_from_extents(c, cutoff, ext));
-    MH_TRY(build_grid(c, c->set[0], q->ids_local || vdw));
-    if (two) MH_TRY(build_grid(c, c->set[1], q->ids_local || vdw));
+    // Pipelined search on a context that owns its stream, inputs already in device memory: the grid build goes to the
+    // side stream.  It touches only this generation's GridSet (last read by the search two frames back, which has been
+    // ended) and its own scan scratch, so it needs to wait for nothing and overlaps the pair kernels of the frame in
+    // front of it; the plan and the pair kernels of THIS search wait for it on the main stream.
+    const bool side = c->want_side && c->own_stream && c->use_box && !vdw && c->set[0].d_xyz == q->xyz1 &&
+                      c->set[0].d_idx == q->idx1 && (!two || (c->set[1].d_xyz == q->xyz2 && c->set[1].d_idx == q->idx2));
+    if (side) {
+        if (!c->side_stream) {
+            int lo = 0, hi = 0;
+            MH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            MH_HIP(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi));
+            MH_HIP(hipEventCreateWithFlags(&c->grid_done, hipEventDisableTiming));
+        }
+        hipStream_t main_stream = c->stream;
+        c->stream = c->side_stream;
+        c->on_side = true;
+        int rc = build_grid(c, c->set[0], q->ids_local || vdw);
+        if (!rc && two) rc = build_grid(c, c->set[1], q->ids_local || vdw);
+        hipError_t e = rc ? hipSuccess : hipEventRecord(c->grid_done, c->side_stream);
+        c->stream = main_stream;
+        c->on_side = false;
+        MH_TRY(rc);
+        MH_HIP(e);
+        MH_HIP(hipStreamWaitEvent(c->stream, c->grid_done, 0));
+    } else {
+        MH_TRY(build_grid(c, c->set[0], q->ids_local || vdw));
+        if (two) MH_TRY(build_grid(c, c->set[1], q->ids_local || vdw));
+    }
 
     const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
     c->ntasks = ncells * 14ull * (two ? 2ull : 1ull);
@@ -1082,7 +1109,10 @@ static int resident_settle(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD,
         MH_TRY(outD.reserve((size_t)(c->total + c->total / 16u) * 4));
         refill = true;
     }
-    if (refill && c->total) MH_TRY(launch_pairs<true>(c, outP.as<uint2>(), outD.as<float>(), nullptr));
+    if (refill && c->total) {
+        MH_TRY(launch_pairs<true>(c, outP.as<uint2>(), outD.as<float>(), nullptr));
+        MH_HIP(hipStreamSynchronize(c->stream));   // like the common case, the result is complete when the call returns
+    }
     return 0;
 }
 
@@ -1115,7 +1145,11 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     if (!T.done) MH_HIP(hipEventCreateWithFlags(&T.done, hipEventDisableTiming));
     T.desc = *q;
     ResidentLaunch L;
-    MH_TRY(resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 16 * slot, &L));
+    c->set = c->set_store[slot];         // this ticket's grid generation (the other one may still be read by the frame in flight)
+    c->want_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") == nullptr;
+    const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 16 * slot, &L);
+    c->want_side = false;
+    MH_TRY(erc);
     MH_HIP(hipEventRecord(T.done, c->stream));
     T.cap0 = L.cap0;
     T.maskcap0 = L.maskcap0;

@@ -606,6 +606,18 @@ def test_randomised_differential(monkeypatch):
     assert mod.main() == 0
 
 
+def test_randomised_pipeline():
+    """tools/fuzz_pipeline.py: random frames through molar_hip_search_resident_begin/_end with two searches in flight
+    (two grid generations, grid build on the side stream, grow-and-repeat), each result equal to count + fill."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_pipeline.py")
+    spec = importlib.util.spec_from_file_location("fuzz_pipeline", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(150, 5, verbose=False) == 0
+
+
 def test_histogram_device_bins_async(eng):
     """Device-resident bins, no per-frame round trip: several frames queued back to back give the same integer bins
     as the host-bins path."""
