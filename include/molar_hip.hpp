@@ -18,6 +18,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <memory>
 #include <optional>
@@ -474,6 +475,54 @@ inline ResidentPairs distance_search_double_pbc_resident(Float cutoff, const Sel
     check(molar_hip_search_resident(d1.ctx(), &d, &r.count, &r.pairs, &r.dist));
     return r;
 }
+
+// Per-frame loop with two searches in flight (molar_hip_search_resident_begin / _end, engine extension):
+//     PairPipeline pipe(ctx);
+//     for (frame : trajectory) { if (auto r = pipe.push(rc, sel_of(frame), box, PBC_FULL)) consume(*r); }
+//     if (auto r = pipe.finish()) consume(*r);
+// push() enqueues the search of its frame and hands back the result of the frame pushed before it, so the host
+// work and the result round trip of one frame hide behind the kernels of the other.  A result stays valid until
+// the second push after the one that produced it.  The selection's coordinates and index must stay alive and
+// unchanged until its result has been handed back (the box matrix is copied).
+class PairPipeline {
+  public:
+    explicit PairPipeline(molar_hip_ctx *ctx) : ctx_(ctx) {}
+    PairPipeline(const PairPipeline &) = delete;
+    PairPipeline &operator=(const PairPipeline &) = delete;
+    ~PairPipeline() {                                   // never leave a ticket pending on the context
+        if (pending_) { uint64_t n; const uint32_t *p; const float *d; (void)molar_hip_search_resident_end(ctx_, ticket_, &n, &p, &d); }
+    }
+    std::optional<ResidentPairs> push(Float cutoff, const SelBound &data, const PeriodicBox &pbox, PbcDims pbc_dims,
+                                      bool ids_local = false) {
+        const int slot = next_;
+        molar_hip_search_desc &d = desc_[slot];
+        d = detail::desc(MOLAR_HIP_SEARCH_SINGLE, cutoff, data, nullptr, ids_local, &pbox, pbc_dims);
+        std::memcpy(box_[slot], pbox.colmajor9(), sizeof box_[slot]);
+        d.box9 = box_[slot];
+        int32_t t = -1;
+        check(molar_hip_search_resident_begin(ctx_, &d, &t));
+        next_ ^= 1;
+        std::optional<ResidentPairs> out = finish();
+        ticket_ = t;
+        pending_ = true;
+        return out;
+    }
+    std::optional<ResidentPairs> finish() {
+        if (!pending_) return std::nullopt;
+        pending_ = false;
+        ResidentPairs r;
+        check(molar_hip_search_resident_end(ctx_, ticket_, &r.count, &r.pairs, &r.dist));
+        return r;
+    }
+
+  private:
+    molar_hip_ctx *ctx_;
+    molar_hip_search_desc desc_[2]{};
+    float box_[2][9]{};
+    int next_ = 0;
+    int32_t ticket_ = -1;
+    bool pending_ = false;
+};
 
 // ids: the reference takes an iterator; the two uses are the selection's own indices
 // (sel.iter_index(), ids_local = false) and 0..n (modify.rs:78, ids_local = true).

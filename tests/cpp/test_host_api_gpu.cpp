@@ -8,6 +8,9 @@
 #include <vector>
 
 #include "molar_hip.hpp"
+
+// the one HIP runtime call this test makes itself (reading a device-resident result back): hipMemcpyDeviceToHost = 2
+extern "C" int hipMemcpy(void *dst, const void *src, size_t bytes, int kind);
 extern "C" {
 #include "molar_oracle.h"
 }
@@ -175,6 +178,29 @@ static void measure_tests() {
         for (size_t k = 0; k < host.size(); ++k)
             same = same && pr[2 * k] == std::get<0>(host[k]) && pr[2 * k + 1] == std::get<1>(host[k]) && dd[k] == std::get<2>(host[k]);
         EXPECT(same);
+    }
+
+    // the same search through the two-in-flight pipeline: three pushes of the same selection, every result = the host result
+    {
+        const auto host = distance_search_single_pbc<std::tuple<usize, usize, Float>>(0.6f, cur, cur.require_box(), PBC_FULL);
+        PairPipeline pipe(cur.ctx());
+        size_t seen = 0;
+        auto verify = [&](const ResidentPairs &rp) {
+            ++seen;
+            EXPECT(rp.count == host.size());
+            std::vector<uint32_t> pr(2 * rp.count);
+            std::vector<float> dd(rp.count);
+            EXPECT(hipMemcpy(pr.data(), rp.pairs, pr.size() * 4, 2) == 0);
+            EXPECT(hipMemcpy(dd.data(), rp.dist, dd.size() * 4, 2) == 0);
+            bool same = rp.count == host.size();
+            for (size_t k = 0; same && k < host.size(); ++k)
+                same = pr[2 * k] == std::get<0>(host[k]) && pr[2 * k + 1] == std::get<1>(host[k]) && dd[k] == std::get<2>(host[k]);
+            EXPECT(same);
+        };
+        for (int f = 0; f < 3; ++f)
+            if (auto r = pipe.push(0.6f, cur, cur.require_box(), PBC_FULL)) verify(*r);
+        if (auto r = pipe.finish()) verify(*r);
+        EXPECT(seen == 3 && !pipe.finish());
     }
 
     // translate / rotate / principal_transform (modify.rs:16-30, measure.rs:100-109)

@@ -33,7 +33,7 @@ def test_host_api_gpu():
     o.build()
     odir = os.path.join(ROOT, "oracle")
     exe = _compile("test_host_api_gpu.cpp", "test_host_api_gpu",
-                   extra=["-I", odir, "-L", odir, "-l:liboracle_f32.so", f"-Wl,-rpath,{odir}"])
+                   extra=["-I", odir, "-L", odir, "-l:liboracle_f32.so", f"-Wl,-rpath,{odir}", "-L", "/opt/rocm/lib", "-lamdhip64"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all host-mirror GPU tests passed" in r.stdout
