@@ -261,7 +261,8 @@ struct Fifo {
     uint32_t head, tail;        // monotonically increasing, wave-uniform
     uint32_t quota;             // entries the next full flush writes: 64 - (base % 64) for the first flush of a slot, so
                                 // that every later flush is one naturally aligned 512-byte / 256-byte block; then 64
-    uint64_t base;              // output offset of this task
+    uint64_t base;              // output offset of this slot
+    bool has_pairs, has_dist;   // which of the two planes the caller wants (wave-uniform)
     uint2 *pairs;
     float *dist;
     uint32_t *ids;              // WITHIN output
@@ -302,7 +303,9 @@ template <int KIND>
 __device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint32_t count, uint32_t lane) {
     if (lane < count) {
         const uint32_t s = (F.head + lane) & (FIFO_CAP - 1);
-        const uint64_t pos = F.base + F.head + lane;
+        // F.pairs / F.dist / F.ids are per-lane pointers to entry (slot base + lane): the flush adds the FIFO head, and
+        // the kernel's output pointers need not stay in (spilled) SGPRs
+        const uint32_t pos = F.head;
         if (KIND == MOLAR_HIP_SEARCH_WITHIN) {
             F.ids[pos] = F.fi[s];
         } else if (F.hist) {
@@ -314,9 +317,9 @@ __device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint3
             if (fb >= 0.0f && fb < F.hn) atomicAdd(&F.hist[(uint32_t)fb], 1u);
         } else {
             const Hit h = fifo_hit(P, F, s);
-            if (F.pairs) F.pairs[pos] = make_uint2(h.i, h.j);
+            if (F.has_pairs) F.pairs[pos] = make_uint2(h.i, h.j);
             // d2.sqrt() (:448): llvm.sqrt.f32 without fpmath metadata = IEEE correctly rounded
-            if (F.dist) F.dist[pos] = __builtin_sqrtf(h.d2);
+            if (F.has_dist) F.dist[pos] = __builtin_sqrtf(h.d2);
         }
     }
     F.head += count;
@@ -822,12 +825,13 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
                     const uint32_t cnt = (uint32_t)__popcll(mask);
                     if (hit) {
                         // FIFO slot = tail + rank among the hit lanes (mbcnt accumulates onto tail)
-                        const uint32_t s = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, F.tail)) &
-                                           (FIFO_CAP - 1);
-                        F.fi[s] = id_i;
-                        F.fj[s] = bid[k];
-                        F.fd[s] = third;
+                        // (rank first, tail added with the shift: v_add_lshl_u32 takes the SGPR, no v_mov of the tail)
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        const uint32_t off = ((rank + F.tail) << 2) & ((FIFO_CAP - 1u) << 2);
+                        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+                        *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fi + off) = id_i;
+                        *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fj + off) = bid[k];
+                        *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fd + off) = third;
                     }
                     F.tail += cnt;
                     total += cnt;
@@ -998,7 +1002,8 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
     // (box.shifts[k]), gets copied to scratch by the compiler and drags every field into VGPRs.
     const SearchParams &P = *Pp;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // one-wave workgroups (count / fill): the wave index is the constant 0, so every LDS address is an immediate
+    const uint32_t wave = WAVES_PER_BLOCK == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr bool hist = MODE == MODE_HIST;
     if (hist) {
         for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += BLOCK) lds_hist[b] = 0u;
@@ -1039,9 +1044,11 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
         F.fd = lds[wave][2];
         F.head = F.tail = 0;
         F.quota = 64u;
-        F.pairs = out_pairs;
-        F.dist = out_dist;
-        F.ids = out_ids;
+        F.has_pairs = out_pairs != nullptr;
+        F.has_dist = out_dist != nullptr;
+        F.pairs = nullptr;
+        F.dist = nullptr;
+        F.ids = nullptr;
         F.base = 0;
         F.hist = hist ? lds_hist : nullptr;
         F.recompute = 0u;
@@ -1057,6 +1064,9 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
             F.quota = 64u - ((uint32_t)F.base & 63u);
             const unsigned long long end = slot_base[slot + 1];
             if (end == F.base || end > P.out_cap) return;  // nothing to emit / no room (the host grows and repeats)
+            if (out_pairs) F.pairs = out_pairs + F.base + lane;
+            if (out_dist) F.dist = out_dist + F.base + lane;
+            if (out_ids) F.ids = out_ids + F.base + lane;
         }
         uint32_t total = 0;
         const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
