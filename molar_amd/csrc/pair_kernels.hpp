@@ -609,7 +609,7 @@ __device__ __forceinline__ uint32_t run_count_sorted(const SearchParams &P, cons
     for (int k = 0; k < NCH; ++k) live |= livek[k];
     while (live) {
         const uint32_t r = (uint32_t)__builtin_ctzll(live);
-        live &= live - 1ull;
+        live &= ~(1ull << r);
         const float4 p = lload4(la, r);              // one broadcast ds_read per row
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -710,7 +710,7 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
             }
             ++nrow;
             const uint32_t r = (uint32_t)__builtin_ctzll(live);
-            live &= live - 1ull;
+            live &= ~(1ull << r);
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 const bool hit = (int32_t)w[k] < 0;
@@ -771,7 +771,7 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
     };
     while (live) {
         const uint32_t r = (uint32_t)__builtin_ctzll(live);
-        live &= live - 1ull;
+        live &= ~(1ull << r);
         const float4 p = lload4(la, r);              // one broadcast ds_read per row
         const uint32_t id_i = __float_as_uint(p.w);
         const uint32_t i = i0 + r;
