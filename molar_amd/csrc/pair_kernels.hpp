@@ -11,8 +11,8 @@ namespace pairk {
 
 enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2 };
 
-// (The count kernel is compiled for 8 waves per SIMD - 64 VGPRs, a few more spills outside the row loop, count -4 % -
-// the fill kernel for 7: at 8 its spills land in the flush.)
+// (Count and fill are compiled for 8 waves per SIMD - 64 VGPRs, the few spills fall outside the row loop: count -4 %,
+// fill -5 % against 7 waves.  32 one-wave workgroups of the fill kernel hold 144 KB of the CU's 160 KB LDS.)
 // Waves per workgroup.  Count / fill: ONE wave per workgroup - slots differ a lot in work, and a workgroup's
 // resources are only released when its slowest wave ends (measured: 4 -> 1 waves gives +7 % frames/s).  The fused
 // histogram keeps 4: every workgroup owns an LDS histogram that it flushes with atomics at the end.
@@ -987,7 +987,7 @@ static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, co
 }
 
 template <int KIND, int MODE>
-__global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 8 : 7)))) pair_kernel(const SearchParams *__restrict__ Pp,
+__global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : 8))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
                                                      const uint32_t nslots,      // the host's bound: slots past the real count are empty
                                                      uint32_t *__restrict__ slot_cnt,
