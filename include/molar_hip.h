@@ -183,7 +183,11 @@ int molar_hip_search_resident(molar_hip_ctx *ctx, const molar_hip_search_desc *d
  * and the host work of frame k+1 (and the result round trip of frame k) hides behind the kernels of frame k.
  * The kernels still run in order on the context's one stream.  A frame that outgrows a buffer is repeated inside
  * _end (after the younger search has drained), so `desc` and everything it points to must stay valid until _end.
- * A result set is valid until the second _begin after the one that produced it.  Errors: both sets in flight
+ * A result set is valid until the second _begin after the one that produced it (ticket 0's set is also the one
+ * molar_hip_search_resident and molar_hip_search_fill_device write: end the tickets before mixing those in).
+ * On a context that owns its stream, with inputs already in device memory, the grid of the new frame is built on an
+ * internal side stream while the kernels of the frame in flight run; the inputs must therefore be complete in
+ * memory when _begin is called (a context created on a caller's stream keeps everything on that stream).  Errors: both sets in flight
  * (_begin), unknown or already finished ticket (_end). */
 int molar_hip_search_resident_begin(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, int32_t *ticket);
 int molar_hip_search_resident_end(molar_hip_ctx *ctx, int32_t ticket, uint64_t *out_count, const uint32_t **d_pairs,
