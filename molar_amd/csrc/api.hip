@@ -84,6 +84,8 @@ void molar_hip_destroy(molar_hip_ctx *c) {
     for (auto &t : c->tickets)
         if (t.done) (void)hipEventDestroy(t.done);
     if (c->grid_done) (void)hipEventDestroy(c->grid_done);
+    for (auto e : c->gen_free)
+        if (e) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;

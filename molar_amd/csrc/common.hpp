@@ -135,7 +135,11 @@ struct molar_hip_ctx {
     mh::GridSet *set = set_store[0];     // the generation the cached search refers to (set[0], set[1]: first / second set)
     hipStream_t side_stream = nullptr;   // grid build of a pipelined search (created on first use, highest priority)
     hipEvent_t grid_done = nullptr;
-    bool want_side = false;              // set by _begin around its enqueue
+    bool want_side = false;              // set by _begin / the asynchronous histogram call around their enqueue
+    hipEvent_t gen_free[2] = {nullptr, nullptr};   // recorded on the main stream behind the last asynchronous reader of
+                                                   // a grid generation (histogram calls that do not wait)
+    hipEvent_t side_wait = nullptr;      // what the side stream has to wait for before it rebuilds the generation
+    int hist_gen = 0;                    // generation of the last asynchronous histogram call
     bool on_side = false;                // launches currently go to side_stream (scans then use scan_tmp_side)
     mh::DevBuf scan_tmp_side;
     uint64_t nslots_bound = 0; // host-side upper bound of the slot count (sizes the launches)

@@ -891,6 +891,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
             MH_HIP(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi));
             MH_HIP(hipEventCreateWithFlags(&c->grid_done, hipEventDisableTiming));
         }
+        if (c->side_wait) MH_HIP(hipStreamWaitEvent(c->side_stream, c->side_wait, 0));
         hipStream_t main_stream = c->stream;
         c->stream = c->side_stream;
         c->on_side = true;
@@ -1147,8 +1148,10 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     ResidentLaunch L;
     c->set = c->set_store[slot];         // this ticket's grid generation (the other one may still be read by the frame in flight)
     c->want_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") == nullptr;
+    c->side_wait = c->gen_free[slot];    // an asynchronous histogram call may have been the last reader of this generation
     const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 16 * slot, &L);
     c->want_side = false;
+    c->side_wait = nullptr;
     MH_TRY(erc);
     MH_HIP(hipEventRecord(T.done, c->stream));
     T.cap0 = L.cap0;
@@ -1285,7 +1288,22 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
     if (q->kind == MOLAR_HIP_SEARCH_WITHIN)
         return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_histogram: a within search has no distances");
     if (nbins == 0 || nbins > 8192) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_histogram: nbins must be in 1..8192");
-    MH_TRY(prepare_search(c, q, /*size_masks=*/false));     // the fused pass records no hit bits
+    // Device-resident bins and no count wanted: the call waits for nothing, so a loop over frames queues them back to
+    // back.  Such calls alternate between the two grid generations and build their grid on the side stream, under the
+    // histogram kernel of the frame before (each generation's last reader is marked by an event on the main stream).
+    const bool async = is_device_ptr(bins) && !out_count && !c->tickets[0].pending && !c->tickets[1].pending;
+    int gen = 0;
+    if (async) {
+        MH_HIP(hipSetDevice(c->device));
+        gen = (c->hist_gen ^= 1);
+        c->set = c->set_store[gen];
+        c->side_wait = c->gen_free[gen];
+        c->want_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") == nullptr;
+    }
+    const int prc = prepare_search(c, q, /*size_masks=*/false);     // the fused pass records no hit bits
+    c->want_side = false;
+    c->side_wait = nullptr;
+    MH_TRY(prc);
     if (out_count) *out_count = 0;
     if (c->have_search) return MOLAR_HIP_OK;     // degenerate (empty vdw input)
     // single pass: no counts, no offsets - every emitted distance goes straight into the histogram
@@ -1298,6 +1316,10 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
         hipLaunchKernelGGL(add_u64_kernel, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, c->stream,
                            reinterpret_cast<unsigned long long *>(bins), c->hist.as<unsigned long long>(), nbins);
         MH_HIP(hipGetLastError());
+        if (async) {
+            if (!c->gen_free[gen]) MH_HIP(hipEventCreateWithFlags(&c->gen_free[gen], hipEventDisableTiming));
+            MH_HIP(hipEventRecord(c->gen_free[gen], c->stream));
+        }
         if (out_count) {
             unsigned long long tot = 0;
             MH_TRY(read_back(c, &tot, c->hist.as<unsigned long long>() + nbins, 8));
