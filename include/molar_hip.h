@@ -196,7 +196,9 @@ int molar_hip_search_resident_end(molar_hip_ctx *ctx, int32_t ticket, uint64_t *
  * Histogram1D::add_one (molar_membrane/src/stats.rs:29-35): b=floor(n*(d-min)/(max-min)),
  * counted in integers (bins: uint64[nbins], accumulated INTO, so frames can be summed).  With `bins` in device
  * memory the sum stays on the GPU, and with out_count == NULL the call returns without waiting for the kernels
- * (frames of a trajectory queue up back to back; molar_hip_synchronize before reading the bins). */
+ * (frames of a trajectory queue up back to back; molar_hip_synchronize before reading the bins).  Calls of that
+ * asynchronous form on a context that owns its stream build their grid on the internal side stream under the
+ * histogram kernel of the frame before: as for _begin, the inputs must be complete in memory at the call. */
 int molar_hip_search_histogram(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, float hmin,
                                float hmax, size_t nbins, uint64_t *bins, uint64_t *out_count);
 
