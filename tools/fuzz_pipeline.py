@@ -59,7 +59,7 @@ def run(nframes=300, seed=1, verbose=True):
     for f in range(nframes):
         box = random_box(rng)
         vol = abs(np.linalg.det(box.astype(np.float64)))
-        n = int(min(max(vol * rng.choice([20.0, 60.0, 100.0]), 50), rng.choice([3000, 12000, 40000])))
+        n = int(min(max(vol * rng.choice([20.0, 60.0, 100.0, 100.0, 600.0, 2000.0]), 50), rng.choice([3000, 12000, 40000])))
         pos_h = (rng.random((n, 3)) @ box.astype(np.float64).T + rng.normal(0, rng.choice([0.0, 0.05, 0.5]), (n, 3))).astype(np.float32)
         pos = torch.from_numpy(pos_h).cuda()
         rc = float(np.float32(rng.uniform(0.25, 1.0)))
