@@ -10,8 +10,11 @@ already resident in HBM, through the whole hot path:
 Frames shard embarrassingly over ranks (one process per GPU, weak scaling: each rank owns K frames);
 the only collective is the end-of-run reduction of the pair count / RMSD sum (RCCL all_reduce).
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
-        N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload search_fit|rdf]
+        N>1 from a bare shell: the script re-launches itself as N ranks through torch.distributed.run
+        (127.0.0.1 rendezvous); under torch.distributed.run it uses the RANK/LOCAL_RANK/WORLD_SIZE it finds.
+        --workload rdf is BASELINE.json configs[3] in the same frame-sharded shape: 250k-atom frames, fused
+        1200-bin radial histogram with the bins resident in HBM, ONE all_reduce of 1200 x int64 at the end.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -51,10 +54,12 @@ def make_frames(nframes, rank, box, device):
     return frames, ref
 
 
-def cpu_baseline(frame0, ref, box, mass, idx):
-    """The oracle (a C restatement of MolAR's algorithm, NOT the Rust binary) in the reference's
-    schedule — serial grid + plan, thread pool over plan entries, serial Measure passes — on one
-    frame of the same workload, all host cores."""
+def cpu_baseline(frame0, ref, box, mass, idx, warmup=2, reps=5):
+    """The oracle (a C restatement of MolAR's algorithm, NOT the Rust binary) in the reference's schedule — serial
+    grid + plan, thread pool over plan entries, ordered concatenation, serial Measure passes — on one frame of the
+    same workload, all host cores.  BASELINE.md §3 protocol, bounded: `warmup` untimed + `reps` timed repetitions,
+    mean and standard deviation.  Only the native calls are inside the clock: the search result stays on the C side
+    and is freed after the clock stops (Oracle.time_search_single_pbc); the Measure calls return scalars."""
     from oracle.oracle import Oracle
     ncores = os.cpu_count() or 1
     o = Oracle("f32")
@@ -66,11 +71,12 @@ def cpu_baseline(frame0, ref, box, mass, idx):
     except Exception:
         pass
     n = NATOMS
-    sample = "1 frame of the same workload (1M atoms)"
+    sample = f"one 1M-atom frame of the same workload, {warmup} warm-up + {reps} timed repetitions"
     pos = frame0
     if mem_gb and mem_gb < 40:     # 3.6e8 pairs x 20 B x 2 (per-entry vectors + ordered concat)
         n = 250_000
-        sample = "250k-atom sub-box at the same density and cutoff (host RAM < 40 GB), scaled by atom count"
+        sample = (f"250k-atom sub-box at the same density and cutoff (host RAM < 40 GB), scaled by atom count, "
+                  f"{warmup} warm-up + {reps} timed repetitions")
         from molar_amd import synth
         box = synth.box_a(n)
         ob = o.box_from_matrix(box)
@@ -78,32 +84,158 @@ def cpu_baseline(frame0, ref, box, mass, idx):
         ref = synth.frame(n, box, 1)
         mass = mass[:n]
         idx = idx[idx < n]
-    t0 = time.perf_counter()
-    res = o.search_single_pbc(CUTOFF, pos, ob, 7, nthreads=ncores)
-    t1 = time.perf_counter()
-    R, t = o.fit_transform(pos, mass, ref, mass, idx, idx)
-    moved = o.apply_transform(pos, R, t, idx)
-    o.rmsd(moved, ref, idx, idx)
-    o.center_of_mass(moved, mass, idx)
-    o.gyration(moved, mass, idx)
-    t2 = time.perf_counter()
-    npairs = len(res["i"])
-    del res
     scale = NATOMS / n
-    sec = (t2 - t0) * scale
+    search_s, fit_s, npairs = [], [], 0
+    for r in range(warmup + reps):
+        dt, npairs = o.time_search_single_pbc(CUTOFF, pos, ob, 7, nthreads=ncores)
+        t1 = time.perf_counter()
+        R, t = o.fit_transform(pos, mass, ref, mass, idx, idx)
+        moved = o.apply_transform(pos, R, t, idx)
+        o.rmsd(moved, ref, idx, idx)
+        o.center_of_mass(moved, mass, idx)
+        o.gyration(moved, mass, idx)
+        t2 = time.perf_counter()
+        if r >= warmup:
+            search_s.append(dt * scale)
+            fit_s.append((t2 - t1) * scale)
+    per_frame = np.array(search_s) + np.array(fit_s)
+    fps = 1.0 / per_frame
     return {
-        "value": 1.0 / sec, "unit": "frames/s", "cores": ncores, "kind": "port",
+        "value": float(1.0 / per_frame.mean()), "unit": "frames/s", "cores": ncores, "kind": "port",
         "sample": sample,
-        "search_s": (t1 - t0) * scale, "fit_s": (t2 - t1) * scale,
-        "matom_pairs_per_sec": npairs / (t1 - t0) / 1e6,
+        "value_std": float(fps.std(ddof=1)) if len(fps) > 1 else 0.0,
+        "seconds_per_frame_mean": float(per_frame.mean()), "seconds_per_frame_std": float(per_frame.std(ddof=1)) if len(per_frame) > 1 else 0.0,
+        "search_s": float(np.mean(search_s)), "fit_s": float(np.mean(fit_s)),
+        "matom_pairs_per_sec": npairs * scale / float(np.mean(search_s)) / 1e6,
+        "timed_span": "native oracle calls only (no result copies, no frees)",
     }
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE): become the launcher of N ranks, one per GPU,
+    through torch.distributed.run with a 127.0.0.1 rendezvous, and exit with its status.  A node with fewer than N
+    GPUs is refused here, with a message, before anything is spawned."""
+    import subprocess
+    if args.backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s); one rank per GPU is required "
+                             f"(run with --gpus {max(have, 1)} or on a node with {args.gpus} GPUs)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, rank, world):
+    """Launch + collective plumbing without the GPU work (CPU test of the self-launch path, gloo): every rank
+    contributes rank+1 pairs and a 1200-bin vector through the same reductions the workloads use."""
+    from molar_amd.distributed import max_over_ranks, reduce_counts
+    bins = np.full(1200, rank + 1, np.int64)
+    tot = reduce_counts(bins)
+    pairs = int(reduce_counts([rank + 1])[0])
+    t = max_over_ranks(float(rank + 1))
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "backend": args.backend, "pairs": pairs,
+                          "bins_sum": int(tot.sum()), "max_over_ranks": t, "frames_per_gpu": args.steps}))
+
+
+def run_rdf(args, rank, local_rank, world, device):
+    """BASELINE.json configs[3] shape: each rank owns K 250k-atom frames (resident in HBM), every frame goes through
+    the fused search + Histogram1D binning (molar_membrane/src/stats.rs:29-35) into int64 bins resident on the GPU
+    (no per-frame round trip), and ONE all_reduce of 1200 x int64 (RCCL) combines the ranks at the end."""
+    import torch
+    import torch.distributed as dist
+    from molar_amd import api, build, synth
+    from molar_amd.distributed import max_over_ranks, reduce_counts
+    build.build_library()
+    n, nbins, K, W = 250_000, 1200, args.steps, args.warmup
+    box = synth.box_a(n)
+    g = torch.Generator(device=device)
+    g.manual_seed(20240607)
+    base = torch.rand((n, 3), generator=g, device=device, dtype=torch.float64) @ torch.from_numpy(box.astype(np.float64)).to(device).T
+    nres = min(K, 64)
+    frames = torch.empty((nres, n, 3), device=device, dtype=torch.float32)
+    for f in range(nres):
+        g.manual_seed(20240607 + 1 + rank * 100003 + f)
+        frames[f] = (base + (torch.randn((n, 3), generator=g, device=device, dtype=torch.float32) * 0.05).double()).float()
+    eng = api.Engine(local_rank)
+    bins = torch.zeros(nbins, dtype=torch.int64, device=device)
+
+    def run(first, count):
+        for s in range(count):
+            eng.search_histogram(api.SEARCH_SINGLE, CUTOFF, 0.0, CUTOFF, nbins, frames[(first + s) % nres], box=box, pbc=7,
+                                 bins=bins, want_count=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        eng.synchronize()
+        torch.cuda.synchronize()
+
+    run(0, W)
+    barrier()
+    bins.zero_()
+    torch.cuda.synchronize()
+    eng.profile_enable(True)
+    eng.profile_read()
+    t0 = time.perf_counter()
+    run(W, K)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    total_bins = reduce_counts(bins.cpu().numpy(), device=device)       # the only collective
+    t = max_over_ranks(elapsed, device=device)
+    if rank == 0:
+        check = None
+        if args.verify:       # rank 0 recomputes every rank's frames alone: the reduced bins must be identical
+            e2 = api.Engine(local_rank)
+            chk = torch.zeros(nbins, dtype=torch.int64, device=device)
+            for r in range(world):
+                for s in range(K):
+                    f = (W + s) % nres
+                    g.manual_seed(20240607 + 1 + r * 100003 + f)
+                    fr = (base + (torch.randn((n, 3), generator=g, device=device, dtype=torch.float32) * 0.05).double()).float()
+                    e2.search_histogram(api.SEARCH_SINGLE, CUTOFF, 0.0, CUTOFF, nbins, fr, box=box, pbc=7, bins=chk, want_count=False)
+                    e2.synchronize()
+            check = bool(np.array_equal(chk.cpu().numpy(), total_bins))
+        pairs = float(total_bins.sum())
+        hist_ms, hist_n = prof["pair_fill"]
+        print(json.dumps({
+            "metric": "frames/sec, 250k-atom frames -> fused 1200-bin radial distance histogram, bins reduced over ranks",
+            "value": K * world / t, "unit": "frames/s", "pairs_binned_per_sec": pairs / t,
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": t / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C4 shape: 250k-atom synthetic triclinic box A frames resident in HBM, rc=1.2 nm, fused "
+                                   "Histogram1D binning (1200 bins of 0.001 nm), frames sharded over ranks, one all_reduce "
+                                   "of 1200 x int64", "natoms": n, "nbins": nbins, "frames_per_gpu": K,
+                       "pairs_per_frame": pairs / (K * world)},
+            "kernel_ms_per_frame": {k: v[0] / K for k, v in prof.items()},
+            "roofline": {"kernel": "pair_kernel<SINGLE,HIST>", "bound": "valu (12*N + 8*nbins bytes per frame: not an HBM-bound "
+                         "kernel, SURVEY.md 8d)", "avg_launch_ms": hist_ms / max(hist_n, 1),
+                         "candidate_evals_per_sec": None},
+            "reduced_bins_equal_single_rank": check,
+        }))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-measure", action="store_true",
                     help="run the Kabsch fit/RMSD/COM/gyration of a frame after its search on the same stream instead of "
@@ -114,21 +246,48 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one search at a time (molar_hip_search_resident) instead of the begin/end form that keeps two "
                          "frames queued on the engine's stream (kernels still run one after the other, in order)")
+    ap.add_argument("--workload", choices=("search_fit", "rdf"), default="search_fit",
+                    help="search_fit: the headline (configs[1]+[2]); rdf: configs[3] shape (fused histogram + all_reduce)")
+    ap.add_argument("--verify", action="store_true", help="rdf: rank 0 recomputes all ranks' frames and compares the reduced bins")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default=os.environ.get("MOLAR_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend; gloo only with --launch-check (CPU test of the launch path)")
+    ap.add_argument("--launch-check", action="store_true", help="launch the ranks and run the collectives only (no GPU work)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+
+    if args.launch_check:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        launch_check(args, rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but this process sees {torch.cuda.device_count()} "
+                         "GPU(s); there is no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.workload == "rdf":
+        run_rdf(args, rank, local_rank, world, device)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from molar_amd import api, build, synth
     build.build_library()
@@ -301,7 +460,8 @@ def main():
                 traffic = json.load(open(tp)).get("pair_fill_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        copy_peak = eng.copy_bandwidth(1 << 30, 10)                # float4 copy kernel, same run
+        copy_peak = eng.copy_bandwidth(1 << 30, 10)                # best float4 copy kernel, same run
+        write_peak = eng.write_bandwidth(1 << 30, 10)              # write-only float4 stream, same run
         line = {
             "metric": "frames/sec + Matom-pairs/sec, 1M-atom PBC neighbor search + RMSD fit",
             "value": frames_total / t,
@@ -330,8 +490,11 @@ def main():
             "roofline": {
                 "kernel": "pair_kernel<SINGLE,FILL>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/traffic.json (rocprofv3 PMC FETCH_SIZE/WRITE_SIZE passes, separate run of this command)",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fill_avg_ms,
+                "end_to_end_frac": alg_bytes * frames_total / t / 1e9 / HBM_PEAK_GBS / world,
                 "copy_peak_measured": copy_peak, "frac_of_copy_peak": achieved / copy_peak if copy_peak > 0 else None,
+                "write_peak_measured": write_peak, "frac_of_write_peak": achieved / write_peak if write_peak > 0 else None,
             },
         }
         if not args.no_cpu_baseline and world == 1:

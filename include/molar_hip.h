@@ -83,10 +83,13 @@ int molar_hip_profile_enable(molar_hip_ctx *ctx, int on);
 int molar_hip_profile_read(molar_hip_ctx *ctx, float ms[MOLAR_HIP_PROFILE_CLASSES],
                            uint64_t launches[MOLAR_HIP_PROFILE_CLASSES]);
 
-/* Device-copy ceiling of this GPU (SURVEY.md §8d "measured device-copy ceiling from a trivial float4 copy
- * kernel in the same run"): copies `bytes` device-to-device `reps` times with a grid-stride float4 kernel on the
- * context's stream and returns (read + written bytes) / time in GB/s.  Diagnostic, not part of the reference. */
+/* Device-memory ceilings of this GPU, measured in the caller's process (SURVEY.md §8d "measured device-copy ceiling
+ * from a trivial float4 copy kernel in the same run").  copy: `bytes` device-to-device `reps` times, best of three
+ * float4 kernels (grid-stride; four loads in flight per thread; the same non-temporal), (read + written bytes) / time.
+ * write: a write-only float4 stream of `bytes` (the pair list is write traffic), bytes / time.  GB/s.
+ * Diagnostics, not part of the reference. */
 int molar_hip_copy_bandwidth(molar_hip_ctx *ctx, size_t bytes, int reps, float *gb_per_s);
+int molar_hip_write_bandwidth(molar_hip_ctx *ctx, size_t bytes, int reps, float *gb_per_s);
 
 /* ------------------------------------------------------------------ PeriodicBox (periodic_box.rs:15-23) */
 

@@ -58,6 +58,7 @@ SYMBOLS = {
     "molar_hip_box_from_vectors_angles": (_I, [_F, _F, _F, _F, _F, _F, _P]),
     "molar_hip_box_shortest_vector": (None, [_P, _P, _U8, _P]),
     "molar_hip_copy_bandwidth": (_I, [_P, _SZ, _I, _P]),
+    "molar_hip_write_bandwidth": (_I, [_P, _SZ, _I, _P]),
     "molar_hip_box_lab_extents": (None, [_P, _P]),
     "molar_hip_box_extents": (None, [_P, _P]),
     "molar_hip_box_to_box_coords": (None, [_P, _P, _P]),

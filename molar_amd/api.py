@@ -38,6 +38,24 @@ def _addr(x):
     return x.ctypes.data, x
 
 
+class _DevicePointer:
+    """__cuda_array_interface__ holder for memory the engine owns (result buffers of the resident search)."""
+
+    def __init__(self, addr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (int(addr), False), "version": 2}
+
+
+def device_view(addr, shape, dtype):
+    """A torch CUDA tensor over `addr` (no copy).  The memory stays owned by the engine: the view is valid until the
+    next search on the same context (or result set, for the begin/end form) reuses the buffer."""
+    import torch
+    count = int(np.prod(shape))
+    if count == 0:
+        return torch.empty(shape, dtype=dtype, device="cuda")
+    typestr = {torch.int32: "<i4", torch.float32: "<f4", torch.int64: "<i8", torch.uint8: "|u1"}[dtype]
+    return torch.as_tensor(_DevicePointer(addr, count, typestr), device="cuda").view(*shape)
+
+
 def _f32(x, shape=None):
     if x is None:
         return None
@@ -474,9 +492,15 @@ class Engine:
         return out[:nout]
 
     def copy_bandwidth(self, nbytes=1 << 30, reps=10) -> float:
-        """Measured device-to-device copy rate in GB/s (read + write) of a float4 grid-stride kernel."""
+        """Measured device-to-device copy rate in GB/s (read + write), best of the library's float4 copy kernels."""
         out = C.c_float(0)
         check(self.lib.molar_hip_copy_bandwidth(self.ctx, int(nbytes), int(reps), C.byref(out)))
+        return float(out.value)
+
+    def write_bandwidth(self, nbytes=1 << 30, reps=10) -> float:
+        """Measured write-only float4 stream rate in GB/s."""
+        out = C.c_float(0)
+        check(self.lib.molar_hip_write_bandwidth(self.ctx, int(nbytes), int(reps), C.byref(out)))
         return float(out.value)
 
     def membrane_smooth(self, box, state, patch_offsets, patch_ids):

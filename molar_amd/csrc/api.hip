@@ -3,8 +3,106 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include <cstdlib>
 
 using namespace mh;
+
+// Device-memory ceilings measured in the same process as the benchmark.  Three copy shapes: a plain
+// grid-stride float4 copy, four independent 16-byte loads in flight per thread, and the same with non-temporal
+// accesses (one CU then keeps 4x the bytes in flight; the guide's 6.3 TB/s figure needs that).  The best one is reported.
+typedef float v4f_copy __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void k_copy_f4x4(const v4f_copy *__restrict__ src, v4f_copy *__restrict__ dst, size_t n) {
+    // n is a multiple of 1024: every block iteration moves 1024 float4 (16 KiB), four per thread, 256 apart
+    for (size_t i = (size_t)blockIdx.x * 1024u + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024u) {
+        v4f_copy v0, v1, v2, v3;
+        if (NT) {
+            v0 = __builtin_nontemporal_load(src + i);
+            v1 = __builtin_nontemporal_load(src + i + 256);
+            v2 = __builtin_nontemporal_load(src + i + 512);
+            v3 = __builtin_nontemporal_load(src + i + 768);
+            __builtin_nontemporal_store(v0, dst + i);
+            __builtin_nontemporal_store(v1, dst + i + 256);
+            __builtin_nontemporal_store(v2, dst + i + 512);
+            __builtin_nontemporal_store(v3, dst + i + 768);
+        } else {
+            v0 = src[i]; v1 = src[i + 256]; v2 = src[i + 512]; v3 = src[i + 768];
+            dst[i] = v0; dst[i + 256] = v1; dst[i + 512] = v2; dst[i + 768] = v3;
+        }
+    }
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void k_write_f4x4(v4f_copy *__restrict__ dst, size_t n) {
+    const v4f_copy v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+    for (size_t i = (size_t)blockIdx.x * 1024u + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024u) {
+        if (NT) {
+            __builtin_nontemporal_store(v, dst + i);
+            __builtin_nontemporal_store(v, dst + i + 256);
+            __builtin_nontemporal_store(v, dst + i + 512);
+            __builtin_nontemporal_store(v, dst + i + 768);
+        } else {
+            dst[i] = v; dst[i + 256] = v; dst[i + 512] = v; dst[i + 768] = v;
+        }
+    }
+}
+
+// mode 0: copy (bytes read + bytes written per second), mode 1: write-only stream
+static int bandwidth_probe(molar_hip_ctx *c, size_t bytes, int reps, int mode, float *gbs) {
+    if (!c || !gbs || reps < 1 || bytes < 16384) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "bandwidth probe: bad argument");
+    MH_HIP(hipSetDevice(c->device));
+    const size_t n = (bytes / 16) & ~(size_t)1023;
+    float4 *a = nullptr, *b = nullptr;
+    MH_HIP(hipMalloc((void **)&a, n * 16));
+    if (hipMalloc((void **)&b, n * 16) != hipSuccess) {
+        (void)hipFree(a);
+        return fail(MOLAR_HIP_ERR_HIP, "bandwidth probe: out of device memory");
+    }
+    (void)hipMemsetAsync(a, 0, n * 16, c->stream);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best = 0.f;
+    hipError_t err = hipSuccess;
+    const unsigned grids[2] = {(unsigned)std::min<size_t>(n / 1024, (size_t)c->num_cus * 8),
+                               (unsigned)std::min<size_t>(n / 1024, (size_t)c->num_cus * 32)};
+    for (int variant = 0; variant < (mode == 0 ? 6 : 4) && err == hipSuccess; ++variant) {
+        const unsigned grid = grids[variant & 1];
+        auto launch = [&]() {
+            const v4f_copy *s4 = reinterpret_cast<const v4f_copy *>(a);
+            v4f_copy *d4 = reinterpret_cast<v4f_copy *>(b);
+            if (mode == 0) {
+                if (variant < 2) hipLaunchKernelGGL(k_copy_f4, dim3(grid * 4), dim3(256), 0, c->stream, a, b, n);
+                else if (variant < 4) hipLaunchKernelGGL(k_copy_f4x4<false>, dim3(grid), dim3(256), 0, c->stream, s4, d4, n);
+                else hipLaunchKernelGGL(k_copy_f4x4<true>, dim3(grid), dim3(256), 0, c->stream, s4, d4, n);
+            } else {
+                if (variant < 2) hipLaunchKernelGGL(k_write_f4x4<false>, dim3(grid), dim3(256), 0, c->stream, d4, n);
+                else hipLaunchKernelGGL(k_write_f4x4<true>, dim3(grid), dim3(256), 0, c->stream, d4, n);
+            }
+        };
+        launch();   // warm-up
+        (void)hipEventRecord(e0, c->stream);
+        for (int r = 0; r < reps; ++r) launch();
+        (void)hipEventRecord(e1, c->stream);
+        err = hipStreamSynchronize(c->stream);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (err == hipSuccess && ms > 0.f) {
+            const float r = (float)((mode == 0 ? 2.0 : 1.0) * (double)(n * 16) * reps / (ms * 1e-3) / 1e9);
+            if (r > best) best = r;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    if (err != hipSuccess || !(best > 0.f)) return fail(MOLAR_HIP_ERR_HIP, "bandwidth probe: %s", hipGetErrorString(err));
+    *gbs = best;
+    return MOLAR_HIP_OK;
+}
+
 
 extern "C" {
 
@@ -52,6 +150,11 @@ molar_hip_ctx *molar_hip_create(int device) {
         return nullptr;
     }
     c->own_stream = true;
+    // environment knobs are read here, once: the per-search paths never call getenv
+    c->env_no_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") != nullptr;
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+    if (const char *dbg = std::getenv("MOLAR_HIP_DEBUG_SKIP")) c->env_debug_skip = (uint32_t)std::atoi(dbg);
+#endif
     if (ensure_pinned(c, 1 << 16)) {
         (void)hipStreamDestroy(c->stream);
         delete c;
@@ -135,40 +238,8 @@ int molar_hip_profile_read(molar_hip_ctx *c, float ms[MOLAR_HIP_PROFILE_CLASSES]
     return MOLAR_HIP_OK;
 }
 
-__global__ __launch_bounds__(256) void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
-}
-
-int molar_hip_copy_bandwidth(molar_hip_ctx *c, size_t bytes, int reps, float *gbs) {
-    if (!c || !gbs || reps < 1 || bytes < 16) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "copy_bandwidth: bad argument");
-    MH_HIP(hipSetDevice(c->device));
-    const size_t n = bytes / 16;
-    float4 *a = nullptr, *b = nullptr;
-    MH_HIP(hipMalloc((void **)&a, n * 16));
-    if (hipMalloc((void **)&b, n * 16) != hipSuccess) {
-        (void)hipFree(a);
-        return fail(MOLAR_HIP_ERR_HIP, "copy_bandwidth: out of device memory");
-    }
-    (void)hipMemsetAsync(a, 0, n * 16, c->stream);
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
-    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->num_cus * 32);
-    hipLaunchKernelGGL(k_copy_f4, dim3(grid), dim3(256), 0, c->stream, a, b, n);   // warm-up
-    (void)hipEventRecord(e0, c->stream);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy_f4, dim3(grid), dim3(256), 0, c->stream, a, b, n);
-    (void)hipEventRecord(e1, c->stream);
-    hipError_t err = hipStreamSynchronize(c->stream);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(a);
-    (void)hipFree(b);
-    if (err != hipSuccess || !(ms > 0.f)) return fail(MOLAR_HIP_ERR_HIP, "copy_bandwidth: %s", hipGetErrorString(err));
-    *gbs = (float)(2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9);
-    return MOLAR_HIP_OK;
-}
+int molar_hip_copy_bandwidth(molar_hip_ctx *c, size_t bytes, int reps, float *gbs) { return bandwidth_probe(c, bytes, reps, 0, gbs); }
+int molar_hip_write_bandwidth(molar_hip_ctx *c, size_t bytes, int reps, float *gbs) { return bandwidth_probe(c, bytes, reps, 1, gbs); }
 
 // ---------------------------------------------------------------- PeriodicBox constructors (host)
 

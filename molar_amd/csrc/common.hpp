@@ -136,6 +136,8 @@ struct molar_hip_ctx {
     hipStream_t side_stream = nullptr;   // grid build of a pipelined search (created on first use, highest priority)
     hipEvent_t grid_done = nullptr;
     bool want_side = false;              // set by _begin / the asynchronous histogram call around their enqueue
+    bool env_no_side = false;            // MOLAR_HIP_NO_SIDE_STREAM, read once in molar_hip_create
+    uint32_t env_debug_skip = 0;         // MOLAR_HIP_DEBUG_SKIP (builds with -DMOLAR_HIP_DEBUG_KNOBS only), read once
     hipEvent_t gen_free[2] = {nullptr, nullptr};   // recorded on the main stream behind the last asynchronous reader of
                                                    // a grid generation (histogram calls that do not wait)
     hipEvent_t side_wait = nullptr;      // what the side stream has to wait for before it rebuilds the generation

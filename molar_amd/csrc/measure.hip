@@ -351,6 +351,13 @@ __global__ void __launch_bounds__(64) k_lipid_order(const float *__restrict__ xy
                 order[i] = -(2.0f * sxx + syy) / 3.0f;
             }
         } else {
+            // a double bond at bond 0 has no C(i-1); at the last bond it has no normal for atom i+1 when normals are
+            // per bond.  The reference indexes out of range there (usize underflow panic / unchecked read,
+            // measure.rs:361-364,385): refuse the tail instead of touching memory outside it.
+            if (i == 0 || (nn != 1 && i + 1 >= nn)) {
+                atomicMax(status, MOLAR_HIP_ERR_INVALID_ARGUMENT);
+                return;
+            }
             const F3 p1 = P(i - 1), p2 = P(i), p3 = P(i + 1), p4 = P(i + 2);
             const float a1 = 0.5f * (pi - f3angle(f3sub(p1, p2), f3sub(p3, p2)));
             const float a2 = 0.5f * (pi - f3angle(f3sub(p2, p3), f3sub(p4, p3)));
@@ -508,6 +515,9 @@ int com_host(molar_hip_ctx *c, const Sel &s, float out[3]) {
 
 // center_of_mass_pbc_dims (:197-220): cm starts at the UNWEIGHTED first position, mass at m0
 int com_pbc_host(molar_hip_ctx *c, const Sel &s, const molar_hip_box &box, uint8_t pbc, bool weighted, float out[3]) {
+    // the periodic centres are taken relative to the selection's FIRST atom (measure.rs:149,180): an empty selection has
+    // none (MolAR cannot construct one, sel.rs:13-19)
+    if (s.n == 0) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "periodic centre of an empty selection");
     double r[7];
     MH_TRY(reduce1(c, s.n, 7, r, [&](uint32_t nb, double *part) {
         hipLaunchKernelGGL(k_sums_pbc, dim3(nb, 1), dim3(RB), 0, c->stream, s, box, (uint32_t)pbc, part);
@@ -967,6 +977,7 @@ int molar_hip_unwrap_simple(molar_hip_ctx *c, float *xyz, size_t natoms, const u
     MH_CTX(c);
     molar_hip_box b;
     MH_TRY(box_or_err(box9, &b));
+    if (idx ? n == 0 : natoms == 0) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "unwrap_simple of an empty selection");
     Sel s;
     MH_TRY(stage_sel(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
     if (s.n > 1) {

@@ -81,7 +81,9 @@ struct SearchParams {
     uint32_t hist_nbins;     // != 0: the fill traversal feeds a histogram instead of writing pairs
     float hist_min, hist_max;
     unsigned long long *hist_bins;    // [nbins] + [1] total
+#ifdef MOLAR_HIP_DEBUG_KNOBS
     uint32_t debug_skip;     // profiling aid (env MOLAR_HIP_DEBUG_SKIP): bit0 plain, bit1 wrapped, bit2 triangular slots do nothing
+#endif
     float cutoff2;
     uint64_t ntasks;
     molar_hip_box box;
@@ -1072,10 +1074,12 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
         }
         uint32_t total = 0;
         const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
-        if (P.debug_skip) {
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+        if (P.debug_skip) {     // not in release builds: tools/dbg_skip.sh builds with -DMOLAR_HIP_DEBUG_KNOBS
             const uint32_t kind_bit = T.tri ? 4u : (wk != WK_NONE ? 2u : 1u);
             if (P.debug_skip & kind_bit) return;
         }
+#endif
         // count/fill pair: the count pass records the hit bits of the fast-path slots, the fill pass replays them
         constexpr bool MASKED = MODE != MODE_HIST;
         uint32_t *mwords = nullptr;

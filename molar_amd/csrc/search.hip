@@ -711,14 +711,22 @@ SearchParams make_params(molar_hip_ctx *c) {
             if (((c->pbc >> d) & 1u) && c->dims[d] < 3u) ok = false;
         P.prune_wrapped = ok ? 1u : 0u;
     }
-    const float lim = c->cutoff + 1.0e-3f;
-    P.prune_limit2 = lim * lim;
-    // Wrapped entries: classify with the plain distance to the image cell, decide exactly inside a band
-    // around cutoff^2.  Both evaluations carry a few ulp(L) of absolute error in each component of the
-    // difference vector (L = largest lab extent), i.e. <= ~2*sqrt(3)*rc*8*ulp(L) in d2, which relative to
-    // rc^2 is ~1.7e-6 * L/rc; the band is 2e-4 + 1e-5 * L/rc, more than 10x that for any box.
+    // Wrapped entries: classify with the plain distance to the image cell (b + S - a), decide exactly inside a band
+    // around cutoff^2, and prune rows against the image box with a margin.  How far can the two evaluations of a
+    // wrapped difference vector disagree?  u = 2^-24, L = largest |coordinate| the box allows (lab extents, box
+    // vectors), kappa = || |M| |M^-1| ||_inf (1 for a rectangular box, grows with shear):
+    //   reference (periodic_box.rs:291-297): v = p2 - p1 (error <= u L per component), f = inv v (3 products, 2 sums:
+    //     <= 4u sum|inv||v| per component), s = M f (the error of f amplified by |M|: <= 4u kappa L, plus 4u L of
+    //     its own roundings)                                            => <= (4 kappa + 5) u L per component
+    //   approximate: S summed from box columns (<= 2u L), b + S (u L), - a (u L)   => <= 4u L per component
+    // so a component of the difference vector differs by at most e = (4 kappa + 9) u L, a distance by sqrt(3) e, and
+    // d2 near cutoff^2 by 2 sqrt(3) rc e, i.e. by 2 sqrt(3) (4 kappa + 9) u L/rc relative to cutoff^2.  The band is
+    // 2e-4 plus FOUR times that; the pruning margin is 1e-3 nm plus four times sqrt(3) e.  Both therefore scale with
+    // the box size AND its shear; boxes for which the band would exceed 5 % of cutoff^2 or the margin 5 % of the
+    // cutoff take the exact path for every wrapped candidate.
     P.approx_wrapped = 0u;
     P.band_lo = P.band_hi = P.cutoff2;
+    float margin = 1.0e-3f;
     if (c->use_box) {
         bool ok = (uint64_t)c->set[0].n + (uint64_t)c->set[1].n < (1ull << 26);   // (row<<26 | position) packing
         float ext[3], lmax = 0.f;
@@ -728,15 +736,43 @@ SearchParams make_params(molar_hip_ctx *c) {
             lmax = std::fmax(lmax, std::fabs(ext[d]));
             for (int k = 0; k < 3; ++k) lmax = std::fmax(lmax, std::fabs(c->box.m[3 * k + d]));
         }
-        const float rel = 2.0e-4f + 1.0e-5f * (lmax / c->cutoff);
-        if (ok && rel < 0.05f) {
+        // atoms sit inside the cell along periodic dims, so a coordinate is bounded by the sum of the |box vectors|
+        float lsum = 0.f;
+        for (int d = 0; d < 3; ++d) {
+            float row = 0.f;
+            for (int k = 0; k < 3; ++k) row += std::fabs(c->box.m[3 * k + d]);
+            lsum = std::fmax(lsum, row);
+        }
+        lmax = std::fmax(lmax, lsum);
+        double kappa = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            double row = 0.0;
+            for (int j = 0; j < 3; ++j) {
+                double e = 0.0;
+                for (int k = 0; k < 3; ++k) e += std::fabs((double)c->box.m[3 * k + i]) * std::fabs((double)c->box.inv[3 * j + k]);
+                row += e;
+            }
+            kappa = std::fmax(kappa, row);
+        }
+        const double u = 5.9604645e-8;
+        const double e = (4.0 * kappa + 9.0) * u * (double)lmax;                   // per-component disagreement bound
+        const double rel = 2.0e-4 + 4.0 * 2.0 * 1.7320508 * e / (double)c->cutoff;
+        margin = (float)(1.0e-3 + 4.0 * 1.7320508 * e);
+        if (!(margin < 0.05f * c->cutoff) || !std::isfinite(kappa)) {
+            P.prune_wrapped = 0u;
+            ok = false;
+        }
+        if (ok && rel < 0.05) {
             P.approx_wrapped = 1u;
-            P.band_lo = P.cutoff2 * (1.0f - rel);
-            P.band_hi = P.cutoff2 * (1.0f + rel);
+            P.band_lo = P.cutoff2 * (float)(1.0 - rel);
+            P.band_hi = P.cutoff2 * (float)(1.0 + rel);
         }
     }
-    const char *dbg = std::getenv("MOLAR_HIP_DEBUG_SKIP");
-    P.debug_skip = dbg ? (uint32_t)std::atoi(dbg) : 0u;
+    const float lim = c->cutoff + margin;
+    P.prune_limit2 = lim * lim;
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+    P.debug_skip = c->env_debug_skip;
+#endif
     return P;
 }
 
@@ -1147,7 +1183,7 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     T.desc = *q;
     ResidentLaunch L;
     c->set = c->set_store[slot];         // this ticket's grid generation (the other one may still be read by the frame in flight)
-    c->want_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") == nullptr;
+    c->want_side = !c->env_no_side;
     c->side_wait = c->gen_free[slot];    // an asynchronous histogram call may have been the last reader of this generation
     const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 16 * slot, &L);
     c->want_side = false;
@@ -1298,7 +1334,7 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
         gen = (c->hist_gen ^= 1);
         c->set = c->set_store[gen];
         c->side_wait = c->gen_free[gen];
-        c->want_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") == nullptr;
+        c->want_side = !c->env_no_side;
     }
     const int prc = prepare_search(c, q, /*size_masks=*/false);     // the fused pass records no hit bits
     c->want_side = false;

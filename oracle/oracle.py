@@ -200,6 +200,21 @@ class Oracle:
         return self._take(self.lib.orc_search_single_pbc(
             cutoff, self._p(pos), self._p(ids), len(pos), C.cast(C.byref(box), C.c_void_p), pbc_mask(dims), nthreads))
 
+    def time_search_single_pbc(self, cutoff, pos, box, dims=PBC_FULL, nthreads=1):
+        """Benchmark helper: runs orc_search_single_pbc and returns (seconds spent inside the C call, number of pairs).
+        The result stays on the C side and is freed after the clock has stopped: no numpy copies in the timed span."""
+        import time
+        pos = self.arr(pos, (-1, 3))
+        pp, bp, m = self._p(pos), C.cast(C.byref(box), C.c_void_p), pbc_mask(dims)
+        t0 = time.perf_counter()
+        ptr = self.lib.orc_search_single_pbc(cutoff, pp, None, len(pos), bp, m, nthreads)
+        dt = time.perf_counter() - t0
+        if not ptr:
+            raise RuntimeError("oracle search refused the grid (too many cells)")
+        n = int(ptr.contents.n)
+        self.lib.orc_pairs_free(ptr)
+        return dt, n
+
     def search_double(self, cutoff, pos1, pos2, ids1=None, ids2=None, nthreads=1):
         pos1 = self.arr(pos1, (-1, 3)); pos2 = self.arr(pos2, (-1, 3)); ids1 = self._ids(ids1); ids2 = self._ids(ids2)
         return self._take(self.lib.orc_search_double(

@@ -10,7 +10,8 @@ environment (no cargo/rustc, no network), so NONE of these vectors comes from ru
                                        ordered results, f64 build for float results).  They pin the oracle and
                                        the HIP path against regressions and against each other; by themselves
                                        they do not prove agreement with MolAR ("parity unpinned").
-  * full_size_digests.json           — SHA-256 of the oracle's ordered pair lists on larger seeded frames.
+  * ordered_pair_digests.json        — SHA-256 of the oracle's ordered pair lists on larger seeded frames, including
+                                       BASELINE config 2 at full size (1M atoms, rc 1.2: `python make_golden.py c2`).
 Run from the repository root:  python tests/golden/make_golden.py
 """
 import hashlib
@@ -146,11 +147,33 @@ def make_digests(o32):
         h.update(r["i"].astype("<u4").tobytes()); h.update(r["j"].astype("<u4").tobytes()); h.update(r["d"].astype("<f4").tobytes())
         dig[name] = dict(natoms=n, cutoff=rc, box=name.split("_")[0] + "_" + name.split("_")[1], npairs=int(len(r["i"])),
                          dims=list(r["dims"]), sha256_i_j_d=h.hexdigest())
-    json.dump(dig, open(os.path.join(HERE, "full_size_digests.json"), "w"), indent=1)
+    json.dump(dig, open(os.path.join(HERE, "ordered_pair_digests.json"), "w"), indent=1)
+
+
+def make_c2_digest(o32, nthreads=8):
+    """BASELINE.json configs[1] at its full size: the 1M-atom box-A frame 0 at rc = 1.2 nm (3.6e8 ordered pairs).  Needs
+    ~25 GB of host memory and a few minutes on 8 cores; kept out of the default run (python make_golden.py c2)."""
+    n, rc = 1_000_000, 1.2
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 0)
+    r = o32.search_single_pbc(rc, pos, o32.box_from_matrix(box), 7, nthreads=nthreads)
+    h = hashlib.sha256()
+    step = 1 << 24
+    for key, dt in (("i", "<u4"), ("j", "<u4"), ("d", "<f4")):
+        for k in range(0, len(r[key]), step):
+            h.update(r[key][k:k + step].astype(dt).tobytes())
+    path = os.path.join(HERE, "ordered_pair_digests.json")
+    dig = json.load(open(path))
+    dig["tric_a_1000000_rc1.2"] = dict(natoms=n, cutoff=rc, box="tric_a", npairs=int(len(r["i"])), dims=list(r["dims"]),
+                                       sha256_i_j_d=h.hexdigest())
+    json.dump(dig, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":
     o32, o64 = Oracle("f32"), Oracle("f64")
+    if sys.argv[1:] == ["c2"]:
+        make_c2_digest(o32)
+        sys.exit(0)
     make_search(o32)
     make_measure(o32, o64)
     make_membrane(o32)

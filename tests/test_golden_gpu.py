@@ -103,10 +103,12 @@ def test_membrane_fixture(eng):
     assert np.array_equal(st["head_markers"][~ok], g["head"][~ok]) or K == ok.sum()
 
 
-def test_full_size_digests(eng):
+def test_ordered_pair_digests(eng):
     from molar_amd import api as a, synth
-    dig = json.load(open(os.path.join(G, "full_size_digests.json")))
+    dig = json.load(open(os.path.join(G, "ordered_pair_digests.json")))
     for name, d in dig.items():
+        if d["natoms"] > 100_000:
+            continue                    # the 1M-atom entry is hashed in chunks from HBM in tests/test_gpu_full_size.py
         box = (synth.box_a if d["box"] == "tric_a" else synth.box_b)(d["natoms"])
         pos = synth.frame(d["natoms"], box, 0)
         n = eng.search_count(a.SEARCH_SINGLE, d["cutoff"], pos, box=box, pbc=7)

@@ -200,6 +200,45 @@ def test_lipid_tail_order_errors(eng):
     assert e.value.code == 9                                       # BondOrderCount (:289-291)
 
 
+def test_lipid_tail_order_misplaced_double_bond(eng):
+    """A double bond at bond 0 has no C(i-1), one at the last bond no normal for atom i+1 when normals are per bond:
+    the reference indexes out of range there (measure.rs:361-364,385).  The engine refuses the tail and touches
+    nothing outside it."""
+    from molar_amd._lib import MolarHipError
+    rng = np.random.default_rng(13)
+    xyz, tails, bonds, n1, nN = _random_tails(rng, 4, 200)
+    t, n = tails[0], len(tails[0])
+    lead = np.ones(n - 1, np.uint8); lead[0] = 2
+    trail = np.ones(n - 1, np.uint8); trail[n - 3] = 2
+    for order_type in (1, 2):
+        for normals, b in ((n1[0], lead), (nN[0], lead), (nN[0], trail)):
+            with pytest.raises(MolarHipError) as e:
+                eng.lipid_tail_order(xyz, [t], order_type, [normals], [b])
+            assert e.value.code == 50
+        # with ONE normal for the whole tail the trailing double bond is inside the reference's ranges
+        got = eng.lipid_tail_order(xyz, [t], order_type, [n1[0]], [trail])
+        assert np.isfinite(got[0]).all() and got[0].shape == (n - 2,)
+
+
+def test_empty_selection_is_refused(eng):
+    """The reference cannot build an empty selection (sel.rs:13-19); with n == 0 the PBC centre / gyration / inertia /
+    unwrap entry points return INVALID_ARGUMENT before any launch instead of reading atom 0."""
+    from molar_amd import synth
+    from molar_amd._lib import MolarHipError
+    box = synth.box_a(1000)
+    xyz = synth.frame(1000, box, 0)
+    mass = synth.masses(1000)
+    none = np.zeros(0, np.uint64)
+    for call in (lambda: eng.center_of_mass_pbc(xyz, mass, box, 7, none),
+                 lambda: eng.center_of_geometry_pbc(xyz, box, 7, none),
+                 lambda: eng.gyration(xyz, mass, none, box=box),
+                 lambda: eng.inertia(xyz, mass, none, box=box),
+                 lambda: eng.unwrap_simple(xyz.copy(), box, 7, none)):
+        with pytest.raises(MolarHipError) as e:
+            call()
+        assert e.value.code == 50
+
+
 def test_principal_transform_translate_rotate(eng, orc64):
     """measure.rs:100-109,646-649 and modify.rs:16-30 on the host mirror: after principal_transform the inertia
     tensor is diagonal with ascending moments and the centre of mass has not moved; translate/rotate equal the

@@ -61,23 +61,26 @@ def check_smooth(got, want, patch_off, K, tol=2e-5):
         assert np.allclose(got[g][ok], want[w][ok], rtol=tol, atol=tol), g
 
 
-def test_membrane_pipeline_matches_oracle(eng, orc32):
+def run_pipeline_check(eng, orc32, per_leaflet, natoms):
+    """Membrane.compute on a synthetic bilayer against the same pipeline assembled from the oracle's primitives."""
     from molar_amd import membrane as mb
-    xyz, box, first, tpl, masses = mb.build_bilayer(200, 40000)
+    xyz, box, first, tpl, masses = mb.build_bilayer(per_leaflet, natoms)
     K = len(first)
     m = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(cutoff=1.5, order_type=1))
     work = xyz.copy()
     res = m.compute(work, box)
     ob = orc32.box_from_matrix(box)
-    # unwrap per lipid (exact f32 arithmetic)
+    # unwrap per lipid (exact f32 arithmetic); a lipid's unwrap touches only its own atoms, so the oracle works on slices
     ref_xyz = xyz.copy()
+    na = tpl.natoms
     for k in range(K):
-        idx = np.arange(first[k], first[k] + tpl.natoms, dtype=np.uint64)
-        ref_xyz = orc32.unwrap_simple_dim(ref_xyz, ob, 7, idx)
+        f0 = int(first[k])
+        ref_xyz[f0:f0 + na] = orc32.unwrap_simple_dim(ref_xyz[f0:f0 + na], ob, 7)
     assert np.array_equal(work, ref_xyz)
     # markers: centre of mass per sub-selection
     for name, sub in (("head", tpl.head), ("mid", tpl.mid), ("tail", tpl.tail_end)):
-        want = np.array([orc32.center_of_mass(ref_xyz, masses, first[k] + sub.astype(np.uint64)) for k in range(K)])
+        want = np.array([orc32.center_of_mass(ref_xyz[int(first[k]):int(first[k]) + na], masses[int(first[k]):int(first[k]) + na],
+                                              sub.astype(np.uint64)) for k in range(K)])
         assert np.allclose(res[name], want, rtol=2e-6, atol=2e-6)
     # patches from the GPU markers (the search itself is bit-exact given identical input)
     r = orc32.search_single_pbc(1.5, res["head"], ob, 7)
@@ -93,7 +96,7 @@ def test_membrane_pipeline_matches_oracle(eng, orc32):
     assert np.allclose(res["initial_normals"], want_n, atol=2e-6)
     assert np.allclose(np.linalg.norm(res["initial_normals"], axis=1), 1.0, atol=1e-5)
     # upper leaflet normals point up, lower down (tails towards the mid-plane)
-    assert (res["initial_normals"][:200, 2] > 0.8).all() and (res["initial_normals"][200:, 2] < -0.8).all()
+    assert (res["initial_normals"][:per_leaflet, 2] > 0.8).all() and (res["initial_normals"][per_leaflet:, 2] < -0.8).all()
     # one smoothing pass (lib.rs:661-812) against the oracle's restatement on the same inputs
     so = orc32.membrane_smooth(ob, res["head"], res["initial_normals"], np.ones(K, np.uint8), res["patch_off"], res["patch_ids"])
     check_smooth(res, so, res["patch_off"], K)
@@ -102,11 +105,25 @@ def test_membrane_pipeline_matches_oracle(eng, orc32):
         for k in range(0, K, 7):
             if not res["valid"][k]:
                 continue
-            want = orc32.lipid_tail_order(ref_xyz, 1, res["normals"][k][None, :], tpl.bond_orders[t],
-                                          idx=first[k] + carbons.astype(np.uint64))
+            f0 = int(first[k])
+            want = orc32.lipid_tail_order(ref_xyz[f0:f0 + na], 1, res["normals"][k][None, :], tpl.bond_orders[t],
+                                          idx=carbons.astype(np.uint64))
             assert np.allclose(res["order"][t][k], want, atol=3e-5)
     # roughly ordered chains along the normal: mean |Scd| in a sensible range
     assert 0.05 < np.abs(np.concatenate([o.reshape(-1) for o in res["order"]])).mean() < 0.6
+    return K, int(np.count_nonzero(res["valid"]))
+
+
+def test_membrane_pipeline_matches_oracle(eng, orc32):
+    run_pipeline_check(eng, orc32, 200, 40000)
+
+
+@pytest.mark.timeout(1500)
+def test_membrane_pipeline_at_baseline_size(eng, orc32):
+    """BASELINE.json configs[4]: the 500k-atom bilayer (2 x 2000 lipids) through Membrane.compute.  Validity, Voronoi
+    neighbour ids and vertex counts exact, floats within 2e-5 of the f32 oracle pipeline."""
+    K, nvalid = run_pipeline_check(eng, orc32, 2000, 500_000)
+    assert K == 4000 and nvalid > 3900
 
 
 def _patches_from_oracle(o, ob, head, cutoff):

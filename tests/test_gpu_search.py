@@ -459,6 +459,55 @@ def test_wrapped_pairs_at_the_cutoff_edge(eng, orc32, boxkind):
     assert c2 == cnt and np.array_equal(bins, want)
 
 
+def _boundary_pairs(box, rc, npairs, seed, emin=-6.0, emax=-4.0):
+    """Pairs that cross a periodic face with distance rc*(1 +- 10^e), e uniform in [emin, emax]."""
+    rng = np.random.default_rng(seed)
+    M = box.astype(np.float64)
+    L = float(np.abs(M).sum(1).max())
+    pts = []
+    while len(pts) < 2 * npairs:
+        fa = rng.random(3)
+        dim = int(rng.integers(0, 3))
+        fa[dim] = 1.0 - (0.5 * rc / L) * rng.random()
+        a = M @ fa
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        e = 10.0 ** rng.uniform(emin, emax) * rng.choice([-1.0, 1.0])
+        b = a + rc * (1.0 + e) * u
+        fb = np.linalg.solve(M, b)
+        if not ((fb < 0) | (fb >= 1)).any():
+            continue
+        pts.append(a); pts.append(M @ (fb % 1.0))
+    return np.array(pts, np.float32)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("boxkind,L", [("dodecahedron", 60.0), ("sheared", 40.0), ("sheared_huge", 160.0)])
+def test_wrapped_band_adversarial_large_sheared_boxes(eng, orc32, boxkind, L):
+    """The band / pruning margins of the wrapped fast path scale with ulp(L) and with the conditioning of the box
+    (search.hip make_params).  Adversarial cases at large L/rc: a 60-degree rhombic dodecahedron of 60 nm and a strongly
+    sheared 40 nm box at rc = 0.3 with >= 1e4 boundary-crossing pairs at rc*(1 +- 1e-6..1e-4), where the f32 evaluation
+    of inv*v / M*f carries errors comparable to the distance from the cutoff; and a 160 nm sheared box at rc = 1.0 (the
+    conditioning term dominates the margin).  Lists must be bit-identical to the oracle's."""
+    rc = 0.3 if L < 100 else 1.0
+    if boxkind == "dodecahedron":
+        box = np.array([[L, 0, L / 2], [0, L, L / 2], [0, 0, L * np.sqrt(2) / 2]], np.float32)
+    else:
+        box = np.array([[L, 0.45 * L, 0.9 * L], [0, L, 0.8 * L], [0, 0, L]], np.float32)
+    pos = _boundary_pairs(box, rc, 12000, seed=int(L))
+    ob = orc32.box_from_matrix(box)
+    ref = orc32.search_single_pbc(rc, pos, ob, 7, nthreads=8)
+    assert min(ref["dims"]) >= 4
+    near = np.abs(ref["d"].astype(np.float64) / rc - 1.0)
+    # (the reference's half-shell grid is incomplete in positively sheared boxes, so not every constructed pair is found)
+    assert len(ref["i"]) > 5000 and (near < 1e-4).sum() > 1000 and (near < 1e-5).sum() > 100
+    gi, gj, gd, cnt = run_single(eng, rc, pos, box, 7)
+    assert cnt == len(ref["i"])
+    assert_same_pairs(gi, gj, gd, ref)
+    a = api()
+    c2, pa, da = eng.search_resident(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+    assert c2 == cnt
+
+
 def test_non_finite_coordinates_and_degenerate_inputs(eng, orc32):
     """NaN / inf coordinates never compare as hits in the reference (and land in cell 0 through the
     saturating `as usize` cast); the engine must agree and must not fault.  Also: coincident atoms (d = 0)."""
