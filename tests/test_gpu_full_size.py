@@ -97,7 +97,8 @@ def test_c3_fit_rmsd_com_gyration_at_baseline_size(eng, orc64):
         assert abs(out["gyration"][f] - w["gyr"]) <= 1e-5 * w["gyr"]
         assert np.allclose(out["com"][f], w["com"], rtol=1e-5, atol=1e-5)
         assert np.allclose(out["R"][f], w["R"], atol=1e-5)
-        assert np.allclose(out["t"][f], w["t"], rtol=1e-5, atol=2e-5 * np.abs(w["t"]).max())
+        # t = c2 - R c1 cancels two centres of ~10 nm: its error scales with THEIR magnitude, not with |t|
+        assert np.allclose(out["t"][f], w["t"], rtol=1e-5, atol=1e-5 * max(np.abs(w["com"]).max(), np.abs(w["t"]).max()))
         sel = idx.astype(np.int64)
         assert np.abs(got_moved[f][sel] - w["moved"][sel]).max() < 1e-4          # f32 coordinates of ~20 nm: 4 ulp
         rest = np.ones(n, bool); rest[sel] = False
@@ -106,7 +107,8 @@ def test_c3_fit_rmsd_com_gyration_at_baseline_size(eng, orc64):
     for f in (0, 1):
         cur = frames[f].copy()
         R, t = eng.fit_transform(cur, mass, ref, mass, idx, idx)
-        assert np.allclose(R, want[f]["R"], atol=1e-5) and np.allclose(t, want[f]["t"], rtol=1e-5, atol=2e-5 * np.abs(want[f]["t"]).max())
+        assert np.allclose(R, want[f]["R"], atol=1e-5)
+        assert np.allclose(t, want[f]["t"], rtol=1e-5, atol=1e-5 * max(np.abs(want[f]["com"]).max(), np.abs(want[f]["t"]).max()))
         eng.apply_transform(cur, R, t, idx)
         r = eng.rmsd(cur, ref, idx, idx)
         assert abs(r - want[f]["rmsd"]) <= 1e-5 * want[f]["rmsd"]
