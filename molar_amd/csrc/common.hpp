@@ -137,7 +137,7 @@ struct molar_hip_ctx {
     hipEvent_t grid_done = nullptr;
     bool want_side = false;              // set by _begin / the asynchronous histogram call around their enqueue
     bool env_no_side = false;            // MOLAR_HIP_NO_SIDE_STREAM, read once in molar_hip_create
-    bool env_two_pass = false;           // MOLAR_HIP_TWO_PASS: resident searches use count / scan / fill instead of the single-pass kernel
+    bool env_single_pass = false;        // MOLAR_HIP_SINGLE_PASS: resident searches use the single-pass kernel (measured slower)
     uint32_t env_debug_skip = 0;         // MOLAR_HIP_DEBUG_SKIP (builds with -DMOLAR_HIP_DEBUG_KNOBS only), read once
     hipEvent_t gen_free[2] = {nullptr, nullptr};   // recorded on the main stream behind the last asynchronous reader of
                                                    // a grid generation (histogram calls that do not wait)

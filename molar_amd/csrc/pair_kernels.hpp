@@ -886,12 +886,139 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
     return total;
 }
 
+
+// Fill pass of the plain and same-cell entries, one ROW at a time instead of one chunk at a time:
+//   1. all chunks of the row are evaluated (NCH compares into NCH scalar masks, no branch in between);
+//   2. the scalar unit turns the masks into FIFO offsets (popcounts, running sum);
+//   3. the hit lanes of every chunk write ONE u16 each - (row << 9 | position in the second cell) - at offset + rank.
+// The per-chunk version interleaved VALU -> SALU -> VALU dependencies (compare, branch on the mask, rank, push, tail
+// update, drain test) five times per row; here the two units hand over once per row.  Ids and the exact d2 of a hit
+// are rebuilt from its two atoms when 64 queued hits are written out (dense: one lane per hit), like the replayed
+// wrapped entries do.  The FIFO holds 1024 entries (2 KB): a row pushes at most 512, fewer than 64 are left over.
+constexpr uint32_t ROWFIFO_CAP = 1024u;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+
+template <int KIND, int NCH, bool TRI>
+__device__ __forceinline__ uint32_t run_fill_rows(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
+                                                  uint32_t lane) {
+    const float cutoff2 = P.cutoff2;
+    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
+    lds_u16 *fifo = (lds_u16 *)F.fq_store;
+    float bx[NCH], by[NCH], bz[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const uint32_t jj = (uint32_t)k * 64u + lane;
+        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);     // past the end: d2 overflows, the compare fails
+        if (jj < T.n2) q = gload4(P.sb, T.b0 + jj);
+        bx[k] = q.x; by[k] = q.y; bz[k] = q.z;
+    }
+    unsigned long long live;
+    {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
+        la[lane] = a;
+        bool need = true;
+        if (!TRI) {
+            const float4 lo = gload4(P.aabb_b, 2 * T.cb), hi = gload4(P.aabb_b, 2 * T.cb + 1);
+            need = !(aabb_d2(a.x, a.y, a.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > cutoff2);     // exact row pruning, see run_fast
+        }
+        live = __builtin_amdgcn_ballot_w64(lane < rows && need);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t head = 0u, tail = 0u;        // wave-uniform, monotonically increasing
+    uint32_t quota = F.quota;             // first write-out of the slot stops at a 64-entry boundary of the output
+    // write out `count` queued hits: lane l resolves entry head + l
+    auto flush = [&](uint32_t count) {
+        if (lane < count) {
+            const uint32_t val = fifo[(head + lane) & (ROWFIFO_CAP - 1u)];
+            const float4 a = lload4(la, val >> 9);
+#ifdef MH_EXP_NOGATHER
+            const float4 b = lload4(la, val & 63u);
+#else
+            const float4 b = gload4(P.sb, T.b0 + (val & 511u));
+#endif
+            const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;       // p2 - p1, the expression of the row loop
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (F.has_pairs) F.pairs[head] = make_uint2(__float_as_uint(a.w), __float_as_uint(b.w));
+            if (F.has_dist) F.dist[head] = __builtin_sqrtf(d2);              // d2.sqrt() (:448), correctly rounded
+        }
+        head += count;
+    };
+    while (live) {
+        const uint32_t r = (uint32_t)__builtin_ctzll(live);
+        live &= live - 1ull;
+        const float4 p = lload4(la, r);              // one broadcast ds_read per row
+        const uint32_t i = i0 + r;
+        unsigned long long m[NCH];       // hit masks of the row's chunks (scalar registers)
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            m[k] = 0ull;
+            if (TRI && (uint32_t)k * 64u + 63u <= i) continue;                     // whole chunk has j <= i
+            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1
+            const float d2 = (dx * dx + dy * dy) + dz * dz;                        // |p2-p1|^2 (:446, :460)
+            m[k] = __builtin_amdgcn_ballot_w64(d2 <= cutoff2);
+            if (TRI && (uint32_t)k * 64u <= i) m[k] &= __builtin_amdgcn_ballot_w64((uint32_t)k * 64u + lane > i);   // j in i+1..n (:443)
+        }
+        uint32_t off[NCH];
+        uint32_t run = tail;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            off[k] = run;
+            run += (uint32_t)__popcll(m[k]);
+        }
+        const uint32_t vrow = (r << 9) | lane;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[k], 0u));
+            const uint32_t addr = ((rank + off[k]) << 1) & ((ROWFIFO_CAP - 1u) << 1);
+            const uint32_t val = vrow | (uint32_t)(k * 64);
+            // the hit lanes store; EXEC is set from the mask for the one instruction and restored (the wave runs this
+            // loop with all 64 lanes enabled: one-wave / full-wave workgroups, uniform control flow)
+            unsigned long long keep;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tds_write_b16 %1, %2\n\ts_mov_b64 exec, %0"
+                         : "=&s"(keep) : "v"((uint32_t)(uintptr_t)fifo + addr), "v"(val), "s"(m[k]) : "memory");
+        }
+        tail = run;
+#ifdef MH_EXP_NOFLUSH
+        head = tail;
+#endif
+        if (tail - head >= 64u) {
+            __builtin_amdgcn_wave_barrier();
+            do {
+                flush(quota);
+                quota = 64u;
+            } while (tail - head >= 64u);
+        }
+    }
+    if (tail != head) {
+        __builtin_amdgcn_wave_barrier();
+        flush(tail - head);
+    }
+    return tail;
+}
+
 // chunk-count dispatch: for the single-set search the non-triangular tasks get a fully unrolled,
 // branch-free row body per chunk count; everything else checks the chunk count at run time
 template <int KIND, bool FILL, int WK, bool MASKED>
 __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                                  uint32_t lane, uint32_t *mwords) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
+    // fill pass of the pair-list kernels (not the fused histogram, which has no 2 KB row FIFO): row-batched emission
+#ifndef MH_EXP_OLD_FILL
+    if (FILL && WK == WK_NONE && (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) &&
+        nchunks <= (uint32_t)KREG && F.fq_store != nullptr && F.hist == nullptr) {
+#define MH_ROWS_CASE(N)                                                                                     \
+    case N:                                                                                                 \
+        return (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) ? run_fill_rows<KIND, N, true>(P, T, i0, F, la, lane) \
+                                                          : run_fill_rows<KIND, N, false>(P, T, i0, F, la, lane);
+        switch (nchunks) {
+            MH_ROWS_CASE(1) MH_ROWS_CASE(2) MH_ROWS_CASE(3) MH_ROWS_CASE(4)
+            MH_ROWS_CASE(5) MH_ROWS_CASE(6) MH_ROWS_CASE(7)
+            default: MH_ROWS_CASE(8)
+        }
+#undef MH_ROWS_CASE
+    }
+#endif
     if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && !T.tri && nchunks <= (uint32_t)KREG) {
         constexpr bool WR = WK != WK_NONE;
         switch (nchunks) {
@@ -1209,8 +1336,6 @@ __device__ __forceinline__ unsigned long long slot_lookback(unsigned long long *
     if (lane == 0u) st_store(state + slot, ST_PRE | (sum + (unsigned long long)count));
     return sum;
 }
-
-typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 // Step 1 of a plain / same-cell slot: row masks in the owner lanes' registers, hits per row in `rowcnt`.
 // Reference arithmetic and order: d2 = ((dx*dx)+(dy*dy))+(dz*dz) on p2 - p1, hit iff d2 <= cutoff^2 (:446-448, :460-462),

@@ -820,7 +820,7 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
 
 // single-pass search (pair_kernel_fused): which kinds, and the launch
 bool fused_kind(const molar_hip_ctx *c) {
-    return (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) && !c->env_two_pass;
+    return (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) && c->env_single_pass;
 }
 unsigned long long *fused_aux(molar_hip_ctx *c) { return c->slot_state.as<unsigned long long>() + c->nslots_bound + 1; }
 
