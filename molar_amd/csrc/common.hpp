@@ -137,7 +137,6 @@ struct molar_hip_ctx {
     hipEvent_t grid_done = nullptr;
     bool want_side = false;              // set by _begin / the asynchronous histogram call around their enqueue
     bool env_no_side = false;            // MOLAR_HIP_NO_SIDE_STREAM, read once in molar_hip_create
-    bool env_single_pass = false;        // MOLAR_HIP_SINGLE_PASS: resident searches use the single-pass kernel (measured slower)
     uint32_t env_debug_skip = 0;         // MOLAR_HIP_DEBUG_SKIP (builds with -DMOLAR_HIP_DEBUG_KNOBS only), read once
     hipEvent_t gen_free[2] = {nullptr, nullptr};   // recorded on the main stream behind the last asynchronous reader of
                                                    // a grid generation (histogram calls that do not wait)
@@ -152,7 +151,6 @@ struct molar_hip_ctx {
     mh::DevBuf slot_desc;      // SlotDesc per slot (+1): what a wave of the pair kernels needs to start
     mh::DevBuf slot_cnt;       // u32 per slot (+1): results of the slot
     mh::DevBuf slot_base;      // u64 per slot (+1): output offset (last = grand total)
-    mh::DevBuf slot_state;     // single-pass kernel: u64 {state, value} per slot (+1), then {grand total, status}
     mh::DevBuf scan_tmp;       // block sums for the scans
     mh::DevBuf scan_state;     // ticket + tile descriptors of the single-pass scans (zeroed by the plan kernel)
     mh::DevBuf out_pairs_set[2];   // ctx-owned result buffers (device-resident results / host staging); the second
@@ -161,14 +159,14 @@ struct molar_hip_ctx {
     mh::DevBuf &out_dist = out_dist_set[0];
     // pipelined resident searches (molar_hip_search_resident_begin/_end): two result sets, two tickets
     struct Ticket {
-        bool pending = false, degenerate = false, fused = false;
+        bool pending = false, degenerate = false;
         unsigned long long cap0 = 0, maskcap0 = 0, serial = 0;
         hipEvent_t done = nullptr;
         molar_hip_search_desc desc{};
     } tickets[2];
     int next_ticket = 0;
     unsigned long long search_serial = 0;   // counts resident searches enqueued on this context
-    void *h_sizes = nullptr;                // pinned: 32 bytes of result sizes per ticket (total, hit-history units, status)
+    void *h_sizes = nullptr;                // pinned: 16 bytes of result sizes per ticket
     mh::DevBuf out_ids;
     mh::DevBuf wide_i, wide_j; // usize widening
     mh::DevBuf hist;           // u64 bins

@@ -10,9 +10,6 @@ namespace mh {
 namespace pairk {
 
 enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2 };
-constexpr uint32_t SLOT_VALID = 0x200u;   // SlotDesc.flags: a real slot
-constexpr uint32_t SLOT_LAST = 0x400u;    // SlotDesc.flags: the last real slot (publishes the grand total of a single-pass search)
-constexpr uint32_t STAGE_CAP = 1792u;     // single-pass kernel: hits one row group may stage in LDS (u16 each, 3.5 KB per wave)
 
 // (Count and fill are compiled for 8 waves per SIMD - 64 VGPRs, the few spills fall outside the row loop: count -4 %,
 // fill -5 % against 7 waves.  32 one-wave workgroups of the fill kernel hold 144 KB of the CU's 160 KB LDS.)
@@ -886,139 +883,12 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
     return total;
 }
 
-
-// Fill pass of the plain and same-cell entries, one ROW at a time instead of one chunk at a time:
-//   1. all chunks of the row are evaluated (NCH compares into NCH scalar masks, no branch in between);
-//   2. the scalar unit turns the masks into FIFO offsets (popcounts, running sum);
-//   3. the hit lanes of every chunk write ONE u16 each - (row << 9 | position in the second cell) - at offset + rank.
-// The per-chunk version interleaved VALU -> SALU -> VALU dependencies (compare, branch on the mask, rank, push, tail
-// update, drain test) five times per row; here the two units hand over once per row.  Ids and the exact d2 of a hit
-// are rebuilt from its two atoms when 64 queued hits are written out (dense: one lane per hit), like the replayed
-// wrapped entries do.  The FIFO holds 1024 entries (2 KB): a row pushes at most 512, fewer than 64 are left over.
-constexpr uint32_t ROWFIFO_CAP = 1024u;
-typedef __attribute__((address_space(3))) uint16_t lds_u16;
-
-template <int KIND, int NCH, bool TRI>
-__device__ __forceinline__ uint32_t run_fill_rows(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
-                                                  uint32_t lane) {
-    const float cutoff2 = P.cutoff2;
-    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
-    lds_u16 *fifo = (lds_u16 *)F.fq_store;
-    float bx[NCH], by[NCH], bz[NCH];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const uint32_t jj = (uint32_t)k * 64u + lane;
-        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);     // past the end: d2 overflows, the compare fails
-        if (jj < T.n2) q = gload4(P.sb, T.b0 + jj);
-        bx[k] = q.x; by[k] = q.y; bz[k] = q.z;
-    }
-    unsigned long long live;
-    {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
-        la[lane] = a;
-        bool need = true;
-        if (!TRI) {
-            const float4 lo = gload4(P.aabb_b, 2 * T.cb), hi = gload4(P.aabb_b, 2 * T.cb + 1);
-            need = !(aabb_d2(a.x, a.y, a.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > cutoff2);     // exact row pruning, see run_fast
-        }
-        live = __builtin_amdgcn_ballot_w64(lane < rows && need);
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint32_t head = 0u, tail = 0u;        // wave-uniform, monotonically increasing
-    uint32_t quota = F.quota;             // first write-out of the slot stops at a 64-entry boundary of the output
-    // write out `count` queued hits: lane l resolves entry head + l
-    auto flush = [&](uint32_t count) {
-        if (lane < count) {
-            const uint32_t val = fifo[(head + lane) & (ROWFIFO_CAP - 1u)];
-            const float4 a = lload4(la, val >> 9);
-#ifdef MH_EXP_NOGATHER
-            const float4 b = lload4(la, val & 63u);
-#else
-            const float4 b = gload4(P.sb, T.b0 + (val & 511u));
-#endif
-            const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;       // p2 - p1, the expression of the row loop
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            if (F.has_pairs) F.pairs[head] = make_uint2(__float_as_uint(a.w), __float_as_uint(b.w));
-            if (F.has_dist) F.dist[head] = __builtin_sqrtf(d2);              // d2.sqrt() (:448), correctly rounded
-        }
-        head += count;
-    };
-    while (live) {
-        const uint32_t r = (uint32_t)__builtin_ctzll(live);
-        live &= live - 1ull;
-        const float4 p = lload4(la, r);              // one broadcast ds_read per row
-        const uint32_t i = i0 + r;
-        unsigned long long m[NCH];       // hit masks of the row's chunks (scalar registers)
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            m[k] = 0ull;
-            if (TRI && (uint32_t)k * 64u + 63u <= i) continue;                     // whole chunk has j <= i
-            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1
-            const float d2 = (dx * dx + dy * dy) + dz * dz;                        // |p2-p1|^2 (:446, :460)
-            m[k] = __builtin_amdgcn_ballot_w64(d2 <= cutoff2);
-            if (TRI && (uint32_t)k * 64u <= i) m[k] &= __builtin_amdgcn_ballot_w64((uint32_t)k * 64u + lane > i);   // j in i+1..n (:443)
-        }
-        uint32_t off[NCH];
-        uint32_t run = tail;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            off[k] = run;
-            run += (uint32_t)__popcll(m[k]);
-        }
-        const uint32_t vrow = (r << 9) | lane;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[k], 0u));
-            const uint32_t addr = ((rank + off[k]) << 1) & ((ROWFIFO_CAP - 1u) << 1);
-            const uint32_t val = vrow | (uint32_t)(k * 64);
-            // the hit lanes store; EXEC is set from the mask for the one instruction and restored (the wave runs this
-            // loop with all 64 lanes enabled: one-wave / full-wave workgroups, uniform control flow)
-            unsigned long long keep;
-            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tds_write_b16 %1, %2\n\ts_mov_b64 exec, %0"
-                         : "=&s"(keep) : "v"((uint32_t)(uintptr_t)fifo + addr), "v"(val), "s"(m[k]) : "memory");
-        }
-        tail = run;
-#ifdef MH_EXP_NOFLUSH
-        head = tail;
-#endif
-        if (tail - head >= 64u) {
-            __builtin_amdgcn_wave_barrier();
-            do {
-                flush(quota);
-                quota = 64u;
-            } while (tail - head >= 64u);
-        }
-    }
-    if (tail != head) {
-        __builtin_amdgcn_wave_barrier();
-        flush(tail - head);
-    }
-    return tail;
-}
-
 // chunk-count dispatch: for the single-set search the non-triangular tasks get a fully unrolled,
 // branch-free row body per chunk count; everything else checks the chunk count at run time
 template <int KIND, bool FILL, int WK, bool MASKED>
 __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                                  uint32_t lane, uint32_t *mwords) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
-    // fill pass of the pair-list kernels (not the fused histogram, which has no 2 KB row FIFO): row-batched emission
-#ifndef MH_EXP_OLD_FILL
-    if (FILL && WK == WK_NONE && (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) &&
-        nchunks <= (uint32_t)KREG && F.fq_store != nullptr && F.hist == nullptr) {
-#define MH_ROWS_CASE(N)                                                                                     \
-    case N:                                                                                                 \
-        return (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) ? run_fill_rows<KIND, N, true>(P, T, i0, F, la, lane) \
-                                                          : run_fill_rows<KIND, N, false>(P, T, i0, F, la, lane);
-        switch (nchunks) {
-            MH_ROWS_CASE(1) MH_ROWS_CASE(2) MH_ROWS_CASE(3) MH_ROWS_CASE(4)
-            MH_ROWS_CASE(5) MH_ROWS_CASE(6) MH_ROWS_CASE(7)
-            default: MH_ROWS_CASE(8)
-        }
-#undef MH_ROWS_CASE
-    }
-#endif
     if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && !T.tri && nchunks <= (uint32_t)KREG) {
         constexpr bool WR = WK != WK_NONE;
         switch (nchunks) {
@@ -1105,14 +975,13 @@ static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, co
     }
     const uint32_t s0 = task_first[t], s1 = task_first[t + 1];
     if (s1 == s0) return;
-    const uint32_t nreal = task_first[ntasks];
     const TaskDesc d = task_desc[t];
     const uint32_t rps = d.flags >> 16, nch = (d.n2 + 63u) >> 6;
     const unsigned long long m0 = task_moff ? task_moff[t] : (~0ull >> 1);
     for (uint32_t s = s0; s < s1; ++s) {
         SlotDesc o;
         o.a0 = d.a0; o.n1 = d.n1; o.b0 = d.b0; o.n2 = d.n2;
-        o.cb = d.cb; o.flags = d.flags | (s + 1u == nreal ? SLOT_LAST : 0u); o.i0 = (s - s0) * rps; o.pad0 = 0u;
+        o.cb = d.cb; o.flags = d.flags; o.i0 = (s - s0) * rps; o.pad0 = 0u;
         o.moff = task_moff ? m0 + (unsigned long long)(s - s0) * 2u * nch : m0;
         o.pad1 = 0ull;
         slot_desc[s] = o;
@@ -1246,347 +1115,11 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
 }
 
 
-// HIP limits gridDim.x * blockDim.x to 2^32 threads: sparse giant grids (10^8 plan entries) spill into grid.y
+// HIP limits gridDim.x * blockDim.x to 2^32 threads: sparse giant grids (10^8 plan entries, one 64-lane workgroup per
+// slot) spill into grid.y; the kernels linearise (x fastest)
 inline dim3 pair_grid(unsigned nblocks) {
     const unsigned gx = nblocks < (1u << 24) ? (nblocks ? nblocks : 1u) : (1u << 24);
     return dim3(gx, (nblocks + gx - 1u) / gx);
-}
-
-// ================================================================= single-pass search (resident path)
-//
-// Count and fill in ONE kernel: every candidate of the plain and same-cell entries (94 % of the pairs of the headline
-// workload) is evaluated once.  A wave
-//   1. evaluates its slot into ROW MASKS: for every row of the slot and every 64-chunk of the second cell the 64-bit
-//      compare result, parked in the registers of the row's owner lane (lane r holds the masks of row r: 2*NCH VGPRs,
-//      bounded - 64 rows x 512 atoms at most - unlike a list of hits);
-//   2. knows its hit count (popcounts), publishes it and obtains its output offset from the slots before it by a
-//      decoupled look-back over 8-byte {state, value} descriptors (slot order = launch order = the reference's output
-//      order, distance_search.rs:949-953);
-//   3. extracts the hits in the reference's order: the owner lanes walk their own bit strings in parallel (64 rows at
-//      a time, one hit per lane per step) and write (row, position) as u16 into an LDS staging area at the hit's
-//      final position inside the slot; 64 staged hits at a time are then resolved densely - ids and the exact d2 are
-//      recomputed from the two atoms, sqrt taken, one 512-byte and one 256-byte store.
-// Wrapped and generic entries run their count pass, look back, then their fill pass inside the same wave.
-// A wave only ever waits for slots launched BEFORE it (they are resident or done), so the chain cannot deadlock under
-// an in-order dispatcher; should a launch order ever violate that, the wait times out, a status word is set and the
-// host repeats the frame with the count / scan / fill kernels.
-
-constexpr unsigned long long ST_AGG = 1ull << 62, ST_PRE = 2ull << 62, ST_VAL = (1ull << 62) - 1ull;
-
-__device__ __forceinline__ unsigned long long st_load(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_store(unsigned long long *p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
-        const unsigned long long t = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)oh << 32) | ol);
-        lo = (uint32_t)t;
-        hi = (uint32_t)(t >> 32);
-    }
-    return ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | __builtin_amdgcn_readfirstlane(lo);
-}
-
-// Publish this slot's count, return the sum of the counts of all slots before it (~0ull: gave up).
-__device__ __forceinline__ unsigned long long slot_lookback(unsigned long long *state, uint32_t slot, uint32_t count,
-                                                            uint32_t lane, uint32_t *status) {
-    if (slot == 0u) {
-        if (lane == 0u) st_store(state, ST_PRE | (unsigned long long)count);
-        return 0ull;
-    }
-    if (lane == 0u) st_store(state + slot, ST_AGG | (unsigned long long)count);
-    unsigned long long sum = 0ull;
-    int pos = (int)slot - 1;          // nearest predecessor not yet accounted for
-    uint32_t spins = 0u;
-    for (;;) {
-        const int idx = pos - (int)lane;
-        const unsigned long long v = idx >= 0 ? st_load(state + idx) : ST_PRE;   // in front of slot 0: prefix 0
-        const uint32_t st = (uint32_t)(v >> 62);
-        const unsigned long long m_pre = __builtin_amdgcn_ballot_w64(st == 2u), m_empty = __builtin_amdgcn_ballot_w64(st == 0u);
-        const uint32_t fp = m_pre ? (uint32_t)__builtin_ctzll(m_pre) : 64u;
-        const uint32_t fe = m_empty ? (uint32_t)__builtin_ctzll(m_empty) : 64u;
-        if (fe < fp) {
-            // lanes below fe hold published counts: take them, then wait for the slot at fe.  ONE lane polls ONE word
-            // with a pause of ~1 us between reads: thousands of waves re-reading 512-byte windows would eat the L2.
-            sum += wave_sum_u64(lane < fe ? (v & ST_VAL) : 0ull);
-            pos -= (int)fe;
-            for (;;) {
-                __builtin_amdgcn_s_sleep(40);
-                unsigned long long w = 1ull;
-                if (lane == 0u) w = st_load(state + pos);
-                if (__builtin_amdgcn_readfirstlane((uint32_t)(w >> 62)) != 0u) break;
-                if ((++spins & 63u) == 0u) {
-                    const uint32_t bad = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (bad || spins > (1u << 21)) {
-                        if (lane == 0u && !bad) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        return ~0ull;
-                    }
-                }
-            }
-            continue;
-        }
-        sum += wave_sum_u64(lane <= fp ? (v & ST_VAL) : 0ull);    // counts below fp, the prefix at fp
-        if (fp < 64u) break;
-        pos -= 64;
-    }
-    if (lane == 0u) st_store(state + slot, ST_PRE | (sum + (unsigned long long)count));
-    return sum;
-}
-
-// Step 1 of a plain / same-cell slot: row masks in the owner lanes' registers, hits per row in `rowcnt`.
-// Reference arithmetic and order: d2 = ((dx*dx)+(dy*dy))+(dz*dz) on p2 - p1, hit iff d2 <= cutoff^2 (:446-448, :460-462),
-// same cell: j in i+1..n (:443); second cell in the reference's cell order, rows pruned exactly as in run_fast.
-template <int NCH, bool TRI>
-__device__ __forceinline__ uint32_t eval_rowmasks(const SearchParams &P, const Task &T, uint32_t i0, float4 *la, uint32_t lane,
-                                                  uint32_t (&mlo)[NCH], uint32_t (&mhi)[NCH], uint32_t &rowcnt) {
-    const float cutoff2 = P.cutoff2;
-    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
-    float bx[NCH], by[NCH], bz[NCH];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const uint32_t jj = (uint32_t)k * 64u + lane;
-        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);     // past the end: d2 overflows, the compare fails
-        if (jj < T.n2) q = gload4(P.sb, T.b0 + jj);
-        bx[k] = q.x; by[k] = q.y; bz[k] = q.z;
-        mlo[k] = 0u; mhi[k] = 0u;
-    }
-    unsigned long long live;
-    {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
-        la[lane] = a;
-        bool need = true;
-        if (!TRI) {
-            const float4 lo = gload4(P.aabb_b, 2 * T.cb), hi = gload4(P.aabb_b, 2 * T.cb + 1);
-            need = !(aabb_d2(a.x, a.y, a.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > cutoff2);     // exact, see run_fast
-        }
-        live = __builtin_amdgcn_ballot_w64(lane < rows && need);
-    }
-    __builtin_amdgcn_wave_barrier();
-    while (live) {
-        const uint32_t r = (uint32_t)__builtin_ctzll(live);
-        live &= live - 1ull;
-        const float4 p = lload4(la, r);              // one broadcast ds_read per row
-        const uint32_t i = i0 + r;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            if (TRI && (uint32_t)k * 64u + 63u <= i) continue;                     // whole chunk has j <= i: bits stay 0
-            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            bool hit = d2 <= cutoff2;
-            if (TRI && (uint32_t)k * 64u <= i) hit = hit && ((uint32_t)k * 64u + lane > i);   // diagonal chunk
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-            // park the 64-bit compare result in lane r of (mlo[k], mhi[k]).  clang has no writelane builtin; with two
-            // scalar sources the lane select of v_writelane_b32 has to come from M0 on gfx9 (constant-bus limit 1).
-            // M0 is a reserved register the compiler sets up right in front of each of its own uses.
-            asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-                         : "+v"(mlo[k]), "+v"(mhi[k]) : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "s"(r));
-        }
-    }
-    uint32_t c = 0u;
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) c += (uint32_t)__popc(mlo[k]) + (uint32_t)__popc(mhi[k]);
-    rowcnt = c;
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-    return __builtin_amdgcn_readfirstlane(c);
-}
-
-// Step 3: extraction.  Lane r owns row r; rows are taken in groups whose hits fit the staging area.
-template <int NCH>
-__device__ __forceinline__ void emit_rowmasks(const SearchParams &P, const Task &T, const float4 *la, void *stage_raw,
-                                              uint32_t lane, const uint32_t (&mlo)[NCH], const uint32_t (&mhi)[NCH],
-                                              uint32_t rowcnt, uint32_t total, unsigned long long base,
-                                              uint2 *__restrict__ out_pairs, float *__restrict__ out_dist) {
-    lds_u16 *stage = (lds_u16 *)stage_raw;
-    // first hit of every row inside the slot (exclusive scan over the owner lanes)
-    uint32_t inc = rowcnt;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(inc, off, 64);
-        if ((int)lane >= off) inc += o;
-    }
-    const uint32_t rowstart = inc - rowcnt;
-    uint32_t r0 = 0u, gstart = 0u;
-    while (gstart < total) {
-        // rows r0..r1-1: as many as fit (a row holds <= 512 hits, so at least one does)
-        const unsigned long long fits = __builtin_amdgcn_ballot_w64(lane >= r0 && inc - gstart <= STAGE_CAP);
-        const unsigned long long nofit = ~fits & (~0ull << r0);
-        const uint32_t r1 = nofit ? (uint32_t)__builtin_ctzll(nofit) : 64u;
-        const uint32_t gend = r1 < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)rowstart, (int)r1) : total;
-        const bool active = lane >= r0 && lane < r1;
-        uint32_t pos = rowstart - gstart;
-        const uint32_t rowbits = lane << 9;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint32_t cur = active ? (h ? mhi[k] : mlo[k]) : 0u;
-                const uint32_t vbase = rowbits | (uint32_t)(k * 64 + h * 32);
-                while (__builtin_amdgcn_ballot_w64(cur != 0u)) {
-                    if (cur != 0u) {
-                        const uint32_t b = (uint32_t)__builtin_ctz(cur);
-                        stage[pos] = (uint16_t)(vbase + b);
-                        ++pos;
-                        cur &= cur - 1u;
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // resolve the staged hits 64 at a time; blocks are aligned to 64-entry boundaries of the OUTPUT, so every
-        // store but the first and last of a slot is a full 512-byte / 256-byte line group
-        const unsigned long long out0 = base + gstart;
-        const uint32_t n = gend - gstart;
-        for (int e = (int)lane - (int)((uint32_t)out0 & 63u); e < (int)n; e += 64) {
-            if (e >= 0) {
-                const uint32_t val = stage[e];
-                const float4 a = lload4(la, val >> 9);
-                const float4 b = gload4(P.sb, T.b0 + (val & 511u));
-                const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;       // p2 - p1, as in step 1
-                const float d2 = (dx * dx + dy * dy) + dz * dz;
-                const unsigned long long o = out0 + (unsigned long long)(uint32_t)e;
-                if (out_pairs) out_pairs[o] = make_uint2(__float_as_uint(a.w), __float_as_uint(b.w));
-                if (out_dist) out_dist[o] = __builtin_sqrtf(d2);                 // d2.sqrt() (:448), correctly rounded
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        r0 = r1;
-        gstart = gend;
-    }
-}
-
-template <int KIND, int NCH, bool TRI>
-__device__ __forceinline__ void fused_fast(const SearchParams &P, const Task &T, uint32_t i0, uint32_t slot, uint32_t flags,
-                                           float4 *la, void *stage, uint32_t lane, unsigned long long *state,
-                                           unsigned long long *aux, uint2 *out_pairs, float *out_dist) {
-    uint32_t mlo[NCH], mhi[NCH], rowcnt;
-    const uint32_t total = eval_rowmasks<NCH, TRI>(P, T, i0, la, lane, mlo, mhi, rowcnt);
-#if defined(MH_EXP_EVAL_ONLY)
-    if (lane == 0u) st_store(state + slot, ST_AGG | total);
-    return;
-#endif
-#if defined(MH_EXP_NO_LOOKBACK)
-    const unsigned long long base = (unsigned long long)(slot & 0xFFFFu) * 4096ull;
-#else
-    const unsigned long long base = slot_lookback(state, slot, total, lane, (uint32_t *)(aux + 1));
-#endif
-    if (base == ~0ull) return;
-    if ((flags & SLOT_LAST) && lane == 0u) aux[0] = base + total;
-#if defined(MH_EXP_NO_EMIT)
-    return;
-#endif
-    if (total == 0u || base + total > P.out_cap) return;      // no room: the host grows the buffers and repeats
-    emit_rowmasks<NCH>(P, T, la, stage, lane, mlo, mhi, rowcnt, total, base, out_pairs, out_dist);
-}
-
-template <int KIND>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
-pair_kernel_fused(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ slot_desc, const uint32_t nslots,
-                  unsigned long long *__restrict__ slot_state, unsigned long long *__restrict__ aux,   // aux[0]: total, aux[1]: status
-                  uint2 *__restrict__ out_pairs, float *__restrict__ out_dist) {
-    __shared__ float4 lds_a[64];
-    __shared__ float4 lds_u[224];       // staging area of the single-pass slots (1792 x u16) / FIFO of the other paths
-    const SearchParams &P = *Pp;
-    const uint32_t lane = threadIdx.x & 63u;
-    // launch order IS slot order here: a wave looks back at earlier launches only (x fastest; y only for > 2^24 slots)
-    const uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
-    if (slot >= nslots) return;
-    Task T;
-    uint32_t i0, fl;
-    unsigned long long moff;
-    {
-        const uint4 lo = reinterpret_cast<const uint4 *>(slot_desc + slot)[0];
-        const uint4 hi = reinterpret_cast<const uint4 *>(slot_desc + slot)[1];
-        const uint2 mo = reinterpret_cast<const uint2 *>(slot_desc + slot)[4];
-        fl = __builtin_amdgcn_readfirstlane(hi.y);
-        if (!(fl & SLOT_VALID)) return;       // past the last slot: nobody looks back at these
-        T.a0 = __builtin_amdgcn_readfirstlane(lo.x);
-        T.n1 = __builtin_amdgcn_readfirstlane(lo.y);
-        T.b0 = __builtin_amdgcn_readfirstlane(lo.z);
-        T.n2 = __builtin_amdgcn_readfirstlane(lo.w);
-        T.cb = __builtin_amdgcn_readfirstlane(hi.x);
-        i0 = __builtin_amdgcn_readfirstlane(hi.z);
-        moff = ((unsigned long long)__builtin_amdgcn_readfirstlane(mo.y) << 32) | __builtin_amdgcn_readfirstlane(mo.x);
-        T.wrap = fl & 7u;
-        T.tri = (fl & 0x100u) != 0u;
-        T.valid = true;
-        T.wrap_b = (fl >> 12) & 7u;
-        T.rps = fl >> 16;
-    }
-    const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
-    const uint32_t nchunks = (T.n2 + 63u) >> 6;
-    if (wk == WK_NONE && nchunks <= (uint32_t)KREG && (KIND == MOLAR_HIP_SEARCH_SINGLE || !T.tri)) {
-#define MH_FUSED_CASE(N)                                                                                                  \
-    case N:                                                                                                               \
-        if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri)                                                                     \
-            fused_fast<KIND, N, true>(P, T, i0, slot, fl, lds_a, lds_u, lane, slot_state, aux, out_pairs, out_dist);      \
-        else                                                                                                              \
-            fused_fast<KIND, N, false>(P, T, i0, slot, fl, lds_a, lds_u, lane, slot_state, aux, out_pairs, out_dist);     \
-        return;
-        switch (nchunks) {
-            MH_FUSED_CASE(1) MH_FUSED_CASE(2) MH_FUSED_CASE(3) MH_FUSED_CASE(4)
-            MH_FUSED_CASE(5) MH_FUSED_CASE(6) MH_FUSED_CASE(7)
-            default: MH_FUSED_CASE(8)
-        }
-#undef MH_FUSED_CASE
-    }
-    // wrapped entries, crowded cells: count pass, look back, fill pass - in this wave
-    Fifo F;
-    uint32_t *fw = reinterpret_cast<uint32_t *>(lds_u);
-    F.fi = fw;
-    F.fj = fw + FIFO_CAP;
-    F.fd = fw + 2 * FIFO_CAP;
-    F.head = F.tail = 0;
-    F.quota = 64u;
-    F.has_pairs = out_pairs != nullptr;
-    F.has_dist = out_dist != nullptr;
-    F.pairs = nullptr;
-    F.dist = nullptr;
-    F.ids = nullptr;
-    F.base = 0;
-    F.hist = nullptr;
-    F.recompute = 0u;
-    F.la = lds_a;
-    F.fq = nullptr;
-    F.fq_store = lds_u + (3 * FIFO_CAP * 4) / 16;
-    F.wrap = 0;
-    F.hmin = F.hmax = F.hn = 0.f;
-    uint32_t *mwords = nullptr;
-    if (moff + 2u * nchunks <= P.mask_cap_units) mwords = P.maskbuf + moff * 64u;
-    uint32_t total;
-    switch (wk) {
-        case WK_NONE: total = run_task_nch<KIND, false, WK_NONE, true>(P, T, i0, F, lds_a, lane, mwords); break;
-        case WK_DIAG: total = run_task_nch<KIND, false, WK_DIAG, true>(P, T, i0, F, lds_a, lane, mwords); break;
-        case WK_UPPER: total = run_task_nch<KIND, false, WK_UPPER, true>(P, T, i0, F, lds_a, lane, mwords); break;
-        default: total = run_task_nch<KIND, false, WK_GENERAL, true>(P, T, i0, F, lds_a, lane, mwords); break;
-    }
-    total = __builtin_amdgcn_readfirstlane(total);
-    const unsigned long long base = slot_lookback(slot_state, slot, total, lane, (uint32_t *)(aux + 1));
-    if (base == ~0ull) return;
-    if ((fl & SLOT_LAST) && lane == 0u) aux[0] = base + total;
-    if (total == 0u || base + total > P.out_cap) return;
-    __builtin_amdgcn_wave_barrier();        // the count pass' LDS reads of lds_a are done before the fill pass rewrites it
-    F.base = base;
-    F.quota = 64u - ((uint32_t)base & 63u);
-    if (out_pairs) F.pairs = out_pairs + base + lane;
-    if (out_dist) F.dist = out_dist + base + lane;
-    switch (wk) {
-        case WK_NONE: run_task_nch<KIND, true, WK_NONE, true>(P, T, i0, F, lds_a, lane, mwords); break;
-        case WK_DIAG: run_task_nch<KIND, true, WK_DIAG, true>(P, T, i0, F, lds_a, lane, mwords); break;
-        case WK_UPPER: run_task_nch<KIND, true, WK_UPPER, true>(P, T, i0, F, lds_a, lane, mwords); break;
-        default: run_task_nch<KIND, true, WK_GENERAL, true>(P, T, i0, F, lds_a, lane, mwords); break;
-    }
-}
-
-template <int KIND>
-inline void launch_pair_fused(unsigned nblocks, hipStream_t stream, const SearchParams *dP, const SlotDesc *slot_desc,
-                              uint32_t nslots, unsigned long long *slot_state, unsigned long long *aux, uint2 *pairs,
-                              float *dist) {
-    hipLaunchKernelGGL((pair_kernel_fused<KIND>), pair_grid(nblocks), dim3(64), 0, stream, dP, slot_desc, nslots, slot_state, aux,
-                       pairs, dist);
 }
 
 // one launch of the pair kernel for a search kind / mode
@@ -1613,11 +1146,5 @@ void launch_pair_within(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t 
 void launch_pair_vdw(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
                      const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                      const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);
-
-// single-pass kernels (pair_k0.hip: single set, pair_k1.hip: two sets)
-void launch_fused_single(unsigned nblocks, hipStream_t stream, const pairk::SearchParams *dP, const pairk::SlotDesc *slot_desc,
-                         uint32_t nslots, unsigned long long *slot_state, unsigned long long *aux, uint2 *pairs, float *dist);
-void launch_fused_double(unsigned nblocks, hipStream_t stream, const pairk::SearchParams *dP, const pairk::SlotDesc *slot_desc,
-                         uint32_t nslots, unsigned long long *slot_state, unsigned long long *aux, uint2 *pairs, float *dist);
 
 }  // namespace mh

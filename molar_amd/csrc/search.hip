@@ -818,32 +818,6 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     return 0;
 }
 
-// single-pass search (pair_kernel_fused): which kinds, and the launch
-bool fused_kind(const molar_hip_ctx *c) {
-    return (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) && c->env_single_pass;
-}
-unsigned long long *fused_aux(molar_hip_ctx *c) { return c->slot_state.as<unsigned long long>() + c->nslots_bound + 1; }
-
-int launch_fused(molar_hip_ctx *c, uint2 *pairs, float *dist, unsigned long long out_cap) {
-    Prof prof(c, 3);
-    SearchParams P = make_params(c);
-    // descriptors, total and status start at zero (also when the frame is repeated with larger buffers)
-    MH_HIP(hipMemsetAsync(c->slot_state.p, 0, (c->nslots_bound + 1) * 8 + 64, c->stream));
-    if (P.nblocks == 0) return 0;
-    P.out_cap = out_cap;
-    MH_TRY(c->params.reserve(sizeof(SearchParams)));
-    hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, c->stream, P, c->params.as<SearchParams>());
-    const SearchParams *dP = c->params.as<SearchParams>();
-    if (c->kind == MOLAR_HIP_SEARCH_SINGLE)
-        launch_fused_single(P.nblocks, c->stream, dP, c->slot_desc.as<SlotDesc>(), (uint32_t)c->nslots_bound,
-                            c->slot_state.as<unsigned long long>(), fused_aux(c), pairs, dist);
-    else
-        launch_fused_double(P.nblocks, c->stream, dP, c->slot_desc.as<SlotDesc>(), (uint32_t)c->nslots_bound,
-                            c->slot_state.as<unsigned long long>(), fused_aux(c), pairs, dist);
-    MH_HIP(hipGetLastError());
-    return 0;
-}
-
 int read_back(molar_hip_ctx *c, void *dst_host, const void *src_dev, size_t bytes) {
     MH_TRY(ensure_pinned(c, bytes));
     MH_HIP(hipMemcpyAsync(c->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -984,7 +958,6 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     MH_TRY(c->slot_desc.reserve((c->nslots_bound + 1) * sizeof(SlotDesc)));
     MH_TRY(c->slot_cnt.reserve((c->nslots_bound + 1) * 4));
     MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
-    MH_TRY(c->slot_state.reserve((c->nslots_bound + 1) * 8 + 64));     // single-pass kernel: look-back descriptors + total/status
     const size_t st_tasks = lookback_state_words(c->ntasks + 1), st_slots = lookback_state_words(c->nslots_bound + 1);
     MH_TRY(c->scan_state.reserve((st_tasks + st_slots) * 8));
     MH_TRY(c->task_mu.reserve((c->ntasks + 1) * 4));
@@ -1121,7 +1094,6 @@ struct ResidentLaunch {
     unsigned long long cap0 = 0;      // result capacity the fill pass was launched with (0: the fill was skipped)
     unsigned long long maskcap0 = 0;  // hit-history units the count pass could record
     bool degenerate = false;          // empty vdw input: nothing was enqueued, the result is empty
-    bool fused = false;               // the single-pass kernel ran (sizes[2] = its status word)
 };
 
 static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::DevBuf &outP, mh::DevBuf &outD,
@@ -1137,17 +1109,6 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     const unsigned long long a = outP.cap / 8u, b = outD.cap / 4u;
     const unsigned long long cap0 = a < b ? a : b;
     L->maskcap0 = c->maskbuf.cap / 256u;
-    std::memset(sizes, 0, 24);
-    if (fused_kind(c)) {
-        // ONE pair kernel: counts, offsets (look-back) and the ordered pair list; the capacity is a kernel-side guard
-        MH_TRY(launch_fused(c, outP.as<uint2>(), outD.as<float>(), cap0));
-        MH_HIP(hipMemcpyAsync(sizes, fused_aux(c), 8, hipMemcpyDeviceToHost, c->stream));
-        MH_HIP(hipMemcpyAsync((char *)sizes + 8, c->task_moff.as<unsigned long long>() + c->ntasks, 8, hipMemcpyDeviceToHost, c->stream));
-        MH_HIP(hipMemcpyAsync((char *)sizes + 16, fused_aux(c) + 1, 8, hipMemcpyDeviceToHost, c->stream));
-        L->cap0 = cap0;
-        L->fused = true;
-        return 0;
-    }
     // one parameter block serves both passes: the count pass ignores the output capacity
     MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, cap0));
     {
@@ -1168,49 +1129,10 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
 // affected passes (first frame of a trajectory; later frames are the same size +- noise).
 static int resident_settle(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD, const void *sizes, const ResidentLaunch &L) {
     const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
-    unsigned long long res[3] = {0, 0, 0};
-    std::memcpy(res, sizes, 24);
-    c->mask_units = fast_kind ? res[1] : 0;
-    if (L.fused) {
-        bool classic = (uint32_t)res[2] != 0u;     // a look-back timed out: repeat the frame with count / scan / fill
-        c->total = res[0];
-        for (int attempt = 0; !classic && attempt < 2; ++attempt) {
-            bool again = false;
-            if (c->mask_units > c->maskbuf.cap / 256u) {
-                MH_TRY(c->maskbuf.reserve((size_t)(c->mask_units + c->mask_units / 4u) * 256u + 256u));
-                again = true;
-            } else if (c->mask_units > L.maskcap0 && attempt == 0) {
-                again = true;
-            }
-            const unsigned long long have = std::min<unsigned long long>(outP.cap / 8u, outD.cap / 4u);
-            if (c->total > have) {
-                MH_TRY(outP.reserve((size_t)(c->total + c->total / 16u) * 8));
-                MH_TRY(outD.reserve((size_t)(c->total + c->total / 16u) * 4));
-                again = true;
-            } else if (c->total > L.cap0 && attempt == 0) {
-                again = true;
-            }
-            if (!again) break;
-            MH_TRY(launch_fused(c, outP.as<uint2>(), outD.as<float>(), std::min<unsigned long long>(outP.cap / 8u, outD.cap / 4u)));
-            unsigned long long r2[2] = {0, 0};
-            MH_TRY(read_back(c, r2, fused_aux(c), 16));
-            c->total = r2[0];
-            classic = (uint32_t)r2[1] != 0u;
-        }
-        if (classic) {
-            MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr));
-            MH_TRY(finish_count(c));
-            if (c->total) {
-                MH_TRY(outP.reserve((size_t)(c->total + c->total / 16u) * 8));
-                MH_TRY(outD.reserve((size_t)(c->total + c->total / 16u) * 4));
-                MH_TRY(launch_pairs<true>(c, outP.as<uint2>(), outD.as<float>(), nullptr));
-                MH_HIP(hipStreamSynchronize(c->stream));
-            }
-        }
-        c->have_search = true;
-        return 0;
-    }
+    unsigned long long res[2] = {0, 0};
+    std::memcpy(res, sizes, 16);
     c->total = res[0];
+    c->mask_units = fast_kind ? res[1] : 0;
     c->have_search = true;
     bool refill = L.cap0 == 0 && c->total != 0;
     if (c->mask_units > L.maskcap0) {        // hit bits did not fit: grow, record them, fill again
@@ -1256,14 +1178,14 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     if (T.pending)
         return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "both result sets are in flight: call molar_hip_search_resident_end first");
     MH_HIP(hipSetDevice(c->device));
-    if (!c->h_sizes) MH_HIP(hipHostMalloc(&c->h_sizes, 128, hipHostMallocDefault));
+    if (!c->h_sizes) MH_HIP(hipHostMalloc(&c->h_sizes, 64, hipHostMallocDefault));
     if (!T.done) MH_HIP(hipEventCreateWithFlags(&T.done, hipEventDisableTiming));
     T.desc = *q;
     ResidentLaunch L;
     c->set = c->set_store[slot];         // this ticket's grid generation (the other one may still be read by the frame in flight)
     c->want_side = !c->env_no_side;
     c->side_wait = c->gen_free[slot];    // an asynchronous histogram call may have been the last reader of this generation
-    const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 32 * slot, &L);
+    const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 16 * slot, &L);
     c->want_side = false;
     c->side_wait = nullptr;
     MH_TRY(erc);
@@ -1271,7 +1193,6 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     T.cap0 = L.cap0;
     T.maskcap0 = L.maskcap0;
     T.degenerate = L.degenerate;
-    T.fused = L.fused;
     T.serial = c->search_serial;
     T.pending = true;
     c->next_ticket ^= 1;
@@ -1291,12 +1212,12 @@ int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *ou
     uint64_t total = 0;
     if (!T.degenerate) {
         MH_HIP(hipEventSynchronize(T.done));
-        const void *sizes = (const char *)c->h_sizes + 32 * ticket;
-        unsigned long long res[3];
-        std::memcpy(res, sizes, 24);
+        const void *sizes = (const char *)c->h_sizes + 16 * ticket;
+        unsigned long long res[2];
+        std::memcpy(res, sizes, 16);
         const bool fast_kind = T.desc.kind == MOLAR_HIP_SEARCH_SINGLE || T.desc.kind == MOLAR_HIP_SEARCH_DOUBLE;
         total = res[0];
-        if (res[0] > T.cap0 || (fast_kind && res[1] > T.maskcap0) || (T.fused && (uint32_t)res[2] != 0u)) {
+        if (res[0] > T.cap0 || (fast_kind && res[1] > T.maskcap0)) {
             // A buffer was too small (first frames of a trajectory).  Let everything in flight finish - a younger
             // search owns the context's intermediate buffers by now, its results sit in the other result set - then
             // grow and repeat: the affected passes if this is still the context's cached search, else the frame.
@@ -1304,7 +1225,6 @@ int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *ou
             ResidentLaunch L;
             L.cap0 = T.cap0;
             L.maskcap0 = T.maskcap0;
-            L.fused = T.fused;
             if (T.serial != c->search_serial) {
                 if (fast_kind && res[1] > c->maskbuf.cap / 256u)
                     MH_TRY(c->maskbuf.reserve((size_t)(res[1] + res[1] / 4u) * 256u + 256u));
