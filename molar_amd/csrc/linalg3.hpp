@@ -18,32 +18,45 @@ namespace mh {
 // v = eigenvectors as COLUMNS (v[r*N+c]).
 template <int N>
 __host__ __device__ inline void jacobi_sym(double *a, double *w, double *v) {
+    // every loop over matrix indices is unrolled: on the GPU the two small matrices then live in registers (dynamic
+    // indexing would put them in scratch memory, ~20 us per call for one lane)
+#pragma unroll
     for (int i = 0; i < N * N; ++i) v[i] = 0.0;
+#pragma unroll
     for (int i = 0; i < N; ++i) v[i * N + i] = 1.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0.0, diag = 0.0;
+#pragma unroll
         for (int p = 0; p < N; ++p) {
             diag += a[p * N + p] * a[p * N + p];
+#pragma unroll
             for (int q = p + 1; q < N; ++q) off += a[p * N + q] * a[p * N + q];
         }
-        if (off <= 1e-32 * diag || off < 1e-300) break;
+        // off-diagonal mass below 1e-13 of the diagonal (squared: 1e-26): eigenvectors good to ~1e-13, far below the f32
+        // results they feed; every further sweep is ~2 us of dependent f64 divisions and square roots on one GPU lane
+        if (off <= 1e-26 * diag || off < 1e-300) break;
+#pragma unroll
         for (int p = 0; p < N - 1; ++p)
+#pragma unroll
             for (int q = p + 1; q < N; ++q) {
                 const double apq = a[p * N + q];
                 if (apq == 0.0) continue;
                 const double tau = (a[q * N + q] - a[p * N + p]) / (2.0 * apq);
                 const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
                 const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+#pragma unroll
                 for (int k = 0; k < N; ++k) {   // columns p,q
                     const double akp = a[k * N + p], akq = a[k * N + q];
                     a[k * N + p] = cs * akp - sn * akq;
                     a[k * N + q] = sn * akp + cs * akq;
                 }
+#pragma unroll
                 for (int k = 0; k < N; ++k) {   // rows p,q
                     const double apk = a[p * N + k], aqk = a[q * N + k];
                     a[p * N + k] = cs * apk - sn * aqk;
                     a[q * N + k] = sn * apk + cs * aqk;
                 }
+#pragma unroll
                 for (int k = 0; k < N; ++k) {
                     const double vkp = v[k * N + p], vkq = v[k * N + q];
                     v[k * N + p] = cs * vkp - sn * vkq;
@@ -51,6 +64,7 @@ __host__ __device__ inline void jacobi_sym(double *a, double *w, double *v) {
                 }
             }
     }
+#pragma unroll
     for (int i = 0; i < N; ++i) w[i] = a[i * N + i];
 }
 
@@ -69,10 +83,14 @@ __host__ __device__ inline bool rotation_from_cov(const double *cov, double *R) 
                      Sxy - Syx,       Szx + Sxz,       Syz + Szy,        -Sxx - Syy + Szz};
     double w[4], v[16];
     jacobi_sym<4>(Nm, w, v);
-    int best = 0;
+    // eigenvector of the largest eigenvalue (first one wins ties); selected with static indices, see jacobi_sym
+    double wb = w[0], q0 = v[0], qx = v[4], qy = v[8], qz = v[12];
+#pragma unroll
     for (int i = 1; i < 4; ++i)
-        if (w[i] > w[best]) best = i;
-    double q0 = v[0 * 4 + best], qx = v[1 * 4 + best], qy = v[2 * 4 + best], qz = v[3 * 4 + best];
+        if (w[i] > wb) {
+            wb = w[i];
+            q0 = v[0 * 4 + i]; qx = v[1 * 4 + i]; qy = v[2 * 4 + i]; qz = v[3 * 4 + i];
+        }
     const double nq = sqrt(q0 * q0 + qx * qx + qy * qy + qz * qz);
     q0 /= nq; qx /= nq; qy /= nq; qz /= nq;
     // column-major R

@@ -113,6 +113,23 @@ __global__ void __launch_bounds__(RB) k_central(Sel s, const float *center, int 
     block_reduce_store<8>(acc, partials);
 }
 
+// uncentred moments for the non-periodic gyration / inertia in ONE pass (exact products, f64 sums):
+// [0]=S m, [1..3]=S m p, [4..9]=S m xx, yy, zz, xy, xz, yz.  The host centres them on the f32 centre of mass:
+// S m (p-c)(p-c)^T = S m p p^T - c (S m p)^T - (S m p) c^T + S m c c^T for any c.
+__global__ void __launch_bounds__(RB) k_moments(Sel s, double *partials) {
+    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const V3 pf = pos_of(s, blockIdx.y, a);
+        const double x = pf.x, y = pf.y, z = pf.z, m = (double)s.mass[a];
+        acc[0] += m;
+        acc[1] += m * x; acc[2] += m * y; acc[3] += m * z;
+        acc[4] += m * (x * x); acc[5] += m * (y * y); acc[6] += m * (z * z);
+        acc[7] += m * (x * y); acc[8] += m * (x * z); acc[9] += m * (y * z);
+    }
+    block_reduce_store<10>(acc, partials);
+}
+
 // two selections: [0]=sum |p2-p1|^2 (rmsd :499-501), [1]=sum |p2-p1|^2 m, [2]=sum m (rmsd_mw :548-551)
 __global__ void __launch_bounds__(RB) k_rmsd(Sel s1, Sel s2, double *partials) {
     double acc[3] = {0, 0, 0};
@@ -152,34 +169,155 @@ __global__ void __launch_bounds__(RB) k_cov(Sel s1, Sel s2, const float *c1v, co
     block_reduce_store<9>(acc, partials);
 }
 
-// apply_transform (modify.rs:32-36): p <- R*p + t in f32 (written back when `write`), fused with the
-// sums the per-frame loop needs afterwards: [0]=sum |ref-p'|^2, [1]=sum m, [2..4]=sum p'*m,
-// [5]=sum m |p'|^2 (gyration about the new COM by the parallel-axis identity, in f64).
-__global__ void __launch_bounds__(RB) k_apply(Sel s1, Sel s2, float *xyz_rw, const float *Rt /*[frame][12]*/,
-                                              int write, double *partials) {
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    const float *R = Rt + 12 * blockIdx.y;
+// ---------------------------------------------------------------- fused fit pass
+// ONE gather pass gives everything the per-frame loop of a fit needs (fit_transform measure.rs:507-522, rot_transform
+// :613-643, rmsd :485-504, center_of_mass :60-75, gyration :78-87 of the fitted selection): uncentred sums in f64,
+//   mass-weighted (m from sel1, :621)   [0] S m   [1..3] S m p   [4..6] S m q   [7..15] S m q_r p_c (column-major c*3+r)
+//                                       [16] S m |p|^2
+//   reference's own masses (cm2, :512)  [17] S m2   [18..20] S m2 q
+//   unweighted (rmsd is, :499-501)      [21..23] S p   [24..26] S q   [27..35] S q_r p_c   [36] S |p|^2   [37] S |q|^2
+// p = atom of the current frame, q = atom of the reference.  The centred covariance, the RMSD after the fit and the
+// gyration radius follow from these analytically in the finalizer; products of two f32 are exact in f64 and the sums
+// keep ~1e-16 relative error, so the cancellation in "uncentred minus centre terms" (<= 1e6 : 1 for MD boxes) costs nothing
+// that the reference's serial f32 sums do not lose a million times over.
+constexpr int FS_W = 21, FS_ALL = 38;
+
+template <bool UNW>
+__global__ void __launch_bounds__(RB) k_fit_sums(Sel s1, Sel s2, double *partials) {
+    constexpr int NV = UNW ? FS_ALL : FS_W;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s1.n; k += gridDim.x * RB) {
+        const uint64_t a1 = atom_of(s1, k), a2 = atom_of(s2, k);
+        const V3 pf = pos_of(s1, blockIdx.y, a1), qf = pos_of(s2, 0, a2);
+        const double p[3] = {pf.x, pf.y, pf.z}, q[3] = {qf.x, qf.y, qf.z};
+        const double m = (double)s1.mass[a1];
+        const double m2 = s2.mass ? (double)s2.mass[a2] : m;
+        const double pp = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+        acc[0] += m;
+        acc[16] += m * pp;
+        acc[17] += m2;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            acc[1 + d] += m * p[d];
+            acc[4 + d] += m * q[d];
+            acc[18 + d] += m2 * q[d];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) acc[7 + d * 3 + r] += (m * q[r]) * p[d];
+        }
+        if (UNW) {
+            acc[36] += pp;
+            acc[37] += (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                acc[21 + d] += p[d];
+                acc[24 + d] += q[d];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) acc[27 + d * 3 + r] += q[r] * p[d];
+            }
+        }
+    }
+    block_reduce_store<NV>(acc, partials);
+}
+
+// One 64-lane workgroup per frame: totals the partials in a fixed order, then lane 0 derives
+//   out[frame] = { R (9, column-major), t (3), rmsd, com (3), gyration, status }      (18 floats)
+// R by Horn's quaternion method (rotation_from_cov); t = cm2 + R (-cm1) in f32 like Translation*rot*Translation (:521).
+// RMSD, COM and gyration are those of the FITTED selection (p' = R p + t), from the sums:
+//   S |R p + t - q|^2 = S|p|^2 + S|q|^2 + n|t|^2 + 2 t.(R S p) - 2 t.S q - 2 sum_rc R[r][c] S q_r p_c      (R orthonormal)
+//   com' = R (S m p / S m) + t,   rg^2 = S m|p|^2 / S m - |S m p / S m|^2                                 (rigid motion)
+__global__ void __launch_bounds__(64) k_fit_final(const double *partials, uint32_t nblk, int nv, uint32_t n, int at_origin,
+                                                  float *out) {
+    const uint32_t f = blockIdx.x, lane = threadIdx.x;
+    double S[FS_ALL];
+#pragma unroll
+    for (int v = 0; v < FS_ALL; ++v) S[v] = 0.0;
+    for (uint32_t b = lane; b < nblk; b += 64) {
+        const double *row = partials + ((size_t)f * nblk + b) * nv;
+#pragma unroll
+        for (int v = 0; v < FS_ALL; ++v)
+            if (v < nv) S[v] += row[v];
+    }
+    // butterfly over the lanes, all values per step (independent shuffles pipeline; one value at a time would
+    // serialise 38 x 6 dependent cross-lane round trips)
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int v = 0; v < FS_ALL; ++v) S[v] += __shfl_xor(S[v], off, 64);
+    }
+    if (lane != 0) return;
+    float *o = out + 18 * (size_t)f;
+    #pragma unroll
+    for (int i = 0; i < 17; ++i) o[i] = 0.f;
+    if (S[0] == 0.0 || (!at_origin && S[17] == 0.0)) {
+        o[17] = __int_as_float(MOLAR_HIP_ERR_ZERO_MASS);
+        return;
+    }
+    // centres as the reference holds them: f32 points (Pos)
+    float c1f[3] = {0.f, 0.f, 0.f}, c2f[3] = {0.f, 0.f, 0.f};
+    if (!at_origin)
+        #pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            c1f[d] = (float)(S[1 + d] / S[0]);
+            c2f[d] = (float)(S[18 + d] / S[17]);
+        }
+    double cov[9], R[9];
+    #pragma unroll
+    for (int c = 0; c < 3; ++c)
+        #pragma unroll
+        for (int r = 0; r < 3; ++r)      // S m (q_r - c2_r)(p_c - c1_c)
+            cov[c * 3 + r] = ((S[7 + c * 3 + r] - (double)c2f[r] * S[1 + c]) - S[4 + r] * (double)c1f[c]) +
+                             S[0] * (double)c2f[r] * (double)c1f[c];
+    if (!rotation_from_cov(cov, R)) {
+        o[17] = __int_as_float(MOLAR_HIP_ERR_SVD);
+        return;
+    }
+    float Rf[9];
+    #pragma unroll
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)R[i];
+    const V3 rv = mat_vec(Rf, v3(-c1f[0], -c1f[1], -c1f[2]));
+    const float tf[3] = {at_origin ? 0.f : c2f[0] + rv.x, at_origin ? 0.f : c2f[1] + rv.y, at_origin ? 0.f : c2f[2] + rv.z};
+    #pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = Rf[i];
+    #pragma unroll
+    for (int d = 0; d < 3; ++d) o[9 + d] = tf[d];
+    o[17] = __int_as_float(0);
+    // scalars of the fitted selection
+    const double t[3] = {tf[0], tf[1], tf[2]};
+    const double cm[3] = {S[1] / S[0], S[2] / S[0], S[3] / S[0]};
+    #pragma unroll
+    for (int r = 0; r < 3; ++r) o[13 + r] = (float)(((R[0 * 3 + r] * cm[0] + R[1 * 3 + r] * cm[1]) + R[2 * 3 + r] * cm[2]) + t[r]);
+    double rg2 = S[16] / S[0] - ((cm[0] * cm[0] + cm[1] * cm[1]) + cm[2] * cm[2]);
+    o[16] = (float)sqrt(rg2 > 0.0 ? rg2 : 0.0);
+    if (nv == FS_ALL && n) {
+        double cross = 0.0, tRp = 0.0, tq = 0.0;
+        #pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double rsp = 0.0;
+            #pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                cross += R[c * 3 + r] * S[27 + c * 3 + r];
+                rsp += R[c * 3 + r] * S[21 + c];
+            }
+            tRp += t[r] * rsp;
+            tq += t[r] * S[24 + r];
+        }
+        const double ss = ((S[36] + S[37]) + (double)n * ((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2])) + 2.0 * ((tRp - tq) - cross);
+        o[12] = (float)sqrt(ss > 0.0 ? ss / (double)n : 0.0);
+    }
+}
+
+// apply_transform (modify.rs:32-36) for every frame of a batch: p <- R p + t in f32, in place
+__global__ void __launch_bounds__(RB) k_apply_batch(Sel s1, float *xyz_rw, const float *fit /*[frame][18]*/) {
+    const float *R = fit + 18 * (size_t)blockIdx.y;
+    if (__float_as_int(R[17]) != 0) return;
     const V3 t = v3(R[9], R[10], R[11]);
     for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s1.n; k += gridDim.x * RB) {
         const uint64_t a1 = atom_of(s1, k);
-        const V3 rp = mat_vec(R, pos_of(s1, blockIdx.y, a1));
-        const V3 pn = rp + t;
-        if (write) {
-            float *q = xyz_rw + (size_t)blockIdx.y * s1.frame_stride + 3 * a1;
-            q[0] = pn.x; q[1] = pn.y; q[2] = pn.z;
-        }
-        if (s2.xyz) {
-            const V3 v = pos_of(s2, 0, atom_of(s2, k)) - pn;
-            acc[0] += (double)norm2(v);
-        }
-        const float m = s1.mass ? s1.mass[a1] : 1.0f;
-        acc[1] += (double)m;
-        acc[2] += (double)(pn.x * m);
-        acc[3] += (double)(pn.y * m);
-        acc[4] += (double)(pn.z * m);
-        acc[5] += (double)m * ((double)pn.x * pn.x + (double)pn.y * pn.y + (double)pn.z * pn.z);
+        const V3 pn = mat_vec(R, pos_of(s1, blockIdx.y, a1)) + t;
+        float *q = xyz_rw + (size_t)blockIdx.y * s1.frame_stride + 3 * a1;
+        q[0] = pn.x; q[1] = pn.y; q[2] = pn.z;
     }
-    block_reduce_store<6>(acc, partials);
 }
 
 // unwrap_simple_dim (modify.rs:40-54): p_k <- closest_image(p_k, p_0) for k >= 1
@@ -385,78 +523,34 @@ __global__ void __launch_bounds__(64) k_lipid_order(const float *__restrict__ xy
 
 // ---------------------------------------------------------------- finalize kernels (one thread per frame)
 
-__device__ __forceinline__ void sum_partials(const double *partials, uint32_t frame, uint32_t nblk, int nv,
-                                             double *out) {
-    for (int v = 0; v < nv; ++v) out[v] = 0.0;
-    const double *p = partials + (size_t)frame * nblk * nv;
-    for (uint32_t b = 0; b < nblk; ++b)
-        for (int v = 0; v < nv; ++v) out[v] += p[(size_t)b * nv + v];
-}
-
-// COM per frame from k_sums partials -> centers[frame][3] (f32, as the reference's Pos) + status
-__global__ void k_fin_com(const double *partials, uint32_t nblk, uint32_t nframes, float *centers, int *status) {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nframes) return;
-    double s[7];
-    sum_partials(partials, f, nblk, 7, s);
-    if (s[0] == 0.0) {
-        atomicMax(status, MOLAR_HIP_ERR_ZERO_MASS);
-        centers[3 * f] = centers[3 * f + 1] = centers[3 * f + 2] = 0.f;
-        return;
-    }
-    centers[3 * f] = (float)(s[1] / s[0]);
-    centers[3 * f + 1] = (float)(s[2] / s[0]);
-    centers[3 * f + 2] = (float)(s[3] / s[0]);
-}
-
-// Kabsch rotation + translation per frame: Rt[frame] = {R (9, column-major), t (3)}
-// fit_transform (:507-522): t = cm2 + R*(-cm1)
-__global__ void k_fin_fit(const double *partials, uint32_t nblk, uint32_t nframes, const float *c1, const float *c2,
-                          float *Rt, int *status) {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nframes) return;
-    double cov[9], R[9];
-    sum_partials(partials, f, nblk, 9, cov);
-    if (!rotation_from_cov(cov, R)) {
-        atomicMax(status, MOLAR_HIP_ERR_SVD);
-        for (int i = 0; i < 12; ++i) Rt[12 * f + i] = 0.f;
-        return;
-    }
-    float Rf[9];
-    for (int i = 0; i < 9; ++i) Rf[i] = (float)R[i];
-    const V3 neg = v3(-c1[3 * f], -c1[3 * f + 1], -c1[3 * f + 2]);
-    const V3 rv = mat_vec(Rf, neg);
-    for (int i = 0; i < 9; ++i) Rt[12 * f + i] = Rf[i];
-    Rt[12 * f + 9] = c2[0] + rv.x;
-    Rt[12 * f + 10] = c2[1] + rv.y;
-    Rt[12 * f + 11] = c2[2] + rv.z;
-}
-
-// per-frame scalars after k_apply: out[frame] = {rmsd, com.x, com.y, com.z, gyration}
-__global__ void k_fin_apply(const double *partials, uint32_t nblk, uint32_t nframes, uint32_t n, float *out) {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nframes) return;
-    double s[6];
-    sum_partials(partials, f, nblk, 6, s);
-    const double cx = s[2] / s[1], cy = s[3] / s[1], cz = s[4] / s[1];
-    double rg2 = s[5] / s[1] - (cx * cx + cy * cy + cz * cz);
-    if (rg2 < 0.0) rg2 = 0.0;
-    out[5 * f] = (float)sqrt(s[0] / (double)n);
-    out[5 * f + 1] = (float)cx;
-    out[5 * f + 2] = (float)cy;
-    out[5 * f + 3] = (float)cz;
-    out[5 * f + 4] = (float)sqrt(rg2);
-}
-
 // generic: total the partials of frame 0 into results[0..nv)
-__global__ void k_fin_sum(const double *partials, uint32_t nblk, int nv, double *results) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) sum_partials(partials, 0, nblk, nv, results);
+// (64 lanes: lane l adds blocks l, l+64, ...; a butterfly adds the lanes - a fixed order, so results are reproducible)
+__global__ void __launch_bounds__(64) k_fin_sum(const double *partials, uint32_t nblk, int nv, double *results) {
+    const uint32_t lane = threadIdx.x;
+    double x[16];        // nv <= 16 for every caller
+#pragma unroll
+    for (int v = 0; v < 16; ++v) x[v] = 0.0;
+    for (uint32_t b = lane; b < nblk; b += 64) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            if (v < nv) x[v] += partials[(size_t)b * nv + v];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) x[v] += __shfl_xor(x[v], off, 64);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+        if (lane == 0 && v < nv) results[v] = x[v];
 }
 
 // ---------------------------------------------------------------- host helpers
 
 uint32_t blocks_for(const molar_hip_ctx *c, uint32_t n, uint32_t nframes) {
-    uint32_t nb = (n + RB * 8 - 1) / (RB * 8);   // >= 8 atoms per thread
+    // >= 8 atoms per thread for batches; a single frame is latency-bound (a thread's gathers are serial round trips to
+    // HBM), so it is spread over more workgroups: 4 atoms per thread
+    const uint32_t per = nframes >= 8 ? 8u : 4u;
+    uint32_t nb = (n + RB * per - 1) / (RB * per);
     if (nb < 1) nb = 1;
     uint32_t cap = nframes >= 64 ? 16u : (uint32_t)c->num_cus * 4u;
     if (nb > cap) nb = cap;
@@ -549,6 +643,25 @@ int central_host(molar_hip_ctx *c, const Sel &s, const float center[3], const mo
     return reduce1(c, s.n, 8, r, [&](uint32_t nb, double *part) {
         hipLaunchKernelGGL(k_central, dim3(nb, 1), dim3(RB), 0, c->stream, s, c->m_out.as<float>(), box ? 1 : 0, b, part);
     });
+}
+
+// non-periodic central moments in one pass: r[] laid out like central_host's result (k_central)
+int central_onepass_host(molar_hip_ctx *c, const Sel &s, double r[8]) {
+    double u[10];
+    MH_TRY(reduce1(c, s.n, 10, u, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k_moments, dim3(nb, 1), dim3(RB), 0, c->stream, s, part);
+    }));
+    if (u[0] == 0.0) return fail(MOLAR_HIP_ERR_ZERO_MASS, "zero mass");
+    const double cx = (double)(float)(u[1] / u[0]), cy = (double)(float)(u[2] / u[0]), cz = (double)(float)(u[3] / u[0]);   // the f32 centre (:82)
+    const double cc[3] = {cx, cy, cz}, sp[3] = {u[1], u[2], u[3]};
+    auto cen = [&](int a, int b, double raw) { return ((raw - cc[a] * sp[b]) - sp[a] * cc[b]) + u[0] * cc[a] * cc[b]; };
+    const double xx = cen(0, 0, u[4]), yy = cen(1, 1, u[5]), zz = cen(2, 2, u[6]);
+    const double xy = cen(0, 1, u[7]), xz = cen(0, 2, u[8]), yz = cen(1, 2, u[9]);
+    r[0] = u[0];
+    r[1] = (xx + yy) + zz;
+    r[2] = yy + zz; r[3] = xx + zz; r[4] = xx + yy;
+    r[5] = -xy; r[6] = -xz; r[7] = -yz;
+    return 0;
 }
 
 #define MH_CTX(c)                                                              \
@@ -644,15 +757,15 @@ int molar_hip_gyration(molar_hip_ctx *c, const float *xyz, size_t natoms, const 
     MH_TRY(stage_sel(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
     float cm[3];
     molar_hip_box b;
+    double r[8];
     if (box9) {
         MH_TRY(molar_hip_box_from_matrix(box9, &b));
         MH_TRY(com_pbc_host(c, s, b, MOLAR_HIP_PBC_FULL, true, cm));   // center_of_mass_pbc (:227)
+        MH_TRY(central_host(c, s, cm, &b, r));
     } else {
-        MH_TRY(com_host(c, s, cm));                                   // (:82)
+        MH_TRY(central_onepass_host(c, s, r));                        // centre of mass (:82) and moments in one pass
     }
-    double r[8];
-    MH_TRY(central_host(c, s, cm, box9 ? &b : nullptr, r));
-    *out = (float)std::sqrt(r[1] / r[0]);
+    *out = (float)std::sqrt(r[1] > 0.0 ? r[1] / r[0] : 0.0);
     return MOLAR_HIP_OK;
 }
 
@@ -664,14 +777,14 @@ int molar_hip_inertia(molar_hip_ctx *c, const float *xyz, size_t natoms, const u
     MH_TRY(stage_sel(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
     float cm[3];
     molar_hip_box b;
+    double r[8];
     if (box9) {
         MH_TRY(molar_hip_box_from_matrix(box9, &b));
         MH_TRY(com_pbc_host(c, s, b, MOLAR_HIP_PBC_FULL, true, cm));
+        MH_TRY(central_host(c, s, cm, &b, r));
     } else {
-        MH_TRY(com_host(c, s, cm));
+        MH_TRY(central_onepass_host(c, s, r));
     }
-    double r[8];
-    MH_TRY(central_host(c, s, cm, box9 ? &b : nullptr, r));
     // symmetric tensor (:580-589); stored as f32 like the reference's Matrix3f before the eigen solve
     const float T00 = (float)r[2], T11 = (float)r[3], T22 = (float)r[4];
     const float T01 = (float)r[5], T02 = (float)r[6], T12 = (float)r[7];
@@ -746,6 +859,24 @@ int molar_hip_fit_transform(molar_hip_ctx *c, const float *xyz1, size_t natoms1,
     Sel s1, s2;
     MH_TRY(stage_sel(c, xyz1, natoms1, idx1, n1, mass1, c->m_xyz1, c->m_idx1, c->m_mass1, &s1));
     MH_TRY(stage_sel(c, xyz2, natoms2, idx2, n2, at_origin ? nullptr : mass2, c->m_xyz2, c->m_idx2, c->m_mass2, &s2));
+    if (s1.n == s2.n && s1.n != 0) {
+        // one gather pass + finalizer (both centres, the centred covariance and Horn's rotation on the device)
+        const uint32_t nb = blocks_for(c, s1.n, 1);
+        MH_TRY(c->m_partials.reserve((size_t)nb * FS_W * 8));
+        MH_TRY(c->m_out.reserve(18 * 4));
+        hipLaunchKernelGGL(k_fit_sums<false>, dim3(nb, 1), dim3(RB), 0, c->stream, s1, s2, c->m_partials.as<double>());
+        hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(64), 0, c->stream, c->m_partials.as<double>(), nb, FS_W, s1.n,
+                           at_origin ? 1 : 0, c->m_out.as<float>());
+        MH_HIP(hipGetLastError());
+        float h[18];
+        MH_TRY(pull(c, h, c->m_out.p, sizeof h));
+        int st;
+        std::memcpy(&st, &h[17], 4);
+        if (st) return fail(st, st == MOLAR_HIP_ERR_ZERO_MASS ? "zero mass" : "SVD failed");
+        std::memcpy(R9, h, 36);
+        std::memcpy(t3, h + 9, 12);
+        return MOLAR_HIP_OK;
+    }
     float cm[6] = {0, 0, 0, 0, 0, 0};
     if (!at_origin) {
         MH_TRY(com_host(c, s1, cm));        // cm1 (:511)
@@ -956,16 +1087,13 @@ int molar_hip_apply_transform(molar_hip_ctx *c, float *xyz, size_t natoms, const
     MH_CTX(c);
     Sel s;
     MH_TRY(stage_sel(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
-    float Rt[12];
+    float Rt[18] = {};       // the record layout of k_fit_final: R, t, ..., status 0
     std::memcpy(Rt, R9, 36);
     std::memcpy(Rt + 9, t3, 12);
-    MH_TRY(c->m_out.reserve(64));
+    MH_TRY(c->m_out.reserve(sizeof Rt));
     MH_HIP(hipMemcpyAsync(c->m_out.p, Rt, sizeof Rt, hipMemcpyHostToDevice, c->stream));
     const uint32_t nb = blocks_for(c, s.n, 1);
-    MH_TRY(c->m_partials.reserve((size_t)nb * 6 * 8));
-    Sel none{};
-    hipLaunchKernelGGL(k_apply, dim3(nb, 1), dim3(RB), 0, c->stream, s, none, const_cast<float *>(s.xyz),
-                       c->m_out.as<float>(), 1, c->m_partials.as<double>());
+    hipLaunchKernelGGL(k_apply_batch, dim3(nb, 1), dim3(RB), 0, c->stream, s, const_cast<float *>(s.xyz), c->m_out.as<float>());
     MH_HIP(hipGetLastError());
     if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, s.xyz, natoms * 12, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
@@ -1010,53 +1138,44 @@ int molar_hip_fit_rmsd_batch(molar_hip_ctx *c, float *frames, size_t nframes, si
     ref.mass = cur.mass;
     const uint32_t F = (uint32_t)nframes;
     const uint32_t nb = blocks_for(c, cur.n, F);
-    const uint32_t nbr = blocks_for(c, ref.n, 1);
-    MH_TRY(c->m_partials.reserve((size_t)std::max(nb * F, nbr) * 9 * 8));
-    // m_out layout: c1[F][3] | c2[3] | Rt[F][12] | scal[F][5] | status
-    const size_t off_c2 = (size_t)F * 3, off_rt = off_c2 + 4, off_sc = off_rt + (size_t)F * 12,
-                 off_st = off_sc + (size_t)F * 5;
-    MH_TRY(c->m_out.reserve((off_st + 4) * 4));
+    MH_TRY(c->m_partials.reserve((size_t)nb * F * FS_ALL * 8));
+    MH_TRY(c->m_out.reserve((size_t)F * 18 * 4));
     float *o = c->m_out.as<float>();
-    int *status = reinterpret_cast<int *>(o + off_st);
     double *part = c->m_partials.as<double>();
-    MH_HIP(hipMemsetAsync(status, 0, 4, c->stream));
-    const unsigned fb = (F + 63) / 64;
-    Prof *prof = new Prof(c, 4);
-    // reference COM (once)
-    hipLaunchKernelGGL(k_sums, dim3(nbr, 1), dim3(RB), 0, c->stream, ref, part);
-    hipLaunchKernelGGL(k_fin_com, dim3(1), dim3(64), 0, c->stream, part, nbr, 1u, o + off_c2, status);
-    // pass 1: COM of every frame
-    hipLaunchKernelGGL(k_sums, dim3(nb, F), dim3(RB), 0, c->stream, cur, part);
-    hipLaunchKernelGGL(k_fin_com, dim3(fb), dim3(64), 0, c->stream, part, nb, F, o, status);
-    // pass 2: covariance -> rotation + translation
-    hipLaunchKernelGGL(k_cov, dim3(nb, F), dim3(RB), 0, c->stream, cur, ref, o, o + off_c2, part);
-    hipLaunchKernelGGL(k_fin_fit, dim3(fb), dim3(64), 0, c->stream, part, nb, F, o, o + off_c2, o + off_rt, status);
-    // pass 3: apply + rmsd + COM/gyration of the fitted selection
-    hipLaunchKernelGGL(k_apply, dim3(nb, F), dim3(RB), 0, c->stream, cur, ref, const_cast<float *>(cur.xyz),
-                       o + off_rt, apply ? 1 : 0, part);
-    hipLaunchKernelGGL(k_fin_apply, dim3(fb), dim3(64), 0, c->stream, part, nb, F, cur.n, o + off_sc);
-    delete prof;
+    {
+        // one gather pass, one finalizer, and the write pass only if the caller wants the frames moved
+        Prof prof(c, 4);
+        hipLaunchKernelGGL(k_fit_sums<true>, dim3(nb, F), dim3(RB), 0, c->stream, cur, ref, part);
+        hipLaunchKernelGGL(k_fit_final, dim3(F), dim3(64), 0, c->stream, part, nb, FS_ALL, cur.n, 0, o);
+        if (apply)
+            hipLaunchKernelGGL(k_apply_batch, dim3(nb, F), dim3(RB), 0, c->stream, cur, const_cast<float *>(cur.xyz), o);
+    }
     MH_HIP(hipGetLastError());
-    // results
-    std::vector<float> h((off_st + 1) - off_rt);
-    MH_TRY(pull(c, h.data(), o + off_rt, h.size() * 4));
-    int st;
-    std::memcpy(&st, &h[off_st - off_rt], 4);
-    if (st) return fail(st, st == MOLAR_HIP_ERR_ZERO_MASS ? "zero mass" : "SVD failed");
+    std::vector<float> h((size_t)F * 18);
+    MH_TRY(pull(c, h.data(), o, h.size() * 4));
+    for (uint32_t f = 0; f < F; ++f) {
+        int st;
+        std::memcpy(&st, &h[18 * (size_t)f + 17], 4);
+        if (st) return fail(st, st == MOLAR_HIP_ERR_ZERO_MASS ? "zero mass" : "SVD failed");
+    }
     auto emit = [&](float *dst, size_t count, auto getter) -> int {
         if (!dst) return 0;
         std::vector<float> tmp(count);
         for (size_t k = 0; k < count; ++k) tmp[k] = getter(k);
-        if (is_device_ptr(dst)) MH_HIP(hipMemcpyAsync(dst, tmp.data(), count * 4, hipMemcpyHostToDevice, c->stream));
-        else std::memcpy(dst, tmp.data(), count * 4);
+        if (is_device_ptr(dst)) {
+            MH_HIP(hipMemcpyAsync(dst, tmp.data(), count * 4, hipMemcpyHostToDevice, c->stream));
+            MH_HIP(hipStreamSynchronize(c->stream));      // tmp dies with this scope
+        } else {
+            std::memcpy(dst, tmp.data(), count * 4);
+        }
         return 0;
     };
-    const float *rt = h.data(), *sc = h.data() + (off_sc - off_rt);
-    MH_TRY(emit(rmsd_out, F, [&](size_t k) { return sc[5 * k]; }));
-    MH_TRY(emit(gyr_out, F, [&](size_t k) { return sc[5 * k + 4]; }));
-    MH_TRY(emit(com_out, (size_t)F * 3, [&](size_t k) { return sc[5 * (k / 3) + 1 + (k % 3)]; }));
-    MH_TRY(emit(R_out, (size_t)F * 9, [&](size_t k) { return rt[12 * (k / 9) + (k % 9)]; }));
-    MH_TRY(emit(t_out, (size_t)F * 3, [&](size_t k) { return rt[12 * (k / 3) + 9 + (k % 3)]; }));
+    const float *r18 = h.data();
+    MH_TRY(emit(rmsd_out, F, [&](size_t k) { return r18[18 * k + 12]; }));
+    MH_TRY(emit(gyr_out, F, [&](size_t k) { return r18[18 * k + 16]; }));
+    MH_TRY(emit(com_out, (size_t)F * 3, [&](size_t k) { return r18[18 * (k / 3) + 13 + (k % 3)]; }));
+    MH_TRY(emit(R_out, (size_t)F * 9, [&](size_t k) { return r18[18 * (k / 9) + (k % 9)]; }));
+    MH_TRY(emit(t_out, (size_t)F * 3, [&](size_t k) { return r18[18 * (k / 3) + 9 + (k % 3)]; }));
     if (apply && !is_device_ptr(frames))
         MH_HIP(hipMemcpyAsync(frames, cur.xyz, nframes * natoms * 12, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));

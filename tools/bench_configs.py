@@ -28,19 +28,27 @@ def main():
     ref = base.float().contiguous()
     mass = torch.from_numpy(synth.masses(n)).to(dev)
     idx = torch.arange(0, n, 10, device=dev, dtype=torch.int64)
-    for batch in (1, 64):
-        eng.fit_rmsd_batch(frames[:batch], mass, ref, idx=idx, apply=False)
+    for batch, apply in ((1, False), (1, True), (64, False), (64, True)):
+        work = frames.clone() if apply else frames          # apply moves the selection in place
+        eng.fit_rmsd_batch(work[:batch], mass, ref, idx=idx, apply=apply)
         eng.synchronize(); torch.cuda.synchronize()
         reps = 20 if batch == 1 else 5
+        eng.profile_enable(True); eng.profile_read()
         t0 = time.perf_counter()
         for _ in range(reps):
             for s in range(0, F, batch):
-                eng.fit_rmsd_batch(frames[s:s + batch], mass, ref, idx=idx, apply=False)
+                eng.fit_rmsd_batch(work[s:s + batch], mass, ref, idx=idx, apply=apply)
         eng.synchronize(); torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / (reps * F)
+        ev_ms, ev_n = eng.profile_read()["measure"]
+        eng.profile_enable(False)
+        alg = (44.0 if apply else 32.0) * 1e5              # 32*M gather pass (+12*M written by apply_transform)
         print(json.dumps({"workload": "C3 fit+rmsd+COM+gyration, M=1e5 of N=1e6, frames resident", "frames_per_call": batch,
-                          "frames_per_s": 1.0 / dt, "us_per_frame": dt * 1e6,
-                          "algorithmic_GBps": 44.0 * 1e5 / dt / 1e9}))
+                          "apply_transform": apply, "launches_per_call": 3 if apply else 2,
+                          "frames_per_s": 1.0 / dt, "us_per_frame": dt * 1e6, "kernel_us_per_call": ev_ms * 1e3 / max(ev_n, 1),
+                          "algorithmic_GBps": alg / dt / 1e9,
+                          "algorithmic_GBps_kernels_only": alg * batch / (ev_ms * 1e-3 / max(ev_n, 1)) / 1e9}))
+        del work
     # streamed from host (PCIe): one 12 MB frame per call
     hframe = frames[0].cpu().numpy(); href = ref.cpu().numpy(); hmass = mass.cpu().numpy(); hidx = idx.cpu().numpy().astype(np.uint64)
     eng.fit_rmsd_batch(hframe[None].copy(), hmass, href, idx=hidx, apply=False)
