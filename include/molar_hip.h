@@ -355,6 +355,45 @@ int molar_hip_fit_rmsd_batch(molar_hip_ctx *ctx, float *frames, size_t nframes, 
                              float *R_out /*[nframes][9]*/, float *t_out /*[nframes][3]*/,
                              float *com_out /*[nframes][3]*/, float *gyr_out /*[nframes]*/);
 
+/* ------------------------------------------------------------------ batched over K selections (CSR)
+ * What MolAR runs from rayon over a ParSplit (selection/system.rs:193-213, README.md:656-691): the same Measure method
+ * on thousands of small sub-selections (residues, lipids, molecules).  Selection k is idx[offsets[k] .. offsets[k+1]);
+ * one 64-lane wave works on each.  Outputs are per selection, caller-allocated (host or device). */
+
+/* gyration (measure.rs:78-87); with box9 != NULL gyration_pbc (:222-232).  out[nsel]. */
+int molar_hip_gyration_batch(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx,
+                             const uint64_t *offsets, size_t nsel, const float *mass, const float *box9, float *out);
+
+/* rmsd (measure.rs:485-504) of selection k of frame 1 against selection k of frame 2 (idx2 NULL: same atoms); with
+ * mass1 != NULL rmsd_mw (:538-558).  out[nsel]. */
+int molar_hip_rmsd_batch(molar_hip_ctx *ctx, const float *xyz1, size_t natoms1, const uint64_t *idx1, const float *xyz2,
+                         size_t natoms2, const uint64_t *idx2, const uint64_t *offsets, size_t nsel, const float *mass1,
+                         float *out);
+
+/* fit_transform (measure.rs:507-522) of every selection of frame 1 onto its counterpart in frame 2 (idx2 NULL: same
+ * atoms, mass2 NULL: mass1); apply != 0 moves the selections of xyz1 in place (modify.rs:32-36).  Any output may be
+ * NULL: R_out[nsel][9] column-major, t_out[nsel][3], and of the FITTED selection rmsd_out[nsel] (unweighted, :485-504),
+ * com_out[nsel][3], gyr_out[nsel]. */
+int molar_hip_fit_batch(molar_hip_ctx *ctx, float *xyz1, size_t natoms1, const uint64_t *idx1, const float *mass1,
+                        const float *xyz2, size_t natoms2, const uint64_t *idx2, const float *mass2,
+                        const uint64_t *offsets, size_t nsel, int apply, float *R_out, float *t_out, float *rmsd_out,
+                        float *com_out, float *gyr_out);
+
+/* ------------------------------------------------------------------ Modify::translate / rotate, principal axes */
+
+/* translate (modify.rs:16-23): p += shift for every selected atom, in place. */
+int molar_hip_translate(molar_hip_ctx *ctx, float *xyz, size_t natoms, const uint64_t *idx, size_t n, const float shift3[3]);
+
+/* rotate (modify.rs:25-30): p <- Rotation3::from_axis_angle(unit_axis, angle) * p about the origin, in place. */
+int molar_hip_rotate(molar_hip_ctx *ctx, float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                     const float unit_axis3[3], float angle);
+
+/* principal_transform (measure.rs:102-109) / principal_transform_pbc (:246-257, box9 != NULL): the isometry
+ * Translation(cm) * Rotation(axes^-1) * Translation(-cm) (:646-649) as R9 (column-major) and t3, p -> R p + t. */
+int molar_hip_principal_transform(molar_hip_ctx *ctx, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                  const float *mass, const float *box9, float R9[9], float t3[3]);
+
+
 #ifdef __cplusplus
 }
 #endif

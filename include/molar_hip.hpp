@@ -336,43 +336,21 @@ class SelBound {
     }
     void unwrap_simple() { unwrap_simple_dim(PBC_FULL); }
     void translate(const Vector3f &shift) {                       // modify.rs:16-23
-        IsometryMatrix3 tr;
-        tr.R.m = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        tr.t = shift;
-        apply_transform(tr);
+        check(molar_hip_translate(ctx(), coords_ptr_mut(), natoms(), index_.data(), index_.size(), &shift.x));
     }
     void rotate(const Vector3f &unit_axis, Float ang) {          // modify.rs:25-30, Rotation3::from_axis_angle
-        const Float ux = unit_axis.x, uy = unit_axis.y, uz = unit_axis.z;
-        const Float s = std::sin(ang), c = std::cos(ang), k = 1.0f - c;
-        const Float sqx = ux * ux, sqy = uy * uy, sqz = uz * uz;
-        IsometryMatrix3 tr;                                      // column-major
-        tr.R.m = {sqx + (1.0f - sqx) * c, ux * uy * k + uz * s, ux * uz * k - uy * s,
-                  ux * uy * k - uz * s, sqy + (1.0f - sqy) * c, uy * uz * k + ux * s,
-                  ux * uz * k + uy * s, uy * uz * k - ux * s, sqz + (1.0f - sqz) * c};
-        tr.t = {0, 0, 0};
-        apply_transform(tr);
+        check(molar_hip_rotate(ctx(), coords_ptr_mut(), natoms(), index_.data(), index_.size(), &unit_axis.x, ang));
     }
 
     // ---- principal axes (measure.rs:100-109, 246-257, 646-649): T(cm) * inverse(axes) * T(-cm)
-    IsometryMatrix3 principal_transform() const { return principal_from(inertia().second, center_of_mass()); }
-    IsometryMatrix3 principal_transform_pbc() const { return principal_from(inertia_pbc().second, center_of_mass_pbc()); }
+    IsometryMatrix3 principal_transform() const { return principal(nullptr); }
+    IsometryMatrix3 principal_transform_pbc() const { return principal(require_box().colmajor9()); }
 
    private:
-    static IsometryMatrix3 principal_from(const Matrix3f &ax, const Pos &cm) {
-        const auto &m = ax.m;                                    // closed-form inverse (nalgebra try_inverse_mut)
-        const Float m11 = m[0], m21 = m[1], m31 = m[2], m12 = m[3], m22 = m[4], m32 = m[5], m13 = m[6], m23 = m[7], m33 = m[8];
-        const Float mi1 = m22 * m33 - m32 * m23, mi2 = m21 * m33 - m31 * m23, mi3 = m21 * m32 - m31 * m22;
-        const Float det = (m11 * mi1 - m12 * mi2) + m13 * mi3;
+    IsometryMatrix3 principal(const Float *box9) const {
         IsometryMatrix3 tr;
-        tr.R = ax;                                               // try_inverse_mut leaves a singular matrix untouched
-        if (det != 0.0f)
-            tr.R.m = {mi1 / det, -mi2 / det, mi3 / det,
-                      (m13 * m32 - m33 * m12) / det, (m11 * m33 - m31 * m13) / det, (m12 * m31 - m32 * m11) / det,
-                      (m12 * m23 - m22 * m13) / det, (m13 * m21 - m23 * m11) / det, (m11 * m22 - m21 * m12) / det};
-        const Vector3f n{-cm.x, -cm.y, -cm.z};
-        const auto &r = tr.R.m;
-        tr.t = {cm.x + ((r[0] * n.x + r[3] * n.y) + r[6] * n.z), cm.y + ((r[1] * n.x + r[4] * n.y) + r[7] * n.z),
-                cm.z + ((r[2] * n.x + r[5] * n.y) + r[8] * n.z)};
+        check(molar_hip_principal_transform(ctx(), coords_ptr(), natoms(), index_.data(), index_.size(), masses(), box9,
+                                            tr.R.m.data(), &tr.t.x));
         return tr;
     }
 };

@@ -102,6 +102,12 @@ SYMBOLS = {
     "molar_hip_apply_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
     "molar_hip_unwrap_simple": (_I, [_P, _P, _SZ, _P, _SZ, _P, _U8]),
     "molar_hip_fit_rmsd_batch": (_I, [_P, _P, _SZ, _SZ, _P, _SZ, _P, _P, _SZ, _P, _I, _P, _P, _P, _P, _P]),
+    "molar_hip_gyration_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _P, _P]),
+    "molar_hip_rmsd_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _P, _SZ, _P, _P]),
+    "molar_hip_fit_batch": (_I, [_P, _P, _SZ, _P, _P, _P, _SZ, _P, _P, _P, _SZ, _I, _P, _P, _P, _P, _P]),
+    "molar_hip_translate": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
+    "molar_hip_rotate": (_I, [_P, _P, _SZ, _P, _SZ, _P, _F]),
+    "molar_hip_principal_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _P, _P]),
 }
 
 

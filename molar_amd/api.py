@@ -550,6 +550,73 @@ class Engine:
             pos += int(n) - 2
         return res
 
+    # ------------------------------------------------------------ CSR-batched Measure (ParSplit-style loops)
+    def gyration_batch(self, xyz, idx, offsets, mass, box=None):
+        """Measure::gyration (measure.rs:78-87; gyration_pbc :222-232 with a box) of each of the K selections
+        idx[offsets[k]:offsets[k+1]] - what MolAR runs from rayon over a ParSplit (system.rs:193-213)."""
+        xyz = _f32(xyz); idx = _u64(idx); offsets = _u64(offsets); mass = _f32(mass)
+        xa, k1 = _addr(xyz); ia, k2 = _addr(idx); oa, k3 = _addr(offsets); ma, k4 = _addr(mass)
+        ba, kb = self._box9(box)
+        K = len(offsets) - 1
+        out = np.zeros(max(K, 1), np.float32)
+        check(self.lib.molar_hip_gyration_batch(self.ctx, xa, xyz.shape[0], ia, oa, K, ma, ba, out.ctypes.data))
+        return out[:K]
+
+    def rmsd_batch(self, xyz1, xyz2, idx, offsets, mass=None, idx2=None):
+        """rmsd (measure.rs:485-504; rmsd_mw :538-558 with `mass`) of selection k in frame 1 against selection k in frame 2."""
+        xyz1 = _f32(xyz1); xyz2 = _f32(xyz2); idx = _u64(idx); idx2 = _u64(idx2); offsets = _u64(offsets); mass = _f32(mass)
+        a1, k1 = _addr(xyz1); a2, k2 = _addr(xyz2); ia, k3 = _addr(idx); ja, k4 = _addr(idx2); oa, k5 = _addr(offsets)
+        ma, k6 = _addr(mass)
+        K = len(offsets) - 1
+        out = np.zeros(max(K, 1), np.float32)
+        check(self.lib.molar_hip_rmsd_batch(self.ctx, a1, xyz1.shape[0], ia, a2, xyz2.shape[0], ja, oa, K, ma, out.ctypes.data))
+        return out[:K]
+
+    def fit_batch(self, xyz1, mass1, xyz2, idx, offsets, idx2=None, mass2=None, apply=False):
+        """fit_transform (measure.rs:507-522) of each selection of frame 1 onto its counterpart in frame 2; `apply`
+        moves the selections of xyz1 in place.  Returns dict(R[K,3,3], t[K,3], rmsd[K], com[K,3], gyration[K]); the last
+        three describe the fitted selections."""
+        if apply and not _is_torch(xyz1):
+            assert xyz1.dtype == np.float32 and xyz1.flags.c_contiguous, "apply works in place"
+        xyz1 = _f32(xyz1); xyz2 = _f32(xyz2); idx = _u64(idx); idx2 = _u64(idx2); offsets = _u64(offsets)
+        mass1 = _f32(mass1); mass2 = _f32(mass2)
+        a1, k1 = _addr(xyz1); a2, k2 = _addr(xyz2); ia, k3 = _addr(idx); ja, k4 = _addr(idx2); oa, k5 = _addr(offsets)
+        m1, k6 = _addr(mass1); m2, k7 = _addr(mass2)
+        K = len(offsets) - 1
+        R = np.zeros((max(K, 1), 9), np.float32); t = np.zeros((max(K, 1), 3), np.float32)
+        rm = np.zeros(max(K, 1), np.float32); com = np.zeros((max(K, 1), 3), np.float32); gy = np.zeros(max(K, 1), np.float32)
+        check(self.lib.molar_hip_fit_batch(self.ctx, a1, xyz1.shape[0], ia, m1, a2, xyz2.shape[0], ja, m2, oa, K,
+                                           1 if apply else 0, R.ctypes.data, t.ctypes.data, rm.ctypes.data,
+                                           com.ctypes.data, gy.ctypes.data))
+        return dict(R=R[:K].reshape(K, 3, 3).transpose(0, 2, 1).copy(), t=t[:K], rmsd=rm[:K], com=com[:K], gyration=gy[:K])
+
+    def translate(self, xyz, shift, idx=None):
+        """Modify::translate (modify.rs:16-23), in place."""
+        if not _is_torch(xyz):
+            assert xyz.dtype == np.float32 and xyz.flags.c_contiguous, "translate works in place"
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        sh = np.ascontiguousarray(shift, np.float32).reshape(3)
+        check(self.lib.molar_hip_translate(self.ctx, xa, na, ia, n, sh.ctypes.data))
+        return xyz
+
+    def rotate(self, xyz, unit_axis, angle, idx=None):
+        """Modify::rotate (modify.rs:25-30): Rotation3::from_axis_angle about the origin, in place."""
+        if not _is_torch(xyz):
+            assert xyz.dtype == np.float32 and xyz.flags.c_contiguous, "rotate works in place"
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        ax = np.ascontiguousarray(unit_axis, np.float32).reshape(3)
+        check(self.lib.molar_hip_rotate(self.ctx, xa, na, ia, n, ax.ctypes.data, float(angle)))
+        return xyz
+
+    def principal_transform(self, xyz, mass, idx=None, box=None):
+        """Measure::principal_transform (measure.rs:102-109; _pbc :246-257 with a box) as (R[3,3], t[3]), p -> R p + t."""
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        mass = _f32(mass); ma, km = _addr(mass)
+        ba, kb = self._box9(box)
+        R = np.zeros(9, np.float32); t = np.zeros(3, np.float32)
+        check(self.lib.molar_hip_principal_transform(self.ctx, xa, na, ia, n, ma, ba, R.ctypes.data, t.ctypes.data))
+        return R.reshape(3, 3).T.copy(), t
+
     def fit_rmsd_batch(self, frames, mass, ref_xyz, idx=None, ref_idx=None, apply=True):
         """frames: [F, natoms, 3] (numpy, modified in place if apply; or torch CUDA tensor).
         Returns dict(rmsd[F], R[F,3,3], t[F,3], com[F,3], gyration[F])."""
@@ -733,27 +800,23 @@ class Sel:
         return self.engine.min_max(self.state.coords, self.index)
 
     # measure.rs:100-109, 246-257, 646-649: T(cm) * inverse(axes) * T(-cm), returned as (R, t) of p -> R p + t
-    def _principal(self, cm, axes):
-        f = np.float32
-        R = np.linalg.inv(np.asarray(axes, np.float64)).astype(f)          # axes is orthonormal: inverse = transpose to f32 roundoff
-        cm = np.asarray(cm, f)
-        return R, (cm + (R @ (-cm)).astype(f)).astype(f)
-
     def principal_transform(self):
-        _, axes = self.inertia()
-        return self._principal(self.center_of_mass(), axes)
+        return self.engine.principal_transform(self.state.coords, self.top.masses, self.index)
 
     def principal_transform_pbc(self):
-        _, axes = self.inertia_pbc()
-        return self._principal(self.com(PBC_FULL), axes)
+        return self.engine.principal_transform(self.state.coords, self.top.masses, self.index, self.require_box())
 
     # modify.rs:16-30
     def translate(self, shift):
-        self.engine.apply_transform(self.state.coords, np.eye(3, dtype=np.float32), np.asarray(shift, np.float32), self.index)
+        self.engine.translate(self.state.coords, shift, self.index)
 
     def rotate(self, axis, angle):
-        """Rotation3::from_axis_angle about a unit axis through the origin (modify.rs:25-30)."""
-        self.engine.apply_transform(self.state.coords, rotation_from_axis_angle(axis, angle), np.zeros(3, np.float32), self.index)
+        """Rotation3::from_axis_angle about a unit axis through the origin (modify.rs:25-30); `axis` is normalised
+        like Unit::new_normalize."""
+        f = np.float32
+        u = np.asarray(axis, f)
+        u = (u / f(np.sqrt(f(f(u[0] * u[0] + u[1] * u[1]) + u[2] * u[2])))).astype(f)
+        self.engine.rotate(self.state.coords, u, angle, self.index)
 
     def apply_transform(self, tr):
         R, t = tr

@@ -182,18 +182,9 @@ __global__ void __launch_bounds__(RB) k_cov(Sel s1, Sel s2, const float *c1v, co
 // that the reference's serial f32 sums do not lose a million times over.
 constexpr int FS_W = 21, FS_ALL = 38;
 
-template <bool UNW>
-__global__ void __launch_bounds__(RB) k_fit_sums(Sel s1, Sel s2, double *partials) {
-    constexpr int NV = UNW ? FS_ALL : FS_W;
-    double acc[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s1.n; k += gridDim.x * RB) {
-        const uint64_t a1 = atom_of(s1, k), a2 = atom_of(s2, k);
-        const V3 pf = pos_of(s1, blockIdx.y, a1), qf = pos_of(s2, 0, a2);
+template <bool UNW, int NV>
+__device__ __forceinline__ void fit_accumulate(double (&acc)[NV], V3 pf, V3 qf, double m, double m2) {
         const double p[3] = {pf.x, pf.y, pf.z}, q[3] = {qf.x, qf.y, qf.z};
-        const double m = (double)s1.mass[a1];
-        const double m2 = s2.mass ? (double)s2.mass[a2] : m;
         const double pp = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
         acc[0] += m;
         acc[16] += m * pp;
@@ -217,36 +208,24 @@ __global__ void __launch_bounds__(RB) k_fit_sums(Sel s1, Sel s2, double *partial
                 for (int r = 0; r < 3; ++r) acc[27 + d * 3 + r] += q[r] * p[d];
             }
         }
+}
+
+template <bool UNW>
+__global__ void __launch_bounds__(RB) k_fit_sums(Sel s1, Sel s2, double *partials) {
+    constexpr int NV = UNW ? FS_ALL : FS_W;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s1.n; k += gridDim.x * RB) {
+        const uint64_t a1 = atom_of(s1, k), a2 = atom_of(s2, k);
+        const double m = (double)s1.mass[a1];
+        fit_accumulate<UNW, NV>(acc, pos_of(s1, blockIdx.y, a1), pos_of(s2, 0, a2), m, s2.mass ? (double)s2.mass[a2] : m);
     }
     block_reduce_store<NV>(acc, partials);
 }
 
-// One 64-lane workgroup per frame: totals the partials in a fixed order, then lane 0 derives
-//   out[frame] = { R (9, column-major), t (3), rmsd, com (3), gyration, status }      (18 floats)
-// R by Horn's quaternion method (rotation_from_cov); t = cm2 + R (-cm1) in f32 like Translation*rot*Translation (:521).
-// RMSD, COM and gyration are those of the FITTED selection (p' = R p + t), from the sums:
-//   S |R p + t - q|^2 = S|p|^2 + S|q|^2 + n|t|^2 + 2 t.(R S p) - 2 t.S q - 2 sum_rc R[r][c] S q_r p_c      (R orthonormal)
-//   com' = R (S m p / S m) + t,   rg^2 = S m|p|^2 / S m - |S m p / S m|^2                                 (rigid motion)
-__global__ void __launch_bounds__(64) k_fit_final(const double *partials, uint32_t nblk, int nv, uint32_t n, int at_origin,
-                                                  float *out) {
-    const uint32_t f = blockIdx.x, lane = threadIdx.x;
-    double S[FS_ALL];
-#pragma unroll
-    for (int v = 0; v < FS_ALL; ++v) S[v] = 0.0;
-    for (uint32_t b = lane; b < nblk; b += 64) {
-        const double *row = partials + ((size_t)f * nblk + b) * nv;
-#pragma unroll
-        for (int v = 0; v < FS_ALL; ++v)
-            if (v < nv) S[v] += row[v];
-    }
-    // butterfly over the lanes, all values per step (independent shuffles pipeline; one value at a time would
-    // serialise 38 x 6 dependent cross-lane round trips)
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int v = 0; v < FS_ALL; ++v) S[v] += __shfl_xor(S[v], off, 64);
-    }
-    if (lane != 0) return;
-    float *o = out + 18 * (size_t)f;
+// the record of one fit from its 38 (21 without the unweighted block) sums; one thread
+__device__ __forceinline__ void fit_finalize(const double (&S)[FS_ALL], int nv, uint32_t n, int at_origin, float *o) {
     #pragma unroll
     for (int i = 0; i < 17; ++i) o[i] = 0.f;
     if (S[0] == 0.0 || (!at_origin && S[17] == 0.0)) {
@@ -305,6 +284,34 @@ __global__ void __launch_bounds__(64) k_fit_final(const double *partials, uint32
         const double ss = ((S[36] + S[37]) + (double)n * ((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2])) + 2.0 * ((tRp - tq) - cross);
         o[12] = (float)sqrt(ss > 0.0 ? ss / (double)n : 0.0);
     }
+}
+
+// One 64-lane workgroup per frame: totals the partials in a fixed order, then lane 0 derives
+//   out[frame] = { R (9, column-major), t (3), rmsd, com (3), gyration, status }      (18 floats)
+// R by Horn's quaternion method (rotation_from_cov); t = cm2 + R (-cm1) in f32 like Translation*rot*Translation (:521).
+// RMSD, COM and gyration are those of the FITTED selection (p' = R p + t), from the sums:
+//   S |R p + t - q|^2 = S|p|^2 + S|q|^2 + n|t|^2 + 2 t.(R S p) - 2 t.S q - 2 sum_rc R[r][c] S q_r p_c      (R orthonormal)
+//   com' = R (S m p / S m) + t,   rg^2 = S m|p|^2 / S m - |S m p / S m|^2                                 (rigid motion)
+__global__ void __launch_bounds__(64) k_fit_final(const double *partials, uint32_t nblk, int nv, uint32_t n, int at_origin,
+                                                  float *out) {
+    const uint32_t f = blockIdx.x, lane = threadIdx.x;
+    double S[FS_ALL];
+#pragma unroll
+    for (int v = 0; v < FS_ALL; ++v) S[v] = 0.0;
+    for (uint32_t b = lane; b < nblk; b += 64) {
+        const double *row = partials + ((size_t)f * nblk + b) * nv;
+#pragma unroll
+        for (int v = 0; v < FS_ALL; ++v)
+            if (v < nv) S[v] += row[v];
+    }
+    // butterfly over the lanes, all values per step (independent shuffles pipeline; one value at a time would
+    // serialise 38 x 6 dependent cross-lane round trips)
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int v = 0; v < FS_ALL; ++v) S[v] += __shfl_xor(S[v], off, 64);
+    }
+    if (lane != 0) return;
+    fit_finalize(S, nv, n, at_origin, out + 18 * (size_t)f);
 }
 
 // apply_transform (modify.rs:32-36) for every frame of a batch: p <- R p + t in f32, in place
@@ -410,6 +417,146 @@ __global__ void __launch_bounds__(256) k_unwrap_batch(float *__restrict__ xyz, c
         float *p = xyz + 3 * idx[q];
         const V3 im = closest_image(box, v3(p[0], p[1], p[2]), p0, pbc);
         p[0] = im.x; p[1] = im.y; p[2] = im.z;
+    }
+}
+
+
+// ---------------------------------------------------------------- CSR-batched Measure: one wave per selection
+// What MolAR runs from rayon over a ParSplit (selection/system.rs:193-213, README :656-691): the same Measure method on
+// thousands of small sub-selections (residues, lipids, molecules).  Selection k is idx[off[k] .. off[k+1]).
+
+template <int NV>
+__device__ __forceinline__ void wave_sum(double (&x)[NV]) {
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) x[v] += __shfl_xor(x[v], off, 64);
+    }
+}
+
+// gyration (measure.rs:78-87) / gyration_pbc (:222-232) per selection.  Non-periodic: one pass of uncentred moments
+// (k_moments).  Periodic: centre of mass from the images relative to the selection's first atom with the reference's
+// unweighted-first-atom quirk (:197-220), then S m |shortest_vector(p - c)|^2.
+__global__ void __launch_bounds__(256) k_gyration_batch(const float *__restrict__ xyz, const uint64_t *__restrict__ idx,
+                                                        const uint64_t *__restrict__ off, uint32_t nsel,
+                                                        const float *__restrict__ mass, int use_box, molar_hip_box box,
+                                                        float *__restrict__ out, int *__restrict__ status) {
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (k >= nsel) return;
+    const uint64_t s = off[k], e = off[k + 1];
+    if (e == s) {
+        if (lane == 0) { atomicMax(status, MOLAR_HIP_ERR_INVALID_ARGUMENT); out[k] = 0.f; }
+        return;
+    }
+    auto P = [&](uint64_t q) { const float *p = xyz + 3 * idx[q]; return v3(p[0], p[1], p[2]); };
+    if (!use_box) {
+        double u[5] = {0, 0, 0, 0, 0};     // S m, S m p, S m |p|^2
+        for (uint64_t q = s + lane; q < e; q += 64) {
+            const V3 pf = P(q);
+            const double x = pf.x, y = pf.y, z = pf.z, m = (double)mass[idx[q]];
+            u[0] += m; u[1] += m * x; u[2] += m * y; u[3] += m * z;
+            u[4] += m * ((x * x + y * y) + z * z);
+        }
+        wave_sum<5>(u);
+        if (lane == 0) {
+            if (u[0] == 0.0) { atomicMax(status, MOLAR_HIP_ERR_ZERO_MASS); out[k] = 0.f; return; }
+            const double cx = (double)(float)(u[1] / u[0]), cy = (double)(float)(u[2] / u[0]), cz = (double)(float)(u[3] / u[0]);
+            const double cc = (cx * cx + cy * cy) + cz * cz;
+            const double ss = (u[4] - 2.0 * ((cx * u[1] + cy * u[2]) + cz * u[3])) + u[0] * cc;     // S m |p - c|^2
+            out[k] = (float)sqrt(ss > 0.0 ? ss / u[0] : 0.0);
+        }
+        return;
+    }
+    const V3 p0 = P(s);
+    double a[4] = {0, 0, 0, 0};
+    for (uint64_t q = s + 1 + lane; q < e; q += 64) {
+        const V3 im = closest_image(box, P(q), p0, MOLAR_HIP_PBC_FULL);
+        const float m = mass[idx[q]];
+        a[0] += (double)m; a[1] += (double)(im.x * m); a[2] += (double)(im.y * m); a[3] += (double)(im.z * m);
+    }
+    wave_sum<4>(a);
+    const double mt = a[0] + (double)mass[idx[s]];
+    if (mt == 0.0) {
+        if (lane == 0) { atomicMax(status, MOLAR_HIP_ERR_ZERO_MASS); out[k] = 0.f; }
+        return;
+    }
+    // cm = p0 (unweighted) + S img m, divided by m0 + S m (:180-182,:213-218)
+    const V3 c = v3((float)(((double)p0.x + a[1]) / mt), (float)(((double)p0.y + a[2]) / mt), (float)(((double)p0.z + a[3]) / mt));
+    double g[2] = {0, 0};
+    for (uint64_t q = s + lane; q < e; q += 64) {
+        const V3 d = shortest_vector(box, P(q) - c, MOLAR_HIP_PBC_FULL);
+        const float m = mass[idx[q]];
+        g[0] += (double)m;
+        g[1] += (double)(norm2(d) * m);
+    }
+    wave_sum<2>(g);
+    if (lane == 0) out[k] = (float)sqrt(g[1] / g[0]);
+}
+
+// rmsd (:485-504) / rmsd_mw (:538-558) per selection pair (idx1[off..], idx2[off..] in lock step)
+__global__ void __launch_bounds__(256) k_rmsd_batch(const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                    const uint64_t *__restrict__ idx1, const uint64_t *__restrict__ idx2,
+                                                    const uint64_t *__restrict__ off, uint32_t nsel,
+                                                    const float *__restrict__ mass, float *__restrict__ out,
+                                                    int *__restrict__ status) {
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (k >= nsel) return;
+    const uint64_t s = off[k], e = off[k + 1];
+    double r[2] = {0, 0};
+    for (uint64_t q = s + lane; q < e; q += 64) {
+        const float *p1 = xyz1 + 3 * idx1[q], *p2 = xyz2 + 3 * idx2[q];
+        const float d2 = norm2(v3(p2[0], p2[1], p2[2]) - v3(p1[0], p1[1], p1[2]));
+        const float m = mass ? mass[idx1[q]] : 1.0f;
+        r[0] += mass ? (double)(d2 * m) : (double)d2;
+        r[1] += (double)m;
+    }
+    wave_sum<2>(r);
+    if (lane == 0) {
+        if (r[1] == 0.0) { atomicMax(status, e == s ? MOLAR_HIP_ERR_INVALID_ARGUMENT : MOLAR_HIP_ERR_ZERO_MASS); out[k] = 0.f; }
+        else out[k] = (float)sqrt(r[0] / r[1]);
+    }
+}
+
+// fit_transform (:507-522) of every selection onto its counterpart, optionally applied in place (modify.rs:32-36), with
+// the RMSD / centre of mass / gyration of the fitted selection: out[k] = the 18-float record of k_fit_final
+__global__ void __launch_bounds__(256) k_fit_csr(float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                 const uint64_t *__restrict__ idx1, const uint64_t *__restrict__ idx2,
+                                                 const uint64_t *__restrict__ off, uint32_t nsel,
+                                                 const float *__restrict__ mass1, const float *__restrict__ mass2, int apply,
+                                                 float *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (k >= nsel) return;
+    const uint64_t s = off[k], e = off[k + 1];
+    double S[FS_ALL];
+#pragma unroll
+    for (int v = 0; v < FS_ALL; ++v) S[v] = 0.0;
+    for (uint64_t q = s + lane; q < e; q += 64) {
+        const uint64_t a1 = idx1[q], a2 = idx2[q];
+        const float *p = xyz1 + 3 * a1, *r = xyz2 + 3 * a2;
+        const double m = (double)mass1[a1];
+        fit_accumulate<true, FS_ALL>(S, v3(p[0], p[1], p[2]), v3(r[0], r[1], r[2]), m, mass2 ? (double)mass2[a2] : m);
+    }
+    wave_sum<FS_ALL>(S);
+    float *o = out + 18 * (size_t)k;
+    if (lane == 0) fit_finalize(S, FS_ALL, (uint32_t)(e - s), 0, o);
+    if (!apply) return;
+    float Rt[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Rt[i] = __shfl(lane == 0 ? o[i] : 0.f, 0, 64);
+    const int st = __shfl(lane == 0 ? __float_as_int(o[17]) : 0, 0, 64);
+    if (st != 0) return;
+    const V3 t = v3(Rt[9], Rt[10], Rt[11]);
+    for (uint64_t q = s + lane; q < e; q += 64) {
+        float *p = xyz1 + 3 * idx1[q];
+        const V3 pn = mat_vec(Rt, v3(p[0], p[1], p[2])) + t;
+        p[0] = pn.x; p[1] = pn.y; p[2] = pn.z;
+    }
+}
+
+// translate (modify.rs:16-23): p += shift
+__global__ void __launch_bounds__(RB) k_translate(Sel s, float *xyz_rw, float sx, float sy, float sz) {
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        float *q = xyz_rw + 3 * atom_of(s, k);
+        q[0] += sx; q[1] += sy; q[2] += sz;
     }
 }
 
@@ -1179,6 +1326,196 @@ int molar_hip_fit_rmsd_batch(molar_hip_ctx *c, float *frames, size_t nframes, si
     if (apply && !is_device_ptr(frames))
         MH_HIP(hipMemcpyAsync(frames, cur.xyz, nframes * natoms * 12, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+
+// ---- CSR-batched entries (one wave per selection)
+
+// last offset = number of index entries; offsets may live on either side
+static int csr_total(const uint64_t *offsets, size_t nsel, uint64_t *last) {
+    if (is_device_ptr(offsets)) MH_HIP(hipMemcpy(last, offsets + nsel, 8, hipMemcpyDeviceToHost));
+    else *last = offsets[nsel];
+    return 0;
+}
+
+static int finish_batch(molar_hip_ctx *c, int *status, float *out, const float *d_out, size_t count, const char *what) {
+    MH_HIP(hipGetLastError());
+    int st = 0;
+    MH_TRY(pull(c, &st, status, 4));
+    if (st) return fail(st, "%s: %s", what, st == MOLAR_HIP_ERR_ZERO_MASS ? "zero mass" : "empty selection");
+    if (out != d_out && count) {
+        MH_HIP(hipMemcpyAsync(out, d_out, count * 4, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_gyration_batch(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, const uint64_t *offsets,
+                             size_t nsel, const float *mass, const float *box9, float *out) {
+    MH_CTX(c);
+    if (!xyz || !idx || !offsets || !mass || !out) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "gyration_batch: null argument");
+    if (nsel == 0) return MOLAR_HIP_OK;
+    molar_hip_box b{};
+    if (box9) MH_TRY(molar_hip_box_from_matrix(box9, &b));
+    uint64_t last = 0;
+    MH_TRY(csr_total(offsets, nsel, &last));
+    const float *d_xyz, *d_mass;
+    const uint64_t *d_idx, *d_off;
+    MH_TRY(to_device(c, xyz, natoms * 3, c->m_xyz1, &d_xyz));
+    MH_TRY(to_device(c, idx, (size_t)last, c->m_idx1, &d_idx));
+    MH_TRY(to_device(c, offsets, nsel + 1, c->m_idx2, &d_off));
+    MH_TRY(to_device(c, mass, natoms, c->m_mass1, &d_mass));
+    MH_TRY(c->m_out.reserve(nsel * 4 + 16));
+    float *d_out = is_device_ptr(out) ? out : c->m_out.as<float>();
+    MH_TRY(c->m_results.reserve(64));
+    int *status = c->m_results.as<int>();
+    MH_HIP(hipMemsetAsync(status, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_gyration_batch, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, c->stream, d_xyz, d_idx, d_off,
+                       (uint32_t)nsel, d_mass, box9 ? 1 : 0, b, d_out, status);
+    return finish_batch(c, status, out, d_out, nsel, "gyration_batch");
+}
+
+int molar_hip_rmsd_batch(molar_hip_ctx *c, const float *xyz1, size_t natoms1, const uint64_t *idx1, const float *xyz2,
+                         size_t natoms2, const uint64_t *idx2, const uint64_t *offsets, size_t nsel, const float *mass1,
+                         float *out) {
+    MH_CTX(c);
+    if (!xyz1 || !xyz2 || !idx1 || !offsets || !out) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "rmsd_batch: null argument");
+    if (nsel == 0) return MOLAR_HIP_OK;
+    uint64_t last = 0;
+    MH_TRY(csr_total(offsets, nsel, &last));
+    const float *d1, *d2, *d_mass = nullptr;
+    const uint64_t *i1, *i2, *d_off;
+    MH_TRY(to_device(c, xyz1, natoms1 * 3, c->m_xyz1, &d1));
+    MH_TRY(to_device(c, xyz2, natoms2 * 3, c->m_xyz2, &d2));
+    MH_TRY(to_device(c, idx1, (size_t)last, c->m_idx1, &i1));
+    if (idx2 && idx2 != idx1) MH_TRY(to_device(c, idx2, (size_t)last, c->m_idx2, &i2));
+    else i2 = i1;
+    MH_TRY(c->m_partials.reserve((nsel + 1) * 8));
+    MH_TRY(to_device(c, offsets, nsel + 1, c->m_partials, &d_off));
+    if (mass1) MH_TRY(to_device(c, mass1, natoms1, c->m_mass1, &d_mass));
+    MH_TRY(c->m_out.reserve(nsel * 4 + 16));
+    float *d_out = is_device_ptr(out) ? out : c->m_out.as<float>();
+    MH_TRY(c->m_results.reserve(64));
+    int *status = c->m_results.as<int>();
+    MH_HIP(hipMemsetAsync(status, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_rmsd_batch, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, c->stream, d1, d2, i1, i2, d_off,
+                       (uint32_t)nsel, d_mass, d_out, status);
+    return finish_batch(c, status, out, d_out, nsel, "rmsd_batch");
+}
+
+int molar_hip_fit_batch(molar_hip_ctx *c, float *xyz1, size_t natoms1, const uint64_t *idx1, const float *mass1,
+                        const float *xyz2, size_t natoms2, const uint64_t *idx2, const float *mass2, const uint64_t *offsets,
+                        size_t nsel, int apply, float *R_out, float *t_out, float *rmsd_out, float *com_out, float *gyr_out) {
+    MH_CTX(c);
+    if (!xyz1 || !xyz2 || !idx1 || !mass1 || !offsets) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_batch: null argument");
+    if (nsel == 0) return MOLAR_HIP_OK;
+    uint64_t last = 0;
+    MH_TRY(csr_total(offsets, nsel, &last));
+    const float *d1, *d2, *m1, *m2 = nullptr;
+    const uint64_t *i1, *i2, *d_off;
+    MH_TRY(to_device(c, (const float *)xyz1, natoms1 * 3, c->m_xyz1, &d1));
+    MH_TRY(to_device(c, xyz2, natoms2 * 3, c->m_xyz2, &d2));
+    MH_TRY(to_device(c, idx1, (size_t)last, c->m_idx1, &i1));
+    if (idx2 && idx2 != idx1) MH_TRY(to_device(c, idx2, (size_t)last, c->m_idx2, &i2));
+    else i2 = i1;
+    MH_TRY(c->m_partials.reserve((nsel + 1) * 8));
+    MH_TRY(to_device(c, offsets, nsel + 1, c->m_partials, &d_off));
+    MH_TRY(to_device(c, mass1, natoms1, c->m_mass1, &m1));
+    if (mass2 && mass2 != mass1) MH_TRY(to_device(c, mass2, natoms2, c->m_mass2, &m2));
+    MH_TRY(c->m_out.reserve(nsel * 18 * 4));
+    float *o = c->m_out.as<float>();
+    hipLaunchKernelGGL(k_fit_csr, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, c->stream, const_cast<float *>(d1), d2, i1, i2,
+                       d_off, (uint32_t)nsel, m1, m2, apply ? 1 : 0, o);
+    MH_HIP(hipGetLastError());
+    std::vector<float> h(nsel * 18);
+    MH_TRY(pull(c, h.data(), o, h.size() * 4));
+    for (size_t k = 0; k < nsel; ++k) {
+        int st;
+        std::memcpy(&st, &h[18 * k + 17], 4);
+        if (st) return fail(st, "fit_batch, selection %zu: %s", k, st == MOLAR_HIP_ERR_ZERO_MASS ? "zero mass" : "SVD failed");
+    }
+    auto emit = [&](float *dst, size_t per, size_t first) -> int {
+        if (!dst) return 0;
+        std::vector<float> tmp(nsel * per);
+        for (size_t k = 0; k < nsel; ++k)
+            for (size_t q = 0; q < per; ++q) tmp[k * per + q] = h[18 * k + first + q];
+        if (is_device_ptr(dst)) {
+            MH_HIP(hipMemcpyAsync(dst, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, c->stream));
+            MH_HIP(hipStreamSynchronize(c->stream));
+        } else {
+            std::memcpy(dst, tmp.data(), tmp.size() * 4);
+        }
+        return 0;
+    };
+    MH_TRY(emit(R_out, 9, 0));
+    MH_TRY(emit(t_out, 3, 9));
+    MH_TRY(emit(rmsd_out, 1, 12));
+    MH_TRY(emit(com_out, 3, 13));
+    MH_TRY(emit(gyr_out, 1, 16));
+    if (apply && !is_device_ptr(xyz1)) {
+        MH_HIP(hipMemcpyAsync(xyz1, d1, natoms1 * 12, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return MOLAR_HIP_OK;
+}
+
+// ---- Modify::translate / rotate (modify.rs:16-30) and Measure::principal_transform(_pbc) (measure.rs:102-109,246-257)
+
+int molar_hip_translate(molar_hip_ctx *c, float *xyz, size_t natoms, const uint64_t *idx, size_t n, const float shift3[3]) {
+    MH_CTX(c);
+    if (!shift3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "translate: null shift");
+    Sel s;
+    MH_TRY(stage_sel(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    if (s.n) {
+        hipLaunchKernelGGL(k_translate, dim3(blocks_for(c, s.n, 1)), dim3(RB), 0, c->stream, s, const_cast<float *>(s.xyz),
+                           shift3[0], shift3[1], shift3[2]);
+        MH_HIP(hipGetLastError());
+    }
+    if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, s.xyz, natoms * 12, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_rotate(molar_hip_ctx *c, float *xyz, size_t natoms, const uint64_t *idx, size_t n, const float unit_axis3[3],
+                     float angle) {
+    if (!unit_axis3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "rotate: null axis");
+    // nalgebra Rotation3::from_axis_angle (Rodrigues' formula on a unit axis), f32, column-major
+    const float ux = unit_axis3[0], uy = unit_axis3[1], uz = unit_axis3[2];
+    const float sn = std::sin(angle), cs = std::cos(angle), k = 1.0f - cs;
+    const float sqx = ux * ux, sqy = uy * uy, sqz = uz * uz;
+    const float R[9] = {sqx + (1.0f - sqx) * cs, ux * uy * k + uz * sn, ux * uz * k - uy * sn,
+                        ux * uy * k - uz * sn, sqy + (1.0f - sqy) * cs, uy * uz * k + ux * sn,
+                        ux * uz * k + uy * sn, uy * uz * k - ux * sn, sqz + (1.0f - sqz) * cs};
+    const float t[3] = {0.f, 0.f, 0.f};
+    return molar_hip_apply_transform(c, xyz, natoms, idx, n, R, t);     // p.coords = tr * p.coords (:28)
+}
+
+int molar_hip_principal_transform(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                  const float *mass, const float *box9, float R9[9], float t3[3]) {
+    MH_CTX(c);
+    if (!R9 || !t3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "principal_transform: null output");
+    float mom[3], axes[9], cm[3];
+    MH_TRY(molar_hip_inertia(c, xyz, natoms, idx, n, mass, box9, mom, axes, nullptr));
+    if (box9) MH_TRY(molar_hip_center_of_mass_pbc(c, xyz, natoms, idx, n, mass, box9, MOLAR_HIP_PBC_FULL, cm));   // (:251)
+    else MH_TRY(molar_hip_center_of_mass(c, xyz, natoms, idx, n, mass, cm));                                   // (:106)
+    // do_principal_transform (:646-649): Translation(cm) * Rotation(axes^-1) * Translation(-cm);
+    // try_inverse_mut leaves a singular matrix untouched (closed-form 3x3 inverse, nalgebra)
+    const float *m = axes;     // column-major: m11 m21 m31 | m12 m22 m32 | m13 m23 m33
+    const float m11 = m[0], m21 = m[1], m31 = m[2], m12 = m[3], m22 = m[4], m32 = m[5], m13 = m[6], m23 = m[7], m33 = m[8];
+    const float mi1 = m22 * m33 - m32 * m23, mi2 = m21 * m33 - m31 * m23, mi3 = m21 * m32 - m31 * m22;
+    const float det = (m11 * mi1 - m12 * mi2) + m13 * mi3;
+    for (int i = 0; i < 9; ++i) R9[i] = axes[i];
+    if (det != 0.0f) {
+        const float inv[9] = {mi1 / det, -mi2 / det, mi3 / det,
+                              (m13 * m32 - m33 * m12) / det, (m11 * m33 - m31 * m13) / det, (m12 * m31 - m32 * m11) / det,
+                              (m12 * m23 - m22 * m13) / det, (m13 * m21 - m23 * m11) / det, (m11 * m22 - m21 * m12) / det};
+        for (int i = 0; i < 9; ++i) R9[i] = inv[i];
+    }
+    const V3 rv = mat_vec(R9, v3(-cm[0], -cm[1], -cm[2]));
+    t3[0] = cm[0] + rv.x;
+    t3[1] = cm[1] + rv.y;
+    t3[2] = cm[2] + rv.z;
     return MOLAR_HIP_OK;
 }
 

@@ -240,7 +240,8 @@ def test_empty_selection_is_refused(eng):
 
 
 def test_principal_transform_translate_rotate(eng, orc64):
-    """measure.rs:100-109,646-649 and modify.rs:16-30 on the host mirror: after principal_transform the inertia
+    """measure.rs:100-109,646-649 and modify.rs:16-30 through the C ABI (molar_hip_principal_transform, _translate,
+    _rotate): after principal_transform the inertia
     tensor is diagonal with ascending moments and the centre of mass has not moved; translate/rotate equal the
     float64 formulas."""
     from molar_amd import api, synth
@@ -278,3 +279,89 @@ def test_principal_transform_translate_rotate(eng, orc64):
     Rr = np.eye(3) + np.sin(0.9) * K + (1 - np.cos(0.9)) * (K @ K)
     assert np.allclose(st.coords[sel.index.astype(np.int64)], before @ Rr.T, atol=2e-5)
     assert np.array_equal(st.coords[1::2], untouched)
+
+
+def _random_csr(rng, natoms, nsel, lo=3, hi=200):
+    sizes = rng.integers(lo, hi, nsel)
+    idx = np.concatenate([np.sort(rng.choice(natoms, int(k), replace=False)) for k in sizes]).astype(np.uint64)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    return idx, off
+
+
+def test_csr_batched_gyration_rmsd_fit(eng, orc32, orc64):
+    """molar_hip_gyration_batch / _rmsd_batch / _fit_batch: one wave per selection, what MolAR runs from rayon over a
+    ParSplit (selection/system.rs:193-213).  Every selection against the per-selection oracle calls."""
+    from molar_amd import synth
+    rng = np.random.default_rng(31)
+    n, K = 20000, 300
+    box = synth.box_a(n)
+    x1 = synth.frame(n, box, 1)
+    x2 = synth.frame(n, box, 2)
+    mass = synth.masses(n)
+    idx, off = _random_csr(rng, n, K)
+    sels = [idx[int(off[k]):int(off[k + 1])] for k in range(K)]
+    # gyration, plain and periodic
+    g = eng.gyration_batch(x1, idx, off, mass)
+    gp = eng.gyration_batch(x1, idx, off, mass, box=box)
+    ob64 = orc64.box_from_matrix(box)
+    for k in range(K):
+        w = orc64.gyration(x1, mass, sels[k])
+        assert abs(g[k] - w) <= 1e-5 * w, (k, g[k], w)
+        wp = orc64.gyration_pbc(x1, mass, ob64, sels[k])
+        assert abs(gp[k] - wp) <= 2e-5 * wp, (k, gp[k], wp)
+    # rmsd / rmsd_mw
+    r = eng.rmsd_batch(x1, x2, idx, off)
+    rw = eng.rmsd_batch(x1, x2, idx, off, mass=mass)
+    for k in range(K):
+        w = orc64.rmsd(x1, x2, sels[k], sels[k]); ww = orc64.rmsd_mw(x1, mass, x2, sels[k], sels[k])
+        assert abs(r[k] - w) <= 1e-5 * w and abs(rw[k] - ww) <= 1e-5 * ww
+    # fit: every selection of frame 1 onto the same atoms of frame 2, rotated + shifted so the fit has work to do
+    Rz = np.asarray(__import__("molar_amd.api", fromlist=["x"]).rotation_from_axis_angle([0.1, 0.7, -0.4], 1.1), np.float64)
+    y1 = (x1.astype(np.float64) @ Rz.T + np.array([1.5, -0.5, 0.25])).astype(np.float32)
+    out = eng.fit_batch(y1, mass, x2, idx, off, apply=False)
+    moved_all = y1.copy()
+    for k in range(K):
+        R, t = orc64.fit_transform(y1, mass, x2, mass, sels[k], sels[k])
+        assert np.allclose(out["R"][k], R, atol=2e-5), k
+        assert np.allclose(out["t"][k], t, atol=2e-4), k
+        mv = orc64.apply_transform(y1, R, t, sels[k])
+        w = orc64.rmsd(mv, x2, sels[k], sels[k])
+        assert abs(out["rmsd"][k] - w) <= 2e-5 * max(w, 1e-3), (k, out["rmsd"][k], w)
+        assert np.allclose(out["com"][k], orc64.center_of_mass(mv, mass, sels[k]), atol=2e-4)
+        wg = orc64.gyration(mv, mass, sels[k])
+        assert abs(out["gyration"][k] - wg) <= 2e-5 * wg
+    # apply moves exactly the selected atoms; selections overlap, so compare one selection at a time on fresh copies
+    for k in (0, 7, K - 1):
+        z = y1.copy()
+        o1 = eng.fit_batch(z, mass, x2, sels[k], np.array([0, len(sels[k])], np.uint64), apply=True)
+        R, t = orc64.fit_transform(y1, mass, x2, mass, sels[k], sels[k])
+        want = orc64.apply_transform(y1, R, t, sels[k])
+        assert np.abs(z - want).max() < 2e-4
+        rest = np.ones(n, bool); rest[sels[k].astype(np.int64)] = False
+        assert np.array_equal(z[rest], y1[rest])
+    # errors: an empty selection in the batch is refused, zero masses reported
+    from molar_amd._lib import MolarHipError
+    with pytest.raises(MolarHipError) as e:
+        eng.gyration_batch(x1, idx, np.array([0, 5, 5, 9], np.uint64), mass)
+    assert e.value.code == 50
+    with pytest.raises(MolarHipError) as e:
+        eng.gyration_batch(x1, idx, off, np.zeros(n, np.float32))
+    assert e.value.code == 2
+
+
+def test_principal_transform_abi_matches_host_formula(eng, orc64):
+    """molar_hip_principal_transform(_pbc) against T(cm) * inverse(axes) * T(-cm) built from the engine's own inertia /
+    centre of mass (measure.rs:102-109, 246-257, 646-649)."""
+    from molar_amd import synth
+    n = 4000
+    box = synth.box_a(n)
+    xyz = synth.frame(n, box, 2)
+    mass = synth.masses(n)
+    idx = np.arange(5, n, 3, dtype=np.uint64)
+    for bx in (None, box):
+        R, t = eng.principal_transform(xyz, mass, idx, box=bx)
+        _, axes, _ = eng.inertia(xyz, mass, idx, box=bx)
+        cm = eng.center_of_mass(xyz, mass, idx) if bx is None else eng.center_of_mass_pbc(xyz, mass, bx, 7, idx)
+        Rw = np.linalg.inv(np.asarray(axes, np.float64))
+        assert np.allclose(R, Rw, atol=1e-5)
+        assert np.allclose(t, cm + Rw @ (-np.asarray(cm, np.float64)), atol=1e-4)
