@@ -1,0 +1,321 @@
+//! Host shim between MolAR and the MI355X engine (`libmolar_hip.so`).
+//!
+//! **Source only**: this crate has not been compiled in the repository's build image (no `cargo` / `rustc` there).
+//! `src/ffi.rs` is generated from `include/molar_hip.h` by `tools/gen_rust_ffi.py`, and
+//! `tests/test_rust_shim_cpu.py` asserts that the symbol set, the argument counts and the safe wrappers below stay in
+//! step with the C header.
+//!
+//! What MolAR hands over is exactly what its provider traits already hold:
+//!
+//! | MolAR                                                   | this crate                         |
+//! |---------------------------------------------------------|------------------------------------|
+//! | `PosProvider::coords_ptr()` (providers.rs:96-106)       | `&[[f32; 3]]`, the WHOLE frame     |
+//! | `IndexSliceProvider::get_index_slice()` (:45-76)        | `Option<&[usize]>` (None = all)    |
+//! | `AtomStorage::masses()` (atom_storage.rs:272)           | `&[f32]`, full-length column       |
+//! | `PeriodicBox` matrix, columns a,b,c (periodic_box.rs)   | `&[f32; 9]` column-major           |
+//! | `PbcDims` (periodic_box.rs:70-128)                      | `u8` mask                          |
+//!
+//! Loading follows MolAR's own plugin crate (molar_gromacs/src/lib.rs:95-176): `MOLAR_HIP_PLUGIN` at run time, then
+//! the path baked in at compile time, then the system search path; symbols are resolved once into a table of function
+//! pointers; the loaded plugin is cached process-wide.  When no library (or no GPU) is found the caller keeps MolAR's
+//! CPU path - `Engine::try_default()` returns `None`, nothing else changes.
+
+pub mod ffi;
+pub mod types;
+
+use std::ffi::CStr;
+use std::sync::{Arc, OnceLock};
+
+use ffi::MolarHipFns;
+pub use types::*;
+
+/// MolAR's `Float` (molar/src/aliases.rs:10-13).
+#[cfg(not(feature = "f64"))]
+pub type Float = f32;
+#[cfg(feature = "f64")]
+pub type Float = f64;
+
+/// Errors of the engine, mapped from the C status codes (header :38-55) onto MolAR's error enums.
+#[derive(thiserror::Error, Debug)]
+pub enum EngineError {
+    #[error("engine library not available: {0}")]
+    Load(#[from] libloading::Error),
+    /// `MeasureError::Sizes` (measure.rs:732-762)
+    #[error("incompatible sizes: {0}")]
+    Sizes(String),
+    /// `MeasureError::ZeroMass`
+    #[error("zero mass")]
+    ZeroMass,
+    /// `MeasureError::Svd`
+    #[error("SVD failed")]
+    Svd,
+    /// `MeasureError::NoPbc`
+    #[error("pbc operation without periodic box")]
+    NoPbc,
+    /// `PeriodicBoxError` (periodic_box.rs:131-144)
+    #[error("periodic box: {0}")]
+    PeriodicBox(String),
+    /// `LipidOrderError` (measure.rs:281-291)
+    #[error("lipid order: {0}")]
+    LipidOrder(String),
+    #[error("engine: {0}")]
+    Other(String),
+}
+
+/// The loaded library plus its resolved entry points.  The `Library` must outlive every call through the table, which
+/// holding both in one struct guarantees.
+pub struct Plugin {
+    _lib: libloading::Library,
+    pub fns: MolarHipFns,
+}
+
+// The table is plain function pointers; contexts are what must not be shared between threads (see `Engine`).
+unsafe impl Send for Plugin {}
+unsafe impl Sync for Plugin {}
+
+impl Plugin {
+    fn open_library() -> Result<libloading::Library, libloading::Error> {
+        // 1. user override at run time
+        if let Ok(path) = std::env::var("MOLAR_HIP_PLUGIN") {
+            return unsafe { libloading::Library::new(path) };
+        }
+        // 2. location recorded when the crate was built
+        if let Some(path) = option_env!("MOLAR_HIP_PLUGIN") {
+            if let Ok(lib) = unsafe { libloading::Library::new(path) } {
+                return Ok(lib);
+            }
+        }
+        // 3. system search path
+        unsafe { libloading::Library::new(libloading::library_filename("molar_hip")) }
+    }
+
+    pub fn load() -> Result<Self, libloading::Error> {
+        let lib = Self::open_library()?;
+        let fns = unsafe { MolarHipFns::resolve(&lib)? };
+        Ok(Plugin { _lib: lib, fns })
+    }
+
+    /// Process-wide instance; loaded at most once, a failed attempt is retried by the next call.
+    pub fn get_cached() -> Result<Arc<Self>, libloading::Error> {
+        static CACHE: OnceLock<Arc<Plugin>> = OnceLock::new();
+        if let Some(p) = CACHE.get() {
+            return Ok(Arc::clone(p));
+        }
+        let fresh = Arc::new(Self::load()?);
+        let _ = CACHE.set(Arc::clone(&fresh));
+        Ok(CACHE.get().map(Arc::clone).unwrap_or(fresh))
+    }
+
+    fn last_error(&self) -> String {
+        unsafe {
+            let p = (self.fns.last_error)();
+            if p.is_null() { String::new() } else { CStr::from_ptr(p).to_string_lossy().into_owned() }
+        }
+    }
+
+    fn check(&self, status: i32) -> Result<(), EngineError> {
+        match status {
+            0 => Ok(()),
+            1 => Err(EngineError::Sizes(self.last_error())),
+            2 => Err(EngineError::ZeroMass),
+            3 => Err(EngineError::Svd),
+            4 => Err(EngineError::NoPbc),
+            5 | 6 | 10 => Err(EngineError::PeriodicBox(self.last_error())),
+            7..=9 => Err(EngineError::LipidOrder(self.last_error())),
+            _ => Err(EngineError::Other(self.last_error())),
+        }
+    }
+}
+
+/// One engine context = one HIP stream with its device buffers.  Not `Sync`: MolAR calls `Measure` from rayon workers
+/// on disjoint selections (system.rs:193-213) - give each worker its own `Engine`, or use the `*_batch` calls.
+pub struct Engine {
+    plugin: Arc<Plugin>,
+    ctx: *mut MolarHipCtx,
+}
+
+unsafe impl Send for Engine {}
+
+impl Drop for Engine {
+    fn drop(&mut self) {
+        unsafe { (self.plugin.fns.destroy)(self.ctx) }
+    }
+}
+
+fn idx_ptr(idx: Option<&[usize]>) -> (*const u64, usize) {
+    // usize == u64 on every target MolAR supports (aliases.rs); the engine reads u64
+    match idx {
+        Some(s) => (s.as_ptr() as *const u64, s.len()),
+        None => (std::ptr::null(), 0),
+    }
+}
+
+fn box_ptr(b: Option<&[f32; 9]>) -> *const f32 {
+    b.map_or(std::ptr::null(), |m| m.as_ptr())
+}
+
+impl Engine {
+    pub fn new(device: i32) -> Result<Self, EngineError> {
+        let plugin = Plugin::get_cached()?;
+        let ctx = unsafe { (plugin.fns.create)(device) };
+        if ctx.is_null() {
+            return Err(EngineError::Other(plugin.last_error()));
+        }
+        Ok(Engine { plugin, ctx })
+    }
+
+    /// `Some(engine)` on a machine with the library and a GPU, `None` otherwise: the caller stays on MolAR's CPU path.
+    pub fn try_default() -> Option<Self> {
+        Self::new(0).ok()
+    }
+
+    pub fn synchronize(&self) -> Result<(), EngineError> {
+        self.plugin.check(unsafe { (self.plugin.fns.synchronize)(self.ctx) })
+    }
+
+    // ---------------------------------------------------------------- distance search (distance_search.rs:519-954)
+
+    fn search(&self, d: &MolarHipSearchDesc) -> Result<Vec<(usize, usize, Float)>, EngineError> {
+        let f = &self.plugin.fns;
+        let mut n = 0u64;
+        self.plugin.check(unsafe { (f.search_count)(self.ctx, d, &mut n) })?;
+        let n = n as usize;
+        let (mut i, mut j, mut dist) = (vec![0u64; n], vec![0u64; n], vec![0f32; n]);
+        self.plugin.check(unsafe { (f.search_fill_usize)(self.ctx, i.as_mut_ptr(), j.as_mut_ptr(), dist.as_mut_ptr()) })?;
+        Ok((0..n).map(|k| (i[k] as usize, j[k] as usize, dist[k] as Float)).collect())
+    }
+
+    /// `distance_search_single_pbc` (distance_search.rs:928-954); `box9 = None` is `distance_search_single` (:892-926).
+    /// Result order is the reference's: plan order, then i-major / j-minor.
+    pub fn distance_search_single(
+        &self, cutoff: f32, coords: &[[f32; 3]], index: Option<&[usize]>, box9: Option<&[f32; 9]>, pbc: u8,
+    ) -> Result<Vec<(usize, usize, Float)>, EngineError> {
+        let (ip, n) = idx_ptr(index);
+        let d = MolarHipSearchDesc {
+            kind: SEARCH_SINGLE, cutoff, xyz1: coords.as_ptr() as *const f32, natoms1: coords.len(), idx1: ip, n1: n,
+            box9: box_ptr(box9), pbc, ..Default::default()
+        };
+        self.search(&d)
+    }
+
+    /// `distance_search_double(_pbc)` (:659-754): pairs (atom of set 1, atom of set 2).
+    pub fn distance_search_double(
+        &self, cutoff: f32, coords1: &[[f32; 3]], index1: Option<&[usize]>, coords2: &[[f32; 3]], index2: Option<&[usize]>,
+        box9: Option<&[f32; 9]>, pbc: u8,
+    ) -> Result<Vec<(usize, usize, Float)>, EngineError> {
+        let (i1, n1) = idx_ptr(index1);
+        let (i2, n2) = idx_ptr(index2);
+        let d = MolarHipSearchDesc {
+            kind: SEARCH_DOUBLE, cutoff, xyz1: coords1.as_ptr() as *const f32, natoms1: coords1.len(), idx1: i1, n1,
+            xyz2: coords2.as_ptr() as *const f32, natoms2: coords2.len(), idx2: i2, n2, box9: box_ptr(box9), pbc,
+            ..Default::default()
+        };
+        self.search(&d)
+    }
+
+    /// `distance_search_within_pbc` (:519-598): ids of set-1 atoms within `cutoff` of set 2, duplicates as the reference
+    /// emits them (the caller sorts and de-duplicates, selection_expr.rs:112).
+    pub fn distance_search_within_pbc(
+        &self, cutoff: f32, coords1: &[[f32; 3]], index1: Option<&[usize]>, coords2: &[[f32; 3]], index2: Option<&[usize]>,
+        box9: &[f32; 9], pbc: u8,
+    ) -> Result<Vec<usize>, EngineError> {
+        let (i1, n1) = idx_ptr(index1);
+        let (i2, n2) = idx_ptr(index2);
+        let d = MolarHipSearchDesc {
+            kind: SEARCH_WITHIN, cutoff, xyz1: coords1.as_ptr() as *const f32, natoms1: coords1.len(), idx1: i1, n1,
+            xyz2: coords2.as_ptr() as *const f32, natoms2: coords2.len(), idx2: i2, n2, box9: box9.as_ptr(), pbc,
+            ..Default::default()
+        };
+        let f = &self.plugin.fns;
+        let mut n = 0u64;
+        self.plugin.check(unsafe { (f.search_count)(self.ctx, &d, &mut n) })?;
+        let mut ids = vec![0u64; n as usize];
+        self.plugin.check(unsafe { (f.search_fill_ids)(self.ctx, ids.as_mut_ptr()) })?;
+        Ok(ids.into_iter().map(|v| v as usize).collect())
+    }
+
+    // ---------------------------------------------------------------- Measure (measure.rs:22-649)
+
+    /// `Measure::center_of_mass` (:60-75)
+    pub fn center_of_mass(&self, coords: &[[f32; 3]], index: Option<&[usize]>, masses: &[f32]) -> Result<[f32; 3], EngineError> {
+        let (ip, n) = idx_ptr(index);
+        let mut out = [0f32; 3];
+        self.plugin.check(unsafe {
+            (self.plugin.fns.center_of_mass)(self.ctx, coords.as_ptr() as *const f32, coords.len(), ip, n, masses.as_ptr(), out.as_mut_ptr())
+        })?;
+        Ok(out)
+    }
+
+    /// `Measure::gyration` (:78-87) / `gyration_pbc` (:222-232) with a box
+    pub fn gyration(&self, coords: &[[f32; 3]], index: Option<&[usize]>, masses: &[f32], box9: Option<&[f32; 9]>) -> Result<f32, EngineError> {
+        let (ip, n) = idx_ptr(index);
+        let mut out = 0f32;
+        self.plugin.check(unsafe {
+            (self.plugin.fns.gyration)(self.ctx, coords.as_ptr() as *const f32, coords.len(), ip, n, masses.as_ptr(), box_ptr(box9), &mut out)
+        })?;
+        Ok(out)
+    }
+
+    /// `rmsd` (:485-504)
+    pub fn rmsd(&self, c1: &[[f32; 3]], i1: Option<&[usize]>, c2: &[[f32; 3]], i2: Option<&[usize]>) -> Result<f32, EngineError> {
+        let (p1, n1) = idx_ptr(i1);
+        let (p2, n2) = idx_ptr(i2);
+        let mut out = 0f32;
+        self.plugin.check(unsafe {
+            (self.plugin.fns.rmsd)(self.ctx, c1.as_ptr() as *const f32, c1.len(), p1, n1, c2.as_ptr() as *const f32, c2.len(), p2, n2, &mut out)
+        })?;
+        Ok(out)
+    }
+
+    /// `fit_transform` (:507-522): (R column-major, t) with p -> R p + t moving selection 1 onto selection 2.
+    pub fn fit_transform(
+        &self, c1: &[[f32; 3]], i1: Option<&[usize]>, m1: &[f32], c2: &[[f32; 3]], i2: Option<&[usize]>, m2: &[f32],
+    ) -> Result<([f32; 9], [f32; 3]), EngineError> {
+        let (p1, n1) = idx_ptr(i1);
+        let (p2, n2) = idx_ptr(i2);
+        let (mut r, mut t) = ([0f32; 9], [0f32; 3]);
+        self.plugin.check(unsafe {
+            (self.plugin.fns.fit_transform)(self.ctx, c1.as_ptr() as *const f32, c1.len(), p1, n1, m1.as_ptr(),
+                                            c2.as_ptr() as *const f32, c2.len(), p2, n2, m2.as_ptr(), 0, r.as_mut_ptr(), t.as_mut_ptr())
+        })?;
+        Ok((r, t))
+    }
+
+    /// `Modify::apply_transform` (modify.rs:32-36), in place
+    pub fn apply_transform(&self, coords: &mut [[f32; 3]], index: Option<&[usize]>, r: &[f32; 9], t: &[f32; 3]) -> Result<(), EngineError> {
+        let (ip, n) = idx_ptr(index);
+        self.plugin.check(unsafe {
+            (self.plugin.fns.apply_transform)(self.ctx, coords.as_mut_ptr() as *mut f32, coords.len(), ip, n, r.as_ptr(), t.as_ptr())
+        })
+    }
+
+    /// `Modify::unwrap_simple_dim` (modify.rs:40-54), in place
+    pub fn unwrap_simple_dim(&self, coords: &mut [[f32; 3]], index: Option<&[usize]>, box9: &[f32; 9], dims: u8) -> Result<(), EngineError> {
+        let (ip, n) = idx_ptr(index);
+        self.plugin.check(unsafe {
+            (self.plugin.fns.unwrap_simple)(self.ctx, coords.as_mut_ptr() as *mut f32, coords.len(), ip, n, box9.as_ptr(), dims)
+        })
+    }
+
+    /// `Measure::gyration` over a `ParSplit` (system.rs:193-213): selection k is `index[offsets[k]..offsets[k+1]]`.
+    pub fn gyration_batch(
+        &self, coords: &[[f32; 3]], index: &[usize], offsets: &[usize], masses: &[f32], box9: Option<&[f32; 9]>,
+    ) -> Result<Vec<f32>, EngineError> {
+        let nsel = offsets.len().saturating_sub(1);
+        let mut out = vec![0f32; nsel];
+        self.plugin.check(unsafe {
+            (self.plugin.fns.gyration_batch)(self.ctx, coords.as_ptr() as *const f32, coords.len(), index.as_ptr() as *const u64,
+                                             offsets.as_ptr() as *const u64, nsel, masses.as_ptr(), box_ptr(box9), out.as_mut_ptr())
+        })?;
+        Ok(out)
+    }
+}
+
+/// The remaining entry points (histogram-fused search, resident/pipelined search, batched fits, membrane smoothing,
+/// lipid order, XTC reader, PeriodicBox helpers) are reachable through `Engine::raw()`; they take the same pointer/size
+/// pairs and follow the count-then-fill convention documented in `include/molar_hip.h`.
+impl Engine {
+    pub fn raw(&self) -> (&MolarHipFns, *mut MolarHipCtx) {
+        (&self.plugin.fns, self.ctx)
+    }
+}

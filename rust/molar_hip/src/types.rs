@@ -1,0 +1,95 @@
+//! `#[repr(C)]` mirrors of the types of `include/molar_hip.h` (line numbers refer to that header).
+
+use std::os::raw::c_void;
+
+/// Opaque engine context (`molar_hip_ctx`, header :62): one HIP stream plus engine-owned device buffers.
+#[repr(C)]
+pub struct MolarHipCtx {
+    _opaque: [u8; 0],
+}
+
+/// Opaque XTC reader (`molar_hip_xtc`).
+#[repr(C)]
+pub struct MolarHipXtc {
+    _opaque: [u8; 0],
+}
+
+/// `molar_hip_box` (header :96-101): MolAR's `PeriodicBox` (periodic_box.rs:15-23) - matrix with columns a, b, c,
+/// its inverse and the triclinic correction shifts.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct MolarHipBox {
+    pub m: [f32; 9],
+    pub inv: [f32; 9],
+    pub nshift: i32,
+    pub shifts: [f32; 78],
+}
+
+/// `molar_hip_search_desc` (header :137-155): one distance-search request.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct MolarHipSearchDesc {
+    pub kind: i32,
+    pub cutoff: f32,
+    pub xyz1: *const f32,
+    pub natoms1: usize,
+    pub idx1: *const u64,
+    pub n1: usize,
+    pub xyz2: *const f32,
+    pub natoms2: usize,
+    pub idx2: *const u64,
+    pub n2: usize,
+    pub vdw1: *const f32,
+    pub vdw2: *const f32,
+    pub ids_local: i32,
+    pub box9: *const f32,
+    pub pbc: u8,
+    pub lower3: *const f32,
+    pub upper3: *const f32,
+}
+
+impl Default for MolarHipSearchDesc {
+    fn default() -> Self {
+        // all-zero is the C side's "unset" for every field
+        unsafe { std::mem::zeroed() }
+    }
+}
+
+/// `molar_hip_membrane_patches`: CSR of the patch (neighbour) lists of K lipids.
+#[repr(C)]
+pub struct MolarHipMembranePatches {
+    pub nlipids: usize,
+    pub patch_offsets: *const u64,
+    pub patch_ids: *const u64,
+}
+
+/// `molar_hip_membrane_state`: per-lipid arrays updated by one smoothing pass (molar_membrane/src/lib.rs:661-812).
+#[repr(C)]
+pub struct MolarHipMembraneState {
+    pub head_markers: *mut f32,
+    pub normals: *mut f32,
+    pub valid: *mut u8,
+    pub quad_coefs: *mut f32,
+    pub mean_curv: *mut f32,
+    pub gauss_curv: *mut f32,
+    pub princ_curvs: *mut f32,
+    pub princ_dirs: *mut f32,
+    pub area: *mut f32,
+    pub nvert: *mut u32,
+    pub neib_ids: *mut u64,
+    pub voro_vertexes: *mut f32,
+    pub fitted_patch_points: *mut f32,
+}
+
+/// Search kinds (header :124-129) = the four driver families of distance_search.rs.
+pub const SEARCH_SINGLE: i32 = 0;
+pub const SEARCH_DOUBLE: i32 = 1;
+pub const SEARCH_WITHIN: i32 = 2;
+pub const SEARCH_DOUBLE_VDW: i32 = 3;
+
+/// `PbcDims` bit masks (periodic_box.rs:126-128).
+pub const PBC_FULL: u8 = 7;
+pub const PBC_NONE: u8 = 0;
+
+/// A raw `hipStream_t` handed to `molar_hip_set_stream`.
+pub type HipStream = *mut c_void;
