@@ -31,9 +31,9 @@ __device__ __forceinline__ V3 pos_of(const Sel &s, uint32_t frame, uint64_t a) {
 }
 
 // block-wide sum of NV doubles; lanes 0..NV-1 of wave 0 write partials[(frame*gridDim.x+block)*NV + v]
-template <int NV>
+template <int NV, int BLOCK = RB>
 __device__ __forceinline__ void block_reduce_store(double *acc, double *partials) {
-    __shared__ double sh[RB / 64][NV];
+    __shared__ double sh[BLOCK / 64][NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -44,7 +44,7 @@ __device__ __forceinline__ void block_reduce_store(double *acc, double *partials
     __syncthreads();
     if (threadIdx.x < NV) {
         double s = 0.0;
-        for (int w = 0; w < RB / 64; ++w) s += sh[w][threadIdx.x];
+        for (int w = 0; w < BLOCK / 64; ++w) s += sh[w][threadIdx.x];
         partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NV + threadIdx.x] = s;
     }
 }
@@ -212,16 +212,38 @@ __device__ __forceinline__ void fit_accumulate(double (&acc)[NV], V3 pf, V3 qf, 
 
 template <bool UNW>
 __global__ void __launch_bounds__(RB) k_fit_sums(Sel s1, Sel s2, double *partials) {
+    constexpr int BLOCK = RB;
     constexpr int NV = UNW ? FS_ALL : FS_W;
     double acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s1.n; k += gridDim.x * RB) {
-        const uint64_t a1 = atom_of(s1, k), a2 = atom_of(s2, k);
-        const double m = (double)s1.mass[a1];
-        fit_accumulate<UNW, NV>(acc, pos_of(s1, blockIdx.y, a1), pos_of(s2, 0, a2), m, s2.mass ? (double)s2.mass[a2] : m);
+    // four atoms per trip, every level of the dependent chain (index -> position, mass) issued for all four before any
+    // is consumed: a thread's latency is one chain, not one chain per atom
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t k0 = blockIdx.x * BLOCK + threadIdx.x; k0 < s1.n; k0 += 4u * stride) {
+        uint64_t a1[4], a2[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t k = k0 + (uint32_t)u * stride;
+            on[u] = k < s1.n;
+            a1[u] = on[u] ? atom_of(s1, k) : 0ull;
+            a2[u] = on[u] ? atom_of(s2, k) : 0ull;
+        }
+        V3 p[4], q[4];
+        float m1[4], m2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            p[u] = pos_of(s1, blockIdx.y, a1[u]);
+            q[u] = pos_of(s2, 0, a2[u]);
+            m1[u] = s1.mass[a1[u]];
+            m2[u] = s2.mass ? s2.mass[a2[u]] : m1[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (on[u]) fit_accumulate<UNW, NV>(acc, p[u], q[u], (double)m1[u], (double)m2[u]);
     }
-    block_reduce_store<NV>(acc, partials);
+    block_reduce_store<NV, BLOCK>(acc, partials);
 }
 
 // the record of one fit from its 38 (21 without the unweighted block) sums; one thread
@@ -292,8 +314,12 @@ __device__ __forceinline__ void fit_finalize(const double (&S)[FS_ALL], int nv, 
 // RMSD, COM and gyration are those of the FITTED selection (p' = R p + t), from the sums:
 //   S |R p + t - q|^2 = S|p|^2 + S|q|^2 + n|t|^2 + 2 t.(R S p) - 2 t.S q - 2 sum_rc R[r][c] S q_r p_c      (R orthonormal)
 //   com' = R (S m p / S m) + t,   rg^2 = S m|p|^2 / S m - |S m p / S m|^2                                 (rigid motion)
-__global__ void __launch_bounds__(64) k_fit_final(const double *partials, uint32_t nblk, int nv, uint32_t n, int at_origin,
-                                                  float *out) {
+// (NV is a template parameter: a run-time "v < nv" around each of the 38 loads makes the compiler branch around every
+// one and wait for it - 76 dependent L2 round trips, 15 us of the kernel's 17)
+template <int NV>
+__global__ void __launch_bounds__(64) k_fit_final(const double *partials, uint32_t nblk, uint32_t n, int at_origin,
+                                                  float *out, float *out_host /* pinned host copy or NULL */) {
+    constexpr int nv = NV;
     const uint32_t f = blockIdx.x, lane = threadIdx.x;
     double S[FS_ALL];
 #pragma unroll
@@ -312,6 +338,10 @@ __global__ void __launch_bounds__(64) k_fit_final(const double *partials, uint32
     }
     if (lane != 0) return;
     fit_finalize(S, nv, n, at_origin, out + 18 * (size_t)f);
+    if (out_host) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) out_host[18 * (size_t)f + i] = out[18 * (size_t)f + i];
+    }
 }
 
 // apply_transform (modify.rs:32-36) for every frame of a batch: p <- R p + t in f32, in place
@@ -672,23 +702,23 @@ __global__ void __launch_bounds__(64) k_lipid_order(const float *__restrict__ xy
 
 // generic: total the partials of frame 0 into results[0..nv)
 // (64 lanes: lane l adds blocks l, l+64, ...; a butterfly adds the lanes - a fixed order, so results are reproducible)
-__global__ void __launch_bounds__(64) k_fin_sum(const double *partials, uint32_t nblk, int nv, double *results) {
+template <int NV>
+__global__ void __launch_bounds__(64) k_fin_sum(const double *partials, uint32_t nblk, double *results) {
     const uint32_t lane = threadIdx.x;
-    double x[16];        // nv <= 16 for every caller
+    double x[NV];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) x[v] = 0.0;
+    for (int v = 0; v < NV; ++v) x[v] = 0.0;
     for (uint32_t b = lane; b < nblk; b += 64) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v)
-            if (v < nv) x[v] += partials[(size_t)b * nv + v];
+        for (int v = 0; v < NV; ++v) x[v] += partials[(size_t)b * NV + v];     // unconditional: the loads pipeline
     }
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) x[v] += __shfl_xor(x[v], off, 64);
+        for (int v = 0; v < NV; ++v) x[v] += __shfl_xor(x[v], off, 64);
     }
 #pragma unroll
-    for (int v = 0; v < 16; ++v)
-        if (lane == 0 && v < nv) results[v] = x[v];
+    for (int v = 0; v < NV; ++v)
+        if (lane == 0) results[v] = x[v];
 }
 
 // ---------------------------------------------------------------- host helpers
@@ -733,8 +763,15 @@ int reduce1(molar_hip_ctx *c, uint32_t n, int nv, double *host_out, Launch launc
     MH_TRY(c->m_partials.reserve((size_t)nb * nv * 8));
     MH_TRY(c->m_results.reserve(64 * 8));
     launch(nb, c->m_partials.as<double>());
-    hipLaunchKernelGGL(k_fin_sum, dim3(1), dim3(64), 0, c->stream, c->m_partials.as<double>(), nb, nv,
-                       c->m_results.as<double>());
+    double *part = c->m_partials.as<double>(), *res = c->m_results.as<double>();
+    switch (nv) {
+        case 3: hipLaunchKernelGGL(k_fin_sum<3>, dim3(1), dim3(64), 0, c->stream, part, nb, res); break;
+        case 7: hipLaunchKernelGGL(k_fin_sum<7>, dim3(1), dim3(64), 0, c->stream, part, nb, res); break;
+        case 8: hipLaunchKernelGGL(k_fin_sum<8>, dim3(1), dim3(64), 0, c->stream, part, nb, res); break;
+        case 9: hipLaunchKernelGGL(k_fin_sum<9>, dim3(1), dim3(64), 0, c->stream, part, nb, res); break;
+        case 10: hipLaunchKernelGGL(k_fin_sum<10>, dim3(1), dim3(64), 0, c->stream, part, nb, res); break;
+        default: return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "reduce1: unsupported width %d", nv);
+    }
     MH_HIP(hipGetLastError());
     return pull(c, host_out, c->m_results.p, (size_t)nv * 8);
 }
@@ -1012,11 +1049,14 @@ int molar_hip_fit_transform(molar_hip_ctx *c, const float *xyz1, size_t natoms1,
         MH_TRY(c->m_partials.reserve((size_t)nb * FS_W * 8));
         MH_TRY(c->m_out.reserve(18 * 4));
         hipLaunchKernelGGL(k_fit_sums<false>, dim3(nb, 1), dim3(RB), 0, c->stream, s1, s2, c->m_partials.as<double>());
-        hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(64), 0, c->stream, c->m_partials.as<double>(), nb, FS_W, s1.n,
-                           at_origin ? 1 : 0, c->m_out.as<float>());
+        // the finalizer also writes the record into pinned host memory: the call ends with a stream wait, not a copy
+        MH_TRY(ensure_pinned(c, 18 * 4));
+        hipLaunchKernelGGL(k_fit_final<FS_W>, dim3(1), dim3(64), 0, c->stream, c->m_partials.as<double>(), nb, s1.n,
+                           at_origin ? 1 : 0, c->m_out.as<float>(), static_cast<float *>(c->h_pinned));
         MH_HIP(hipGetLastError());
+        MH_HIP(hipStreamSynchronize(c->stream));
         float h[18];
-        MH_TRY(pull(c, h, c->m_out.p, sizeof h));
+        std::memcpy(h, c->h_pinned, sizeof h);
         int st;
         std::memcpy(&st, &h[17], 4);
         if (st) return fail(st, st == MOLAR_HIP_ERR_ZERO_MASS ? "zero mass" : "SVD failed");
@@ -1293,13 +1333,17 @@ int molar_hip_fit_rmsd_batch(molar_hip_ctx *c, float *frames, size_t nframes, si
         // one gather pass, one finalizer, and the write pass only if the caller wants the frames moved
         Prof prof(c, 4);
         hipLaunchKernelGGL(k_fit_sums<true>, dim3(nb, F), dim3(RB), 0, c->stream, cur, ref, part);
-        hipLaunchKernelGGL(k_fit_final, dim3(F), dim3(64), 0, c->stream, part, nb, FS_ALL, cur.n, 0, o);
+        MH_TRY(ensure_pinned(c, (size_t)F * 18 * 4));
+        // (the records also land in pinned host memory: the call ends with a stream wait instead of a device-to-host copy)
+        hipLaunchKernelGGL(k_fit_final<FS_ALL>, dim3(F), dim3(64), 0, c->stream, part, nb, cur.n, 0, o,
+                           static_cast<float *>(c->h_pinned));
         if (apply)
             hipLaunchKernelGGL(k_apply_batch, dim3(nb, F), dim3(RB), 0, c->stream, cur, const_cast<float *>(cur.xyz), o);
     }
     MH_HIP(hipGetLastError());
+    MH_HIP(hipStreamSynchronize(c->stream));
     std::vector<float> h((size_t)F * 18);
-    MH_TRY(pull(c, h.data(), o, h.size() * 4));
+    std::memcpy(h.data(), c->h_pinned, h.size() * 4);
     for (uint32_t f = 0; f < F; ++f) {
         int st;
         std::memcpy(&st, &h[18 * (size_t)f + 17], 4);
