@@ -39,7 +39,8 @@ enum {
     MOLAR_HIP_OK = 0,
     MOLAR_HIP_ERR_SIZES = 1,
     MOLAR_HIP_ERR_ZERO_MASS = 2,
-    MOLAR_HIP_ERR_SVD = 3,
+    MOLAR_HIP_ERR_SVD = 3,           /* the rotation is found by Horn's quaternion method, which cannot fail to converge like an
+                                      * SVD; this code is returned when the covariance is not finite (NaN / inf coordinates) */
     MOLAR_HIP_ERR_NO_PBC = 4,
     MOLAR_HIP_ERR_ZERO_LENGTH_VECTOR = 5,
     MOLAR_HIP_ERR_INVERSE_FAILED = 6,
