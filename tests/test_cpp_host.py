@@ -27,6 +27,18 @@ def test_analysis_task_and_suffix_cpu():
     assert "all host-mirror CPU tests passed" in r.stdout
 
 
+def test_rotation_solver_cpu():
+    """molar_amd/csrc/linalg3.hpp on the host (hipcc, no GPU needed to run): Newton + adjugate vs Jacobi, known rotations."""
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, "test_linalg")
+    cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-std=c++17",
+           os.path.join(ROOT, "tests", "cpp", "test_linalg.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all linalg tests passed" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_host_api_gpu():
     from oracle import oracle as o
