@@ -761,9 +761,10 @@ template <class Launch>
 int reduce1(molar_hip_ctx *c, uint32_t n, int nv, double *host_out, Launch launch) {
     const uint32_t nb = blocks_for(c, n, 1);
     MH_TRY(c->m_partials.reserve((size_t)nb * nv * 8));
-    MH_TRY(c->m_results.reserve(64 * 8));
+    // the totals are written straight into pinned host memory: the call ends with a stream wait, not a copy
+    MH_TRY(ensure_pinned(c, 64 * 8));
     launch(nb, c->m_partials.as<double>());
-    double *part = c->m_partials.as<double>(), *res = c->m_results.as<double>();
+    double *part = c->m_partials.as<double>(), *res = static_cast<double *>(c->h_pinned);
     switch (nv) {
         case 3: hipLaunchKernelGGL(k_fin_sum<3>, dim3(1), dim3(64), 0, c->stream, part, nb, res); break;
         case 7: hipLaunchKernelGGL(k_fin_sum<7>, dim3(1), dim3(64), 0, c->stream, part, nb, res); break;
@@ -773,7 +774,9 @@ int reduce1(molar_hip_ctx *c, uint32_t n, int nv, double *host_out, Launch launc
         default: return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "reduce1: unsupported width %d", nv);
     }
     MH_HIP(hipGetLastError());
-    return pull(c, host_out, c->m_results.p, (size_t)nv * 8);
+    MH_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(host_out, c->h_pinned, (size_t)nv * 8);
+    return 0;
 }
 
 int box_or_err(const float *box9, molar_hip_box *b) {
