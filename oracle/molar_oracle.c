@@ -1119,8 +1119,11 @@ static void svd3(const double A_in[9], double U[9], double S[3], double V[9]) {
         }
     }
     memcpy(V, Vs, sizeof Vs);
-    /* complete U if rank deficient (degenerate inputs are excluded from parity, but keep U orthonormal) */
-    if (S[2] <= 1e-300 * (S[0] > 0 ? S[0] : 1.0) || S[2] == 0) {
+    /* Rank two (a PLANAR selection: an aromatic ring, a leaflet of markers): the third column of A V is rounding noise,
+     * so A V / S[2] is not a unit vector.  A true SVD (nalgebra's, measure.rs:626) returns an orthonormal U whatever the
+     * rank, and U diag(1,1,d) V^T is still unique then: u2 = +-(u0 x u1), and the sign cancels against d (:631-641).
+     * Rank one (collinear atoms) leaves the rotation about the line free: excluded from parity. */
+    if (S[2] <= 1e-10 * S[0] || S[2] == 0) {
         if (S[1] > 0 && S[0] > 0) {
             double *u0 = U, *u1 = U + 3, *u2 = U + 6;
             u2[0] = u0[1] * u1[2] - u0[2] * u1[1];

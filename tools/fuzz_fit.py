@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Randomised differential test of the fused fit path (molar_hip_fit_rmsd_batch, molar_hip_fit_batch, fit_transform)
+against the f64 oracle: selection sizes 3..20000, far-from-origin clouds, near-identical frames (RMSD ~ 1e-4), planar and
+nearly collinear selections (for the collinear ones the rotation is not unique: only the RMSD after the fit, the
+centre and the gyration radius are compared), large rigid motions.  Usage: python tools/fuzz_fit.py [ncases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from molar_amd import api, build
+    from oracle.oracle import Oracle
+    build.build_library()
+    eng = api.Engine(0)
+    o = Oracle("f64")
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    fails = 0
+    for case in range(ncases):
+        natoms = int(rng.integers(50, 30000))
+        m = int(rng.integers(3, min(natoms, 20000)))
+        kind = case % 6
+        centre = rng.uniform(-30, 30, 3) if kind != 1 else rng.uniform(-400, 400, 3)
+        ref = (centre + rng.normal(0, rng.uniform(0.3, 5.0), (natoms, 3))).astype(np.float32)
+        if kind == 2:      # planar cloud
+            ref[:, 2] = np.float32(centre[2])
+        if kind == 3:      # nearly collinear
+            ref = (centre + np.outer(rng.normal(0, 3, natoms), [1, 0.5, -0.2]) + rng.normal(0, 1e-3, (natoms, 3))).astype(np.float32)
+        noise = 1e-4 if kind == 4 else rng.uniform(0.01, 0.3)
+        Rz = api.rotation_from_axis_angle(rng.normal(size=3), float(rng.uniform(-3, 3))).astype(np.float64)
+        cur = ((ref.astype(np.float64) - centre) @ Rz.T + centre + rng.uniform(-5, 5, 3) + rng.normal(0, noise, (natoms, 3))).astype(np.float32)
+        mass = rng.uniform(1, 40, natoms).astype(np.float32)
+        idx = np.sort(rng.choice(natoms, m, replace=False)).astype(np.uint64)
+        out = eng.fit_rmsd_batch(cur[None].copy(), mass, ref, idx=idx, apply=False)
+        R, t = o.fit_transform(cur, mass, ref, mass, idx, idx)
+        mv = o.apply_transform(cur, R, t, idx)
+        w_rmsd, w_com, w_gyr = o.rmsd(mv, ref, idx, idx), o.center_of_mass(mv, mass, idx), o.gyration(mv, mass, idx)
+        scale = max(float(np.abs(ref[idx.astype(np.int64)]).max()), float(np.abs(cur[idx.astype(np.int64)]).max()), 1.0)
+        # f32 coordinates of magnitude `scale` carry +-scale * 6e-8 of quantisation noise, which enters the RMSD in
+        # quadrature: for near-identical frames (RMSD ~ 1e-4 at |x| ~ 30) that is 5e-5 relative in ANY f32 evaluation
+        quant = 3.0 * (scale * 6e-8) ** 2 / max(w_rmsd, 1e-12)
+        ok = abs(out["rmsd"][0] - w_rmsd) <= 2e-5 * w_rmsd + quant \
+            and np.allclose(out["com"][0], w_com, atol=2e-5 * scale) and abs(out["gyration"][0] - w_gyr) <= 2e-5 * max(w_gyr, 1e-3)
+        if kind != 3 and m > 3:        # planar selections still have a unique proper rotation; collinear ones do not
+            ok = ok and np.allclose(out["R"][0], R, atol=3e-5) and np.allclose(out["t"][0], t, atol=3e-5 * scale * 10)
+        # the single-call entry agrees with the batched one bit for bit (same kernels)
+        R1, t1 = eng.fit_transform(cur, mass, ref, mass, idx, idx)
+        ok = ok and np.array_equal(R1, out["R"][0]) and np.array_equal(t1, out["t"][0])
+        if not ok:
+            fails += 1
+            print("MISMATCH", case, kind, natoms, m, out["rmsd"][0], w_rmsd, out["gyration"][0], w_gyr, np.abs(out["R"][0] - R).max())
+    print(f"{ncases} cases, {fails} failures")
+
+
+if __name__ == "__main__":
+    main()
