@@ -365,3 +365,13 @@ def test_principal_transform_abi_matches_host_formula(eng, orc64):
         Rw = np.linalg.inv(np.asarray(axes, np.float64))
         assert np.allclose(R, Rw, atol=1e-5)
         assert np.allclose(t, cm + Rw @ (-np.asarray(cm, np.float64)), atol=1e-4)
+
+
+def test_fit_randomised_differential(eng):
+    """A 300-case slice of tools/fuzz_fit.py: selection sizes 3..20000, clouds far from the origin, near-identical
+    frames, planar and nearly collinear selections, large rigid motions - batched and single-call fits against the f64
+    oracle (RMSD / COM / gyration of the fitted selection always; R and t wherever the rotation is unique)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_fit
+    assert fuzz_fit.run(300, 5, eng) == 0

@@ -12,14 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def run(ncases=300, seed=1, eng=None):
     from molar_amd import api, build
     from oracle.oracle import Oracle
     build.build_library()
-    eng = api.Engine(0)
+    eng = eng or api.Engine(0)
     o = Oracle("f64")
-    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    rng = np.random.default_rng(seed)
     fails = 0
     for case in range(ncases):
         natoms = int(rng.integers(50, 30000))
@@ -41,9 +40,10 @@ def main():
         mv = o.apply_transform(cur, R, t, idx)
         w_rmsd, w_com, w_gyr = o.rmsd(mv, ref, idx, idx), o.center_of_mass(mv, mass, idx), o.gyration(mv, mass, idx)
         scale = max(float(np.abs(ref[idx.astype(np.int64)]).max()), float(np.abs(cur[idx.astype(np.int64)]).max()), 1.0)
-        # f32 coordinates of magnitude `scale` carry +-scale * 6e-8 of quantisation noise, which enters the RMSD in
-        # quadrature: for near-identical frames (RMSD ~ 1e-4 at |x| ~ 30) that is 5e-5 relative in ANY f32 evaluation
-        quant = 3.0 * (scale * 6e-8) ** 2 / max(w_rmsd, 1e-12)
+        # The engine (like the reference) applies an f32 translation: |dt| <= scale * 6e-8 * sqrt(3) is a common shift of
+        # the whole selection that the f64 oracle does not have.  It moves the RMSD by up to |dt| * |mean residual| / RMSD
+        # <= |dt|: an absolute floor of ~1e-7 * scale on what ANY f32 fit can reproduce (2 % of an RMSD of 1e-4 at |x| ~ 30).
+        quant = 1.2e-7 * scale
         ok = abs(out["rmsd"][0] - w_rmsd) <= 2e-5 * w_rmsd + quant \
             and np.allclose(out["com"][0], w_com, atol=2e-5 * scale) and abs(out["gyration"][0] - w_gyr) <= 2e-5 * max(w_gyr, 1e-3)
         if kind != 3 and m > 3:        # planar selections still have a unique proper rotation; collinear ones do not
@@ -55,7 +55,8 @@ def main():
             fails += 1
             print("MISMATCH", case, kind, natoms, m, out["rmsd"][0], w_rmsd, out["gyration"][0], w_gyr, np.abs(out["R"][0] - R).max())
     print(f"{ncases} cases, {fails} failures")
+    return fails
 
 
 if __name__ == "__main__":
-    main()
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
