@@ -375,3 +375,13 @@ def test_fit_randomised_differential(eng):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_fit
     assert fuzz_fit.run(300, 5, eng) == 0
+
+
+def test_measure_randomised_differential(eng):
+    """A 300-case slice of tools/fuzz_measure.py: centres (plain / periodic, all PbcDims masks), gyration and inertia
+    (plain / periodic), rmsd, rmsd_mw, min_max, unwrap_simple and the CSR-batched gyration / rmsd on random selections,
+    boxes and blobs, some 400 nm from the origin, against the f64 oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_measure
+    assert fuzz_measure.run(300, 4, eng) == 0
