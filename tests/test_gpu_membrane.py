@@ -256,3 +256,12 @@ def test_membrane_groups_accumulate(eng, tmp_path):
     m.finalize(tmp_path)
     assert sorted(p.name for p in tmp_path.iterdir()) == ["gr_lower_neib_stats.dat", "gr_lower_order_LIP.dat", "gr_lower_stats.dat",
                                                           "gr_upper_neib_stats.dat", "gr_upper_order_LIP.dat", "gr_upper_stats.dat"]
+
+
+def test_membrane_smooth_randomised_differential(eng):
+    """A 60-case slice of tools/fuzz_membrane.py: undulating, noisy, tilted sheets with holes, sheared boxes, sparse to
+    crowded patches, pre-invalidated lipids - validity / neighbour ids / vertex counts exact, floats within 5e-5."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_membrane
+    assert fuzz_membrane.run(60, 2, eng) == 0
