@@ -385,3 +385,12 @@ def test_measure_randomised_differential(eng):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_measure
     assert fuzz_measure.run(300, 4, eng) == 0
+
+
+def test_lipid_order_randomised_differential(eng):
+    """A 150-case slice of tools/fuzz_lipid_order.py: tails of 3..30 carbons, one normal per tail or per bond, up to three
+    double bonds, all order types, straight segments (NaN in the reference's formula, reproduced) - against the f32 oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_lipid_order
+    assert fuzz_lipid_order.run(150, 2, eng) == 0

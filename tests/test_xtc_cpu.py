@@ -171,3 +171,12 @@ def test_corrupt_streams_do_not_crash(reader_cls, orc32):
             outcomes["error"] += 1
         r.close()
     assert outcomes["error"] > 0 and outcomes["ok"] > 0 and outcomes["short"] > 0
+
+
+def test_xtc_randomised_differential():
+    """A 300-case slice of tools/fuzz_xtc.py: random atom counts (incl. the uncompressed <= 9 atom form), precisions,
+    magic numbers, water-like triplets, lattices, chains, kilometre-sized coordinates; product decoder == oracle codec."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_xtc
+    assert fuzz_xtc.run(300, 3) == 0
