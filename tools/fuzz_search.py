@@ -65,6 +65,14 @@ def main():
                 pr, d = eng.search_fill(cnt)
                 cnt2, _, _ = eng.search_resident(api.SEARCH_SINGLE, rc, pos, idx, **kw)
                 pr2, d2 = eng.search_fill(cnt2)
+                if case % 3 == 0:
+                    # the consumer-fused mode: Histogram1D::add_one (stats.rs:29-35) over the same distance stream,
+                    # with a range that also produces out-of-range and negative bins
+                    nb = int(rng.integers(1, 900)); hmin = float(np.float32(rng.uniform(-0.2, 0.4))); hmax = float(np.float32(rng.uniform(0.5, 1.6)))
+                    want = o.histogram_add(hmin, hmax, nb, ref["d"]).astype(np.uint64)
+                    bins, hc = eng.search_histogram(api.SEARCH_SINGLE, rc, hmin, hmax, nb, pos, idx, **kw)
+                    if hc != len(ref["i"]) or not np.array_equal(bins, want):
+                        fails += 1; print("MISMATCH histogram", tag, nb, hmin, hmax)
             elif kind in (1, 3):
                 perm = rng.permutation(n)
                 i1 = np.sort(perm[: n // 3]).astype(np.uint64); i2 = np.sort(perm[n // 3:]).astype(np.uint64)
