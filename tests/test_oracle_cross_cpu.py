@@ -73,3 +73,27 @@ def test_c_oracle_equals_python_restatement(orc32, seed):
         assert same(orc32.search_within(rc, s1, s2, lo, up, i1, i2), R.double(rc, s1, s2, i1, i2, within=True, lower=lo, upper=up)[0], within=True)
         checked += 4
     assert checked == 6 * 24
+
+
+def test_lipid_tail_order_second_restatement(orc64):
+    """Measure::lipid_tail_order (measure.rs:270-422): the C oracle (f64 build) against a separate numpy re-reading, on
+    random tails with one normal or one per bond and double bonds at every legal position."""
+    from oracle import ref_measure as M
+    rng = np.random.default_rng(17)
+    for case in range(300):
+        n = int(rng.integers(3, 24))
+        p = np.cumsum(rng.normal(0, 0.1, (n, 3)), axis=0) + rng.uniform(-5, 5, 3)
+        order_type = case % 3
+        per_bond = bool(rng.integers(0, 2))
+        bo = np.ones(n - 1, np.uint8)
+        if order_type:
+            for _ in range(int(rng.integers(0, 3))):
+                hi = n - 3 if per_bond else n - 2
+                if hi > 1:
+                    b = int(rng.integers(1, hi))
+                    if bo[b - 1] == 1 and (b + 1 >= n - 1 or bo[b + 1] == 1):
+                        bo[b] = 2
+        nn = rng.normal(size=(n - 2 if per_bond else 1, 3)); nn /= np.linalg.norm(nn, axis=1)[:, None]
+        want = M.lipid_tail_order(p, order_type, nn, bo)
+        got = orc64.lipid_tail_order(p, order_type, nn, bo)
+        assert np.allclose(got, want, atol=1e-9, equal_nan=True), (case, order_type, bo)
