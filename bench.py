@@ -125,7 +125,7 @@ def self_launch(args, argv):
     through torch.distributed.run with a 127.0.0.1 rendezvous, and exit with its status.  A node with fewer than N
     GPUs is refused here, with a message, before anything is spawned."""
     import subprocess
-    if args.backend == "nccl":
+    if args.backend == "nccl" and not args.share_gpu:
         import torch
         have = torch.cuda.device_count()
         if have < args.gpus:
@@ -152,7 +152,7 @@ def launch_check(args, rank, world):
                           "bins_sum": int(tot.sum()), "max_over_ranks": t, "frames_per_gpu": args.steps}))
 
 
-def run_rdf(args, rank, local_rank, world, device):
+def run_rdf(args, rank, local_rank, world, device, cdev):
     """BASELINE.json configs[3] shape: each rank owns K 250k-atom frames (resident in HBM), every frame goes through
     the fused search + Histogram1D binning (molar_membrane/src/stats.rs:29-35) into int64 bins resident on the GPU
     (no per-frame round trip), and ONE all_reduce of 1200 x int64 (RCCL) combines the ranks at the end."""
@@ -197,8 +197,8 @@ def run_rdf(args, rank, local_rank, world, device):
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(False)
-    total_bins = reduce_counts(bins.cpu().numpy(), device=device)       # the only collective
-    t = max_over_ranks(elapsed, device=device)
+    total_bins = reduce_counts(bins.cpu().numpy(), device=cdev)       # the only collective
+    t = max_over_ranks(elapsed, device=cdev)
     if rank == 0:
         check = None
         if args.verify:       # rank 0 recomputes every rank's frames alone: the reduced bins must be identical
@@ -252,6 +252,9 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default=os.environ.get("MOLAR_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend; gloo only with --launch-check (CPU test of the launch path)")
     ap.add_argument("--launch-check", action="store_true", help="launch the ranks and run the collectives only (no GPU work)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="functional check of the N>1 code path on a box with fewer GPUs: ranks share the visible GPUs "
+                         "(rank r uses GPU r mod count) and reduce over gloo; the line it prints is NOT a scaling result")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -275,16 +278,22 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    if args.share_gpu and torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        local_rank = local_rank % torch.cuda.device_count()
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but this process sees {torch.cuda.device_count()} "
                          "GPU(s); there is no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    cdev = None if args.share_gpu else device          # where the end-of-run reductions run (gloo: host tensors)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if args.workload == "rdf":
-        run_rdf(args, rank, local_rank, world, device)
+        run_rdf(args, rank, local_rank, world, device, cdev)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -443,8 +452,8 @@ def main():
 
     # end-of-run reductions (RCCL when world > 1): integer pair count, max-over-ranks wall time
     from molar_amd.distributed import max_over_ranks, reduce_counts
-    total_pairs = float(reduce_counts([pairs], device=device)[0])
-    t = max_over_ranks(elapsed, device=device)
+    total_pairs = float(reduce_counts([pairs], device=cdev)[0])
+    t = max_over_ranks(elapsed, device=cdev)
 
     if rank == 0:
         frames_total = K * world
@@ -481,7 +490,8 @@ def main():
                             "(ordered pair list in HBM) + Kabsch RMSD fit/COM/gyration of a 100k-atom selection",
                 "natoms": NATOMS, "cutoff_nm": CUTOFF, "pairs_per_frame": p_per_frame,
                 "selection_atoms": int(len(idx_np)), "frames_per_gpu": K,
-                "parallelism": f"frames sharded over {world} rank(s), no data-path collective",
+                "parallelism": f"frames sharded over {world} rank(s), no data-path collective"
+                               + (" - ranks SHARE the GPUs (functional check, not a scaling result)" if args.share_gpu else ""),
                 "streams_per_gpu": S * (2 if overlap else 1),
                 "frames_in_flight_per_stream": 2 if (S == 1 and pipelined) else 1,
                 "measure_overlapped_with_search": overlap,
