@@ -108,7 +108,7 @@ extern "C" {
 
 const char *molar_hip_last_error(void) { return last_error().c_str(); }
 
-const char *molar_hip_version(void) { return "molar_hip 0.1 (gfx950)"; }
+const char *molar_hip_version(void) { return "molar_hip 0.2 (gfx950)"; }
 
 int molar_hip_device_count(void) {
     int n = 0;
