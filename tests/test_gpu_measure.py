@@ -394,3 +394,35 @@ def test_lipid_order_randomised_differential(eng):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_lipid_order
     assert fuzz_lipid_order.run(150, 2, eng) == 0
+
+
+def test_csr_batches_with_device_resident_inputs(eng):
+    """The CSR-batched entries take device pointers for every array (frames that never leave HBM) and give the same
+    numbers as with host arrays; apply moves the device frame in place."""
+    import torch
+    from molar_amd import synth
+    rng = np.random.default_rng(41)
+    n, K = 30000, 500
+    box = synth.box_a(n)
+    x1, x2, mass = synth.frame(n, box, 1), synth.frame(n, box, 2), synth.masses(n)
+    idx, off = _random_csr(rng, n, K, 3, 120)
+    d = lambda a, t=None: torch.from_numpy(a if t is None else a.astype(t)).cuda()
+    dx1, dx2, dm, di, do = d(x1), d(x2), d(mass), d(idx, np.int64), d(off, np.int64)
+    assert np.array_equal(eng.gyration_batch(dx1, di, do, dm), eng.gyration_batch(x1, idx, off, mass))
+    assert np.array_equal(eng.gyration_batch(dx1, di, do, dm, box=box), eng.gyration_batch(x1, idx, off, mass, box=box))
+    assert np.array_equal(eng.rmsd_batch(dx1, dx2, di, do, mass=dm), eng.rmsd_batch(x1, x2, idx, off, mass=mass))
+    a = eng.fit_batch(dx1, dm, dx2, di, do, apply=False)
+    b = eng.fit_batch(x1, mass, x2, idx, off, apply=False)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    # disjoint selections so that apply is well defined for the whole batch
+    perm = rng.permutation(n)[: 6000].astype(np.uint64)
+    idx2 = np.sort(perm.reshape(100, 60), axis=1).reshape(-1); off2 = (np.arange(101) * 60).astype(np.uint64)
+    h = x1.copy()
+    eng.fit_batch(h, mass, x2, idx2, off2, apply=True)
+    dv = dx1.clone()
+    eng.fit_batch(dv, dm, dx2, d(idx2, np.int64), d(off2, np.int64), apply=True)
+    eng.synchronize()
+    assert np.array_equal(dv.cpu().numpy(), h)
+    rest = np.ones(n, bool); rest[idx2.astype(np.int64)] = False
+    assert np.array_equal(h[rest], x1[rest]) and not np.array_equal(h[~rest], x1[~rest])
