@@ -81,6 +81,7 @@ struct SearchParams {
     uint32_t hist_nbins;     // != 0: the fill traversal feeds a histogram instead of writing pairs
     float hist_min, hist_max;
     unsigned long long *hist_bins;    // [nbins] + [1] total
+    uint32_t hist_lean;      // histogram mode: hist_kernel takes the slots hist_lean_slot() accepts, pair_kernel<MODE_HIST> the rest
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     uint32_t debug_skip;     // profiling aid (env MOLAR_HIP_DEBUG_SKIP): bit0 plain, bit1 wrapped, bit2 triangular slots do nothing
 #endif
@@ -173,7 +174,9 @@ __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     // second cell of the task: c2, or c1 for the swapped half of a two-grid entry
     T.wrap_b = (KIND != MOLAR_HIP_SEARCH_SINGLE && half) ? (wrap & ~wrap_c2) : wrap_c2;
     // only the entries of the single home cell (dx-1,dy-1,dz-1) can wrap in all three dims: <= 28 tasks
-    T.rps = (P.use_box && wrap == MOLAR_HIP_PBC_FULL && P.box.nshift != 0 && T.n1 <= 4096u) ? 8u : 64u;
+    // (their candidate loop reads the lattice shifts from memory, one dependent scalar load per candidate image: a slot
+    // is latency-bound, so these few tasks are cut into many short slots - 2 rows, or 8 for very large cells)
+    T.rps = (P.use_box && wrap == MOLAR_HIP_PBC_FULL && P.box.nshift != 0 && T.n1 <= 4096u) ? (T.n1 <= 1024u ? 2u : 8u) : 64u;
     T.cb = cb;
     if (UNIFORM) {
         T.cb = __builtin_amdgcn_readfirstlane(T.cb);
@@ -988,6 +991,17 @@ static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, co
     }
 }
 
+// fused histogram: the slots hist_kernel (below) takes; pair_kernel<MODE_HIST> leaves them alone
+template <int KIND>
+__device__ __forceinline__ bool hist_lean_slot(const SearchParams &P, uint32_t flags, uint32_t n2) {
+    if (KIND != MOLAR_HIP_SEARCH_SINGLE && KIND != MOLAR_HIP_SEARCH_DOUBLE) return false;
+    if (((n2 + 63u) >> 6) > (uint32_t)KREG) return false;
+    const uint32_t wrap = flags & 7u;
+    if (!(P.use_box && wrap != 0u)) return true;                    // plain or same-cell entry
+    if (flags & 0x100u) return false;                               // a cell paired with its own periodic image
+    return P.approx_wrapped != 0u && !(P.box.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL);
+}
+
 template <int KIND, int MODE>
 __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : 8))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
@@ -1074,9 +1088,10 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
         }
         uint32_t total = 0;
         const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
+        if (hist && P.hist_lean && hist_lean_slot<KIND>(P, (T.tri ? 0x100u : 0u) | T.wrap, T.n2)) return;   // hist_kernel's
 #ifdef MOLAR_HIP_DEBUG_KNOBS
         if (P.debug_skip) {     // not in release builds: tools/dbg_skip.sh builds with -DMOLAR_HIP_DEBUG_KNOBS
-            const uint32_t kind_bit = T.tri ? 4u : (wk != WK_NONE ? 2u : 1u);
+            const uint32_t kind_bit = T.tri ? 4u : (wk != WK_NONE ? (T.rps == 8u ? 8u : 2u) : 1u);   // 8: triclinic corner entries
             if (P.debug_skip & kind_bit) return;
         }
 #endif
@@ -1115,6 +1130,320 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
 }
 
 
+// ================================================================= fused histogram, lean kernel
+// Consumer-fused histogram (molar_hip_search_histogram) for the slots that make up nearly all of the work: plain,
+// same-cell and band-classified wrapped entries whose second cell fits in registers.  Bins do not depend on the order
+// in which hits are found, so
+//  * plain and same-cell entries walk the second cell in the spatial order of the count pass (chunk bounding boxes:
+//    ~43 % of the candidate evaluations of the neighbour entries skipped) and queue only d2 (one LDS plane);
+//  * wrapped entries queue (row, unshifted second atom) in LDS and the exact PeriodicBox::distance_squared of the
+//    hits is evaluated densely at flush time (no global gather in the flush);
+//  * 64 queued hits at a time go through sqrt + Histogram1D::add_one (molar_membrane/src/stats.rs:29-35);
+//  * the queue of plain hits carries over from one slot to the next (no partial flush per slot).
+// Everything else (triclinic corner entries, cells > 512 atoms, vdW radii, boxes without the band classification)
+// stays with pair_kernel<KIND, MODE_HIST>, which skips the slots accepted here (SearchParams::hist_lean).
+// 64 VGPRs, 8 waves per SIMD; pair_kernel<MODE_HIST> carries every generic path and needs 108 (4 waves).
+struct HistFifo {
+    uint32_t *fd;        // LDS, FIFO_CAP words: d2 (plain) or the row (wrapped)
+    float4 *fq;          // LDS, FIFO_CAP: unshifted second atom of a wrapped hit
+    const float4 *la;    // the slot's first-cell atoms in LDS
+    uint32_t head, tail; // wave-uniform
+    uint32_t *hist;      // workgroup histogram in LDS
+    float hmin, hmax, hn;
+};
+
+// Histogram1D::add_one (stats.rs:29-35) on d = sqrt(d2):  b = (n as Float * (val - min) / (max - min)).floor() as isize
+__device__ __forceinline__ void hist_add(const HistFifo &F, float d2) {
+    const float d = __builtin_sqrtf(d2);
+    float fb = __builtin_floorf(F.hn * (d - F.hmin) / (F.hmax - F.hmin));
+    if (fb != fb) fb = 0.0f;                                    // NaN as isize == 0
+    if (fb >= 0.0f && fb < F.hn) atomicAdd(&F.hist[(uint32_t)fb], 1u);
+}
+
+template <bool WRAPPED>
+__device__ __forceinline__ void hist_flush(const SearchParams &P, HistFifo &F, uint32_t count, uint32_t lane, uint32_t wrap) {
+    if (lane < count) {
+        const uint32_t s = (F.head + lane) & (FIFO_CAP - 1);
+        float d2;
+        if (WRAPPED) {
+            const float4 a = lload4(F.la, F.fd[s]);
+            const float4 b = lload4(F.fq, s);
+            d2 = wrapped_d2_exact(P, wrap, b.x - a.x, b.y - a.y, b.z - a.z);     // p2 - p1 (:485-486)
+        } else {
+            d2 = __uint_as_float(F.fd[s]);
+        }
+        hist_add(F, d2);
+    }
+    F.head += count;
+}
+
+template <int KIND, int NCH, bool TRI>
+__device__ __forceinline__ uint32_t run_hist_sorted(const SearchParams &P, const Task &T, uint32_t i0, HistFifo &F, float4 *la,
+                                                    uint32_t lane) {
+    const float cutoff2 = P.cutoff2;
+    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
+    la[lane] = a;
+    float bx[NCH], by[NCH], bz[NCH];
+    uint32_t bpos[TRI ? NCH : 1];      // position in the reference's cell order (same-cell entries: j > i, :443)
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const uint32_t jj = (uint32_t)k * 64u + lane;
+        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+        if (jj < T.n2) q = gload4(P.perm_b, T.b0 + jj);
+        bx[k] = q.x; by[k] = q.y; bz[k] = q.z;
+        if (TRI) bpos[k] = __float_as_uint(q.w);
+    }
+    const uint32_t ubase = (T.b0 >> 6) + T.cb;
+    unsigned long long livek[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const float4 lo = gload4(P.chunk_aabb_b, 2u * (ubase + k)), hi = gload4(P.chunk_aabb_b, 2u * (ubase + k) + 1u);
+        const bool need = lane < rows && !(aabb_d2(a.x, a.y, a.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > cutoff2);
+        livek[k] = __builtin_amdgcn_ballot_w64(need);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t total = 0;
+    unsigned long long live = 0ull;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) live |= livek[k];
+    while (live) {
+        const uint32_t r = (uint32_t)__builtin_ctzll(live);
+        live &= ~(1ull << r);
+        const float4 p = lload4(la, r);              // one broadcast ds_read per row
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (!((livek[k] >> r) & 1ull)) continue;                              // wave-uniform: scalar branch
+            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1
+            float d2 = (dx * dx + dy * dy) + dz * dz;                            // |p2-p1|^2 (:446, :460)
+            if (TRI) d2 = (bpos[k] > i0 + r) ? d2 : INFINITY;
+            const bool hit = d2 <= cutoff2;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+            if (mask) {
+                const uint32_t cnt = (uint32_t)__popcll(mask);
+                if (hit) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    const uint32_t off = ((rank + F.tail) << 2) & ((FIFO_CAP - 1u) << 2);
+                    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+                    *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fd + off) = __float_as_uint(d2);
+                }
+                F.tail += cnt;
+                total += cnt;
+                if (F.tail - F.head >= 64u) {
+                    __builtin_amdgcn_wave_barrier();
+                    hist_flush<false>(P, F, 64u, lane, 0u);
+                }
+            }
+        }
+    }
+    return total;       // < 64 hits stay queued for the next slot
+}
+
+template <int KIND, int NCH>
+__device__ __forceinline__ uint32_t run_hist_wrapped(const SearchParams &P, const Task &T, uint32_t i0, HistFifo &F, float4 *la,
+                                                     uint32_t lane) {
+    // as run_fast<FILL, WRAPPED> with the band classification: candidates are classified with the plain distance to the
+    // image of the second cell (b + S); only those inside the band take the exact formula
+    float Sx = 0.f, Sy = 0.f, Sz = 0.f;
+    for (int d = 0; d < 3; ++d) {
+        if (!((T.wrap >> d) & 1u)) continue;
+        const float sgn = ((T.wrap_b >> d) & 1u) ? 1.0f : -1.0f;   // second cell wrapped: +col, first cell: -col
+        Sx += sgn * P.box.m[3 * d];
+        Sy += sgn * P.box.m[3 * d + 1];
+        Sz += sgn * P.box.m[3 * d + 2];
+    }
+    float bx[NCH], by[NCH], bz[NCH];         // unshifted: the shift is added per candidate, the hit queues the original
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const uint32_t jj = (uint32_t)k * 64u + lane;
+        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+        if (jj < T.n2) q = gload4(P.sb, T.b0 + jj);
+        bx[k] = q.x; by[k] = q.y; bz[k] = q.z;
+    }
+    const float cutoff2 = P.cutoff2;
+    const float band_lo = P.band_lo, band_hi = P.band_hi;
+    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
+    unsigned long long live;
+    {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
+        la[lane] = a;
+        const float4 lo = gload4(P.aabb_b, 2 * T.cb), hi = gload4(P.aabb_b, 2 * T.cb + 1);
+        const bool need = !(aabb_d2(a.x - Sx, a.y - Sy, a.z - Sz, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > P.prune_limit2);
+        live = __builtin_amdgcn_ballot_w64(lane < rows && need);
+    }
+    __builtin_amdgcn_wave_barrier();
+    F.la = la;
+    uint32_t total = 0;
+    while (live) {
+        const uint32_t r = (uint32_t)__builtin_ctzll(live);
+        live &= ~(1ull << r);
+        const float4 p = lload4(la, r);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const float qx = bx[k] + Sx, qy = by[k] + Sy, qz = bz[k] + Sz;       // image of p2 next to the first cell
+            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            const bool sure = d2 < band_lo, maybe = d2 <= band_hi;
+            bool hit = sure;
+            if (__builtin_amdgcn_ballot_w64(maybe && !sure))
+                hit = sure || (maybe && wrapped_d2_exact(P, T.wrap, bx[k] - p.x, by[k] - p.y, bz[k] - p.z) <= cutoff2);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+            if (mask) {
+                const uint32_t cnt = (uint32_t)__popcll(mask);
+                if (hit) {
+                    const uint32_t s = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, F.tail)) &
+                                       (FIFO_CAP - 1);
+                    F.fq[s] = make_float4(bx[k], by[k], bz[k], 0.f);
+                    F.fd[s] = r;
+                }
+                F.tail += cnt;
+                total += cnt;
+                if (F.tail - F.head >= 64u) {
+                    __builtin_amdgcn_wave_barrier();
+                    hist_flush<true>(P, F, 64u, lane, T.wrap);
+                }
+            }
+        }
+    }
+    if (F.tail != F.head) {            // these entries refer to this slot's rows
+        __builtin_amdgcn_wave_barrier();
+        hist_flush<true>(P, F, F.tail - F.head, lane, T.wrap);
+    }
+    return total;
+}
+
+#ifndef HK_HIST_WAVES
+#define HK_HIST_WAVES 16
+#endif
+constexpr int HIST_WAVES = HK_HIST_WAVES;      // waves per workgroup of hist_kernel (one LDS histogram and one slot counter per workgroup)
+
+#ifndef HK_LEAN_WPE
+#define HK_LEAN_WPE 8
+#endif
+template <int KIND>
+__global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(HK_LEAN_WPE)))
+hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ slot_desc, uint32_t nslots) {
+    __shared__ uint32_t lds_fd[HIST_WAVES][FIFO_CAP];
+    __shared__ float4 lds_a[HIST_WAVES][64];
+    __shared__ float4 lds_q[HIST_WAVES][FIFO_CAP];
+    __shared__ uint32_t lds_next;
+    extern __shared__ uint32_t lds_hist[];
+    const SearchParams &P = *Pp;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += 64 * HIST_WAVES) lds_hist[b] = 0u;
+    if (threadIdx.x == 0) lds_next = 0u;
+    __syncthreads();
+    HistFifo F;
+    F.fd = lds_fd[wave];
+    F.fq = lds_q[wave];
+    F.la = lds_a[wave];
+    F.head = F.tail = 0u;
+    F.hist = lds_hist;
+    F.hmin = P.hist_min;
+    F.hmax = P.hist_max;
+    F.hn = (float)P.hist_nbins;
+    unsigned long long wave_total = 0;
+    // A workgroup owns every gridDim.x-th slot and hands them to its waves one at a time through a counter in LDS:
+    // slots differ ~10x in work, and with a fixed share of ~9 slots per wave the slowest wave took 1.7x the mean.
+    // (One counter in memory for the whole grid serialises: 7*10^4 device-scope atomics on one address took 1.1 ms.)
+    for (;;) {
+        uint32_t tk = 0u;
+        if (lane == 0) tk = atomicAdd(&lds_next, 1u);
+        const unsigned long long w64 = blockIdx.x + (unsigned long long)__builtin_amdgcn_readfirstlane(tk) * gridDim.x;
+        if (w64 >= nslots) break;
+        const uint32_t w = (uint32_t)w64;
+        const uint32_t slot = nslots - 1u - w;       // reverse plan order, as pair_kernel
+        Task T;
+        uint32_t i0, fl;
+        {
+            const uint4 lo = reinterpret_cast<const uint4 *>(slot_desc + slot)[0];
+            const uint4 hi = reinterpret_cast<const uint4 *>(slot_desc + slot)[1];
+            fl = __builtin_amdgcn_readfirstlane(hi.y);
+            if (!(fl & 0x200u)) continue;             // past the last slot
+            T.a0 = __builtin_amdgcn_readfirstlane(lo.x);
+            T.n1 = __builtin_amdgcn_readfirstlane(lo.y);
+            T.b0 = __builtin_amdgcn_readfirstlane(lo.z);
+            T.n2 = __builtin_amdgcn_readfirstlane(lo.w);
+            T.cb = __builtin_amdgcn_readfirstlane(hi.x);
+            i0 = __builtin_amdgcn_readfirstlane(hi.z);
+            T.wrap = fl & 7u;
+            T.tri = (fl & 0x100u) != 0u;
+            T.valid = true;
+            T.wrap_b = (fl >> 12) & 7u;
+            T.rps = fl >> 16;
+        }
+        if (!hist_lean_slot<KIND>(P, fl, T.n2)) continue;
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+        if (P.debug_skip) {
+            const uint32_t kind_bit = T.tri ? 4u : ((P.use_box && T.wrap != 0u) ? 2u : 1u);
+            if (P.debug_skip & kind_bit) continue;
+        }
+#endif
+        const uint32_t nchunks = (T.n2 + 63u) >> 6;
+        uint32_t total = 0;
+        if (P.use_box && T.wrap != 0u) {
+            if (F.tail != F.head) {        // plain hits still queued: out before entries of another kind go in
+                __builtin_amdgcn_wave_barrier();
+                hist_flush<false>(P, F, F.tail - F.head, lane, 0u);
+            }
+            switch (nchunks) {
+                case 1: total = run_hist_wrapped<KIND, 1>(P, T, i0, F, lds_a[wave], lane); break;
+                case 2: total = run_hist_wrapped<KIND, 2>(P, T, i0, F, lds_a[wave], lane); break;
+                case 3: total = run_hist_wrapped<KIND, 3>(P, T, i0, F, lds_a[wave], lane); break;
+                case 4: total = run_hist_wrapped<KIND, 4>(P, T, i0, F, lds_a[wave], lane); break;
+                case 5: total = run_hist_wrapped<KIND, 5>(P, T, i0, F, lds_a[wave], lane); break;
+                case 6: total = run_hist_wrapped<KIND, 6>(P, T, i0, F, lds_a[wave], lane); break;
+                case 7: total = run_hist_wrapped<KIND, 7>(P, T, i0, F, lds_a[wave], lane); break;
+                default: total = run_hist_wrapped<KIND, 8>(P, T, i0, F, lds_a[wave], lane); break;
+            }
+        } else if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) {
+            switch (nchunks) {
+                case 1: total = run_hist_sorted<KIND, 1, true>(P, T, i0, F, lds_a[wave], lane); break;
+                case 2: total = run_hist_sorted<KIND, 2, true>(P, T, i0, F, lds_a[wave], lane); break;
+                case 3: total = run_hist_sorted<KIND, 3, true>(P, T, i0, F, lds_a[wave], lane); break;
+                case 4: total = run_hist_sorted<KIND, 4, true>(P, T, i0, F, lds_a[wave], lane); break;
+                case 5: total = run_hist_sorted<KIND, 5, true>(P, T, i0, F, lds_a[wave], lane); break;
+                case 6: total = run_hist_sorted<KIND, 6, true>(P, T, i0, F, lds_a[wave], lane); break;
+                case 7: total = run_hist_sorted<KIND, 7, true>(P, T, i0, F, lds_a[wave], lane); break;
+                default: total = run_hist_sorted<KIND, 8, true>(P, T, i0, F, lds_a[wave], lane); break;
+            }
+        } else {
+            switch (nchunks) {
+                case 1: total = run_hist_sorted<KIND, 1, false>(P, T, i0, F, lds_a[wave], lane); break;
+                case 2: total = run_hist_sorted<KIND, 2, false>(P, T, i0, F, lds_a[wave], lane); break;
+                case 3: total = run_hist_sorted<KIND, 3, false>(P, T, i0, F, lds_a[wave], lane); break;
+                case 4: total = run_hist_sorted<KIND, 4, false>(P, T, i0, F, lds_a[wave], lane); break;
+                case 5: total = run_hist_sorted<KIND, 5, false>(P, T, i0, F, lds_a[wave], lane); break;
+                case 6: total = run_hist_sorted<KIND, 6, false>(P, T, i0, F, lds_a[wave], lane); break;
+                case 7: total = run_hist_sorted<KIND, 7, false>(P, T, i0, F, lds_a[wave], lane); break;
+                default: total = run_hist_sorted<KIND, 8, false>(P, T, i0, F, lds_a[wave], lane); break;
+            }
+        }
+        wave_total += total;
+    }
+    if (F.tail != F.head) {
+        __builtin_amdgcn_wave_barrier();
+        hist_flush<false>(P, F, F.tail - F.head, lane, 0u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += 64 * HIST_WAVES) {
+        const uint32_t v = lds_hist[b];
+        if (v) atomicAdd(&P.hist_bins[b], (unsigned long long)v);
+    }
+    if (lane == 0 && wave_total) atomicAdd(&P.hist_bins[P.hist_nbins], wave_total);
+}
+
+template <int KIND>
+inline void launch_hist_kernel(unsigned num_cus, size_t dyn_lds, hipStream_t stream, const SearchParams *dP,
+                               const SlotDesc *slot_desc, uint32_t nslots) {
+    // persistent workgroups: 32 waves per CU (8 per SIMD)
+    hipLaunchKernelGGL((hist_kernel<KIND>), dim3(num_cus * (32 / HIST_WAVES)), dim3(64 * HIST_WAVES), dyn_lds, stream, dP, slot_desc, nslots);
+}
+
+
 // HIP limits gridDim.x * blockDim.x to 2^32 threads: sparse giant grids (10^8 plan entries, one 64-lane workgroup per
 // slot) spill into grid.y; the kernels linearise (x fastest)
 inline dim3 pair_grid(unsigned nblocks) {
@@ -1134,6 +1463,8 @@ inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t str
 }  // namespace pairk
 
 // defined in pair_k0.hip .. pair_k3.hip (one search kind each)
+void launch_hist_lean(int kind, unsigned num_cus, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
+                      const pairk::SlotDesc *slot_desc, uint32_t nslots);
 void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
                         const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                         const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);

@@ -789,12 +789,16 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     P.hist_max = hmax;
     P.hist_bins = hist_bins;
     size_t dyn_lds = 0;
+    P.hist_lean = 0u;
     if (hist_nbins) {
         dyn_lds = (size_t)hist_nbins * 4;
         const uint32_t wpb = (uint32_t)waves_per_block(MODE_HIST);
         P.nblocks = (P.nblocks + wpb - 1u) / wpb;
         const uint32_t cap = (uint32_t)c->num_cus * 8u;
         if (P.nblocks > cap) P.nblocks = cap;
+        // plain, same-cell and band-classified wrapped slots go to the lean kernel (8 waves per SIMD), the rest to
+        // pair_kernel<MODE_HIST>; both add into the same bins
+        P.hist_lean = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
     }
     MH_TRY(c->params.reserve(sizeof(SearchParams)));
     // params_resident: the block uploaded for the previous pass of this search is still valid for this one
@@ -808,6 +812,7 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     uint32_t *sc = c->slot_cnt.as<uint32_t>();
     auto *sb = c->slot_base.as<unsigned long long>();
     const int mode = !FILL ? MODE_COUNT : (hist_nbins ? MODE_HIST : MODE_FILL);
+    if (P.hist_lean) launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st);
     switch (c->kind) {
         case MOLAR_HIP_SEARCH_SINGLE: launch_pair_single(mode, P.nblocks, dyn_lds, c->stream, dP, tf, st, sc, sb, pairs, dist, ids); break;
         case MOLAR_HIP_SEARCH_DOUBLE: launch_pair_double(mode, P.nblocks, dyn_lds, c->stream, dP, tf, st, sc, sb, pairs, dist, ids); break;
@@ -949,7 +954,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     // every set-1 cell is the first cell of at most 14 (two grids: 28) tasks, so
     // sum_t ceil(n1(t)/64) <= mult*N1/64 + ntasks
     c->nslots_bound = (two ? 28ull : 14ull) * (((uint64_t)c->set[0].n + 63ull) / 64ull) + c->ntasks;
-    // entries wrapping in all three dims of a triclinic box use 8-row slots: <= 28 tasks of <= 4096 rows
+    // entries wrapping in all three dims of a triclinic box use 2-row (<= 1024 rows) or 8-row slots: <= 28 tasks of <= 512 slots
     c->nslots_bound += 28ull * 512ull;
     if (c->ntasks >= 0xFFFFFFF0ull || c->nslots_bound >= 0xFFFFFFF0ull || c->ntasks + c->nslots_bound >= 0xFFFFFF00ull)
         return fail(MOLAR_HIP_ERR_TOO_LARGE, "search plan too large (%llu entries)", (unsigned long long)c->ntasks);

@@ -332,6 +332,57 @@ def test_fused_histogram_bit_identical(eng, orc32, n, cutoff, nbins):
     assert np.array_equal(half, want_half)
 
 
+@pytest.mark.parametrize("case", ["rhombic", "ortho", "big_cells", "pbc_xy", "no_box", "few_cells", "hmin", "vdw", "two_sets_rhombic"])
+def test_fused_histogram_equals_the_distance_stream(eng, orc32, case):
+    """Every class of plan entry of the fused histogram (plain / same-cell / band-classified wrapped entries in the lean
+    kernel; triclinic corner entries, cells > 512 atoms, boxes without the band classification, vdW radii in the generic
+    one) against Histogram1D::add_one (stats.rs:29-35) applied to the distance stream of the pair search, which the
+    tests above pin to the oracle."""
+    a = api()
+    rng = np.random.default_rng(11)
+    kind, n, cutoff, nbins, hmin, pbc, box, kw = a.SEARCH_SINGLE, 30000, 0.9, 450, 0.0, 7, None, {}
+    if case == "rhombic":
+        box = synth.box_b(n)
+    elif case == "ortho":
+        box = synth.box_ortho(n)
+    elif case == "big_cells":
+        cutoff, nbins = 2.1, 700            # ~900 atoms per cell: streaming path
+        box = synth.box_a(n)
+    elif case == "pbc_xy":
+        box, pbc = synth.box_a(n), 3
+    elif case == "no_box":
+        box, pbc = synth.box_a(n), 0
+    elif case == "few_cells":
+        n, cutoff = 4000, 1.2               # 2-3 cells per dimension: wrapped entries evaluated exactly
+        box = synth.box_b(n)
+    elif case == "hmin":
+        box, hmin = synth.box_a(n), 0.35
+    elif case == "vdw":
+        kind, box = a.SEARCH_DOUBLE_VDW, synth.box_a(n)
+    elif case == "two_sets_rhombic":
+        kind, box = a.SEARCH_DOUBLE, synth.box_b(n)
+    pos = synth.frame(n, box, 5)
+    hmax = cutoff
+    if kind == a.SEARCH_SINGLE:
+        args = dict(xyz1=pos)
+    else:
+        idx1 = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.uint64)
+        idx2 = np.setdiff1d(np.arange(n, dtype=np.uint64), idx1)
+        args = dict(xyz1=pos, idx1=idx1, xyz2=pos, idx2=idx2)
+        if kind == a.SEARCH_DOUBLE_VDW:
+            cutoff, hmax, nbins = None, 0.5, 250
+            kw = dict(vdw1=rng.uniform(0.1, 0.22, len(idx1)).astype(np.float32),
+                      vdw2=rng.uniform(0.1, 0.22, len(idx2)).astype(np.float32))
+    use_box = box if case != "no_box" else None
+    cnt = eng.search_count(kind, cutoff, box=use_box, pbc=pbc, **args, **kw)
+    _, dist = eng.search_fill(cnt)
+    assert cnt > 1000
+    want = orc32.histogram_add(hmin, hmax, nbins, dist).astype(np.uint64)
+    bins, c2 = eng.search_histogram(kind, cutoff, hmin, hmax, nbins, box=use_box, pbc=pbc, **args, **kw)
+    assert c2 == cnt
+    assert np.array_equal(bins, want)
+
+
 def test_fused_histogram_two_sets(eng, orc32):
     a = api()
     n = 12000
