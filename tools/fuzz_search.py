@@ -90,6 +90,12 @@ def main():
                     pr, d = eng.search_fill(cnt)
                     cnt2, _, _ = eng.search_resident(api.SEARCH_DOUBLE_VDW, None, pos, i1, pos, i2, vdw1=v1, vdw2=v2, **kw)
                 pr2, d2 = eng.search_fill(cnt2)
+                if kind == 1 and case % 2 == 0:       # fused histogram of the two-set stream (same-cell duplicates included)
+                    nb = int(rng.integers(1, 900)); hmin = float(np.float32(rng.uniform(-0.2, 0.4))); hmax = float(np.float32(rng.uniform(0.5, 1.6)))
+                    want = o.histogram_add(hmin, hmax, nb, ref["d"]).astype(np.uint64)
+                    bins, hc = eng.search_histogram(api.SEARCH_DOUBLE, rc, hmin, hmax, nb, pos, i1, pos, i2, **kw)
+                    if hc != len(ref["i"]) or not np.array_equal(bins, want):
+                        fails += 1; print("MISMATCH histogram", tag, nb, hmin, hmax)
             else:
                 i1 = np.arange(n, dtype=np.uint64); i2 = np.sort(rng.choice(n, max(n // 20, 1), replace=False)).astype(np.uint64)
                 p2 = pos[i2.astype(int)]
