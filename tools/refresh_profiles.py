@@ -29,3 +29,11 @@ print(round(d["value"], 1), round(d["ms_per_step"], 3), d["kernel_ms_per_frame"]
 for r in csv.DictReader(open(f"{P}/{TAG}_bench_kernel_stats.csv")):
     if "pair_kernel" in r["Name"]:
         print(r["Name"][:40], r["Calls"], float(r["AverageNs"]) / 1e6, "ms")
+try:
+    shutil.copy(newest(f"{R}/rdf_stats/**/*kernel_stats.csv"), f"{P}/{TAG}_rdf_kernel_stats.csv")
+    line = [l for l in open(f"{R}/rdf_bench.json").read().splitlines() if l.startswith("{")][-1]
+    open(f"{P}/{TAG}_rdf_bench.json", "w").write(line + "\n")
+    dr = json.loads(line)
+    print("rdf", round(dr["value"], 1), "frames/s", dr["kernel_ms_per_frame"])
+except Exception as exc:
+    print("no rdf profile:", exc)
