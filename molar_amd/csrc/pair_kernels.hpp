@@ -1160,6 +1160,23 @@ __device__ __forceinline__ void hist_add(const HistFifo &F, float d2) {
     if (fb >= 0.0f && fb < F.hn) atomicAdd(&F.hist[(uint32_t)fb], 1u);
 }
 
+#ifndef HK_PLAIN_CAP
+#define HK_PLAIN_CAP 256
+#endif
+constexpr uint32_t HIST_PLAIN_CAP = HK_PLAIN_CAP;    // d2 queue of the plain path; the wrapped path uses the first FIFO_CAP words
+
+// plain queue: `count` <= 128 entries, two per lane (two independent sqrt / divide / atomic chains in flight)
+__device__ __forceinline__ void hist_flush_plain(HistFifo &F, uint32_t count, uint32_t lane) {
+    const uint32_t s0 = (F.head + lane) & (HIST_PLAIN_CAP - 1), s1 = (F.head + 64u + lane) & (HIST_PLAIN_CAP - 1);
+    const bool a0 = lane < count, a1 = lane + 64u < count;
+    float d0 = 0.f, d1 = 0.f;
+    if (a0) d0 = __uint_as_float(F.fd[s0]);
+    if (a1) d1 = __uint_as_float(F.fd[s1]);
+    if (a0) hist_add(F, d0);
+    if (a1) hist_add(F, d1);
+    F.head += count;
+}
+
 template <bool WRAPPED>
 __device__ __forceinline__ void hist_flush(const SearchParams &P, HistFifo &F, uint32_t count, uint32_t lane, uint32_t wrap) {
     if (lane < count) {
@@ -1212,6 +1229,10 @@ __device__ __forceinline__ uint32_t run_hist_sorted(const SearchParams &P, const
         const uint32_t r = (uint32_t)__builtin_ctzll(live);
         live &= ~(1ull << r);
         const float4 p = lload4(la, r);              // one broadcast ds_read per row
+        // wait for the row here, once: the chunk bodies sit behind branches, and at their merge points the compiler
+        // would otherwise place `s_waitcnt lgkmcnt(0)` in front of every chunk - which also waits for the LDS write of
+        // the previous chunk's queue push
+        asm volatile("" ::"v"(p.x), "v"(p.y), "v"(p.z));
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             if (!((livek[k] >> r) & 1ull)) continue;                              // wave-uniform: scalar branch
@@ -1224,15 +1245,15 @@ __device__ __forceinline__ uint32_t run_hist_sorted(const SearchParams &P, const
                 const uint32_t cnt = (uint32_t)__popcll(mask);
                 if (hit) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    const uint32_t off = ((rank + F.tail) << 2) & ((FIFO_CAP - 1u) << 2);
+                    const uint32_t off = ((rank + F.tail) << 2) & ((HIST_PLAIN_CAP - 1u) << 2);
                     typedef __attribute__((address_space(3))) uint32_t lds_u32;
                     *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fd + off) = __float_as_uint(d2);
                 }
                 F.tail += cnt;
                 total += cnt;
-                if (F.tail - F.head >= 64u) {
+                if (F.tail - F.head >= HIST_PLAIN_CAP / 2u) {
                     __builtin_amdgcn_wave_barrier();
-                    hist_flush<false>(P, F, 64u, lane, 0u);
+                    hist_flush_plain(F, HIST_PLAIN_CAP / 2u, lane);
                 }
             }
         }
@@ -1325,7 +1346,7 @@ constexpr int HIST_WAVES = HK_HIST_WAVES;      // waves per workgroup of hist_ke
 template <int KIND>
 __global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(HK_LEAN_WPE)))
 hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ slot_desc, uint32_t nslots) {
-    __shared__ uint32_t lds_fd[HIST_WAVES][FIFO_CAP];
+    __shared__ uint32_t lds_fd[HIST_WAVES][HIST_PLAIN_CAP > FIFO_CAP ? HIST_PLAIN_CAP : FIFO_CAP];
     __shared__ float4 lds_a[HIST_WAVES][64];
     __shared__ float4 lds_q[HIST_WAVES][FIFO_CAP];
     __shared__ uint32_t lds_next;
@@ -1387,7 +1408,7 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         if (P.use_box && T.wrap != 0u) {
             if (F.tail != F.head) {        // plain hits still queued: out before entries of another kind go in
                 __builtin_amdgcn_wave_barrier();
-                hist_flush<false>(P, F, F.tail - F.head, lane, 0u);
+                hist_flush_plain(F, F.tail - F.head, lane);       // < HIST_PLAIN_CAP / 2 <= 128 entries
             }
             switch (nchunks) {
                 case 1: total = run_hist_wrapped<KIND, 1>(P, T, i0, F, lds_a[wave], lane); break;
@@ -1426,7 +1447,7 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
     }
     if (F.tail != F.head) {
         __builtin_amdgcn_wave_barrier();
-        hist_flush<false>(P, F, F.tail - F.head, lane, 0u);
+        hist_flush_plain(F, F.tail - F.head, lane);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += 64 * HIST_WAVES) {
