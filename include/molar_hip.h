@@ -205,6 +205,11 @@ int molar_hip_search_resident_end(molar_hip_ctx *ctx, int32_t ticket, uint64_t *
  * histogram kernel of the frame before: as for _begin, the inputs must be complete in memory at the call. */
 int molar_hip_search_histogram(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, float hmin,
                                float hmax, size_t nbins, uint64_t *bins, uint64_t *out_count);
+/* Host arithmetic, no GPU: the table the fused histogram bins with.  Histogram1D::add_one's bin (stats.rs:29-35) is a
+ * non-decreasing function of the squared distance; edges[b], b = 0..nbins (nbins + 1 floats), is the smallest
+ * non-negative float d2 whose bin floor(n*(sqrt(d2)-min)/(max-min)) is >= b, found by bisection with the formula
+ * itself, so "largest b with edges[b] <= d2" IS the formula.  INVALID_ARGUMENT unless min < max, both finite. */
+int molar_hip_histogram_edges(float hmin, float hmax, size_t nbins, float *edges);
 
 /* ------------------------------------------------------------------ Measure (measure.rs) */
 

@@ -668,6 +668,14 @@ def new_membrane_state(head_markers, normals, valid=None, npatch_entries=0):
         fitted_patch_points=np.zeros((max(npatch_entries, 1), 3), np.float32))
 
 
+def histogram_edges(hmin, hmax, nbins):
+    """Exact bin edges of Histogram1D::add_one (molar_membrane/src/stats.rs:29-35) over the SQUARED distance: float32
+    [nbins + 1], edges[b] = the smallest d2 >= 0 whose bin is >= b (host arithmetic of the engine, no GPU)."""
+    e = np.zeros(nbins + 1, np.float32)
+    check(_lib.load().molar_hip_histogram_edges(float(hmin), float(hmax), int(nbins), e.ctypes.data))
+    return e
+
+
 def membrane_patches_from_pairs(pairs, nlipids):
     """compute_patches' list building (molar_membrane/src/lib.rs:548-557): CSR (offsets, ids) in push order."""
     pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)

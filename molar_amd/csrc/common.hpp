@@ -170,6 +170,9 @@ struct molar_hip_ctx {
     mh::DevBuf out_ids;
     mh::DevBuf wide_i, wide_j; // usize widening
     mh::DevBuf hist;           // u64 bins
+    mh::DevBuf hist_edges;     // f32[nbins + 1]: smallest d2 that reaches each bin (hist_kernel), for the cached (min, max, nbins)
+    float edges_min = 0.f, edges_max = 0.f;
+    size_t edges_nbins = 0;    // 0: no table cached
     mh::DevBuf task_mu;        // u32 per task (+1): 64-word hit-history units of the task's slots
     mh::DevBuf task_moff;      // u64 per task (+1): exclusive scan of task_mu
     mh::DevBuf maskbuf;        // hit bits recorded by the count pass, replayed by the fill pass

@@ -81,6 +81,8 @@ struct SearchParams {
     uint32_t hist_nbins;     // != 0: the fill traversal feeds a histogram instead of writing pairs
     float hist_min, hist_max;
     unsigned long long *hist_bins;    // [nbins] + [1] total
+    const float *hist_edges; // f32[nbins + 1], see histogram_edges() in search.hip; NULL: hist_kernel evaluates the formula per hit
+    float hist_scale;        // nbins / (max - min), for the first guess of the bin
     uint32_t hist_lean;      // histogram mode: hist_kernel takes the slots hist_lean_slot() accepts, pair_kernel<MODE_HIST> the rest
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     uint32_t debug_skip;     // profiling aid (env MOLAR_HIP_DEBUG_SKIP): bit0 plain, bit1 wrapped, bit2 triangular slots do nothing
@@ -1144,16 +1146,34 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
 // stays with pair_kernel<KIND, MODE_HIST>, which skips the slots accepted here (SearchParams::hist_lean).
 // 64 VGPRs, 8 waves per SIMD; pair_kernel<MODE_HIST> carries every generic path and needs 108 (4 waves).
 struct HistFifo {
-    uint32_t *fd;        // LDS, FIFO_CAP words: d2 (plain) or the row (wrapped)
-    float4 *fq;          // LDS, FIFO_CAP: unshifted second atom of a wrapped hit
+    uint32_t *fd;        // LDS: d2 queue of the plain path (HIST_PLAIN_CAP words, the same memory as fq)
+    float4 *fq;          // LDS, FIFO_CAP: {unshifted second atom, row} of a wrapped hit
     const float4 *la;    // the slot's first-cell atoms in LDS
     uint32_t head, tail; // wave-uniform
     uint32_t *hist;      // workgroup histogram in LDS
-    float hmin, hmax, hn;
+    const float *edges;  // LDS copy of SearchParams::hist_edges, or NULL
+    float hmin, hmax, hn, scale;
 };
 
 // Histogram1D::add_one (stats.rs:29-35) on d = sqrt(d2):  b = (n as Float * (val - min) / (max - min)).floor() as isize
+// The bin is a non-decreasing function of d2 (correctly rounded sqrt, subtraction of and multiplication / division by
+// constants, floor), so it is fully described by the smallest d2 that reaches each bin: edges[b], b = 0..n, computed
+// on the host with the formula itself (histogram_edges()).  A cheap estimate of the bin (v_sqrt_f32, one multiply) is at
+// most one bin off and is corrected with two comparisons against the exact edges.
 __device__ __forceinline__ void hist_add(const HistFifo &F, float d2) {
+    if (F.edges) {
+        typedef __attribute__((address_space(3))) float lds_f32;
+        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+        float est = (__builtin_amdgcn_sqrtf(d2) - F.hmin) * F.scale;
+        est = __builtin_fminf(__builtin_fmaxf(est, 0.0f), F.hn - 1.0f);      // also sends a NaN to 0
+        const int n = (int)F.hn;
+        int b = (int)est;
+        const lds_f32 *e = (const lds_f32 *)F.edges;
+        const float e0 = e[b], e1 = e[b + 1];
+        b += (d2 >= e1 ? 1 : 0) - (d2 < e0 ? 1 : 0);
+        if ((uint32_t)b < (uint32_t)n) atomicAdd(&F.hist[b], 1u);
+        return;
+    }
     const float d = __builtin_sqrtf(d2);
     float fb = __builtin_floorf(F.hn * (d - F.hmin) / (F.hmax - F.hmin));
     if (fb != fb) fb = 0.0f;                                    // NaN as isize == 0
@@ -1183,8 +1203,8 @@ __device__ __forceinline__ void hist_flush(const SearchParams &P, HistFifo &F, u
         const uint32_t s = (F.head + lane) & (FIFO_CAP - 1);
         float d2;
         if (WRAPPED) {
-            const float4 a = lload4(F.la, F.fd[s]);
-            const float4 b = lload4(F.fq, s);
+            const float4 b = lload4(F.fq, s);                      // {x, y, z, row}
+            const float4 a = lload4(F.la, __float_as_uint(b.w));
             d2 = wrapped_d2_exact(P, wrap, b.x - a.x, b.y - a.y, b.z - a.z);     // p2 - p1 (:485-486)
         } else {
             d2 = __uint_as_float(F.fd[s]);
@@ -1316,8 +1336,7 @@ __device__ __forceinline__ uint32_t run_hist_wrapped(const SearchParams &P, cons
                 if (hit) {
                     const uint32_t s = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, F.tail)) &
                                        (FIFO_CAP - 1);
-                    F.fq[s] = make_float4(bx[k], by[k], bz[k], 0.f);
-                    F.fd[s] = r;
+                    F.fq[s] = make_float4(bx[k], by[k], bz[k], __uint_as_float(r));
                 }
                 F.tail += cnt;
                 total += cnt;
@@ -1346,19 +1365,24 @@ constexpr int HIST_WAVES = HK_HIST_WAVES;      // waves per workgroup of hist_ke
 template <int KIND>
 __global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(HK_LEAN_WPE)))
 hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ slot_desc, uint32_t nslots) {
-    __shared__ uint32_t lds_fd[HIST_WAVES][HIST_PLAIN_CAP > FIFO_CAP ? HIST_PLAIN_CAP : FIFO_CAP];
+    static_assert(HIST_PLAIN_CAP * 4 <= FIFO_CAP * 16, "the d2 queue of the plain path lives inside the wrapped path's queue");
     __shared__ float4 lds_a[HIST_WAVES][64];
-    __shared__ float4 lds_q[HIST_WAVES][FIFO_CAP];
+    __shared__ float4 lds_q[HIST_WAVES][FIFO_CAP];      // wrapped path: {x, y, z, row} per hit; plain path: d2 words in the same memory
     __shared__ uint32_t lds_next;
     extern __shared__ uint32_t lds_hist[];
     const SearchParams &P = *Pp;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += 64 * HIST_WAVES) lds_hist[b] = 0u;
+    float *lds_edges = reinterpret_cast<float *>(lds_hist + P.hist_nbins);       // nbins + 1 floats behind the counters
+    if (P.hist_edges)
+        for (uint32_t b = threadIdx.x; b <= P.hist_nbins; b += 64 * HIST_WAVES) lds_edges[b] = P.hist_edges[b];
     if (threadIdx.x == 0) lds_next = 0u;
     __syncthreads();
     HistFifo F;
-    F.fd = lds_fd[wave];
+    F.edges = P.hist_edges ? lds_edges : nullptr;
+    F.scale = P.hist_scale;
+    F.fd = reinterpret_cast<uint32_t *>(lds_q[wave]);
     F.fq = lds_q[wave];
     F.la = lds_a[wave];
     F.head = F.tail = 0u;
@@ -1461,7 +1485,7 @@ template <int KIND>
 inline void launch_hist_kernel(unsigned num_cus, size_t dyn_lds, hipStream_t stream, const SearchParams *dP,
                                const SlotDesc *slot_desc, uint32_t nslots) {
     // persistent workgroups: 32 waves per CU (8 per SIMD)
-    hipLaunchKernelGGL((hist_kernel<KIND>), dim3(num_cus * (32 / HIST_WAVES)), dim3(64 * HIST_WAVES), dyn_lds, stream, dP, slot_desc, nslots);
+    hipLaunchKernelGGL((hist_kernel<KIND>), dim3(num_cus * (32 / HIST_WAVES)), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots);   // counters, then the nbins + 1 bin edges
 }
 
 

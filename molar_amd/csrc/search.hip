@@ -790,6 +790,8 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     P.hist_bins = hist_bins;
     size_t dyn_lds = 0;
     P.hist_lean = 0u;
+    P.hist_edges = nullptr;
+    P.hist_scale = 0.f;
     if (hist_nbins) {
         dyn_lds = (size_t)hist_nbins * 4;
         const uint32_t wpb = (uint32_t)waves_per_block(MODE_HIST);
@@ -799,6 +801,10 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
         // plain, same-cell and band-classified wrapped slots go to the lean kernel (8 waves per SIMD), the rest to
         // pair_kernel<MODE_HIST>; both add into the same bins
         P.hist_lean = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
+        if (P.hist_lean && c->edges_nbins == hist_nbins && c->edges_min == hmin && c->edges_max == hmax) {
+            P.hist_edges = c->hist_edges.as<float>();
+            P.hist_scale = (float)hist_nbins / (hmax - hmin);
+        }
     }
     MH_TRY(c->params.reserve(sizeof(SearchParams)));
     // params_resident: the block uploaded for the previous pass of this search is still valid for this one
@@ -820,6 +826,57 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
         default: launch_pair_vdw(mode, P.nblocks, dyn_lds, c->stream, dP, tf, st, sc, sb, pairs, dist, ids); break;
     }
     MH_HIP(hipGetLastError());
+    return 0;
+}
+
+// Exact bin edges of Histogram1D::add_one (molar_membrane/src/stats.rs:29-35) in terms of the SQUARED distance:
+// edges[b], b = 0..nbins, is the smallest non-negative float x with floor(n * (sqrt(x) - min) / (max - min)) >= b, found
+// by bisection over the bit patterns of the non-negative floats with the formula itself (IEEE sqrt / divide, no
+// contraction - the same operations the kernels and the reference perform).  The bin of x is then the largest b with
+// edges[b] <= x.  Returns false when the formula is not monotone-finite (max <= min, non-finite bounds): callers then
+// evaluate the formula per value.
+bool histogram_edges(float hmin, float hmax, size_t nbins, float *edges) {
+    if (!(hmax > hmin) || !std::isfinite(hmin) || !std::isfinite(hmax) || nbins == 0) return false;
+    const float hn = (float)nbins, range = hmax - hmin;
+    auto bin_of = [&](uint32_t bits) -> float {
+        float x;
+        std::memcpy(&x, &bits, 4);
+        volatile float d = std::sqrt(x);
+        volatile float t = d - hmin;
+        volatile float u = hn * t;
+        volatile float v = u / range;
+        return std::floor(v);
+    };
+    for (size_t b = 0; b <= nbins; ++b) {
+        uint32_t lo = 0u, hi = 0x7F800000u;        // +0.0 .. +inf; bin_of(+inf) = +inf >= b
+        if (bin_of(lo) >= (float)b) {
+            hi = lo;
+        } else {
+            while (hi - lo > 1u) {                 // invariant: bin_of(lo) < b <= bin_of(hi)
+                const uint32_t mid = lo + (hi - lo) / 2u;
+                if (bin_of(mid) >= (float)b) hi = mid;
+                else lo = mid;
+            }
+        }
+        std::memcpy(&edges[b], &hi, 4);
+    }
+    return true;
+}
+
+int ensure_hist_edges(molar_hip_ctx *c, float hmin, float hmax, size_t nbins) {
+    if (c->edges_nbins == nbins && c->edges_min == hmin && c->edges_max == hmax) return 0;
+    c->edges_nbins = 0;
+    std::vector<float> e(nbins + 1);
+    if (!histogram_edges(hmin, hmax, nbins, e.data())) return 0;      // formula path
+    MH_TRY(c->hist_edges.reserve((nbins + 1) * 4));
+    MH_TRY(ensure_pinned(c, (nbins + 1) * 4));
+    MH_HIP(hipStreamSynchronize(c->stream));       // a kernel of an earlier call may still read the old table / the staging area
+    std::memcpy(c->h_pinned, e.data(), (nbins + 1) * 4);
+    MH_HIP(hipMemcpyAsync(c->hist_edges.p, c->h_pinned, (nbins + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    c->edges_min = hmin;
+    c->edges_max = hmax;
+    c->edges_nbins = nbins;
     return 0;
 }
 
@@ -1323,6 +1380,13 @@ int molar_hip_search_fill_ids(molar_hip_ctx *c, uint64_t *ids) {
     return MOLAR_HIP_OK;
 }
 
+int molar_hip_histogram_edges(float hmin, float hmax, size_t nbins, float *edges) {
+    if (!edges) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "histogram_edges: null argument");
+    if (!histogram_edges(hmin, hmax, nbins, edges))
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "histogram_edges: needs finite min < max and nbins > 0");
+    return MOLAR_HIP_OK;
+}
+
 int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q, float hmin, float hmax, size_t nbins,
                                uint64_t *bins, uint64_t *out_count) {
     if (!c || !q || !bins) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_histogram: null argument");
@@ -1348,6 +1412,7 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
     if (out_count) *out_count = 0;
     if (c->have_search) return MOLAR_HIP_OK;     // degenerate (empty vdw input)
     // single pass: no counts, no offsets - every emitted distance goes straight into the histogram
+    MH_TRY(ensure_hist_edges(c, hmin, hmax, nbins));
     MH_TRY(c->hist.reserve((nbins + 1) * 8));
     hipLaunchKernelGGL(zero2_kernel, dim3(1), dim3(256), 0, c->stream, c->hist.as<uint32_t>(), (nbins + 1) * 2, (uint32_t *)nullptr,
                        (size_t)0);

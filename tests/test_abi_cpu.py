@@ -92,6 +92,42 @@ def test_box_errors(lib):
     assert e.value.code == 10
 
 
+@pytest.mark.parametrize("hmin,hmax,nbins", [(0.0, 1.2, 1200), (0.35, 0.9, 450), (-0.2, 0.7, 350), (0.0, 0.6, 1), (0.1, 2.5, 8192)])
+def test_histogram_edges_are_the_formula(lib, orc32, hmin, hmax, nbins):
+    """The table the fused histogram bins with (molar_hip_histogram_edges) against Histogram1D::add_one
+    (stats.rs:29-35): at every edge the distance d = sqrt(edge) falls into a bin >= b, at the float just below it into a
+    bin < b; random squared distances bin identically through the table and through the oracle."""
+    from molar_amd import api
+    e = api.histogram_edges(hmin, hmax, nbins)
+    assert e.shape == (nbins + 1,) and np.all(np.diff(e) >= 0) and e[0] >= 0
+
+    def formula(d2):         # numpy float32 arithmetic is IEEE like the oracle's C (cross-checked against it below)
+        d = np.sqrt(np.asarray(d2, np.float32)).astype(np.float32)
+        return np.floor(np.float32(nbins) * (d - np.float32(hmin)) / (np.float32(hmax) - np.float32(hmin)))
+    rng = np.random.default_rng(3)
+    x = (rng.uniform(0, 1.1 * max(hmax, 0.1), 20000).astype(np.float32)) ** 2
+    want = orc32.histogram_add(hmin, hmax, nbins, np.sqrt(x)).astype(np.int64)
+    fb = formula(x)
+    ok = (fb >= 0) & (fb < nbins)
+    assert np.array_equal(np.bincount(fb[ok].astype(np.int64), minlength=nbins), want)
+    tb = np.searchsorted(e, x, side="right") - 1          # largest b with e[b] <= x
+    assert np.array_equal(tb[ok], fb[ok].astype(np.int64))
+    assert np.all((tb[~ok] < 0) | (tb[~ok] >= nbins))
+    # every edge is tight
+    assert np.all(formula(e) >= np.arange(nbins + 1))
+    pos = e > 0
+    below = np.nextafter(e[pos], np.float32(-1.0), dtype=np.float32)
+    assert np.all(formula(below) < np.arange(nbins + 1)[pos])
+
+
+def test_histogram_edges_rejects_degenerate_ranges(lib):
+    from molar_amd import api
+    from molar_amd._lib import MolarHipError
+    for lo, hi in ((1.0, 1.0), (2.0, 1.0), (0.0, float("inf")), (float("nan"), 1.0)):
+        with pytest.raises(MolarHipError):
+            api.histogram_edges(lo, hi, 10)
+
+
 def test_fails_loudly_without_gpu(lib):
     import torch
     if torch.cuda.is_available():
