@@ -63,9 +63,6 @@ struct SearchParams {
     const float4 *aabb_b;    // per-cell bounding boxes of set 2 (== set 1 for SINGLE)
     const float4 *perm_b;    // set 2: atoms in Morton order inside each cell, {x,y,z,position in the cell} (cells of <= 512 atoms), see place_order_kernel
     const float4 *chunk_aabb_b;   // set 2: bounding boxes of the 64-atom Morton chunks, slot (cell_start >> 6) + cell + k
-    const uint4 *h16_b;      // set 2, Morton order like perm_b: 8 x f16 {hi xyz, lo xyz, |.|^2 hi, lo} relative to the cell origin
-    const float4 *cell_org_b; // set 2: per cell {origin, bound on |position - origin|}
-    uint32_t mfma_count;     // count pass of plain / same-cell entries on the matrix cores (run_count_mfma)
     const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
     uint32_t *maskbuf;       // fast-path slots: hit bits found by the count pass, replayed by the fill pass
     const unsigned long long *task_moff;   // per task: first 64-word unit of its slots in maskbuf (a slot owns 2*nch units)
@@ -285,7 +282,6 @@ struct Fifo {
     const float4 *la;           // the slot's first-cell atoms in LDS
     float4 *fq_store;           // LDS backing of fq (fill kernels)
     float4 *fq;                 // replay mode: FIFO of the hits' second atoms {x,y,z,id}; fd then holds the row
-    uint4 *lh;                  // count pass: LDS staging of the slot's matrix-core row records (128 x 16 B), or NULL
     uint32_t wrap;
 };
 
@@ -637,149 +633,6 @@ __device__ __forceinline__ uint32_t run_count_sorted(const SearchParams &P, cons
     return acc;
 }
 
-// ================================================================= count pass on the matrix cores
-// Count pass of plain and same-cell entries.  |p2 - p1|^2 - cutoff^2 of a 32 x 32 block of (row, atom) pairs is ONE
-// v_mfma_f32_32x32x16_f16: with both positions taken relative to the second cell's origin O and split into f16 hi + lo
-// parts (22 significant bits),
-//     |b - a|^2 - c = sum_k A[row][k] * B[k][col],
-//     A = (-2 ah, -2 ah, |a|^2 - c (hi, lo) | -2 al, -2 al, 1, 1),   B = (bh, bl, 1, 1 | bh, bl, |b|^2 (hi, lo))
-// (f16 products are exact in the f32 accumulator).  The B records are prepared once per frame by place_order_kernel in
-// the spatial order of the count pass; the A records of the slot's 64 rows are built in the prologue and redistributed
-// through LDS.  Only the DECISION d2 <= cutoff^2 has to equal the reference's f32 evaluation: the sign of an accumulator
-// decides when its magnitude exceeds E, a bound on every difference between the two evaluations -
-//     positions relative to O in f32 and their 22-bit split     2.6 * 2^-22 * R^2     (R = Ra + Rb, bounds on |a - O|, |b - O|)
-//     the squared norms in f32 and their split                  2^-22 * (2 R^2 + 2 c)
-//     16 f32 additions of partial sums <= R^2 + c              4 * 2^-22 * (R^2 + c)
-//     the reference's own three roundings                      0.75 * 2^-22 * R^2
-// so E = 2^-22 * (12 R^2 + 8 c) holds with room to spare (R from the data: Ra is reduced over the slot's rows, Rb comes
-// with the cell).  A block with an accumulator inside (-E, E) is recounted with the exact f32 formula (2-3 % of the
-// blocks); slots whose bound is not small against c, or not finite, are left to run_count_sorted.  Per block:
-// 16 v_alignbit (sign bits), 8 v_min3 (magnitudes), a popcount - 28 VALU instructions for 1024 candidates instead of 160.
-typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
-typedef float v16f_t __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b) {
-    return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
-}
-
-#ifndef HK_MFMA_BATCH
-#define HK_MFMA_BATCH 6
-#endif
-constexpr int MFMA_BATCH = HK_MFMA_BATCH;    // block columns (32 atoms) whose B records are requested together
-
-template <int KIND, bool TRI>
-__device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const Task &T, uint32_t i0, float4 *la, uint4 *lh,
-                                                   uint32_t lane, bool &done) {
-    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) u4_t lds_u4;
-    typedef __attribute__((address_space(1))) u4_t glb_u4;
-    const float cutoff2 = P.cutoff2;
-    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
-    const uint32_t kh = lane >> 5, cl = lane & 31u;
-    const uint32_t nct = (T.n2 + 31u) >> 5;
-    // B record (and, for same-cell entries, the reference position) of this lane's atom in block column ct
-    auto load_b = [&](uint32_t ct, u4_t &bq, uint32_t &bpos) {
-        const uint32_t col = ct * 32u + cl;
-        bq = u4_t{0u, 0u, 0u, 0x00007BFFu};                             // atom past the end: |b|^2 = 65504, never a hit
-        bpos = 0u;
-        if (col < T.n2) {
-            bq = ((const glb_u4 *)P.h16_b)[T.b0 + col];
-            if (TRI) bpos = gload_u32(reinterpret_cast<const uint32_t *>(P.perm_b), 4u * (size_t)(T.b0 + col) + 3u);
-        }
-    };
-    // everything the slot reads from memory is requested at once: its rows, the second cell's origin and the first
-    // batch of B records (a slot is a chain of memory latencies, not of arithmetic)
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
-    const float4 org = gload4(P.cell_org_b, T.cb);
-    // three block columns in flight
-    u4_t bq0, bq1, bq2;
-    uint32_t bp0, bp1, bp2;
-    load_b(0u, bq0, bp0);
-    load_b(1u, bq1, bp1);
-    load_b(2u, bq2, bp2);
-    la[lane] = a;                                   // f32 rows, for the exact decision inside the band
-    const float r0 = a.x - org.x, r1 = a.y - org.y, r2 = a.z - org.z;
-    float ra2 = lane < rows ? (r0 * r0 + r1 * r1) + r2 * r2 : 0.0f;
-    const bool fin = ra2 == ra2;
-    for (int off = 32; off > 0; off >>= 1) ra2 = fmaxf(ra2, __shfl_xor(ra2, off, 64));
-    const float R = 1.0001f * __builtin_sqrtf(ra2) + org.w;
-    const float E = 2.3841858e-07f * (12.0f * R * R + 8.0f * cutoff2);          // 2^-22 * (...)
-    if (__builtin_amdgcn_ballot_w64(!fin) != 0ull || !(R < 64.0f) || !(E < 0.02f * cutoff2)) {
-        done = false;                               // not finite / not small: the exact path takes the slot
-        return 0u;
-    }
-    {   // A records of this lane's row: k = 0..7 and k = 8..15
-        u4_t k0 = {0u, 0u, 0u, 0x00007BFFu}, k1 = {0u, 0u, 0u, 0x3C003C00u};      // row past the end: +65504
-        if (lane < rows) {
-            const _Float16 h0 = (_Float16)r0, h1 = (_Float16)r1, h2 = (_Float16)r2;
-            const _Float16 l0 = (_Float16)(r0 - (float)h0), l1 = (_Float16)(r1 - (float)h1), l2 = (_Float16)(r2 - (float)h2);
-            const float e0 = (float)h0 + (float)l0, e1 = (float)h1 + (float)l1, e2 = (float)h2 + (float)l2;
-            const float na = ((e0 * e0 + e1 * e1) + e2 * e2) - cutoff2;
-            const _Float16 nh = (_Float16)na, nl = (_Float16)(na - (float)nh);
-            const _Float16 m2 = (_Float16)-2.0f;
-            const _Float16 g0 = m2 * h0, g1 = m2 * h1, g2 = m2 * h2, s0 = m2 * l0, s1 = m2 * l1, s2 = m2 * l2;
-            k0 = u4_t{pack_h2(g0, g1), pack_h2(g2, g0), pack_h2(g1, g2), pack_h2(nh, nl)};
-            k1 = u4_t{pack_h2(s0, s1), pack_h2(s2, s0), pack_h2(s1, s2), 0x3C003C00u};
-        }
-        ((lds_u4 *)lh)[2u * lane] = k0;
-        ((lds_u4 *)lh)[2u * lane + 1u] = k1;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const u4_t a0q = ((const lds_u4 *)lh)[2u * cl + kh], a1q = ((const lds_u4 *)lh)[2u * (32u + cl) + kh];
-    const v8h_t A0 = __builtin_bit_cast(v8h_t, a0q), A1 = __builtin_bit_cast(v8h_t, a1q);
-    uint32_t cnt = 0;
-    for (uint32_t ct = 0; ct < nct; ++ct) {
-        {
-            u4_t bt = bq0;
-            const uint32_t bpt = bp0;
-            bq0 = bq1; bp0 = bp1;
-            bq1 = bq2; bp1 = bp2;
-            load_b(ct + 3u, bq2, bp2);
-            const uint32_t col = ct * 32u + cl;
-            if (kh == 0u) bt.w = 0x3C003C00u;                           // k = 6, 7 of the first half: (1, 1)
-            const v8h_t B = __builtin_bit_cast(v8h_t, bt);
-            const int tv = (int)bpt - (int)(i0 + 4u * kh);          // same-cell entries: j > i  <=>  tv > row inside the block
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                v16f_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(rt == 0 ? A0 : A1, B, acc, 0, 0, 0);
-                // accumulator i of lane (kh, cl): row 32 rt + 8 (i / 4) + 4 kh + i % 4, atom `col`
-                float v[16];
-                float m = INFINITY;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    v[i] = acc[i];
-                    if (TRI) v[i] = (tv > 32 * rt + 8 * (i / 4) + (i % 4)) ? v[i] : 1.0e30f;
-                    m = __builtin_fminf(m, __builtin_fabsf(v[i]));
-                }
-                if (__builtin_amdgcn_ballot_w64(m < E) != 0ull) {
-                    // some accumulator of the block lies inside (-E, E): those candidates (and only those) are decided
-                    // with the exact f32 formula.  Padding and masked entries are far outside the band.
-                    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (col < T.n2) q = gload4(P.perm_b, T.b0 + col);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const bool amb = __builtin_fabsf(v[i]) < E;
-                        if (__builtin_amdgcn_ballot_w64(amb) != 0ull) {
-                            const float4 p = lload4(la, (uint32_t)(32 * rt + 8 * (i / 4) + (i % 4)) + 4u * kh);
-                            const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;     // p2 - p1
-                            const float d2 = (dx * dx + dy * dy) + dz * dz;                // |p2-p1|^2 (:446, :460)
-                            v[i] = amb ? (d2 <= cutoff2 ? -1.0f : 1.0f) : v[i];
-                        }
-                    }
-                }
-                uint32_t h = 0u;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) h = __builtin_amdgcn_alignbit(h, __float_as_uint(v[i]), 31);       // h = 2 h + sign
-                cnt += (uint32_t)__popc(h);
-            }
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-    return cnt;
-}
-
 template <int KIND, bool FILL, bool WRAPPED, int NCH, bool TRI, bool MASKED>
 __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                              uint32_t lane, uint32_t *mwords) {
@@ -1041,15 +894,6 @@ template <int KIND, bool FILL, int WK, bool MASKED>
 __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                                  uint32_t lane, uint32_t *mwords) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
-    if constexpr (!FILL && WK == WK_NONE && (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE)) {
-        // plain and same-cell entries: the count goes to the matrix cores unless the slot's error bound is too wide
-        if (P.mfma_count && F.lh && nchunks <= (uint32_t)KREG) {
-            bool done = true;
-            const uint32_t cm = (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) ? run_count_mfma<KIND, true>(P, T, i0, la, F.lh, lane, done)
-                                                                          : run_count_mfma<KIND, false>(P, T, i0, la, F.lh, lane, done);
-            if (done) return cm;
-        }
-    }
     if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && !T.tri && nchunks <= (uint32_t)KREG) {
         constexpr bool WR = WK != WK_NONE;
         switch (nchunks) {
@@ -1160,12 +1004,8 @@ __device__ __forceinline__ bool hist_lean_slot(const SearchParams &P, uint32_t f
     return P.approx_wrapped != 0u && !(P.box.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL);
 }
 
-#ifndef HK_COUNT_WPE
-#define HK_COUNT_WPE 8
-#endif
 template <int KIND, int MODE>
-__global__ void __launch_bounds__(64 * waves_per_block(MODE))
-__attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? HK_COUNT_WPE : 8)))) pair_kernel(const SearchParams *__restrict__ Pp,
+__global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : 8))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
                                                      const uint32_t nslots,      // the host's bound: slots past the real count are empty
                                                      uint32_t *__restrict__ slot_cnt,
@@ -1176,7 +1016,6 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
     __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
     __shared__ float4 lds_a[WAVES_PER_BLOCK][64];
     __shared__ float4 lds_q[MODE == MODE_FILL ? WAVES_PER_BLOCK : 1][MODE == MODE_FILL ? FIFO_CAP : 1];   // replayed hits' second atoms
-    __shared__ uint4 lds_h[MODE == MODE_COUNT ? WAVES_PER_BLOCK : 1][MODE == MODE_COUNT ? 128 : 1];       // matrix-core row records of the count pass
     constexpr bool FILL = MODE != MODE_COUNT;
     extern __shared__ uint32_t lds_hist[];     // histogram mode only (hist_nbins counters)
     // The parameter block lives in device memory: a by-value struct this large, indexed dynamically
@@ -1236,7 +1075,6 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         F.la = lds_a[wave];
         F.fq = nullptr;
         F.fq_store = MODE == MODE_FILL ? lds_q[wave] : nullptr;
-        F.lh = MODE == MODE_COUNT ? lds_h[wave] : nullptr;
         F.wrap = 0;
         F.hmin = P.hist_min;
         F.hmax = P.hist_max;
