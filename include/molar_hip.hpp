@@ -502,6 +502,54 @@ class PairPipeline {
     bool pending_ = false;
 };
 
+// Histogram1D (molar_membrane/src/stats.rs:13-55) with the engine's consumer-fused search as a feed: every distance
+// of a search stream goes through add_one's binning rule on the GPU without the pairs ever being written
+// (molar_hip_search_histogram - the shape of a radial distribution over a trajectory).  Counts are integers, so frames,
+// ranks and the host's add_one sum exactly; bins() gives them as the reference's Float counters (which stop growing
+// at 2^24 per bin - the integer counts do not).
+class Histogram1D {
+  public:
+    Histogram1D(Float min, Float max, usize n_bins) : min_(min), max_(max), counts_(n_bins, 0) {}   // stats.rs:20-27
+    void add_one(Float val) {                                                                        // stats.rs:29-35
+        const Float fb = std::floor(static_cast<Float>(counts_.size()) * (val - min_) / (max_ - min_));
+        if (fb != fb) { if (!counts_.empty()) counts_[0] += 1; return; }                             // NaN as isize == 0
+        if (fb >= 0 && fb < static_cast<Float>(counts_.size())) counts_[static_cast<size_t>(fb)] += 1;
+    }
+    // the distance stream of distance_search_single_pbc / _double_pbc (:892-954, :659-754), binned on the GPU
+    uint64_t add_distances_single_pbc(Float cutoff, const SelBound &data, const PeriodicBox &pbox, PbcDims pbc_dims) {
+        const molar_hip_search_desc d = detail::desc(MOLAR_HIP_SEARCH_SINGLE, cutoff, data, nullptr, false, &pbox, pbc_dims);
+        return feed(data.ctx(), d);
+    }
+    uint64_t add_distances_double_pbc(Float cutoff, const SelBound &d1, const SelBound &d2, const PeriodicBox &pbox,
+                                      PbcDims pbc_dims) {
+        const molar_hip_search_desc d = detail::desc(MOLAR_HIP_SEARCH_DOUBLE, cutoff, d1, &d2, false, &pbox, pbc_dims);
+        return feed(d1.ctx(), d);
+    }
+    const std::vector<uint64_t> &counts() const { return counts_; }
+    std::vector<Float> bins() const { return std::vector<Float>(counts_.begin(), counts_.end()); }
+    std::vector<Float> normalized_density() const {                                                  // stats.rs:37-43
+        const Float d = (max_ - min_) / static_cast<Float>(counts_.size());
+        Float sum = 0;
+        for (uint64_t c : counts_) sum += static_cast<Float>(c);
+        std::vector<Float> out(counts_.size());
+        for (size_t b = 0; b < out.size(); ++b) out[b] = static_cast<Float>(counts_[b]) / (sum * d);
+        return out;
+    }
+    Float bin_center(usize b) const {                                                                // stats.rs:45-55
+        const Float d = (max_ - min_) / static_cast<Float>(counts_.size());
+        return min_ + static_cast<Float>(b) * d + Float(0.5) * d;
+    }
+
+  private:
+    uint64_t feed(molar_hip_ctx *ctx, const molar_hip_search_desc &d) {
+        uint64_t n = 0;
+        check(molar_hip_search_histogram(ctx, &d, min_, max_, counts_.size(), counts_.data(), &n));
+        return n;
+    }
+    Float min_, max_;
+    std::vector<uint64_t> counts_;
+};
+
 // ids: the reference takes an iterator; the two uses are the selection's own indices
 // (sel.iter_index(), ids_local = false) and 0..n (modify.rs:78, ids_local = true).
 template <class T>

@@ -71,6 +71,26 @@ static void search_tests() {
         for (size_t k = 0; same && k < ref->n; ++k)
             same = std::get<0>(got[k]) == ref->i[k] && std::get<1>(got[k]) == ref->j[k] && std::get<2>(got[k]) == ref->d[k];
         EXPECT(same);
+        // Histogram1D fed by the fused search = add_one over the reference's distance stream (stats.rs:29-35)
+        {
+            Histogram1D h(0.05f, 0.6f, 220), hh(0.05f, 0.6f, 220);
+            const uint64_t nd = h.add_distances_single_pbc(0.6f, all, pb, PBC_FULL);
+            std::vector<float> want(220, 0.0f);
+            orc_histogram_add(0.05f, 0.6f, 220, ref->d, ref->n, want.data());
+            bool hs = nd == ref->n;
+            for (size_t b = 0; hs && b < 220; ++b) hs = (float)h.counts()[b] == want[b];
+            EXPECT(hs);
+            for (size_t k = 0; k < ref->n; ++k) hh.add_one(ref->d[k]);
+            EXPECT(hh.counts() == h.counts());
+            h.add_distances_single_pbc(0.6f, all, pb, PBC_FULL);              // a second frame adds into the same bins
+            bool twice = true;
+            for (size_t b = 0; b < 220; ++b) twice = twice && h.counts()[b] == 2 * hh.counts()[b];
+            EXPECT(twice);
+            const auto dens = h.normalized_density();
+            double integral = 0;
+            for (size_t b = 0; b < 220; ++b) integral += dens[b] * (0.55 / 220);
+            EXPECT(std::fabs(integral - 1.0) < 1e-4);
+        }
         orc_pairs_free(ref);
         // (usize,usize) projection and local ids (modify.rs:78)
         auto pr = distance_search_single_pbc<std::pair<usize, usize>>(0.6f, s_ev, pb, PBC_FULL, true);
