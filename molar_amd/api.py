@@ -481,14 +481,18 @@ class Engine:
         """Same as lipid_tail_order with the CSR arrays prepared by the caller (no per-call Python loops)."""
         xyz = _f32(xyz)
         xa, kx = _addr(xyz)
-        idx = _u64(idx); tail_offsets = _u64(tail_offsets); normal_offsets = _u64(normal_offsets)
-        normals = np.ascontiguousarray(normals, np.float32); bond_orders = np.ascontiguousarray(bond_orders, np.uint8)
+        idx = _u64(idx); tail_offsets = np.ascontiguousarray(tail_offsets, np.uint64)
+        normal_offsets = np.ascontiguousarray(normal_offsets, np.uint64)
+        normals = np.ascontiguousarray(normals, np.float32)
+        if not _is_torch(bond_orders):                      # idx and bond_orders may live on the GPU (torch int64 / uint8)
+            bond_orders = np.ascontiguousarray(bond_orders, np.uint8)
+        ia, ki = _addr(idx); ba, kb = _addr(bond_orders)
         K = len(tail_offsets) - 1
         nout = int(tail_offsets[-1]) - 2 * K
         out = np.zeros(max(nout, 1), np.float32)
-        check(self.lib.molar_hip_lipid_tail_order(self.ctx, xa, xyz.shape[0], idx.ctypes.data, tail_offsets.ctypes.data, K,
+        check(self.lib.molar_hip_lipid_tail_order(self.ctx, xa, xyz.shape[0], ia, tail_offsets.ctypes.data, K,
                                                   int(order_type), normals.ctypes.data, normal_offsets.ctypes.data,
-                                                  bond_orders.ctypes.data, out.ctypes.data))
+                                                  ba, out.ctypes.data))
         return out[:nout]
 
     def copy_bandwidth(self, nbytes=1 << 30, reps=10) -> float:

@@ -185,15 +185,29 @@ class Membrane:
         R.sum_duplicates(); R.sort_indices()
         return R
 
+    def _constants(self, xyz):
+        """The per-trajectory index / mass columns: with frames resident on the GPU they are uploaded once and stay
+        there (the C ABI takes device pointers); with host frames they are the numpy arrays."""
+        if not api._is_torch(xyz):
+            return dict(lipid_idx=self.lipid_idx, marker_idx=self.marker_idx, masses=self.masses, tail_idx=self.tail_idx,
+                        tail_bonds=self.tail_bonds)
+        if getattr(self, "_dev", None) is None or self._dev["device"] != xyz.device:
+            import torch
+            up = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(xyz.device)
+            self._dev = dict(device=xyz.device, lipid_idx=up(self.lipid_idx), marker_idx=up(self.marker_idx),
+                             masses=up(self.masses), tail_idx=up(self.tail_idx), tail_bonds=up(self.tail_bonds))
+        return self._dev
+
     def compute(self, xyz, box):
         """One frame (Membrane::compute, lib.rs:410-454).  xyz: float32 [N,3] (numpy; unwrapped in place when
         options.unwrap).  Returns a dict: markers, patch CSR, per-lipid state (valid, normals, curvatures, area,
         Voronoi neighbours/vertices) and order: list over tails of [K, n_t-2]."""
         e, K, opt = self.eng, self.K, self.opt
         pb = box if isinstance(box, api.PeriodicBox) else api.PeriodicBox.from_matrix(box)
+        cst = self._constants(xyz)
         if opt.unwrap:                                                          # lipid_molecule.rs:75-76
-            e.unwrap_simple_batch(xyz, self.lipid_idx, self.lipid_off, pb)
-        mk = e.center_batch(xyz, self.marker_idx, self.marker_off, self.masses).reshape(K, 3, 3)
+            e.unwrap_simple_batch(xyz, cst["lipid_idx"], self.lipid_off, pb)
+        mk = e.center_batch(xyz, cst["marker_idx"], self.marker_off, cst["masses"]).reshape(K, 3, 3)
         head, mid, tail = mk[:, 0].copy(), mk[:, 1].copy(), mk[:, 2].copy()
         # compute_patches (lib.rs:539-558): search among the valid lipids' head markers, ids = lipid ids
         vidx = np.flatnonzero(self.valid).astype(np.uint64)
@@ -225,7 +239,7 @@ class Membrane:
         nl = st["normals"] if opt.global_normal is None else np.tile(np.asarray(opt.global_normal, np.float32), (K, 1))
         nrm = np.repeat(nl, self.ntails, axis=0)
         noff = np.arange(K * self.ntails + 1, dtype=np.uint64)
-        flat = e.lipid_tail_order_csr(xyz, self.tail_idx, self.tail_off, opt.order_type, nrm, noff, self.tail_bonds)
+        flat = e.lipid_tail_order_csr(xyz, cst["tail_idx"], self.tail_off, opt.order_type, nrm, noff, cst["tail_bonds"])
         per_lipid = sum(l - 2 for l in self.tail_lens)
         flat = flat.reshape(K, per_lipid)
         out, pos = [], 0
