@@ -214,6 +214,14 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
             check = bool(np.array_equal(chk.cpu().numpy(), total_bins))
         pairs = float(total_bins.sum())
         hist_ms, hist_n = prof["pair_fill"]
+        # algorithmic work of one frame: the plan's candidate evaluations, 13.5 * N * mean cell
+        # population (13 neighbour cells in full, the own cell as a triangle), 9 flop each; the kernels skip part of
+        # them by bounding boxes, the reference evaluates all
+        ext = np.asarray(box, np.float32).sum(axis=1)              # get_lab_extents: row sums (periodic_box.rs:369-375)
+        gd = np.maximum(np.floor(ext / np.float32(CUTOFF)), 1).astype(np.int64)     # Grid::from_cutoff_and_extents (:103-110)
+        ncell = max(int(gd[0]) * int(gd[1]) * int(gd[2]), 1)
+        cand = 13.5 * n * (n / ncell)
+        valu_peak = 157.3
         print(json.dumps({
             "metric": "frames/sec, 250k-atom frames -> fused 1200-bin radial distance histogram, bins reduced over ranks",
             "value": K * world / t, "unit": "frames/s", "pairs_binned_per_sec": pairs / t,
@@ -224,9 +232,13 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
                                    "of 1200 x int64", "natoms": n, "nbins": nbins, "frames_per_gpu": K,
                        "pairs_per_frame": pairs / (K * world)},
             "kernel_ms_per_frame": {k: v[0] / K for k, v in prof.items()},
-            "roofline": {"kernel": "pair_kernel<SINGLE,HIST>", "bound": "valu (12*N + 8*nbins bytes per frame: not an HBM-bound "
-                         "kernel, SURVEY.md 8d)", "avg_launch_ms": hist_ms / max(hist_n, 1),
-                         "candidate_evals_per_sec": None},
+            "roofline": {"kernel": "hist_kernel<SINGLE> + pair_kernel<SINGLE,HIST>", "bound": "valu",
+                         "note": "12*N + 8*nbins bytes per frame: not an HBM-bound path (SURVEY.md 8d); priced as the plan's "
+                                 "candidate evaluations x 9 flop against the fp32 vector peak",
+                         "achieved": cand * 9 / (hist_ms / max(hist_n, 1) * 1e-3) / 1e12, "peak": valu_peak, "unit": "TFLOP/s",
+                         "frac": cand * 9 / (hist_ms / max(hist_n, 1) * 1e-3) / 1e12 / valu_peak, "traffic": None,
+                         "avg_launch_ms": hist_ms / max(hist_n, 1), "grid_dims": [int(x) for x in gd],
+                         "candidate_evals_per_frame": cand, "candidate_evals_per_sec": cand * K * world / t},
             "reduced_bins_equal_single_rank": check,
         }))
 
