@@ -383,6 +383,21 @@ def test_fused_histogram_equals_the_distance_stream(eng, orc32, case):
     assert np.array_equal(bins, want)
 
 
+@pytest.mark.parametrize("nbins", [1, 2, 4096, 8191, 8192])
+def test_fused_histogram_extreme_bin_counts(eng, orc32, nbins):
+    """1 bin, and the largest table the histogram kernel keeps in LDS (8192 counters + 8193 bin edges next to the queues)."""
+    a = api()
+    n = 20000
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 2)
+    ref = orc32.search_single_pbc(0.8, pos, orc32.box_from_matrix(box), 7, nthreads=8)
+    want = orc32.histogram_add(0.0, 0.8, nbins, ref["d"]).astype(np.uint64)
+    bins, cnt = eng.search_histogram(a.SEARCH_SINGLE, 0.8, 0.0, 0.8, nbins, pos, box=box, pbc=7)
+    assert cnt == len(ref["i"]) and np.array_equal(bins, want)
+    with pytest.raises(Exception):
+        eng.search_histogram(a.SEARCH_SINGLE, 0.8, 0.0, 0.8, 8193, pos, box=box, pbc=7)
+
+
 def test_fused_histogram_two_sets(eng, orc32):
     a = api()
     n = 12000
