@@ -1163,7 +1163,6 @@ struct HistFifo {
 __device__ __forceinline__ void hist_add(const HistFifo &F, float d2) {
     if (F.edges) {
         typedef __attribute__((address_space(3))) float lds_f32;
-        typedef __attribute__((address_space(3))) uint32_t lds_u32;
         float est = (__builtin_amdgcn_sqrtf(d2) - F.hmin) * F.scale;
         est = __builtin_fminf(__builtin_fmaxf(est, 0.0f), F.hn - 1.0f);      // also sends a NaN to 0
         const int n = (int)F.hn;
