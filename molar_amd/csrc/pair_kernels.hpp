@@ -1179,10 +1179,7 @@ __device__ __forceinline__ void hist_add(const HistFifo &F, float d2) {
     if (fb >= 0.0f && fb < F.hn) atomicAdd(&F.hist[(uint32_t)fb], 1u);
 }
 
-#ifndef HK_PLAIN_CAP
-#define HK_PLAIN_CAP 256
-#endif
-constexpr uint32_t HIST_PLAIN_CAP = HK_PLAIN_CAP;    // d2 queue of the plain path; the wrapped path uses the first FIFO_CAP words
+constexpr uint32_t HIST_PLAIN_CAP = 256;    // d2 queue of the plain path (flushed 128 at a time); the wrapped path's records use the same memory
 
 // plain queue: `count` <= 128 entries, two per lane (two independent sqrt / divide / atomic chains in flight)
 __device__ __forceinline__ void hist_flush_plain(HistFifo &F, uint32_t count, uint32_t lane) {
@@ -1353,16 +1350,10 @@ __device__ __forceinline__ uint32_t run_hist_wrapped(const SearchParams &P, cons
     return total;
 }
 
-#ifndef HK_HIST_WAVES
-#define HK_HIST_WAVES 16
-#endif
-constexpr int HIST_WAVES = HK_HIST_WAVES;      // waves per workgroup of hist_kernel (one LDS histogram and one slot counter per workgroup)
+constexpr int HIST_WAVES = 16;      // waves per workgroup of hist_kernel (one LDS histogram and one slot counter per workgroup; 4 / 8: +7 / +5 %)
 
-#ifndef HK_LEAN_WPE
-#define HK_LEAN_WPE 8
-#endif
 template <int KIND>
-__global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(HK_LEAN_WPE)))
+__global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(8)))
 hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ slot_desc, uint32_t nslots) {
     static_assert(HIST_PLAIN_CAP * 4 <= FIFO_CAP * 16, "the d2 queue of the plain path lives inside the wrapped path's queue");
     __shared__ float4 lds_a[HIST_WAVES][64];
