@@ -42,6 +42,24 @@ def test_search_fixtures(eng, name):
     v1, v2 = vdw[i1.astype(int)], vdw[i2.astype(int)]           # radii per SELECTED atom (molar_hip.h)
     pairs("vdw_pbc7", a.SEARCH_DOUBLE_VDW, None, pos, i1, pos, i2, box=box, pbc=7, vdw1=v1, vdw2=v2)
     pairs("vdw", a.SEARCH_DOUBLE_VDW, None, pos, i1, pos, i2, vdw1=v1, vdw2=v2)
+
+    def hist(key, kind, cutoff, *args, **kw):
+        """The fused histogram against Histogram1D::add_one (stats.rs:29-35) applied, in numpy float32, to the fixture's
+        distance stream: in-range bins, distances below the range and above it."""
+        d = g[key + "_d"]
+        nb, hmin, hmax = 97, np.float32(0.03), np.float32(0.47)
+        fb = np.floor(np.float32(nb) * (d - hmin) / (hmax - hmin))
+        ok = (fb >= 0) & (fb < nb)
+        want = np.bincount(fb[ok].astype(np.int64), minlength=nb).astype(np.uint64)
+        bins, cnt = eng.search_histogram(kind, cutoff, float(hmin), float(hmax), nb, *args, **kw)
+        assert cnt == len(d) and np.array_equal(bins, want), key
+
+    hist("single_pbc7", a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+    hist("single_pbc3", a.SEARCH_SINGLE, rc, pos, box=box, pbc=3)
+    hist("single", a.SEARCH_SINGLE, rc, pos)
+    hist("double_pbc7", a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=7)
+    hist("double", a.SEARCH_DOUBLE, rc, pos, i1, pos, i2)
+    hist("vdw_pbc7", a.SEARCH_DOUBLE_VDW, None, pos, i1, pos, i2, box=box, pbc=7, vdw1=v1, vdw2=v2)
     n = eng.search_count(a.SEARCH_WITHIN, rc, pos, i1, pos, i2, box=box, pbc=7)
     assert np.array_equal(eng.search_fill_ids(n), g["within_pbc7_i"])
     n = eng.search_count(a.SEARCH_WITHIN, rc, pos, i1, pos, i2, lower=g["within_lower"], upper=g["within_upper"])
