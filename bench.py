@@ -54,7 +54,7 @@ def make_frames(nframes, rank, box, device):
     return frames, ref
 
 
-def cpu_baseline(frame0, ref, box, mass, idx, warmup=2, reps=5):
+def cpu_baseline(frame0, ref, box, mass, idx, warmup=3, reps=10):
     """The oracle (a C restatement of MolAR's algorithm, NOT the Rust binary) in the reference's schedule — serial
     grid + plan, thread pool over plan entries, ordered concatenation, serial Measure passes — on one frame of the
     same workload, all host cores.  BASELINE.md §3 protocol, bounded: `warmup` untimed + `reps` timed repetitions,
