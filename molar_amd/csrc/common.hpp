@@ -104,6 +104,9 @@ struct GridSet {
     DevBuf aabb;               // float4 lo/hi per cell
     DevBuf perm;               // float4 per sorted atom: the cell in Morton order, {x,y,z,position} (count pass of the fast path)
     DevBuf chunk_aabb;         // float4 lo/hi per 64-atom Morton chunk, slot (cell_start >> 6) + cell + k
+    DevBuf h16;                // 8 x f16 per sorted atom (Morton order, like perm): hi/lo split of the position relative to the
+                               // cell's origin and of its squared norm - the B operand of the matrix-core count pass
+    DevBuf cell_org;           // float4 per cell: origin (centre of the bounding box), .w = bound on |position - origin|
 };
 
 }  // namespace mh
@@ -137,6 +140,7 @@ struct molar_hip_ctx {
     hipEvent_t grid_done = nullptr;
     bool want_side = false;              // set by _begin / the asynchronous histogram call around their enqueue
     bool env_no_side = false;            // MOLAR_HIP_NO_SIDE_STREAM, read once in molar_hip_create
+    bool env_no_mfma = false;            // MOLAR_HIP_NO_MFMA_COUNT: count pass of plain entries on the vector ALUs (A/B runs)
     uint32_t env_debug_skip = 0;         // MOLAR_HIP_DEBUG_SKIP (builds with -DMOLAR_HIP_DEBUG_KNOBS only), read once
     hipEvent_t gen_free[2] = {nullptr, nullptr};   // recorded on the main stream behind the last asynchronous reader of
                                                    // a grid generation (histogram calls that do not wait)

@@ -11,8 +11,9 @@ namespace pairk {
 
 enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2 };
 
-// (Count and fill are compiled for 8 waves per SIMD - 64 VGPRs, the few spills fall outside the row loop: count -4 %,
-// fill -5 % against 7 waves.  32 one-wave workgroups of the fill kernel hold 144 KB of the CU's 160 KB LDS.)
+// (The fill kernel is compiled for 8 waves per SIMD - 64 VGPRs, the few spills fall outside the row loop: -5 % against
+// 7 waves; 32 one-wave workgroups hold 144 KB of the CU's 160 KB LDS.  The count kernel runs 7 waves per SIMD since its
+// plain entries go through the matrix cores (run_count_mfma keeps a cell's B records in registers): 0.475 against 0.52 ms.)
 // Waves per workgroup.  Count / fill: ONE wave per workgroup - slots differ a lot in work, and a workgroup's
 // resources are only released when its slowest wave ends (measured: 4 -> 1 waves gives +7 % frames/s).  The fused
 // histogram keeps 4: every workgroup owns an LDS histogram that it flushes with atomics at the end.
@@ -63,6 +64,9 @@ struct SearchParams {
     const float4 *aabb_b;    // per-cell bounding boxes of set 2 (== set 1 for SINGLE)
     const float4 *perm_b;    // set 2: atoms in Morton order inside each cell, {x,y,z,position in the cell} (cells of <= 512 atoms), see place_order_kernel
     const float4 *chunk_aabb_b;   // set 2: bounding boxes of the 64-atom Morton chunks, slot (cell_start >> 6) + cell + k
+    const uint4 *h16_b;      // set 2, Morton order like perm_b: 8 x f16 {hi xyz, lo xyz, |.|^2 hi, lo} relative to the cell origin
+    const float4 *cell_org_b; // set 2: per cell {origin, bound on |position - origin|}
+    uint32_t mfma_count;     // count pass of plain / same-cell entries on the matrix cores (run_count_mfma)
     const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
     uint32_t *maskbuf;       // fast-path slots: hit bits found by the count pass, replayed by the fill pass
     const unsigned long long *task_moff;   // per task: first 64-word unit of its slots in maskbuf (a slot owns 2*nch units)
@@ -282,6 +286,7 @@ struct Fifo {
     const float4 *la;           // the slot's first-cell atoms in LDS
     float4 *fq_store;           // LDS backing of fq (fill kernels)
     float4 *fq;                 // replay mode: FIFO of the hits' second atoms {x,y,z,id}; fd then holds the row
+    uint4 *lh;                  // count pass: LDS staging of the slot's matrix-core row records (128 x 16 B), or NULL
     uint32_t wrap;
 };
 
@@ -633,6 +638,145 @@ __device__ __forceinline__ uint32_t run_count_sorted(const SearchParams &P, cons
     return acc;
 }
 
+// ================================================================= count pass on the matrix cores
+// Count pass of plain entries (two different cells, no periodic image, second cell <= 320 atoms).  |p2 - p1|^2 - cutoff^2
+// of a 32 x 32 block of (row, atom) pairs is ONE v_mfma_f32_32x32x16_f16: with both positions taken relative to the
+// second cell's origin O and split into f16 hi + lo parts (22 significant bits; subnormal parts are multiplied exactly,
+// profiles/microbench/mfma_f16_denormals_mi355x.txt),
+//     |b - a|^2 - c = sum_k A[row][k] * B[k][col],
+//     A = (-2 ah, -2 ah, |a|^2 - c (hi, lo) | -2 al, -2 al, 1, 1),   B = (bh, bl, 1, 1 | bh, bl, |b|^2 (hi, lo))
+// (f16 products are exact in the f32 accumulator).  The B records are prepared once per frame by place_order_kernel in
+// the spatial order of the count pass; the A records of the slot's 64 rows are built in the prologue and redistributed
+// through LDS.  Only the DECISION d2 <= cutoff^2 has to equal the reference's f32 evaluation: the sign of an accumulator
+// decides when its magnitude exceeds E, a bound on every difference between the two evaluations, with R = Ra + Rb the
+// bounds on |a - O| (reduced over the slot's rows) and |b - O| (stored with the cell), c = cutoff^2, in units of 2^-22:
+//     positions relative to O in f32 (2^-24 each) and their 22-bit split, times 2 |b - a| <= 2 R          2.6 R^2
+//     the two squared norms in f32 (4 roundings) and their hi + lo split                                  2 R^2 + 2 c
+//     16 f32 additions inside the instruction, partial sums <= R^2 + c                                    4 (R^2 + c)
+//     the reference's own roundings (three differences, three squares, two sums: 5 * 2^-24 relative)      1.25 R^2
+// together < 9.9 R^2 + 6 c; E = 2^-22 * (16 R^2 + 8 c).  Blocks with an accumulator inside (-E, E) - 3-4 % of them - are
+// recounted with the exact f32 formula after the loop; slots whose bound is not small against c, or not finite, are left
+// to run_count_sorted.  Per block: 16 v_alignbit (sign bits), 8 v_min3 (magnitudes), a popcount - 28 VALU instructions
+// for 1024 candidates instead of 160 (90 after run_count_sorted's bounding-box skips).  All memory a slot needs (rows,
+// origin, <= 10 B records per lane) is requested at once: with one block column prefetched the slot was a chain of ten
+// exposed latencies and the kernel no faster than before.  The count kernel runs 7 waves per SIMD (72 registers) for it.
+typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b) {
+    return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+constexpr int MFMA_TILES = 10;     // block columns (32 atoms) per second cell the matrix-core count keeps in registers: cells of <= 320 atoms
+
+template <int KIND>
+__device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const Task &T, uint32_t i0, float4 *la, uint4 *lh,
+                                                   uint32_t lane, bool &done) {
+    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u4_t lds_u4;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(1))) u4_t glb_u4;
+    const float cutoff2 = P.cutoff2;
+    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
+    const uint32_t kh = lane >> 5, cl = lane & 31u;
+    const uint32_t nct = (T.n2 + 31u) >> 5;
+    // Everything the slot reads from memory is requested at once - its rows, the second cell's origin and ALL B
+    // records: a slot is a chain of memory latencies, not of arithmetic (one block column prefetched: 0.50 ms for the
+    // count kernel, exactly what 8 waves x (2 + 9 exposed latencies) per slot predict).
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
+    const float4 org = gload4(P.cell_org_b, T.cb);
+    u4_t bq[MFMA_TILES];
+#pragma unroll
+    for (int t = 0; t < MFMA_TILES; ++t) {
+        const uint32_t col = (uint32_t)t * 32u + cl;
+        bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                          // atom past the end: |b|^2 = 65504, never a hit
+        if (col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
+    }
+    la[lane] = a;                                   // f32 rows, for the exact decision inside the band
+    const float r0 = a.x - org.x, r1 = a.y - org.y, r2 = a.z - org.z;
+    float ra2 = lane < rows ? (r0 * r0 + r1 * r1) + r2 * r2 : 0.0f;
+    const bool fin = ra2 == ra2;
+    for (int off = 32; off > 0; off >>= 1) ra2 = fmaxf(ra2, __shfl_xor(ra2, off, 64));
+    const float R = 1.0001f * __builtin_sqrtf(ra2) + org.w;
+    const float E = 2.3841858e-07f * (16.0f * R * R + 8.0f * cutoff2);          // 2^-22 * (...)
+    if (__builtin_amdgcn_ballot_w64(!fin) != 0ull || !(R < 64.0f) || !(E < 0.02f * cutoff2)) {
+        done = false;                               // not finite / not small: the exact path takes the slot
+        return 0u;
+    }
+    {   // A records of this lane's row: k = 0..7 and k = 8..15
+        u4_t k0 = {0u, 0u, 0u, 0x00007BFFu}, k1 = {0u, 0u, 0u, 0x3C003C00u};      // row past the end: +65504
+        if (lane < rows) {
+            const _Float16 h0 = (_Float16)r0, h1 = (_Float16)r1, h2 = (_Float16)r2;
+            const _Float16 l0 = (_Float16)(r0 - (float)h0), l1 = (_Float16)(r1 - (float)h1), l2 = (_Float16)(r2 - (float)h2);
+            const float e0 = (float)h0 + (float)l0, e1 = (float)h1 + (float)l1, e2 = (float)h2 + (float)l2;
+            const float na = ((e0 * e0 + e1 * e1) + e2 * e2) - cutoff2;
+            const _Float16 nh = (_Float16)na, nl = (_Float16)(na - (float)nh);
+            const _Float16 m2 = (_Float16)-2.0f;
+            const _Float16 g0 = m2 * h0, g1 = m2 * h1, g2 = m2 * h2, s0 = m2 * l0, s1 = m2 * l1, s2 = m2 * l2;
+            k0 = u4_t{pack_h2(g0, g1), pack_h2(g2, g0), pack_h2(g1, g2), pack_h2(nh, nl)};
+            k1 = u4_t{pack_h2(s0, s1), pack_h2(s2, s0), pack_h2(s1, s2), 0x3C003C00u};
+        }
+        ((lds_u4 *)lh)[2u * lane] = k0;
+        ((lds_u4 *)lh)[2u * lane + 1u] = k1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const u4_t a0q = ((const lds_u4 *)lh)[2u * cl + kh], a1q = ((const lds_u4 *)lh)[2u * (32u + cl) + kh];
+    const v8h_t A0 = __builtin_bit_cast(v8h_t, a0q), A1 = __builtin_bit_cast(v8h_t, a1q);
+    __builtin_amdgcn_wave_barrier();
+    // blocks with an accumulator inside (-E, E) are not counted here: their ids go to a list (the A staging area is
+    // free again) and they are recounted with the exact formula after the loop (2-3 % of the blocks)
+    lds_u32 *todo = (lds_u32 *)lh;
+    uint32_t ntodo = 0;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int t = 0; t < MFMA_TILES; ++t) {
+        if ((uint32_t)t < nct) {
+            u4_t bt = bq[t];
+            if (kh == 0u) bt.w = 0x3C003C00u;                           // k = 6, 7 of the first half: (1, 1)
+            const v8h_t B = __builtin_bit_cast(v8h_t, bt);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                v16f_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(rt == 0 ? A0 : A1, B, acc, 0, 0, 0);
+                uint32_t h = 0u;
+                float m = INFINITY;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    h = __builtin_amdgcn_alignbit(h, __float_as_uint(acc[i]), 31);       // h = 2 h + sign
+                    m = __builtin_fminf(m, __builtin_fabsf(acc[i]));
+                }
+                if (__builtin_amdgcn_ballot_w64(m < E) == 0ull) {
+                    cnt += (uint32_t)__popc(h);
+                } else {
+                    if (lane == 0) todo[ntodo] = (uint32_t)(2 * t + rt);
+                    ++ntodo;
+                }
+            }
+        }
+    }
+    if (ntodo) {
+        __builtin_amdgcn_wave_barrier();
+        // exact recount of the listed blocks: lanes = the block's 32 atoms, each half of the wave takes 16 of its 32 rows
+        for (uint32_t q = 0; q < ntodo; ++q) {
+            const uint32_t id = __builtin_amdgcn_readfirstlane(todo[q]);
+            const uint32_t ct = id >> 1, rt = id & 1u;
+            const uint32_t col = ct * 32u + cl;
+            float4 b = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+            if (col < T.n2) b = gload4(P.perm_b, T.b0 + col);
+            for (uint32_t r = 0; r < 16u; ++r) {
+                const uint32_t row = 32u * rt + 16u * kh + r;
+                const float4 p = lload4(la, row);
+                const float dx = b.x - p.x, dy = b.y - p.y, dz = b.z - p.z;     // p2 - p1
+                const float d2 = (dx * dx + dy * dy) + dz * dz;                // |p2-p1|^2 (:446, :460)
+                cnt += (row < rows && d2 <= cutoff2) ? 1u : 0u;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    return cnt;
+}
+
 template <int KIND, bool FILL, bool WRAPPED, int NCH, bool TRI, bool MASKED>
 __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                              uint32_t lane, uint32_t *mwords) {
@@ -894,6 +1038,14 @@ template <int KIND, bool FILL, int WK, bool MASKED>
 __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                                  uint32_t lane, uint32_t *mwords) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
+    if constexpr (!FILL && WK == WK_NONE && (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE)) {
+        // plain entries with a second cell of <= 320 atoms: the count goes to the matrix cores unless the slot's error bound is too wide
+        if (P.mfma_count && F.lh && !T.tri && T.n2 <= 32u * (uint32_t)MFMA_TILES) {
+            bool done = true;
+            const uint32_t cm = run_count_mfma<KIND>(P, T, i0, la, F.lh, lane, done);
+            if (done) return cm;
+        }
+    }
     if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && !T.tri && nchunks <= (uint32_t)KREG) {
         constexpr bool WR = WK != WK_NONE;
         switch (nchunks) {
@@ -1005,7 +1157,8 @@ __device__ __forceinline__ bool hist_lean_slot(const SearchParams &P, uint32_t f
 }
 
 template <int KIND, int MODE>
-__global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : 8))) pair_kernel(const SearchParams *__restrict__ Pp,
+__global__ void __launch_bounds__(64 * waves_per_block(MODE))
+__attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 7 : 8)))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
                                                      const uint32_t nslots,      // the host's bound: slots past the real count are empty
                                                      uint32_t *__restrict__ slot_cnt,
@@ -1016,6 +1169,7 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
     __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
     __shared__ float4 lds_a[WAVES_PER_BLOCK][64];
     __shared__ float4 lds_q[MODE == MODE_FILL ? WAVES_PER_BLOCK : 1][MODE == MODE_FILL ? FIFO_CAP : 1];   // replayed hits' second atoms
+    __shared__ uint4 lds_h[MODE == MODE_COUNT ? WAVES_PER_BLOCK : 1][MODE == MODE_COUNT ? 128 : 1];       // matrix-core row records of the count pass
     constexpr bool FILL = MODE != MODE_COUNT;
     extern __shared__ uint32_t lds_hist[];     // histogram mode only (hist_nbins counters)
     // The parameter block lives in device memory: a by-value struct this large, indexed dynamically
@@ -1075,6 +1229,7 @@ __global__ void __launch_bounds__(64 * waves_per_block(MODE)) __attribute__((amd
         F.la = lds_a[wave];
         F.fq = nullptr;
         F.fq_store = MODE == MODE_FILL ? lds_q[wave] : nullptr;
+        F.lh = MODE == MODE_COUNT ? lds_h[wave] : nullptr;
         F.wrap = 0;
         F.hmin = P.hist_min;
         F.hmax = P.hist_max;

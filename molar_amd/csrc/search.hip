@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t 
                                                           const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
                                                           float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
                                                           float4 *__restrict__ aabb, float4 *__restrict__ perm,
-                                                          float4 *__restrict__ chunk_aabb) {
+                                                          float4 *__restrict__ chunk_aabb, uint4 *__restrict__ h16,
+                                                          float4 *__restrict__ cell_org) {
     __shared__ uint32_t keys_s[4][ORDER_MAX];     // sort keys of the cell; reused as the Morton histogram
     __shared__ uint32_t kr_s[4][ORDER_MAX];
     __shared__ uint16_t perm_s[4][ORDER_MAX];
@@ -230,6 +231,15 @@ __global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t 
         aabb[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f);
         aabb[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
     }
+    // origin of the cell for the matrix-core count pass (pair_kernels.hpp, run_count_mfma): centre of the bounding box;
+    // .w bounds the distance of any atom of the cell from it (NaN / empty cells give a non-finite bound: that pass
+    // then leaves the cell to the exact path)
+    const float org[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+    if (lane == 0) {
+        const float ex = fmaxf(hi[0] - org[0], org[0] - lo[0]), ey = fmaxf(hi[1] - org[1], org[1] - lo[1]),
+                    ez = fmaxf(hi[2] - org[2], org[2] - lo[2]);
+        cell_org[c] = make_float4(org[0], org[1], org[2], 1.0001f * sqrtf((ex * ex + ey * ey) + ez * ez));
+    }
     if (n == 0 || !small) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the records placed above are re-read by other lanes of this wave (same CU: no L2 write-back needed)
     __builtin_amdgcn_wave_barrier();
@@ -276,6 +286,22 @@ __global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t 
             const uint32_t t = pl[m];
             const float4 p = pos[t];
             perm[s + m] = make_float4(p.x, p.y, p.z, __uint_as_float(t));
+            {   // f16 hi/lo split of the position relative to the cell origin and of its squared norm (22 bits each)
+                const float r[3] = {p.x - org[0], p.y - org[1], p.z - org[2]};
+                _Float16 h[3], l[3];
+                float eff[3];
+                for (int d = 0; d < 3; ++d) {
+                    h[d] = (_Float16)r[d];
+                    l[d] = (_Float16)(r[d] - (float)h[d]);
+                    eff[d] = (float)h[d] + (float)l[d];
+                }
+                const float nb = (eff[0] * eff[0] + eff[1] * eff[1]) + eff[2] * eff[2];
+                const _Float16 nh = (_Float16)nb, nl = (_Float16)(nb - (float)nh);
+                auto pk = [](_Float16 a, _Float16 b) -> uint32_t {
+                    return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+                };
+                h16[s + m] = make_uint4(pk(h[0], h[1]), pk(h[2], l[0]), pk(l[1], l[2]), pk(nh, nl));
+            }
             l3[0] = h3[0] = p.x; l3[1] = h3[1] = p.y; l3[2] = h3[2] = p.z;
         }
         for (int d = 0; d < 3; ++d)
@@ -615,6 +641,8 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     MH_TRY(S.aabb.reserve((size_t)ncells * 2 * sizeof(float4)));
     MH_TRY(S.perm.reserve((size_t)(S.n ? S.n : 1) * 16));
     MH_TRY(S.chunk_aabb.reserve(((size_t)S.n / 64 + ncells + 1) * 2 * sizeof(float4)));
+    MH_TRY(S.h16.reserve((size_t)(S.n ? S.n : 1) * 16));
+    MH_TRY(S.cell_org.reserve((size_t)(ncells + 1) * 16));
     // one counter per 128-byte line while that stays small (<= 64 MB) and cells are crowded
     const uint32_t pad_shift = (S.n && ncells <= (1u << 19) && (uint64_t)S.n >= 8ull * ncells) ? 5u : 0u;
     const size_t npad = pad_shift ? ((size_t)ncells << pad_shift) : 0;
@@ -640,7 +668,7 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         hipLaunchKernelGGL(place_order_kernel, dim3((ncells + 3u) / 4u), dim3(256), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
                            S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<float4>(),
-                           S.chunk_aabb.as<float4>());
+                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>());
         MH_HIP(hipGetLastError());
     }
     return 0;
@@ -675,6 +703,9 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.aabb_b = two ? c->set[1].aabb.as<float4>() : c->set[0].aabb.as<float4>();
     P.perm_b = two ? c->set[1].perm.as<float4>() : c->set[0].perm.as<float4>();
     P.chunk_aabb_b = two ? c->set[1].chunk_aabb.as<float4>() : c->set[0].chunk_aabb.as<float4>();
+    P.h16_b = two ? c->set[1].h16.as<uint4>() : c->set[0].h16.as<uint4>();
+    P.cell_org_b = two ? c->set[1].cell_org.as<float4>() : c->set[0].cell_org.as<float4>();
+    P.mfma_count = c->env_no_mfma ? 0u : 1u;
     P.task_desc = c->task_desc.as<TaskDesc>();
     P.maskbuf = c->maskbuf.as<uint32_t>();
     P.task_moff = c->task_moff.as<unsigned long long>();
