@@ -104,7 +104,7 @@ struct GridSet {
     DevBuf aabb;               // float4 lo/hi per cell
     DevBuf perm;               // float4 per sorted atom: the cell in Morton order, {x,y,z,position} (count pass of the fast path)
     DevBuf chunk_aabb;         // float4 lo/hi per 64-atom Morton chunk, slot (cell_start >> 6) + cell + k
-    DevBuf h16;                // 8 x f16 per sorted atom (Morton order, like perm): hi/lo split of the position relative to the
+    DevBuf h16;                // 8 x f16 per sorted atom (the reference's cell order, like `sorted`): hi/lo split of the position relative to the
                                // cell's origin and of its squared norm - the B operand of the matrix-core count pass
     DevBuf cell_org;           // float4 per cell: origin (centre of the bounding box), .w = bound on |position - origin|
 };

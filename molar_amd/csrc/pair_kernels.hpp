@@ -13,7 +13,8 @@ enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2 };
 
 // (The fill kernel is compiled for 8 waves per SIMD - 64 VGPRs, the few spills fall outside the row loop: -5 % against
 // 7 waves; 32 one-wave workgroups hold 144 KB of the CU's 160 KB LDS.  The count kernel runs 7 waves per SIMD since its
-// plain entries go through the matrix cores (run_count_mfma keeps a cell's B records in registers): 0.475 against 0.52 ms.)
+// plain and same-cell entries go through the matrix cores (run_count_mfma keeps a cell's B records in registers):
+// 0.44 against 0.52 ms.)
 // Waves per workgroup.  Count / fill: ONE wave per workgroup - slots differ a lot in work, and a workgroup's
 // resources are only released when its slowest wave ends (measured: 4 -> 1 waves gives +7 % frames/s).  The fused
 // histogram keeps 4: every workgroup owns an LDS histogram that it flushes with atomics at the end.
@@ -64,7 +65,7 @@ struct SearchParams {
     const float4 *aabb_b;    // per-cell bounding boxes of set 2 (== set 1 for SINGLE)
     const float4 *perm_b;    // set 2: atoms in Morton order inside each cell, {x,y,z,position in the cell} (cells of <= 512 atoms), see place_order_kernel
     const float4 *chunk_aabb_b;   // set 2: bounding boxes of the 64-atom Morton chunks, slot (cell_start >> 6) + cell + k
-    const uint4 *h16_b;      // set 2, Morton order like perm_b: 8 x f16 {hi xyz, lo xyz, |.|^2 hi, lo} relative to the cell origin
+    const uint4 *h16_b;      // set 2, in the order of sb: 8 x f16 {hi xyz, lo xyz, |.|^2 hi, lo} relative to the cell origin
     const float4 *cell_org_b; // set 2: per cell {origin, bound on |position - origin|}
     uint32_t mfma_count;     // count pass of plain / same-cell entries on the matrix cores (run_count_mfma)
     const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
@@ -639,14 +640,15 @@ __device__ __forceinline__ uint32_t run_count_sorted(const SearchParams &P, cons
 }
 
 // ================================================================= count pass on the matrix cores
-// Count pass of plain entries (two different cells, no periodic image, second cell <= 320 atoms).  |p2 - p1|^2 - cutoff^2
+// Count pass of plain and same-cell entries (no periodic image, second cell <= 320 atoms).  |p2 - p1|^2 - cutoff^2
 // of a 32 x 32 block of (row, atom) pairs is ONE v_mfma_f32_32x32x16_f16: with both positions taken relative to the
 // second cell's origin O and split into f16 hi + lo parts (22 significant bits; subnormal parts are multiplied exactly,
 // profiles/microbench/mfma_f16_denormals_mi355x.txt),
 //     |b - a|^2 - c = sum_k A[row][k] * B[k][col],
 //     A = (-2 ah, -2 ah, |a|^2 - c (hi, lo) | -2 al, -2 al, 1, 1),   B = (bh, bl, 1, 1 | bh, bl, |b|^2 (hi, lo))
 // (f16 products are exact in the f32 accumulator).  The B records are prepared once per frame by place_order_kernel in
-// the spatial order of the count pass; the A records of the slot's 64 rows are built in the prologue and redistributed
+// the reference's cell order (a same-cell entry's j > i is then a comparison of block coordinates: blocks below the
+// diagonal are skipped, blocks on it masked); the A records of the slot's 64 rows are built in the prologue and redistributed
 // through LDS.  Only the DECISION d2 <= cutoff^2 has to equal the reference's f32 evaluation: the sign of an accumulator
 // decides when its magnitude exceeds E, a bound on every difference between the two evaluations, with R = Ra + Rb the
 // bounds on |a - O| (reduced over the slot's rows) and |b - O| (stored with the cell), c = cutoff^2, in units of 2^-22:
@@ -669,7 +671,7 @@ __device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b) {
 
 constexpr int MFMA_TILES = 10;     // block columns (32 atoms) per second cell the matrix-core count keeps in registers: cells of <= 320 atoms
 
-template <int KIND>
+template <int KIND, bool TRI>
 __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const Task &T, uint32_t i0, float4 *la, uint4 *lh,
                                                    uint32_t lane, bool &done) {
     typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
@@ -737,8 +739,22 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
             const v8h_t B = __builtin_bit_cast(v8h_t, bt);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
+                // same-cell entries (j > i, :443; B records are in the reference's order, so atom `col` has position col):
+                // blocks below the diagonal hold no pair, blocks above it all of theirs, blocks on it are masked
+                bool diag = false;
+                if (TRI) {
+                    const uint32_t row0 = i0 + 32u * (uint32_t)rt;
+                    if (32u * (uint32_t)t + 31u <= row0) continue;                       // every j <= every i
+                    diag = 32u * (uint32_t)t <= row0 + 31u;
+                }
                 v16f_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(rt == 0 ? A0 : A1, B, acc, 0, 0, 0);
+                // accumulator i of lane (kh, cl): row 32 rt + 8 (i / 4) + 4 kh + i % 4, atom 32 t + cl
+                if (TRI && diag) {
+                    const int tv = (int)(32u * (uint32_t)t + cl) - (int)(i0 + 32u * (uint32_t)rt + 4u * kh);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = (tv > 8 * (i / 4) + (i % 4)) ? acc[i] : 1.0e30f;
+                }
                 uint32_t h = 0u;
                 float m = INFINITY;
 #pragma unroll
@@ -763,13 +779,13 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
             const uint32_t ct = id >> 1, rt = id & 1u;
             const uint32_t col = ct * 32u + cl;
             float4 b = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
-            if (col < T.n2) b = gload4(P.perm_b, T.b0 + col);
+            if (col < T.n2) b = gload4(P.sb, T.b0 + col);
             for (uint32_t r = 0; r < 16u; ++r) {
                 const uint32_t row = 32u * rt + 16u * kh + r;
                 const float4 p = lload4(la, row);
                 const float dx = b.x - p.x, dy = b.y - p.y, dz = b.z - p.z;     // p2 - p1
                 const float d2 = (dx * dx + dy * dy) + dz * dz;                // |p2-p1|^2 (:446, :460)
-                cnt += (row < rows && d2 <= cutoff2) ? 1u : 0u;
+                cnt += (row < rows && (!TRI || col > i0 + row) && d2 <= cutoff2) ? 1u : 0u;
             }
         }
     }
@@ -1039,10 +1055,12 @@ __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Ta
                                                  uint32_t lane, uint32_t *mwords) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
     if constexpr (!FILL && WK == WK_NONE && (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE)) {
-        // plain entries with a second cell of <= 320 atoms: the count goes to the matrix cores unless the slot's error bound is too wide
-        if (P.mfma_count && F.lh && !T.tri && T.n2 <= 32u * (uint32_t)MFMA_TILES) {
+        // plain and same-cell entries with a second cell of <= 320 atoms: the count goes to the matrix cores unless the
+        // slot's error bound is too wide
+        if (P.mfma_count && F.lh && T.n2 <= 32u * (uint32_t)MFMA_TILES) {
             bool done = true;
-            const uint32_t cm = run_count_mfma<KIND>(P, T, i0, la, F.lh, lane, done);
+            const uint32_t cm = (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) ? run_count_mfma<KIND, true>(P, T, i0, la, F.lh, lane, done)
+                                                                          : run_count_mfma<KIND, false>(P, T, i0, la, F.lh, lane, done);
             if (done) return cm;
         }
     }

@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t 
                 auto pk = [](_Float16 a, _Float16 b) -> uint32_t {
                     return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
                 };
-                h16[s + m] = make_uint4(pk(h[0], h[1]), pk(h[2], l[0]), pk(l[1], l[2]), pk(nh, nl));
+                h16[s + t] = make_uint4(pk(h[0], h[1]), pk(h[2], l[0]), pk(l[1], l[2]), pk(nh, nl));      // in the REFERENCE's cell order
             }
             l3[0] = h3[0] = p.x; l3[1] = h3[1] = p.y; l3[2] = h3[2] = p.z;
         }
