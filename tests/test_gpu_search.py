@@ -546,6 +546,53 @@ def _boundary_pairs(box, rc, npairs, seed, emin=-6.0, emax=-4.0):
     return np.array(pts, np.float32)
 
 
+@pytest.mark.parametrize("case", ["ortho_30nm", "tric_12nm", "no_box_far_from_origin", "crowded_cells", "nan_atom"])
+def test_matrix_core_count_band_adversarial(eng, orc32, case):
+    """The count pass of plain and same-cell entries decides d2 <= cutoff^2 from a matrix-core evaluation of f16 hi/lo
+    splits and re-decides exactly inside an error band (pair_kernels.hpp, run_count_mfma).  Stress that band: tens of
+    thousands of INTERIOR pairs (no periodic image involved) at rc * (1 +- 1e-8 .. 1e-4), where one ulp of the f32
+    formula decides membership; plus the guards - coordinates far from the origin without a box, cells beyond the
+    register-resident size, a NaN coordinate.  A single wrong count shifts every later slot's output offset, so the lists
+    must be bit-identical to the oracle's."""
+    a = api()
+    rng = np.random.default_rng(5)
+    rc, use_box, pbc, shift = 1.0, True, 7, 0.0
+    if case == "ortho_30nm":
+        box = np.diag([30.0, 30.0, 30.0]).astype(np.float32)
+    elif case == "tric_12nm":
+        box = np.array([[12.0, 0.0, -2.0], [0.0, 12.0, -2.0], [0.0, 0.0, 12.0]], np.float32)
+    elif case == "no_box_far_from_origin":
+        box = np.diag([14.0, 14.0, 14.0]).astype(np.float32); use_box, pbc, shift = False, 0, 30.0     # the error bound works on coordinates relative to the cell
+    elif case == "crowded_cells":
+        box = np.diag([8.0, 8.0, 8.0]).astype(np.float32)
+    else:
+        box = np.diag([10.0, 10.0, 10.0]).astype(np.float32)
+    M = box.astype(np.float64)
+    npairs = 20000
+    fa = 0.15 + 0.7 * rng.random((npairs, 3))                     # interior: no pair reaches a periodic face
+    pa = fa @ M.T
+    u = rng.normal(size=(npairs, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    e = 10.0 ** rng.uniform(-8.0, -4.0, npairs) * rng.choice([-1.0, 1.0], npairs)
+    pb = pa + rc * (1.0 + e)[:, None] * u
+    pos = np.concatenate([pa, pb]).astype(np.float32)
+    nbg = 60000 if case == "crowded_cells" else 8000              # crowded: ~120 atoms/nm^3 -> cells beyond 320 atoms
+    pos = np.concatenate([pos, (rng.random((nbg, 3)) @ M.T).astype(np.float32)]) + np.float32(shift)
+    if case == "nan_atom":
+        pos[12345] = np.nan
+    ob = orc32.box_from_matrix(box)
+    if use_box:
+        ref = orc32.search_single_pbc(rc, pos, ob, pbc, nthreads=8)
+        cnt = eng.search_count(a.SEARCH_SINGLE, rc, pos, box=box, pbc=pbc)
+    else:
+        ref = orc32.search_single(rc, pos, nthreads=8)
+        cnt = eng.search_count(a.SEARCH_SINGLE, rc, pos)
+    pr, d = eng.search_fill(cnt)
+    near = np.abs(ref["d"].astype(np.float64) / rc - 1.0)
+    assert (near < 1e-4).sum() > 8000 and (near < 1e-6).sum() > 1500       # the half of the constructed pairs inside the cutoff
+    assert cnt == len(ref["i"])
+    assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"])
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("boxkind,L", [("dodecahedron", 60.0), ("sheared", 40.0), ("sheared_huge", 160.0)])
 def test_wrapped_band_adversarial_large_sheared_boxes(eng, orc32, boxkind, L):
