@@ -59,23 +59,65 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def exec_restore_hazards(asm_path: str) -> list[str]:
+    """Audit of generated gfx950 ISA for one register-allocator hazard of ROCm 7.2's compiler: a VGPR copy
+    (`v_mov_b32 vA, vB`) or VGPR spill store placed at the top of a join block AHEAD of the instruction that restores
+    EXEC (`s_or_b64 exec, exec, ...`).  Such a copy moves only the lanes that were active inside the divergent region;
+    when the value is live for all lanes (a wave-uniform value kept in a VGPR, a lane id) the masked-off lanes keep a
+    stale copy.  It happened in hist_kernel (round 2, found by tools/fuzz_search.py: wrong histogram bins for the lanes
+    concerned); the build refuses a library whose kernels contain the pattern."""
+    import re
+    lines = open(asm_path).read().split("\n")
+    kernel, found = "?", []
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            kernel = m.group(1)
+        if not l.startswith(".LBB"):
+            continue
+        seen, j = [], i + 1
+        while j < len(lines) and not lines[j].startswith(".LBB") and j < i + 14:     # an EXEC restore sits at the top of its block
+            t = lines[j].strip()
+            if t.startswith("s_or_b64 exec, exec"):
+                found += [f"{os.path.basename(asm_path)}:{i + 1}: {kernel[:80]}: `{x}` ahead of the EXEC restore"
+                          for x in seen if re.match(r"v_mov_b32_e32 v\d+, v\d+$", x) or x.startswith("scratch_store")]
+                break
+            if t and not t.startswith(";"):
+                seen.append(t)
+            j += 1
+    return found
+
+
 def _build_locked(verbose: bool) -> str:
+    import glob
+    import shutil
+    import tempfile
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    tmp = tempfile.mkdtemp(prefix="molar_hip_build_")      # compiler temporaries (the device ISA is audited below)
     for s in SOURCES:
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", obj]
+        cmd = [hipcc, *FLAGS, "-save-temps", "-c", os.path.join(CSRC, s), "-o", obj]      # temporaries go to the cwd
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=tmp)))
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{out}")
         if verbose and out.strip():
             print(out)
+    hazards = []
+    asms = sorted(glob.glob(os.path.join(tmp, "*-hip-amdgcn-amd-amdhsa-gfx950.s")))
+    if len(asms) != len(SOURCES):
+        raise RuntimeError(f"ISA audit: expected {len(SOURCES)} device assembly files in {tmp}, found {len(asms)}")
+    for asm in asms:
+        hazards += exec_restore_hazards(asm)
+    shutil.rmtree(tmp, ignore_errors=True)
+    if hazards and not os.environ.get("MOLAR_HIP_ALLOW_EXEC_HAZARD"):
+        raise RuntimeError("the compiler placed VGPR copies ahead of an EXEC restore (see exec_restore_hazards):\n" + "\n".join(hazards))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -1326,7 +1326,15 @@ struct HistFifo {
     uint32_t *hist;      // workgroup histogram in LDS
     const float *edges;  // LDS copy of SearchParams::hist_edges, or NULL
     float hmin, hmax, hn, scale;
+    // Wave-uniform values that live across hist_kernel's whole slot loop are kept in SGPRs (readfirstlane), never as
+    // "the same value in every lane" of a VGPR: under register pressure the allocator splits such a VGPR's live range
+    // with copies, and ROCm 7.2's compiler placed one of them in a join block ahead of the instruction that restores
+    // EXEC - lanes that were masked off at that point kept a stale copy for the rest of the kernel (found by the fuzzer:
+    // two-set search, 400-atom cells, bins of those lanes' hits wrong; tests/golden/hist_regression_case.npz).
+    float hn1;           // nbins - 1 as float
+    uint32_t nbins;
 };
+__device__ __forceinline__ float uniform_f32(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
 // Histogram1D::add_one (stats.rs:29-35) on d = sqrt(d2):  b = (n as Float * (val - min) / (max - min)).floor() as isize
 // The bin is a non-decreasing function of d2 (correctly rounded sqrt, subtraction of and multiplication / division by
@@ -1337,8 +1345,8 @@ __device__ __forceinline__ void hist_add(const HistFifo &F, float d2) {
     if (F.edges) {
         typedef __attribute__((address_space(3))) float lds_f32;
         float est = (__builtin_amdgcn_sqrtf(d2) - F.hmin) * F.scale;
-        est = __builtin_fminf(__builtin_fmaxf(est, 0.0f), F.hn - 1.0f);      // also sends a NaN to 0
-        const int n = (int)F.hn;
+        est = __builtin_fminf(__builtin_fmaxf(est, 0.0f), F.hn1);            // also sends a NaN to 0
+        const int n = (int)F.nbins;
         int b = (int)est;
         const lds_f32 *e = (const lds_f32 *)F.edges;
         const float e0 = e[b], e1 = e[b + 1];
@@ -1552,7 +1560,9 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
     F.hist = lds_hist;
     F.hmin = P.hist_min;
     F.hmax = P.hist_max;
-    F.hn = (float)P.hist_nbins;
+    F.hn = uniform_f32((float)P.hist_nbins);
+    F.hn1 = uniform_f32((float)P.hist_nbins - 1.0f);
+    F.nbins = P.hist_nbins;
     unsigned long long wave_total = 0;
     // A workgroup owns every gridDim.x-th slot and hands them to its waves one at a time through a counter in LDS:
     // slots differ ~10x in work, and with a fixed share of ~9 slots per wave the slowest wave took 1.7x the mean.

@@ -398,6 +398,25 @@ def test_fused_histogram_extreme_bin_counts(eng, orc32, nbins):
         eng.search_histogram(a.SEARCH_SINGLE, 0.8, 0.0, 0.8, 8193, pos, box=box, pbc=7)
 
 
+def test_fused_histogram_regression_case_of_the_fuzzer(eng, orc32):
+    """tools/fuzz_search.py, seed 123, case 500: a two-set search in a triclinic box periodic in y only, grid (1, 4, 2),
+    ~400 atoms of the second set per cell (7 chunks: the register-hungriest instance of the histogram kernel's wrapped
+    path).  ROCm 7.2's compiler had placed a VGPR copy of a wave-uniform value ahead of an EXEC restore there, and 1.6 %
+    of the hits landed in bin 1 (molar_amd/build.py now audits the ISA for the pattern; the kernel keeps such values in
+    SGPRs).  Fixture: tests/golden/hist_regression_case.npz (positions, box, the two index sets, parameters)."""
+    a = api()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hist_regression_case.npz"))
+    pos, box, i1, i2 = g["pos"], g["box"], g["i1"], g["i2"]
+    rc, pbc, nb, hmin, hmax = float(g["rc"]), int(g["pbc"]), int(g["nb"]), float(g["hmin"]), float(g["hmax"])
+    ob = orc32.box_from_matrix(box)
+    for s1, s2 in ((i1, i2), (i2, i2), (i2, i1)):
+        ref = orc32.search_double_pbc(rc, pos[s1.astype(int)], pos[s2.astype(int)], ob, pbc, ids1=s1, ids2=s2, nthreads=4)
+        for lo, hi, n in ((hmin, hmax, nb), (0.0, hmax, nb), (0.0, rc, 300)):
+            want = orc32.histogram_add(lo, hi, n, ref["d"]).astype(np.uint64)
+            bins, cnt = eng.search_histogram(a.SEARCH_DOUBLE, rc, lo, hi, n, pos, s1, pos, s2, box=box, pbc=pbc)
+            assert cnt == len(ref["i"]) and np.array_equal(bins, want), (len(s1), len(s2), lo, hi, n)
+
+
 def test_fused_histogram_two_sets(eng, orc32):
     a = api()
     n = 12000

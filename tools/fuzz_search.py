@@ -96,6 +96,11 @@ def main():
                     bins, hc = eng.search_histogram(api.SEARCH_DOUBLE, rc, hmin, hmax, nb, pos, i1, pos, i2, **kw)
                     if hc != len(ref["i"]) or not np.array_equal(bins, want):
                         fails += 1; print("MISMATCH histogram", tag, nb, hmin, hmax)
+                        if os.environ.get("FUZZ_DEBUG"):
+                            print(" count", hc, len(ref["i"]), "bins sum", int(bins.sum()), int(want.sum()))
+                            bad = np.flatnonzero(bins != want)
+                            print(" bad bins", bad[:20], bins[bad[:20]], want[bad[:20]])
+                            np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_case.npz"), pos=pos, box=box, i1=i1, i2=i2, rc=rc, pbc=pbc, nb=nb, hmin=hmin, hmax=hmax)
             else:
                 i1 = np.arange(n, dtype=np.uint64); i2 = np.sort(rng.choice(n, max(n // 20, 1), replace=False)).astype(np.uint64)
                 p2 = pos[i2.astype(int)]
