@@ -5,6 +5,8 @@ output order (plan order, then i-major / j-minor, distance_search.rs:949-953).  
 the same f32 operation order and a correctly rounded sqrt, so they are compared for exact
 equality too (tolerance allowed by north_star: 1e-5 relative).
 """
+import os
+
 import numpy as np
 import pytest
 
