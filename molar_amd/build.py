@@ -60,31 +60,39 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 
 def exec_restore_hazards(asm_path: str) -> list[str]:
-    """Audit of generated gfx950 ISA for one register-allocator hazard of ROCm 7.2's compiler: a VGPR copy
-    (`v_mov_b32 vA, vB`) or VGPR spill store placed at the top of a join block AHEAD of the instruction that restores
-    EXEC (`s_or_b64 exec, exec, ...`).  Such a copy moves only the lanes that were active inside the divergent region;
-    when the value is live for all lanes (a wave-uniform value kept in a VGPR, a lane id) the masked-off lanes keep a
-    stale copy.  It happened in hist_kernel (round 2, found by tools/fuzz_search.py: wrong histogram bins for the lanes
-    concerned); the build refuses a library whose kernels contain the pattern."""
+    """Audit of generated gfx950 ISA for one register-allocator hazard of ROCm 7.2's compiler: a live-range split of a
+    VGPR whose copy (`v_mov vA, vB`, later undone by `v_mov vB, vA`) or spill store was placed at the top of a join block
+    AHEAD of the instruction that restores EXEC (`s_or_b64 exec, exec, ...`).  Such a copy moves only the lanes that were
+    active inside the divergent region; when the value is live for all lanes (a wave-uniform value kept in a VGPR, a lane
+    id) the masked-off lanes keep a stale copy.  It happened in hist_kernel (round 2, found by tools/fuzz_search.py: wrong
+    histogram bins for the lanes concerned); the build refuses a library whose kernels contain the pattern.  (A copy in
+    front of an EXEC restore that is never undone is an ordinary conditional assignment at the end of a then-block.)"""
     import re
     lines = open(asm_path).read().split("\n")
-    kernel, found = "?", []
-    for i, l in enumerate(lines):
-        m = re.match(r"^(_Z\w+):", l)
-        if m:
-            kernel = m.group(1)
-        if not l.startswith(".LBB"):
-            continue
-        seen, j = [], i + 1
-        while j < len(lines) and not lines[j].startswith(".LBB") and j < i + 14:     # an EXEC restore sits at the top of its block
-            t = lines[j].strip()
-            if t.startswith("s_or_b64 exec, exec"):
-                found += [f"{os.path.basename(asm_path)}:{i + 1}: {kernel[:80]}: `{x}` ahead of the EXEC restore"
-                          for x in seen if re.match(r"v_mov_b32_e32 v\d+, v\d+$", x) or x.startswith("scratch_store")]
-                break
-            if t and not t.startswith(";"):
-                seen.append(t)
-            j += 1
+    # kernel bodies, for the "undone later" test
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)] + [len(lines)]
+    found = []
+    for ki in range(len(starts) - 1):
+        k0, k1 = starts[ki], starts[ki + 1]
+        kernel = lines[k0].rstrip(":")
+        body = [l.strip() for l in lines[k0:k1]]
+        copies = set(x for x in body if x.startswith("v_mov_b32_e32 v") or x.startswith("v_mov_b64_e32 v["))
+        for i in range(k0, k1):
+            if not lines[i].startswith(".LBB"):
+                continue
+            seen, j = [], i + 1
+            while j < k1 and not lines[j].startswith(".LBB") and j < i + 14:     # an EXEC restore sits at the top of its block
+                t = lines[j].strip()
+                if re.match(r"s_or_b64 exec, (exec, s\[|s\[\d+:\d+\], exec)", t):
+                    for x in seen:
+                        m = re.match(r"(v_mov_b32_e32|v_mov_b64_e32) (v\d+|v\[\d+:\d+\]), (v\d+|v\[\d+:\d+\])$", x)
+                        undone = m is not None and f"{m.group(1)} {m.group(3)}, {m.group(2)}" in copies
+                        if undone or x.startswith("scratch_store"):
+                            found.append(f"{os.path.basename(asm_path)}:{i + 1}: {kernel[:80]}: `{x}` ahead of the EXEC restore")
+                    break
+                if t and not t.startswith(";"):
+                    seen.append(t)
+                j += 1
     return found
 
 

@@ -134,9 +134,10 @@ def test_isa_audit_flags_a_copy_ahead_of_an_exec_restore(tmp_path):
     from molar_amd.build import exec_restore_hazards
     bad = tmp_path / "bad.s"
     bad.write_text("_Z4kernv:\n\tv_add_f32_e32 v59, -1.0, v1\n.LBB2_1115:\n\ts_mov_b64 s[10:11], 0\n\tv_writelane_b32 v63, s10, 11\n"
-                   "\tv_mov_b32_e32 v62, v59\n\ts_nop 0\n\ts_or_b64 exec, exec, s[12:13]\n\ts_endpgm\n")
+                   "\tv_mov_b32_e32 v62, v59\n\ts_nop 0\n\ts_or_b64 exec, exec, s[12:13]\n.LBB2_1261:\n\tv_mov_b32_e32 v59, v62\n\ts_endpgm\n")
     good = tmp_path / "good.s"
-    good.write_text("_Z4kernv:\n.LBB2_1:\n\ts_or_b64 exec, exec, s[12:13]\n\tv_mov_b32_e32 v62, v59\n.LBB2_2:\n\tv_mov_b32_e32 v1, v2\n\ts_endpgm\n")
+    good.write_text("_Z4kernv:\n.LBB2_1:\n\ts_or_b64 exec, exec, s[12:13]\n\tv_mov_b32_e32 v62, v59\n.LBB2_2:\n\tv_mov_b64_e32 v[0:1], v[50:51]\n"
+                    "\ts_or_b64 exec, exec, s[2:3]\n\ts_endpgm\n")      # a conditional assignment at the end of a then-block
     hits = exec_restore_hazards(str(bad))
     assert len(hits) == 1 and "v_mov_b32_e32 v62, v59" in hits[0] and "_Z4kernv" in hits[0]
     assert exec_restore_hazards(str(good)) == []
