@@ -87,6 +87,9 @@ def exec_restore_hazards(asm_path: str) -> list[str]:
                     for x in seen:
                         m = re.match(r"(v_mov_b32_e32|v_mov_b64_e32) (v\d+|v\[\d+:\d+\]), (v\d+|v\[\d+:\d+\])$", x)
                         undone = m is not None and f"{m.group(1)} {m.group(3)}, {m.group(2)}" in copies
+                        ma = re.match(r"v_accvgpr_write_b32 (a\d+), (v\d+)", x)      # AGPRs as spill space: same hazard
+                        if ma is not None and any(y.startswith("v_accvgpr_read_b32") and y.endswith(", " + ma.group(1)) for y in body):
+                            undone = True
                         if undone or x.startswith("scratch_store"):
                             found.append(f"{os.path.basename(asm_path)}:{i + 1}: {kernel[:80]}: `{x}` ahead of the EXEC restore")
                     break
