@@ -50,6 +50,8 @@ __device__ __forceinline__ uint32_t gload_u32(const uint32_t *p, size_t i) {
 __device__ __forceinline__ void gstore_u32(uint32_t *p, size_t i, uint32_t v) {
     ((__attribute__((address_space(1))) uint32_t *)p)[i] = v;
 }
+// a wave-uniform float pinned to an SGPR (see HistFifo: uniform values that live long are not left in VGPRs)
+__device__ __forceinline__ float uniform_f32(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 __device__ __forceinline__ float4 lload4(const float4 *p, uint32_t i) {
     const v4f_t v = ((const __attribute__((address_space(3))) v4f_t *)p)[i];
     return make_float4(v.x, v.y, v.z, v.w);
@@ -701,7 +703,8 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
     const bool fin = ra2 == ra2;
     for (int off = 32; off > 0; off >>= 1) ra2 = fmaxf(ra2, __shfl_xor(ra2, off, 64));
     const float R = 1.0001f * __builtin_sqrtf(ra2) + org.w;
-    const float E = 2.3841858e-07f * (16.0f * R * R + 8.0f * cutoff2);          // 2^-22 * (...)
+    // (R and E live across the whole block loop: pinned to SGPRs, see HistFifo)
+    const float E = uniform_f32(2.3841858e-07f * (16.0f * R * R + 8.0f * cutoff2));          // 2^-22 * (...)
     if (__builtin_amdgcn_ballot_w64(!fin) != 0ull || !(R < 64.0f) || !(E < 0.02f * cutoff2)) {
         done = false;                               // not finite / not small: the exact path takes the slot
         return 0u;
@@ -1334,7 +1337,6 @@ struct HistFifo {
     float hn1;           // nbins - 1 as float
     uint32_t nbins;
 };
-__device__ __forceinline__ float uniform_f32(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
 // Histogram1D::add_one (stats.rs:29-35) on d = sqrt(d2):  b = (n as Float * (val - min) / (max - min)).floor() as isize
 // The bin is a non-decreasing function of d2 (correctly rounded sqrt, subtraction of and multiplication / division by
