@@ -77,6 +77,9 @@ def exec_restore_hazards(asm_path: str) -> list[str]:
         kernel = lines[k0].rstrip(":")
         body = [l.strip() for l in lines[k0:k1]]
         copies = set(x for x in body if x.startswith("v_mov_b32_e32 v") or x.startswith("v_mov_b64_e32 v["))
+        # labels reached by the branch that SKIPS a then-body: real join blocks (a label entered by s_cbranch_execnz is
+        # a then-body, where a copy in front of the closing EXEC restore is an ordinary conditional assignment)
+        joins = set(m.group(1) for x in body for m in [re.match(r"s_cbranch_execz (\.LBB\w+)", x)] if m)
         for i in range(k0, k1):
             if not lines[i].startswith(".LBB"):
                 continue
@@ -90,6 +93,8 @@ def exec_restore_hazards(asm_path: str) -> list[str]:
                         ma = re.match(r"v_accvgpr_write_b32 (a\d+), (v\d+)", x)      # AGPRs as spill space: same hazard
                         if ma is not None and any(y.startswith("v_accvgpr_read_b32") and y.endswith(", " + ma.group(1)) for y in body):
                             undone = True
+                        if m is not None and lines[i].split(":")[0] in joins:
+                            undone = True          # any VGPR copy at the top of a join block, before EXEC is whole again
                         if undone or x.startswith("scratch_store"):
                             found.append(f"{os.path.basename(asm_path)}:{i + 1}: {kernel[:80]}: `{x}` ahead of the EXEC restore")
                     break

@@ -141,6 +141,15 @@ def test_isa_audit_flags_a_copy_ahead_of_an_exec_restore(tmp_path):
     hits = exec_restore_hazards(str(bad))
     assert len(hits) == 1 and "v_mov_b32_e32 v62, v59" in hits[0] and "_Z4kernv" in hits[0]
     assert exec_restore_hazards(str(good)) == []
+    # a copy at the top of a JOIN block (the label the skip branch s_cbranch_execz jumps to) is flagged even when it is
+    # never undone; the same copy in a then-body entered by s_cbranch_execnz is not
+    join = tmp_path / "join.s"
+    join.write_text("_Z5kern2v:\n\ts_and_saveexec_b64 s[2:3], vcc\n\ts_cbranch_execz .LBB0_2\n\tv_add_f32_e32 v1, v1, v1\n.LBB0_2:\n"
+                    "\tv_mov_b32_e32 v7, v9\n\ts_or_b64 exec, exec, s[2:3]\n\ts_endpgm\n")
+    then = tmp_path / "then.s"
+    then.write_text("_Z5kern3v:\n\ts_and_saveexec_b64 s[2:3], vcc\n\ts_cbranch_execnz .LBB0_2\n\ts_branch .LBB0_3\n.LBB0_2:\n"
+                    "\tv_mov_b32_e32 v7, v9\n\ts_or_b64 exec, exec, s[2:3]\n.LBB0_3:\n\ts_endpgm\n")
+    assert len(exec_restore_hazards(str(join))) == 1 and exec_restore_hazards(str(then)) == []
 
 
 def test_fails_loudly_without_gpu(lib):
