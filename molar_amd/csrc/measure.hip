@@ -246,6 +246,58 @@ __global__ void __launch_bounds__(RB) k_fit_sums(Sel s1, Sel s2, double *partial
     block_reduce_store<NV, BLOCK>(acc, partials);
 }
 
+// Batched fits (fit_rmsd_batch): the reference selection, both mass columns and the index do not change from frame to
+// frame, so they are gathered ONCE into a dense record per selected atom - {q.x, q.y, q.z, m1} and {atom of the frame,
+// m2} - and every frame then reads 24 coalesced bytes per atom plus ONE scattered 12-byte position instead of four
+// scattered reads behind two 8-byte indices.  The terms, their order and the trip structure are those of k_fit_sums:
+// the sums are bit-identical to the unpacked kernel's.
+__global__ void __launch_bounds__(RB) k_fit_pack(Sel s1, Sel s2, float4 *__restrict__ qm, uint2 *__restrict__ am) {
+    const uint32_t k = blockIdx.x * RB + threadIdx.x;
+    if (k >= s1.n) return;
+    const uint64_t a1 = atom_of(s1, k), a2 = atom_of(s2, k);
+    const V3 q = pos_of(s2, 0, a2);
+    const float m1 = s1.mass[a1];
+    const float m2 = s2.mass ? s2.mass[a2] : m1;
+    qm[k] = make_float4(q.x, q.y, q.z, m1);
+    am[k] = make_uint2((uint32_t)a1, __float_as_uint(m2));
+}
+
+template <bool UNW>
+__global__ void __launch_bounds__(RB) k_fit_sums_packed(const float *__restrict__ xyz, size_t frame_stride, uint32_t n,
+                                                        const float4 *__restrict__ qm, const uint2 *__restrict__ am,
+                                                        double *partials) {
+    constexpr int BLOCK = RB;
+    constexpr int NV = UNW ? FS_ALL : FS_W;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    const float *__restrict__ frame = xyz + (size_t)blockIdx.y * frame_stride;
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t k0 = blockIdx.x * BLOCK + threadIdx.x; k0 < n; k0 += 4u * stride) {
+        uint2 a[4];
+        float4 r[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t k = k0 + (uint32_t)u * stride;
+            on[u] = k < n;
+            a[u] = on[u] ? am[k] : make_uint2(0u, 0u);
+            r[u] = on[u] ? qm[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        V3 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *q = frame + 3 * (size_t)a[u].x;
+            p[u] = v3(q[0], q[1], q[2]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (on[u])
+                fit_accumulate<UNW, NV>(acc, p[u], v3(r[u].x, r[u].y, r[u].z), (double)r[u].w, (double)__uint_as_float(a[u].y));
+    }
+    block_reduce_store<NV, BLOCK>(acc, partials);
+}
+
 // the record of one fit from its 38 (21 without the unweighted block) sums; one thread
 __device__ __forceinline__ void fit_finalize(const double (&S)[FS_ALL], int nv, uint32_t n, int at_origin, float *o) {
     #pragma unroll
@@ -1328,14 +1380,26 @@ int molar_hip_fit_rmsd_batch(molar_hip_ctx *c, float *frames, size_t nframes, si
     ref.mass = cur.mass;
     const uint32_t F = (uint32_t)nframes;
     const uint32_t nb = blocks_for(c, cur.n, F);
-    MH_TRY(c->m_partials.reserve((size_t)nb * F * FS_ALL * 8));
+    const size_t part_bytes = (((size_t)nb * F * FS_ALL * 8) + 255) & ~(size_t)255;
+    const size_t qm_bytes = (((size_t)cur.n * 16) + 255) & ~(size_t)255;
+    MH_TRY(c->m_partials.reserve(part_bytes + qm_bytes + (size_t)cur.n * 8 + 256));
     MH_TRY(c->m_out.reserve((size_t)F * 18 * 4));
     float *o = c->m_out.as<float>();
     double *part = c->m_partials.as<double>();
+    float4 *pk_qm = reinterpret_cast<float4 *>(static_cast<char *>(c->m_partials.p) + part_bytes);
+    uint2 *pk_am = reinterpret_cast<uint2 *>(static_cast<char *>(c->m_partials.p) + part_bytes + qm_bytes);
     {
-        // one gather pass, one finalizer, and the write pass only if the caller wants the frames moved
+        // one gather pass (batches: behind the once-per-call packing of the frame-invariant columns), one finalizer,
+        // and the write pass only if the caller wants the frames moved
         Prof prof(c, 4);
-        hipLaunchKernelGGL(k_fit_sums<true>, dim3(nb, F), dim3(RB), 0, c->stream, cur, ref, part);
+        if (F >= 4) {
+            // frame-invariant columns gathered once (k_fit_pack), then one scattered read per atom and frame
+            hipLaunchKernelGGL(k_fit_pack, dim3((cur.n + RB - 1) / RB), dim3(RB), 0, c->stream, cur, ref, pk_qm, pk_am);
+            hipLaunchKernelGGL(k_fit_sums_packed<true>, dim3(nb, F), dim3(RB), 0, c->stream, cur.xyz, cur.frame_stride,
+                               cur.n, pk_qm, pk_am, part);
+        } else {
+            hipLaunchKernelGGL(k_fit_sums<true>, dim3(nb, F), dim3(RB), 0, c->stream, cur, ref, part);
+        }
         MH_TRY(ensure_pinned(c, (size_t)F * 18 * 4));
         // (the records also land in pinned host memory: the call ends with a stream wait instead of a device-to-host copy)
         hipLaunchKernelGGL(k_fit_final<FS_ALL>, dim3(F), dim3(64), 0, c->stream, part, nb, cur.n, 0, o,
