@@ -142,6 +142,42 @@ def test_fit_rmsd_batch(eng, orc32, orc64):
         assert out["rmsd"][f] < 0.2
 
 
+def test_fit_rmsd_batch_packed_equals_per_frame(eng, orc64):
+    """Batches of >= 4 frames gather the frame-invariant columns once (k_fit_pack) and read them coalesced; the records
+    must be those of the per-frame calls bit for bit, also when the reference selection is a different index set
+    (fit_transform takes sel2's own masses for cm2, measure.rs:512) and for a selection that is no multiple of anything."""
+    from molar_amd import api
+    rng = np.random.default_rng(11)
+    n, F, m = 30011, 7, 4099
+    ref = rng.uniform(0, 12, (n, 3)).astype(np.float32)
+    mass = rng.uniform(1, 40, n).astype(np.float32)
+    idx = np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+    ref_idx = np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+    frames = np.empty((F, n, 3), np.float32)
+    for f in range(F):
+        R = api.rotation_from_axis_angle(rng.normal(size=3), float(rng.uniform(-3, 3))).astype(np.float64)
+        frames[f] = rng.uniform(0, 12, (n, 3))
+        frames[f][idx.astype(np.int64)] = (ref[ref_idx.astype(np.int64)].astype(np.float64) @ R.T + rng.uniform(-3, 3, 3)
+                                           + rng.normal(0, 0.05, (m, 3))).astype(np.float32)
+    for ri in (idx, ref_idx):
+        for apply in (False, True):
+            wb = frames.copy()
+            batch = eng.fit_rmsd_batch(wb, mass, ref, idx=idx, ref_idx=ri, apply=apply)
+            for f in range(F):
+                w1 = frames[f:f + 1].copy()
+                one = eng.fit_rmsd_batch(w1, mass, ref, idx=idx, ref_idx=ri, apply=apply)
+                for k in ("rmsd", "R", "t", "com", "gyration"):
+                    assert np.array_equal(batch[k][f], one[k][0]), (k, f)
+                assert np.array_equal(wb[f], w1[0])
+    # and against the oracle (different index sets)
+    out = eng.fit_rmsd_batch(frames.copy(), mass, ref, idx=idx, ref_idx=ref_idx, apply=False)
+    for f in range(F):
+        R64, t64 = orc64.fit_transform(frames[f], mass, ref, mass, idx, ref_idx)
+        assert np.allclose(out["R"][f], R64, atol=1e-5)
+        assert np.allclose(out["t"][f], t64, rtol=1e-5, atol=2e-4)
+        assert out["rmsd"][f] < 0.2
+
+
 def _random_tails(rng, ntails, natoms):
     """Random-walk 'lipid tails' of 14-18 carbons with C-C ~0.153 nm and bond angle ~112 deg."""
     xyz = rng.uniform(0, 10, (natoms, 3)).astype(np.float32)

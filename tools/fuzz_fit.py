@@ -51,6 +51,14 @@ def run(ncases=300, seed=1, eng=None):
         # the single-call entry agrees with the batched one bit for bit (same kernels)
         R1, t1 = eng.fit_transform(cur, mass, ref, mass, idx, idx)
         ok = ok and np.array_equal(R1, out["R"][0]) and np.array_equal(t1, out["t"][0])
+        if case % 5 == 0:              # batches of >= 4 frames take the packed gather: records equal to the per-frame ones
+            nf = int(rng.integers(4, 8))   # (4..7 frames: same workgroup count as one frame, so the same partial sums; from 8 on
+                                           # blocks_for() gives a thread more atoms and the f64 partials group differently)
+            fr = np.stack([cur] + [(cur + rng.normal(0, 0.02, cur.shape)).astype(np.float32) for _ in range(nf - 1)])
+            ob = eng.fit_rmsd_batch(fr.copy(), mass, ref, idx=idx, apply=False)
+            for f in range(nf):
+                o1 = eng.fit_rmsd_batch(fr[f:f + 1].copy(), mass, ref, idx=idx, apply=False)
+                ok = ok and all(np.array_equal(ob[k][f], o1[k][0]) for k in ("rmsd", "R", "t", "com", "gyration"))
         if not ok:
             fails += 1
             print("MISMATCH", case, kind, natoms, m, out["rmsd"][0], w_rmsd, out["gyration"][0], w_gyr, np.abs(out["R"][0] - R).max())
