@@ -247,6 +247,33 @@ int molar_hip_fit_transform(molar_hip_ctx *ctx, const float *xyz1, size_t natoms
                             const uint64_t *idx2, size_t n2, const float *mass2, int at_origin, float R9[9],
                             float t3[3]);
 
+/* ---- MolAR built with its `f64` feature (Float = f64: molar/src/aliases.rs:10-13, molar/Cargo.toml:56-60).
+ * The non-periodic Measure / Modify methods on double-precision coordinates and masses, same argument meaning and
+ * error codes as the f32 entries above; every per-atom term is formed and accumulated in f64 (two passes where the
+ * reference has two: centre, then centred terms).  The search and the periodic variants are f32 only. */
+/* center_of_geometry :39-47, center_of_mass :60-75 (ERR_ZERO_MASS) */
+int molar_hip_center_of_geometry_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx,
+                                     size_t n, double out[3]);
+int molar_hip_center_of_mass_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                 const double *mass, double out[3]);
+/* gyration :78-87 */
+int molar_hip_gyration_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                           const double *mass, double *out);
+/* rmsd :485-504 (ERR_SIZES), rmsd_mw :538-558 */
+int molar_hip_rmsd_f64(molar_hip_ctx *ctx, const double *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                       const double *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2, double *out);
+int molar_hip_rmsd_mw_f64(molar_hip_ctx *ctx, const double *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                          const double *mass1, const double *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2,
+                          double *out);
+/* fit_transform :507-522 / fit_transform_at_origin :525-535: R column-major, p -> R p + t */
+int molar_hip_fit_transform_f64(molar_hip_ctx *ctx, const double *xyz1, size_t natoms1, const uint64_t *idx1,
+                                size_t n1, const double *mass1, const double *xyz2, size_t natoms2,
+                                const uint64_t *idx2, size_t n2, const double *mass2, int at_origin, double R9[9],
+                                double t3[3]);
+/* apply_transform (modify.rs:32-36), in place */
+int molar_hip_apply_transform_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                  const double R9[9], const double t3[3]);
+
 /* Batched selections (CSR): selection k = idx[offsets[k] .. offsets[k+1]).  Replaces the rayon loops over
  * ParSplit sub-selections / per-lipid selections (selection/system.rs:193-213, molar_membrane/src/lib.rs:
  * 135-137, lipid_molecule.rs:65-99) where one GPU launch per ~100-atom selection would be slower than the

@@ -86,6 +86,13 @@ SYMBOLS = {
     "molar_hip_rmsd": (_I, [_P, _P, _SZ, _P, _SZ, _P, _SZ, _P, _SZ, _P]),
     "molar_hip_rmsd_mw": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P]),
     "molar_hip_fit_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P, _I, _P, _P]),
+    "molar_hip_center_of_geometry_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
+    "molar_hip_center_of_mass_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
+    "molar_hip_gyration_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
+    "molar_hip_rmsd_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _SZ, _P, _SZ, _P]),
+    "molar_hip_rmsd_mw_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P]),
+    "molar_hip_fit_transform_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P, _I, _P, _P]),
+    "molar_hip_apply_transform_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
     "molar_hip_center_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _P]),
     "molar_hip_unwrap_simple_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _U8]),
     "molar_hip_membrane_initial_normals": (_I, [_SZ, _P, _P, _P, _P, _P, _P]),

@@ -645,6 +645,84 @@ class Engine:
         return dict(rmsd=rm, R=R.reshape(F, 3, 3).transpose(0, 2, 1).copy(), t=t, com=com, gyration=gy)
 
 
+def _f64(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        import torch
+        assert x.dtype == torch.float64
+        return x.contiguous()
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+class MeasureF64:
+    """The non-periodic Measure / Modify methods for MolAR's `f64` feature (Float = f64, molar/src/aliases.rs:10-13) on
+    an Engine's context: float64 coordinates and masses (numpy or torch CUDA), float64 results.  Same argument meaning
+    as the Engine methods of the same name; the search and the periodic variants exist in f32 only."""
+
+    def __init__(self, engine: "Engine"):
+        self.eng, self.lib, self.ctx = engine, engine.lib, engine.ctx
+
+    @staticmethod
+    def _sel(xyz, idx):
+        xyz = _f64(xyz); idx = _u64(idx)
+        xa, k1 = _addr(xyz); ia, k2 = _addr(idx)
+        natoms = xyz.shape[0] if xyz.ndim == 2 else xyz.shape[0] // 3
+        return xa, natoms, ia, (0 if idx is None else idx.shape[0]), (k1, k2)
+
+    def center_of_geometry(self, xyz, idx=None):
+        a = self._sel(xyz, idx)
+        out = np.zeros(3, np.float64)
+        check(self.lib.molar_hip_center_of_geometry_f64(self.ctx, *a[:4], out.ctypes.data))
+        return out
+
+    def center_of_mass(self, xyz, mass, idx=None):
+        a = self._sel(xyz, idx)
+        mass = _f64(mass); ma, km = _addr(mass)
+        out = np.zeros(3, np.float64)
+        check(self.lib.molar_hip_center_of_mass_f64(self.ctx, *a[:4], ma, out.ctypes.data))
+        return out
+
+    def gyration(self, xyz, mass, idx=None):
+        a = self._sel(xyz, idx)
+        mass = _f64(mass); ma, km = _addr(mass)
+        out = C.c_double(0)
+        check(self.lib.molar_hip_gyration_f64(self.ctx, *a[:4], ma, C.byref(out)))
+        return float(out.value)
+
+    def rmsd(self, xyz1, xyz2, idx1=None, idx2=None):
+        a1 = self._sel(xyz1, idx1); a2 = self._sel(xyz2, idx2)
+        out = C.c_double(0)
+        check(self.lib.molar_hip_rmsd_f64(self.ctx, *a1[:4], *a2[:4], C.byref(out)))
+        return float(out.value)
+
+    def rmsd_mw(self, xyz1, mass1, xyz2, idx1=None, idx2=None):
+        a1 = self._sel(xyz1, idx1); a2 = self._sel(xyz2, idx2)
+        mass1 = _f64(mass1); ma, km = _addr(mass1)
+        out = C.c_double(0)
+        check(self.lib.molar_hip_rmsd_mw_f64(self.ctx, *a1[:4], ma, *a2[:4], C.byref(out)))
+        return float(out.value)
+
+    def fit_transform(self, xyz1, mass1, xyz2, mass2, idx1=None, idx2=None, at_origin=False):
+        """(R, t) with p -> R @ p + t."""
+        a1 = self._sel(xyz1, idx1); a2 = self._sel(xyz2, idx2)
+        mass1 = _f64(mass1); m1, k1 = _addr(mass1)
+        mass2 = _f64(mass2); m2, k2 = _addr(mass2)
+        R = np.zeros(9, np.float64); t = np.zeros(3, np.float64)
+        check(self.lib.molar_hip_fit_transform_f64(self.ctx, *a1[:4], m1, *a2[:4], m2, 1 if at_origin else 0,
+                                                   R.ctypes.data, t.ctypes.data))
+        return R.reshape(3, 3).T.copy(), t
+
+    def apply_transform(self, xyz, R, t, idx=None):
+        """In place on xyz (numpy float64 C-contiguous array or torch CUDA tensor)."""
+        if not _is_torch(xyz):
+            assert xyz.dtype == np.float64 and xyz.flags.c_contiguous, "apply_transform works in place"
+        a = self._sel(xyz, idx)
+        R9 = np.ascontiguousarray(np.asarray(R, np.float64).reshape(3, 3).T).reshape(9)
+        t3 = np.ascontiguousarray(t, np.float64)
+        check(self.lib.molar_hip_apply_transform_f64(self.ctx, *a[:4], R9.ctypes.data, t3.ctypes.data))
+
+
 _MEMBRANE_FIELDS = ("head_markers", "normals", "valid", "quad_coefs", "mean_curv", "gauss_curv", "princ_curvs",
                     "princ_dirs", "area", "nvert", "neib_ids", "voro_vertexes", "fitted_patch_points")
 

@@ -17,7 +17,7 @@ namespace mh {
 // Cyclic Jacobi on a symmetric NxN (row-major a[N*N], destroyed).  w = eigenvalues,
 // v = eigenvectors as COLUMNS (v[r*N+c]).
 template <int N>
-__host__ __device__ inline void jacobi_sym(double *a, double *w, double *v) {
+__host__ __device__ inline void jacobi_sym(double *a, double *w, double *v, double tol2 = 1e-26) {
     // every loop over matrix indices is unrolled: on the GPU the two small matrices then live in registers (dynamic
     // indexing would put them in scratch memory, ~20 us per call for one lane)
 #pragma unroll
@@ -34,7 +34,8 @@ __host__ __device__ inline void jacobi_sym(double *a, double *w, double *v) {
         }
         // off-diagonal mass below 1e-13 of the diagonal (squared: 1e-26): eigenvectors good to ~1e-13, far below the f32
         // results they feed; every further sweep is ~2 us of dependent f64 divisions and square roots on one GPU lane
-        if (off <= 1e-26 * diag || off < 1e-300) break;
+        // (tol2: callers with f64 results ask for 1e-34 - one or two sweeps more, the convergence is quadratic)
+        if (off <= tol2 * diag || off < 1e-300) break;
 #pragma unroll
         for (int p = 0; p < N - 1; ++p)
 #pragma unroll
@@ -151,7 +152,9 @@ __host__ __device__ inline bool horn_dominant_eigenvector(const double *K, doubl
 
 // cov(r,c) = sum m * q2[r] * q1[c]  (measure.rs:621-623), column-major cov[c*3+r].
 // Writes R (column-major) with q2 ~ R q1.  Returns false if cov holds a NaN.
-__host__ __device__ inline bool rotation_from_cov(const double *cov, double *R) {
+// precise: Jacobi only, swept to f64 working precision (the f64 Measure entries; the Newton path accepts an eigenvector
+// with a 1e-10 relative residual, ample for f32 records only).
+__host__ __device__ inline bool rotation_from_cov(const double *cov, double *R, bool precise = false) {
     for (int i = 0; i < 9; ++i)
         if (cov[i] != cov[i]) return false;
     // S[a][b] = sum m q1[a] q2[b] = cov(b,a)
@@ -163,9 +166,9 @@ __host__ __device__ inline bool rotation_from_cov(const double *cov, double *R) 
                      Szx - Sxz,       Sxy + Syx,       -Sxx + Syy - Szz, Syz + Szy,
                      Sxy - Syx,       Szx + Sxz,       Syz + Szy,        -Sxx - Syy + Szz};
     double q0, qx, qy, qz;
-    if (!horn_dominant_eigenvector(Nm, q0, qx, qy, qz)) {
+    if (precise || !horn_dominant_eigenvector(Nm, q0, qx, qy, qz)) {
     double w[4], v[16];
-    jacobi_sym<4>(Nm, w, v);
+    jacobi_sym<4>(Nm, w, v, precise ? 1e-34 : 1e-26);
     // eigenvector of the largest eigenvalue (first one wins ties); selected with static indices, see jacobi_sym
     double wb = w[0];
     q0 = v[0]; qx = v[4]; qy = v[8]; qz = v[12];

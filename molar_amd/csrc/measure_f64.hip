@@ -1,0 +1,314 @@
+// measure_f64.hip — the non-periodic Measure / Modify methods for MolAR built with its `f64` feature
+// (Float = f64: molar/src/aliases.rs:10-13, molar/Cargo.toml:56-60): centres, gyration radius, RMSD, Kabsch fit and
+// apply_transform on double-precision coordinates and masses.
+//
+// Structure follows the reference, not the fused f32 path: a centre pass, then a pass over the centred terms
+// (gyration :78-87, rot_transform :613-643), every per-atom term formed in f64 in the reference's operation order and
+// accumulated per thread -> wave -> workgroup -> fixed-order total, so results agree with the reference's serial f64 sums
+// to ~1e-15 relative and do not depend on the launch shape.  These passes move 24-56 bytes per atom: HBM-bound like
+// their f32 counterparts (measure.hip); the search and the periodic variants have no f64 build.
+#include <cmath>
+#include <cstring>
+
+#include "common.hpp"
+#include "linalg3.hpp"
+
+using namespace mh;
+
+namespace {
+
+constexpr int RB = 256;
+
+struct SelD {
+    const double *xyz;
+    const uint64_t *idx;
+    const double *mass;   // full-length column, gathered through idx
+    uint32_t n;
+};
+
+__device__ __forceinline__ uint64_t atom_of(const SelD &s, uint32_t k) { return s.idx ? s.idx[k] : (uint64_t)k; }
+
+template <int NV>
+__device__ __forceinline__ void block_store(double *acc, double *partials) {
+    __shared__ double sh[RB / 64][NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double x = acc[v];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+        if (lane == 0) sh[wave][v] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+        for (int w = 0; w < RB / 64; ++w) s += sh[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * NV + threadIdx.x] = s;
+    }
+}
+
+// [0] = sum m, [1..3] = sum p*m, [4..6] = sum p      (center_of_mass :60-75, center_of_geometry :39-47)
+__global__ void __launch_bounds__(RB) k64_sums(SelD s, double *partials) {
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const double *p = s.xyz + 3 * a;
+        const double m = s.mass ? s.mass[a] : 1.0;
+        acc[0] += m;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            acc[1 + d] += p[d] * m;
+            acc[4 + d] += p[d];
+        }
+    }
+    block_store<7>(acc, partials);
+}
+
+// [0] = sum |p - c|^2 * m, [1] = sum m                  (gyration :78-87)
+__global__ void __launch_bounds__(RB) k64_central(SelD s, double cx, double cy, double cz, double *partials) {
+    double acc[2] = {0, 0};
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const double *p = s.xyz + 3 * a;
+        const double dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+        const double m = s.mass[a];
+        acc[0] += ((dx * dx + dy * dy) + dz * dz) * m;
+        acc[1] += m;
+    }
+    block_store<2>(acc, partials);
+}
+
+// [0] = sum |p - q|^2, [1] = sum |p - q|^2 * m1, [2] = sum m1      (rmsd :485-504, rmsd_mw :538-558)
+__global__ void __launch_bounds__(RB) k64_rmsd(SelD s1, SelD s2, double *partials) {
+    double acc[3] = {0, 0, 0};
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s1.n; k += gridDim.x * RB) {
+        const uint64_t a1 = atom_of(s1, k), a2 = atom_of(s2, k);
+        const double *p = s1.xyz + 3 * a1, *q = s2.xyz + 3 * a2;
+        const double dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+        const double d2 = (dx * dx + dy * dy) + dz * dz;
+        const double m = s1.mass ? s1.mass[a1] : 1.0;
+        acc[0] += d2;
+        acc[1] += d2 * m;
+        acc[2] += m;
+    }
+    block_store<3>(acc, partials);
+}
+
+// cov[c*3 + r] = sum m1 (q - c2)_r (p - c1)_c            (rot_transform :613-643; layout of rotation_from_cov)
+struct Centres {
+    double c1[3], c2[3];
+};
+__global__ void __launch_bounds__(RB) k64_cov(SelD s1, SelD s2, Centres C, double *partials) {
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s1.n; k += gridDim.x * RB) {
+        const uint64_t a1 = atom_of(s1, k), a2 = atom_of(s2, k);
+        const double *p = s1.xyz + 3 * a1, *q = s2.xyz + 3 * a2;
+        const double m = s1.mass[a1];
+        const double pc[3] = {p[0] - C.c1[0], p[1] - C.c1[1], p[2] - C.c1[2]};
+        const double qc[3] = {q[0] - C.c2[0], q[1] - C.c2[1], q[2] - C.c2[2]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) acc[c * 3 + r] += (qc[r] * pc[c]) * m;
+    }
+    block_store<9>(acc, partials);
+}
+
+// p <- R p + t (modify.rs:32-36), R column-major
+struct Iso {
+    double R[9], t[3];
+};
+__global__ void __launch_bounds__(RB) k64_apply(SelD s, double *xyz_rw, Iso T) {
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        double *p = xyz_rw + 3 * atom_of(s, k);
+        const double x = p[0], y = p[1], z = p[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) p[r] = ((T.R[r] * x + T.R[3 + r] * y) + T.R[6 + r] * z) + T.t[r];
+    }
+}
+
+// totals of the per-workgroup partials in a fixed order, written to pinned host memory
+template <int NV>
+__global__ void __launch_bounds__(64) k64_total(const double *partials, uint32_t nblk, double *out_host) {
+    double S[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) S[v] = 0.0;
+    for (uint32_t b = threadIdx.x; b < nblk; b += 64)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) S[v] += partials[(size_t)b * NV + v];
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) S[v] += __shfl_xor(S[v], off, 64);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) out_host[v] = S[v];
+}
+
+uint32_t blocks64(const molar_hip_ctx *c, uint32_t n) {
+    uint32_t nb = (n + RB * 4 - 1) / (RB * 4);
+    if (nb < 1) nb = 1;
+    const uint32_t cap = (uint32_t)c->num_cus * 4u;
+    return nb > cap ? cap : nb;
+}
+
+int stage64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n, const double *mass,
+            DevBuf &bx, DevBuf &bi, DevBuf &bm, SelD *out) {
+    if (!xyz) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "measure (f64): xyz pointer is null");
+    const size_t nsel = idx ? n : natoms;
+    if (nsel >= 0xFFFFFFFFull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "measure (f64): selection too large");
+    out->n = (uint32_t)nsel;
+    MH_TRY(to_device(c, xyz, natoms * 3, bx, &out->xyz));
+    MH_TRY(to_device(c, idx, idx ? n : 0, bi, &out->idx));
+    out->mass = nullptr;
+    if (mass) MH_TRY(to_device(c, mass, natoms, bm, &out->mass));
+    return 0;
+}
+
+template <int NV, class Launch>
+int reduce64(molar_hip_ctx *c, uint32_t n, double *host_out, Launch launch) {
+    const uint32_t nb = blocks64(c, n);
+    MH_TRY(c->m_partials.reserve((size_t)nb * NV * 8));
+    MH_TRY(ensure_pinned(c, 64 * 8));
+    launch(nb, c->m_partials.as<double>());
+    hipLaunchKernelGGL(k64_total<NV>, dim3(1), dim3(64), 0, c->stream, c->m_partials.as<double>(), nb,
+                       static_cast<double *>(c->h_pinned));
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(host_out, c->h_pinned, (size_t)NV * 8);
+    return 0;
+}
+
+int com64(molar_hip_ctx *c, const SelD &s, bool weighted, double out[3]) {
+    double r[7];
+    MH_TRY((reduce64<7>(c, s.n, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k64_sums, dim3(nb), dim3(RB), 0, c->stream, s, part);
+    })));
+    if (weighted) {
+        if (r[0] == 0.0) return fail(MOLAR_HIP_ERR_ZERO_MASS, "zero mass");
+        for (int d = 0; d < 3; ++d) out[d] = r[1 + d] / r[0];
+    } else {
+        for (int d = 0; d < 3; ++d) out[d] = r[4 + d] / (double)s.n;      // 0/0 = NaN for an empty selection, as the reference
+    }
+    return 0;
+}
+
+int rmsd64(molar_hip_ctx *c, const double *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1, const double *mass1,
+           const double *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2, bool weighted, double *out) {
+    const size_t s1n = idx1 ? n1 : natoms1, s2n = idx2 ? n2 : natoms2;
+    if (s1n != s2n) return fail(MOLAR_HIP_ERR_SIZES, "incompatible sizes: %zu and %zu", s1n, s2n);
+    SelD s1, s2;
+    MH_TRY(stage64(c, xyz1, natoms1, idx1, n1, mass1, c->m_xyz1, c->m_idx1, c->m_mass1, &s1));
+    MH_TRY(stage64(c, xyz2, natoms2, idx2, n2, nullptr, c->m_xyz2, c->m_idx2, c->m_mass2, &s2));
+    double r[3];
+    MH_TRY((reduce64<3>(c, s1.n, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k64_rmsd, dim3(nb), dim3(RB), 0, c->stream, s1, s2, part);
+    })));
+    if (weighted) {
+        if (r[2] == 0.0) return fail(MOLAR_HIP_ERR_ZERO_MASS, "zero mass");
+        *out = std::sqrt(r[1] / r[2]);
+    } else {
+        *out = std::sqrt(r[0] / (double)s1.n);
+    }
+    return MOLAR_HIP_OK;
+}
+
+}  // namespace
+
+#define MH64_CTX(c)                                                                  \
+    do {                                                                             \
+        if (!(c)) return ::mh::fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "null context"); \
+        MH_HIP(hipSetDevice((c)->device));                                           \
+    } while (0)
+
+extern "C" {
+
+int molar_hip_center_of_geometry_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                     double out[3]) {
+    MH64_CTX(c);
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    return com64(c, s, false, out);
+}
+
+int molar_hip_center_of_mass_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                 const double *mass, double out[3]) {
+    MH64_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "center_of_mass_f64: mass pointer is null");
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    return com64(c, s, true, out);
+}
+
+int molar_hip_gyration_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                           const double *mass, double *out) {
+    MH64_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "gyration_f64: mass pointer is null");
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    double cm[3], r[2];
+    MH_TRY(com64(c, s, true, cm));                                        // center_of_mass (:82)
+    MH_TRY((reduce64<2>(c, s.n, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k64_central, dim3(nb), dim3(RB), 0, c->stream, s, cm[0], cm[1], cm[2], part);
+    })));
+    *out = std::sqrt(r[0] / r[1]);
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_rmsd_f64(molar_hip_ctx *c, const double *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                       const double *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2, double *out) {
+    MH64_CTX(c);
+    return rmsd64(c, xyz1, natoms1, idx1, n1, nullptr, xyz2, natoms2, idx2, n2, false, out);
+}
+
+int molar_hip_rmsd_mw_f64(molar_hip_ctx *c, const double *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                          const double *mass1, const double *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2,
+                          double *out) {
+    MH64_CTX(c);
+    if (!mass1) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "rmsd_mw_f64: mass pointer is null");
+    return rmsd64(c, xyz1, natoms1, idx1, n1, mass1, xyz2, natoms2, idx2, n2, true, out);
+}
+
+int molar_hip_fit_transform_f64(molar_hip_ctx *c, const double *xyz1, size_t natoms1, const uint64_t *idx1, size_t n1,
+                                const double *mass1, const double *xyz2, size_t natoms2, const uint64_t *idx2, size_t n2,
+                                const double *mass2, int at_origin, double R9[9], double t3[3]) {
+    MH64_CTX(c);
+    if (!mass1 || (!at_origin && !mass2)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_transform_f64: mass pointer is null");
+    SelD s1, s2;
+    MH_TRY(stage64(c, xyz1, natoms1, idx1, n1, mass1, c->m_xyz1, c->m_idx1, c->m_mass1, &s1));
+    MH_TRY(stage64(c, xyz2, natoms2, idx2, n2, at_origin ? nullptr : mass2, c->m_xyz2, c->m_idx2, c->m_mass2, &s2));
+    Centres C{};
+    if (!at_origin) {
+        MH_TRY(com64(c, s1, true, C.c1));        // cm1 (:511)
+        MH_TRY(com64(c, s2, true, C.c2));        // cm2 with sel2's own masses (:512)
+    }
+    SelD a = s1, b = s2;
+    a.n = b.n = s1.n < s2.n ? s1.n : s2.n;       // izip! stops at the shorter selection (:621)
+    double cov[9];
+    MH_TRY((reduce64<9>(c, a.n, cov, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k64_cov, dim3(nb), dim3(RB), 0, c->stream, a, b, C, part);
+    })));
+    double R[9];
+    if (!rotation_from_cov(cov, R, /*precise=*/true)) return fail(MOLAR_HIP_ERR_SVD, "SVD failed");
+    std::memcpy(R9, R, sizeof R);
+    for (int r = 0; r < 3; ++r)                  // Translation(cm2) * rot * Translation(-cm1) (:521)
+        t3[r] = at_origin ? 0.0 : C.c2[r] + (((R[r] * -C.c1[0]) + (R[3 + r] * -C.c1[1])) + (R[6 + r] * -C.c1[2]));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_apply_transform_f64(molar_hip_ctx *c, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                  const double R9[9], const double t3[3]) {
+    MH64_CTX(c);
+    if (!R9 || !t3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "apply_transform_f64: null argument");
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    if (s.n == 0) return MOLAR_HIP_OK;
+    Iso T;
+    std::memcpy(T.R, R9, sizeof T.R);
+    std::memcpy(T.t, t3, sizeof T.t);
+    hipLaunchKernelGGL(k64_apply, dim3(blocks64(c, s.n)), dim3(RB), 0, c->stream, s, const_cast<double *>(s.xyz), T);
+    MH_HIP(hipGetLastError());
+    if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, s.xyz, natoms * 24, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+}  // extern "C"

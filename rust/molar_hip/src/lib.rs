@@ -289,6 +289,62 @@ impl Engine {
         })
     }
 
+    // ---- MolAR built with `f64` (Float = f64): the non-periodic Measure / Modify methods on double-precision data
+    // (header: "MolAR built with its `f64` feature").  The search and the periodic variants take f32 only.
+
+    /// `Measure::center_of_mass` (:60-75), f64
+    pub fn center_of_mass_f64(&self, coords: &[[f64; 3]], index: Option<&[usize]>, masses: &[f64]) -> Result<[f64; 3], EngineError> {
+        let (ip, n) = idx_ptr(index);
+        let mut out = [0f64; 3];
+        self.plugin.check(unsafe {
+            (self.plugin.fns.center_of_mass_f64)(self.ctx, coords.as_ptr() as *const f64, coords.len(), ip, n, masses.as_ptr(), out.as_mut_ptr())
+        })?;
+        Ok(out)
+    }
+
+    /// `Measure::gyration` (:78-87), f64
+    pub fn gyration_f64(&self, coords: &[[f64; 3]], index: Option<&[usize]>, masses: &[f64]) -> Result<f64, EngineError> {
+        let (ip, n) = idx_ptr(index);
+        let mut out = 0f64;
+        self.plugin.check(unsafe {
+            (self.plugin.fns.gyration_f64)(self.ctx, coords.as_ptr() as *const f64, coords.len(), ip, n, masses.as_ptr(), &mut out)
+        })?;
+        Ok(out)
+    }
+
+    /// `rmsd` (:485-504), f64
+    pub fn rmsd_f64(&self, c1: &[[f64; 3]], i1: Option<&[usize]>, c2: &[[f64; 3]], i2: Option<&[usize]>) -> Result<f64, EngineError> {
+        let (p1, n1) = idx_ptr(i1);
+        let (p2, n2) = idx_ptr(i2);
+        let mut out = 0f64;
+        self.plugin.check(unsafe {
+            (self.plugin.fns.rmsd_f64)(self.ctx, c1.as_ptr() as *const f64, c1.len(), p1, n1, c2.as_ptr() as *const f64, c2.len(), p2, n2, &mut out)
+        })?;
+        Ok(out)
+    }
+
+    /// `fit_transform` (:507-522), f64: (R column-major, t)
+    pub fn fit_transform_f64(
+        &self, c1: &[[f64; 3]], i1: Option<&[usize]>, m1: &[f64], c2: &[[f64; 3]], i2: Option<&[usize]>, m2: &[f64],
+    ) -> Result<([f64; 9], [f64; 3]), EngineError> {
+        let (p1, n1) = idx_ptr(i1);
+        let (p2, n2) = idx_ptr(i2);
+        let (mut r, mut t) = ([0f64; 9], [0f64; 3]);
+        self.plugin.check(unsafe {
+            (self.plugin.fns.fit_transform_f64)(self.ctx, c1.as_ptr() as *const f64, c1.len(), p1, n1, m1.as_ptr(),
+                                                c2.as_ptr() as *const f64, c2.len(), p2, n2, m2.as_ptr(), 0, r.as_mut_ptr(), t.as_mut_ptr())
+        })?;
+        Ok((r, t))
+    }
+
+    /// `Modify::apply_transform` (modify.rs:32-36), f64, in place
+    pub fn apply_transform_f64(&self, coords: &mut [[f64; 3]], index: Option<&[usize]>, r: &[f64; 9], t: &[f64; 3]) -> Result<(), EngineError> {
+        let (ip, n) = idx_ptr(index);
+        self.plugin.check(unsafe {
+            (self.plugin.fns.apply_transform_f64)(self.ctx, coords.as_mut_ptr() as *mut f64, coords.len(), ip, n, r.as_ptr(), t.as_ptr())
+        })
+    }
+
     /// `Modify::unwrap_simple_dim` (modify.rs:40-54), in place
     pub fn unwrap_simple_dim(&self, coords: &mut [[f32; 3]], index: Option<&[usize]>, box9: &[f32; 9], dims: u8) -> Result<(), EngineError> {
         let (ip, n) = idx_ptr(index);

@@ -1,0 +1,90 @@
+"""GPU parity of the f64 Measure / Modify entries (MolAR's `f64` feature, molar/src/aliases.rs:10-13) against the
+oracle's f64 build.  Both sides do every per-atom term in f64; the engine's sums are grouped per thread / wave /
+workgroup, the oracle's are serial: agreement is at the level of f64 summation noise, stated below."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12          # reductions of <= 1e6 f64 terms
+RTOL_ROT = 1e-10      # Horn's quaternion (engine) against the oracle's SVD-based Kabsch
+
+
+@pytest.fixture(scope="module")
+def m64():
+    from molar_amd import build
+    from molar_amd.api import Engine, MeasureF64
+    build.build_library()
+    return MeasureF64(Engine(0))
+
+
+def _system(n, seed, far=False):
+    from molar_amd import api
+    rng = np.random.default_rng(seed)
+    centre = rng.uniform(-400, 400, 3) if far else rng.uniform(0, 20, 3)
+    ref = centre + rng.normal(0, 3.0, (n, 3))
+    R = api.rotation_from_axis_angle(rng.normal(size=3), float(rng.uniform(-3, 3))).astype(np.float64)
+    cur = (ref - centre) @ R.T + centre + rng.uniform(-5, 5, 3) + rng.normal(0, 0.05, (n, 3))
+    mass = rng.uniform(1, 40, n)
+    return np.ascontiguousarray(cur), np.ascontiguousarray(ref), mass, rng
+
+
+@pytest.mark.parametrize("n,m,far", [(50_000, 5_000, False), (1_000_000, 100_000, False), (20_000, 20_000, True), (7, 3, False)])
+def test_f64_measure_matches_f64_oracle(m64, orc64, n, m, far):
+    cur, ref, mass, rng = _system(n, 100 + n % 97, far)
+    idx = None if m == n else np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+    scale = max(np.abs(cur).max(), np.abs(ref).max())
+    assert np.allclose(m64.center_of_geometry(cur, idx), orc64.center_of_geometry(cur, idx), rtol=0, atol=RTOL * scale)
+    assert np.allclose(m64.center_of_mass(cur, mass, idx), orc64.center_of_mass(cur, mass, idx), rtol=0, atol=RTOL * scale)
+    assert m64.gyration(cur, mass, idx) == pytest.approx(orc64.gyration(cur, mass, idx), rel=RTOL)
+    assert m64.rmsd(cur, ref, idx, idx) == pytest.approx(orc64.rmsd(cur, ref, idx, idx), rel=RTOL)
+    assert m64.rmsd_mw(cur, mass, ref, idx, idx) == pytest.approx(orc64.rmsd_mw(cur, mass, ref, idx, idx), rel=RTOL)
+    # (at_origin on a cloud 400 nm from the origin is a rank-one covariance plus noise: neither side's rotation is
+    # determined to better than ~1e-7 there, so that combination is left out)
+    for at_origin in ((False,) if far else (False, True)):
+        R, t = m64.fit_transform(cur, mass, ref, mass, idx, idx, at_origin=at_origin)
+        Ro, to = (orc64.fit_transform_at_origin(cur, mass, ref, idx, idx) if at_origin
+                  else orc64.fit_transform(cur, mass, ref, mass, idx, idx))
+        assert np.allclose(R, Ro, rtol=0, atol=RTOL_ROT)
+        assert np.allclose(t, to, rtol=0, atol=RTOL_ROT * scale * 10)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-13) and np.linalg.det(R) == pytest.approx(1.0, abs=1e-13)
+    R, t = m64.fit_transform(cur, mass, ref, mass, idx, idx)
+    moved = cur.copy()
+    m64.apply_transform(moved, R, t, idx)
+    assert np.array_equal(moved, orc64.apply_transform(cur, R, t, idx))          # same f64 operations, same bits
+    # the fit brings the selection onto the reference: RMSD ~ the noise that was added, far below the f32 floor
+    assert m64.rmsd(moved, ref, idx, idx) == pytest.approx(orc64.rmsd(orc64.apply_transform(cur, R, t, idx), ref, idx, idx), rel=1e-9)
+    assert m64.rmsd(moved, ref, idx, idx) < 0.2
+
+
+def test_f64_resolves_what_f32_cannot(m64, orc64):
+    """A selection 400 nm from the origin moved by 1e-9 nm: the f64 entries see it (RMSD to 1e-3 relative), f32 cannot
+    represent the displacement at all (ulp(400) = 3e-5)."""
+    rng = np.random.default_rng(5)
+    n = 4096
+    ref = np.array([400.0, -350.0, 380.0]) + rng.normal(0, 1.0, (n, 3))
+    cur = ref + rng.normal(0, 1e-9, (n, 3))
+    got, want = m64.rmsd(cur, ref), orc64.rmsd(cur, ref)
+    assert got == pytest.approx(want, rel=1e-12) and 1e-9 < got < 3e-9
+    assert (np.float32(cur) != np.float32(ref)).mean() < 1e-3        # only values that sat on a rounding boundary differ
+
+
+def test_f64_device_resident_and_errors(m64, orc64):
+    import torch
+    from molar_amd.api import MolarHipError
+    cur, ref, mass, rng = _system(30_000, 9)
+    idx = np.sort(rng.choice(30_000, 3_000, replace=False)).astype(np.uint64)
+    d_cur, d_ref, d_mass = (torch.from_numpy(a).cuda() for a in (cur, ref, mass))
+    d_idx = torch.from_numpy(idx.astype(np.int64)).cuda()
+    assert m64.gyration(d_cur, d_mass, d_idx) == m64.gyration(cur, mass, idx)              # same kernels, same grouping
+    R, t = m64.fit_transform(d_cur, d_mass, d_ref, d_mass, d_idx, d_idx)
+    R2, t2 = m64.fit_transform(cur, mass, ref, mass, idx, idx)
+    assert np.array_equal(R, R2) and np.array_equal(t, t2)
+    m64.apply_transform(d_cur, R, t, d_idx)
+    assert np.array_equal(d_cur.cpu().numpy(), orc64.apply_transform(cur, R, t, idx))
+    with pytest.raises(MolarHipError) as e:
+        m64.center_of_mass(cur, np.zeros_like(mass), idx)
+    assert e.value.code == 2                                                                 # MeasureError::ZeroMass
+    with pytest.raises(MolarHipError) as e:
+        m64.rmsd(cur, ref, idx, idx[:-1])
+    assert e.value.code == 1                                                                 # MeasureError::Sizes
