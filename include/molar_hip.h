@@ -270,6 +270,13 @@ int molar_hip_fit_transform_f64(molar_hip_ctx *ctx, const double *xyz1, size_t n
                                 size_t n1, const double *mass1, const double *xyz2, size_t natoms2,
                                 const uint64_t *idx2, size_t n2, const double *mass2, int at_origin, double R9[9],
                                 double t3[3]);
+/* min_max :22-36; inertia :90-99 (moments ascending, axes column-major, optional raw tensor); translate modify.rs:16-23 */
+int molar_hip_min_max_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                          double lower[3], double upper[3]);
+int molar_hip_inertia_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                          const double *mass, double moments[3], double axes9[9], double tensor9[9]);
+int molar_hip_translate_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                            const double shift3[3]);
 /* apply_transform (modify.rs:32-36), in place */
 int molar_hip_apply_transform_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
                                   const double R9[9], const double t3[3]);

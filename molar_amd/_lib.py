@@ -93,6 +93,9 @@ SYMBOLS = {
     "molar_hip_rmsd_mw_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P]),
     "molar_hip_fit_transform_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P, _I, _P, _P]),
     "molar_hip_apply_transform_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
+    "molar_hip_min_max_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
+    "molar_hip_inertia_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _P, _P]),
+    "molar_hip_translate_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
     "molar_hip_center_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _P]),
     "molar_hip_unwrap_simple_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _U8]),
     "molar_hip_membrane_initial_normals": (_I, [_SZ, _P, _P, _P, _P, _P, _P]),

@@ -713,6 +713,27 @@ class MeasureF64:
                                                    R.ctypes.data, t.ctypes.data))
         return R.reshape(3, 3).T.copy(), t
 
+    def min_max(self, xyz, idx=None):
+        a = self._sel(xyz, idx)
+        lo = np.zeros(3, np.float64); hi = np.zeros(3, np.float64)
+        check(self.lib.molar_hip_min_max_f64(self.ctx, *a[:4], lo.ctypes.data, hi.ctypes.data))
+        return lo, hi
+
+    def inertia(self, xyz, mass, idx=None):
+        """(moments[3] ascending, axes 3x3 with axes as columns, raw tensor 3x3)."""
+        a = self._sel(xyz, idx)
+        mass = _f64(mass); ma, km = _addr(mass)
+        mom = np.zeros(3, np.float64); axes = np.zeros(9, np.float64); tens = np.zeros(9, np.float64)
+        check(self.lib.molar_hip_inertia_f64(self.ctx, *a[:4], ma, mom.ctypes.data, axes.ctypes.data, tens.ctypes.data))
+        return mom, axes.reshape(3, 3).T.copy(), tens.reshape(3, 3).T.copy()
+
+    def translate(self, xyz, shift, idx=None):
+        if not _is_torch(xyz):
+            assert xyz.dtype == np.float64 and xyz.flags.c_contiguous, "translate works in place"
+        a = self._sel(xyz, idx)
+        sh = np.ascontiguousarray(shift, np.float64)
+        check(self.lib.molar_hip_translate_f64(self.ctx, *a[:4], sh.ctypes.data))
+
     def apply_transform(self, xyz, R, t, idx=None):
         """In place on xyz (numpy float64 C-contiguous array or torch CUDA tensor)."""
         if not _is_torch(xyz):

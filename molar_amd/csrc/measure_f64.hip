@@ -1,12 +1,14 @@
 // measure_f64.hip — the non-periodic Measure / Modify methods for MolAR built with its `f64` feature
 // (Float = f64: molar/src/aliases.rs:10-13, molar/Cargo.toml:56-60): centres, gyration radius, RMSD, Kabsch fit and
-// apply_transform on double-precision coordinates and masses.
+// apply_transform, plus min_max, the inertia tensor with its principal axes and translate, on double-precision
+// coordinates and masses.
 //
 // Structure follows the reference, not the fused f32 path: a centre pass, then a pass over the centred terms
 // (gyration :78-87, rot_transform :613-643), every per-atom term formed in f64 in the reference's operation order and
 // accumulated per thread -> wave -> workgroup -> fixed-order total, so results agree with the reference's serial f64 sums
 // to ~1e-15 relative and do not depend on the launch shape.  These passes move 24-56 bytes per atom: HBM-bound like
 // their f32 counterparts (measure.hip); the search and the periodic variants have no f64 build.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -111,6 +113,68 @@ __global__ void __launch_bounds__(RB) k64_cov(SelD s1, SelD s2, Centres C, doubl
             for (int r = 0; r < 3; ++r) acc[c * 3 + r] += (qc[r] * pc[c]) * m;
     }
     block_store<9>(acc, partials);
+}
+
+// inertia tensor about c (:577-590): [0..2] = T00, T11, T22, [3..5] = T01, T02, T12 (negated products)
+__global__ void __launch_bounds__(RB) k64_inertia(SelD s, double cx, double cy, double cz, double *partials) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const double *p = s.xyz + 3 * a;
+        const double x = p[0] - cx, y = p[1] - cy, z = p[2] - cz;
+        const double m = s.mass[a];
+        acc[0] += m * (y * y + z * z);
+        acc[1] += m * (x * x + z * z);
+        acc[2] += m * (x * x + y * y);
+        acc[3] -= m * x * y;
+        acc[4] -= m * x * z;
+        acc[5] -= m * y * z;
+    }
+    block_store<6>(acc, partials);
+}
+
+// min_max (:22-36): per-workgroup lower / upper corners, folded by the host (min / max are exact in any order)
+__global__ void __launch_bounds__(RB) k64_minmax(SelD s, double *partials) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const double *p = s.xyz + 3 * atom_of(s, k);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = p[d] < lo[d] ? p[d] : lo[d];
+            hi[d] = p[d] > hi[d] ? p[d] : hi[d];
+        }
+    }
+    __shared__ double sh[RB / 64][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const double a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+            lo[d] = a < lo[d] ? a : lo[d];
+            hi[d] = b > hi[d] ? b : hi[d];
+        }
+        if (lane == 0) {
+            sh[wave][d] = lo[d];
+            sh[wave][3 + d] = hi[d];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = sh[0][threadIdx.x];
+        for (int w = 1; w < RB / 64; ++w) {
+            const double o = sh[w][threadIdx.x];
+            v = threadIdx.x < 3 ? (o < v ? o : v) : (o > v ? o : v);
+        }
+        partials[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// translate (modify.rs:16-23)
+__global__ void __launch_bounds__(RB) k64_translate(SelD s, double *xyz_rw, double sx, double sy, double sz) {
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        double *p = xyz_rw + 3 * atom_of(s, k);
+        p[0] += sx; p[1] += sy; p[2] += sz;
+    }
 }
 
 // p <- R p + t (modify.rs:32-36), R column-major
@@ -291,6 +355,84 @@ int molar_hip_fit_transform_f64(molar_hip_ctx *c, const double *xyz1, size_t nat
     std::memcpy(R9, R, sizeof R);
     for (int r = 0; r < 3; ++r)                  // Translation(cm2) * rot * Translation(-cm1) (:521)
         t3[r] = at_origin ? 0.0 : C.c2[r] + (((R[r] * -C.c1[0]) + (R[3 + r] * -C.c1[1])) + (R[6 + r] * -C.c1[2]));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_min_max_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n, double lower[3],
+                          double upper[3]) {
+    MH64_CTX(c);
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    const uint32_t nb = blocks64(c, s.n);
+    MH_TRY(c->m_partials.reserve((size_t)nb * 6 * 8));
+    MH_TRY(ensure_pinned(c, (size_t)nb * 6 * 8));
+    hipLaunchKernelGGL(k64_minmax, dim3(nb), dim3(RB), 0, c->stream, s, c->m_partials.as<double>());
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipMemcpyAsync(c->h_pinned, c->m_partials.p, (size_t)nb * 6 * 8, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    const double *part = static_cast<const double *>(c->h_pinned);
+    for (int d = 0; d < 3; ++d) {
+        // the reference starts from +-Float::MAX (:23-24); an empty selection returns those
+        double lo = 1.7976931348623157e308, hi = -1.7976931348623157e308;
+        for (uint32_t b = 0; b < nb; ++b) {
+            lo = part[b * 6 + d] < lo ? part[b * 6 + d] : lo;
+            hi = part[b * 6 + 3 + d] > hi ? part[b * 6 + 3 + d] : hi;
+        }
+        lower[d] = lo;
+        upper[d] = hi;
+    }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_inertia_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                          const double *mass, double moments[3], double axes9[9], double tensor9[9]) {
+    MH64_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "inertia_f64: mass pointer is null");
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    double cm[3], r[6];
+    MH_TRY(com64(c, s, true, cm));                                        // center_of_mass (:94)
+    MH_TRY((reduce64<6>(c, s.n, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k64_inertia, dim3(nb), dim3(RB), 0, c->stream, s, cm[0], cm[1], cm[2], part);
+    })));
+    const double T[9] = {r[0], r[3], r[4], r[3], r[1], r[5], r[4], r[5], r[2]};
+    if (tensor9) std::memcpy(tensor9, T, sizeof T);
+    double A[9], w[3], V[9];
+    std::memcpy(A, T, sizeof A);
+    jacobi_sym<3>(A, w, V, 1e-34);
+    int ord[3] = {0, 1, 2};   // ascending moments (:594-601)
+    for (int a = 0; a < 2; ++a)
+        for (int q = a + 1; q < 3; ++q)
+            if (w[ord[q]] < w[ord[a]]) std::swap(ord[a], ord[q]);
+    for (int k = 0; k < 3; ++k) moments[k] = w[ord[k]];
+    // col0, col1 normalised, col2 = col0 x col1 (:603-607)
+    double e[2][3];
+    for (int k = 0; k < 2; ++k) {
+        const double v[3] = {V[0 * 3 + ord[k]], V[1 * 3 + ord[k]], V[2 * 3 + ord[k]]};
+        const double nn = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+        for (int d = 0; d < 3; ++d) e[k][d] = v[d] / nn;
+    }
+    const double c2[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2],
+                          e[0][0] * e[1][1] - e[0][1] * e[1][0]};
+    for (int d = 0; d < 3; ++d) {
+        axes9[0 * 3 + d] = e[0][d];
+        axes9[1 * 3 + d] = e[1][d];
+        axes9[2 * 3 + d] = c2[d];
+    }
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_translate_f64(molar_hip_ctx *c, double *xyz, size_t natoms, const uint64_t *idx, size_t n, const double shift3[3]) {
+    MH64_CTX(c);
+    if (!shift3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "translate_f64: null argument");
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    if (s.n == 0) return MOLAR_HIP_OK;
+    hipLaunchKernelGGL(k64_translate, dim3(blocks64(c, s.n)), dim3(RB), 0, c->stream, s, const_cast<double *>(s.xyz), shift3[0],
+                       shift3[1], shift3[2]);
+    MH_HIP(hipGetLastError());
+    if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, s.xyz, natoms * 24, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
     return MOLAR_HIP_OK;
 }
 

@@ -385,6 +385,14 @@ class Oracle:
         self.lib.orc_apply_transform(self._p(xyz), self._p(idx), C.c_size_t(n), self._p(Rf), self._p(t))
         return xyz
 
+    def translate(self, xyz, shift, idx=None):
+        """Returns a translated COPY of xyz (modify.rs:16-23)."""
+        xyz, idx, n = self._sel(xyz, idx)
+        xyz = xyz.copy()
+        sh = self.arr(shift)
+        self.lib.orc_translate(self._p(xyz), self._p(idx), C.c_size_t(n), self._p(sh))
+        return xyz
+
     def unwrap_simple_dim(self, xyz, box, dims=PBC_FULL, idx=None):
         xyz, idx, n = self._sel(xyz, idx)
         xyz = xyz.copy()

@@ -41,6 +41,19 @@ def test_f64_measure_matches_f64_oracle(m64, orc64, n, m, far):
     assert m64.rmsd_mw(cur, mass, ref, idx, idx) == pytest.approx(orc64.rmsd_mw(cur, mass, ref, idx, idx), rel=RTOL)
     # (at_origin on a cloud 400 nm from the origin is a rank-one covariance plus noise: neither side's rotation is
     # determined to better than ~1e-7 there, so that combination is left out)
+    lo, hi = m64.min_max(cur, idx)
+    rlo, rhi = orc64.min_max(cur, idx)
+    assert np.array_equal(lo, rlo) and np.array_equal(hi, rhi)
+    mom, axes, tens = m64.inertia(cur, mass, idx)
+    rmom, raxes = orc64.inertia(cur, mass, idx)
+    rt = orc64.inertia_tensor(cur, mass, idx)
+    assert np.allclose(tens, rt, rtol=0, atol=1e-11 * np.abs(rt).max())
+    assert np.allclose(mom, rmom, rtol=1e-10)
+    assert np.allclose(axes.T @ axes, np.eye(3), atol=1e-13) and np.linalg.det(axes) == pytest.approx(1.0, abs=1e-13)
+    assert np.allclose(axes @ np.diag(mom) @ axes.T, rt, rtol=0, atol=1e-10 * np.abs(rt).max())   # axis signs are open
+    tr = cur.copy()
+    m64.translate(tr, [0.25, -1.5, 3.0], idx)
+    assert np.array_equal(tr, orc64.translate(cur, [0.25, -1.5, 3.0], idx))
     for at_origin in ((False,) if far else (False, True)):
         R, t = m64.fit_transform(cur, mass, ref, mass, idx, idx, at_origin=at_origin)
         Ro, to = (orc64.fit_transform_at_origin(cur, mass, ref, idx, idx) if at_origin
