@@ -277,6 +277,14 @@ int molar_hip_inertia_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, 
                           const double *mass, double moments[3], double axes9[9], double tensor9[9]);
 int molar_hip_translate_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
                             const double shift3[3]);
+/* the per-frame loop of benches/comparison_small.rs:14-25 in f64, same argument meaning as molar_hip_fit_rmsd_batch:
+ * every frame's selection fitted onto the reference selection (masses of the frame's atoms; the reference centre with
+ * the same column through ref_idx), RMSD / centre of mass / gyration of the FITTED selection, frames moved if apply.
+ * Outputs (each optional): rmsd[F], R[F][9] column-major, t[F][3], com[F][3], gyr[F]. */
+int molar_hip_fit_rmsd_batch_f64(molar_hip_ctx *ctx, double *frames, size_t nframes, size_t natoms,
+                                 const uint64_t *idx, size_t n, const double *mass, const double *ref_xyz,
+                                 size_t ref_natoms, const uint64_t *ref_idx, int apply, double *rmsd_out,
+                                 double *R_out, double *t_out, double *com_out, double *gyr_out);
 /* apply_transform (modify.rs:32-36), in place */
 int molar_hip_apply_transform_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
                                   const double R9[9], const double t3[3]);

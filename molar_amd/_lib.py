@@ -93,6 +93,7 @@ SYMBOLS = {
     "molar_hip_rmsd_mw_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P]),
     "molar_hip_fit_transform_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P, _I, _P, _P]),
     "molar_hip_apply_transform_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
+    "molar_hip_fit_rmsd_batch_f64": (_I, [_P, _P, _SZ, _SZ, _P, _SZ, _P, _P, _SZ, _P, _I, _P, _P, _P, _P, _P]),
     "molar_hip_min_max_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
     "molar_hip_inertia_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _P, _P]),
     "molar_hip_translate_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P]),

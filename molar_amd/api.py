@@ -713,6 +713,29 @@ class MeasureF64:
                                                    R.ctypes.data, t.ctypes.data))
         return R.reshape(3, 3).T.copy(), t
 
+    def fit_rmsd_batch(self, frames, mass, ref_xyz, idx=None, ref_idx=None, apply=True):
+        """frames: float64 [F, natoms, 3] (numpy, modified in place if apply; or torch CUDA tensor).
+        Returns dict(rmsd[F], R[F,3,3], t[F,3], com[F,3], gyration[F]) in float64."""
+        if not _is_torch(frames):
+            assert frames.dtype == np.float64 and frames.flags.c_contiguous
+        else:
+            import torch
+            assert frames.dtype == torch.float64 and frames.is_contiguous()
+        F, natoms = frames.shape[0], frames.shape[1]
+        fa, kf = _addr(frames)
+        idx = _u64(idx); ref_idx = _u64(ref_idx) if ref_idx is not None else idx
+        ia, ki = _addr(idx); ra, kr = _addr(ref_idx)
+        n = 0 if idx is None else idx.shape[0]
+        mass = _f64(mass); ma, km = _addr(mass)
+        ref_xyz = _f64(ref_xyz); xa, kx = _addr(ref_xyz)
+        ref_natoms = ref_xyz.shape[0] if ref_xyz.ndim == 2 else ref_xyz.shape[0] // 3
+        rm = np.zeros(F, np.float64); R = np.zeros((F, 9), np.float64); t = np.zeros((F, 3), np.float64)
+        com = np.zeros((F, 3), np.float64); gy = np.zeros(F, np.float64)
+        check(self.lib.molar_hip_fit_rmsd_batch_f64(self.ctx, fa, F, natoms, ia, n, ma, xa, ref_natoms, ra,
+                                                    1 if apply else 0, rm.ctypes.data, R.ctypes.data, t.ctypes.data,
+                                                    com.ctypes.data, gy.ctypes.data))
+        return dict(rmsd=rm, R=R.reshape(F, 3, 3).transpose(0, 2, 1).copy(), t=t, com=com, gyration=gy)
+
     def min_max(self, xyz, idx=None):
         a = self._sel(xyz, idx)
         lo = np.zeros(3, np.float64); hi = np.zeros(3, np.float64)

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "common.hpp"
 #include "linalg3.hpp"
@@ -188,6 +189,144 @@ __global__ void __launch_bounds__(RB) k64_apply(SelD s, double *xyz_rw, Iso T) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) p[r] = ((T.R[r] * x + T.R[3 + r] * y) + T.R[6 + r] * z) + T.t[r];
     }
+}
+
+// ---- the per-frame loop (benches/comparison_small.rs:14-25) over a batch of frames: fit every frame's selection onto the
+// reference selection, RMSD / centre of mass / gyration of the fitted selection, optionally move the frame.  Three
+// gather passes per frame (centre; centred covariance; residual of the fitted positions), each frame's totals and its
+// rotation derived on the device, so a batch is six launches whatever its length.
+struct BatchD {
+    const double *frames;      // [F][natoms][3]
+    size_t stride;             // doubles between frames
+    const uint64_t *idx;       // selection of the frames (NULL = all atoms)
+    const double *mass;        // full-length column
+    const double *ref;         // reference coordinates
+    const uint64_t *ref_idx;   // its selection (NULL = all atoms)
+    uint32_t n;
+};
+constexpr int REC64 = 20;      // per frame: R[9] (column-major), t[3], rmsd, com[3], gyration, status, c1 scratch is separate
+
+template <int NV>
+__device__ __forceinline__ void block_store_y(double *acc, double *partials) {
+    block_store<NV>(acc, partials + (size_t)blockIdx.y * gridDim.x * NV);
+}
+
+// sum over the partial rows of frame f, result valid in every lane
+template <int NV>
+__device__ __forceinline__ void frame_total(const double *partials, uint32_t nblk, uint32_t f, double (&S)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) S[v] = 0.0;
+    for (uint32_t b = threadIdx.x; b < nblk; b += 64)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) S[v] += partials[((size_t)f * nblk + b) * NV + v];
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) S[v] += __shfl_xor(S[v], off, 64);
+}
+
+__global__ void __launch_bounds__(RB) k64b_sums(BatchD B, double *partials) {
+    double acc[4] = {0, 0, 0, 0};
+    const double *fr = B.frames + (size_t)blockIdx.y * B.stride;
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < B.n; k += gridDim.x * RB) {
+        const uint64_t a = B.idx ? B.idx[k] : (uint64_t)k;
+        const double *p = fr + 3 * a;
+        const double m = B.mass[a];
+        acc[0] += m;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[1 + d] += p[d] * m;
+    }
+    block_store_y<4>(acc, partials);
+}
+
+// centres[f] = {c1.x, c1.y, c1.z, sum m}; status in rec
+__global__ void __launch_bounds__(64) k64b_centres(const double *partials, uint32_t nblk, double *centres, double *rec) {
+    double S[4];
+    frame_total<4>(partials, nblk, blockIdx.x, S);
+    if (threadIdx.x != 0) return;
+    double *c = centres + 4 * (size_t)blockIdx.x;
+    rec[REC64 * (size_t)blockIdx.x + 17] = S[0] == 0.0 ? (double)MOLAR_HIP_ERR_ZERO_MASS : 0.0;
+    c[3] = S[0];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c[d] = S[0] == 0.0 ? 0.0 : S[1 + d] / S[0];
+}
+
+// [0..8] = cov[c*3+r] = sum m (q - c2)_r (p - c1)_c, [9] = sum m |p - c1|^2
+__global__ void __launch_bounds__(RB) k64b_cov(BatchD B, const double *centres, Centres C2, double *partials) {
+    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const double *fr = B.frames + (size_t)blockIdx.y * B.stride;
+    const double *c1 = centres + 4 * (size_t)blockIdx.y;
+    const double c1x = c1[0], c1y = c1[1], c1z = c1[2];
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < B.n; k += gridDim.x * RB) {
+        const uint64_t a1 = B.idx ? B.idx[k] : (uint64_t)k, a2 = B.ref_idx ? B.ref_idx[k] : (uint64_t)k;
+        const double *p = fr + 3 * a1, *q = B.ref + 3 * a2;
+        const double m = B.mass[a1];
+        const double pc[3] = {p[0] - c1x, p[1] - c1y, p[2] - c1z};
+        const double qc[3] = {q[0] - C2.c2[0], q[1] - C2.c2[1], q[2] - C2.c2[2]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) acc[c * 3 + r] += (qc[r] * pc[c]) * m;
+        acc[9] += ((pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]) * m;
+    }
+    block_store_y<10>(acc, partials);
+}
+
+// rotation, translation, centre of mass and gyration radius of the fitted selection of frame blockIdx.x
+__global__ void __launch_bounds__(64) k64b_rot(const double *partials, uint32_t nblk, const double *centres, Centres C2,
+                                               double *rec) {
+    double S[10];
+    frame_total<10>(partials, nblk, blockIdx.x, S);
+    if (threadIdx.x != 0) return;
+    double *o = rec + REC64 * (size_t)blockIdx.x;
+    if (o[17] != 0.0) return;
+    const double *c1 = centres + 4 * (size_t)blockIdx.x;
+    double R[9];
+    if (!rotation_from_cov(S, R, true)) {
+        o[17] = (double)MOLAR_HIP_ERR_SVD;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = R[i];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        o[9 + r] = C2.c2[r] + (((R[r] * -c1[0]) + (R[3 + r] * -c1[1])) + (R[6 + r] * -c1[2]));     // (:521)
+        o[13 + r] = (((R[r] * c1[0]) + (R[3 + r] * c1[1])) + (R[6 + r] * c1[2])) + o[9 + r];       // R cm + t
+    }
+    o[16] = sqrt(S[9] / c1[3]);                                                                   // rigid motion keeps it
+}
+
+// sum |R p + t - q|^2 of the fitted positions; with `apply` the frame's selection is moved (modify.rs:32-36)
+__global__ void __launch_bounds__(RB) k64b_resid(BatchD B, const double *rec, int apply, double *frames_rw, double *partials) {
+    double acc[1] = {0};
+    const double *o = rec + REC64 * (size_t)blockIdx.y;
+    double *fr = frames_rw + (size_t)blockIdx.y * B.stride;
+    if (o[17] == 0.0) {
+        for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < B.n; k += gridDim.x * RB) {
+            const uint64_t a1 = B.idx ? B.idx[k] : (uint64_t)k, a2 = B.ref_idx ? B.ref_idx[k] : (uint64_t)k;
+            double *p = fr + 3 * a1;
+            const double *q = B.ref + 3 * a2;
+            const double x = p[0], y = p[1], z = p[2];
+            double w[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) w[r] = ((o[r] * x + o[3 + r] * y) + o[6 + r] * z) + o[9 + r];
+            const double dx = q[0] - w[0], dy = q[1] - w[1], dz = q[2] - w[2];
+            acc[0] += (dx * dx + dy * dy) + dz * dz;
+            if (apply) {
+                p[0] = w[0]; p[1] = w[1]; p[2] = w[2];
+            }
+        }
+    }
+    block_store_y<1>(acc, partials);
+}
+
+__global__ void __launch_bounds__(64) k64b_rmsd(const double *partials, uint32_t nblk, uint32_t n, double *rec, double *rec_host) {
+    double S[1];
+    frame_total<1>(partials, nblk, blockIdx.x, S);
+    if (threadIdx.x != 0) return;
+    double *o = rec + REC64 * (size_t)blockIdx.x;
+    o[12] = sqrt(S[0] / (double)n);
+#pragma unroll
+    for (int i = 0; i < REC64; ++i) rec_host[REC64 * (size_t)blockIdx.x + i] = o[i];
 }
 
 // totals of the per-workgroup partials in a fixed order, written to pinned host memory
@@ -433,6 +572,76 @@ int molar_hip_translate_f64(molar_hip_ctx *c, double *xyz, size_t natoms, const 
     MH_HIP(hipGetLastError());
     if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, s.xyz, natoms * 24, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_fit_rmsd_batch_f64(molar_hip_ctx *c, double *frames, size_t nframes, size_t natoms, const uint64_t *idx, size_t n,
+                                 const double *mass, const double *ref_xyz, size_t ref_natoms, const uint64_t *ref_idx,
+                                 int apply, double *rmsd_out, double *R_out, double *t_out, double *com_out, double *gyr_out) {
+    MH64_CTX(c);
+    if (!frames || !mass || !ref_xyz) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_rmsd_batch_f64: null argument");
+    if (nframes == 0) return MOLAR_HIP_OK;
+    if (nframes > 65535) return fail(MOLAR_HIP_ERR_TOO_LARGE, "fit_rmsd_batch_f64: at most 65535 frames per call");
+    const size_t nsel = idx ? n : natoms, nref = ref_idx ? n : ref_natoms;
+    if (nsel != nref) return fail(MOLAR_HIP_ERR_SIZES, "incompatible sizes: %zu and %zu", nsel, nref);
+    if (nsel == 0 || nsel >= 0xFFFFFFFFull) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_rmsd_batch_f64: selection of %zu atoms", nsel);
+    // the reference selection and its centre with the same mass column gathered through ITS index (:512)
+    SelD ref;
+    BatchD B;
+    MH_TRY(stage64(c, ref_xyz, ref_natoms, ref_idx, n, nullptr, c->m_xyz2, c->m_idx2, c->m_mass2, &ref));
+    MH_TRY(to_device(c, mass, natoms, c->m_mass1, &B.mass));        // one column, as long as a frame
+    ref.mass = B.mass;
+    Centres C2{};
+    MH_TRY(com64(c, ref, true, C2.c2));
+    B.n = (uint32_t)nsel;
+    B.stride = natoms * 3;
+    B.ref = ref.xyz;
+    B.ref_idx = ref.idx;
+    MH_TRY(to_device(c, (const double *)frames, natoms * 3 * nframes, c->m_xyz1, &B.frames));
+    MH_TRY(to_device(c, idx, idx ? n : 0, c->m_idx1, &B.idx));
+    const uint32_t F = (uint32_t)nframes;
+    uint32_t nb = (B.n + RB * 8 - 1) / (RB * 8);
+    nb = nb < 1 ? 1 : (nb > 64 ? 64 : nb);
+    const size_t part_bytes = (size_t)nb * F * 10 * 8;
+    MH_TRY(c->m_partials.reserve(part_bytes + (size_t)F * (REC64 + 4) * 8 + 64));
+    MH_TRY(ensure_pinned(c, (size_t)F * REC64 * 8));
+    double *part = c->m_partials.as<double>();
+    double *rec = reinterpret_cast<double *>(static_cast<char *>(c->m_partials.p) + part_bytes);
+    double *centres = rec + (size_t)F * REC64;
+    double *frames_rw = const_cast<double *>(B.frames);
+    hipLaunchKernelGGL(k64b_sums, dim3(nb, F), dim3(RB), 0, c->stream, B, part);
+    hipLaunchKernelGGL(k64b_centres, dim3(F), dim3(64), 0, c->stream, part, nb, centres, rec);
+    hipLaunchKernelGGL(k64b_cov, dim3(nb, F), dim3(RB), 0, c->stream, B, centres, C2, part);
+    hipLaunchKernelGGL(k64b_rot, dim3(F), dim3(64), 0, c->stream, part, nb, centres, C2, rec);
+    hipLaunchKernelGGL(k64b_resid, dim3(nb, F), dim3(RB), 0, c->stream, B, rec, apply ? 1 : 0, frames_rw, part);
+    hipLaunchKernelGGL(k64b_rmsd, dim3(F), dim3(64), 0, c->stream, part, nb, B.n, rec, static_cast<double *>(c->h_pinned));
+    MH_HIP(hipGetLastError());
+    if (apply && !is_device_ptr(frames))
+        MH_HIP(hipMemcpyAsync(frames, B.frames, nframes * natoms * 24, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    const double *h = static_cast<const double *>(c->h_pinned);
+    for (uint32_t f = 0; f < F; ++f) {
+        const int st = (int)h[REC64 * (size_t)f + 17];
+        if (st) return fail(st, st == MOLAR_HIP_ERR_ZERO_MASS ? "zero mass" : "SVD failed");
+    }
+    auto emit = [&](double *dst, size_t per, size_t at) -> int {
+        if (!dst) return 0;
+        std::vector<double> tmp((size_t)F * per);
+        for (uint32_t f = 0; f < F; ++f)
+            for (size_t k = 0; k < per; ++k) tmp[f * per + k] = h[REC64 * (size_t)f + at + k];
+        if (is_device_ptr(dst)) {
+            MH_HIP(hipMemcpyAsync(dst, tmp.data(), tmp.size() * 8, hipMemcpyHostToDevice, c->stream));
+            MH_HIP(hipStreamSynchronize(c->stream));
+        } else {
+            std::memcpy(dst, tmp.data(), tmp.size() * 8);
+        }
+        return 0;
+    };
+    MH_TRY(emit(R_out, 9, 0));
+    MH_TRY(emit(t_out, 3, 9));
+    MH_TRY(emit(rmsd_out, 1, 12));
+    MH_TRY(emit(com_out, 3, 13));
+    MH_TRY(emit(gyr_out, 1, 16));
     return MOLAR_HIP_OK;
 }
 

@@ -101,3 +101,39 @@ def test_f64_device_resident_and_errors(m64, orc64):
     with pytest.raises(MolarHipError) as e:
         m64.rmsd(cur, ref, idx, idx[:-1])
     assert e.value.code == 1                                                                 # MeasureError::Sizes
+
+
+@pytest.mark.parametrize("n,m,F,resident", [(20_000, 2_000, 5, False), (1_000_000, 100_000, 3, True)])
+def test_f64_fit_rmsd_batch(m64, orc64, n, m, F, resident):
+    """The per-frame loop (benches/comparison_small.rs:14-25) in f64, also at the C3 size, against the f64 oracle run
+    frame by frame: fit, apply, then rmsd / centre of mass / gyration of the moved selection."""
+    from molar_amd import api
+    rng = np.random.default_rng(21)
+    ref = rng.uniform(0, 20, (n, 3))
+    mass = rng.uniform(1, 40, n)
+    idx = np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+    ref_idx = idx if resident else np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+    frames = np.empty((F, n, 3))
+    for f in range(F):
+        R = api.rotation_from_axis_angle(rng.normal(size=3), float(rng.uniform(-3, 3))).astype(np.float64)
+        frames[f] = rng.uniform(0, 20, (n, 3))
+        frames[f][idx.astype(np.int64)] = ref[ref_idx.astype(np.int64)] @ R.T + rng.uniform(-3, 3, 3) + rng.normal(0, 10.0 ** -(2 + 3 * f), (m, 3))
+    work = frames.copy()
+    if resident:
+        import torch
+        d = torch.from_numpy(work).cuda()
+        out = m64.fit_rmsd_batch(d, torch.from_numpy(mass).cuda(), torch.from_numpy(ref).cuda(),
+                                 idx=torch.from_numpy(idx.astype(np.int64)).cuda(), apply=True)
+        work = d.cpu().numpy()
+    else:
+        out = m64.fit_rmsd_batch(work, mass, ref, idx=idx, ref_idx=ref_idx, apply=True)
+    for f in range(F):
+        Ro, to = orc64.fit_transform(frames[f], mass, ref, mass, idx, ref_idx)
+        assert np.allclose(out["R"][f], Ro, rtol=0, atol=RTOL_ROT)
+        assert np.allclose(out["t"][f], to, rtol=0, atol=RTOL_ROT * 400)
+        moved = orc64.apply_transform(frames[f], out["R"][f], out["t"][f], idx)
+        assert np.array_equal(work[f], moved)                                  # same f64 operations, same bits
+        # residuals down to 1e-11 nm (the last frames) are resolved: the RMSD comes from the fitted positions themselves
+        assert out["rmsd"][f] == pytest.approx(orc64.rmsd(moved, ref, idx, ref_idx), rel=1e-9)
+        assert np.allclose(out["com"][f], orc64.center_of_mass(moved, mass, idx), rtol=0, atol=1e-11 * 20)
+        assert out["gyration"][f] == pytest.approx(orc64.gyration(moved, mass, idx), rel=1e-11)
