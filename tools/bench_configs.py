@@ -54,6 +54,21 @@ def main():
                           "algorithmic_GBps": alg / dt / 1e9,
                           "algorithmic_GBps_kernels_only": alg * batch / (ev_ms * 1e-3 / max(ev_n, 1)) / 1e9}))
         del work
+    # the same loop for an f64 MolAR (molar_hip_fit_rmsd_batch_f64: three gather passes per frame, not the fused f32 pass)
+    m64 = api.MeasureF64(eng)
+    F64 = 16
+    fr64 = frames[:F64].double().contiguous(); ref64 = ref.double().contiguous(); mass64 = mass.double().contiguous()
+    m64.fit_rmsd_batch(fr64, mass64, ref64, idx=idx, apply=False)
+    eng.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        m64.fit_rmsd_batch(fr64, mass64, ref64, idx=idx, apply=False)
+    eng.synchronize(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (5 * F64)
+    print(json.dumps({"workload": "C3 in f64 (fit+rmsd+COM+gyration, M=1e5 of N=1e6, frames resident, 16 frames per call, no apply)",
+                      "frames_per_s": 1.0 / dt, "us_per_frame": dt * 1e6,
+                      "algorithmic_GBps": (24 + 8 + 8 + 2 * (24 + 24 + 8 + 16)) * 1e5 / dt / 1e9}))
+    del fr64, ref64, mass64
     # streamed from host (PCIe): one 12 MB frame per call
     hframe = frames[0].cpu().numpy(); href = ref.cpu().numpy(); hmass = mass.cpu().numpy(); hidx = idx.cpu().numpy().astype(np.uint64)
     eng.fit_rmsd_batch(hframe[None].copy(), hmass, href, idx=hidx, apply=False)
