@@ -3,7 +3,7 @@ R=/root/repo
 T=${ROUND:-r02}          # round tag: raw output under gpurun_out/$T, tools/refresh_profiles.py copies the summaries into profiles/
 mkdir -p $R/gpurun_out/$T
 python $R/bench.py > $R/gpurun_out/$T/bench.json 2> $R/gpurun_out/$T/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/stats -- python $R/bench.py --steps 200 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$T/fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$T/write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 # C4-shaped workload (fused histogram): bench line + kernel stats
