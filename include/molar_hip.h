@@ -248,9 +248,9 @@ int molar_hip_fit_transform(molar_hip_ctx *ctx, const float *xyz1, size_t natoms
                             float t3[3]);
 
 /* ---- MolAR built with its `f64` feature (Float = f64: molar/src/aliases.rs:10-13, molar/Cargo.toml:56-60).
- * The non-periodic Measure / Modify methods on double-precision coordinates and masses, same argument meaning and
+ * The Measure / Modify methods (centres, gyration, rmsd, fit, inertia, min_max, apply, translate, periodic centres and unwrap) on double-precision coordinates and masses, same argument meaning and
  * error codes as the f32 entries above; every per-atom term is formed and accumulated in f64 (two passes where the
- * reference has two: centre, then centred terms).  The search and the periodic variants are f32 only. */
+ * reference has two: centre, then centred terms).  The search is f32 only. */
 /* center_of_geometry :39-47, center_of_mass :60-75 (ERR_ZERO_MASS) */
 int molar_hip_center_of_geometry_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx,
                                      size_t n, double out[3]);
@@ -285,6 +285,17 @@ int molar_hip_fit_rmsd_batch_f64(molar_hip_ctx *ctx, double *frames, size_t nfra
                                  const uint64_t *idx, size_t n, const double *mass, const double *ref_xyz,
                                  size_t ref_natoms, const uint64_t *ref_idx, int apply, double *rmsd_out,
                                  double *R_out, double *t_out, double *com_out, double *gyr_out);
+/* the periodic centres (:156-168, :197-220), gyration_pbc (:222-232) and unwrap_simple_dim (modify.rs:40-54) with an f64
+ * PeriodicBox built from box9 (column-major, columns a,b,c) exactly as PeriodicBox::from_matrix does: ERR_NO_PBC if
+ * box9 == NULL, ERR_ZERO_LENGTH_VECTOR / ERR_INVERSE_FAILED from the construction. */
+int molar_hip_center_of_geometry_pbc_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx,
+                                         size_t n, const double *box9, uint8_t pbc, double out[3]);
+int molar_hip_center_of_mass_pbc_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx,
+                                     size_t n, const double *mass, const double *box9, uint8_t pbc, double out[3]);
+int molar_hip_gyration_pbc_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                               const double *mass, const double *box9, double *out);
+int molar_hip_unwrap_simple_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                const double *box9, uint8_t pbc);
 /* apply_transform (modify.rs:32-36), in place */
 int molar_hip_apply_transform_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
                                   const double R9[9], const double t3[3]);

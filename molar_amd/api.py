@@ -656,9 +656,9 @@ def _f64(x):
 
 
 class MeasureF64:
-    """The non-periodic Measure / Modify methods for MolAR's `f64` feature (Float = f64, molar/src/aliases.rs:10-13) on
+    """The Measure / Modify methods for MolAR's `f64` feature (Float = f64, molar/src/aliases.rs:10-13) on
     an Engine's context: float64 coordinates and masses (numpy or torch CUDA), float64 results.  Same argument meaning
-    as the Engine methods of the same name; the search and the periodic variants exist in f32 only."""
+    as the Engine methods of the same name; the search exists in f32 only."""
 
     def __init__(self, engine: "Engine"):
         self.eng, self.lib, self.ctx = engine, engine.lib, engine.ctx
@@ -712,6 +712,38 @@ class MeasureF64:
         check(self.lib.molar_hip_fit_transform_f64(self.ctx, *a1[:4], m1, *a2[:4], m2, 1 if at_origin else 0,
                                                    R.ctypes.data, t.ctypes.data))
         return R.reshape(3, 3).T.copy(), t
+
+    @staticmethod
+    def _box9(box):
+        """box: 3x3 with COLUMNS = box vectors (PeriodicBox::from_matrix), float64."""
+        b9 = np.ascontiguousarray(np.asarray(box, np.float64).reshape(3, 3).T).reshape(9)
+        return b9.ctypes.data, b9
+
+    def center_of_geometry_pbc(self, xyz, box, dims=PBC_FULL, idx=None):
+        a = self._sel(xyz, idx); ba, kb = self._box9(box)
+        out = np.zeros(3, np.float64)
+        check(self.lib.molar_hip_center_of_geometry_pbc_f64(self.ctx, *a[:4], ba, pbc_mask(dims), out.ctypes.data))
+        return out
+
+    def center_of_mass_pbc(self, xyz, mass, box, dims=PBC_FULL, idx=None):
+        a = self._sel(xyz, idx); ba, kb = self._box9(box)
+        mass = _f64(mass); ma, km = _addr(mass)
+        out = np.zeros(3, np.float64)
+        check(self.lib.molar_hip_center_of_mass_pbc_f64(self.ctx, *a[:4], ma, ba, pbc_mask(dims), out.ctypes.data))
+        return out
+
+    def gyration_pbc(self, xyz, mass, box, idx=None):
+        a = self._sel(xyz, idx); ba, kb = self._box9(box)
+        mass = _f64(mass); ma, km = _addr(mass)
+        out = C.c_double(0)
+        check(self.lib.molar_hip_gyration_pbc_f64(self.ctx, *a[:4], ma, ba, C.byref(out)))
+        return float(out.value)
+
+    def unwrap_simple(self, xyz, box, dims=PBC_FULL, idx=None):
+        if not _is_torch(xyz):
+            assert xyz.dtype == np.float64 and xyz.flags.c_contiguous, "unwrap_simple works in place"
+        a = self._sel(xyz, idx); ba, kb = self._box9(box)
+        check(self.lib.molar_hip_unwrap_simple_f64(self.ctx, *a[:4], ba, pbc_mask(dims)))
 
     def fit_rmsd_batch(self, frames, mass, ref_xyz, idx=None, ref_idx=None, apply=True):
         """frames: float64 [F, natoms, 3] (numpy, modified in place if apply; or torch CUDA tensor).

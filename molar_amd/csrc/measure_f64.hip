@@ -1,4 +1,4 @@
-// measure_f64.hip — the non-periodic Measure / Modify methods for MolAR built with its `f64` feature
+// measure_f64.hip — the Measure / Modify methods for MolAR built with its `f64` feature
 // (Float = f64: molar/src/aliases.rs:10-13, molar/Cargo.toml:56-60): centres, gyration radius, RMSD, Kabsch fit and
 // apply_transform, plus min_max, the inertia tensor with its principal axes and translate, on double-precision
 // coordinates and masses.
@@ -7,7 +7,8 @@
 // (gyration :78-87, rot_transform :613-643), every per-atom term formed in f64 in the reference's operation order and
 // accumulated per thread -> wave -> workgroup -> fixed-order total, so results agree with the reference's serial f64 sums
 // to ~1e-15 relative and do not depend on the launch shape.  These passes move 24-56 bytes per atom: HBM-bound like
-// their f32 counterparts (measure.hip); the search and the periodic variants have no f64 build.
+// their f32 counterparts (measure.hip); the periodic centres, gyration radius and unwrap_simple carry their own f64
+// PeriodicBox; the search has no f64 build.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -30,6 +31,96 @@ struct SelD {
 };
 
 __device__ __forceinline__ uint64_t atom_of(const SelD &s, uint32_t k) { return s.idx ? s.idx[k] : (uint64_t)k; }
+
+// PeriodicBox in f64 (periodic_box.rs:15-23 with Float = f64): the same construction and the same shortest_vector as
+// boxmath.hpp / api.hip, every operation in double.
+struct BoxD {
+    double m[9];       // column-major, columns a, b, c
+    double inv[9];     // nalgebra try_inverse
+    int32_t nshift;    // tric_corrections.len()
+    double shifts[26 * 3];
+};
+struct D3 {
+    double x, y, z;
+};
+#define MH64_HD __host__ __device__ __forceinline__
+MH64_HD D3 operator+(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+MH64_HD D3 operator-(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+MH64_HD double norm2(D3 v) { return (v.x * v.x + v.y * v.y) + v.z * v.z; }
+MH64_HD D3 mat_vec(const double *m, D3 v) {
+    return D3{(m[0] * v.x + m[3] * v.y) + m[6] * v.z, (m[1] * v.x + m[4] * v.y) + m[7] * v.z,
+              (m[2] * v.x + m[5] * v.y) + m[8] * v.z};
+}
+MH64_HD double round_away(double x) {          // Rust f64::round - half away from zero
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_round(x);
+#else
+    return std::round(x);
+#endif
+}
+// shortest_vector_dims (periodic_box.rs:286-318)
+MH64_HD D3 shortest_vector(const BoxD &b, D3 v, uint32_t pbc) {
+    D3 f = mat_vec(b.inv, v);
+    if (pbc & 1u) f.x -= round_away(f.x);
+    if (pbc & 2u) f.y -= round_away(f.y);
+    if (pbc & 4u) f.z -= round_away(f.z);
+    const D3 start = mat_vec(b.m, f);
+    if (b.nshift == 0 || pbc != MOLAR_HIP_PBC_FULL) return start;
+    D3 best = start;
+    double best2 = norm2(start);
+    for (int k = 0; k < b.nshift; ++k) {
+        const D3 cand = start + D3{b.shifts[3 * k], b.shifts[3 * k + 1], b.shifts[3 * k + 2]};
+        const double n2 = norm2(cand);
+        if (n2 < best2) {
+            best2 = n2;
+            best = cand;
+        }
+    }
+    return best;
+}
+// closest_image_dims (:322-330)
+MH64_HD D3 closest_image(const BoxD &b, D3 p, D3 target, uint32_t pbc) { return target + shortest_vector(b, p - target, pbc); }
+
+// PeriodicBox::from_matrix (:156-176) + build_tric_corrections (:25-66)
+int box64_from_matrix(const double *m9, BoxD *out) {
+    if (!m9) return fail(MOLAR_HIP_ERR_NO_PBC, "pbc operation without periodic box");
+    D3 col[3];
+    for (int k = 0; k < 3; ++k) {
+        col[k] = D3{m9[3 * k], m9[3 * k + 1], m9[3 * k + 2]};
+        if (std::sqrt(norm2(col[k])) == 0.0) return fail(MOLAR_HIP_ERR_ZERO_LENGTH_VECTOR, "zero length box vector");
+    }
+    std::memcpy(out->m, m9, sizeof out->m);
+    {   // nalgebra try_inverse, 3x3 closed form
+        const double *m = out->m;
+        double *o = out->inv;
+        const double a = m[0], d = m[1], g = m[2], b = m[3], e = m[4], h = m[5], c = m[6], f = m[7], i = m[8];
+        const double minor_bf = e * i - h * f, minor_af = d * i - g * f, minor_ae = d * h - g * e;
+        const double det = (a * minor_bf - b * minor_af) + c * minor_ae;
+        if (det == 0.0) return fail(MOLAR_HIP_ERR_INVERSE_FAILED, "box matrix inverse failed");
+        o[0] = minor_bf / det;  o[3] = (c * h - i * b) / det;  o[6] = (b * f - e * c) / det;
+        o[1] = -minor_af / det; o[4] = (a * i - g * c) / det;  o[7] = (c * d - f * a) / det;
+        o[2] = minor_ae / det;  o[5] = (b * g - h * a) / det;  o[8] = (a * e - d * b) / det;
+    }
+    out->nshift = 0;
+    const bool ortho = m9[3] == 0.0 && m9[6] == 0.0 && m9[1] == 0.0 && m9[7] == 0.0 && m9[2] == 0.0 && m9[5] == 0.0;
+    if (ortho) return 0;
+    const D3 a = col[0], b = col[1], c = col[2], na = D3{-a.x, -a.y, -a.z};
+    auto len = [](D3 v) { return std::sqrt(norm2(v)); };
+    const double longest = std::fmax(std::fmax(std::fmax(len((a + b) + c), len((a + b) - c)), len((a - b) + c)), len((na + b) + c));
+    const double half_diag = 0.5 * longest, two = 2.0 * half_diag, bound2 = two * two;
+    for (int i = -1; i <= 1; ++i)
+        for (int j = -1; j <= 1; ++j)
+            for (int k = -1; k <= 1; ++k) {
+                if (!i && !j && !k) continue;
+                const double fi = i, fj = j, fk = k;
+                const D3 sft = (D3{fi * a.x, fi * a.y, fi * a.z} + D3{fj * b.x, fj * b.y, fj * b.z}) + D3{fk * c.x, fk * c.y, fk * c.z};
+                if (norm2(sft) < bound2) {
+                    double *dst = out->shifts + 3 * out->nshift++;
+                    dst[0] = sft.x; dst[1] = sft.y; dst[2] = sft.z;
+                }
+            }
+    return 0;
+}
 
 template <int NV>
 __device__ __forceinline__ void block_store(double *acc, double *partials) {
@@ -175,6 +266,54 @@ __global__ void __launch_bounds__(RB) k64_translate(SelD s, double *xyz_rw, doub
     for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
         double *p = xyz_rw + 3 * atom_of(s, k);
         p[0] += sx; p[1] += sy; p[2] += sz;
+    }
+}
+
+// images relative to the first selected atom (center_of_*_pbc_dims :156-168, :197-220):
+// [0] = sum m (k >= 1), [1..3] = sum img*m (k >= 1), [4..6] = sum img (k >= 1)
+__global__ void __launch_bounds__(RB) k64_sums_pbc(SelD s, const BoxD *box, uint32_t pbc, double *partials) {
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    const BoxD &B = *box;
+    const double *q0 = s.xyz + 3 * atom_of(s, 0);
+    const D3 p0 = D3{q0[0], q0[1], q0[2]};
+    for (uint32_t k = 1 + blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const double *q = s.xyz + 3 * a;
+        const D3 im = closest_image(B, D3{q[0], q[1], q[2]}, p0, pbc);
+        const double m = s.mass ? s.mass[a] : 1.0;
+        acc[0] += m;
+        acc[1] += im.x * m; acc[2] += im.y * m; acc[3] += im.z * m;
+        acc[4] += im.x; acc[5] += im.y; acc[6] += im.z;
+    }
+    block_store<7>(acc, partials);
+}
+
+// gyration_pbc (:222-232): [0] = sum |shortest_vector(p - c)|^2 * m, [1] = sum m
+__global__ void __launch_bounds__(RB) k64_central_pbc(SelD s, const BoxD *box, double cx, double cy, double cz, double *partials) {
+    double acc[2] = {0, 0};
+    const BoxD &B = *box;
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const double *p = s.xyz + 3 * a;
+        const D3 d = shortest_vector(B, D3{p[0] - cx, p[1] - cy, p[2] - cz}, MOLAR_HIP_PBC_FULL);
+        const double m = s.mass[a];
+        acc[0] += norm2(d) * m;
+        acc[1] += m;
+    }
+    block_store<2>(acc, partials);
+}
+
+// unwrap_simple_dim (modify.rs:40-54): every atom becomes its image closest to the first one
+__global__ void __launch_bounds__(RB) k64_unwrap(SelD s, double *xyz_rw, const BoxD *box, uint32_t pbc) {
+    const BoxD &B = *box;
+    const double *q0 = s.xyz + 3 * atom_of(s, 0);
+    const D3 p0 = D3{q0[0], q0[1], q0[2]};
+    for (uint32_t k = 1 + blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const double *q = s.xyz + 3 * a;
+        const D3 im = closest_image(B, D3{q[0], q[1], q[2]}, p0, pbc);
+        double *w = xyz_rw + 3 * a;
+        w[0] = im.x; w[1] = im.y; w[2] = im.z;
     }
 }
 
@@ -642,6 +781,102 @@ int molar_hip_fit_rmsd_batch_f64(molar_hip_ctx *c, double *frames, size_t nframe
     MH_TRY(emit(rmsd_out, 1, 12));
     MH_TRY(emit(com_out, 3, 13));
     MH_TRY(emit(gyr_out, 1, 16));
+    return MOLAR_HIP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// the box of a call, built on the host and copied behind the partials' buffer (its own DevBuf: m_out)
+int box64_to_device(molar_hip_ctx *c, const double *box9, const BoxD **d_box) {
+    BoxD b;
+    MH_TRY(box64_from_matrix(box9, &b));
+    MH_TRY(c->m_out.reserve(sizeof(BoxD)));
+    MH_HIP(hipMemcpyAsync(c->m_out.p, &b, sizeof b, hipMemcpyHostToDevice, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));          // `b` lives on this stack frame
+    *d_box = c->m_out.as<BoxD>();
+    return 0;
+}
+
+// center_of_mass_pbc_dims (:197-220) / center_of_geometry_pbc_dims (:156-168): the sums start at the UNWEIGHTED first
+// position (and its mass), the other atoms enter as their images closest to it
+int com64_pbc(molar_hip_ctx *c, const SelD &s, const BoxD *d_box, uint32_t pbc, bool weighted, double out[3]) {
+    if (s.n == 0) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "periodic centre of an empty selection");
+    double r[7];
+    MH_TRY((reduce64<7>(c, s.n, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k64_sums_pbc, dim3(nb), dim3(RB), 0, c->stream, s, d_box, pbc, part);
+    })));
+    uint64_t a0 = 0;
+    double p0[3], m0 = 1.0;
+    if (s.idx) MH_HIP(hipMemcpy(&a0, s.idx, 8, hipMemcpyDeviceToHost));
+    MH_HIP(hipMemcpy(p0, s.xyz + 3 * a0, 24, hipMemcpyDeviceToHost));
+    if (s.mass) MH_HIP(hipMemcpy(&m0, s.mass + a0, 8, hipMemcpyDeviceToHost));
+    if (weighted) {
+        const double mass = m0 + r[0];
+        if (mass == 0.0) return fail(MOLAR_HIP_ERR_ZERO_MASS, "zero mass");
+        for (int d = 0; d < 3; ++d) out[d] = (p0[d] + r[1 + d]) / mass;
+    } else {
+        for (int d = 0; d < 3; ++d) out[d] = (p0[d] + r[4 + d]) / (double)s.n;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int molar_hip_center_of_geometry_pbc_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                         const double *box9, uint8_t pbc, double out[3]) {
+    MH64_CTX(c);
+    const BoxD *d_box;
+    MH_TRY(box64_to_device(c, box9, &d_box));
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    return com64_pbc(c, s, d_box, pbc & 7u, false, out);
+}
+
+int molar_hip_center_of_mass_pbc_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                     const double *mass, const double *box9, uint8_t pbc, double out[3]) {
+    MH64_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "center_of_mass_pbc_f64: mass pointer is null");
+    const BoxD *d_box;
+    MH_TRY(box64_to_device(c, box9, &d_box));
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    return com64_pbc(c, s, d_box, pbc & 7u, true, out);
+}
+
+int molar_hip_gyration_pbc_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                               const double *mass, const double *box9, double *out) {
+    MH64_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "gyration_pbc_f64: mass pointer is null");
+    const BoxD *d_box;
+    MH_TRY(box64_to_device(c, box9, &d_box));
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    double cm[3], r[2];
+    MH_TRY(com64_pbc(c, s, d_box, MOLAR_HIP_PBC_FULL, true, cm));        // center_of_mass_pbc (:227)
+    MH_TRY((reduce64<2>(c, s.n, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k64_central_pbc, dim3(nb), dim3(RB), 0, c->stream, s, d_box, cm[0], cm[1], cm[2], part);
+    })));
+    *out = std::sqrt(r[0] / r[1]);
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_unwrap_simple_f64(molar_hip_ctx *c, double *xyz, size_t natoms, const uint64_t *idx, size_t n, const double *box9,
+                                uint8_t pbc) {
+    MH64_CTX(c);
+    if (idx ? n == 0 : natoms == 0) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "unwrap_simple_f64 of an empty selection");
+    const BoxD *d_box;
+    MH_TRY(box64_to_device(c, box9, &d_box));
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, nullptr, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    hipLaunchKernelGGL(k64_unwrap, dim3(blocks64(c, s.n)), dim3(RB), 0, c->stream, s, const_cast<double *>(s.xyz), d_box,
+                       (uint32_t)(pbc & 7u));
+    MH_HIP(hipGetLastError());
+    if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, s.xyz, natoms * 24, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
     return MOLAR_HIP_OK;
 }
 

@@ -289,8 +289,8 @@ impl Engine {
         })
     }
 
-    // ---- MolAR built with `f64` (Float = f64): the non-periodic Measure / Modify methods on double-precision data
-    // (header: "MolAR built with its `f64` feature").  The search and the periodic variants take f32 only.
+    // ---- MolAR built with `f64` (Float = f64): the Measure / Modify methods on double-precision data
+    // (header: "MolAR built with its `f64` feature"); the periodic ones are bound in ffi.rs.  The search takes f32 only.
 
     /// `Measure::center_of_mass` (:60-75), f64
     pub fn center_of_mass_f64(&self, coords: &[[f64; 3]], index: Option<&[usize]>, masses: &[f64]) -> Result<[f64; 3], EngineError> {

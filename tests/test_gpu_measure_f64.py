@@ -137,3 +137,38 @@ def test_f64_fit_rmsd_batch(m64, orc64, n, m, F, resident):
         assert out["rmsd"][f] == pytest.approx(orc64.rmsd(moved, ref, idx, ref_idx), rel=1e-9)
         assert np.allclose(out["com"][f], orc64.center_of_mass(moved, mass, idx), rtol=0, atol=1e-11 * 20)
         assert out["gyration"][f] == pytest.approx(orc64.gyration(moved, mass, idx), rel=1e-11)
+
+
+@pytest.mark.parametrize("boxkind", ["triclinic", "orthorhombic"])
+def test_f64_periodic_centres_gyration_unwrap(m64, orc64, boxkind):
+    """center_of_*_pbc_dims, gyration_pbc and unwrap_simple_dim with an f64 PeriodicBox, against the oracle's f64 build."""
+    from molar_amd import synth
+    box = synth.box_a(20000).astype(np.float64) if boxkind == "triclinic" else np.diag([6.0, 7.5, 5.25])
+    rng = np.random.default_rng(8)
+    blob = rng.normal(0, 0.4, (3000, 3)) + rng.uniform(0, 5, 3)
+    inv = np.linalg.inv(box)
+    wrapped = np.ascontiguousarray(((blob @ inv.T) % 1.0) @ box.T)          # split over the periodic images
+    m = rng.uniform(1, 16, 3000)
+    idx = np.sort(rng.choice(3000, 1200, replace=False)).astype(np.uint64)
+    b64 = orc64.box_from_matrix(box)
+    for sel in (None, idx):
+        for dims in (7, 3, 5):
+            assert np.allclose(m64.center_of_mass_pbc(wrapped, m, box, dims, sel),
+                               orc64.center_of_mass_pbc_dims(wrapped, m, b64, dims, sel), rtol=0, atol=1e-12)
+            assert np.allclose(m64.center_of_geometry_pbc(wrapped, box, dims, sel),
+                               orc64.center_of_geometry_pbc_dims(wrapped, b64, dims, sel), rtol=0, atol=1e-12)
+        assert m64.gyration_pbc(wrapped, m, box, sel) == pytest.approx(orc64.gyration_pbc(wrapped, m, b64, sel), rel=1e-12)
+        un = wrapped.copy()
+        m64.unwrap_simple(un, box, 7, sel)
+        assert np.array_equal(un, orc64.unwrap_simple_dim(wrapped, b64, 7, sel))      # same f64 operations, same bits
+    # the unwrapped blob is whole again: its plain gyration radius is the periodic one, up to the reference's centre
+    # quirk (center_of_mass_pbc adds the first position unweighted, measure.rs:197-220: the centre is off by ~1e-3 nm)
+    assert m64.gyration(un, m, idx) == pytest.approx(m64.gyration_pbc(wrapped, m, box, idx), rel=1e-3)
+    from molar_amd.api import MolarHipError
+    with pytest.raises(MolarHipError) as e:
+        m64.lib.molar_hip_gyration_pbc_f64    # bound
+        from molar_amd._lib import check
+        import ctypes as C
+        out = C.c_double(0)
+        check(m64.lib.molar_hip_gyration_pbc_f64(m64.ctx, wrapped.ctypes.data, 3000, None, 0, m.ctypes.data, None, C.byref(out)))
+    assert e.value.code == 4                                                           # PeriodicBoxError::NoPbc
