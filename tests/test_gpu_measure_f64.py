@@ -172,3 +172,13 @@ def test_f64_periodic_centres_gyration_unwrap(m64, orc64, boxkind):
         out = C.c_double(0)
         check(m64.lib.molar_hip_gyration_pbc_f64(m64.ctx, wrapped.ctypes.data, 3000, None, 0, m.ctypes.data, None, C.byref(out)))
     assert e.value.code == 4                                                           # PeriodicBoxError::NoPbc
+
+
+def test_f64_randomised_differential():
+    """A 200-case slice of tools/fuzz_measure_f64.py: every f64 entry on random selections (whole, sorted, contiguous,
+    unsorted), clouds up to 500 nm from the origin, residuals 1e-9..1e-1 nm, batches of 1..6 frames, orthorhombic and
+    triclinic boxes with every periodicity mask - against the oracle's f64 build."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_measure_f64
+    assert fuzz_measure_f64.run(200, 3) == 0
