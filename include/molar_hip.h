@@ -296,6 +296,10 @@ int molar_hip_gyration_pbc_f64(molar_hip_ctx *ctx, const double *xyz, size_t nat
                                const double *mass, const double *box9, double *out);
 int molar_hip_unwrap_simple_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
                                 const double *box9, uint8_t pbc);
+/* inertia_pbc :234-244 */
+int molar_hip_inertia_pbc_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                              const double *mass, const double *box9, double moments[3], double axes9[9],
+                              double tensor9[9]);
 /* apply_transform (modify.rs:32-36), in place */
 int molar_hip_apply_transform_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
                                   const double R9[9], const double t3[3]);

@@ -774,12 +774,17 @@ class MeasureF64:
         check(self.lib.molar_hip_min_max_f64(self.ctx, *a[:4], lo.ctypes.data, hi.ctypes.data))
         return lo, hi
 
-    def inertia(self, xyz, mass, idx=None):
-        """(moments[3] ascending, axes 3x3 with axes as columns, raw tensor 3x3)."""
+    def inertia(self, xyz, mass, idx=None, box=None):
+        """(moments[3] ascending, axes 3x3 with axes as columns, raw tensor 3x3); inertia_pbc with a box."""
         a = self._sel(xyz, idx)
         mass = _f64(mass); ma, km = _addr(mass)
         mom = np.zeros(3, np.float64); axes = np.zeros(9, np.float64); tens = np.zeros(9, np.float64)
-        check(self.lib.molar_hip_inertia_f64(self.ctx, *a[:4], ma, mom.ctypes.data, axes.ctypes.data, tens.ctypes.data))
+        if box is None:
+            check(self.lib.molar_hip_inertia_f64(self.ctx, *a[:4], ma, mom.ctypes.data, axes.ctypes.data, tens.ctypes.data))
+        else:
+            ba, kb = self._box9(box)
+            check(self.lib.molar_hip_inertia_pbc_f64(self.ctx, *a[:4], ma, ba, mom.ctypes.data, axes.ctypes.data,
+                                                     tens.ctypes.data))
         return mom, axes.reshape(3, 3).T.copy(), tens.reshape(3, 3).T.copy()
 
     def translate(self, xyz, shift, idx=None):

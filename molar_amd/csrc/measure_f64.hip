@@ -303,6 +303,25 @@ __global__ void __launch_bounds__(RB) k64_central_pbc(SelD s, const BoxD *box, d
     block_store<2>(acc, partials);
 }
 
+// inertia_pbc (:234-244): the tensor of k64_inertia over d = shortest_vector(p - c)
+__global__ void __launch_bounds__(RB) k64_inertia_pbc(SelD s, const BoxD *box, double cx, double cy, double cz, double *partials) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const BoxD &B = *box;
+    for (uint32_t k = blockIdx.x * RB + threadIdx.x; k < s.n; k += gridDim.x * RB) {
+        const uint64_t a = atom_of(s, k);
+        const double *p = s.xyz + 3 * a;
+        const D3 d = shortest_vector(B, D3{p[0] - cx, p[1] - cy, p[2] - cz}, MOLAR_HIP_PBC_FULL);
+        const double m = s.mass[a];
+        acc[0] += m * (d.y * d.y + d.z * d.z);
+        acc[1] += m * (d.x * d.x + d.z * d.z);
+        acc[2] += m * (d.x * d.x + d.y * d.y);
+        acc[3] -= m * d.x * d.y;
+        acc[4] -= m * d.x * d.z;
+        acc[5] -= m * d.y * d.z;
+    }
+    block_store<6>(acc, partials);
+}
+
 // unwrap_simple_dim (modify.rs:40-54): every atom becomes its image closest to the first one
 __global__ void __launch_bounds__(RB) k64_unwrap(SelD s, double *xyz_rw, const BoxD *box, uint32_t pbc) {
     const BoxD &B = *box;
@@ -662,17 +681,7 @@ int molar_hip_min_max_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, co
     return MOLAR_HIP_OK;
 }
 
-int molar_hip_inertia_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
-                          const double *mass, double moments[3], double axes9[9], double tensor9[9]) {
-    MH64_CTX(c);
-    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "inertia_f64: mass pointer is null");
-    SelD s;
-    MH_TRY(stage64(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
-    double cm[3], r[6];
-    MH_TRY(com64(c, s, true, cm));                                        // center_of_mass (:94)
-    MH_TRY((reduce64<6>(c, s.n, r, [&](uint32_t nb, double *part) {
-        hipLaunchKernelGGL(k64_inertia, dim3(nb), dim3(RB), 0, c->stream, s, cm[0], cm[1], cm[2], part);
-    })));
+static void inertia64_finish(const double r[6], double moments[3], double axes9[9], double tensor9[9]) {
     const double T[9] = {r[0], r[3], r[4], r[3], r[1], r[5], r[4], r[5], r[2]};
     if (tensor9) std::memcpy(tensor9, T, sizeof T);
     double A[9], w[3], V[9];
@@ -697,6 +706,20 @@ int molar_hip_inertia_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, co
         axes9[1 * 3 + d] = e[1][d];
         axes9[2 * 3 + d] = c2[d];
     }
+}
+
+int molar_hip_inertia_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                          const double *mass, double moments[3], double axes9[9], double tensor9[9]) {
+    MH64_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "inertia_f64: mass pointer is null");
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    double cm[3], r[6];
+    MH_TRY(com64(c, s, true, cm));                                        // center_of_mass (:94)
+    MH_TRY((reduce64<6>(c, s.n, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k64_inertia, dim3(nb), dim3(RB), 0, c->stream, s, cm[0], cm[1], cm[2], part);
+    })));
+    inertia64_finish(r, moments, axes9, tensor9);
     return MOLAR_HIP_OK;
 }
 
@@ -877,6 +900,23 @@ int molar_hip_unwrap_simple_f64(molar_hip_ctx *c, double *xyz, size_t natoms, co
     MH_HIP(hipGetLastError());
     if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, s.xyz, natoms * 24, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_inertia_pbc_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                              const double *mass, const double *box9, double moments[3], double axes9[9], double tensor9[9]) {
+    MH64_CTX(c);
+    if (!mass) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "inertia_pbc_f64: mass pointer is null");
+    const BoxD *d_box;
+    MH_TRY(box64_to_device(c, box9, &d_box));
+    SelD s;
+    MH_TRY(stage64(c, xyz, natoms, idx, n, mass, c->m_xyz1, c->m_idx1, c->m_mass1, &s));
+    double cm[3], r[6];
+    MH_TRY(com64_pbc(c, s, d_box, MOLAR_HIP_PBC_FULL, true, cm));        // center_of_mass_pbc (:239)
+    MH_TRY((reduce64<6>(c, s.n, r, [&](uint32_t nb, double *part) {
+        hipLaunchKernelGGL(k64_inertia_pbc, dim3(nb), dim3(RB), 0, c->stream, s, d_box, cm[0], cm[1], cm[2], part);
+    })));
+    inertia64_finish(r, moments, axes9, tensor9);
     return MOLAR_HIP_OK;
 }
 

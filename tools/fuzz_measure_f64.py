@@ -85,6 +85,9 @@ def run(ncases=300, seed=1):
             ok &= close(m64.center_of_mass_pbc(wrapped, mass, box, dims, idx), o.center_of_mass_pbc_dims(wrapped, mass, bo, dims, idx), 1e-11)
             ok &= close(m64.center_of_geometry_pbc(wrapped, box, dims, idx), o.center_of_geometry_pbc_dims(wrapped, bo, dims, idx), 1e-11)
             ok &= abs(m64.gyration_pbc(wrapped, mass, box, idx) - o.gyration_pbc(wrapped, mass, bo, idx)) <= 1e-11
+            pm, pa, pt = m64.inertia(wrapped, mass, idx, box)
+            prt = o.inertia_tensor(wrapped, mass, idx, bo)
+            ok &= close(pt, prt, 1e-10 * np.abs(prt).max()) and close(pa @ np.diag(pm) @ pa.T, prt, 1e-9 * np.abs(prt).max())
             un = wrapped.copy(); m64.unwrap_simple(un, box, dims, idx)
             ok &= np.array_equal(un, o.unwrap_simple_dim(wrapped, bo, dims, idx))
         if not ok:
