@@ -296,6 +296,11 @@ int molar_hip_gyration_pbc_f64(molar_hip_ctx *ctx, const double *xyz, size_t nat
                                const double *mass, const double *box9, double *out);
 int molar_hip_unwrap_simple_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
                                 const double *box9, uint8_t pbc);
+/* rotate (modify.rs:25-30) about the origin, in place; principal_transform :102-109 / _pbc :246-257 (box9 != NULL) */
+int molar_hip_rotate_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                         const double unit_axis3[3], double angle);
+int molar_hip_principal_transform_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx,
+                                      size_t n, const double *mass, const double *box9, double R9[9], double t3[3]);
 /* inertia_pbc :234-244 */
 int molar_hip_inertia_pbc_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
                               const double *mass, const double *box9, double moments[3], double axes9[9],

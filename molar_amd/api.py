@@ -794,6 +794,22 @@ class MeasureF64:
         sh = np.ascontiguousarray(shift, np.float64)
         check(self.lib.molar_hip_translate_f64(self.ctx, *a[:4], sh.ctypes.data))
 
+    def rotate(self, xyz, unit_axis, angle, idx=None):
+        if not _is_torch(xyz):
+            assert xyz.dtype == np.float64 and xyz.flags.c_contiguous, "rotate works in place"
+        a = self._sel(xyz, idx)
+        ax = np.ascontiguousarray(unit_axis, np.float64)
+        check(self.lib.molar_hip_rotate_f64(self.ctx, *a[:4], ax.ctypes.data, float(angle)))
+
+    def principal_transform(self, xyz, mass, idx=None, box=None):
+        """(R, t) of Translation(cm) * Rotation(axes^-1) * Translation(-cm); principal_transform_pbc with a box."""
+        a = self._sel(xyz, idx)
+        mass = _f64(mass); ma, km = _addr(mass)
+        ba, kb = self._box9(box) if box is not None else (None, None)
+        R = np.zeros(9, np.float64); t = np.zeros(3, np.float64)
+        check(self.lib.molar_hip_principal_transform_f64(self.ctx, *a[:4], ma, ba, R.ctypes.data, t.ctypes.data))
+        return R.reshape(3, 3).T.copy(), t
+
     def apply_transform(self, xyz, R, t, idx=None):
         """In place on xyz (numpy float64 C-contiguous array or torch CUDA tensor)."""
         if not _is_torch(xyz):

@@ -937,4 +937,47 @@ int molar_hip_apply_transform_f64(molar_hip_ctx *c, double *xyz, size_t natoms, 
     return MOLAR_HIP_OK;
 }
 
+int molar_hip_rotate_f64(molar_hip_ctx *c, double *xyz, size_t natoms, const uint64_t *idx, size_t n, const double unit_axis3[3],
+                         double angle) {
+    if (!unit_axis3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "rotate_f64: null axis");
+    // nalgebra Rotation3::from_axis_angle (Rodrigues' formula on a unit axis), column-major
+    const double ux = unit_axis3[0], uy = unit_axis3[1], uz = unit_axis3[2];
+    const double sn = std::sin(angle), cs = std::cos(angle), k = 1.0 - cs;
+    const double sqx = ux * ux, sqy = uy * uy, sqz = uz * uz;
+    const double R[9] = {sqx + (1.0 - sqx) * cs, ux * uy * k + uz * sn, ux * uz * k - uy * sn,
+                         ux * uy * k - uz * sn, sqy + (1.0 - sqy) * cs, uy * uz * k + ux * sn,
+                         ux * uz * k + uy * sn, uy * uz * k - ux * sn, sqz + (1.0 - sqz) * cs};
+    const double t[3] = {0.0, 0.0, 0.0};
+    return molar_hip_apply_transform_f64(c, xyz, natoms, idx, n, R, t);     // p.coords = tr * p.coords (modify.rs:28)
+}
+
+int molar_hip_principal_transform_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                      const double *mass, const double *box9, double R9[9], double t3[3]) {
+    MH64_CTX(c);
+    if (!R9 || !t3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "principal_transform_f64: null output");
+    double mom[3], axes[9], cm[3];
+    if (box9) {
+        MH_TRY(molar_hip_inertia_pbc_f64(c, xyz, natoms, idx, n, mass, box9, mom, axes, nullptr));
+        MH_TRY(molar_hip_center_of_mass_pbc_f64(c, xyz, natoms, idx, n, mass, box9, MOLAR_HIP_PBC_FULL, cm));   // (:251)
+    } else {
+        MH_TRY(molar_hip_inertia_f64(c, xyz, natoms, idx, n, mass, mom, axes, nullptr));
+        MH_TRY(molar_hip_center_of_mass_f64(c, xyz, natoms, idx, n, mass, cm));                                // (:106)
+    }
+    // do_principal_transform (:646-649): Translation(cm) * Rotation(axes^-1) * Translation(-cm);
+    // try_inverse_mut leaves a singular matrix untouched (closed-form 3x3 inverse, nalgebra)
+    const double *m = axes;
+    const double m11 = m[0], m21 = m[1], m31 = m[2], m12 = m[3], m22 = m[4], m32 = m[5], m13 = m[6], m23 = m[7], m33 = m[8];
+    const double mi1 = m22 * m33 - m32 * m23, mi2 = m21 * m33 - m31 * m23, mi3 = m21 * m32 - m31 * m22;
+    const double det = (m11 * mi1 - m12 * mi2) + m13 * mi3;
+    for (int i = 0; i < 9; ++i) R9[i] = axes[i];
+    if (det != 0.0) {
+        const double inv[9] = {mi1 / det, -mi2 / det, mi3 / det,
+                               (m13 * m32 - m33 * m12) / det, (m11 * m33 - m31 * m13) / det, (m12 * m31 - m32 * m11) / det,
+                               (m12 * m23 - m22 * m13) / det, (m13 * m21 - m23 * m11) / det, (m11 * m22 - m21 * m12) / det};
+        for (int i = 0; i < 9; ++i) R9[i] = inv[i];
+    }
+    for (int r = 0; r < 3; ++r) t3[r] = cm[r] + (((R9[r] * -cm[0]) + (R9[3 + r] * -cm[1])) + (R9[6 + r] * -cm[2]));
+    return MOLAR_HIP_OK;
+}
+
 }  // extern "C"

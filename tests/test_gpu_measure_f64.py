@@ -182,3 +182,33 @@ def test_f64_randomised_differential():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_measure_f64
     assert fuzz_measure_f64.run(200, 3) == 0
+
+
+def test_f64_principal_transform_and_rotate(m64):
+    """measure.rs:100-109,646-649 and modify.rs:25-30 in f64: after principal_transform the inertia tensor is diagonal
+    with ascending moments (to f64 working precision) and the centre of mass has not moved; rotate is Rodrigues' formula."""
+    from molar_amd import api
+    rng = np.random.default_rng(12)
+    n = 6000
+    xyz = rng.normal(0, 1.0, (n, 3)) * [3.0, 1.5, 0.6] + [12.0, -7.0, 30.0]
+    xyz = np.ascontiguousarray(xyz @ api.rotation_from_axis_angle([0.3, -0.5, 0.8], 0.7).astype(np.float64).T)
+    mass = rng.uniform(1, 30, n)
+    idx = np.arange(0, n, 2, dtype=np.uint64)
+    cm0 = m64.center_of_mass(xyz, mass, idx)
+    R, t = m64.principal_transform(xyz, mass, idx)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-13) and np.isclose(np.linalg.det(R), 1.0, atol=1e-13)
+    moved = xyz.copy()
+    m64.apply_transform(moved, R, t, idx)
+    assert np.allclose(m64.center_of_mass(moved, mass, idx), cm0, rtol=0, atol=1e-12)
+    mom, axes, tens = m64.inertia(moved, mass, idx)
+    off = tens - np.diag(np.diag(tens))
+    assert np.abs(off).max() < 1e-11 * np.abs(np.diag(tens)).max()
+    assert np.all(np.diff(np.diag(tens)) >= 0)                      # ascending moments along x, y, z
+    assert np.array_equal(moved[1::2], xyz[1::2])
+    ax = np.array([1.0, 2.0, -0.5]); ax /= np.linalg.norm(ax)
+    rot = xyz.copy()
+    m64.rotate(rot, ax, 0.9, idx)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    Rr = np.eye(3) + np.sin(0.9) * K + (1 - np.cos(0.9)) * (K @ K)
+    assert np.allclose(rot[::2], xyz[::2] @ Rr.T, rtol=0, atol=1e-13 * 40)
+    assert np.array_equal(rot[1::2], xyz[1::2])
