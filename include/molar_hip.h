@@ -301,6 +301,10 @@ int molar_hip_rotate_f64(molar_hip_ctx *ctx, double *xyz, size_t natoms, const u
                          const double unit_axis3[3], double angle);
 int molar_hip_principal_transform_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx,
                                       size_t n, const double *mass, const double *box9, double R9[9], double t3[3]);
+/* Measure::lipid_tail_order (measure.rs:270-422) in f64, CSR layout and error codes of molar_hip_lipid_tail_order */
+int molar_hip_lipid_tail_order_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx,
+                                   const uint64_t *tail_offsets, size_t ntails, int order_type, const double *normals,
+                                   const uint64_t *normal_offsets, const uint8_t *bond_orders, double *out);
 /* inertia_pbc :234-244 */
 int molar_hip_inertia_pbc_f64(molar_hip_ctx *ctx, const double *xyz, size_t natoms, const uint64_t *idx, size_t n,
                               const double *mass, const double *box9, double moments[3], double axes9[9],

@@ -101,6 +101,7 @@ SYMBOLS = {
     "molar_hip_inertia_pbc_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _P, _P, _P]),
     "molar_hip_rotate_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, C.c_double]),
     "molar_hip_principal_transform_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _P, _P]),
+    "molar_hip_lipid_tail_order_f64": (_I, [_P, _P, _SZ, _P, _P, _SZ, _I, _P, _P, _P, _P]),
     "molar_hip_min_max_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
     "molar_hip_inertia_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _P, _P]),
     "molar_hip_translate_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P]),

@@ -794,6 +794,29 @@ class MeasureF64:
         sh = np.ascontiguousarray(shift, np.float64)
         check(self.lib.molar_hip_translate_f64(self.ctx, *a[:4], sh.ctypes.data))
 
+    def lipid_tail_order(self, xyz, tails, order_type, normals, bond_orders):
+        """Batched Measure::lipid_tail_order (measure.rs:270-422) in f64; arguments as Engine.lipid_tail_order."""
+        xyz = _f64(xyz)
+        xa, kx = _addr(xyz)
+        lens = np.array([len(t) for t in tails], dtype=np.uint64)
+        toff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(t, np.uint64) for t in tails]))
+        nl = [np.asarray(n, np.float64).reshape(-1, 3) for n in normals]
+        noff = np.concatenate([[0], np.cumsum([len(n) for n in nl])]).astype(np.uint64)
+        nrm = np.ascontiguousarray(np.concatenate(nl))
+        bo = np.ascontiguousarray(np.concatenate([np.asarray(b, np.uint8) for b in bond_orders])) if bond_orders is not None else None
+        if bo is not None and len(bo) != int(toff[-1]) - len(tails):
+            raise MolarHipError(9, "for N tail carbons # of bond orders should be N-1")       # LipidOrderError::BondOrderCount
+        nout = max(int(toff[-1]) - 2 * len(tails), 0)
+        out = np.zeros(max(nout, 1), np.float64)
+        check(self.lib.molar_hip_lipid_tail_order_f64(self.ctx, xa, xyz.shape[0], idx.ctypes.data, toff.ctypes.data, len(tails),
+                                                      int(order_type), nrm.ctypes.data, noff.ctypes.data,
+                                                      None if bo is None else bo.ctypes.data, out.ctypes.data))
+        res, pos = [], 0
+        for n in lens:
+            res.append(out[pos:pos + int(n) - 2].copy()); pos += int(n) - 2
+        return res
+
     def rotate(self, xyz, unit_axis, angle, idx=None):
         if not _is_torch(xyz):
             assert xyz.dtype == np.float64 and xyz.flags.c_contiguous, "rotate works in place"

@@ -487,6 +487,112 @@ __global__ void __launch_bounds__(64) k64b_rmsd(const double *partials, uint32_t
     for (int i = 0; i < REC64; ++i) rec_host[REC64 * (size_t)blockIdx.x + i] = o[i];
 }
 
+// Measure::lipid_tail_order (measure.rs:270-422) in f64: the f32 kernel of measure.hip with every operation in double
+// (one thread per tail, bonds walked sequentially to keep the reference's last-writer-wins behaviour).
+struct E3 {
+    double x, y, z;
+};
+__device__ __forceinline__ E3 e3sub(E3 a, E3 b) { return E3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ double e3dot(E3 a, E3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ double e3norm(E3 a) { return sqrt(e3dot(a, a)); }
+__device__ __forceinline__ E3 e3cross(E3 a, E3 b) {
+    return E3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ E3 e3unit(E3 a) {
+    const double n = e3norm(a);
+    return E3{a.x / n, a.y / n, a.z / n};
+}
+// nalgebra Vector::angle: acos(clamp(a.b / (|a||b|), -1, 1)), 0 if either vector is zero
+__device__ __forceinline__ double e3angle(E3 a, E3 b) {
+    const double n1 = e3norm(a), n2 = e3norm(b);
+    if (n1 == 0.0 || n2 == 0.0) return 0.0;
+    double c = e3dot(a, b) / (n1 * n2);
+    c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);
+    return acos(c);
+}
+
+__global__ void __launch_bounds__(64) k64_lipid_order(const double *__restrict__ xyz, const uint64_t *__restrict__ idx,
+                                                    const uint64_t *__restrict__ toff, uint32_t ntails, int order_type,
+                                                    const double *__restrict__ normals, const uint64_t *__restrict__ noff,
+                                                    const uint8_t *__restrict__ bonds, double *__restrict__ out,
+                                                    int *__restrict__ status) {
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    if (t >= ntails) return;
+    const uint64_t a0 = toff[t];
+    const uint32_t n = (uint32_t)(toff[t + 1] - a0);
+    const uint32_t nn = (uint32_t)(noff[t + 1] - noff[t]);
+    if (n < 3) {
+        atomicMax(status, MOLAR_HIP_ERR_LIPID_TAIL_TOO_SHORT);
+        return;
+    }
+    if (nn != 1 && nn != n - 2) {
+        atomicMax(status, MOLAR_HIP_ERR_LIPID_NORMALS_COUNT);
+        return;
+    }
+    const uint8_t *bo = bonds + (a0 - t);
+    double *order = out + (a0 - 2ull * t);
+    auto P = [&](uint32_t k) {
+        const double *q = xyz + 3 * idx[a0 + k];
+        return E3{q[0], q[1], q[2]};
+    };
+    auto N = [&](uint32_t k) {
+        const double *q = normals + 3 * (noff[t] + (nn == 1 ? 0 : k));
+        return E3{q[0], q[1], q[2]};
+    };
+    for (uint32_t k = 0; k < n - 2; ++k) order[k] = 0.0;
+    if (order_type == 0) {
+        for (uint32_t at = 1; at + 1 < n; ++at) {
+            const double c = cos(e3angle(e3sub(P(at + 1), P(at - 1)), N(at - 1)));
+            order[at - 1] = 1.5 * (c * c) - 0.5;
+        }
+        return;
+    }
+    const double sqrt3 = sqrt(3.0), pi = 3.14159265358979323846;
+    for (uint32_t i = 0; i + 2 < n; ++i) {
+        if (bo[i] == 1) {
+            if (bo[i + 1] == 1) {
+                const E3 p1 = P(i), p2 = P(i + 1), p3 = P(i + 2);
+                const E3 lz = e3unit(e3sub(p3, p1));
+                const E3 lx = e3unit(e3cross(e3sub(p1, p2), e3sub(p3, p2)));
+                const E3 ly = e3cross(lx, lz);
+                const E3 nv = N(i);
+                const double cx = cos(e3angle(lx, nv)), cy = cos(e3angle(ly, nv));
+                const double sxx = 0.5 * (3.0 * (cx * cx) - 1.0), syy = 0.5 * (3.0 * (cy * cy) - 1.0);
+                order[i] = -(2.0 * sxx + syy) / 3.0;
+            }
+        } else {
+            // a double bond at bond 0 has no C(i-1); at the last bond it has no normal for atom i+1 when normals are
+            // per bond.  The reference indexes out of range there (usize underflow panic / unchecked read,
+            // measure.rs:361-364,385): refuse the tail instead of touching memory outside it.
+            if (i == 0 || (nn != 1 && i + 1 >= nn)) {
+                atomicMax(status, MOLAR_HIP_ERR_INVALID_ARGUMENT);
+                return;
+            }
+            const E3 p1 = P(i - 1), p2 = P(i), p3 = P(i + 1), p4 = P(i + 2);
+            const double a1 = 0.5 * (pi - e3angle(e3sub(p1, p2), e3sub(p3, p2)));
+            const double a2 = 0.5 * (pi - e3angle(e3sub(p2, p3), e3sub(p4, p3)));
+            const E3 lz = e3unit(e3sub(p3, p2));
+            for (int side = 0; side < 2; ++side) {
+                const E3 lx = e3unit(e3cross(side == 0 ? e3sub(p1, p2) : e3sub(p3, p4), lz));
+                const E3 ly = e3cross(lx, lz);
+                const E3 nv = N(side == 0 ? i : i + 1);
+                const double cy = cos(e3angle(ly, nv)), cz = cos(e3angle(lz, nv));
+                const double szz = 0.5 * (3.0 * (cz * cz) - 1.0), syy = 0.5 * (3.0 * (cy * cy) - 1.0);
+                const double syz = 1.5 * cy * cz;
+                const double a = side == 0 ? a1 : a2, sgn = side == 0 ? -1.0 : 1.0;
+                double v;
+                if (order_type == 2) {
+                    const double ca = cos(a), sa = sin(a);
+                    v = -(((ca * ca) * syy + (sa * sa) * szz) + sgn * (2.0 * ca * sa * syz));
+                } else {
+                    v = -((szz / 4.0 + 3.0 * syy / 4.0) + sgn * (sqrt3 * syz / 2.0));
+                }
+                order[side == 0 ? i - 1 : i] = v;
+            }
+        }
+    }
+}
+
 // totals of the per-workgroup partials in a fixed order, written to pinned host memory
 template <int NV>
 __global__ void __launch_bounds__(64) k64_total(const double *partials, uint32_t nblk, double *out_host) {
@@ -934,6 +1040,55 @@ int molar_hip_apply_transform_f64(molar_hip_ctx *c, double *xyz, size_t natoms, 
     MH_HIP(hipGetLastError());
     if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, s.xyz, natoms * 24, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_lipid_tail_order_f64(molar_hip_ctx *c, const double *xyz, size_t natoms, const uint64_t *idx,
+                                   const uint64_t *tail_offsets, size_t ntails, int order_type, const double *normals,
+                                   const uint64_t *normal_offsets, const uint8_t *bond_orders, double *out) {
+    MH64_CTX(c);
+    if (!xyz || !idx || !tail_offsets || !normals || !normal_offsets || !out)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "lipid_tail_order_f64: null argument");
+    if (order_type < 0 || order_type > 2) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "lipid_tail_order_f64: order_type %d", order_type);
+    if (!bond_orders && order_type != 0) return fail(MOLAR_HIP_ERR_LIPID_BOND_ORDER_COUNT, "bond orders missing");
+    if (ntails == 0) return MOLAR_HIP_OK;
+    // the CSR offsets are needed on the host to size the transfers
+    std::vector<uint64_t> toff(ntails + 1), noff(ntails + 1);
+    if (is_device_ptr(tail_offsets)) MH_HIP(hipMemcpy(toff.data(), tail_offsets, (ntails + 1) * 8, hipMemcpyDeviceToHost));
+    else std::memcpy(toff.data(), tail_offsets, (ntails + 1) * 8);
+    if (is_device_ptr(normal_offsets)) MH_HIP(hipMemcpy(noff.data(), normal_offsets, (ntails + 1) * 8, hipMemcpyDeviceToHost));
+    else std::memcpy(noff.data(), normal_offsets, (ntails + 1) * 8);
+    const size_t nidx = toff[ntails], nnorm = noff[ntails];
+    if (nidx < 2 * ntails) return fail(MOLAR_HIP_ERR_LIPID_TAIL_TOO_SHORT, "tail should have at least 3 carbons");
+    const size_t nout = nidx - 2 * ntails, nbond = nidx - ntails;
+    const double *d_xyz, *d_norm;
+    const uint64_t *d_idx, *d_toff, *d_noff;
+    const uint8_t *d_bo = nullptr;
+    MH_TRY(to_device(c, xyz, natoms * 3, c->m_xyz1, &d_xyz));
+    MH_TRY(to_device(c, idx, nidx, c->m_idx1, &d_idx));
+    MH_TRY(to_device(c, normals, nnorm * 3, c->m_xyz2, &d_norm));
+    MH_TRY(to_device(c, (const uint64_t *)toff.data(), ntails + 1, c->m_idx2, &d_toff));
+    MH_TRY(to_device(c, (const uint64_t *)noff.data(), ntails + 1, c->m_mass2, &d_noff));
+    static const uint8_t dummy = 1;
+    if (bond_orders) MH_TRY(to_device(c, bond_orders, nbond, c->m_mass1, &d_bo));
+    else MH_TRY(to_device(c, &dummy, (size_t)1, c->m_mass1, &d_bo));
+    const bool out_dev = is_device_ptr(out);
+    MH_TRY(c->m_out.reserve((nout + 4) * 8));
+    double *d_out = out_dev ? out : c->m_out.as<double>();
+    MH_TRY(c->m_results.reserve(64));
+    int *status = c->m_results.as<int>();
+    MH_HIP(hipMemsetAsync(status, 0, 4, c->stream));
+    hipLaunchKernelGGL(k64_lipid_order, dim3((unsigned)((ntails + 63) / 64)), dim3(64), 0, c->stream, d_xyz, d_idx, d_toff,
+                       (uint32_t)ntails, order_type, d_norm, d_noff, d_bo, d_out, status);
+    MH_HIP(hipGetLastError());
+    int st = 0;
+    MH_HIP(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    if (st) return fail(st, "lipid order error (status %d)", st);
+    if (!out_dev && nout) {
+        MH_HIP(hipMemcpyAsync(out, d_out, nout * 8, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
+    }
     return MOLAR_HIP_OK;
 }
 

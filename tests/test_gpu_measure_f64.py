@@ -212,3 +212,32 @@ def test_f64_principal_transform_and_rotate(m64):
     Rr = np.eye(3) + np.sin(0.9) * K + (1 - np.cos(0.9)) * (K @ K)
     assert np.allclose(rot[::2], xyz[::2] @ Rr.T, rtol=0, atol=1e-13 * 40)
     assert np.array_equal(rot[1::2], xyz[1::2])
+
+
+@pytest.mark.parametrize("order_type", [0, 1, 2])
+def test_f64_lipid_tail_order(m64, orc64, order_type):
+    """Measure::lipid_tail_order (measure.rs:270-422) in f64 over 300 random tails (14-18 carbons, a double bond in every
+    third one, one normal per tail or per bond) against the oracle's f64 build, tail by tail."""
+    rng = np.random.default_rng(40 + order_type)
+    natoms, used = 8000, 0
+    xyz = rng.uniform(0, 10, (natoms, 3))
+    tails, bonds, normals = [], [], []
+    for t in range(300):
+        n = int(rng.integers(14, 19))
+        idx = np.arange(used, used + n); used += n
+        p = np.zeros((n, 3)); p[0] = rng.uniform(1, 9, 3)
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        for k in range(1, n):
+            d = d + 0.9 * rng.normal(size=3); d /= np.linalg.norm(d)
+            p[k] = p[k - 1] + 0.153 * d
+        xyz[idx] = p
+        bo = np.ones(n - 1, np.uint8)
+        if t % 3 == 0:
+            bo[int(rng.integers(1, n - 3))] = 2
+        nn = 1 if t % 2 == 0 else n - 2
+        nv = rng.normal(size=(nn, 3)); nv /= np.linalg.norm(nv, axis=1)[:, None]
+        tails.append(idx.astype(np.uint64)); bonds.append(bo); normals.append(nv)
+    got = m64.lipid_tail_order(xyz, tails, order_type, normals, bonds)
+    for t in range(300):
+        want = orc64.lipid_tail_order(xyz, order_type, normals[t], bonds[t], tails[t])
+        assert np.allclose(got[t], want, rtol=0, atol=1e-12, equal_nan=True), t
