@@ -1,9 +1,9 @@
 # Builds a variant of the library for A/B runs on one box: tools/build_variant.sh NAME "-DFLAG ..." [sources...]
-# Recompiles the given translation units (default: pair_f0.hip) with the extra flags and links them with the objects of
+# Recompiles the given translation units (default: pair_k0.hip) with the extra flags and links them with the objects of
 # the regular build into molar_amd/_ab/libmolar_hip_NAME.so (select with MOLAR_HIP_PLUGIN).
 set -e
 name=$1; flags=$2; shift 2
-srcs=${@:-pair_f0.hip}
+srcs=${@:-pair_k0.hip}
 cd "$(dirname "$0")/../molar_amd"
 mkdir -p _ab
 base="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize"
