@@ -16,10 +16,4 @@ void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t 
         launch_pair_kernel<KIND, MODE_FILL>(nblocks, dyn_lds, stream, dP, slot_desc, nslots, slot_cnt, slot_base, pairs, dist, ids);
 }
 
-void launch_count_task_single(hipStream_t stream, const pairk::SearchParams *dP, const pairk::TaskDesc *task_desc, const uint32_t *task_first,
-                              const pairk::SlotDesc *slot_desc, uint32_t ntasks, uint32_t xw, const uint32_t *other_list,
-                              const uint32_t *n_other, const unsigned long long *task_moff, uint32_t *slot_cnt) {
-    pairk::launch_count_task_kernel<MOLAR_HIP_SEARCH_SINGLE>(stream, dP, task_desc, task_first, slot_desc, ntasks, xw, other_list, n_other, task_moff, slot_cnt);
-}
-
 }  // namespace mh

@@ -19,23 +19,6 @@ enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2 };
 // resources are only released when its slowest wave ends (measured: 4 -> 1 waves gives +7 % frames/s).  The fused
 // histogram keeps 4: every workgroup owns an LDS histogram that it flushes with atomics at the end.
 constexpr int waves_per_block(int mode) { return mode == MODE_HIST ? 4 : 1; }
-// Fill kernel: run_fill_mfma keeps the second cell's f16 records, 16 accumulators and the hit words in registers (<= 128)
-// and 10 KB of LDS per wave: 16 one-wave workgroups per CU.
-// MOLAR_HIP_FILL_MFMA (off in the shipped library): compile run_fill_mfma into the fill kernel - see the comment at
-// that function for what it does and why it is not the default (10 KB of LDS per wave hold the kernel at 4 waves per SIMD).
-#ifndef MOLAR_HIP_FILL_MFMA
-#define MOLAR_HIP_FILL_MFMA 0
-#endif
-#ifndef FM_WEU
-#define FM_WEU (MOLAR_HIP_FILL_MFMA ? 4 : 8)
-#endif
-#ifndef FM_STAGE_N
-#define FM_STAGE_N 2048
-#endif
-#ifndef FM_GATHER
-#define FM_GATHER 0
-#endif
-constexpr int FILL_WAVES_PER_EU = FM_WEU;
 constexpr int KREG = 8;            // B-cell chunks (of 64 atoms) a lane keeps in registers
 constexpr int FIFO_CAP = 128;      // per-wave LDS FIFO entries (flush threshold 64, push <= 64)
 constexpr float F32_EPS = 1.1920929e-07f;
@@ -87,7 +70,6 @@ struct SearchParams {
     const uint4 *h16_b;      // set 2, in the order of sb: 8 x f16 {hi xyz, lo xyz, |.|^2 hi, lo} relative to the cell origin
     const float4 *cell_org_b; // set 2: per cell {origin, bound on |position - origin|}
     uint32_t mfma_count;     // count pass of plain / same-cell entries on the matrix cores (run_count_mfma)
-    uint32_t mfma_fill;      // fill pass of plain / same-cell / band-classified wrapped entries on the matrix cores (run_fill_mfma)
     const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
     uint32_t *maskbuf;       // fast-path slots: hit bits found by the count pass, replayed by the fill pass
     const unsigned long long *task_moff;   // per task: first 64-word unit of its slots in maskbuf (a slot owns 2*nch units)
@@ -699,12 +681,11 @@ constexpr int MFMA_TILES = 10;     // block columns (32 atoms) per second cell t
 __device__ __forceinline__ float mfma_error_bound(float R, float c) {
     return 2.3841858e-07f * ((16.0f * R * R + 8.0f * c) + (4.0f * R + 1.0f));          // 2^-22 * (...)
 }
-// The matrix-core classification is used for a slot only when the bound is small against the cutoff (few undecided
-// candidates) and every f16 operand stays finite: |a|^2 - c, |b|^2 <= R^2 + c and the padding value 65504 ("never a
-// hit") must remain the largest term, so c + R^2 is kept below 3e4.  `c` is the constant folded into the row records,
-// `cutoff2` the squared cutoff the bound is compared with.
-__device__ __forceinline__ bool mfma_bound_usable(float R, float E, float c, float cutoff2) {
-    return R < 64.0f && E < 0.02f * cutoff2 && (c + R * R) < 3.0e4f;
+// The matrix-core count is used for a slot only when the bound is small against the cutoff (few undecided blocks) and
+// every f16 operand stays finite: |a|^2 - c and |b|^2 are at most R^2 + c in size, and the padding value 65504 ("never a
+// hit") must remain the largest term, so c + R^2 is kept below 3e4.
+__device__ __forceinline__ bool mfma_bound_usable(float R, float E, float c) {
+    return R < 64.0f && E < 0.02f * c && (c + R * R) < 3.0e4f;
 }
 
 template <int KIND, bool TRI>
@@ -739,7 +720,7 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
     const float R = 1.0001f * __builtin_sqrtf(ra2) + org.w;
     // (R and E live across the whole block loop: pinned to SGPRs, see HistFifo)
     const float E = uniform_f32(mfma_error_bound(R, cutoff2));
-    if (__builtin_amdgcn_ballot_w64(!fin) != 0ull || !mfma_bound_usable(R, E, cutoff2, cutoff2)) {
+    if (__builtin_amdgcn_ballot_w64(!fin) != 0ull || !mfma_bound_usable(R, E, cutoff2)) {
         done = false;                               // not finite / not small: the exact path takes the slot
         return 0u;
     }
@@ -828,286 +809,6 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
     }
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
     return cnt;
-}
-
-// ================================================================= fill pass on the matrix cores
-// Fill pass of plain, same-cell and band-classified wrapped entries whose second cell holds <= 320 atoms (all of the
-// headline workload).  The vector path above evaluates every candidate a second time in exact f32 and ranks the hits of
-// every (row, 64-atom chunk) with a ballot, a popcount, two v_mbcnt and three LDS stores: 13 VALU + 9 SALU instructions
-// per live chunk-row, ~1800 VALU + ~1100 SALU per slot, and the scalar unit (one per CU) is as busy as the vector ALUs.
-// Here a slot is done in four steps whose cost follows the HITS, not the candidates:
-//  1. classify: as run_count_mfma, one v_mfma_f32_32x32x16_f16 per 32 x 32 block, but with the operands swapped - the
-//     instruction's rows are the second cell's atoms, its columns the slot's rows - so that lane (kh, cl) ends up with 16
-//     accumulators of ONE row (cl) and 16 consecutive atoms.  The threshold folded into the row records is cutoff^2 + E
-//     (E: the error bound of the matrix-core evaluation), so the sign bits are a SUPERSET of the hits: no band test in
-//     the loop (16 v_alignbit per 1024 candidates).  Atoms are dealt to the instruction's rows so that the lanes of half
-//     kh own the contiguous range [kh * 16 nct, (kh + 1) * 16 nct) of the second cell: a lane's bit string is a
-//     contiguous piece of its row in output order (<= 160 bits per 32-row block, five 32-bit words).
-//  2. count: popcounts per lane, one exchange between the two halves, one wave scan -> the offset of every row and lane
-//     inside the slot's output, and the total T.  The count pass counted exactly; T - exact = the number of false
-//     positives in the slot, known before anything is written (0 for ~half of the plain slots).
-//  3. walk: every lane walks its own bits (v_ffbl, clear, store) and writes (row, atom) as 16-bit entries to their final
-//     position in an LDS staging area (the slot's output order).  No ballots, no scalar work.
-//  4. write out: 64 staged entries at a time, one per lane: both atoms from LDS (the second cell's records are copied to
-//     LDS in the prologue), the reference's exact d2 (:446, :460 / periodic_box.rs:286-318), its square root, one
-//     contiguous 512-byte and one 256-byte store.  Slots with false positives drop them here by the exact test
-//     d2 <= cutoff^2 (ranks by v_mbcnt, in the rare path only): the emitted set is exactly the reference's.
-// Slots whose T exceeds the staging area are done in several passes over ranges of rows.  Returns false without having
-// written anything if the slot has to take the vector path (error bound too wide or not finite).
-constexpr uint32_t FM_STAGE = FM_STAGE_N;           // staging entries (u16) per wave
-constexpr uint32_t FM_LJ = 32u * MFMA_TILES;        // atoms of the second cell
-constexpr uint32_t FM_LJ_LDS = (FM_GATHER || !MOLAR_HIP_FILL_MFMA) ? 224u : FM_LJ;    // (otherwise the area only has to hold the vector paths' FIFO)
-constexpr uint32_t FM_LDS_BYTES = FM_LJ_LDS * 16u + 64u * 16u + (MOLAR_HIP_FILL_MFMA ? FM_STAGE * 2u : 0u);     // second cell, rows, staging
-
-template <int KIND, bool TRI, bool WRAPPED>
-__device__ __forceinline__ bool run_fill_mfma(const SearchParams &P, const Task &T, uint32_t i0, unsigned long long out_base,
-                                              uint32_t expect, uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
-                                              unsigned char *blk, uint32_t lane) {
-    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) u4_t lds_u4;
-    typedef __attribute__((address_space(3))) unsigned short lds_u16;
-    typedef __attribute__((address_space(1))) u4_t glb_u4;
-    float4 *lj = reinterpret_cast<float4 *>(blk);                      // second cell {x, y, z, id}
-    float4 *la = lj + FM_LJ_LDS;                                        // the slot's rows
-    lds_u16 *st = (lds_u16 *)(blk + (FM_LJ_LDS + 64u) * 16u);           // staging; first the row records of the classification
-    lds_u4 *lh = (lds_u4 *)(blk + (FM_LJ_LDS + 64u) * 16u);
-    static_assert(FM_STAGE * 2u >= 128u * 16u, "the row records are staged in the same memory");
-    static_assert(FM_STAGE >= FM_LJ, "one row always fits the staging area");
-
-    const float cutoff2 = P.cutoff2;
-    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < 64u ? T.n1 - i0 : 64u);
-    const uint32_t kh = lane >> 5, cl = lane & 31u;
-    const uint32_t nct = (T.n2 + 31u) >> 5;
-    const uint32_t half = 16u * nct;                // atoms [kh * half, (kh + 1) * half) belong to the lanes of half kh
-    // image shift of a wrapped entry, as run_fast: b + S is the image of the second cell next to the first one; the
-    // classification measures from a - S to b
-    float Sx = 0.f, Sy = 0.f, Sz = 0.f;
-    if (WRAPPED) {
-        for (int d = 0; d < 3; ++d) {
-            if (!((T.wrap >> d) & 1u)) continue;
-            const float sgn = ((T.wrap_b >> d) & 1u) ? 1.0f : -1.0f;
-            Sx += sgn * P.box.m[3 * d];
-            Sy += sgn * P.box.m[3 * d + 1];
-            Sz += sgn * P.box.m[3 * d + 2];
-        }
-    }
-    // ---- everything the slot reads from memory, requested at once
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
-    const float4 org = gload4(P.cell_org_b, T.cb);
-    // the instruction's row m = cl of block column t is atom  khm * half + 16 t + 4 q + p  with cl = 8 q + 4 khm + p:
-    // accumulator r of lane (kh, cl) is then (row cl, atom kh * half + 16 t + r)
-    const uint32_t jm = ((cl >> 2) & 1u) * half + 4u * (cl >> 3) + (cl & 3u);
-    u4_t bq[MFMA_TILES];
-#pragma unroll
-    for (int t = 0; t < MFMA_TILES; ++t) {
-        const uint32_t col = jm + 16u * (uint32_t)t;
-        bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                          // atom past the end: |b|^2 = 65504, never a hit
-        if ((uint32_t)t < nct && col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
-    }
-#pragma unroll
-    for (int k = 0; k < MFMA_TILES / 2; ++k) {
-        const uint32_t jj = (uint32_t)k * 64u + lane;
-        if (!FM_GATHER && jj < T.n2) lj[jj] = gload4(P.sb, T.b0 + jj);
-    }
-    la[lane] = a;
-    const float r0 = (a.x - Sx) - org.x, r1 = (a.y - Sy) - org.y, r2 = (a.z - Sz) - org.z;
-    float ra2 = lane < rows ? (r0 * r0 + r1 * r1) + r2 * r2 : 0.0f;
-    bool fin = ra2 == ra2;
-    float big = 0.0f;                               // wrapped: the largest coordinate in play (rounding of a - S, b + S)
-    if (WRAPPED) {
-        big = lane < rows ? fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)) : 0.0f;
-        for (int off = 32; off > 0; off >>= 1) big = fmaxf(big, __shfl_xor(big, off, 64));
-    }
-    for (int off = 32; off > 0; off >>= 1) ra2 = fmaxf(ra2, __shfl_xor(ra2, off, 64));
-    const float R = 1.0001f * __builtin_sqrtf(ra2) + org.w;
-    // Threshold of the classification.  Plain: cutoff^2.  Wrapped: run_fast's band argument says that every true hit has
-    // fl(|fl(b + S) - a|^2) <= band_hi; the matrix cores measure |b - fl(a - S)|^2 instead, whose difference vector is off
-    // by at most eta = 2^-24 (2 L + 2 rc) per component (L: the largest coordinate involved), i.e. the squared distance by
-    // 2 sqrt(3) eta rc - taken four times over (candidates past the threshold only cost an exact test in step 4).
-    float c0 = cutoff2;
-    if (WRAPPED) {
-        const float rc = __builtin_sqrtf(P.band_hi);
-        const float L = (fmaxf(fmaxf(fabsf(org.x), fabsf(org.y)), fabsf(org.z)) + R) + (fmaxf(fmaxf(fabsf(Sx), fabsf(Sy)), fabsf(Sz)) + big);
-        c0 = P.band_hi * 1.000001f + 16.0f * (5.9604645e-08f * (2.0f * L + 2.0f * rc)) * rc;
-        fin = fin && (c0 == c0);
-    }
-    const float E = mfma_error_bound(R, c0);
-    const float cthr = uniform_f32(c0 + E);
-    if (__builtin_amdgcn_ballot_w64(!fin) != 0ull || !mfma_bound_usable(R, E, cthr, cutoff2)) return false;
-#if defined(FM_KO) && FM_KO == 4
-    if (lj[lane].x != 12345.0f) return true;
-#endif
-    {   // row records (see run_count_mfma), with cutoff^2 + E folded into the norm term
-        u4_t k0 = {0u, 0u, 0u, 0x00007BFFu}, k1 = {0u, 0u, 0u, 0x3C003C00u};      // row past the end: +65504
-        if (lane < rows) {
-            const _Float16 h0 = (_Float16)r0, h1 = (_Float16)r1, h2 = (_Float16)r2;
-            const _Float16 l0 = (_Float16)(r0 - (float)h0), l1 = (_Float16)(r1 - (float)h1), l2 = (_Float16)(r2 - (float)h2);
-            const float e0 = (float)h0 + (float)l0, e1 = (float)h1 + (float)l1, e2 = (float)h2 + (float)l2;
-            const float na = ((e0 * e0 + e1 * e1) + e2 * e2) - cthr;
-            const _Float16 nh = (_Float16)na, nl = (_Float16)(na - (float)nh);
-            const _Float16 m2 = (_Float16)-2.0f;
-            const _Float16 g0 = m2 * h0, g1 = m2 * h1, g2 = m2 * h2, s0 = m2 * l0, s1 = m2 * l1, s2 = m2 * l2;
-            k0 = u4_t{pack_h2(g0, g1), pack_h2(g2, g0), pack_h2(g1, g2), pack_h2(nh, nl)};
-            k1 = u4_t{pack_h2(s0, s1), pack_h2(s2, s0), pack_h2(s1, s2), 0x3C003C00u};
-        }
-        lh[2u * lane] = k0;
-        lh[2u * lane + 1u] = k1;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const u4_t a0q = lh[2u * cl + kh], a1q = lh[2u * (32u + cl) + kh];
-    const v8h_t A0 = __builtin_bit_cast(v8h_t, a0q), A1 = __builtin_bit_cast(v8h_t, a1q);
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- 1. classify.  W[rt][tp]: bit b = candidate (row 32 rt + cl, atom kh * half + 32 tp + b)
-    uint32_t W[2][MFMA_TILES / 2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int tp = 0; tp < MFMA_TILES / 2; ++tp) W[rt][tp] = 0u;
-    const bool two_blocks = rows > 32u;
-#pragma unroll
-    for (int t = 0; t < MFMA_TILES; ++t) {
-        if ((uint32_t)t < nct) {
-            u4_t bt = bq[t];
-            if (kh == 0u) bt.w = 0x3C003C00u;                           // k = 6, 7 of the first half: (1, 1)
-            const v8h_t B = __builtin_bit_cast(v8h_t, bt);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                if (rt == 1 && !two_blocks) continue;
-                v16f_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(B, rt == 0 ? A0 : A1, acc, 0, 0, 0);
-                uint32_t h = 0u;
-#pragma unroll
-                for (int i = 15; i >= 0; --i) h = __builtin_amdgcn_alignbit(h, __float_as_uint(acc[i]), 31);   // bit i = sign of acc[i]
-                if (TRI) {
-                    // same cell (j > i, :443): atom kh * half + 16 t + r survives iff r > i - (kh * half + 16 t)
-                    const int d1 = (int)(i0 + 32u * (uint32_t)rt + cl + 1u) - (int)(kh * half + 16u * (uint32_t)t);
-                    const int sh = d1 < 0 ? 0 : (d1 > 16 ? 16 : d1);
-                    h &= (0xFFFFu << sh) & 0xFFFFu;
-                }
-                W[rt][t >> 1] |= h << (16 * (t & 1));
-            }
-        }
-    }
-
-    // ---- 2. offsets.  c0/c1: hits of this lane in the two row blocks; the partner lane holds the other half of the rows
-    uint32_t n0 = 0u, n1 = 0u;
-#pragma unroll
-    for (int tp = 0; tp < MFMA_TILES / 2; ++tp) {
-        n0 += (uint32_t)__popc(W[0][tp]);
-        n1 += (uint32_t)__popc(W[1][tp]);
-    }
-    const uint32_t mine = n0 | (n1 << 16);
-    const uint32_t other = (uint32_t)__shfl_xor((int)mine, 32, 64);
-    const uint32_t rt0 = n0 + (other & 0xFFFFu), rt1 = n1 + (other >> 16);       // hits of rows cl and 32 + cl
-    const uint32_t rowtot = kh ? rt1 : rt0;                                      // lane l: hits of row l
-    uint32_t incl = rowtot;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
-        if ((int)lane >= off) incl += o;
-    }
-    const uint32_t excl = incl - rowtot;                                         // first entry of row l
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (total < expect) return false;               // cannot happen while E bounds the error; the vector path is exact
-#if defined(FM_KO) && FM_KO == 3
-    if (total != 0xFFFFFFFFu) return true;
-#endif
-    const uint32_t excl_o = (uint32_t)__shfl_xor((int)excl, 32, 64);
-    // first entry of this lane's bits in row block 0 / 1 (the kh = 1 lane starts behind its partner's hits)
-    const uint32_t o0 = (kh ? excl_o : excl) + (kh ? (other & 0xFFFFu) : 0u);
-    const uint32_t o1 = (kh ? excl : excl_o) + (kh ? (other >> 16) : 0u);
-    const bool filter = total != expect;            // false positives among the staged entries: step 4 tests exactly
-
-    // ---- 3 + 4, in passes over row ranges whose entries fit the staging area
-    unsigned long long cursor = out_base;           // next output entry (filtering passes)
-    uint32_t row_lo = 0u;
-    while (row_lo < 64u) {
-        const uint32_t base_lo = row_lo ? (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)row_lo) : 0u;
-        uint32_t row_hi = 64u;
-        if (total - base_lo > FM_STAGE) {
-            const unsigned long long fit = __builtin_amdgcn_ballot_w64(incl <= base_lo + FM_STAGE);    // monotone: rows 0 .. k-1
-            row_hi = (uint32_t)__builtin_ctzll(~fit);
-        }
-        const uint32_t nent = (row_hi == 64u ? total : (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)row_hi)) - base_lo;
-        // -- 3. walk
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const uint32_t row = 32u * (uint32_t)rt + cl;
-            const bool inr = row >= row_lo && row < row_hi;
-            uint32_t o = (rt == 0 ? o0 : o1) - base_lo;
-            const uint32_t ebase = (row << 9) + kh * half;
-#pragma unroll
-            for (int tp = 0; tp < MFMA_TILES / 2; ++tp) {
-                uint32_t w = inr ? W[rt][tp] : 0u;
-                while (w) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(w);
-                    st[o] = (unsigned short)(ebase + 32u * (uint32_t)tp + b);
-                    o += 1u;
-                    w &= w - 1u;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-#if defined(FM_KO) && FM_KO == 2
-        if (total != 0xFFFFFFFFu) return true;
-#endif
-        // -- 4. write out
-        auto resolve = [&](uint32_t idx, uint32_t &id_i, uint32_t &id_j) -> float {
-            const uint32_t e = st[idx];
-            const float4 pa = lload4(la, e >> 9), pb = FM_GATHER ? gload4(P.sb, T.b0 + (e & 511u)) : lload4(lj, e & 511u);
-            const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;               // p2 - p1
-            id_i = __float_as_uint(pa.w);
-            id_j = __float_as_uint(pb.w);
-            if (WRAPPED) return wrapped_d2_exact(P, T.wrap, dx, dy, dz);                     // :485-486
-            return (dx * dx + dy * dy) + dz * dz;                                           // :446, :460
-        };
-        if (!filter) {
-            // groups of 64 entries aligned to 64-entry boundaries of the output arrays (see fifo_drain)
-            const unsigned long long first = out_base + base_lo;
-            const uint32_t mis = (uint32_t)first & 63u;
-            uint2 *pp = out_pairs ? out_pairs + (first - mis) : nullptr;
-            float *pd = out_dist ? out_dist + (first - mis) : nullptr;
-            for (uint32_t g = 0; g < nent + mis; g += 64u) {
-                const uint32_t k = g + lane;                    // entry k - mis of the pass
-                if (k >= mis && k - mis < nent) {
-#if defined(FM_KO) && FM_KO == 6
-                    if (pp) pp[k] = make_uint2(k, lane);
-                    if (pd) pd[k] = 1.0f;
-#else
-                    uint32_t id_i, id_j;
-                    const float d2 = resolve(k - mis, id_i, id_j);
-#if defined(FM_KO) && FM_KO == 5
-                    if (d2 == -1.0f) {
-#endif
-                    if (pp) pp[k] = make_uint2(id_i, id_j);
-                    if (pd) pd[k] = __builtin_sqrtf(d2);        // d2.sqrt() (:448)
-#if defined(FM_KO) && FM_KO == 5
-                    }
-#endif
-#endif
-                }
-            }
-        } else {
-            for (uint32_t g = 0; g < nent; g += 64u) {
-                const uint32_t k = g + lane;
-                uint32_t id_i = 0u, id_j = 0u;
-                float d2 = INFINITY;
-                if (k < nent) d2 = resolve(k, id_i, id_j);
-                const bool hit = d2 <= cutoff2;                 // the reference's test (:446, :486)
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-                if (hit) {
-                    const unsigned long long pos = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (out_pairs) out_pairs[pos] = make_uint2(id_i, id_j);
-                    if (out_dist) out_dist[pos] = __builtin_sqrtf(d2);
-                }
-                cursor += (uint32_t)__popcll(m);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        row_lo = row_hi;
-    }
-    return true;
 }
 
 template <int KIND, bool FILL, bool WRAPPED, int NCH, bool TRI, bool MASKED>
@@ -1423,10 +1124,8 @@ template <int KIND>
 __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__restrict__ task_nb,
                                                    TaskDesc *__restrict__ task_desc, uint32_t *__restrict__ task_mu,
                                                    uint32_t fast_kind, uint32_t *__restrict__ slot_cnt, uint64_t nslot_cnt,
-                                                   unsigned long long *__restrict__ scan_state, uint64_t nstate,
-                                                   uint32_t *__restrict__ n_other) {
+                                                   unsigned long long *__restrict__ scan_state, uint64_t nstate) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (t == 0 && n_other) *n_other = 0u;    // length of slotmap_kernel's list for the task-wise count pass
     if (t < nslot_cnt) slot_cnt[t] = 0u;     // the count kernel writes the slots that exist; the scan runs over the bound
     if (t < nstate) scan_state[t] = 0ull;    // ticket + tile descriptors of this search's look-back scans
     if (t == P.ntasks) {                 // terminators of the two exclusive scans (the grid covers ntasks + 1)
@@ -1450,13 +1149,10 @@ __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__r
     task_desc[t] = d;
 }
 
-__device__ __forceinline__ bool count_task_listed(uint32_t flags, uint32_t nb);
 static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, const uint32_t *__restrict__ task_first,
                                                       const TaskDesc *__restrict__ task_desc,
                                                       const unsigned long long *__restrict__ task_moff,   // NULL: no hit history
-                                                      SlotDesc *__restrict__ slot_desc, uint64_t nslots_bound,
-                                                      uint32_t *__restrict__ other_list,      // NULL: the count pass runs one wave per slot
-                                                      uint32_t *__restrict__ n_other) {
+                                                      SlotDesc *__restrict__ slot_desc, uint64_t nslots_bound) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= ntasks) {
         // slots between the real count and the host's bound: waves launched for them leave at once
@@ -1475,11 +1171,6 @@ static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, co
     const TaskDesc d = task_desc[t];
     const uint32_t rps = d.flags >> 16, nch = (d.n2 + 63u) >> 6;
     const unsigned long long m0 = task_moff ? task_moff[t] : (~0ull >> 1);
-    if (other_list && count_task_listed(d.flags, s1 - s0)) {
-        // slots the task-wise count pass (count_task_kernel) does not loop over: listed for its per-slot workers
-        const uint32_t base = atomicAdd(n_other, s1 - s0);
-        for (uint32_t s = s0; s < s1; ++s) other_list[base + (s - s0)] = s;
-    }
     for (uint32_t s = s0; s < s1; ++s) {
         SlotDesc o;
         o.a0 = d.a0; o.n1 = d.n1; o.b0 = d.b0; o.n2 = d.n2;
@@ -1503,7 +1194,7 @@ __device__ __forceinline__ bool hist_lean_slot(const SearchParams &P, uint32_t f
 
 template <int KIND, int MODE>
 __global__ void __launch_bounds__(64 * waves_per_block(MODE))
-__attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 7 : FILL_WAVES_PER_EU)))) pair_kernel(const SearchParams *__restrict__ Pp,
+__attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 7 : 8)))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
                                                      const uint32_t nslots,      // the host's bound: slots past the real count are empty
                                                      uint32_t *__restrict__ slot_cnt,
@@ -1511,14 +1202,10 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
                                                      uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
                                                      uint32_t *__restrict__ out_ids) {
     constexpr int WAVES_PER_BLOCK = waves_per_block(MODE), BLOCK = 64 * WAVES_PER_BLOCK;
-    // The fill kernel owns one block of LDS per wave, used either by run_fill_mfma (second cell, rows, staging) or by the
-    // vector paths (three FIFO planes and the replayed hits' second atoms inside the second-cell area, rows in place).
-    constexpr bool FILLK = MODE == MODE_FILL;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_blk[FILLK ? WAVES_PER_BLOCK : 1][FILLK ? FM_LDS_BYTES : 16];
-    __shared__ uint32_t lds_planes[FILLK ? 1 : WAVES_PER_BLOCK][3][FILLK ? 1 : FIFO_CAP];
-    __shared__ float4 lds_rows[FILLK ? 1 : WAVES_PER_BLOCK][FILLK ? 1 : 64];
+    __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
+    __shared__ float4 lds_a[WAVES_PER_BLOCK][64];
+    __shared__ float4 lds_q[MODE == MODE_FILL ? WAVES_PER_BLOCK : 1][MODE == MODE_FILL ? FIFO_CAP : 1];   // replayed hits' second atoms
     __shared__ uint4 lds_h[MODE == MODE_COUNT ? WAVES_PER_BLOCK : 1][MODE == MODE_COUNT ? 128 : 1];       // matrix-core row records of the count pass
-    static_assert(3u * FIFO_CAP * 4u + FIFO_CAP * 16u <= FM_LJ_LDS * 16u, "FIFO planes + replay queue fit into the second-cell area");
     constexpr bool FILL = MODE != MODE_COUNT;
     extern __shared__ uint32_t lds_hist[];     // histogram mode only (hist_nbins counters)
     // The parameter block lives in device memory: a by-value struct this large, indexed dynamically
@@ -1532,9 +1219,6 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += BLOCK) lds_hist[b] = 0u;
         __syncthreads();
     }
-    uint32_t *const planes = FILLK ? reinterpret_cast<uint32_t *>(lds_blk[wave]) : &lds_planes[wave][0][0];
-    float4 *const lds_a_w = FILLK ? reinterpret_cast<float4 *>(lds_blk[wave]) + FM_LJ_LDS : lds_rows[wave];
-    float4 *const lds_q_w = FILLK ? reinterpret_cast<float4 *>(lds_blk[wave] + 3u * FIFO_CAP * 4u) : nullptr;   // replayed hits' second atoms
     unsigned long long wave_total = 0;
     auto process_slot = [&](uint32_t w) __attribute__((always_inline)) {
         // Blocks are handed out in launch order: walk the plan BACKWARDS so the cells at the far x edge,
@@ -1565,9 +1249,9 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
             T.rps = fl >> 16;
         }
         Fifo F;
-        F.fi = planes;
-        F.fj = planes + FIFO_CAP;
-        F.fd = planes + 2 * FIFO_CAP;
+        F.fi = lds[wave][0];
+        F.fj = lds[wave][1];
+        F.fd = lds[wave][2];
         F.head = F.tail = 0;
         F.quota = 64u;
         F.has_pairs = out_pairs != nullptr;
@@ -1578,49 +1262,25 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         F.base = 0;
         F.hist = hist ? lds_hist : nullptr;
         F.recompute = 0u;
-        F.la = lds_a_w;
+        F.la = lds_a[wave];
         F.fq = nullptr;
-        F.fq_store = lds_q_w;
+        F.fq_store = MODE == MODE_FILL ? lds_q[wave] : nullptr;
         F.lh = MODE == MODE_COUNT ? lds_h[wave] : nullptr;
         F.wrap = 0;
         F.hmin = P.hist_min;
         F.hmax = P.hist_max;
         F.hn = (float)P.hist_nbins;
-        unsigned long long end = 0;
         if (FILL && !hist) {
             F.base = slot_base[slot];
             F.quota = 64u - ((uint32_t)F.base & 63u);
-            end = slot_base[slot + 1];
+            const unsigned long long end = slot_base[slot + 1];
             if (end == F.base || end > P.out_cap) return;  // nothing to emit / no room (the host grows and repeats)
-        }
-        uint32_t total = 0;
-        const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
-        if constexpr (FILLK && (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE)) {
-            // plain, same-cell and band-classified wrapped entries: classification on the matrix cores, bit walk, dense
-            // write-out (run_fill_mfma); it declines slots whose error bound is too wide
-            if (MOLAR_HIP_FILL_MFMA && P.mfma_fill && T.n2 <= FM_LJ && T.rps == 64u) {
-#ifdef MOLAR_HIP_DEBUG_KNOBS
-                if (P.debug_skip) {
-                    const uint32_t kind_bit = T.tri ? 4u : (wk != WK_NONE ? 2u : 1u);
-                    if (P.debug_skip & kind_bit) return;
-                }
-#endif
-                const uint32_t expect = (uint32_t)(end - F.base);
-                bool done = false;
-                if (wk == (uint32_t)WK_NONE) {
-                    if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) done = run_fill_mfma<KIND, true, false>(P, T, i0, F.base, expect, out_pairs, out_dist, lds_blk[wave], lane);
-                    else done = run_fill_mfma<KIND, false, false>(P, T, i0, F.base, expect, out_pairs, out_dist, lds_blk[wave], lane);
-                } else if (!T.tri && P.approx_wrapped != 0u && !(P.box.nshift != 0 && T.wrap == MOLAR_HIP_PBC_FULL)) {
-                    done = run_fill_mfma<KIND, false, true>(P, T, i0, F.base, expect, out_pairs, out_dist, lds_blk[wave], lane);
-                }
-                if (done) return;
-            }
-        }
-        if (FILL && !hist) {
             if (out_pairs) F.pairs = out_pairs + F.base + lane;
             if (out_dist) F.dist = out_dist + F.base + lane;
             if (out_ids) F.ids = out_ids + F.base + lane;
         }
+        uint32_t total = 0;
+        const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
         if (hist && P.hist_lean && hist_lean_slot<KIND>(P, (T.tri ? 0x100u : 0u) | T.wrap, T.n2)) return;   // hist_kernel's
 #ifdef MOLAR_HIP_DEBUG_KNOBS
         if (P.debug_skip) {     // not in release builds: tools/dbg_skip.sh builds with -DMOLAR_HIP_DEBUG_KNOBS
@@ -1636,10 +1296,10 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
             if (moff + 2u * nch <= P.mask_cap_units) mwords = P.maskbuf + moff * 64u;
         }
         switch (wk) {
-            case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE, MASKED>(P, T, i0, F, lds_a_w, lane, mwords); break;
-            case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG, MASKED>(P, T, i0, F, lds_a_w, lane, mwords); break;
-            case WK_UPPER: total = run_task_nch<KIND, FILL, WK_UPPER, MASKED>(P, T, i0, F, lds_a_w, lane, mwords); break;
-            default: total = run_task_nch<KIND, FILL, WK_GENERAL, MASKED>(P, T, i0, F, lds_a_w, lane, mwords); break;
+            case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
+            case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
+            case WK_UPPER: total = run_task_nch<KIND, FILL, WK_UPPER, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
+            default: total = run_task_nch<KIND, FILL, WK_GENERAL, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
         }
         if (!FILL && lane == 0) slot_cnt[slot] = total;
         wave_total += total;
@@ -1662,274 +1322,6 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
     }
 }
 
-
-// HIP limits gridDim.x * blockDim.x to 2^32 threads: sparse giant grids (10^8 plan entries, one 64-lane workgroup per
-// slot) spill into grid.y; the kernels linearise (x fastest)
-inline dim3 pair_grid(unsigned nblocks) {
-    const unsigned gx = nblocks < (1u << 24) ? (nblocks ? nblocks : 1u) : (1u << 24);
-    return dim3(gx, (nblocks + gx - 1u) / gx);
-}
-
-// ================================================================= count pass, one wave per plan entry
-// The count kernel above runs one wave per 64-row slot: 2.9*10^5 one-wave workgroups on the headline frame, each a
-// chain of memory latencies (slot record -> rows, origin, B records -> LDS round trip) in front of ~0.75 us of matrix-core
-// work - the kernel takes 0.41 ms and is bound by those chains, not by arithmetic.  Here a wave takes a whole plan entry
-// (task): the second cell's B records and origin are fetched ONCE and stay in registers, the rows of slot k + 1 are
-// requested before slot k is classified, and the per-slot results go to the same slot_cnt[] entries - a fifth of the
-// workgroups, and per slot one latency that overlaps the previous slot's arithmetic.
-// Tasks that are not looped over - entries cut into 2- or 8-row slots (the triclinic corner entries: ~80 us of latency
-// per slot, they must spread over many waves) and entries of more than COUNT_LOOP_MAX slots (crowded cells) - are listed
-// slot by slot by slotmap_kernel (`other_list`); the first `xw` workgroups of the grid are persistent workers over that
-// list, so they start before everything else and need no size known to the host.
-constexpr uint32_t COUNT_LOOP_MAX = 16;        // slots of a task one wave loops over (cells of <= 1024 atoms)
-
-// does slotmap_kernel list the slots of this task for the per-slot workers?
-__device__ __forceinline__ bool count_task_listed(uint32_t flags, uint32_t nb) { return (flags >> 16) != 64u || nb > COUNT_LOOP_MAX; }
-
-// matrix-core count of ALL slots of a plain / same-cell task (see run_count_mfma for the arithmetic and the error bound).
-// Returns a bit mask of the slots it declined (bound too wide / not finite): the caller counts those on the vector path.
-template <int KIND, bool TRI>
-__device__ __forceinline__ uint32_t run_count_mfma_task(const SearchParams &P, const Task &T, uint32_t s0, uint32_t nb, float4 *la,
-                                                        uint4 *lh, uint32_t lane, uint32_t *__restrict__ slot_cnt) {
-    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) u4_t lds_u4;
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    typedef __attribute__((address_space(1))) u4_t glb_u4;
-    const float cutoff2 = P.cutoff2;
-    const uint32_t kh = lane >> 5, cl = lane & 31u;
-    const uint32_t nct = (T.n2 + 31u) >> 5;
-    float4 a_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < T.n1) a_next = gload4(P.sa, T.a0 + lane);
-    const float4 org = gload4(P.cell_org_b, T.cb);
-    u4_t bq[MFMA_TILES];
-#pragma unroll
-    for (int t = 0; t < MFMA_TILES; ++t) {
-        const uint32_t col = (uint32_t)t * 32u + cl;
-        bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                          // atom past the end: |b|^2 = 65504, never a hit
-        if (col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
-        if (kh == 0u) bq[t].w = 0x3C003C00u;                            // k = 6, 7 of the first half: (1, 1)
-    }
-    uint32_t declined = 0u;
-    for (uint32_t k = 0; k < nb; ++k) {
-        const uint32_t i0 = 64u * k;
-        const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < 64u ? T.n1 - i0 : 64u);
-        const float4 a = a_next;
-        if (k + 1u < nb) {                                              // rows of the next slot: in flight during this one
-            a_next = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 + 64u + lane < T.n1) a_next = gload4(P.sa, T.a0 + i0 + 64u + lane);
-        }
-        __builtin_amdgcn_wave_barrier();
-        la[lane] = a;                                   // f32 rows, for the exact decision inside the band
-        const float r0 = a.x - org.x, r1 = a.y - org.y, r2 = a.z - org.z;
-        float ra2 = lane < rows ? (r0 * r0 + r1 * r1) + r2 * r2 : 0.0f;
-        const bool fin = ra2 == ra2;
-        for (int off = 32; off > 0; off >>= 1) ra2 = fmaxf(ra2, __shfl_xor(ra2, off, 64));
-        const float R = 1.0001f * __builtin_sqrtf(ra2) + org.w;
-        const float E = uniform_f32(mfma_error_bound(R, cutoff2));
-        if (__builtin_amdgcn_ballot_w64(!fin) != 0ull || !mfma_bound_usable(R, E, cutoff2, cutoff2)) {
-            declined |= 1u << k;
-            continue;
-        }
-        {   // A records of this lane's row: k = 0..7 and k = 8..15
-            u4_t k0 = {0u, 0u, 0u, 0x00007BFFu}, k1 = {0u, 0u, 0u, 0x3C003C00u};      // row past the end: +65504
-            if (lane < rows) {
-                const _Float16 h0 = (_Float16)r0, h1 = (_Float16)r1, h2 = (_Float16)r2;
-                const _Float16 l0 = (_Float16)(r0 - (float)h0), l1 = (_Float16)(r1 - (float)h1), l2 = (_Float16)(r2 - (float)h2);
-                const float e0 = (float)h0 + (float)l0, e1 = (float)h1 + (float)l1, e2 = (float)h2 + (float)l2;
-                const float na = ((e0 * e0 + e1 * e1) + e2 * e2) - cutoff2;
-                const _Float16 nh = (_Float16)na, nl = (_Float16)(na - (float)nh);
-                const _Float16 m2 = (_Float16)-2.0f;
-                const _Float16 g0 = m2 * h0, g1 = m2 * h1, g2 = m2 * h2, s0h = m2 * l0, s1h = m2 * l1, s2h = m2 * l2;
-                k0 = u4_t{pack_h2(g0, g1), pack_h2(g2, g0), pack_h2(g1, g2), pack_h2(nh, nl)};
-                k1 = u4_t{pack_h2(s0h, s1h), pack_h2(s2h, s0h), pack_h2(s1h, s2h), 0x3C003C00u};
-            }
-            ((lds_u4 *)lh)[2u * lane] = k0;
-            ((lds_u4 *)lh)[2u * lane + 1u] = k1;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const u4_t a0q = ((const lds_u4 *)lh)[2u * cl + kh], a1q = ((const lds_u4 *)lh)[2u * (32u + cl) + kh];
-        const v8h_t A0 = __builtin_bit_cast(v8h_t, a0q), A1 = __builtin_bit_cast(v8h_t, a1q);
-        __builtin_amdgcn_wave_barrier();
-        lds_u32 *todo = (lds_u32 *)lh;          // blocks with an accumulator inside (-E, E): recounted exactly below
-        uint32_t ntodo = 0;
-        uint32_t cnt = 0;
-        const bool two_blocks = rows > 32u;
-#pragma unroll
-        for (int t = 0; t < MFMA_TILES; ++t) {
-            if ((uint32_t)t < nct) {
-                const v8h_t B = __builtin_bit_cast(v8h_t, bq[t]);
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    if (rt == 1 && !two_blocks) continue;
-                    bool diag = false;
-                    if (TRI) {          // same cell (j > i, :443): blocks below the diagonal hold no pair, blocks on it are masked
-                        const uint32_t row0 = i0 + 32u * (uint32_t)rt;
-                        if (32u * (uint32_t)t + 31u <= row0) continue;
-                        diag = 32u * (uint32_t)t <= row0 + 31u;
-                    }
-                    v16f_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(rt == 0 ? A0 : A1, B, acc, 0, 0, 0);
-                    if (TRI && diag) {
-                        const int tv = (int)(32u * (uint32_t)t + cl) - (int)(i0 + 32u * (uint32_t)rt + 4u * kh);
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[i] = (tv > 8 * (i / 4) + (i % 4)) ? acc[i] : 1.0e30f;
-                    }
-                    uint32_t h = 0u;
-                    float m = INFINITY;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        h = __builtin_amdgcn_alignbit(h, __float_as_uint(acc[i]), 31);
-                        m = __builtin_fminf(m, __builtin_fabsf(acc[i]));
-                    }
-                    if (__builtin_amdgcn_ballot_w64(m < E) == 0ull) {
-                        cnt += (uint32_t)__popc(h);
-                    } else {
-                        if (lane == 0) todo[ntodo] = (uint32_t)(2 * t + rt);
-                        ++ntodo;
-                    }
-                }
-            }
-        }
-        if (ntodo) {
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t q = 0; q < ntodo; ++q) {
-                const uint32_t id = __builtin_amdgcn_readfirstlane(todo[q]);
-                const uint32_t ct = id >> 1, rt = id & 1u;
-                const uint32_t col = ct * 32u + cl;
-                float4 b = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
-                if (col < T.n2) b = gload4(P.sb, T.b0 + col);
-                for (uint32_t r = 0; r < 16u; ++r) {
-                    const uint32_t row = 32u * rt + 16u * kh + r;
-                    const float4 p = lload4(la, row);
-                    const float dx = b.x - p.x, dy = b.y - p.y, dz = b.z - p.z;     // p2 - p1
-                    const float d2 = (dx * dx + dy * dy) + dz * dz;                // |p2-p1|^2 (:446, :460)
-                    cnt += (row < rows && (!TRI || col > i0 + row) && d2 <= cutoff2) ? 1u : 0u;
-                }
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-        if (lane == 0) slot_cnt[s0 + k] = cnt;
-    }
-    return declined;
-}
-
-template <int KIND>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) count_task_kernel(
-    const SearchParams *__restrict__ Pp, const TaskDesc *__restrict__ task_desc, const uint32_t *__restrict__ task_first,
-    const SlotDesc *__restrict__ slot_desc, const uint32_t ntasks, const uint32_t xw, const uint32_t *__restrict__ other_list,
-    const uint32_t *__restrict__ n_other, const unsigned long long *__restrict__ task_moff,      // NULL: no hit history (kinds without a fast path)
-    uint32_t *__restrict__ slot_cnt) {
-    __shared__ float4 lds_rows[64];
-    __shared__ uint4 lds_h[128];
-    const SearchParams &P = *Pp;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t w = blockIdx.y * gridDim.x + blockIdx.x;
-    Fifo F;                                     // the count paths never queue anything; the vector paths want the struct
-    F.fi = F.fj = F.fd = nullptr;
-    F.head = F.tail = 0;
-    F.quota = 64u;
-    F.has_pairs = F.has_dist = false;
-    F.pairs = nullptr; F.dist = nullptr; F.ids = nullptr;
-    F.base = 0;
-    F.hist = nullptr;
-    F.recompute = 0u;
-    F.la = lds_rows;
-    F.fq = nullptr; F.fq_store = nullptr;
-    F.lh = nullptr;
-    F.wrap = 0;
-    F.hmin = F.hmax = F.hn = 0.f;
-    // one slot on the per-slot paths of pair_kernel<KIND, MODE_COUNT>
-    auto count_slot = [&](const Task &T, uint32_t i0, unsigned long long moff, bool mfma) __attribute__((always_inline)) -> uint32_t {
-        const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
-        uint32_t *mwords = nullptr;
-        const uint32_t nch = (T.n2 + 63u) >> 6;
-        if (moff + 2u * nch <= P.mask_cap_units) mwords = P.maskbuf + moff * 64u;
-        F.lh = mfma ? lds_h : nullptr;
-        switch (wk) {
-            case WK_NONE: return run_task_nch<KIND, false, WK_NONE, true>(P, T, i0, F, lds_rows, lane, mwords);
-            case WK_DIAG: return run_task_nch<KIND, false, WK_DIAG, true>(P, T, i0, F, lds_rows, lane, mwords);
-            case WK_UPPER: return run_task_nch<KIND, false, WK_UPPER, true>(P, T, i0, F, lds_rows, lane, mwords);
-            default: return run_task_nch<KIND, false, WK_GENERAL, true>(P, T, i0, F, lds_rows, lane, mwords);
-        }
-    };
-    if (w < xw) {
-        // ---- persistent worker over the listed slots (triclinic corner entries, crowded cells)
-        const uint32_t nlist = __builtin_amdgcn_readfirstlane(*n_other);
-        for (uint32_t i = w; i < nlist; i += xw) {
-            const uint32_t slot = __builtin_amdgcn_readfirstlane(other_list[i]);
-            const uint4 lo = reinterpret_cast<const uint4 *>(slot_desc + slot)[0];
-            const uint4 hi = reinterpret_cast<const uint4 *>(slot_desc + slot)[1];
-            const uint2 mo = reinterpret_cast<const uint2 *>(slot_desc + slot)[4];
-            const uint32_t fl = __builtin_amdgcn_readfirstlane(hi.y);
-            if (!(fl & 0x200u)) continue;
-            Task T;
-            T.a0 = __builtin_amdgcn_readfirstlane(lo.x);
-            T.n1 = __builtin_amdgcn_readfirstlane(lo.y);
-            T.b0 = __builtin_amdgcn_readfirstlane(lo.z);
-            T.n2 = __builtin_amdgcn_readfirstlane(lo.w);
-            T.cb = __builtin_amdgcn_readfirstlane(hi.x);
-            const uint32_t i0 = __builtin_amdgcn_readfirstlane(hi.z);
-            const unsigned long long moff = ((unsigned long long)__builtin_amdgcn_readfirstlane(mo.y) << 32) | __builtin_amdgcn_readfirstlane(mo.x);
-            T.wrap = fl & 7u;
-            T.tri = (fl & 0x100u) != 0u;
-            T.valid = true;
-            T.wrap_b = (fl >> 12) & 7u;
-            T.rps = fl >> 16;
-            const uint32_t total = count_slot(T, i0, moff, true);
-            if (lane == 0) slot_cnt[slot] = total;
-            __builtin_amdgcn_wave_barrier();
-        }
-        return;
-    }
-    // ---- one plan entry, reverse plan order (the wrapped entries of the far x edge start first, as pair_kernel)
-    const uint32_t tw = w - xw;
-    if (tw >= ntasks) return;
-    const uint32_t t = ntasks - 1u - tw;
-    const uint4 dlo = reinterpret_cast<const uint4 *>(task_desc + t)[0];
-    const uint4 dhi = reinterpret_cast<const uint4 *>(task_desc + t)[1];
-    const uint32_t fl = __builtin_amdgcn_readfirstlane(dhi.y);
-    if (!(fl & 0x200u)) return;                 // dropped / empty entry
-    const uint32_t s0 = __builtin_amdgcn_readfirstlane(task_first[t]);
-    const uint32_t nb = __builtin_amdgcn_readfirstlane(task_first[t + 1]) - s0;
-    if (count_task_listed(fl, nb)) return;      // its slots are on the list
-    Task T;
-    T.a0 = __builtin_amdgcn_readfirstlane(dlo.x);
-    T.n1 = __builtin_amdgcn_readfirstlane(dlo.y);
-    T.b0 = __builtin_amdgcn_readfirstlane(dlo.z);
-    T.n2 = __builtin_amdgcn_readfirstlane(dlo.w);
-    T.cb = __builtin_amdgcn_readfirstlane(dhi.x);
-    T.wrap = fl & 7u;
-    T.tri = (fl & 0x100u) != 0u;
-    T.valid = true;
-    T.wrap_b = (fl >> 12) & 7u;
-    T.rps = 64u;
-    const uint32_t nch = (T.n2 + 63u) >> 6;
-    unsigned long long moff0 = ~0ull >> 1;
-    if (task_moff) moff0 = task_moff[t];
-    uint32_t todo_slots = nb >= 32u ? ~0u : ((1u << nb) - 1u);
-    if constexpr (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) {
-        const bool plain = !(P.use_box && T.wrap != 0);
-        if (plain && P.mfma_count && T.n2 <= 32u * (uint32_t)MFMA_TILES) {
-            if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) todo_slots = run_count_mfma_task<KIND, true>(P, T, s0, nb, lds_rows, lds_h, lane, slot_cnt);
-            else todo_slots = run_count_mfma_task<KIND, false>(P, T, s0, nb, lds_rows, lds_h, lane, slot_cnt);
-        }
-    }
-    for (uint32_t k = 0; k < nb; ++k) {
-        if (!((todo_slots >> k) & 1u)) continue;
-        __builtin_amdgcn_wave_barrier();
-        const unsigned long long moff = task_moff ? moff0 + (unsigned long long)k * 2u * nch : moff0;
-        const uint32_t total = count_slot(T, 64u * k, moff, false);
-        if (lane == 0) slot_cnt[s0 + k] = total;
-    }
-}
-
-template <int KIND>
-inline void launch_count_task_kernel(hipStream_t stream, const SearchParams *dP, const TaskDesc *task_desc, const uint32_t *task_first,
-                                     const SlotDesc *slot_desc, uint32_t ntasks, uint32_t xw, const uint32_t *other_list,
-                                     const uint32_t *n_other, const unsigned long long *task_moff, uint32_t *slot_cnt) {
-    hipLaunchKernelGGL((count_task_kernel<KIND>), pair_grid(ntasks + xw), dim3(64), 0, stream, dP, task_desc, task_first, slot_desc, ntasks, xw,
-                       other_list, n_other, task_moff, slot_cnt);
-}
 
 // ================================================================= fused histogram, lean kernel
 // Consumer-fused histogram (molar_hip_search_histogram) for the slots that make up nearly all of the work: plain,
@@ -2287,6 +1679,12 @@ inline void launch_hist_kernel(unsigned num_cus, size_t dyn_lds, hipStream_t str
 }
 
 
+// HIP limits gridDim.x * blockDim.x to 2^32 threads: sparse giant grids (10^8 plan entries, one 64-lane workgroup per
+// slot) spill into grid.y; the kernels linearise (x fastest)
+inline dim3 pair_grid(unsigned nblocks) {
+    const unsigned gx = nblocks < (1u << 24) ? (nblocks ? nblocks : 1u) : (1u << 24);
+    return dim3(gx, (nblocks + gx - 1u) / gx);
+}
 
 // one launch of the pair kernel for a search kind / mode
 template <int KIND, int MODE>
@@ -2300,18 +1698,6 @@ inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t str
 }  // namespace pairk
 
 // defined in pair_k0.hip .. pair_k3.hip (one search kind each)
-void launch_count_task_single(hipStream_t stream, const pairk::SearchParams *dP, const pairk::TaskDesc *task_desc, const uint32_t *task_first,
-                              const pairk::SlotDesc *slot_desc, uint32_t ntasks, uint32_t xw, const uint32_t *other_list,
-                              const uint32_t *n_other, const unsigned long long *task_moff, uint32_t *slot_cnt);
-void launch_count_task_double(hipStream_t stream, const pairk::SearchParams *dP, const pairk::TaskDesc *task_desc, const uint32_t *task_first,
-                              const pairk::SlotDesc *slot_desc, uint32_t ntasks, uint32_t xw, const uint32_t *other_list,
-                              const uint32_t *n_other, const unsigned long long *task_moff, uint32_t *slot_cnt);
-void launch_count_task_within(hipStream_t stream, const pairk::SearchParams *dP, const pairk::TaskDesc *task_desc, const uint32_t *task_first,
-                              const pairk::SlotDesc *slot_desc, uint32_t ntasks, uint32_t xw, const uint32_t *other_list,
-                              const uint32_t *n_other, const unsigned long long *task_moff, uint32_t *slot_cnt);
-void launch_count_task_vdw(hipStream_t stream, const pairk::SearchParams *dP, const pairk::TaskDesc *task_desc, const uint32_t *task_first,
-                           const pairk::SlotDesc *slot_desc, uint32_t ntasks, uint32_t xw, const uint32_t *other_list,
-                           const uint32_t *n_other, const unsigned long long *task_moff, uint32_t *slot_cnt);
 void launch_hist_lean(int kind, unsigned num_cus, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
                       const pairk::SlotDesc *slot_desc, uint32_t nslots);
 void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,

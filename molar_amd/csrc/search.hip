@@ -706,7 +706,6 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.h16_b = two ? c->set[1].h16.as<uint4>() : c->set[0].h16.as<uint4>();
     P.cell_org_b = two ? c->set[1].cell_org.as<float4>() : c->set[0].cell_org.as<float4>();
     P.mfma_count = c->env_no_mfma ? 0u : 1u;
-    P.mfma_fill = c->env_no_mfma_fill ? 0u : 1u;
     P.task_desc = c->task_desc.as<TaskDesc>();
     P.maskbuf = c->maskbuf.as<uint32_t>();
     P.task_moff = c->task_moff.as<unsigned long long>();
@@ -850,24 +849,6 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     uint32_t *sc = c->slot_cnt.as<uint32_t>();
     auto *sb = c->slot_base.as<unsigned long long>();
     const int mode = !FILL ? MODE_COUNT : (hist_nbins ? MODE_HIST : MODE_FILL);
-    if (mode == MODE_COUNT && c->count_by_task) {
-        const uint32_t *ol = c->other_list.as<uint32_t>();
-        const uint32_t *no = ol + c->nslots_bound + 1;
-        const uint32_t xw = 16384u;             // persistent workers over the listed slots (the <= 28 x 512 corner slots: one each)
-        const bool fast = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
-        const unsigned long long *moff = fast ? c->task_moff.as<unsigned long long>() : nullptr;
-        const TaskDesc *td = c->task_desc.as<TaskDesc>();
-        const uint32_t *tfirst = c->task_nb.as<uint32_t>();
-        const uint32_t nt = (uint32_t)c->ntasks;
-        switch (c->kind) {
-            case MOLAR_HIP_SEARCH_SINGLE: launch_count_task_single(c->stream, dP, td, tfirst, tf, nt, xw, ol, no, moff, sc); break;
-            case MOLAR_HIP_SEARCH_DOUBLE: launch_count_task_double(c->stream, dP, td, tfirst, tf, nt, xw, ol, no, moff, sc); break;
-            case MOLAR_HIP_SEARCH_WITHIN: launch_count_task_within(c->stream, dP, td, tfirst, tf, nt, xw, ol, no, moff, sc); break;
-            default: launch_count_task_vdw(c->stream, dP, td, tfirst, tf, nt, xw, ol, no, moff, sc); break;
-        }
-        MH_HIP(hipGetLastError());
-        return 0;
-    }
     if (P.hist_lean) launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st);
     switch (c->kind) {
         case MOLAR_HIP_SEARCH_SINGLE: launch_pair_single(mode, P.nblocks, dyn_lds, c->stream, dP, tf, st, sc, sb, pairs, dist, ids); break;
@@ -1075,16 +1056,6 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     MH_TRY(c->task_mu.reserve((c->ntasks + 1) * 4));
     MH_TRY(c->task_moff.reserve((c->ntasks + 1) * 8));
     const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
-    // Count pass one wave per plan entry (count_task_kernel) while cells are not crowded: a wave loops over the <= 16
-    // slots of an entry.  With several hundred atoms per cell and more an entry has tens of slots and there are few
-    // entries: the per-slot kernel spreads those better.
-    c->count_by_task = !c->env_no_count_task && ncells > 0 && (uint64_t)c->set[0].n <= 400ull * ncells && c->ntasks < 0xFFFF0000ull;
-    uint32_t *other_list = nullptr, *n_other = nullptr;
-    if (c->count_by_task) {
-        MH_TRY(c->other_list.reserve((c->nslots_bound + 2) * 4));
-        other_list = c->other_list.as<uint32_t>();
-        n_other = other_list + c->nslots_bound + 1;
-    }
     {
         Prof prof(c, 0);
         const SearchParams P = make_params(c);
@@ -1096,12 +1067,12 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
             case MOLAR_HIP_SEARCH_SINGLE:
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
                                    c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
-                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots), n_other);
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots));
                 break;
             default:   // the three two-grid kinds decode tasks identically
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
                                    c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
-                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots), n_other);
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots));
                 break;
         }
         // slot index of every task and (fast kinds) its first hit-history unit: one single-pass scan over both
@@ -1112,7 +1083,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         const unsigned nbs = (unsigned)((c->ntasks + c->nslots_bound + 1 + 255) / 256);
         hipLaunchKernelGGL(slotmap_kernel, dim3(nbs), dim3(256), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
                            c->task_desc.as<TaskDesc>(), fast_kind ? c->task_moff.as<unsigned long long>() : nullptr,
-                           c->slot_desc.as<SlotDesc>(), c->nslots_bound, other_list, n_other);
+                           c->slot_desc.as<SlotDesc>(), c->nslots_bound);
         MH_HIP(hipGetLastError());
     }
     // hit-history buffer of the count -> fill pair: sized exactly (one small read-back; the fused histogram

@@ -614,6 +614,48 @@ def test_matrix_core_count_band_adversarial(eng, orc32, case):
     assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"])
 
 
+@pytest.mark.parametrize("scale", [0.01, 0.02, 0.04, 300.0])
+def test_matrix_core_count_band_at_other_length_scales(eng, orc32, scale, monkeypatch):
+    """The f16 operands of the matrix-core count pass have ABSOLUTE limits the relative error terms do not see: a lo part
+    below 2^-14 is a subnormal f16 with a fixed quantum of 2^-24 (cutoffs of a few hundredths of a unit: the error no longer
+    shrinks with the coordinates), and |a|^2 - cutoff^2 overflows f16 once cutoff^2 exceeds 65504 (pair_kernels.hpp,
+    mfma_error_bound / mfma_bound_usable).  The band stress of the test above, scaled: tens of thousands of interior pairs at
+    rc * (1 +- 1e-8 .. 1e-4); at scale 300 (cutoff^2 = 9e4) a blob whose cells are tight enough for the path to be tried.
+    A wrong count shifts every later slot's output, so lists must equal the oracle's bit for bit - with the matrix-core
+    count and with the vector count (MOLAR_HIP_NO_MFMA_COUNT) alike."""
+    a = api()
+    rng = np.random.default_rng(11)
+    rc = np.float32(1.0 * scale)
+    if scale < 1.0:
+        box = (np.diag([12.0, 12.0, 12.0]) * scale).astype(np.float32)
+        M = box.astype(np.float64)
+        npairs = 20000
+        pa = (0.15 + 0.7 * rng.random((npairs, 3))) @ M.T
+        u = rng.normal(size=(npairs, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+        e = 10.0 ** rng.uniform(-8.0, -4.0, npairs) * rng.choice([-1.0, 1.0], npairs)
+        pb = pa + float(rc) * (1.0 + e)[:, None] * u
+        pos = np.concatenate([pa, pb, rng.random((8000, 3)) @ M.T]).astype(np.float32)
+        ob = orc32.box_from_matrix(box)
+        ref = orc32.search_single_pbc(float(rc), pos, ob, 7, nthreads=8)
+        kw = dict(box=box, pbc=7)
+    else:
+        # no box: one blob of radius ~20 units, cutoff 300: a single cell (of <= 320 atoms per block column: 300 atoms)
+        pos = (rng.normal(size=(300, 3)) * 8.0).astype(np.float32)
+        ref = orc32.search_single(float(rc), pos, nthreads=4)
+        kw = {}
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("MOLAR_HIP_NO_MFMA_COUNT", env)
+        e2 = a.Engine(0)          # the knob is read when a context is created
+        cnt = e2.search_count(a.SEARCH_SINGLE, float(rc), pos, **kw)
+        pr, d = e2.search_fill(cnt)
+        assert cnt == len(ref["i"]), (scale, env)
+        assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"])
+    if scale < 1.0:
+        near = np.abs(ref["d"].astype(np.float64) / float(rc) - 1.0)
+        assert (near < 1e-4).sum() > 8000
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("boxkind,L", [("dodecahedron", 60.0), ("sheared", 40.0), ("sheared_huge", 160.0)])
 def test_wrapped_band_adversarial_large_sheared_boxes(eng, orc32, boxkind, L):
