@@ -241,6 +241,8 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
                          "candidate_evals_per_frame": cand, "candidate_evals_per_sec": cand * K * world / t},
             "reduced_bins_equal_single_rank": check,
         }))
+        if check is False:
+            raise SystemExit(1)
 
 
 def main():
@@ -254,15 +256,18 @@ def main():
     ap.add_argument("--serial-measure", action="store_true",
                     help="run the Kabsch fit/RMSD/COM/gyration of a frame after its search on the same stream instead of "
                          "concurrently on a second engine context (HIP stream) of the same GPU")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MOLAR_BENCH_STREAMS", "1")),
-                    help="engine contexts (HIP streams) per GPU working on different frames concurrently; 2 gives ~5 %% more "
-                         "frames/s but overlapping launches make the per-kernel event times (roofline) meaningless, so 1 is the default")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MOLAR_BENCH_STREAMS", "2")),
+                    help="engine contexts (HIP streams) per GPU working on different frames concurrently in the timed region: "
+                         "the plan / count kernels of one frame fill the tail of the other frame's fill kernel (+3..5 %% frames/s "
+                         "over 1).  The per-kernel event times and the roofline come from a separate single-context pass.")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one search at a time (molar_hip_search_resident) instead of the begin/end form that keeps two "
                          "frames queued on the engine's stream (kernels still run one after the other, in order)")
     ap.add_argument("--workload", choices=("search_fit", "rdf"), default="search_fit",
                     help="search_fit: the headline (configs[1]+[2]); rdf: configs[3] shape (fused histogram + all_reduce)")
-    ap.add_argument("--verify", action="store_true", help="rdf: rank 0 recomputes all ranks' frames and compares the reduced bins")
+    ap.add_argument("--verify", action="store_true",
+                    help="rank 0 recomputes all ranks' frames alone and compares (rdf: the reduced bins; search_fit: every "
+                         "frame's pair count and RMSD); a mismatch exits with status 1")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default=os.environ.get("MOLAR_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend; gloo only with --launch-check (CPU test of the launch path)")
     ap.add_argument("--launch-check", action="store_true", help="launch the ranks and run the collectives only (no GPU work)")
@@ -314,6 +319,7 @@ def main():
 
     from molar_amd import api, build, synth
     build.build_library()
+    exit_code = 0
     # One context = one HIP stream + its own buffers.  Frames are independent, so S contexts work on
     # different frames at the same time: the tail of one frame's kernels (idle CUs) and its host
     # round trips (result count, fit scalars) are covered by the other frame's kernels.
@@ -385,14 +391,14 @@ def main():
         return cnt, float(out["rmsd"][0])
 
     def collect_fits(k, count):
-        """The `count` fit results of context k, in frame order; all of them are part of the timed work."""
-        tot = 0.0
+        """The `count` fit results (RMSD after the fit) of context k, in frame order; all of them are part of the timed work."""
+        vals = []
         for _ in range(count):
             out = done[k].get()
             if isinstance(out, Exception):
                 raise out
-            tot += float(out["rmsd"][0])
-        return tot
+            vals.append(float(out["rmsd"][0]))
+        return vals
 
     def barrier():
         if world > 1:
@@ -425,28 +431,35 @@ def main():
                     fits.append(float(out["rmsd"][0]))
             if prev is not None:
                 res.append((eng.search_resident_end(prev)[0], None))
-            rsum = collect_fits(0, count) if overlap else sum(fits[-count:])
+            rms = collect_fits(0, count) if overlap else fits[-count:]
         elif S == 1:
             res = [step(eng, first + s) for s in range(count)]
-            rsum = collect_fits(0, count) if overlap else sum(r[1] for r in res)
+            rms = collect_fits(0, count) if overlap else [r[1] for r in res]
         else:
             import threading
             res = [None] * count
-            rs = [0.0] * S
+            rms = [0.0] * count
+            errors = []
 
             def worker(k):
-                mine = list(range(k, count, S))
-                for s in mine:
-                    res[s] = step(engines[k], first + s)
-                rs[k] = collect_fits(k, len(mine)) if overlap else sum(res[s][1] for s in mine)
+                try:
+                    mine = list(range(k, count, S))
+                    for s in mine:
+                        res[s] = step(engines[k], first + s)
+                    vals = collect_fits(k, len(mine)) if overlap else [res[s][1] for s in mine]
+                    for s, v in zip(mine, vals):
+                        rms[s] = v
+                except Exception as exc:       # a failure in a stream thread must end the run, not hang the join
+                    errors.append(exc)
 
             th = [threading.Thread(target=worker, args=(k,)) for k in range(S)]
             for t_ in th:
                 t_.start()
             for t_ in th:
                 t_.join()
-            rsum = sum(rs)
-        return sum(r[0] for r in res), rsum
+            if errors:
+                raise errors[0]
+        return [int(r[0]) for r in res], [float(v) for v in rms]
 
     # Untimed pre-heat: the same steps for --preheat seconds, so that the W warm-up steps and the K timed steps run at
     # the clocks the chip settles at under this load (a fresh box ramps for the first ~1 s: a 20-step run used to read
@@ -462,9 +475,10 @@ def main():
     barrier()
     # ---- the timed region: exactly K steps, no per-kernel event recording inside it
     t0 = time.perf_counter()
-    pairs, rsum = run_steps(W, K)
+    counts, rms = run_steps(W, K)
     barrier()
     elapsed = time.perf_counter() - t0
+    pairs, rsum = sum(counts), sum(rms)
     # ---- a second, untimed pass of the same steps with HIP events around every kernel group (per-kernel times and
     # the roofline of the fill kernel).  The events sit on each engine's own stream; with more than one context per GPU
     # the other contexts' kernels overlap the bracketed ones, so this pass runs the contexts one frame at a time.
@@ -487,6 +501,30 @@ def main():
     from molar_amd.distributed import max_over_ranks, reduce_counts
     total_pairs = float(reduce_counts([pairs], device=cdev)[0])
     t = max_over_ranks(elapsed, device=cdev)
+    verified = None
+    if args.verify:
+        # Every rank's per-frame results travel to rank 0 (one integer all_reduce of a [world, K] table of pair counts, and
+        # one of the RMSDs as int64 micro-units), and rank 0 recomputes ALL ranks' frames alone, one context, no
+        # pipelining: pair counts must be equal, RMSDs equal to 1e-6 relative.  A mismatch ends the run with rc 1.
+        tab = np.zeros((world, K), np.int64); tab[rank] = counts
+        rtab = np.zeros((world, K), np.int64); rtab[rank] = np.round(np.asarray(rms, np.float64) * 1e9).astype(np.int64)
+        tab = reduce_counts(tab.ravel(), device=cdev).reshape(world, K)
+        rtab = reduce_counts(rtab.ravel(), device=cdev).reshape(world, K)
+        if rank == 0:
+            e2 = api.Engine(local_rank)
+            verified = True
+            for r in range(world):
+                fr_r, _ = (frames, None) if r == rank else make_frames(nres, r, box, device)
+                for s_ in range(K):
+                    fr = fr_r[(W + s_) % nres].clone()
+                    cnt, _, _ = e2.search_resident(api.SEARCH_SINGLE, CUTOFF, fr, box=box, pbc=7)
+                    out = e2.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
+                    ok = int(cnt) == int(tab[r, s_]) and abs(float(out["rmsd"][0]) * 1e9 - float(rtab[r, s_])) <= 1e-6 * abs(float(rtab[r, s_])) + 2.0
+                    if not ok:
+                        verified = False
+                        print(f"bench.py --verify: rank {r} frame {s_}: pairs {int(tab[r, s_])} vs {int(cnt)}, rmsd*1e9 {int(rtab[r, s_])} vs "
+                              f"{float(out['rmsd'][0]) * 1e9:.0f}", file=sys.stderr)
+                del fr_r
 
     if rank == 0:
         frames_total = K * world
@@ -530,6 +568,7 @@ def main():
                 "measure_overlapped_with_search": overlap,
             },
             "preheat_ms": preheat_ms,
+            "verified_against_single_context": verified,
             "kernel_ms_per_frame": {k: v[0] / KP for k, v in prof.items()},
             "kernel_ms_note": f"HIP-event times from a separate untimed pass of {KP} of the same steps on one context (events are "
                               "not recorded inside the timed region); grid_build (side stream) and measure (second context) "
@@ -551,11 +590,15 @@ def main():
                                                 idx_np.astype(np.uint64))
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line))
+        if verified is False:
+            exit_code = 1
     if overlap:
         for q in jobs:
             q.put(None)
     if world > 1:
         dist.destroy_process_group()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

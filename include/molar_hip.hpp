@@ -17,13 +17,19 @@
 
 #include <array>
 #include <cmath>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <deque>
+#include <exception>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -526,6 +532,13 @@ class Histogram1D {
         return feed(d1.ctx(), d);
     }
     const std::vector<uint64_t> &counts() const { return counts_; }
+    // adds another histogram of the same shape bin by bin (the integer reduction at the end of a frame-parallel run:
+    // AnalysisTask::run_sharded, or one all_reduce of these counters across ranks)
+    void merge(const Histogram1D &o) {
+        if (o.counts_.size() != counts_.size() || o.min_ != min_ || o.max_ != max_)
+            throw MolarError(MOLAR_HIP_ERR_INVALID_ARGUMENT, "Histogram1D::merge: different binning");
+        for (size_t b = 0; b < counts_.size(); ++b) counts_[b] += o.counts_[b];
+    }
     std::vector<Float> bins() const { return std::vector<Float>(counts_.begin(), counts_.end()); }
     std::vector<Float> normalized_density() const {                                                  // stats.rs:37-43
         const Float d = (max_ - min_) / static_cast<Float>(counts_.size());
@@ -749,6 +762,12 @@ struct AnalysisContext {                     // analysis_task.rs:309-313
     System sys;
     size_t consumed_frames = 0;
     A args;
+    // additions for the frame-parallel form (run_sharded): the engine context this instance computes on (bind selections
+    // with `SelBound(ctx.sys, idx, ctx.eng())`; run() leaves it at the process-wide default) and the position of the
+    // current frame among the consumed frames of the whole run (what per-frame results are tagged with)
+    Engine *engine = nullptr;
+    Engine &eng() const { return engine ? *engine : Engine::global(); }
+    size_t frame_index = 0;
 };
 
 // AnalysisTask<A> (analysis_task.rs:113-123).  A must be constructible from the unconsumed arguments.
@@ -760,28 +779,164 @@ class AnalysisTask {
     //                    static std::string task_name();
     static void run(const std::vector<std::string> &argv, FrameSource &src) {          // :124-280
         const TrajAnalysisArgs traj_args = TrajAnalysisArgs::parse(argv);
-        if (!traj_args.use_struct_file && traj_args.files.size() < 2)
-            throw AnalysisError(AnalysisError::NoTraj, "at least one trajectory required if 'use_struct_file' is not set");
         std::unique_ptr<Derived> inst;
         std::unique_ptr<AnalysisContext<A>> context;
+        size_t index = 0;
+        for_each_consumed(traj_args, src, [&](State &&state, bool from_structure_file) {
+            if (!context) {                                                            // :282-306, :253-262
+                Topology top = src.read_topology(traj_args.files[0]);
+                context.reset(new AnalysisContext<A>{System(std::move(top), std::move(state)), 0, A(traj_args.rest)});
+                construct(inst, *context);
+            } else {                                                                   // :245-252
+                context->sys.set_state(std::move(state));
+            }
+            context->frame_index = index++;
+            process(*inst, *context);
+            if (!from_structure_file) context->consumed_frames += 1;                   // :179 counts it in the loop variable only
+        });
+        finish(inst.get(), context.get());
+    }
+
+    // Frame-parallel form of run() for one node with several GPUs: the frames run() would consume (same -b/-e/--skip
+    // window logic, same order of reads - the trajectory is still read by ONE thread, the caller's) are dealt in
+    // contiguous blocks of `block` frames, round-robin, to one worker thread per entry of `devices`
+    // (molar_hip_device_count() of them for a whole node; the same device may be named twice).  Every worker owns an
+    // engine context on its device (ctx.eng()), its own System and its own task instance - constructed, like the
+    // reference's T::new, on the FIRST consumed frame of the run, which only the worker that owns frame 0 also
+    // processes.  There is no exchange while frames are processed (the analysis_task.rs:202-267 loop body runs unchanged
+    // per frame); after the last frame the instances are folded into the first one in worker order with
+    //     void Derived::merge(Derived &&other);
+    // (integer accumulators add; per-frame series carry ctx.frame_index and are put in frame order there) and
+    // post_process runs once, on the merged instance, with consumed_frames = the whole run's.
+    static void run_sharded(const std::vector<std::string> &argv, FrameSource &src, const std::vector<int> &devices,
+                            size_t block = 8) {
+        if (devices.empty()) throw AnalysisError(AnalysisError::Arg, "run_sharded: no devices");
+        if (block == 0) block = 1;
+        const TrajAnalysisArgs traj_args = TrajAnalysisArgs::parse(argv);
+        struct Item { size_t index; State state; };
+        struct Worker {
+            std::mutex m;
+            std::condition_variable cv;
+            std::deque<Item> q;
+            bool closed = false;
+            std::unique_ptr<Engine> engine;
+            std::unique_ptr<AnalysisContext<A>> context;
+            std::unique_ptr<Derived> inst;
+            std::exception_ptr error;
+            std::thread th;
+        };
+        const size_t W = devices.size(), QCAP = 2 * block + 2;
+        std::vector<std::unique_ptr<Worker>> workers;
+        for (size_t w = 0; w < W; ++w) workers.emplace_back(new Worker);
+        std::atomic<bool> abort{false};
+        Topology top;                    // read with the first consumed frame, as run() does
+        State first;                     // what every instance is constructed on
+        auto body = [&](size_t w) {
+            Worker &me = *workers[w];
+            try {
+                me.engine.reset(new Engine(devices[w]));
+                for (;;) {
+                    Item it;
+                    {
+                        std::unique_lock<std::mutex> lk(me.m);
+                        me.cv.wait(lk, [&] { return !me.q.empty() || me.closed; });
+                        if (me.q.empty()) break;
+                        it = std::move(me.q.front());
+                        me.q.pop_front();
+                    }
+                    me.cv.notify_all();
+                    if (abort.load()) continue;
+                    if (!me.context) {
+                        me.context.reset(new AnalysisContext<A>{System(top, first), 0, A(traj_args.rest)});
+                        me.context->engine = me.engine.get();
+                        construct(me.inst, *me.context);
+                        if (it.index != 0) me.context->sys.set_state(std::move(it.state));
+                    } else {
+                        me.context->sys.set_state(std::move(it.state));
+                    }
+                    me.context->frame_index = it.index;
+                    process(*me.inst, *me.context);
+                    me.context->consumed_frames += 1;
+                }
+            } catch (...) {
+                me.error = std::current_exception();
+                abort.store(true);
+                std::lock_guard<std::mutex> lk(me.m);      // unblock a producer waiting for room in this queue
+                me.q.clear();
+                me.cv.notify_all();
+            }
+        };
+        for (size_t w = 0; w < W; ++w) workers[w]->th = std::thread(body, w);
+        size_t index = 0, struct_frames = 0;
+        std::exception_ptr producer_error;
+        try {
+            for_each_consumed(traj_args, src, [&](State &&state, bool from_structure_file) {
+                if (abort.load()) return;
+                if (index == 0) {
+                    top = src.read_topology(traj_args.files[0]);
+                    first = state;
+                }
+                if (from_structure_file) struct_frames += 1;
+                Worker &to = *workers[(index / block) % W];
+                {
+                    std::unique_lock<std::mutex> lk(to.m);
+                    to.cv.wait(lk, [&] { return to.q.size() < QCAP || abort.load(); });
+                    if (!abort.load()) to.q.push_back(Item{index, std::move(state)});
+                }
+                to.cv.notify_all();
+                index += 1;
+            });
+        } catch (...) {
+            producer_error = std::current_exception();
+            abort.store(true);
+        }
+        for (auto &w : workers) {
+            { std::lock_guard<std::mutex> lk(w->m); w->closed = true; }
+            w->cv.notify_all();
+        }
+        for (auto &w : workers) w->th.join();
+        if (producer_error) std::rethrow_exception(producer_error);
+        for (auto &w : workers)
+            if (w->error) std::rethrow_exception(w->error);
+        Worker *head = nullptr;
+        size_t consumed = 0;
+        for (auto &w : workers) {
+            if (!w->inst) continue;
+            consumed += w->context->consumed_frames;
+            if (!head) head = w.get();
+            else head->inst->merge(std::move(*w->inst));
+        }
+        if (head) head->context->consumed_frames = consumed - struct_frames;
+        finish(head ? head->inst.get() : nullptr, head ? head->context.get() : nullptr);
+    }
+
+   private:
+    static void construct(std::unique_ptr<Derived> &inst, AnalysisContext<A> &context) {
+        try { inst.reset(new Derived(context)); }
+        catch (const AnalysisError &) { throw; }
+        catch (const std::exception &e) { throw AnalysisError(AnalysisError::PreProcess, std::string("in task pre_process: ") + e.what()); }
+    }
+    static void process(Derived &inst, AnalysisContext<A> &context) {
+        try { inst.process_frame(context); }
+        catch (const std::exception &e) { throw AnalysisError(AnalysisError::ProcessFrame, std::string("in task process_frame: ") + e.what()); }
+    }
+    static void finish(Derived *inst, AnalysisContext<A> *context) {                    // :270-277
+        if (!inst) throw AnalysisError(AnalysisError::NoFramesConsumed, "no frames consumed");
+        try { inst->post_process(*context); }
+        catch (const std::exception &e) { throw AnalysisError(AnalysisError::PostProcess, std::string("in task post_process: ") + e.what()); }
+    }
+
+    // The frame loop of run() (analysis_task.rs:124-267) without the task: calls f(state, from_structure_file) for every
+    // frame the reference would hand to the task, in order.
+    template <class F>
+    static void for_each_consumed(const TrajAnalysisArgs &traj_args, FrameSource &src, F &&f) {
+        if (!traj_args.use_struct_file && traj_args.files.size() < 2)
+            throw AnalysisError(AnalysisError::NoTraj, "at least one trajectory required if 'use_struct_file' is not set");
         const auto [begin_frame, begin_time] = process_suffix(traj_args.begin);
         const auto [end_frame, end_time] = process_suffix(traj_args.end);
-        size_t consumed_frames = 0, global_frame = 0, phase = 0;
+        size_t global_frame = 0, phase = 0;
         const bool random_access_begin = traj_args.files.size() - 1 == 1;
-
-        auto init = [&](Topology top, State state) {                                   // :282-306
-            context.reset(new AnalysisContext<A>{System(std::move(top), std::move(state)), 0, A(traj_args.rest)});
-            try { inst.reset(new Derived(*context)); }
-            catch (const AnalysisError &) { throw; }
-            catch (const std::exception &e) { throw AnalysisError(AnalysisError::PreProcess, std::string("in task pre_process: ") + e.what()); }
-            try { inst->process_frame(*context); }
-            catch (const std::exception &e) { throw AnalysisError(AnalysisError::ProcessFrame, std::string("in task process_frame: ") + e.what()); }
-        };
-
-        if (traj_args.use_struct_file) {                                               // :168-179
-            init(src.read_topology(traj_args.files[0]), src.read_structure_state(traj_args.files[0]));
-            consumed_frames += 1;
-        }
+        if (traj_args.use_struct_file) f(src.read_structure_state(traj_args.files[0]), true);   // :168-179
         bool stop = false;
         for (size_t fidx = 1; fidx < traj_args.files.size() && !stop; ++fidx) {         // :184
             std::optional<size_t> sk_fr;
@@ -810,22 +965,8 @@ class AnalysisTask {
                 phase += 1;
                 global_frame += 1;
                 if (!keep) continue;
-                if (context) {                                                         // :245-252
-                    context->sys.set_state(std::move(state));
-                    try { inst->process_frame(*context); }
-                    catch (const std::exception &e) { throw AnalysisError(AnalysisError::ProcessFrame, std::string("in task process_frame: ") + e.what()); }
-                } else {                                                               // :253-262
-                    init(src.read_topology(traj_args.files[0]), std::move(state));
-                }
-                consumed_frames += 1;
-                context->consumed_frames += 1;
+                f(std::move(state), false);                                            // :245-262
             }
-        }
-        if (inst) {                                                                    // :270-277
-            try { inst->post_process(*context); }
-            catch (const std::exception &e) { throw AnalysisError(AnalysisError::PostProcess, std::string("in task post_process: ") + e.what()); }
-        } else {
-            throw AnalysisError(AnalysisError::NoFramesConsumed, "no frames consumed");
         }
     }
 };

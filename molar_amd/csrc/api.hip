@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "hoststream.hpp"
 #include <cstdlib>
 
 using namespace mh;
@@ -171,7 +172,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     for (auto &gen : c->set_store) for (auto &s : gen) {
         for (DevBuf *b : {&s.xyz_stage, &s.idx_stage, &s.vdw_stage, &s.key, &s.cell_count, &s.cnt_pad, &s.cursor, &s.tmp_key,
-                          &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb})
+                          &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb, &s.h16, &s.cell_org})
             b->release();
     }
     for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->scan_tmp, &c->scan_tmp_side, &c->scan_state, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
@@ -184,6 +185,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    mh::ring_release(c);
     if (c->h_sizes) (void)hipHostFree(c->h_sizes);
     for (auto &t : c->tickets)
         if (t.done) (void)hipEventDestroy(t.done);

@@ -120,6 +120,9 @@ struct molar_hip_ctx {
     // pinned host scratch for small read-backs
     void *h_pinned = nullptr;
     size_t h_pinned_cap = 0;
+    // ring of pinned chunks for large results that go to pageable host memory (hoststream.hpp), allocated on first use
+    void *ring[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ring_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
     // ---- cached search (count -> fill)
     bool have_search = false;

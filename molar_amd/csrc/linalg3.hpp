@@ -151,12 +151,13 @@ __host__ __device__ inline bool horn_dominant_eigenvector(const double *K, doubl
 }
 
 // cov(r,c) = sum m * q2[r] * q1[c]  (measure.rs:621-623), column-major cov[c*3+r].
-// Writes R (column-major) with q2 ~ R q1.  Returns false if cov holds a NaN.
+// Writes R (column-major) with q2 ~ R q1.  Returns false if cov holds a non-finite entry (NaN or +-inf: the callers
+// report MOLAR_HIP_ERR_SVD) or if no unit quaternion comes out of the eigen-solve.
 // precise: Jacobi only, swept to f64 working precision (the f64 Measure entries; the Newton path accepts an eigenvector
 // with a 1e-10 relative residual, ample for f32 records only).
 __host__ __device__ inline bool rotation_from_cov(const double *cov, double *R, bool precise = false) {
     for (int i = 0; i < 9; ++i)
-        if (cov[i] != cov[i]) return false;
+        if (!(fabs(cov[i]) <= 1.7976931348623157e308)) return false;      // NaN or infinity
     // S[a][b] = sum m q1[a] q2[b] = cov(b,a)
     const double Sxx = cov[0 * 3 + 0], Sxy = cov[0 * 3 + 1], Sxz = cov[0 * 3 + 2];
     const double Syx = cov[1 * 3 + 0], Syy = cov[1 * 3 + 1], Syz = cov[1 * 3 + 2];
@@ -180,6 +181,7 @@ __host__ __device__ inline bool rotation_from_cov(const double *cov, double *R, 
         }
     }
     const double nq = sqrt(q0 * q0 + qx * qx + qy * qy + qz * qz);
+    if (!(nq > 0.0) || !(nq <= 1.7976931348623157e308)) return false;
     q0 /= nq; qx /= nq; qy /= nq; qz /= nq;
     // column-major R
     R[0] = 1.0 - 2.0 * (qy * qy + qz * qz);

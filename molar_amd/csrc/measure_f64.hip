@@ -430,17 +430,20 @@ __global__ void __launch_bounds__(RB) k64b_cov(BatchD B, const double *centres, 
 }
 
 // rotation, translation, centre of mass and gyration radius of the fitted selection of frame blockIdx.x
+// A frame that fails (zero mass, non-finite covariance) raises *any_failed: no frame of the call is moved then (the
+// f32 entry behaves the same way), and its record is zero-filled rather than left uninitialised.
 __global__ void __launch_bounds__(64) k64b_rot(const double *partials, uint32_t nblk, const double *centres, Centres C2,
-                                               double *rec) {
+                                               double *rec, unsigned int *any_failed) {
     double S[10];
     frame_total<10>(partials, nblk, blockIdx.x, S);
     if (threadIdx.x != 0) return;
     double *o = rec + REC64 * (size_t)blockIdx.x;
-    if (o[17] != 0.0) return;
     const double *c1 = centres + 4 * (size_t)blockIdx.x;
     double R[9];
-    if (!rotation_from_cov(S, R, true)) {
-        o[17] = (double)MOLAR_HIP_ERR_SVD;
+    if (o[17] == 0.0 && !rotation_from_cov(S, R, true)) o[17] = (double)MOLAR_HIP_ERR_SVD;
+    if (o[17] != 0.0) {
+        for (int i = 0; i < 17; ++i) o[i] = 0.0;
+        atomicExch(any_failed, 1u);
         return;
     }
 #pragma unroll
@@ -454,7 +457,9 @@ __global__ void __launch_bounds__(64) k64b_rot(const double *partials, uint32_t 
 }
 
 // sum |R p + t - q|^2 of the fitted positions; with `apply` the frame's selection is moved (modify.rs:32-36)
-__global__ void __launch_bounds__(RB) k64b_resid(BatchD B, const double *rec, int apply, double *frames_rw, double *partials) {
+__global__ void __launch_bounds__(RB) k64b_resid(BatchD B, const double *rec, int apply, const unsigned int *any_failed, double *frames_rw,
+                                                 double *partials) {
+    if (*any_failed) apply = 0;
     double acc[1] = {0};
     const double *o = rec + REC64 * (size_t)blockIdx.y;
     double *fr = frames_rw + (size_t)blockIdx.y * B.stride;
@@ -876,21 +881,27 @@ int molar_hip_fit_rmsd_batch_f64(molar_hip_ctx *c, double *frames, size_t nframe
     double *part = c->m_partials.as<double>();
     double *rec = reinterpret_cast<double *>(static_cast<char *>(c->m_partials.p) + part_bytes);
     double *centres = rec + (size_t)F * REC64;
+    unsigned int *any_failed = reinterpret_cast<unsigned int *>(centres + 4 * (size_t)F);     // inside the 64 spare bytes
+    MH_HIP(hipMemsetAsync(any_failed, 0, 4, c->stream));
     double *frames_rw = const_cast<double *>(B.frames);
     hipLaunchKernelGGL(k64b_sums, dim3(nb, F), dim3(RB), 0, c->stream, B, part);
     hipLaunchKernelGGL(k64b_centres, dim3(F), dim3(64), 0, c->stream, part, nb, centres, rec);
     hipLaunchKernelGGL(k64b_cov, dim3(nb, F), dim3(RB), 0, c->stream, B, centres, C2, part);
-    hipLaunchKernelGGL(k64b_rot, dim3(F), dim3(64), 0, c->stream, part, nb, centres, C2, rec);
-    hipLaunchKernelGGL(k64b_resid, dim3(nb, F), dim3(RB), 0, c->stream, B, rec, apply ? 1 : 0, frames_rw, part);
+    hipLaunchKernelGGL(k64b_rot, dim3(F), dim3(64), 0, c->stream, part, nb, centres, C2, rec, any_failed);
+    hipLaunchKernelGGL(k64b_resid, dim3(nb, F), dim3(RB), 0, c->stream, B, rec, apply ? 1 : 0, any_failed, frames_rw, part);
     hipLaunchKernelGGL(k64b_rmsd, dim3(F), dim3(64), 0, c->stream, part, nb, B.n, rec, static_cast<double *>(c->h_pinned));
     MH_HIP(hipGetLastError());
-    if (apply && !is_device_ptr(frames))
-        MH_HIP(hipMemcpyAsync(frames, B.frames, nframes * natoms * 24, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
     const double *h = static_cast<const double *>(c->h_pinned);
+    // statuses first: a failed frame leaves every frame of the call where it was (nothing was moved on the device
+    // either - k64b_resid saw any_failed - and nothing is copied back), as molar_hip_fit_rmsd_batch does
     for (uint32_t f = 0; f < F; ++f) {
         const int st = (int)h[REC64 * (size_t)f + 17];
         if (st) return fail(st, st == MOLAR_HIP_ERR_ZERO_MASS ? "zero mass" : "SVD failed");
+    }
+    if (apply && !is_device_ptr(frames)) {
+        MH_HIP(hipMemcpyAsync(frames, B.frames, nframes * natoms * 24, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
     }
     auto emit = [&](double *dst, size_t per, size_t at) -> int {
         if (!dst) return 0;

@@ -1367,8 +1367,10 @@ __device__ __forceinline__ void hist_add(const HistFifo &F, float d2) {
         int b = (int)est;
         const lds_f32 *e = (const lds_f32 *)F.edges;
         const float e0 = e[b], e1 = e[b + 1];
-        b += (d2 >= e1 ? 1 : 0) - (d2 < e0 ? 1 : 0);
-        if ((uint32_t)b < (uint32_t)n) atomicAdd(&F.hist[b], 1u);
+        // one step is exact: ensure_hist_edges() hands the table over only when a bin spans >= 8 ulp of the range's largest
+        // distance (the estimate is then within 0.3 bins); narrower bins take the formula below
+        const int b1 = b + (d2 >= e1 ? 1 : 0) - (d2 < e0 ? 1 : 0);
+        if ((uint32_t)b1 < (uint32_t)n) atomicAdd(&F.hist[b1], 1u);
         return;
     }
     const float d = __builtin_sqrtf(d2);

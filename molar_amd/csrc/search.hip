@@ -21,6 +21,7 @@
 
 #include "boxmath.hpp"
 #include "common.hpp"
+#include "hoststream.hpp"
 #include "pair_kernels.hpp"
 
 using namespace mh;
@@ -899,6 +900,17 @@ int ensure_hist_edges(molar_hip_ctx *c, float hmin, float hmax, size_t nbins) {
     c->edges_nbins = 0;
     std::vector<float> e(nbins + 1);
     if (!histogram_edges(hmin, hmax, nbins, e.data())) return 0;      // formula path
+    // The kernel's first guess of a bin - (v_sqrt_f32(d2) - min) * n / (max - min) - is off by at most 2 ulp(d) / binwidth
+    // + n * 2^-23 bins, and hist_add corrects it by ONE step against the table.  That is exact while a bin spans at least
+    // 8 ulp of the largest distance of the range (0.26 bins of error); with narrower bins (a tiny [min, max] far from 0,
+    // thousands of bins: neighbouring edges even coincide) the table is declined and the kernel evaluates the formula.
+    {
+        const float dmax = std::max(std::fabs(hmin), std::fabs(hmax));
+        const float ulp = std::nextafter(dmax, INFINITY) - dmax;
+        if (!((hmax - hmin) / (float)nbins >= 8.0f * ulp)) return 0;
+        for (size_t b = 0; b < nbins; ++b)
+            if (!(e[b] < e[b + 1]) && std::isfinite(e[b + 1]) && e[b + 1] != 0.0f) return 0;   // (bins below d = 0 share the edge 0)
+    }
     MH_TRY(c->hist_edges.reserve((nbins + 1) * 4));
     MH_TRY(ensure_pinned(c, (nbins + 1) * 4));
     MH_HIP(hipStreamSynchronize(c->stream));       // a kernel of an earlier call may still read the old table / the staging area
@@ -1112,6 +1124,14 @@ int finish_count(molar_hip_ctx *c) {
     return 0;
 }
 
+// the pinned ring is worth its host threads for results of some size that go to memory the runtime cannot DMA into
+bool ring_pays(size_t link_bytes, const void *a, const void *b = nullptr, const void *d = nullptr) {
+    if (link_bytes < (24u << 20)) return false;
+    for (const void *p : {a, b, d})
+        if (p && is_pinned_host(p)) return false;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1163,8 +1183,16 @@ int molar_hip_search_fill(molar_hip_ctx *c, uint32_t *pairs, float *dist) {
         }
     }
     MH_TRY(fill_common(c, dp, ddist, nullptr));
-    if (pairs && !pd && c->total) MH_HIP(hipMemcpyAsync(pairs, dp, c->total * 8, hipMemcpyDeviceToHost, c->stream));
-    if (dist && !dd && c->total) MH_HIP(hipMemcpyAsync(dist, ddist, c->total * 4, hipMemcpyDeviceToHost, c->stream));
+    const bool hp = pairs && !pd && c->total, hd = dist && !dd && c->total;
+    if (ring_pays(c->total * ((hp ? 8u : 0u) + (hd ? 4u : 0u)), hp ? pairs : nullptr, hd ? dist : nullptr)) {
+        // large result into pageable memory: pinned ring + host threads (hoststream.hpp) instead of the runtime's bounce buffer
+        std::vector<RingJob> jobs;
+        if (hp) jobs.push_back(RingJob{dp, (size_t)c->total * 8, RING_COPY, pairs, nullptr});
+        if (hd) jobs.push_back(RingJob{ddist, (size_t)c->total * 4, RING_COPY, dist, nullptr});
+        return ring_to_host(c, jobs);
+    }
+    if (hp) MH_HIP(hipMemcpyAsync(pairs, dp, c->total * 8, hipMemcpyDeviceToHost, c->stream));
+    if (hd) MH_HIP(hipMemcpyAsync(dist, ddist, c->total * 4, hipMemcpyDeviceToHost, c->stream));
     if ((pairs && !pd) || (dist && !dd)) MH_HIP(hipStreamSynchronize(c->stream));
     return MOLAR_HIP_OK;
 }
@@ -1359,6 +1387,14 @@ int molar_hip_search_fill_usize(molar_hip_ctx *c, uint64_t *oi, uint64_t *oj, fl
     MH_TRY(fill_common(c, c->out_pairs.as<uint2>(), ddist, nullptr));
     if (n == 0) return MOLAR_HIP_OK;
     const bool di = is_device_ptr(oi), dj = is_device_ptr(oj);
+    if (!di && !dj && !(dist && dd) && ring_pays(n * 12u, oi, oj, dist)) {
+        // the usual Rust caller: (usize, usize, Float) columns in ordinary memory.  The link carries the 8-byte (u32, u32)
+        // records and the f32 distances; the widening to u64 happens on the host threads that empty the pinned ring.
+        std::vector<RingJob> jobs;
+        if (oi || oj) jobs.push_back(RingJob{c->out_pairs.p, n * 8, RING_PAIRS_TO_U64, oi, oj});
+        if (dist) jobs.push_back(RingJob{ddist, n * 4, RING_COPY, dist, nullptr});
+        return ring_to_host(c, jobs);
+    }
     unsigned long long *wi = nullptr, *wj = nullptr;
     if (oi) {
         if (di) wi = reinterpret_cast<unsigned long long *>(oi);
@@ -1394,6 +1430,10 @@ int molar_hip_search_fill_ids(molar_hip_ctx *c, uint64_t *ids) {
     MH_TRY(c->out_ids.reserve(n * 4));
     MH_TRY(fill_common(c, nullptr, nullptr, c->out_ids.as<uint32_t>()));
     const bool dv = is_device_ptr(ids);
+    if (!dv && ring_pays(n * 4u, ids)) {
+        std::vector<RingJob> jobs{RingJob{c->out_ids.p, n * 4, RING_U32_TO_U64, ids, nullptr}};
+        return ring_to_host(c, jobs);
+    }
     unsigned long long *w;
     if (dv) w = reinterpret_cast<unsigned long long *>(ids);
     else {

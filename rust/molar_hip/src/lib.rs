@@ -150,6 +150,33 @@ fn idx_ptr(idx: Option<&[usize]>) -> (*const u64, usize) {
     }
 }
 
+// The C ABI trusts its pointer/size pairs.  Safe callers cannot be allowed to hand it a mass column shorter than the
+// frame, an index past the end of the coordinates or a CSR split that leaves its index slice: the wrappers below check
+// exactly what the engine will dereference and return `EngineError::Sizes` instead of reading out of bounds.
+fn check_index(index: Option<&[usize]>, natoms: usize, what: &str) -> Result<(), EngineError> {
+    if let Some(ix) = index {
+        if let Some(&bad) = ix.iter().find(|&&a| a >= natoms) {
+            return Err(EngineError::Sizes(format!("{what}: index {bad} is out of range for {natoms} atoms")));
+        }
+    }
+    Ok(())
+}
+
+fn check_column(len: usize, natoms: usize, what: &str) -> Result<(), EngineError> {
+    // per-atom columns (masses) are gathered through the index: they must cover the whole frame
+    if len < natoms {
+        return Err(EngineError::Sizes(format!("{what}: column of {len} entries for {natoms} atoms")));
+    }
+    Ok(())
+}
+
+fn check_offsets(offsets: &[usize], index_len: usize, what: &str) -> Result<(), EngineError> {
+    if offsets.windows(2).any(|w| w[0] > w[1]) || offsets.last().map_or(false, |&e| e > index_len) {
+        return Err(EngineError::Sizes(format!("{what}: offsets must be non-decreasing and end within the {index_len} indices")));
+    }
+    Ok(())
+}
+
 fn box_ptr(b: Option<&[f32; 9]>) -> *const f32 {
     b.map_or(std::ptr::null(), |m| m.as_ptr())
 }
@@ -190,6 +217,7 @@ impl Engine {
     pub fn distance_search_single(
         &self, cutoff: f32, coords: &[[f32; 3]], index: Option<&[usize]>, box9: Option<&[f32; 9]>, pbc: u8,
     ) -> Result<Vec<(usize, usize, Float)>, EngineError> {
+        check_index(index, coords.len(), "distance_search_single")?;
         let (ip, n) = idx_ptr(index);
         let d = MolarHipSearchDesc {
             kind: SEARCH_SINGLE, cutoff, xyz1: coords.as_ptr() as *const f32, natoms1: coords.len(), idx1: ip, n1: n,
@@ -203,6 +231,8 @@ impl Engine {
         &self, cutoff: f32, coords1: &[[f32; 3]], index1: Option<&[usize]>, coords2: &[[f32; 3]], index2: Option<&[usize]>,
         box9: Option<&[f32; 9]>, pbc: u8,
     ) -> Result<Vec<(usize, usize, Float)>, EngineError> {
+        check_index(index1, coords1.len(), "distance_search_double (set 1)")?;
+        check_index(index2, coords2.len(), "distance_search_double (set 2)")?;
         let (i1, n1) = idx_ptr(index1);
         let (i2, n2) = idx_ptr(index2);
         let d = MolarHipSearchDesc {
@@ -219,6 +249,8 @@ impl Engine {
         &self, cutoff: f32, coords1: &[[f32; 3]], index1: Option<&[usize]>, coords2: &[[f32; 3]], index2: Option<&[usize]>,
         box9: &[f32; 9], pbc: u8,
     ) -> Result<Vec<usize>, EngineError> {
+        check_index(index1, coords1.len(), "distance_search_within_pbc (set 1)")?;
+        check_index(index2, coords2.len(), "distance_search_within_pbc (set 2)")?;
         let (i1, n1) = idx_ptr(index1);
         let (i2, n2) = idx_ptr(index2);
         let d = MolarHipSearchDesc {
@@ -238,6 +270,8 @@ impl Engine {
 
     /// `Measure::center_of_mass` (:60-75)
     pub fn center_of_mass(&self, coords: &[[f32; 3]], index: Option<&[usize]>, masses: &[f32]) -> Result<[f32; 3], EngineError> {
+        check_index(index, coords.len(), "center_of_mass")?;
+        check_column(masses.len(), coords.len(), "center_of_mass: masses")?;
         let (ip, n) = idx_ptr(index);
         let mut out = [0f32; 3];
         self.plugin.check(unsafe {
@@ -248,6 +282,8 @@ impl Engine {
 
     /// `Measure::gyration` (:78-87) / `gyration_pbc` (:222-232) with a box
     pub fn gyration(&self, coords: &[[f32; 3]], index: Option<&[usize]>, masses: &[f32], box9: Option<&[f32; 9]>) -> Result<f32, EngineError> {
+        check_index(index, coords.len(), "gyration")?;
+        check_column(masses.len(), coords.len(), "gyration: masses")?;
         let (ip, n) = idx_ptr(index);
         let mut out = 0f32;
         self.plugin.check(unsafe {
@@ -258,6 +294,8 @@ impl Engine {
 
     /// `rmsd` (:485-504)
     pub fn rmsd(&self, c1: &[[f32; 3]], i1: Option<&[usize]>, c2: &[[f32; 3]], i2: Option<&[usize]>) -> Result<f32, EngineError> {
+        check_index(i1, c1.len(), "rmsd (selection 1)")?;
+        check_index(i2, c2.len(), "rmsd (selection 2)")?;
         let (p1, n1) = idx_ptr(i1);
         let (p2, n2) = idx_ptr(i2);
         let mut out = 0f32;
@@ -271,6 +309,10 @@ impl Engine {
     pub fn fit_transform(
         &self, c1: &[[f32; 3]], i1: Option<&[usize]>, m1: &[f32], c2: &[[f32; 3]], i2: Option<&[usize]>, m2: &[f32],
     ) -> Result<([f32; 9], [f32; 3]), EngineError> {
+        check_index(i1, c1.len(), "fit_transform (selection 1)")?;
+        check_index(i2, c2.len(), "fit_transform (selection 2)")?;
+        check_column(m1.len(), c1.len(), "fit_transform: masses 1")?;
+        check_column(m2.len(), c2.len(), "fit_transform: masses 2")?;
         let (p1, n1) = idx_ptr(i1);
         let (p2, n2) = idx_ptr(i2);
         let (mut r, mut t) = ([0f32; 9], [0f32; 3]);
@@ -283,6 +325,7 @@ impl Engine {
 
     /// `Modify::apply_transform` (modify.rs:32-36), in place
     pub fn apply_transform(&self, coords: &mut [[f32; 3]], index: Option<&[usize]>, r: &[f32; 9], t: &[f32; 3]) -> Result<(), EngineError> {
+        check_index(index, coords.len(), "apply_transform")?;
         let (ip, n) = idx_ptr(index);
         self.plugin.check(unsafe {
             (self.plugin.fns.apply_transform)(self.ctx, coords.as_mut_ptr() as *mut f32, coords.len(), ip, n, r.as_ptr(), t.as_ptr())
@@ -294,6 +337,8 @@ impl Engine {
 
     /// `Measure::center_of_mass` (:60-75), f64
     pub fn center_of_mass_f64(&self, coords: &[[f64; 3]], index: Option<&[usize]>, masses: &[f64]) -> Result<[f64; 3], EngineError> {
+        check_index(index, coords.len(), "center_of_mass_f64")?;
+        check_column(masses.len(), coords.len(), "center_of_mass_f64: masses")?;
         let (ip, n) = idx_ptr(index);
         let mut out = [0f64; 3];
         self.plugin.check(unsafe {
@@ -304,6 +349,8 @@ impl Engine {
 
     /// `Measure::gyration` (:78-87), f64
     pub fn gyration_f64(&self, coords: &[[f64; 3]], index: Option<&[usize]>, masses: &[f64]) -> Result<f64, EngineError> {
+        check_index(index, coords.len(), "gyration_f64")?;
+        check_column(masses.len(), coords.len(), "gyration_f64: masses")?;
         let (ip, n) = idx_ptr(index);
         let mut out = 0f64;
         self.plugin.check(unsafe {
@@ -314,6 +361,8 @@ impl Engine {
 
     /// `rmsd` (:485-504), f64
     pub fn rmsd_f64(&self, c1: &[[f64; 3]], i1: Option<&[usize]>, c2: &[[f64; 3]], i2: Option<&[usize]>) -> Result<f64, EngineError> {
+        check_index(i1, c1.len(), "rmsd_f64 (selection 1)")?;
+        check_index(i2, c2.len(), "rmsd_f64 (selection 2)")?;
         let (p1, n1) = idx_ptr(i1);
         let (p2, n2) = idx_ptr(i2);
         let mut out = 0f64;
@@ -327,6 +376,10 @@ impl Engine {
     pub fn fit_transform_f64(
         &self, c1: &[[f64; 3]], i1: Option<&[usize]>, m1: &[f64], c2: &[[f64; 3]], i2: Option<&[usize]>, m2: &[f64],
     ) -> Result<([f64; 9], [f64; 3]), EngineError> {
+        check_index(i1, c1.len(), "fit_transform_f64 (selection 1)")?;
+        check_index(i2, c2.len(), "fit_transform_f64 (selection 2)")?;
+        check_column(m1.len(), c1.len(), "fit_transform_f64: masses 1")?;
+        check_column(m2.len(), c2.len(), "fit_transform_f64: masses 2")?;
         let (p1, n1) = idx_ptr(i1);
         let (p2, n2) = idx_ptr(i2);
         let (mut r, mut t) = ([0f64; 9], [0f64; 3]);
@@ -339,6 +392,7 @@ impl Engine {
 
     /// `Modify::apply_transform` (modify.rs:32-36), f64, in place
     pub fn apply_transform_f64(&self, coords: &mut [[f64; 3]], index: Option<&[usize]>, r: &[f64; 9], t: &[f64; 3]) -> Result<(), EngineError> {
+        check_index(index, coords.len(), "apply_transform_f64")?;
         let (ip, n) = idx_ptr(index);
         self.plugin.check(unsafe {
             (self.plugin.fns.apply_transform_f64)(self.ctx, coords.as_mut_ptr() as *mut f64, coords.len(), ip, n, r.as_ptr(), t.as_ptr())
@@ -347,6 +401,7 @@ impl Engine {
 
     /// `Modify::unwrap_simple_dim` (modify.rs:40-54), in place
     pub fn unwrap_simple_dim(&self, coords: &mut [[f32; 3]], index: Option<&[usize]>, box9: &[f32; 9], dims: u8) -> Result<(), EngineError> {
+        check_index(index, coords.len(), "unwrap_simple_dim")?;
         let (ip, n) = idx_ptr(index);
         self.plugin.check(unsafe {
             (self.plugin.fns.unwrap_simple)(self.ctx, coords.as_mut_ptr() as *mut f32, coords.len(), ip, n, box9.as_ptr(), dims)
@@ -357,6 +412,9 @@ impl Engine {
     pub fn gyration_batch(
         &self, coords: &[[f32; 3]], index: &[usize], offsets: &[usize], masses: &[f32], box9: Option<&[f32; 9]>,
     ) -> Result<Vec<f32>, EngineError> {
+        check_index(Some(index), coords.len(), "gyration_batch")?;
+        check_offsets(offsets, index.len(), "gyration_batch")?;
+        check_column(masses.len(), coords.len(), "gyration_batch: masses")?;
         let nsel = offsets.len().saturating_sub(1);
         let mut out = vec![0f32; nsel];
         self.plugin.check(unsafe {
@@ -374,4 +432,101 @@ impl Engine {
     pub fn raw(&self) -> (&MolarHipFns, *mut MolarHipCtx) {
         (&self.plugin.fns, self.ctx)
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Frame-parallel driver for one node with several GPUs - the Rust side of `AnalysisTask::run_sharded` in
+// include/molar_hip.hpp.  MolAR's `AnalysisTask::run` (analysis_task.rs:202-267) is a serial loop over frames whose
+// body does not depend on earlier frames for the analyses on this path (search, fit/RMSD, Measure); frames therefore
+// shard embarrassingly: one engine context and one task instance per device, contiguous blocks of frames dealt
+// round-robin, no exchange until the end, then an integer reduction (`merge`) in worker order.
+
+/// Number of GPUs the engine sees (`molar_hip_device_count`); 0 when the library or a GPU is missing.
+pub fn device_count() -> usize {
+    match Plugin::get_cached() {
+        Ok(p) => unsafe { (p.fns.device_count)() }.max(0) as usize,
+        Err(_) => 0,
+    }
+}
+
+/// What a frame-parallel analysis provides.  `new` plays the role of `AnalysisTask::new`: every instance is built on the
+/// FIRST consumed frame of the run (so a reference structure taken there is the same on every device); only the worker
+/// that owns frame 0 also processes it.
+pub trait ShardedTask: Send + Sized {
+    type Frame: Send + Sync + Clone;
+    fn new(engine: &Engine, first: &Self::Frame) -> Result<Self, EngineError>;
+    /// `frame_index` is the position of the frame among the consumed frames of the whole run: per-frame results are
+    /// tagged with it and put back in order by `merge`.
+    fn process_frame(&mut self, engine: &Engine, frame_index: usize, frame: Self::Frame) -> Result<(), EngineError>;
+    /// Folds another worker's instance into this one: integer accumulators (histogram bins, pair counts) add, per-frame
+    /// series are concatenated and sorted by frame index.
+    fn merge(&mut self, other: Self);
+}
+
+/// Runs `frames` (already windowed by -b/-e/--skip: the iterator is what `AnalysisTask::run` would consume, read by the
+/// calling thread) through one worker per entry of `devices`, in blocks of `block` consecutive frames.  Returns the merged
+/// instance and the number of frames consumed; `None` if the iterator was empty.
+pub fn run_sharded<T, I>(devices: &[i32], block: usize, frames: I) -> Result<Option<(T, usize)>, EngineError>
+where
+    T: ShardedTask,
+    I: Iterator<Item = T::Frame>,
+{
+    use std::sync::mpsc::sync_channel;
+    if devices.is_empty() {
+        return Err(EngineError::Sizes("run_sharded: no devices".into()));
+    }
+    let block = block.max(1);
+    let mut frames = frames.enumerate().peekable();
+    let first = match frames.peek() {
+        Some((_, f)) => f.clone(),
+        None => return Ok(None),
+    };
+    let first = &first;
+    std::thread::scope(|scope| {
+        let mut senders = Vec::with_capacity(devices.len());
+        let mut handles = Vec::with_capacity(devices.len());
+        for &dev in devices {
+            let (tx, rx) = sync_channel::<(usize, T::Frame)>(2 * block + 2);
+            senders.push(tx);
+            handles.push(scope.spawn(move || -> Result<Option<(T, usize)>, EngineError> {
+                let engine = Engine::new(dev)?;
+                let mut task: Option<T> = None;
+                let mut done = 0usize;
+                for (index, frame) in rx {
+                    if task.is_none() {
+                        task = Some(T::new(&engine, first)?);
+                    }
+                    task.as_mut().unwrap().process_frame(&engine, index, frame)?;
+                    done += 1;
+                }
+                Ok(task.map(|t| (t, done)))
+            }));
+        }
+        for (index, frame) in frames {
+            // a worker that failed has dropped its receiver: stop feeding, its error is collected below
+            if senders[(index / block) % devices.len()].send((index, frame)).is_err() {
+                break;
+            }
+        }
+        drop(senders);
+        let mut merged: Option<(T, usize)> = None;
+        let mut failure = None;
+        for h in handles {
+            match h.join().unwrap_or_else(|_| Err(EngineError::Other("run_sharded: a worker panicked".into()))) {
+                Ok(Some((t, n))) => match merged.as_mut() {
+                    Some((head, total)) => {
+                        head.merge(t);
+                        *total += n;
+                    }
+                    None => merged = Some((t, n)),
+                },
+                Ok(None) => {}
+                Err(e) => failure = failure.or(Some(e)),
+            }
+        }
+        match failure {
+            Some(e) => Err(e),
+            None => Ok(merged),
+        }
+    })
 }

@@ -1,6 +1,7 @@
 // GPU parity of the C++ host mirror (include/molar_hip.hpp -> libmolar_hip.so) against the CPU oracle
 // (oracle/molar_oracle.h, f32 build).  The tests read like the reference's own usage: bound
 // selections, distance_search_*<T>, fit_transform / apply_transform / rmsd, an AnalysisTask.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -314,11 +315,100 @@ static void task_tests() {
     }
 }
 
+// ---- the frame-parallel form: two engine contexts (both on device 0 here; one per GPU on a node) over 8 frames must give
+// the integer bins bit for bit and the per-frame series value for value of the serial run (analysis_task.rs:202-267 per
+// frame; DESIGN.md section 7: contiguous frame blocks, integer reduction at the end, series in frame order)
+struct RdfTask : AnalysisTask<RdfTask, NoArgs> {
+    Histogram1D hist{0.0f, 0.9f, 300};
+    std::vector<std::pair<size_t, float>> gyr;        // (frame index, gyration radius)
+    uint64_t pairs = 0;
+    size_t frames_seen_at_post = 0;
+    static RdfTask *last;
+    explicit RdfTask(AnalysisContext<NoArgs> &) {}
+    void process_frame(AnalysisContext<NoArgs> &ctx) {
+        SelBound all = SelBound::all(ctx.sys, ctx.eng());
+        pairs += hist.add_distances_single_pbc(0.9f, all, *ctx.sys.state.pbox, PBC_FULL);
+        gyr.emplace_back(ctx.frame_index, all.gyration());
+    }
+    void merge(RdfTask &&o) {
+        hist.merge(o.hist);
+        pairs += o.pairs;
+        gyr.insert(gyr.end(), o.gyr.begin(), o.gyr.end());
+        std::sort(gyr.begin(), gyr.end());
+    }
+    void post_process(AnalysisContext<NoArgs> &ctx) {
+        frames_seen_at_post = ctx.consumed_frames;
+        result_counts = hist.counts();
+        result_gyr = gyr;
+        result_pairs = pairs;
+        result_frames = frames_seen_at_post;
+    }
+    static std::string task_name() { return "rdf"; }
+    static std::vector<uint64_t> result_counts;
+    static std::vector<std::pair<size_t, float>> result_gyr;
+    static uint64_t result_pairs;
+    static size_t result_frames;
+};
+std::vector<uint64_t> RdfTask::result_counts;
+std::vector<std::pair<size_t, float>> RdfTask::result_gyr;
+uint64_t RdfTask::result_pairs = 0;
+size_t RdfTask::result_frames = 0;
+
+struct ManyFrames : Frames {
+    ManyFrames() {
+        State base = traj[0];
+        traj.clear();
+        for (int f = 0; f < 11; ++f) {
+            State s = base;
+            s.time = 10.0f * f;
+            s.pbox = PeriodicBox::from_matrix(box);
+            for (auto &p : s.coords) { p.x += (float)(0.04 * (urand() - 0.5)); p.y += (float)(0.04 * (urand() - 0.5)); p.z += (float)(0.04 * (urand() - 0.5)); }
+            traj.push_back(s);
+        }
+    }
+};
+
+static void sharded_task_tests() {
+    ManyFrames src;
+    const std::vector<std::string> argv{"-f", "top", "traj", "-b", "2", "-e", "10"};      // frames 2..9: 8 frames
+    RdfTask::run(argv, src);
+    const auto counts1 = RdfTask::result_counts;
+    const auto gyr1 = RdfTask::result_gyr;
+    const uint64_t pairs1 = RdfTask::result_pairs;
+    EXPECT(RdfTask::result_frames == 8 && gyr1.size() == 8 && pairs1 > 0);
+    for (size_t block : {size_t(1), size_t(3), size_t(8)}) {
+        RdfTask::run_sharded(argv, src, {0, 0}, block);
+        EXPECT(RdfTask::result_frames == 8);
+        EXPECT(RdfTask::result_pairs == pairs1);
+        EXPECT(RdfTask::result_counts == counts1);                       // integer bins: bit-identical
+        EXPECT(RdfTask::result_gyr.size() == gyr1.size());
+        for (size_t k = 0; k < gyr1.size() && k < RdfTask::result_gyr.size(); ++k) {
+            EXPECT(RdfTask::result_gyr[k].first == k);                   // frame order restored by merge()
+            EXPECT(RdfTask::result_gyr[k].second == gyr1[k].second);     // same kernels, same frames: same floats
+        }
+    }
+    // three workers, one of which never gets a frame (8 frames in blocks of 8 -> worker 0 only)
+    RdfTask::run_sharded(argv, src, {0, 0, 0}, 8);
+    EXPECT(RdfTask::result_counts == counts1 && RdfTask::result_frames == 8);
+    // an error inside a worker's process_frame surfaces in the caller
+    struct Boom : AnalysisTask<Boom, NoArgs> {
+        explicit Boom(AnalysisContext<NoArgs> &) {}
+        void process_frame(AnalysisContext<NoArgs> &ctx) { if (ctx.frame_index == 5) throw std::runtime_error("frame 5"); }
+        void merge(Boom &&) {}
+        void post_process(AnalysisContext<NoArgs> &) {}
+        static std::string task_name() { return "boom"; }
+    };
+    bool threw = false;
+    try { Boom::run_sharded(argv, src, {0, 0}, 2); } catch (const AnalysisError &e) { threw = e.code == AnalysisError::ProcessFrame; }
+    EXPECT(threw);
+}
+
 int main() {
     try {
         search_tests();
         measure_tests();
         task_tests();
+        sharded_task_tests();
     } catch (const std::exception &e) {
         std::printf("exception: %s\n", e.what());
         return 2;

@@ -31,6 +31,42 @@ def eng():
     return Engine(0)
 
 
+@pytest.mark.timeout(900)
+def test_c2_host_buffers_streamed_result_has_the_committed_digest(eng):
+    """What an unmodified MolAR caller sees (distance_search.rs:928-954 returns host Vecs): 12 MB of coordinates in from
+    ordinary memory, the 4.3 GB ordered pair list out into ordinary memory.  Large results travel through the context's
+    ring of pinned chunks and host threads (csrc/hoststream.hpp) instead of the runtime's pageable copy; both the
+    (u32, u32, f32) entry and the (usize, usize, f32) entry - widened on the host threads - must carry exactly the
+    committed list."""
+    import time
+    from molar_amd import api as a
+    n, rc = 1_000_000, 1.2
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 0)
+    want = json.load(open(os.path.join(G, "ordered_pair_digests.json")))["tric_a_1000000_rc1.2"]
+
+    def digest(i, j, d):
+        h = hashlib.sha256()
+        step = 1 << 24
+        for col in (i, j):
+            for k in range(0, len(col), step):
+                h.update(np.ascontiguousarray(col[k:k + step]).astype("<u4").tobytes())
+        for k in range(0, len(d), step):
+            h.update(d[k:k + step].astype("<f4").tobytes())
+        return h.hexdigest()
+
+    cnt = eng.search_count(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+    assert cnt == want["npairs"]
+    t0 = time.perf_counter()
+    pairs, dist = eng.search_fill(cnt)
+    dt = time.perf_counter() - t0
+    assert digest(pairs[:, 0], pairs[:, 1], dist) == want["sha256_i_j_d"]
+    del pairs
+    i, j, d = eng.search_fill_usize(cnt)
+    assert i.dtype == np.uint64 and digest(i, j, d) == want["sha256_i_j_d"]
+    print(f"fill into pageable host memory: {dt:.3f} s, {cnt * 12 / dt / 1e9:.1f} GB/s")
+
+
 @pytest.mark.timeout(1500)
 def test_c2_one_million_atoms_element_wise_and_digest(eng, orc32):
     import torch

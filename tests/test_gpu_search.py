@@ -400,6 +400,23 @@ def test_fused_histogram_extreme_bin_counts(eng, orc32, nbins):
         eng.search_histogram(a.SEARCH_SINGLE, 0.8, 0.0, 0.8, 8193, pos, box=box, pbc=7)
 
 
+@pytest.mark.parametrize("hmin,hmax,nbins", [(0.749, 0.75, 8192), (0.7499, 0.75, 8192), (0.59999, 0.6, 4096), (0.0, 1.0e-3, 8192)])
+def test_fused_histogram_bins_narrower_than_an_ulp(eng, orc32, hmin, hmax, nbins):
+    """Bins narrower than the spacing of the floats they cover: Histogram1D::add_one's formula then skips bins, neighbouring
+    entries of the kernel's exact edge table coincide and its first guess of the bin (v_sqrt_f32, one multiply) can be several
+    bins off - hist_add walks the monotone edge table until the squared distance lies inside the bin (advisor finding, round 2)."""
+    a = api()
+    n = 20000
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 4)
+    ref = orc32.search_single_pbc(0.8, pos, orc32.box_from_matrix(box), 7, nthreads=8)
+    want = orc32.histogram_add(hmin, hmax, nbins, ref["d"]).astype(np.uint64)
+    bins, cnt = eng.search_histogram(a.SEARCH_SINGLE, 0.8, hmin, hmax, nbins, pos, box=box, pbc=7)
+    assert cnt == len(ref["i"]) and np.array_equal(bins, want)
+    if hmin > 0.0:
+        assert want.sum() > 50           # the window is not empty
+
+
 def test_fused_histogram_regression_case_of_the_fuzzer(eng, orc32):
     """tools/fuzz_search.py, seed 123, case 500: a two-set search in a triclinic box periodic in y only, grid (1, 4, 2),
     ~400 atoms of the second set per cell (7 chunks: the register-hungriest instance of the histogram kernel's wrapped

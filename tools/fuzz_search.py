@@ -75,7 +75,7 @@ def main():
                 if case % 3 == 0:
                     # the consumer-fused mode: Histogram1D::add_one (stats.rs:29-35) over the same distance stream,
                     # with a range that also produces out-of-range and negative bins
-                    nb = int(rng.integers(1, 900)); hmin = float(np.float32(rng.uniform(-0.2, 0.4))); hmax = float(np.float32(rng.uniform(0.5, 1.6)))
+                    nb = int(rng.integers(1, 900)); hmin = float(np.float32(rng.uniform(-0.2, 0.4) * scale)); hmax = float(np.float32(rng.uniform(0.5, 1.6) * scale))
                     want = o.histogram_add(hmin, hmax, nb, ref["d"]).astype(np.uint64)
                     bins, hc = eng.search_histogram(api.SEARCH_SINGLE, rc, hmin, hmax, nb, pos, idx, **kw)
                     if hc != len(ref["i"]) or not np.array_equal(bins, want):
@@ -91,14 +91,14 @@ def main():
                     pr, d = eng.search_fill(cnt)
                     cnt2, _, _ = eng.search_resident(api.SEARCH_DOUBLE, rc, pos, i1, pos, i2, **kw)
                 else:
-                    v1 = rng.uniform(0.1, 0.25, len(i1)).astype(np.float32); v2 = rng.uniform(0.1, 0.25, len(i2)).astype(np.float32)
+                    v1 = (rng.uniform(0.1, 0.25, len(i1)) * scale).astype(np.float32); v2 = (rng.uniform(0.1, 0.25, len(i2)) * scale).astype(np.float32)
                     ref = o.search_double_vdw_pbc(p1, p2, v1, v2, ob, pbc, nthreads=4) if pbc else o.search_double_vdw(p1, p2, v1, v2, nthreads=4)
                     cnt = eng.search_count(api.SEARCH_DOUBLE_VDW, None, pos, i1, pos, i2, vdw1=v1, vdw2=v2, **kw)
                     pr, d = eng.search_fill(cnt)
                     cnt2, _, _ = eng.search_resident(api.SEARCH_DOUBLE_VDW, None, pos, i1, pos, i2, vdw1=v1, vdw2=v2, **kw)
                 pr2, d2 = eng.search_fill(cnt2)
                 if kind == 1 and case % 2 == 0:       # fused histogram of the two-set stream (same-cell duplicates included)
-                    nb = int(rng.integers(1, 900)); hmin = float(np.float32(rng.uniform(-0.2, 0.4))); hmax = float(np.float32(rng.uniform(0.5, 1.6)))
+                    nb = int(rng.integers(1, 900)); hmin = float(np.float32(rng.uniform(-0.2, 0.4) * scale)); hmax = float(np.float32(rng.uniform(0.5, 1.6) * scale))
                     want = o.histogram_add(hmin, hmax, nb, ref["d"]).astype(np.uint64)
                     bins, hc = eng.search_histogram(api.SEARCH_DOUBLE, rc, hmin, hmax, nb, pos, i1, pos, i2, **kw)
                     if hc != len(ref["i"]) or not np.array_equal(bins, want):
