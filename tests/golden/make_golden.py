@@ -12,7 +12,9 @@ environment (no cargo/rustc, no network), so NONE of these vectors comes from ru
                                        they do not prove agreement with MolAR ("parity unpinned").
   * ordered_pair_digests.json        — SHA-256 of the oracle's ordered pair lists on larger seeded frames, including
                                        BASELINE config 2 at full size (1M atoms, rc 1.2: `python make_golden.py c2`).
-Run from the repository root:  python tests/golden/make_golden.py
+Run from the repository root:  python tests/golden/make_golden.py          (regenerates the .npz / .json fixtures)
+                               python tests/golden/make_golden.py bin      (re-exports them as raw .bin + manifest for
+                                                                            rust/molar_hip/tests/parity.rs)
 """
 import hashlib
 import json
@@ -169,7 +171,38 @@ def make_c2_digest(o32, nthreads=8):
     json.dump(dig, open(path, "w"), indent=1)
 
 
+RUST_FIXTURES = os.path.join(ROOT, "rust", "molar_hip", "tests", "fixtures")
+RUST_EXPORTS = ("search_ortho", "search_tric_a", "search_hex_b", "search_rhombic_dodecahedron", "measure")
+_DT = {"float32": "f32", "float64": "f64", "uint8": "u8", "uint32": "u32", "uint64": "u64", "int64": "i64"}
+
+
+def export_for_rust():
+    """The search and Measure fixtures once more, in a format a Rust test can read without any crate: one raw
+    little-endian .bin per array (C order) + manifest.json {fixture: {key: {dtype, shape, file}}}.  The consumer is
+    rust/molar_hip/tests/parity.rs, which runs MolAR ITSELF on the inputs and compares with the committed outputs -
+    the one-command route from "parity unpinned by the reference" to pinned once a Rust toolchain is at hand.
+    tests/test_rust_parity_cpu.py keeps the export equal to the .npz files."""
+    manifest = {}
+    for name in RUST_EXPORTS:
+        z = np.load(os.path.join(HERE, name + ".npz"))
+        os.makedirs(os.path.join(RUST_FIXTURES, name), exist_ok=True)
+        entry = {}
+        for key in z.files:
+            a = np.ascontiguousarray(z[key])
+            dt = _DT[str(a.dtype)]
+            rel = f"{name}/{key}.bin"
+            a.astype(a.dtype.newbyteorder("<")).tofile(os.path.join(RUST_FIXTURES, rel))
+            entry[key] = {"dtype": dt, "shape": list(a.shape), "file": rel}
+        manifest[name] = entry
+    json.dump({"format": "raw little-endian arrays, C order", "generator": "tests/golden/make_golden.py bin", "fixtures": manifest},
+              open(os.path.join(RUST_FIXTURES, "manifest.json"), "w"), indent=1, sort_keys=True)
+    print("exported", sum(len(v) for v in manifest.values()), "arrays to", RUST_FIXTURES)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["bin"]:
+        export_for_rust()
+        sys.exit(0)
     o32, o64 = Oracle("f32"), Oracle("f64")
     if sys.argv[1:] == ["c2"]:
         make_c2_digest(o32)
