@@ -211,6 +211,34 @@ int molar_hip_search_histogram(molar_hip_ctx *ctx, const molar_hip_search_desc *
  * itself, so "largest b with edges[b] <= d2" IS the formula.  INVALID_ARGUMENT unless min < max, both finite. */
 int molar_hip_histogram_edges(float hmin, float hmax, size_t nbins, float *edges);
 
+/* ---- the drivers for MolAR built with its `f64` feature (Float = f64, aliases.rs:10-13): every operation in double -
+ * cell assignment, the predicate d2 <= cutoff^2 and the distances - results as (usize, usize, f64) columns or usize ids.
+ * Same request / count-then-fill convention as above; correct before fast (grid and plan on the host, one untuned
+ * kernel pair): the tuned path is the f32 one. */
+typedef struct {
+    int32_t kind;
+    double cutoff;
+    const double *xyz1;
+    size_t natoms1;
+    const uint64_t *idx1;
+    size_t n1;
+    const double *xyz2;
+    size_t natoms2;
+    const uint64_t *idx2;
+    size_t n2;
+    const double *vdw1;
+    const double *vdw2;
+    int32_t ids_local;
+    const double *box9;
+    uint8_t pbc;
+    const double *lower3;
+    const double *upper3;
+} molar_hip_search_desc_f64;
+int molar_hip_search_count_f64(molar_hip_ctx *ctx, const molar_hip_search_desc_f64 *desc, uint64_t *out_count);
+int molar_hip_search_fill_f64(molar_hip_ctx *ctx, uint64_t *i, uint64_t *j, double *dist);
+int molar_hip_search_fill_ids_f64(molar_hip_ctx *ctx, uint64_t *ids);
+int molar_hip_search_grid_dims_f64(molar_hip_ctx *ctx, uint64_t dims[3]);
+
 /* ------------------------------------------------------------------ Measure (measure.rs) */
 
 /* min_max :22-36 */

@@ -42,6 +42,19 @@ class SearchDesc(C.Structure):
     ]
 
 
+class SearchDescF64(C.Structure):
+    """molar_hip_search_desc_f64: the request of the f64 drivers (MolAR's `f64` feature)."""
+    _fields_ = [
+        ("kind", C.c_int32), ("cutoff", C.c_double),
+        ("xyz1", C.c_void_p), ("natoms1", C.c_size_t), ("idx1", C.c_void_p), ("n1", C.c_size_t),
+        ("xyz2", C.c_void_p), ("natoms2", C.c_size_t), ("idx2", C.c_void_p), ("n2", C.c_size_t),
+        ("vdw1", C.c_void_p), ("vdw2", C.c_void_p),
+        ("ids_local", C.c_int32),
+        ("box9", C.c_void_p), ("pbc", C.c_uint8),
+        ("lower3", C.c_void_p), ("upper3", C.c_void_p),
+    ]
+
+
 # every symbol include/molar_hip.h declares: name -> (restype, argtypes)
 _P, _SZ, _F, _I, _U8 = C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_uint8
 SYMBOLS = {
@@ -70,6 +83,10 @@ SYMBOLS = {
     "molar_hip_search_fill_usize": (_I, [_P, _P, _P, _P]),
     "molar_hip_search_fill_ids": (_I, [_P, _P]),
     "molar_hip_search_grid_dims": (_I, [_P, _P]),
+    "molar_hip_search_count_f64": (_I, [_P, _P, _P]),
+    "molar_hip_search_fill_f64": (_I, [_P, _P, _P, _P]),
+    "molar_hip_search_fill_ids_f64": (_I, [_P, _P]),
+    "molar_hip_search_grid_dims_f64": (_I, [_P, _P]),
     "molar_hip_search_resident": (_I, [_P, _P, _P, _P, _P]),
     "molar_hip_search_fill_device": (_I, [_P, _P, _P]),
     "molar_hip_search_resident_begin": (_I, [_P, _P, _P]),

@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Box, MolarHipError, SearchDesc, check
+from ._lib import Box, MolarHipError, SearchDesc, SearchDescF64, check
 
 PBC_FULL = 7
 PBC_NONE = 0
@@ -305,6 +305,51 @@ class Engine:
         """Fill caller-owned torch CUDA tensors (uint32/int32 [N,2], float32 [N]) in place."""
         pa, _ = _addr(pairs_t); da, _ = _addr(dist_t)
         check(self.lib.molar_hip_search_fill(self.ctx, pa, da))
+
+    # ------------------------------------------------------------ search, f64 build of MolAR (Float = f64)
+    def search_f64(self, kind, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, vdw1=None, vdw2=None,
+                   ids_local=False, lower=None, upper=None):
+        """The distance_search drivers with every operation in double (molar_hip_search_count_f64 + fill): returns
+        (i, j, d) as uint64 / uint64 / float64 arrays in the reference's order, or the uint64 ids for SEARCH_WITHIN."""
+        def f64(a):
+            return None if a is None else np.ascontiguousarray(a, np.float64)
+        xyz1, xyz2, vdw1, vdw2 = f64(xyz1), f64(xyz2), f64(vdw1), f64(vdw2)
+        idx1, idx2 = _u64(idx1), _u64(idx2)
+        d = SearchDescF64()
+        d.kind = kind
+        d.cutoff = float(cutoff) if cutoff is not None else 0.0
+        keep = [xyz1, xyz2, vdw1, vdw2, idx1, idx2]
+        for name, arr in (("xyz1", xyz1), ("idx1", idx1), ("xyz2", xyz2), ("idx2", idx2), ("vdw1", vdw1), ("vdw2", vdw2)):
+            setattr(d, name, None if arr is None else arr.ctypes.data)
+        d.natoms1 = 0 if xyz1 is None else xyz1.reshape(-1, 3).shape[0]
+        d.natoms2 = 0 if xyz2 is None else xyz2.reshape(-1, 3).shape[0]
+        d.n1 = 0 if idx1 is None else idx1.shape[0]
+        d.n2 = 0 if idx2 is None else idx2.shape[0]
+        d.ids_local = 1 if ids_local else 0
+        if box is not None:
+            b9 = np.ascontiguousarray(np.asarray(box, np.float64).T).reshape(9)      # column-major: columns a, b, c
+            keep.append(b9)
+            d.box9 = b9.ctypes.data
+            d.pbc = int(pbc)
+        if lower is not None:
+            lo, up = f64(lower), f64(upper)
+            keep += [lo, up]
+            d.lower3, d.upper3 = lo.ctypes.data, up.ctypes.data
+        n = C.c_uint64()
+        check(self.lib.molar_hip_search_count_f64(self.ctx, C.byref(d), C.byref(n)))
+        n = int(n.value)
+        if kind == SEARCH_WITHIN:
+            ids = np.empty(n, np.uint64)
+            check(self.lib.molar_hip_search_fill_ids_f64(self.ctx, ids.ctypes.data))
+            return ids
+        i = np.empty(n, np.uint64); j = np.empty(n, np.uint64); dist = np.empty(n, np.float64)
+        check(self.lib.molar_hip_search_fill_f64(self.ctx, i.ctypes.data, j.ctypes.data, dist.ctypes.data))
+        return i, j, dist
+
+    def grid_dims_f64(self):
+        dims = (C.c_uint64 * 3)()
+        check(self.lib.molar_hip_search_grid_dims_f64(self.ctx, dims))
+        return tuple(int(x) for x in dims)
 
     def grid_dims(self):
         dims = (C.c_uint64 * 3)()

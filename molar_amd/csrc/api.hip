@@ -4,6 +4,7 @@
 
 #include "common.hpp"
 #include "hoststream.hpp"
+namespace mh { void search64_release(molar_hip_ctx *c); }
 #include <cstdlib>
 
 using namespace mh;
@@ -186,6 +187,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     mh::ring_release(c);
+    mh::search64_release(c);
     if (c->h_sizes) (void)hipHostFree(c->h_sizes);
     for (auto &t : c->tickets)
         if (t.done) (void)hipEventDestroy(t.done);

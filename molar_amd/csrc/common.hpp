@@ -111,6 +111,8 @@ struct GridSet {
 
 }  // namespace mh
 
+struct molar_hip_search64_state;        // the cached f64 search (search_f64.hip)
+
 struct molar_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -120,6 +122,7 @@ struct molar_hip_ctx {
     // pinned host scratch for small read-backs
     void *h_pinned = nullptr;
     size_t h_pinned_cap = 0;
+    molar_hip_search64_state *s64 = nullptr;      // created by the first molar_hip_search_count_f64
     // ring of pinned chunks for large results that go to pageable host memory (hoststream.hpp), allocated on first use
     void *ring[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ring_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

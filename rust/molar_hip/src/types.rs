@@ -55,6 +55,35 @@ impl Default for MolarHipSearchDesc {
     }
 }
 
+/// `molar_hip_search_desc_f64`: the same request for MolAR built with its `f64` feature (Float = f64).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct MolarHipSearchDescF64 {
+    pub kind: i32,
+    pub cutoff: f64,
+    pub xyz1: *const f64,
+    pub natoms1: usize,
+    pub idx1: *const u64,
+    pub n1: usize,
+    pub xyz2: *const f64,
+    pub natoms2: usize,
+    pub idx2: *const u64,
+    pub n2: usize,
+    pub vdw1: *const f64,
+    pub vdw2: *const f64,
+    pub ids_local: i32,
+    pub box9: *const f64,
+    pub pbc: u8,
+    pub lower3: *const f64,
+    pub upper3: *const f64,
+}
+
+impl Default for MolarHipSearchDescF64 {
+    fn default() -> Self {
+        unsafe { std::mem::zeroed() }
+    }
+}
+
 /// `molar_hip_membrane_patches`: CSR of the patch (neighbour) lists of K lipids.
 #[repr(C)]
 pub struct MolarHipMembranePatches {

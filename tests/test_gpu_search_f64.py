@@ -1,0 +1,104 @@
+"""The f64 drivers (MolAR built with its `f64` feature: Float = f64, molar/src/aliases.rs:10-13) against the oracle's f64
+build: ids, ORDER and distances bit for bit, for all eight drivers on the four fixture boxes, with partial periodicity,
+selections and the cases where f64 arithmetic decides differently from f32 (atoms on cell faces, pairs at the cutoff)."""
+import numpy as np
+import pytest
+
+from molar_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from molar_amd import build
+    from molar_amd.api import Engine
+    build.build_library()
+    return Engine(0)
+
+
+@pytest.fixture(scope="module")
+def orc64():
+    from oracle.oracle import Oracle
+    return Oracle("f64")
+
+
+def boxes(n):
+    rd = np.array([[1.0, 0.0, 0.5], [0.0, 1.0, 0.5], [0.0, 0.0, np.sqrt(0.5)]])
+    rd = rd * ((n / 100.0) / abs(np.linalg.det(rd))) ** (1 / 3)
+    return {"ortho": synth.box_ortho(n).astype(np.float64), "tric_a": synth.box_a(n).astype(np.float64),
+            "hex_b": synth.box_b(n).astype(np.float64), "rhombic_dodecahedron": rd}
+
+
+def same(got, ref):
+    i, j, d = got
+    assert len(i) == len(ref["i"]), (len(i), len(ref["i"]))
+    assert np.array_equal(i, ref["i"]) and np.array_equal(j, ref["j"])
+    assert d.dtype == np.float64 and np.array_equal(d, ref["d"])        # same f64 operation order, correctly rounded sqrt
+
+
+@pytest.mark.parametrize("name", ["ortho", "tric_a", "hex_b", "rhombic_dodecahedron"])
+def test_all_eight_drivers_bit_exact(eng, orc64, name):
+    import molar_amd.api as a
+    n, rc = 2400, 0.55
+    box = boxes(n)[name]
+    rng = np.random.default_rng(17)
+    pos = (rng.random((n, 3)) @ box.T + rng.normal(0, 0.08, (n, 3)))                # f64 coordinates, some outside the cell
+    ob = orc64.box_from_matrix(box)
+    i1 = np.arange(0, n, 2, dtype=np.uint64); i2 = np.arange(1, n, 2, dtype=np.uint64)
+    p1, p2 = pos[0::2], pos[1::2]
+    vdw = 0.12 + 0.1 * rng.random(n)
+    for pbc in (7, 3, 5, 1):
+        same(eng.search_f64(a.SEARCH_SINGLE, rc, pos, box=box, pbc=pbc), orc64.search_single_pbc(rc, pos, ob, pbc))
+    ref = orc64.search_single_pbc(rc, pos, ob, 7)
+    eng.search_f64(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+    assert eng.grid_dims_f64() == tuple(int(x) for x in ref["dims"])
+    same(eng.search_f64(a.SEARCH_SINGLE, rc, pos), orc64.search_single(rc, pos))
+    sel = np.sort(rng.choice(n, n // 3, replace=False)).astype(np.uint64)
+    same(eng.search_f64(a.SEARCH_SINGLE, rc, pos, sel, box=box, pbc=7), orc64.search_single_pbc(rc, pos[sel.astype(int)], ob, 7, ids=sel))
+    same(eng.search_f64(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=7), orc64.search_double_pbc(rc, p1, p2, ob, 7, ids1=i1, ids2=i2))
+    same(eng.search_f64(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=6), orc64.search_double_pbc(rc, p1, p2, ob, 6, ids1=i1, ids2=i2))
+    same(eng.search_f64(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2), orc64.search_double(rc, p1, p2, ids1=i1, ids2=i2))
+    same(eng.search_f64(a.SEARCH_DOUBLE_VDW, None, pos, i1, pos, i2, box=box, pbc=7, vdw1=vdw[0::2], vdw2=vdw[1::2]),
+         orc64.search_double_vdw_pbc(p1, p2, vdw[0::2], vdw[1::2], ob, 7))
+    same(eng.search_f64(a.SEARCH_DOUBLE_VDW, None, pos, i1, pos, i2, vdw1=vdw[0::2], vdw2=vdw[1::2]),
+         orc64.search_double_vdw(p1, p2, vdw[0::2], vdw[1::2]))
+    ids = eng.search_f64(a.SEARCH_WITHIN, rc, pos, i1, pos, i2, box=box, pbc=7)
+    assert np.array_equal(ids, orc64.search_within_pbc(rc, p1, p2, ob, 7, ids1=i1, ids2=i2)["i"])
+    lo = p1.min(0) - (rc + 2.220446049250313e-16); up = p1.max(0) + (rc + 2.220446049250313e-16)
+    ids = eng.search_f64(a.SEARCH_WITHIN, rc, pos, i1, pos, i2, lower=lo, upper=up)
+    assert np.array_equal(ids, orc64.search_within(rc, p1, p2, lo, up, ids1=i1, ids2=i2)["i"])
+
+
+def test_f64_decides_where_f32_cannot(eng, orc64):
+    """Pairs at rc * (1 +- 1e-12) and atoms 1e-13 from a cell face: an f32 search cannot tell them apart, the f64 drivers
+    must agree with the f64 reference on every one of them."""
+    import molar_amd.api as a
+    rng = np.random.default_rng(3)
+    rc, L = 0.8, 8.0
+    box = np.diag([L, L, L])
+    npairs = 4000
+    pa = 0.2 * L + 0.6 * L * rng.random((npairs, 3))
+    u = rng.normal(size=(npairs, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    e = 10.0 ** rng.uniform(-14.0, -9.0, npairs) * rng.choice([-1.0, 1.0], npairs)
+    pb = pa + rc * (1.0 + e)[:, None] * u
+    cell = L / np.floor(L / rc)
+    faces = np.stack([np.round(rng.random(2000) * 9) * cell + rng.choice([-1e-13, 0.0, 1e-13], 2000), L * rng.random(2000), L * rng.random(2000)], 1)
+    pos = np.concatenate([pa, pb, faces, L * rng.random((3000, 3))])
+    ob = orc64.box_from_matrix(box)
+    ref = orc64.search_single_pbc(rc, pos, ob, 7)
+    same(eng.search_f64(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7), ref)
+    near = np.abs(ref["d"] / rc - 1.0)
+    assert (near < 1e-9).sum() > 1000
+
+
+def test_errors_f64(eng):
+    import molar_amd.api as a
+    from molar_amd._lib import MolarHipError
+    pos = np.random.default_rng(0).random((100, 3))
+    with pytest.raises(MolarHipError):
+        eng.search_f64(a.SEARCH_SINGLE, -1.0, pos)
+    with pytest.raises(MolarHipError):
+        eng.search_f64(a.SEARCH_WITHIN, 0.5, pos, None, pos, None)          # needs lower / upper without a box
+    i, j, d = eng.search_f64(a.SEARCH_SINGLE, 0.01, pos[:1])                # one atom: nothing to pair
+    assert len(i) == 0

@@ -54,3 +54,39 @@ def test_reference_benzene_states_on_device(eng):
     assert len(st) == 5 and np.array_equal(st[4].coords, host[4])
     # centre of geometry of a decoded frame through the engine
     assert np.allclose(eng.center_of_geometry(dev[0]), host[0].astype(np.float64).mean(0), atol=1e-5)
+
+
+@pytest.mark.timeout(900)
+def test_c4_shape_xtc_window_to_fused_histogram(eng, orc32):
+    """BASELINE config 4 at its frame size: a window of 250k-atom XTC frames (box A, 100 atoms/nm^3) is decoded by the
+    engine's host threads straight into HBM and every frame goes through the fused search + Histogram1D binning
+    (1200 bins of 0.001 nm, bins resident on the GPU, no per-frame round trip).  The summed integer bins must equal
+    Histogram1D::add_one (stats.rs:29-35) applied to the oracle's distance stream of the oracle-decoded frames."""
+    import torch
+    from molar_amd import api, synth
+    from molar_amd.xtc import XtcReader
+    n, nframes, rc, nbins = 250_000, 3, 1.2, 1200
+    box = synth.box_a(n)                                      # columns a, b, c
+    box9 = np.ascontiguousarray(box.T).reshape(9)             # the file stores rows a, b, c
+    blob = b"".join(orc32.xtc_encode(synth.frame(n, box, f), box9, step=f, time=float(f)) for f in range(nframes))
+    r = XtcReader(blob, engine=eng, nthreads=8)
+    assert len(r) == nframes and r.natoms == n
+    dev = torch.empty((nframes, n, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    r.read_frames(0, nframes, out=dev)
+    bins = torch.zeros(nbins, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for f in range(nframes):
+        eng.search_histogram(api.SEARCH_SINGLE, rc, 0.0, rc, nbins, dev[f], box=box, pbc=7, bins=bins, want_count=False)
+    eng.synchronize()
+    got = bins.cpu().numpy().astype(np.uint64)
+    want = np.zeros(nbins, np.uint64)
+    ob = orc32.box_from_matrix(box)
+    ncpu = os.cpu_count() or 8
+    for f, off in enumerate(orc32.xtc_index(blob)):
+        xyz = orc32.xtc_decode(blob, off)[0]
+        assert np.array_equal(dev[f].cpu().numpy(), xyz)     # same bits as the oracle's decoder
+        ref = orc32.search_single_pbc(rc, xyz, ob, 7, nthreads=ncpu)
+        want += orc32.histogram_add(0.0, rc, nbins, ref["d"]).astype(np.uint64)
+        del ref
+    assert want.sum() > 2.5e8 and np.array_equal(got, want)

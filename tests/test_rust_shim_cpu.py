@@ -66,6 +66,7 @@ def test_repr_c_structs_match_the_header():
     hdr = gen.strip_comments(open(gen.HEADER).read())
     rs = open(os.path.join(CRATE, "src", "types.rs")).read()
     for cname, rname in (("molar_hip_box", "MolarHipBox"), ("molar_hip_search_desc", "MolarHipSearchDesc"),
+                         ("molar_hip_search_desc_f64", "MolarHipSearchDescF64"),
                          ("molar_hip_membrane_patches", "MolarHipMembranePatches"),
                          ("molar_hip_membrane_state", "MolarHipMembraneState")):
         body = re.search(r"typedef\s+struct\s*\{([^{}]*)\}\s*" + cname + r"\s*;", hdr).group(1)
