@@ -155,7 +155,6 @@ molar_hip_ctx *molar_hip_create(int device) {
     // environment knobs are read here, once: the per-search paths never call getenv
     c->env_no_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") != nullptr;
     c->env_no_mfma = std::getenv("MOLAR_HIP_NO_MFMA_COUNT") != nullptr;
-    c->env_no_count_task = std::getenv("MOLAR_HIP_NO_COUNT_TASK") != nullptr;
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     if (const char *dbg = std::getenv("MOLAR_HIP_DEBUG_SKIP")) c->env_debug_skip = (uint32_t)std::atoi(dbg);
 #endif
@@ -177,7 +176,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
                           &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb, &s.h16, &s.cell_org})
             b->release();
     }
-    for (DevBuf *b : {&c->other_list, &c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->scan_tmp, &c->scan_tmp_side, &c->scan_state, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
+    for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->scan_tmp, &c->scan_tmp_side, &c->scan_state, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
                       &c->wide_i, &c->wide_j, &c->hist, &c->task_mu, &c->task_moff, &c->maskbuf, &c->m_xyz1, &c->m_xyz2, &c->m_idx1, &c->m_idx2,
                       &c->m_mass1, &c->m_mass2, &c->m_partials, &c->m_results, &c->m_out})
         b->release();

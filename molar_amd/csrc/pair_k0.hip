@@ -16,10 +16,4 @@ void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t 
         launch_pair_kernel<KIND, MODE_FILL>(nblocks, dyn_lds, stream, dP, slot_desc, nslots, slot_cnt, slot_base, pairs, dist, ids);
 }
 
-void launch_count_by_task_single(unsigned xw, hipStream_t stream, const pairk::SearchParams *dP, const pairk::SlotDesc *slot_desc,
-                                 uint32_t nslots, uint32_t *slot_cnt, const uint32_t *other_list, const uint32_t *n_other,
-                                 const pairk::TaskDesc *task_desc, const uint32_t *task_first, uint32_t ntasks) {
-    pairk::launch_count_by_task<MOLAR_HIP_SEARCH_SINGLE>(xw, stream, dP, slot_desc, nslots, slot_cnt, other_list, n_other, task_desc, task_first, ntasks);
-}
-
 }  // namespace mh

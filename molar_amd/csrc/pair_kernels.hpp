@@ -101,10 +101,8 @@ struct SearchParams {
 
 // what plan_kernel stores per plan entry and the pair kernels read back with one 32-byte load
 struct TaskDesc {
-    uint32_t a0, n1, b0, n2, cb, flags, pad0, pad1;   // flags: wrap | tri<<8 | valid<<9 | looped<<10 | wrap_b<<12 | rps<<16
+    uint32_t a0, n1, b0, n2, cb, flags, pad0, pad1;   // flags: wrap | tri<<8 | valid<<9 | wrap_b<<12 | rps<<16
 };
-constexpr uint32_t TASK_LOOPED = 0x400u;       // counted by count_tasks_kernel (one wave per plan entry), not slot by slot
-constexpr uint32_t COUNT_LOOP_MAX = 16;        // slots of a plan entry one wave loops over (first cells of <= 1024 atoms)
 
 // what slotmap_kernel stores per slot: everything a wave needs to start on its slot, so that the chain of dependent
 // loads in front of the first atom is kernel arguments -> this record -> atoms (it used to be parameter block ->
@@ -1126,10 +1124,8 @@ template <int KIND>
 __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__restrict__ task_nb,
                                                    TaskDesc *__restrict__ task_desc, uint32_t *__restrict__ task_mu,
                                                    uint32_t fast_kind, uint32_t *__restrict__ slot_cnt, uint64_t nslot_cnt,
-                                                   unsigned long long *__restrict__ scan_state, uint64_t nstate,
-                                                   uint32_t loop_tasks, uint32_t *__restrict__ n_other) {
+                                                   unsigned long long *__restrict__ scan_state, uint64_t nstate) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (t == 0 && n_other) *n_other = 0u;    // length of slotmap_kernel's list of slots counted one by one
     if (t < nslot_cnt) slot_cnt[t] = 0u;     // the count kernel writes the slots that exist; the scan runs over the bound
     if (t < nstate) scan_state[t] = 0ull;    // ticket + tile descriptors of this search's look-back scans
     if (t == P.ntasks) {                 // terminators of the two exclusive scans (the grid covers ntasks + 1)
@@ -1149,11 +1145,6 @@ __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__r
     TaskDesc d;
     d.a0 = T.a0; d.n1 = T.n1; d.b0 = T.b0; d.n2 = T.n2; d.cb = T.cb;
     d.flags = T.wrap | (T.tri ? 0x100u : 0u) | (T.valid ? 0x200u : 0u) | (T.wrap_b << 12) | (T.rps << 16);
-    // entries the task-wise count kernel loops over (count_tasks_kernel): plain / same-cell entries of the fast kinds whose
-    // second cell the matrix-core count keeps in registers; everything else is counted slot by slot (list mode)
-    if (loop_tasks && fast_kind && T.valid && !(P.use_box && T.wrap != 0u) && T.n2 <= 32u * (uint32_t)MFMA_TILES && T.rps == 64u &&
-        nb <= COUNT_LOOP_MAX)
-        d.flags |= TASK_LOOPED;
     d.pad0 = d.pad1 = 0;
     task_desc[t] = d;
 }
@@ -1161,35 +1152,8 @@ __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__r
 static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, const uint32_t *__restrict__ task_first,
                                                       const TaskDesc *__restrict__ task_desc,
                                                       const unsigned long long *__restrict__ task_moff,   // NULL: no hit history
-                                                      SlotDesc *__restrict__ slot_desc, uint64_t nslots_bound,
-                                                      uint32_t *__restrict__ other_list,      // NULL: the count pass runs one wave per slot
-                                                      uint32_t *__restrict__ n_other) {
+                                                      SlotDesc *__restrict__ slot_desc, uint64_t nslots_bound) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    uint32_t s0 = 0, s1 = 0;
-    TaskDesc d{};
-    if (t < ntasks) {
-        s0 = task_first[t];
-        s1 = task_first[t + 1];
-        if (s1 != s0) d = task_desc[t];
-    }
-    if (other_list) {
-        // slots count_tasks_kernel does not loop over are listed for its slot-wise workers (order does not matter): one
-        // atomic per wave, the lanes' shares by a wave scan
-        const uint32_t mine = (s1 != s0 && !(d.flags & TASK_LOOPED)) ? s1 - s0 : 0u;
-        uint32_t inc = mine;
-        const uint32_t lane = threadIdx.x & 63u;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
-            if ((int)lane >= off) inc += o;
-        }
-        const uint32_t wave_total = (uint32_t)__shfl((int)inc, 63, 64);
-        if (wave_total) {
-            uint32_t base = 0u;
-            if (lane == 63u) base = atomicAdd(n_other, wave_total);
-            base = (uint32_t)__shfl((int)base, 63, 64) + inc - mine;
-            for (uint32_t s = s0; s < s0 + mine; ++s) other_list[base + (s - s0)] = s;
-        }
-    }
     if (t >= ntasks) {
         // slots between the real count and the host's bound: waves launched for them leave at once
         const uint64_t s = (uint64_t)task_first[ntasks] + (t - ntasks);
@@ -1202,7 +1166,9 @@ static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, co
         }
         return;
     }
+    const uint32_t s0 = task_first[t], s1 = task_first[t + 1];
     if (s1 == s0) return;
+    const TaskDesc d = task_desc[t];
     const uint32_t rps = d.flags >> 16, nch = (d.n2 + 63u) >> 6;
     const unsigned long long m0 = task_moff ? task_moff[t] : (~0ull >> 1);
     for (uint32_t s = s0; s < s1; ++s) {
@@ -1226,7 +1192,7 @@ __device__ __forceinline__ bool hist_lean_slot(const SearchParams &P, uint32_t f
     return P.approx_wrapped != 0u && !(P.box.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL);
 }
 
-template <int KIND, int MODE, bool LISTLOOP = false>
+template <int KIND, int MODE>
 __global__ void __launch_bounds__(64 * waves_per_block(MODE))
 __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 7 : 8)))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
@@ -1234,10 +1200,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
                                                      uint32_t *__restrict__ slot_cnt,
                                                      const unsigned long long *__restrict__ slot_base,
                                                      uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
-                                                     uint32_t *__restrict__ out_ids,
-                                                     const uint32_t *__restrict__ other_list,   // LISTLOOP (count pass): the listed slots,
-                                                     const uint32_t *__restrict__ n_other,      // their number,
-                                                     const uint32_t list_first) {               // the first entry this launch takes
+                                                     uint32_t *__restrict__ out_ids) {
     constexpr int WAVES_PER_BLOCK = waves_per_block(MODE), BLOCK = 64 * WAVES_PER_BLOCK;
     __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
     __shared__ float4 lds_a[WAVES_PER_BLOCK][64];
@@ -1257,7 +1220,12 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         __syncthreads();
     }
     unsigned long long wave_total = 0;
-    auto process_slot = [&](uint32_t slot) __attribute__((always_inline)) {
+    auto process_slot = [&](uint32_t w) __attribute__((always_inline)) {
+        // Blocks are handed out in launch order: walk the plan BACKWARDS so the cells at the far x edge,
+        // whose entries wrap (several times the arithmetic per candidate), start first and the cheap
+        // entries fill the tail; consecutive blocks land on different XCDs, which spreads that band
+        // over the whole chip.
+        const uint32_t slot = nslots - 1u - w;
         Task T;   // record prepared by slotmap_kernel: one dependent load between the kernel arguments and the atoms
         uint32_t i0;
         unsigned long long moff;
@@ -1336,25 +1304,13 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         if (!FILL && lane == 0) slot_cnt[slot] = total;
         wave_total += total;
     };
-    // Blocks are handed out in launch order: walk the plan BACKWARDS so the cells at the far x edge, whose entries wrap
-    // (several times the arithmetic per candidate), start first and the cheap entries fill the tail; consecutive blocks
-    // land on different XCDs, which spreads that band over the whole chip.
     const uint32_t w0 = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES_PER_BLOCK + wave;
-    if (MODE == MODE_COUNT && LISTLOOP) {
-        // what count_tasks_kernel's own list workers could not reach: entries [list_first, length) of the list, strided
-        // (normally none; this loop form keeps more values live across slots - 94 spilled VGPRs against 20 - so it is
-        // not how the slots are counted in general)
-        const uint32_t nlist = __builtin_amdgcn_readfirstlane(*n_other);
-        for (uint32_t i = list_first + w0; i < nlist; i += gridDim.x * gridDim.y) {
-            process_slot(__builtin_amdgcn_readfirstlane(other_list[i]));
-            __builtin_amdgcn_wave_barrier();
-        }
-    } else if (!hist) {
+    if (!hist) {
         // COUNT / FILL: one wave per slot (nothing is live across slots -> fewer registers, more waves)
-        if (w0 < nslots) process_slot(nslots - 1u - w0);
+        if (w0 < nslots) process_slot(w0);
     } else {
         // histogram mode: capped grid, strided slots, so each workgroup flushes its LDS histogram once
-        for (uint32_t w = w0; w < nslots; w += gridDim.x * gridDim.y * WAVES_PER_BLOCK) process_slot(nslots - 1u - w);
+        for (uint32_t w = w0; w < nslots; w += gridDim.x * gridDim.y * WAVES_PER_BLOCK) process_slot(w);
     }
     if (hist) {
         __syncthreads();
@@ -1366,290 +1322,6 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
     }
 }
 
-
-// ================================================================= count pass, one wave per plan entry
-// pair_kernel<MODE_COUNT> runs one wave per 64-row slot: 2.9*10^5 one-wave workgroups on the headline frame, and in front
-// of the ~450 VALU instructions of a slot's matrix-core classification stand as many again of per-slot set-up (slot record,
-// B records and origin of the second cell, row reduction, row records through LDS).  Here a wave takes a whole plan entry:
-// the second cell's B records and origin are fetched ONCE and stay in registers, the rows of slot k + 1 are requested
-// before slot k is classified, and the per-slot results go to the same slot_cnt[] entries.  Only plain and same-cell
-// entries of the fast kinds are looped over (TASK_LOOPED, decided by plan_kernel); the rest - wrapped entries with their
-// hit history, the triclinic corner entries cut into 2-row slots, crowded cells - stays with pair_kernel in list mode.
-// A kernel of its own: inside pair_kernel the register allocation is the maximum over every path, and the looped form in
-// there spilled 126 VGPRs (0.565 ms against 0.46 ms; round 3, commit 9410e52).
-#ifndef CT_WEU
-#define CT_WEU 5        // waves per SIMD of count_tasks_kernel
-#endif
-#ifndef CT_TWO
-#define CT_TWO 1        // both row blocks of a block column in flight (32 accumulators)
-#endif
-// matrix-core count of ALL slots of a plain / same-cell task (see run_count_mfma for the arithmetic and the error bound).
-// Returns a bit mask of the slots it declined (bound too wide / not finite): the caller counts those on the vector path.
-template <int KIND, bool TRI>
-__device__ __forceinline__ uint32_t run_count_mfma_task(const SearchParams &P, const Task &T, uint32_t s0, uint32_t nb, float4 *la,
-                                                        uint4 *lh, uint4 *lb, uint32_t lane, uint32_t *__restrict__ slot_cnt) {
-    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) u4_t lds_u4;
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    typedef __attribute__((address_space(1))) u4_t glb_u4;
-    const float cutoff2 = P.cutoff2;
-    const uint32_t kh = lane >> 5, cl = lane & 31u;
-    const uint32_t nct = (T.n2 + 31u) >> 5;
-    float4 a_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < T.n1) a_next = gload4(P.sa, T.a0 + lane);
-    const float4 org = gload4(P.cell_org_b, T.cb);
-    // the second cell's B records go to LDS once per plan entry (5 KB): a block column is then one ds_read_b128 instead of
-    // four registers held for the whole entry, which leaves room for both row blocks' accumulators in flight
-#pragma unroll
-    for (int k = 0; k < MFMA_TILES / 2; ++k) {
-        const uint32_t col = (uint32_t)k * 64u + lane;
-        u4_t rec = u4_t{0u, 0u, 0u, 0x00007BFFu};                       // atom past the end: |b|^2 = 65504, never a hit
-        if (col < T.n2) rec = ((const glb_u4 *)P.h16_b)[T.b0 + col];
-        ((lds_u4 *)lb)[col] = rec;
-    }
-    uint32_t declined = 0u;
-    for (uint32_t k = 0; k < nb; ++k) {
-        const uint32_t i0 = 64u * k;
-        const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < 64u ? T.n1 - i0 : 64u);
-        const float4 a = a_next;
-        if (k + 1u < nb) {                                              // rows of the next slot: in flight during this one
-            a_next = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 + 64u + lane < T.n1) a_next = gload4(P.sa, T.a0 + i0 + 64u + lane);
-        }
-        __builtin_amdgcn_wave_barrier();
-        la[lane] = a;                                   // f32 rows, for the exact decision inside the band
-        const float r0 = a.x - org.x, r1 = a.y - org.y, r2 = a.z - org.z;
-        float ra2 = lane < rows ? (r0 * r0 + r1 * r1) + r2 * r2 : 0.0f;
-        const bool fin = ra2 == ra2;
-        for (int off = 32; off > 0; off >>= 1) ra2 = fmaxf(ra2, __shfl_xor(ra2, off, 64));
-        const float R = 1.0001f * __builtin_sqrtf(ra2) + org.w;
-        const float E = uniform_f32(mfma_error_bound(R, cutoff2));
-        // (one ballot over the whole condition: R and E are the same in every lane, but only a ballot tells the compiler so,
-        // and a branch it takes for divergent would put the loop-long `declined` into a VGPR - see HistFifo)
-        if (__builtin_amdgcn_ballot_w64(!fin || !mfma_bound_usable(R, E, cutoff2)) != 0ull) {
-            declined = __builtin_amdgcn_readfirstlane(declined | (1u << k));     // wave-uniform and loop-long: pinned to an SGPR (see HistFifo)
-            continue;
-        }
-        {   // A records of this lane's row: k = 0..7 and k = 8..15
-            u4_t k0 = {0u, 0u, 0u, 0x00007BFFu}, k1 = {0u, 0u, 0u, 0x3C003C00u};      // row past the end: +65504
-            if (lane < rows) {
-                const _Float16 h0 = (_Float16)r0, h1 = (_Float16)r1, h2 = (_Float16)r2;
-                const _Float16 l0 = (_Float16)(r0 - (float)h0), l1 = (_Float16)(r1 - (float)h1), l2 = (_Float16)(r2 - (float)h2);
-                const float e0 = (float)h0 + (float)l0, e1 = (float)h1 + (float)l1, e2 = (float)h2 + (float)l2;
-                const float na = ((e0 * e0 + e1 * e1) + e2 * e2) - cutoff2;
-                const _Float16 nh = (_Float16)na, nl = (_Float16)(na - (float)nh);
-                const _Float16 m2 = (_Float16)-2.0f;
-                const _Float16 g0 = m2 * h0, g1 = m2 * h1, g2 = m2 * h2, s0h = m2 * l0, s1h = m2 * l1, s2h = m2 * l2;
-                k0 = u4_t{pack_h2(g0, g1), pack_h2(g2, g0), pack_h2(g1, g2), pack_h2(nh, nl)};
-                k1 = u4_t{pack_h2(s0h, s1h), pack_h2(s2h, s0h), pack_h2(s1h, s2h), 0x3C003C00u};
-            }
-            ((lds_u4 *)lh)[2u * lane] = k0;
-            ((lds_u4 *)lh)[2u * lane + 1u] = k1;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const u4_t a0q = ((const lds_u4 *)lh)[2u * cl + kh], a1q = ((const lds_u4 *)lh)[2u * (32u + cl) + kh];
-        const v8h_t A0 = __builtin_bit_cast(v8h_t, a0q), A1 = __builtin_bit_cast(v8h_t, a1q);
-        __builtin_amdgcn_wave_barrier();
-        lds_u32 *todo = (lds_u32 *)lh;          // candidates with an accumulator inside (-E, E): decided exactly below
-        constexpr uint32_t TODO_CAP = 512u;     // (the row records' staging area, free again: 128 x 16 bytes)
-        uint32_t ntodo = 0;
-        uint32_t cnt = 0;
-        const bool two_blocks = rows > 32u;
-#pragma unroll
-        for (int t = 0; t < MFMA_TILES; ++t) {
-            if ((uint32_t)t < nct) {
-                u4_t bt = ((const lds_u4 *)lb)[32u * (uint32_t)t + cl];
-                if (kh == 0u) bt.w = 0x3C003C00u;                       // k = 6, 7 of the first half: (1, 1)
-                const v8h_t B = __builtin_bit_cast(v8h_t, bt);
-                // both row blocks of the column are issued before either is read: the second instruction runs while the
-                // first one's 16 accumulators are turned into a hit word
-                bool use[2] = {true, two_blocks}, diag[2] = {false, false};
-                if (TRI) {          // same cell (j > i, :443): blocks below the diagonal hold no pair, blocks on it are masked
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) {
-                        const uint32_t row0 = i0 + 32u * (uint32_t)rt;
-                        if (32u * (uint32_t)t + 31u <= row0) use[rt] = false;
-                        diag[rt] = 32u * (uint32_t)t <= row0 + 31u;
-                    }
-                }
-                const v16f_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if CT_TWO
-                v16f_t acc2[2] = {zero, zero};
-                if (use[0]) acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B, zero, 0, 0, 0);
-                if (use[1]) acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B, zero, 0, 0, 0);
-#endif
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    if (!use[rt]) continue;
-#if CT_TWO
-                    v16f_t acc = acc2[rt];
-#else
-                    v16f_t acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(rt == 0 ? A0 : A1, B, zero, 0, 0, 0);
-#endif
-                    if (TRI && diag[rt]) {
-                        const int tv = (int)(32u * (uint32_t)t + cl) - (int)(i0 + 32u * (uint32_t)rt + 4u * kh);
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[i] = (tv > 8 * (i / 4) + (i % 4)) ? acc[i] : 1.0e30f;
-                    }
-                    uint32_t h = 0u;
-                    float m = INFINITY;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        h = __builtin_amdgcn_alignbit(h, __float_as_uint(acc[i]), 31);
-                        m = __builtin_fminf(m, __builtin_fabsf(acc[i]));
-                    }
-                    if (__builtin_amdgcn_ballot_w64(m < E) != 0ull) {
-                        // some accumulator of the block lies inside (-E, E): those candidates (a handful per slot) are
-                        // taken out of the hit word and queued as (row, atom); they are decided exactly, all at once, below
-                        uint32_t bm = 0u;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const bool ib = __builtin_fabsf(acc[i]) < E;
-                            bm = (bm << 1) | (ib ? 1u : 0u);
-                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(ib);
-                            if (mk) {
-                                const uint32_t at = ntodo + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                                const uint32_t row = 32u * (uint32_t)rt + 8u * (uint32_t)(i / 4) + 4u * kh + (uint32_t)(i % 4);
-                                if (ib && at < TODO_CAP) todo[at] = (row << 16) | (32u * (uint32_t)t + cl);
-                                ntodo += (uint32_t)__popcll(mk);
-                            }
-                        }
-                        h &= ~bm;
-                    }
-                    cnt += (uint32_t)__popc(h);
-                }
-            }
-        }
-        if (ntodo > TODO_CAP) {            // a slot full of pairs at the cutoff (adversarial input): the vector path counts it
-            declined = __builtin_amdgcn_readfirstlane(declined | (1u << k));     // wave-uniform and loop-long: pinned to an SGPR (see HistFifo)
-            continue;
-        }
-        if (ntodo) {
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t q0 = 0; q0 < ntodo; q0 += 64u) {
-                bool hx = false;
-                if (q0 + lane < ntodo) {
-                    const uint32_t e = todo[q0 + lane];
-                    const uint32_t row = e >> 16, col = e & 0xFFFFu;
-                    const float4 b = gload4(P.sb, T.b0 + col);
-                    const float4 p = lload4(la, row);
-                    const float dx = b.x - p.x, dy = b.y - p.y, dz = b.z - p.z;     // p2 - p1
-                    const float d2 = (dx * dx + dy * dy) + dz * dz;                // |p2-p1|^2 (:446, :460)
-                    hx = row < rows && col < T.n2 && (!TRI || col > i0 + row) && d2 <= cutoff2;
-                }
-                const unsigned long long mx = __builtin_amdgcn_ballot_w64(hx);
-                if (lane == 0) cnt += (uint32_t)__popcll(mx);
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-        if (lane == 0) slot_cnt[s0 + k] = cnt;
-    }
-    return declined;
-}
-
-
-// one slot on the slot-wise paths of the count pass (what pair_kernel<KIND, MODE_COUNT> runs per workgroup)
-template <int KIND>
-__device__ __forceinline__ uint32_t count_slot_generic(const SearchParams &P, const Task &T, uint32_t i0, unsigned long long moff,
-                                                       float4 *la, uint4 *lh, uint32_t lane) {
-    Fifo F;                                     // the count paths never queue anything; the vector paths want the struct
-    F.fi = F.fj = F.fd = nullptr;
-    F.head = F.tail = 0;
-    F.quota = 64u;
-    F.has_pairs = F.has_dist = false;
-    F.pairs = nullptr; F.dist = nullptr; F.ids = nullptr;
-    F.base = 0;
-    F.hist = nullptr;
-    F.recompute = 0u;
-    F.la = la;
-    F.fq = nullptr; F.fq_store = nullptr;
-    F.lh = lh;
-    F.wrap = 0;
-    F.hmin = F.hmax = F.hn = 0.f;
-    const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
-    uint32_t *mwords = nullptr;
-    const uint32_t nch = (T.n2 + 63u) >> 6;
-    if (moff + 2u * nch <= P.mask_cap_units) mwords = P.maskbuf + moff * 64u;
-    switch (wk) {
-        case WK_NONE: return run_task_nch<KIND, false, WK_NONE, true>(P, T, i0, F, la, lane, mwords);
-        case WK_DIAG: return run_task_nch<KIND, false, WK_DIAG, true>(P, T, i0, F, la, lane, mwords);
-        case WK_UPPER: return run_task_nch<KIND, false, WK_UPPER, true>(P, T, i0, F, la, lane, mwords);
-        default: return run_task_nch<KIND, false, WK_GENERAL, true>(P, T, i0, F, la, lane, mwords);
-    }
-}
-
-
-// Grid: `xw` list workers first - one listed slot each (wrapped entries with their hit history, triclinic corner entries,
-// crowded cells: they start before everything else, as the reverse plan order of pair_kernel makes them) - then one
-// workgroup per plan entry.  5 waves per SIMD: the loop keeps the B records of the second cell (40 registers) live across
-// the slots next to 16 accumulators and the row records - 96 registers without spills, 97 spilled at 72.
-template <int KIND>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CT_WEU))) count_tasks_kernel(
-    const SearchParams *__restrict__ Pp, const TaskDesc *__restrict__ task_desc, const uint32_t *__restrict__ task_first,
-    const SlotDesc *__restrict__ slot_desc, const uint32_t ntasks, const uint32_t xw, const uint32_t *__restrict__ other_list,
-    const uint32_t *__restrict__ n_other, uint32_t *__restrict__ slot_cnt) {
-    __shared__ float4 lds_rows[64];
-    __shared__ uint4 lds_h[128];
-    __shared__ uint4 lds_b[32 * MFMA_TILES];
-    const SearchParams &P = *Pp;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t w = blockIdx.y * gridDim.x + blockIdx.x;
-    if (w < xw) {
-        if (w >= __builtin_amdgcn_readfirstlane(*n_other)) return;
-        const uint32_t slot = __builtin_amdgcn_readfirstlane(other_list[w]);
-        const uint4 lo = reinterpret_cast<const uint4 *>(slot_desc + slot)[0];
-        const uint4 hi = reinterpret_cast<const uint4 *>(slot_desc + slot)[1];
-        const uint2 mo = reinterpret_cast<const uint2 *>(slot_desc + slot)[4];
-        const uint32_t fl = __builtin_amdgcn_readfirstlane(hi.y);
-        if (!(fl & 0x200u)) return;
-        Task T;
-        T.a0 = __builtin_amdgcn_readfirstlane(lo.x);
-        T.n1 = __builtin_amdgcn_readfirstlane(lo.y);
-        T.b0 = __builtin_amdgcn_readfirstlane(lo.z);
-        T.n2 = __builtin_amdgcn_readfirstlane(lo.w);
-        T.cb = __builtin_amdgcn_readfirstlane(hi.x);
-        const uint32_t i0 = __builtin_amdgcn_readfirstlane(hi.z);
-        const unsigned long long moff = ((unsigned long long)__builtin_amdgcn_readfirstlane(mo.y) << 32) | __builtin_amdgcn_readfirstlane(mo.x);
-        T.wrap = fl & 7u;
-        T.tri = (fl & 0x100u) != 0u;
-        T.valid = true;
-        T.wrap_b = (fl >> 12) & 7u;
-        T.rps = fl >> 16;
-        const uint32_t total = count_slot_generic<KIND>(P, T, i0, moff, lds_rows, lds_h, lane);
-        if (lane == 0) slot_cnt[slot] = total;
-        return;
-    }
-    if (w - xw >= ntasks) return;
-    const uint32_t t = ntasks - 1u - (w - xw);   // reverse plan order, as pair_kernel
-    const uint4 dlo = reinterpret_cast<const uint4 *>(task_desc + t)[0];
-    const uint4 dhi = reinterpret_cast<const uint4 *>(task_desc + t)[1];
-    const uint32_t fl = __builtin_amdgcn_readfirstlane(dhi.y);
-    if (!(fl & TASK_LOOPED)) return;
-    const uint32_t s0 = __builtin_amdgcn_readfirstlane(task_first[t]);
-    const uint32_t nb = __builtin_amdgcn_readfirstlane(task_first[t + 1]) - s0;
-    Task T;
-    T.a0 = __builtin_amdgcn_readfirstlane(dlo.x);
-    T.n1 = __builtin_amdgcn_readfirstlane(dlo.y);
-    T.b0 = __builtin_amdgcn_readfirstlane(dlo.z);
-    T.n2 = __builtin_amdgcn_readfirstlane(dlo.w);
-    T.cb = __builtin_amdgcn_readfirstlane(dhi.x);
-    T.wrap = 0u;
-    T.wrap_b = 0u;
-    T.tri = (fl & 0x100u) != 0u;
-    T.valid = true;
-    T.rps = 64u;
-    uint32_t declined;
-    if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) declined = run_count_mfma_task<KIND, true>(P, T, s0, nb, lds_rows, lds_h, lds_b, lane, slot_cnt);
-    else declined = run_count_mfma_task<KIND, false>(P, T, s0, nb, lds_rows, lds_h, lds_b, lane, slot_cnt);
-    // slots whose error bound was too wide (or not finite): the vector count (no hit history: these entries do not wrap)
-    while (declined) {
-        const uint32_t k = (uint32_t)__builtin_ctz(declined);
-        declined &= declined - 1u;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t total = count_slot_generic<KIND>(P, T, 64u * k, ~0ull >> 1, lds_rows, nullptr, lane);
-        if (lane == 0) slot_cnt[s0 + k] = total;
-    }
-}
 
 // ================================================================= fused histogram, lean kernel
 // Consumer-fused histogram (molar_hip_search_histogram) for the slots that make up nearly all of the work: plain,
@@ -2022,31 +1694,12 @@ inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t str
                                const SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                                const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids) {
     hipLaunchKernelGGL((pair_kernel<KIND, MODE>), pair_grid(nblocks), dim3(64 * waves_per_block(MODE)), dyn_lds, stream, dP, slot_desc, nslots,
-                       slot_cnt, slot_base, pairs, dist, ids, nullptr, nullptr, 0u);
-}
-
-// count pass of the fast kinds, task-wise: count_tasks_kernel (the listed slots one wave each + one wave per plan entry), then -
-// in pair_kernel's loop form - whatever of the list lies beyond that launch's list workers (normally nothing: 1024
-// workgroups that leave at once)
-template <int KIND>
-inline void launch_count_by_task(unsigned xw, hipStream_t stream, const SearchParams *dP, const SlotDesc *slot_desc,
-                                 uint32_t nslots, uint32_t *slot_cnt, const uint32_t *other_list, const uint32_t *n_other,
-                                 const TaskDesc *task_desc, const uint32_t *task_first, uint32_t ntasks) {
-    hipLaunchKernelGGL((count_tasks_kernel<KIND>), pair_grid(xw + ntasks), dim3(64), 0, stream, dP, task_desc, task_first, slot_desc, ntasks, xw,
-                       other_list, n_other, slot_cnt);
-    hipLaunchKernelGGL((pair_kernel<KIND, MODE_COUNT, true>), dim3(1024), dim3(64), 0, stream, dP, slot_desc, nslots, slot_cnt, nullptr,
-                       nullptr, nullptr, nullptr, other_list, n_other, xw);
+                       slot_cnt, slot_base, pairs, dist, ids);
 }
 
 }  // namespace pairk
 
 // defined in pair_k0.hip .. pair_k3.hip (one search kind each)
-void launch_count_by_task_single(unsigned xw, hipStream_t stream, const pairk::SearchParams *dP, const pairk::SlotDesc *slot_desc,
-                                 uint32_t nslots, uint32_t *slot_cnt, const uint32_t *other_list, const uint32_t *n_other,
-                                 const pairk::TaskDesc *task_desc, const uint32_t *task_first, uint32_t ntasks);
-void launch_count_by_task_double(unsigned xw, hipStream_t stream, const pairk::SearchParams *dP, const pairk::SlotDesc *slot_desc,
-                                 uint32_t nslots, uint32_t *slot_cnt, const uint32_t *other_list, const uint32_t *n_other,
-                                 const pairk::TaskDesc *task_desc, const uint32_t *task_first, uint32_t ntasks);
 void launch_hist_lean(int kind, unsigned num_cus, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
                       const pairk::SlotDesc *slot_desc, uint32_t nslots);
 void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,

@@ -850,18 +850,6 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     uint32_t *sc = c->slot_cnt.as<uint32_t>();
     auto *sb = c->slot_base.as<unsigned long long>();
     const int mode = !FILL ? MODE_COUNT : (hist_nbins ? MODE_HIST : MODE_FILL);
-    if (mode == MODE_COUNT && c->count_by_task) {
-        const uint32_t *ol = c->other_list.as<uint32_t>();
-        const uint32_t *no = ol + c->nslots_bound + 1;
-        // the listed slots (wrapped, corner, crowded): one wave each up to 65536 of them, strided beyond that
-        const unsigned lb = (unsigned)std::min<uint64_t>(c->nslots_bound, 65536);
-        const TaskDesc *td = c->task_desc.as<TaskDesc>();
-        const uint32_t *tfirst = c->task_nb.as<uint32_t>();
-        if (c->kind == MOLAR_HIP_SEARCH_SINGLE) launch_count_by_task_single(lb, c->stream, dP, tf, st, sc, ol, no, td, tfirst, (uint32_t)c->ntasks);
-        else launch_count_by_task_double(lb, c->stream, dP, tf, st, sc, ol, no, td, tfirst, (uint32_t)c->ntasks);
-        MH_HIP(hipGetLastError());
-        return 0;
-    }
     if (P.hist_lean) launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st);
     switch (c->kind) {
         case MOLAR_HIP_SEARCH_SINGLE: launch_pair_single(mode, P.nblocks, dyn_lds, c->stream, dP, tf, st, sc, sb, pairs, dist, ids); break;
@@ -1080,17 +1068,6 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     MH_TRY(c->task_mu.reserve((c->ntasks + 1) * 4));
     MH_TRY(c->task_moff.reserve((c->ntasks + 1) * 8));
     const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
-    // Count pass of the fast kinds one wave per plan entry (count_tasks_kernel) while cells are not crowded: plain and
-    // same-cell entries whose second cell has <= 320 atoms are looped over, the rest is listed for the slot-wise kernel.
-    // With several hundred atoms per cell most entries would be listed: then the slot-wise kernel takes everything, as before.
-    c->count_by_task = fast_kind && !c->env_no_mfma && !c->env_no_count_task && ncells > 0 && (uint64_t)c->set[0].n <= 300ull * ncells &&
-                       (!two || (uint64_t)c->set[1].n <= 300ull * ncells);
-    uint32_t *other_list = nullptr, *n_other = nullptr;
-    if (c->count_by_task) {
-        MH_TRY(c->other_list.reserve((c->nslots_bound + 2) * 4));
-        other_list = c->other_list.as<uint32_t>();
-        n_other = other_list + c->nslots_bound + 1;
-    }
     {
         Prof prof(c, 0);
         const SearchParams P = make_params(c);
@@ -1102,12 +1079,12 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
             case MOLAR_HIP_SEARCH_SINGLE:
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
                                    c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
-                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots), c->count_by_task ? 1u : 0u, n_other);
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots));
                 break;
             default:   // the three two-grid kinds decode tasks identically
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
                                    c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
-                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots), c->count_by_task ? 1u : 0u, n_other);
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots));
                 break;
         }
         // slot index of every task and (fast kinds) its first hit-history unit: one single-pass scan over both
@@ -1118,7 +1095,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         const unsigned nbs = (unsigned)((c->ntasks + c->nslots_bound + 1 + 255) / 256);
         hipLaunchKernelGGL(slotmap_kernel, dim3(nbs), dim3(256), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
                            c->task_desc.as<TaskDesc>(), fast_kind ? c->task_moff.as<unsigned long long>() : nullptr,
-                           c->slot_desc.as<SlotDesc>(), c->nslots_bound, other_list, n_other);
+                           c->slot_desc.as<SlotDesc>(), c->nslots_bound);
         MH_HIP(hipGetLastError());
     }
     // hit-history buffer of the count -> fill pair: sized exactly (one small read-back; the fused histogram
