@@ -69,7 +69,7 @@ struct SearchParams {
     const float4 *chunk_aabb_b;   // set 2: bounding boxes of the 64-atom Morton chunks, slot (cell_start >> 6) + cell + k
     const uint4 *h16_b;      // set 2, in the order of sb: 8 x f16 {hi xyz, lo xyz, |.|^2 hi, lo} relative to the cell origin
     const float4 *cell_org_b; // set 2: per cell {origin, bound on |position - origin|}
-    uint32_t mfma_count;     // count pass of plain / same-cell entries on the matrix cores (run_count_mfma)
+    uint32_t mfma_count;     // count pass on the matrix cores: bit 0 plain / same-cell entries (run_count_mfma), bit 1 wrapped entries (run_count_mfma_wrapped)
     const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
     uint32_t *maskbuf;       // fast-path slots: hit bits found by the count pass, replayed by the fill pass
     const unsigned long long *task_moff;   // per task: first 64-word unit of its slots in maskbuf (a slot owns 2*nch units)
@@ -711,6 +711,9 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
         const uint32_t col = (uint32_t)t * 32u + cl;
         bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                          // atom past the end: |b|^2 = 65504, never a hit
         if (col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
+        // an atom with a NaN / infinite coordinate has a non-finite |b|^2: it pairs with nothing in the reference (its d2 is
+        // NaN or inf), but its accumulators would be NaNs of either sign
+        if ((bq[t].w & 0x7C00u) == 0x7C00u) bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};
     }
     la[lane] = a;                                   // f32 rows, for the exact decision inside the band
     const float r0 = a.x - org.x, r1 = a.y - org.y, r2 = a.z - org.z;
@@ -809,6 +812,188 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
     }
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
     return cnt;
+}
+
+// Count pass of band-classified WRAPPED entries on the matrix cores.  The vector path (run_fast<.., WRAPPED, .., MASKED>)
+// evaluates every candidate of these entries in f32 (plain distance to the image of the second cell, two band compares,
+// hit history by carry-add): 6 % of the pairs, but as many VALU instructions as the whole matrix-core count of the other
+// 94 % (run as separate kernels: 134 us against 267 us).  Here the same 32 x 32 blocks go through
+// v_mfma_f32_32x32x16_f16 with the row side shifted by the wrap's lattice vector (a - S, so that the B records of the
+// second cell serve unchanged), and the result is written in EXACTLY the hit-history format the fill pass replays
+// (word (g, k) of lane l = the bits of atom 64 k + l for the g-th group of 32 LIVE rows, first row in bit 31):
+//  * the rows that survive run_fast's image-box pruning are compacted in front of the instruction (their records go to
+//    consecutive LDS slots by rank), so a row block IS a history group and pruned rows cost nothing - half of these slots
+//    need one row block instead of two;
+//  * a candidate is decided by the sign of its accumulator when |acc| > band + E: band = rel * cutoff^2 of make_params (the
+//    argument of run_fast: outside it the plain distance to the image decides like PeriodicBox::distance_squared), E the
+//    matrix-core error bound, plus 4 eta rc for measuring from fl(a - S) instead of to fl(b + S) (eta = 2^-24 (2 L + 2 rc));
+//  * candidates inside that range (one or two per slot) are queued and decided with the exact formula
+//    (periodic_box.rs:286-318), all at once; their bits are OR-ed into the stored words afterwards;
+//  * the two 16-row halves of a column's hit bits live in lanes l and l + 32: one exchange per (chunk, row block) and a
+//    nibble interleave put them into row order.
+// Returns false (nothing written) when the slot has to take the vector path: bound too wide, not finite.
+template <int KIND>
+__device__ __forceinline__ bool run_count_mfma_wrapped(const SearchParams &P, const Task &T, uint32_t i0, float4 *la, uint4 *lh,
+                                                       uint32_t lane, uint32_t *mwords, uint32_t &count_out) {
+    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u4_t lds_u4;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(1))) u4_t glb_u4;
+    const float cutoff2 = P.cutoff2;
+    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < 64u ? T.n1 - i0 : 64u);
+    const uint32_t kh = lane >> 5, cl = lane & 31u;
+    const uint32_t nct = (T.n2 + 31u) >> 5, nch = (T.n2 + 63u) >> 6;
+    float Sx = 0.f, Sy = 0.f, Sz = 0.f;      // b + S is the image of the second cell next to the first one (run_fast)
+    for (int d = 0; d < 3; ++d) {
+        if (!((T.wrap >> d) & 1u)) continue;
+        const float sgn = ((T.wrap_b >> d) & 1u) ? 1.0f : -1.0f;
+        Sx += sgn * P.box.m[3 * d];
+        Sy += sgn * P.box.m[3 * d + 1];
+        Sz += sgn * P.box.m[3 * d + 2];
+    }
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
+    const float4 org = gload4(P.cell_org_b, T.cb);
+    const float4 blo = gload4(P.aabb_b, 2 * T.cb), bhi = gload4(P.aabb_b, 2 * T.cb + 1);
+    // the live rows, exactly as run_fast finds them in both passes
+    const bool need = lane < rows && !(aabb_d2(a.x - Sx, a.y - Sy, a.z - Sz, blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z) > P.prune_limit2);
+    const unsigned long long live = __builtin_amdgcn_ballot_w64(need);
+    const uint32_t nlive = (uint32_t)__popcll(live);
+    if (nlive == 0u) {
+        count_out = 0u;
+        return true;
+    }
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+    const float r0 = (a.x - Sx) - org.x, r1 = (a.y - Sy) - org.y, r2 = (a.z - Sz) - org.z;
+    float ra2 = need ? (r0 * r0 + r1 * r1) + r2 * r2 : 0.0f;
+    float big = need ? fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)) : 0.0f;
+    const bool fin = ra2 == ra2;
+    for (int off = 32; off > 0; off >>= 1) {
+        ra2 = fmaxf(ra2, __shfl_xor(ra2, off, 64));
+        big = fmaxf(big, __shfl_xor(big, off, 64));
+    }
+    const float R = 1.0001f * __builtin_sqrtf(ra2) + org.w;
+    const float rc = __builtin_sqrtf(P.band_hi);
+    const float L = (fmaxf(fmaxf(fabsf(org.x), fabsf(org.y)), fabsf(org.z)) + R) + (fmaxf(fmaxf(fabsf(Sx), fabsf(Sy)), fabsf(Sz)) + big);
+    const float Em = mfma_error_bound(R, cutoff2);
+    // |acc| beyond this: decided by the sign.  (band_hi - cutoff^2 = rel * cutoff^2 is the half width of run_fast's band)
+    const float E = uniform_f32((P.band_hi - cutoff2) * 1.0001f + Em + 4.0f * (5.9604645e-08f * (2.0f * L + 2.0f * rc)) * rc);
+    if (__builtin_amdgcn_ballot_w64(!fin || !(E == E) || !mfma_bound_usable(R, Em, cutoff2) || !(E < 0.06f * cutoff2)) != 0ull) return false;
+    // B records of this lane's column of every block column, requested at once (see run_count_mfma)
+    u4_t bq[MFMA_TILES];
+#pragma unroll
+    for (int t = 0; t < MFMA_TILES; ++t) {
+        const uint32_t col = (uint32_t)t * 32u + cl;
+        bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                          // atom past the end: |b|^2 = 65504, never a hit
+        if (col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
+        // an atom with a NaN / infinite coordinate has a non-finite |b|^2: it pairs with nothing in the reference (its d2 is
+        // NaN or inf), but its accumulators would be NaNs of either sign
+        if ((bq[t].w & 0x7C00u) == 0x7C00u) bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};
+    }
+    {   // row records by RANK among the live rows; everything behind them is "a row past the end"
+        ((lds_u4 *)lh)[2u * lane] = u4_t{0u, 0u, 0u, 0x00007BFFu};
+        ((lds_u4 *)lh)[2u * lane + 1u] = u4_t{0u, 0u, 0u, 0x3C003C00u};
+        __builtin_amdgcn_wave_barrier();
+        if (need) {
+            const _Float16 h0 = (_Float16)r0, h1 = (_Float16)r1, h2 = (_Float16)r2;
+            const _Float16 l0 = (_Float16)(r0 - (float)h0), l1 = (_Float16)(r1 - (float)h1), l2 = (_Float16)(r2 - (float)h2);
+            const float e0 = (float)h0 + (float)l0, e1 = (float)h1 + (float)l1, e2 = (float)h2 + (float)l2;
+            const float na = ((e0 * e0 + e1 * e1) + e2 * e2) - cutoff2;
+            const _Float16 nh = (_Float16)na, nl = (_Float16)(na - (float)nh);
+            const _Float16 m2 = (_Float16)-2.0f;
+            const _Float16 g0 = m2 * h0, g1 = m2 * h1, g2 = m2 * h2, s0 = m2 * l0, s1 = m2 * l1, s2 = m2 * l2;
+            ((lds_u4 *)lh)[2u * rank] = u4_t{pack_h2(g0, g1), pack_h2(g2, g0), pack_h2(g1, g2), pack_h2(nh, nl)};
+            ((lds_u4 *)lh)[2u * rank + 1u] = u4_t{pack_h2(s0, s1), pack_h2(s2, s0), pack_h2(s1, s2), 0x3C003C00u};
+            la[rank] = a;                            // the live rows, compacted, for the exact decisions
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const u4_t a0q = ((const lds_u4 *)lh)[2u * cl + kh], a1q = ((const lds_u4 *)lh)[2u * (32u + cl) + kh];
+    const v8h_t A0 = __builtin_bit_cast(v8h_t, a0q), A1 = __builtin_bit_cast(v8h_t, a1q);
+    __builtin_amdgcn_wave_barrier();
+    lds_u32 *todo = (lds_u32 *)lh;              // candidates inside the range: (live row << 16 | atom), decided exactly below
+    constexpr uint32_t TODO_CAP = 512u;
+    uint32_t ntodo = 0, cnt = 0;
+    const uint32_t ngroups = nlive > 32u ? 2u : 1u;
+    // hit word of one block: bit 15 - i = accumulator i = live row 32 rt + 8 (i / 4) + 4 kh + i % 4
+    auto block = [&](int t, int rt) __attribute__((always_inline)) -> uint32_t {
+        u4_t bt = bq[t];
+        if (kh == 0u) bt.w = 0x3C003C00u;                               // k = 6, 7 of the first half: (1, 1)
+        const v16f_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const v16f_t acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(rt == 0 ? A0 : A1, __builtin_bit_cast(v8h_t, bt), zero, 0, 0, 0);
+        uint32_t h = 0u;
+        float m = INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            h = __builtin_amdgcn_alignbit(h, __float_as_uint(acc[i]), 31);
+            m = __builtin_fminf(m, __builtin_fabsf(acc[i]));
+        }
+        if (__builtin_amdgcn_ballot_w64(m < E) != 0ull) {
+            uint32_t bm = 0u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool ib = __builtin_fabsf(acc[i]) < E;
+                bm = (bm << 1) | (ib ? 1u : 0u);
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(ib);
+                if (mk) {
+                    const uint32_t at = ntodo + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    const uint32_t rl = 32u * (uint32_t)rt + 8u * (uint32_t)(i / 4) + 4u * kh + (uint32_t)(i % 4);
+                    if (ib && at < TODO_CAP) todo[at] = (rl << 16) | (32u * (uint32_t)t + cl);
+                    ntodo += (uint32_t)__popcll(mk);
+                }
+            }
+            h &= ~bm;
+        }
+        return h;
+    };
+    // nibbles of a 16-bit word to the low halves of the four bytes
+    auto spread = [](uint32_t x) -> uint32_t {
+        x = (x | (x << 8)) & 0x00FF00FFu;
+        return (x | (x << 4)) & 0x0F0F0F0Fu;
+    };
+#pragma unroll
+    for (int k = 0; k < MFMA_TILES / 2; ++k) {
+        if ((uint32_t)k < nch) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                if ((uint32_t)rt >= ngroups) continue;
+                const uint32_t hx = block(2 * k, rt);
+                const uint32_t hy = (uint32_t)(2 * k + 1) < nct ? block(2 * k + 1, rt) : 0u;
+                // lane l < 32 owns atom 64 k + l (block 2k): it holds that column's rows 4 kh' = 0 half and gets the other
+                // half from lane l + 32; lane l >= 32 owns atom 64 k + l (block 2k + 1): the other way round
+                const uint32_t got = (uint32_t)__shfl_xor((int)(kh ? hx : hy), 32, 64);
+                const uint32_t half0 = kh ? got : hx, half1 = kh ? hy : got;
+                const uint32_t word = (spread(half0) << 4) | spread(half1);
+                cnt += (uint32_t)__popc(word);
+                gstore_u32(mwords, ((uint32_t)rt * nch + (uint32_t)k) * 64u + lane, word);
+            }
+        }
+    }
+    if (ntodo > TODO_CAP) return false;       // (a slot full of pairs at the cutoff: the vector path, which rewrites every word)
+    if (ntodo) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the words are in memory before single bits are OR-ed into them
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t q0 = 0; q0 < ntodo; q0 += 64u) {
+            bool hx = false;
+            uint32_t rl = 0u, col = 0u;
+            if (q0 + lane < ntodo) {
+                const uint32_t e = todo[q0 + lane];
+                rl = e >> 16;
+                col = e & 0xFFFFu;
+                if (rl < nlive && col < T.n2) {
+                    const float4 b = gload4(P.sb, T.b0 + col);
+                    const float4 p = lload4(la, rl);
+                    hx = wrapped_d2_exact(P, T.wrap, b.x - p.x, b.y - p.y, b.z - p.z) <= cutoff2;      // p2 - p1 (:485-486)
+                }
+            }
+            if (hx) atomicOr(mwords + ((rl >> 5) * nch + (col >> 6)) * 64u + (col & 63u), 0x80000000u >> (rl & 31u));
+            const unsigned long long mx = __builtin_amdgcn_ballot_w64(hx);
+            if (lane == 0) cnt += (uint32_t)__popcll(mx);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    count_out = cnt;
+    return true;
 }
 
 template <int KIND, bool FILL, bool WRAPPED, int NCH, bool TRI, bool MASKED>
@@ -1075,11 +1260,21 @@ __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Ta
     if constexpr (!FILL && WK == WK_NONE && (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE)) {
         // plain and same-cell entries with a second cell of <= 320 atoms: the count goes to the matrix cores unless the
         // slot's error bound is too wide
-        if (P.mfma_count && F.lh && T.n2 <= 32u * (uint32_t)MFMA_TILES) {
+        if ((P.mfma_count & 1u) && F.lh && T.n2 <= 32u * (uint32_t)MFMA_TILES) {
             bool done = true;
             const uint32_t cm = (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) ? run_count_mfma<KIND, true>(P, T, i0, la, F.lh, lane, done)
                                                                           : run_count_mfma<KIND, false>(P, T, i0, la, F.lh, lane, done);
             if (done) return cm;
+        }
+    }
+    if constexpr (!FILL && MASKED && WK != WK_NONE && (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE)) {
+        // band-classified wrapped entries with a second cell of <= 320 atoms: matrix-core count that writes the hit history
+        // the fill pass replays (same live rows, same format); declined slots fall through to the vector path
+        if ((P.mfma_count & 2u) && F.lh && mwords && !T.tri && T.rps == 64u && T.n2 <= 32u * (uint32_t)MFMA_TILES && P.approx_wrapped != 0u &&
+            !(P.box.nshift != 0 && T.wrap == MOLAR_HIP_PBC_FULL)) {
+            uint32_t cw = 0u;
+            if (run_count_mfma_wrapped<KIND>(P, T, i0, la, F.lh, lane, mwords, cw)) return cw;
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && !T.tri && nchunks <= (uint32_t)KREG) {
