@@ -156,7 +156,6 @@ molar_hip_ctx *molar_hip_create(int device) {
     c->env_no_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") != nullptr;
     c->env_no_mfma = std::getenv("MOLAR_HIP_NO_MFMA_COUNT") != nullptr;
     c->env_no_mfma_wrapped = std::getenv("MOLAR_HIP_NO_MFMA_WRAPPED") != nullptr;
-    c->env_no_fill_sparse = std::getenv("MOLAR_HIP_NO_FILL_SPARSE") != nullptr;
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     if (const char *dbg = std::getenv("MOLAR_HIP_DEBUG_SKIP")) c->env_debug_skip = (uint32_t)std::atoi(dbg);
 #endif

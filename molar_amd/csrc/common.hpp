@@ -147,7 +147,6 @@ struct molar_hip_ctx {
     bool want_side = false;              // set by _begin / the asynchronous histogram call around their enqueue
     bool env_no_side = false;            // MOLAR_HIP_NO_SIDE_STREAM, read once in molar_hip_create
     bool env_no_mfma = false;            // MOLAR_HIP_NO_MFMA_COUNT: count pass of plain entries on the vector ALUs (A/B runs)
-    bool env_no_fill_sparse = false;     // MOLAR_HIP_NO_FILL_SPARSE: every slot of the fill pass on the vector paths (A/B runs)
     bool env_no_mfma_wrapped = false;    // MOLAR_HIP_NO_MFMA_WRAPPED: count pass of wrapped entries on the vector ALUs (A/B runs)
     uint32_t env_debug_skip = 0;         // MOLAR_HIP_DEBUG_SKIP (builds with -DMOLAR_HIP_DEBUG_KNOBS only), read once
     hipEvent_t gen_free[2] = {nullptr, nullptr};   // recorded on the main stream behind the last asynchronous reader of

@@ -70,7 +70,6 @@ struct SearchParams {
     const uint4 *h16_b;      // set 2, in the order of sb: 8 x f16 {hi xyz, lo xyz, |.|^2 hi, lo} relative to the cell origin
     const float4 *cell_org_b; // set 2: per cell {origin, bound on |position - origin|}
     uint32_t mfma_count;     // count pass on the matrix cores: bit 0 plain / same-cell entries (run_count_mfma), bit 1 wrapped entries (run_count_mfma_wrapped)
-    uint32_t fill_sparse;    // fill pass: plain slots with few results take run_fill_sparse (matrix-core classification)
     const struct TaskDesc *task_desc;   // per plan entry, written by plan_kernel
     uint32_t *maskbuf;       // fast-path slots: hit bits found by the count pass, replayed by the fill pass
     const unsigned long long *task_moff;   // per task: first 64-word unit of its slots in maskbuf (a slot owns 2*nch units)
@@ -997,202 +996,6 @@ __device__ __forceinline__ bool run_count_mfma_wrapped(const SearchParams &P, co
     return true;
 }
 
-// ================================================================= fill pass of SPARSE plain slots on the matrix cores
-// The vector fill (run_fast) costs per live (row, 64-atom chunk), whether the chunk holds a hit or not: 13 VALU + 9 SALU + 2 LDS.
-// That is well spent on face-neighbour and same-cell entries (a fifth to a half of the candidates are hits), but the 6 edge
-// and 4 corner entries of a cell are 10 of its 14 plan entries and 2/3 of its live chunk-rows for a fifth of its pairs: a
-// corner slot evaluates ~7000 candidates in f32 to emit ~30.  The count pass has told us every slot's exact number of
-// results, so the fill can choose per slot: slots with few results (<= FS_MAX) take this path, whose cost follows the
-// hits - the full version of which (run_fill_mfma, round 3, commit 9410e52) lost to the vector path on DENSE slots and on
-// the 10 KB of LDS it needed for the second cell; with few hits neither applies:
-//  1. classify as the count pass does, one v_mfma_f32_32x32x16_f16 per 32 x 32 block, operands swapped (the instruction's rows
-//     are the second cell's atoms, its columns the slot's rows) so that lane (kh, cl) gets 16 accumulators of ONE row and 16
-//     consecutive atoms; the threshold in the row records is cutoff^2 + E, so the sign bits are a SUPERSET of the hits and
-//     no band test sits in the loop; atoms are dealt to the instruction's rows so that half kh of the lanes owns the contiguous
-//     atom range [kh * 16 nct, (kh + 1) * 16 nct): a lane's bits are a contiguous piece of its row in output order;
-//  2. popcounts, one exchange between the halves, one wave scan: the offset of every row and lane in the slot's output and
-//     the total T; T - (the count pass's exact number) = the false positives among them, known before anything is written;
-//  3. every lane walks its own bits (v_ffbl, clear, ds_write_b16 of (row, atom) to its final position in a 2 KB LDS staging
-//     area that first held the row records);
-//  4. 64 staged entries at a time, one per lane: row from LDS, second atom gathered from L2 (a few hundred per slot), the
-//     reference's exact d2 (:446, :460), sqrt, contiguous stores; slots with false positives drop them here by the exact
-//     test d2 <= cutoff^2 (ranks by v_mbcnt).
-// Returns false without having written anything when the slot has to take the vector path (bound too wide or not finite,
-// more candidates than the staging area holds).
-constexpr uint32_t FS_MAX = 640;            // results of a slot up to which it takes this path
-constexpr uint32_t FS_STAGE = 1024;         // staging entries (u16): 2 KB, the replay queue's LDS
-
-template <int KIND>
-__device__ __forceinline__ bool run_fill_sparse(const SearchParams &P, const Task &T, uint32_t i0, unsigned long long out_base,
-                                                uint32_t expect, uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
-                                                float4 *la, void *stage, uint32_t lane) {
-    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) u4_t lds_u4;
-    typedef __attribute__((address_space(3))) unsigned short lds_u16;
-    typedef __attribute__((address_space(1))) u4_t glb_u4;
-    lds_u16 *st = (lds_u16 *)stage;
-    lds_u4 *lh = (lds_u4 *)stage;
-    const float cutoff2 = P.cutoff2;
-    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < 64u ? T.n1 - i0 : 64u);
-    const uint32_t kh = lane >> 5, cl = lane & 31u;
-    const uint32_t nct = (T.n2 + 31u) >> 5;
-    const uint32_t half = 16u * nct;                // atoms [kh * half, (kh + 1) * half) belong to the lanes of half kh
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
-    const float4 org = gload4(P.cell_org_b, T.cb);
-    // the instruction's row m = cl of block column t is atom  khm * half + 16 t + 4 q + p  with cl = 8 q + 4 khm + p:
-    // accumulator r of lane (kh, cl) is then (row cl, atom kh * half + 16 t + r)
-    const uint32_t jm = ((cl >> 2) & 1u) * half + 4u * (cl >> 3) + (cl & 3u);
-    u4_t bq[MFMA_TILES];
-#pragma unroll
-    for (int t = 0; t < MFMA_TILES; ++t) {
-        const uint32_t col = jm + 16u * (uint32_t)t;
-        bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                          // atom past the end: |b|^2 = 65504, never a hit
-        if ((uint32_t)t < nct && col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
-        if ((bq[t].w & 0x7C00u) == 0x7C00u) bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};      // NaN / inf atom: pairs with nothing
-    }
-    la[lane] = a;
-    const float r0 = a.x - org.x, r1 = a.y - org.y, r2 = a.z - org.z;
-    float ra2 = lane < rows ? (r0 * r0 + r1 * r1) + r2 * r2 : 0.0f;
-    const bool fin = ra2 == ra2;
-    for (int off = 32; off > 0; off >>= 1) ra2 = fmaxf(ra2, __shfl_xor(ra2, off, 64));
-    const float R = 1.0001f * __builtin_sqrtf(ra2) + org.w;
-    const float E = mfma_error_bound(R, cutoff2);
-    const float cthr = uniform_f32(cutoff2 + E);
-    if (__builtin_amdgcn_ballot_w64(!fin || !mfma_bound_usable(R, E, cthr)) != 0ull) return false;
-    {   // row records (see run_count_mfma), with cutoff^2 + E folded into the norm term
-        u4_t k0 = {0u, 0u, 0u, 0x00007BFFu}, k1 = {0u, 0u, 0u, 0x3C003C00u};      // row past the end: +65504
-        if (lane < rows) {
-            const _Float16 h0 = (_Float16)r0, h1 = (_Float16)r1, h2 = (_Float16)r2;
-            const _Float16 l0 = (_Float16)(r0 - (float)h0), l1 = (_Float16)(r1 - (float)h1), l2 = (_Float16)(r2 - (float)h2);
-            const float e0 = (float)h0 + (float)l0, e1 = (float)h1 + (float)l1, e2 = (float)h2 + (float)l2;
-            const float na = ((e0 * e0 + e1 * e1) + e2 * e2) - cthr;
-            const _Float16 nh = (_Float16)na, nl = (_Float16)(na - (float)nh);
-            const _Float16 m2 = (_Float16)-2.0f;
-            const _Float16 g0 = m2 * h0, g1 = m2 * h1, g2 = m2 * h2, s0 = m2 * l0, s1 = m2 * l1, s2 = m2 * l2;
-            k0 = u4_t{pack_h2(g0, g1), pack_h2(g2, g0), pack_h2(g1, g2), pack_h2(nh, nl)};
-            k1 = u4_t{pack_h2(s0, s1), pack_h2(s2, s0), pack_h2(s1, s2), 0x3C003C00u};
-        }
-        lh[2u * lane] = k0;
-        lh[2u * lane + 1u] = k1;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const u4_t a0q = lh[2u * cl + kh], a1q = lh[2u * (32u + cl) + kh];
-    const v8h_t A0 = __builtin_bit_cast(v8h_t, a0q), A1 = __builtin_bit_cast(v8h_t, a1q);
-    __builtin_amdgcn_wave_barrier();
-    // ---- 1. classify.  W[rt][tp]: bit b = candidate (row 32 rt + cl, atom kh * half + 32 tp + b)
-    uint32_t W[2][MFMA_TILES / 2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int tp = 0; tp < MFMA_TILES / 2; ++tp) W[rt][tp] = 0u;
-    const bool two_blocks = rows > 32u;
-#pragma unroll
-    for (int t = 0; t < MFMA_TILES; ++t) {
-        if ((uint32_t)t < nct) {
-            u4_t bt = bq[t];
-            if (kh == 0u) bt.w = 0x3C003C00u;                           // k = 6, 7 of the first half: (1, 1)
-            const v8h_t B = __builtin_bit_cast(v8h_t, bt);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                if (rt == 1 && !two_blocks) continue;
-                const v16f_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const v16f_t acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(B, rt == 0 ? A0 : A1, zero, 0, 0, 0);
-                uint32_t h = 0u;
-#pragma unroll
-                for (int i = 15; i >= 0; --i) h = __builtin_amdgcn_alignbit(h, __float_as_uint(acc[i]), 31);   // bit i = sign of acc[i]
-                W[rt][t >> 1] |= h << (16 * (t & 1));
-            }
-        }
-    }
-    // ---- 2. offsets
-    uint32_t n0 = 0u, n1 = 0u;
-#pragma unroll
-    for (int tp = 0; tp < MFMA_TILES / 2; ++tp) {
-        n0 += (uint32_t)__popc(W[0][tp]);
-        n1 += (uint32_t)__popc(W[1][tp]);
-    }
-    const uint32_t mine = n0 | (n1 << 16);
-    const uint32_t other = (uint32_t)__shfl_xor((int)mine, 32, 64);
-    const uint32_t rt0 = n0 + (other & 0xFFFFu), rt1 = n1 + (other >> 16);       // hits of rows cl and 32 + cl
-    const uint32_t rowtot = kh ? rt1 : rt0;                                      // lane l: hits of row l
-    uint32_t incl = rowtot;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
-        if ((int)lane >= off) incl += o;
-    }
-    const uint32_t excl = incl - rowtot;                                         // first entry of row l
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (total < expect || total > FS_STAGE) return false;   // (the first cannot happen while E bounds the error)
-    const uint32_t excl_o = (uint32_t)__shfl_xor((int)excl, 32, 64);
-    const uint32_t o0 = (kh ? excl_o : excl) + (kh ? (other & 0xFFFFu) : 0u);    // the kh = 1 lane starts behind its partner's hits
-    const uint32_t o1 = (kh ? excl : excl_o) + (kh ? (other >> 16) : 0u);
-    const bool filter = total != expect;            // false positives among the staged entries: step 4 tests exactly
-    // ---- 3. walk
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        uint32_t o = rt == 0 ? o0 : o1;
-        const uint32_t ebase = ((32u * (uint32_t)rt + cl) << 9) + kh * half;
-#pragma unroll
-        for (int tp = 0; tp < MFMA_TILES / 2; ++tp) {
-            uint32_t w = W[rt][tp];
-            while (w) {
-                const uint32_t b = (uint32_t)__builtin_ctz(w);
-                st[o] = (unsigned short)(ebase + 32u * (uint32_t)tp + b);
-                o += 1u;
-                w &= w - 1u;
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- 4. write out, FS_UNROLL groups of 64 entries at a time: the second atoms come from L2 (~1 us away), so every
-    // gather of a batch is requested before the first is used (one group per trip left the kernel waiting on them: +0.23 ms)
-    constexpr int FS_UNROLL = 4;
-    unsigned long long cursor = out_base;             // filtering slots: next output entry
-    const uint32_t mis = filter ? 0u : ((uint32_t)out_base & 63u);       // else: groups aligned to 64-entry boundaries of the output
-    uint2 *pp = out_pairs ? out_pairs + (out_base - mis) : nullptr;
-    float *pd = out_dist ? out_dist + (out_base - mis) : nullptr;
-    for (uint32_t g = 0; g < total + mis; g += 64u * FS_UNROLL) {
-        float4 pb[FS_UNROLL];
-        uint32_t ent[FS_UNROLL];
-        bool act[FS_UNROLL];
-#pragma unroll
-        for (int u = 0; u < FS_UNROLL; ++u) {
-            const uint32_t k = g + 64u * (uint32_t)u + lane;
-            act[u] = k >= mis && k - mis < total;
-            ent[u] = act[u] ? (uint32_t)st[k - mis] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < FS_UNROLL; ++u) pb[u] = gload4(P.sb, T.b0 + (ent[u] & 511u));
-#pragma unroll
-        for (int u = 0; u < FS_UNROLL; ++u) {
-            const uint32_t k = g + 64u * (uint32_t)u + lane;
-            if (g + 64u * (uint32_t)u >= total + mis) break;
-            const float4 pa = lload4(la, ent[u] >> 9);
-            const float dx = pb[u].x - pa.x, dy = pb[u].y - pa.y, dz = pb[u].z - pa.z;      // p2 - p1
-            const float d2 = act[u] ? (dx * dx + dy * dy) + dz * dz : INFINITY;            // :446, :460
-            const uint32_t id_i = __float_as_uint(pa.w), id_j = __float_as_uint(pb[u].w);
-            if (!filter) {
-                if (act[u]) {
-                    if (pp) pp[k] = make_uint2(id_i, id_j);
-                    if (pd) pd[k] = __builtin_sqrtf(d2);    // d2.sqrt() (:448)
-                }
-            } else {
-                const bool hit = d2 <= cutoff2;             // the reference's test (:446) drops the false positives
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-                if (hit) {
-                    const unsigned long long pos = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (out_pairs) out_pairs[pos] = make_uint2(id_i, id_j);
-                    if (out_dist) out_dist[pos] = __builtin_sqrtf(d2);
-                }
-                cursor += (uint32_t)__popcll(m);
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    return true;
-}
-
 template <int KIND, bool FILL, bool WRAPPED, int NCH, bool TRI, bool MASKED>
 __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                              uint32_t lane, uint32_t *mwords) {
@@ -1667,15 +1470,6 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
             F.quota = 64u - ((uint32_t)F.base & 63u);
             const unsigned long long end = slot_base[slot + 1];
             if (end == F.base || end > P.out_cap) return;  // nothing to emit / no room (the host grows and repeats)
-            if constexpr (MODE == MODE_FILL && (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE)) {
-                // plain slots with few results (edge and corner neighbours): cost by hits, not by candidates
-                if (P.fill_sparse && end - F.base <= FS_MAX && !T.tri && !(P.use_box && T.wrap != 0) && T.rps == 64u &&
-                    T.n2 <= 32u * (uint32_t)MFMA_TILES) {
-                    if (run_fill_sparse<KIND>(P, T, i0, F.base, (uint32_t)(end - F.base), out_pairs, out_dist, lds_a[wave], lds_q[wave], lane))
-                        return;
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
             if (out_pairs) F.pairs = out_pairs + F.base + lane;
             if (out_dist) F.dist = out_dist + F.base + lane;
             if (out_ids) F.ids = out_ids + F.base + lane;

@@ -707,7 +707,6 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.h16_b = two ? c->set[1].h16.as<uint4>() : c->set[0].h16.as<uint4>();
     P.cell_org_b = two ? c->set[1].cell_org.as<float4>() : c->set[0].cell_org.as<float4>();
     P.mfma_count = c->env_no_mfma ? 0u : (c->env_no_mfma_wrapped ? 1u : 3u);
-    P.fill_sparse = c->env_no_fill_sparse ? 0u : 1u;
     P.task_desc = c->task_desc.as<TaskDesc>();
     P.maskbuf = c->maskbuf.as<uint32_t>();
     P.task_moff = c->task_moff.as<unsigned long long>();
