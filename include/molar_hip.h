@@ -396,6 +396,90 @@ typedef struct {
 int molar_hip_membrane_smooth(molar_hip_ctx *ctx, const molar_hip_membrane_patches *patches, const float *box9,
                               molar_hip_membrane_state *state);
 
+/* One whole frame of Membrane::compute (molar_membrane/src/lib.rs:410-454) as a chain of kernels with no host round
+ * trip inside: unwrap of every lipid (lipid_molecule.rs:75-76) -> head / mid / tail-end markers (:65-99) -> PBC search
+ * among the valid lipids' head markers and the patch lists in push order (compute_patches, lib.rs:539-558) ->
+ * compute_initial_normals (:456-505, including the second pass that updates normals in place in lipid order) ->
+ * max_smooth_iter iterations of smooth (:661-812) -> lipid_tail_order of every tail with its lipid's normal (:435-443).
+ * The stages are the ones behind molar_hip_unwrap_simple_batch, _center_batch, _search_*, _membrane_patches_from_pairs,
+ * _membrane_initial_normals, _membrane_smooth and _lipid_tail_order, and give the same bits; what differs is that the
+ * pair list, the patches and every per-lipid array stay in device memory between them.
+ *
+ * A plan holds what is constant over a trajectory (the index lists, masses, options) and the per-lipid `valid` flags,
+ * which the reference carries from frame to frame (LipidMolecule::valid: a lipid dropped by smooth stays out of the
+ * patches of later frames until reset_valid_lipids, lib.rs:269-273).  Two frames may be in flight:
+ *     begin(frame k+1); end(frame k); fetch / use the device view of k; ...
+ * so the host work of a frame hides behind the kernels of the one before it.  Frames are chained on the context's
+ * stream in begin order, `valid` included.  The result of a frame stays readable until the second _begin after its own.
+ * Sizes that vary with the frame (pairs, patch entries) are provisioned from earlier frames; a frame that outgrows
+ * them is repeated inside _end, transparently.  Options outside this entry (patches from the n-th neighbour shell,
+ * curvature smoothing over shells: lib.rs:562-621) stay with the staged calls.  All pointers of the description are
+ * host memory and are copied at creation. */
+typedef struct molar_hip_membrane_plan molar_hip_membrane_plan;
+typedef struct {
+    size_t natoms, nlipids;
+    const uint64_t *lipid_idx;        /* CSR of whole lipids: lipid k = lipid_idx[lipid_offsets[k] .. lipid_offsets[k+1]) */
+    const uint64_t *lipid_offsets;    /* [nlipids + 1] */
+    const uint64_t *marker_idx;       /* CSR of 3 * nlipids selections: head, mid, tail-end of lipid 0, head of lipid 1, ... */
+    const uint64_t *marker_offsets;   /* [3 * nlipids + 1] */
+    const float *masses;              /* [natoms] */
+    size_t ntails;
+    const uint64_t *tail_idx;         /* CSR of the tails' carbons in chain order, layout of molar_hip_lipid_tail_order */
+    const uint64_t *tail_offsets;     /* [ntails + 1] */
+    const uint32_t *tail_lipid;       /* [ntails] the lipid whose normal a tail is measured against */
+    const uint8_t *tail_bonds;        /* bond orders, layout of molar_hip_lipid_tail_order */
+    float cutoff;                     /* patch search radius (MembraneOptions::cutoff) */
+    int32_t order_type;               /* 0 Sz, 1 Scd, 2 ScdCorr */
+    int32_t max_smooth_iter;          /* >= 1 */
+    int32_t unwrap;                   /* make every lipid whole before the markers are taken */
+    int32_t use_global_normal;        /* order against global_normal instead of the lipid's normal */
+    float global_normal[3];
+} molar_hip_membrane_desc;
+/* Device addresses of one frame's results (valid as described above); E = patch entries of the frame. */
+typedef struct {
+    size_t nlipids, patch_entries, npairs;
+    const float *head, *mid, *tail;             /* [K][3] markers before smoothing */
+    const uint64_t *patch_offsets, *patch_ids;  /* [K+1], [E] */
+    const float *initial_normals;               /* [K][3] */
+    const uint8_t *valid;                       /* [K] after the frame */
+    const float *smoothed_head, *normals;       /* [K][3] */
+    const float *quad_coefs, *mean_curv, *gauss_curv, *princ_curvs, *princ_dirs, *area;
+    const uint32_t *nvert;
+    const uint64_t *neib_ids;                   /* [E + 4K] slotted like molar_hip_membrane_state */
+    const float *voro_vertexes;                 /* [E + 4K][3] */
+    const float *fitted_patch_points;           /* [E][3] */
+    const float *order;                         /* concatenated per tail, layout of molar_hip_lipid_tail_order */
+    size_t norder;
+} molar_hip_membrane_view;
+/* Host destinations for molar_hip_membrane_frame_fetch: any pointer may be NULL (skipped); the E-sized arrays are
+ * written up to the frame's patch_entries (see the view). */
+typedef struct {
+    float *head, *mid, *tail;
+    uint64_t *patch_offsets, *patch_ids;
+    float *initial_normals;
+    uint8_t *valid;
+    float *smoothed_head, *normals;
+    float *quad_coefs, *mean_curv, *gauss_curv, *princ_curvs, *princ_dirs, *area;
+    uint32_t *nvert;
+    uint64_t *neib_ids;
+    float *voro_vertexes;
+    float *fitted_patch_points;
+    float *order;
+} molar_hip_membrane_out;
+int molar_hip_membrane_plan_create(molar_hip_ctx *ctx, const molar_hip_membrane_desc *desc, molar_hip_membrane_plan **out);
+void molar_hip_membrane_plan_destroy(molar_hip_membrane_plan *plan);
+/* valid[nlipids] from host memory (NULL: all valid = reset_valid_lipids, lib.rs:269-273); ends the frames in flight. */
+int molar_hip_membrane_plan_set_valid(molar_hip_membrane_plan *plan, const uint8_t *valid);
+/* xyz: float[natoms][3], device memory (unwrapped in place, and read until the frame ends) or host memory (uploaded;
+ * the unwrapped frame is written back before _begin returns).  box9: column-major box matrix.  Returns with a ticket
+ * (0 or 1) without waiting for the frame. */
+int molar_hip_membrane_frame_begin(molar_hip_membrane_plan *plan, float *xyz, const float *box9, int32_t *ticket);
+/* Waits for that frame; `view` may be NULL.  Errors of the frame's stages surface here (ERR_ZERO_MASS,
+ * ERR_LIPID_TAIL_TOO_SHORT, ...). */
+int molar_hip_membrane_frame_end(molar_hip_membrane_plan *plan, int32_t ticket, molar_hip_membrane_view *view);
+/* Copies the chosen arrays of an ended frame to host memory. */
+int molar_hip_membrane_frame_fetch(molar_hip_membrane_plan *plan, int32_t ticket, const molar_hip_membrane_out *out);
+
 /* Measure::lipid_tail_order (measure.rs:270-422), batched over `ntails` tails given as CSR:
  * tail t holds the carbons idx[tail_offsets[t] .. tail_offsets[t+1]) (n_t atoms), its normals are
  * normals[3*normal_offsets[t] .. 3*normal_offsets[t+1]) (1 or n_t-2 vectors), its n_t-1 bond orders

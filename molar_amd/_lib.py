@@ -55,6 +55,34 @@ class SearchDescF64(C.Structure):
     ]
 
 
+class MembraneDesc(C.Structure):
+    """molar_hip_membrane_desc: what is constant over a trajectory for molar_hip_membrane_frame_*."""
+    _fields_ = [
+        ("natoms", C.c_size_t), ("nlipids", C.c_size_t),
+        ("lipid_idx", C.c_void_p), ("lipid_offsets", C.c_void_p), ("marker_idx", C.c_void_p), ("marker_offsets", C.c_void_p),
+        ("masses", C.c_void_p), ("ntails", C.c_size_t), ("tail_idx", C.c_void_p), ("tail_offsets", C.c_void_p),
+        ("tail_lipid", C.c_void_p), ("tail_bonds", C.c_void_p),
+        ("cutoff", C.c_float), ("order_type", C.c_int32), ("max_smooth_iter", C.c_int32), ("unwrap", C.c_int32),
+        ("use_global_normal", C.c_int32), ("global_normal", C.c_float * 3),
+    ]
+
+
+MEMBRANE_ARRAYS = ("head", "mid", "tail", "patch_offsets", "patch_ids", "initial_normals", "valid", "smoothed_head", "normals",
+                   "quad_coefs", "mean_curv", "gauss_curv", "princ_curvs", "princ_dirs", "area", "nvert", "neib_ids",
+                   "voro_vertexes", "fitted_patch_points", "order")
+
+
+class MembraneView(C.Structure):
+    """molar_hip_membrane_view: device addresses of one frame's results."""
+    _fields_ = ([("nlipids", C.c_size_t), ("patch_entries", C.c_size_t), ("npairs", C.c_size_t)]
+                + [(k, C.c_void_p) for k in MEMBRANE_ARRAYS] + [("norder", C.c_size_t)])
+
+
+class MembraneOut(C.Structure):
+    """molar_hip_membrane_out: host destinations of molar_hip_membrane_frame_fetch."""
+    _fields_ = [(k, C.c_void_p) for k in MEMBRANE_ARRAYS]
+
+
 # every symbol include/molar_hip.h declares: name -> (restype, argtypes)
 _P, _SZ, _F, _I, _U8 = C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_uint8
 SYMBOLS = {
@@ -127,6 +155,12 @@ SYMBOLS = {
     "molar_hip_membrane_initial_normals": (_I, [_SZ, _P, _P, _P, _P, _P, _P]),
     "molar_hip_membrane_smooth": (_I, [_P, _P, _P, _P]),
     "molar_hip_membrane_patches_from_pairs": (_I, [_P, _SZ, _SZ, _P, _P]),
+    "molar_hip_membrane_plan_create": (_I, [_P, _P, _P]),
+    "molar_hip_membrane_plan_destroy": (None, [_P]),
+    "molar_hip_membrane_plan_set_valid": (_I, [_P, _P]),
+    "molar_hip_membrane_frame_begin": (_I, [_P, _P, _P, _P]),
+    "molar_hip_membrane_frame_end": (_I, [_P, _I, _P]),
+    "molar_hip_membrane_frame_fetch": (_I, [_P, _I, _P]),
     "molar_hip_xtc_open": (_P, [C.c_char_p]),
     "molar_hip_xtc_open_memory": (_P, [_P, _SZ]),
     "molar_hip_xtc_close": (None, [_P]),

@@ -16,7 +16,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Box, MolarHipError, SearchDesc, SearchDescF64, check
+from ._lib import (MEMBRANE_ARRAYS, Box, MembraneDesc, MembraneOut, MembraneView, MolarHipError, SearchDesc, SearchDescF64,
+                   check)
 
 PBC_FULL = 7
 PBC_NONE = 0
@@ -913,6 +914,102 @@ def new_membrane_state(head_markers, normals, valid=None, npatch_entries=0):
         princ_dirs=np.zeros((K, 2, 3), np.float32), area=np.zeros(K, np.float32), nvert=np.zeros(K, np.uint32),
         neib_ids=np.zeros(slots, np.uint64), voro_vertexes=np.zeros((slots, 3), np.float32),
         fitted_patch_points=np.zeros((max(npatch_entries, 1), 3), np.float32))
+
+
+class MembranePlan:
+    """molar_hip_membrane_plan: one frame of Membrane::compute (molar_membrane/src/lib.rs:410-454) per begin/end pair,
+    chained on the engine's stream without a host round trip inside; two frames may be in flight.  `valid` is carried
+    from frame to frame on the device like LipidMolecule::valid."""
+
+    # (dtype, shape as a function of K, E, slots, norder)
+    _SHAPES = {
+        "head": (np.float32, lambda K, E, S, N: (K, 3)), "mid": (np.float32, lambda K, E, S, N: (K, 3)),
+        "tail": (np.float32, lambda K, E, S, N: (K, 3)), "patch_offsets": (np.uint64, lambda K, E, S, N: (K + 1,)),
+        "patch_ids": (np.uint64, lambda K, E, S, N: (E,)), "initial_normals": (np.float32, lambda K, E, S, N: (K, 3)),
+        "valid": (np.uint8, lambda K, E, S, N: (K,)), "smoothed_head": (np.float32, lambda K, E, S, N: (K, 3)),
+        "normals": (np.float32, lambda K, E, S, N: (K, 3)), "quad_coefs": (np.float32, lambda K, E, S, N: (K, 6)),
+        "mean_curv": (np.float32, lambda K, E, S, N: (K,)), "gauss_curv": (np.float32, lambda K, E, S, N: (K,)),
+        "princ_curvs": (np.float32, lambda K, E, S, N: (K, 2)), "princ_dirs": (np.float32, lambda K, E, S, N: (K, 2, 3)),
+        "area": (np.float32, lambda K, E, S, N: (K,)), "nvert": (np.uint32, lambda K, E, S, N: (K,)),
+        "neib_ids": (np.uint64, lambda K, E, S, N: (S,)), "voro_vertexes": (np.float32, lambda K, E, S, N: (S, 3)),
+        "fitted_patch_points": (np.float32, lambda K, E, S, N: (E, 3)), "order": (np.float32, lambda K, E, S, N: (N,)),
+    }
+
+    def __init__(self, engine, natoms, lipid_idx, lipid_off, marker_idx, marker_off, masses, tail_idx, tail_off, tail_lipid,
+                 tail_bonds, cutoff, order_type, max_smooth_iter=1, unwrap=True, global_normal=None):
+        self.eng = engine
+        self.lib = engine.lib
+        keep = [np.ascontiguousarray(lipid_idx, np.uint64), np.ascontiguousarray(lipid_off, np.uint64),
+                np.ascontiguousarray(marker_idx, np.uint64), np.ascontiguousarray(marker_off, np.uint64),
+                np.ascontiguousarray(masses, np.float32), np.ascontiguousarray(tail_idx, np.uint64),
+                np.ascontiguousarray(tail_off, np.uint64), np.ascontiguousarray(tail_lipid, np.uint32),
+                None if tail_bonds is None else np.ascontiguousarray(tail_bonds, np.uint8)]
+        d = MembraneDesc()
+        d.natoms = int(natoms); d.nlipids = len(keep[1]) - 1
+        d.lipid_idx, d.lipid_offsets, d.marker_idx, d.marker_offsets, d.masses = (a.ctypes.data for a in keep[:5])
+        d.ntails = len(keep[6]) - 1
+        d.tail_idx, d.tail_offsets, d.tail_lipid = keep[5].ctypes.data, keep[6].ctypes.data, keep[7].ctypes.data
+        d.tail_bonds = None if keep[8] is None else keep[8].ctypes.data
+        d.cutoff = float(cutoff); d.order_type = int(order_type); d.max_smooth_iter = int(max_smooth_iter); d.unwrap = int(bool(unwrap))
+        d.use_global_normal = int(global_normal is not None)
+        g = np.zeros(3, np.float32) if global_normal is None else np.asarray(global_normal, np.float32).reshape(3)
+        d.global_normal[:] = [float(v) for v in g]
+        self.K = int(d.nlipids)
+        self.norder = int(keep[6][-1]) - 2 * int(d.ntails)
+        self.handle = C.c_void_p()
+        check(self.lib.molar_hip_membrane_plan_create(engine.ctx, C.byref(d), C.byref(self.handle)))
+        self._views = {}
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.molar_hip_membrane_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_valid(self, valid=None):
+        """valid flags for the frames to come (None: reset_valid_lipids, lib.rs:269-273)."""
+        v = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+        check(self.lib.molar_hip_membrane_plan_set_valid(self.handle, None if v is None else v.ctypes.data))
+
+    def begin(self, xyz, box):
+        """Enqueue one frame; xyz: float32 [N,3] torch CUDA tensor (unwrapped in place) or numpy array (unwrapped in place
+        as well, through a copy).  Returns the ticket."""
+        pb = box if isinstance(box, PeriodicBox) else PeriodicBox.from_matrix(box)
+        m9 = pb.colmajor9()
+        xa, kx = _addr(xyz)
+        t = C.c_int32(-1)
+        check(self.lib.molar_hip_membrane_frame_begin(self.handle, xa, m9.ctypes.data, C.byref(t)))
+        self._keep[t.value] = kx
+        return t.value
+
+    def end(self, ticket):
+        """Wait for the frame; returns its MembraneView (device addresses, sizes)."""
+        v = MembraneView()
+        rc = self.lib.molar_hip_membrane_frame_end(self.handle, int(ticket), C.byref(v))
+        if rc == 0 or int(ticket) not in (0, 1) or v.nlipids:      # the frame is over (even if one of its stages failed)
+            self._keep.pop(int(ticket), None)
+        check(rc)
+        self._views[int(ticket)] = v
+        return v
+
+    def fetch(self, ticket, names=MEMBRANE_ARRAYS):
+        """The named arrays of an ended frame as numpy arrays."""
+        v = self._views[int(ticket)]
+        K, E = self.K, int(v.patch_entries)
+        out, o = {}, MembraneOut()
+        for k in names:
+            dt, shp = self._SHAPES[k]
+            a = np.zeros(shp(K, E, E + 4 * K, self.norder), dt)
+            out[k] = a
+            setattr(o, k, a.ctypes.data if a.size else None)
+        check(self.lib.molar_hip_membrane_frame_fetch(self.handle, int(ticket), C.byref(o)))
+        return out
 
 
 def histogram_edges(hmin, hmax, nbins):

@@ -8,6 +8,7 @@
 // These passes move 12-44 bytes per atom and a handful of flops: HBM-bound, no MFMA.
 #include "boxmath.hpp"
 #include "common.hpp"
+#include "stages.hpp"
 #include "linalg3.hpp"
 
 using namespace mh;
@@ -911,6 +912,36 @@ int central_onepass_host(molar_hip_ctx *c, const Sel &s, double r[8]) {
 
 }  // namespace
 
+namespace mh {
+
+int enqueue_unwrap_batch(molar_hip_ctx *c, float *xyz, const uint64_t *idx, const uint64_t *off, uint32_t nsel,
+                         const molar_hip_box &box, uint32_t pbc) {
+    if (nsel == 0) return 0;
+    hipLaunchKernelGGL(k_unwrap_batch, dim3((nsel + 3u) / 4u), dim3(256), 0, c->stream, xyz, idx, off, nsel, box, pbc & 7u);
+    MH_HIP(hipGetLastError());
+    return 0;
+}
+
+int enqueue_center_batch(molar_hip_ctx *c, const float *xyz, const uint64_t *idx, const uint64_t *off, uint32_t nsel,
+                         const float *mass, float *out, int *status) {
+    if (nsel == 0) return 0;
+    hipLaunchKernelGGL(k_center_batch, dim3((nsel + 3u) / 4u), dim3(256), 0, c->stream, xyz, idx, off, nsel, mass, out, status);
+    MH_HIP(hipGetLastError());
+    return 0;
+}
+
+int enqueue_lipid_order(molar_hip_ctx *c, const float *xyz, const uint64_t *idx, const uint64_t *toff, uint32_t ntails,
+                        int order_type, const float *normals, const uint64_t *noff, const uint8_t *bonds, float *out,
+                        int *status) {
+    if (ntails == 0) return 0;
+    hipLaunchKernelGGL(k_lipid_order, dim3((ntails + 63u) / 64u), dim3(64), 0, c->stream, xyz, idx, toff, ntails, order_type,
+                       normals, noff, bonds, out, status);
+    MH_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mh
+
 extern "C" {
 
 int molar_hip_min_max(molar_hip_ctx *c, const float *xyz, size_t natoms, const uint64_t *idx, size_t n, float lower[3],
@@ -1168,9 +1199,7 @@ int molar_hip_center_batch(molar_hip_ctx *c, const float *xyz, size_t natoms, co
     MH_TRY(c->m_results.reserve(64));
     int *status = c->m_results.as<int>();
     MH_HIP(hipMemsetAsync(status, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_center_batch, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, c->stream, d_xyz, d_idx, d_off,
-                       (uint32_t)nsel, d_mass, d_out, status);
-    MH_HIP(hipGetLastError());
+    MH_TRY(enqueue_center_batch(c, d_xyz, d_idx, d_off, (uint32_t)nsel, d_mass, d_out, status));
     int st = 0;
     MH_TRY(pull(c, &st, status, 4));
     if (st) return fail(st, "zero mass");
@@ -1196,9 +1225,7 @@ int molar_hip_unwrap_simple_batch(molar_hip_ctx *c, float *xyz, size_t natoms, c
     MH_TRY(to_device(c, (const float *)xyz, natoms * 3, c->m_xyz1, &d_xyz));
     MH_TRY(to_device(c, idx, (size_t)last, c->m_idx1, &d_idx));
     MH_TRY(to_device(c, offsets, nsel + 1, c->m_idx2, &d_off));
-    hipLaunchKernelGGL(k_unwrap_batch, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, c->stream, const_cast<float *>(d_xyz),
-                       d_idx, d_off, (uint32_t)nsel, b, (uint32_t)(pbc & 7u));
-    MH_HIP(hipGetLastError());
+    MH_TRY(enqueue_unwrap_batch(c, const_cast<float *>(d_xyz), d_idx, d_off, (uint32_t)nsel, b, pbc));
     if (!is_device_ptr(xyz)) MH_HIP(hipMemcpyAsync(xyz, d_xyz, natoms * 12, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
     return MOLAR_HIP_OK;
@@ -1311,9 +1338,7 @@ int molar_hip_lipid_tail_order(molar_hip_ctx *c, const float *xyz, size_t natoms
     MH_TRY(c->m_results.reserve(64));
     int *status = c->m_results.as<int>();
     MH_HIP(hipMemsetAsync(status, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_lipid_order, dim3((unsigned)((ntails + 63) / 64)), dim3(64), 0, c->stream, d_xyz, d_idx, d_toff,
-                       (uint32_t)ntails, order_type, d_norm, d_noff, d_bo, d_out, status);
-    MH_HIP(hipGetLastError());
+    MH_TRY(enqueue_lipid_order(c, d_xyz, d_idx, d_toff, (uint32_t)ntails, order_type, d_norm, d_noff, d_bo, d_out, status));
     int st = 0;
     MH_TRY(pull(c, &st, status, 4));
     if (st) return fail(st, "lipid order error (status %d)", st);

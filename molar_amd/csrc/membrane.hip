@@ -8,14 +8,18 @@
 //   k_membrane_average  one lane per lipid: gathers the fitted images of its marker from every valid patch
 //                       that contains it, in the order the reference's scatter loop adds them (owner lipid
 //                       ascending, patch order inside), so the f32 sum is the same sum.
+// molar_hip_membrane_frame_* (second half of this file) chains a whole frame of Membrane::compute on the stream.
 // Per-lipid state of unbounded length (local points, Voronoi vertices) lives in HBM slices owned by the lane;
 // the work per lipid is ~30 neighbours, so the kernel is latency bound and tiny next to the neighbour search.
 // f32 throughout, in the reference's operation order (nalgebra gemv/cross/normalize, Cholesky::new + solve).
 #include <algorithm>
 #include <vector>
 
+#include <cmath>
+
 #include "boxmath.hpp"
 #include "common.hpp"
+#include "stages.hpp"
 
 namespace {
 
@@ -438,5 +442,832 @@ extern "C" int molar_hip_membrane_smooth(molar_hip_ctx *c, const molar_hip_membr
     get(S->princ_curvs, o_pcurv, K * 8); get(S->princ_dirs, o_pdirs, K * 24); get(S->area, o_area, K * 4);
     get(S->nvert, o_nvert, K * 4); get(S->neib_ids, o_neib, slots * 8); get(S->voro_vertexes, o_voro, slots * 12);
     get(S->fitted_patch_points, o_fitted, E * 12);
+    return MOLAR_HIP_OK;
+}
+
+
+// ================================================================ one whole frame of Membrane::compute on the stream
+//
+// Everything between the coordinates of a frame and its per-lipid results, enqueued without a host wait: the number of
+// pairs the marker search finds stays in device memory, the kernels behind it are launched over the capacity that
+// earlier frames established and read the real sizes from there.  The host looks once, at the end of the frame.
+
+namespace {
+
+struct FrameInfo {                 // device block of a frame, read back with its results
+    unsigned long long npairs;     // pairs of the marker search taken into the patches
+    unsigned long long E;          // patch entries (2 * npairs)
+    int overflow;                  // more pairs than the search buffers, or more entries than the patch arrays, hold
+    int st_center, st_order;       // MOLAR_HIP_ERR_* raised by the marker / order kernels
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void k_split_markers(uint32_t K, const float *__restrict__ mk, const uint8_t *__restrict__ valid,
+                                                       float *__restrict__ head, float *__restrict__ mid, float *__restrict__ tail,
+                                                       float *__restrict__ head_search) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= K) return;
+    const bool ok = valid[i] != 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float h = mk[9 * i + d];
+        head[3 * i + d] = h;
+        mid[3 * i + d] = mk[9 * i + 3 + d];
+        tail[3 * i + d] = mk[9 * i + 6 + d];
+        // compute_patches searches among the valid lipids only (lib.rs:540-546).  A NaN position pairs with nothing and
+        // leaves the order of every other pair alone, so the search keeps its fixed size and the ids stay lipid ids.
+        head_search[3 * i + d] = ok ? h : __builtin_nanf("");
+    }
+}
+
+__global__ void k_patch_begin(const unsigned long long *__restrict__ total, unsigned long long cap_pairs, unsigned long long cap_entries,
+                              FrameInfo *__restrict__ info) {
+    const unsigned long long t = total ? *total : 0ull;
+    const bool over = t > cap_pairs || 2ull * t > cap_entries;
+    info->npairs = over ? 0ull : t;
+    info->E = over ? 0ull : 2ull * t;
+    info->overflow = over ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_patch_degree(const uint2 *__restrict__ pairs, const FrameInfo *__restrict__ info,
+                                                      uint32_t *__restrict__ deg) {
+    const unsigned long long p = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (p >= info->npairs) return;
+    const uint2 ij = pairs[p];
+    atomicAdd(&deg[ij.x], 1u);
+    atomicAdd(&deg[ij.y], 1u);
+}
+
+// exclusive scan of deg[0 .. K) into poff[0 .. K] (one workgroup; K is a number of lipids)
+__global__ __launch_bounds__(1024) void k_patch_scan(uint32_t K, const uint32_t *__restrict__ deg, uint64_t *__restrict__ poff,
+                                                     uint32_t *__restrict__ roff) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry_s;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0ull;
+    __syncthreads();
+    for (uint32_t base = 0; base < K + 1u; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < K ? deg[i] : 0ull;
+        unsigned long long x = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long y = __shfl_up(x, o, 64);
+            if ((int)lane >= o) x += y;
+        }
+        if (lane == 63u) wsum[wave] = x;
+        __syncthreads();
+        unsigned long long before = carry_s;
+        for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+        if (i < K + 1u) {
+            poff[i] = before + x - v;
+            roff[i] = (uint32_t)(before + x - v);
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023u) carry_s = before + x;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_patch_bucket(const uint2 *__restrict__ pairs, const FrameInfo *__restrict__ info,
+                                                      const uint64_t *__restrict__ poff, uint32_t *__restrict__ cursor,
+                                                      uint32_t *__restrict__ t_ord, uint32_t *__restrict__ t_oth,
+                                                      uint32_t *__restrict__ t_grp) {
+    const unsigned long long p = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (p >= info->npairs) return;
+    const uint2 ij = pairs[p];
+    const uint64_t a = poff[ij.x] + atomicAdd(&cursor[ij.x], 1u);
+    t_ord[a] = (uint32_t)p; t_oth[a] = ij.y; t_grp[a] = ij.x;
+    const uint64_t b = poff[ij.y] + atomicAdd(&cursor[ij.y], 1u);
+    t_ord[b] = (uint32_t)p; t_oth[b] = ij.x; t_grp[b] = ij.y;
+}
+
+// patch_ids[i].push(j); patch_ids[j].push(i) in pair order (lib.rs:553-556): an entry's place inside its lipid's list is
+// the number of entries of that list that come from earlier pairs (a pair feeds a list at most once: i != j)
+__global__ __launch_bounds__(256) void k_patch_rank(const FrameInfo *__restrict__ info, const uint64_t *__restrict__ poff,
+                                                    const uint32_t *__restrict__ t_ord, const uint32_t *__restrict__ t_oth,
+                                                    const uint32_t *__restrict__ t_grp, uint64_t *__restrict__ pids,
+                                                    uint32_t *__restrict__ owner) {
+    const unsigned long long e = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (e >= info->E) return;
+    const uint32_t g = t_grp[e], mine = t_ord[e];
+    const uint64_t a = poff[g], b = poff[g + 1];
+    uint64_t rank = 0;
+    for (uint64_t q = a; q < b; ++q) rank += t_ord[q] < mine ? 1u : 0u;
+    pids[a + rank] = t_oth[e];
+    owner[a + rank] = g;
+}
+
+// Transpose of the patch lists for the marker averaging (k_membrane_average): for lipid t the entries q that hold t,
+// ordered by q = by (owner lipid, position in the owner's list).  The lists are symmetric (a pair pushes both ways), so
+// t's transposed list is as long as its own and the entries of owners below i are as many as the ids below i in it.
+__global__ __launch_bounds__(256) void k_patch_reverse(const FrameInfo *__restrict__ info, const uint64_t *__restrict__ poff,
+                                                       const uint64_t *__restrict__ pids, const uint32_t *__restrict__ owner,
+                                                       uint32_t *__restrict__ rev_entry, uint32_t *__restrict__ rev_owner) {
+    const unsigned long long q = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (q >= info->E) return;
+    const uint32_t i = owner[q];
+    const uint64_t t = pids[q];
+    const uint64_t ta = poff[t], tb = poff[t + 1];
+    uint64_t less = 0, same = 0;
+    for (uint64_t e = ta; e < tb; ++e) {
+        const uint64_t l = pids[e];
+        less += l < i ? 1u : 0u;
+        same += l == i ? 1u : 0u;
+    }
+    if (same > 1)          // the same pair more than once (boxes of fewer than three cells across): keep entry order
+        for (uint64_t e = poff[i]; e < q; ++e) less += pids[e] == t ? 1u : 0u;
+    rev_entry[ta + less] = (uint32_t)q;
+    rev_owner[ta + less] = i;
+}
+
+__device__ __forceinline__ float nrm3(float x, float y, float z) { return __builtin_sqrtf((x * x + y * y) + z * z); }
+
+// tail -> head unit vectors of the valid lipids (lib.rs:459-461); zero for the others
+__global__ __launch_bounds__(256) void k_tail_head(uint32_t K, const float *__restrict__ head, const float *__restrict__ tail,
+                                                   const uint8_t *__restrict__ valid, float *__restrict__ thv, float *__restrict__ nrm) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= K) return;
+    const bool ok = valid[i] != 0;
+    const float x = head[3 * i] - tail[3 * i], y = head[3 * i + 1] - tail[3 * i + 1], z = head[3 * i + 2] - tail[3 * i + 2];
+    const float n = nrm3(x, y, z);
+    thv[3 * i] = ok ? x / n : 0.f; thv[3 * i + 1] = ok ? y / n : 0.f; thv[3 * i + 2] = ok ? z / n : 0.f;
+    nrm[3 * i] = 0.f; nrm[3 * i + 1] = 0.f; nrm[3 * i + 2] = 0.f;
+}
+
+// "angle <= FRAC_PI_2" of nalgebra's Vector::angle (lib.rs:472-473, 494) as a threshold on the cosine: `cos_min` is the
+// smallest f32 whose acos rounds to at most pi/2 in the host's libm (found at plan creation), zero vectors give angle 0.
+__device__ __forceinline__ bool within_half_pi(float ox, float oy, float oz, float no, float sx, float sy, float sz, float ns,
+                                               float cos_min) {
+    if (no == 0.0f || ns == 0.0f) return true;
+    const float cc = ((ox * sx + oy * sy) + oz * sz) / (no * ns);
+    return cc >= cos_min;
+}
+
+// One neighbour average of compute_initial_normals for lipid i by 16 lanes: sum, in patch order, of the patch members'
+// vectors within 90 degrees of the lipid's own, plus its own, normalised.  `src` holds the vectors.
+template <class F>
+__device__ __forceinline__ void patch_average16(uint32_t i, uint32_t sub, uint64_t p0, uint32_t np, const uint64_t *__restrict__ pids,
+                                                F load, float cos_min, float &rx, float &ry, float &rz) {
+    float sx, sy, sz;
+    load(i, sx, sy, sz);
+    const float ns = nrm3(sx, sy, sz);
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (uint32_t base = 0; base < np; base += 16u) {
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        if (base + sub < np) {
+            const uint32_t l = (uint32_t)pids[p0 + base + sub];
+            float x, y, z;
+            load(l, x, y, z);
+            if (within_half_pi(x, y, z, nrm3(x, y, z), sx, sy, sz, ns, cos_min)) { ox = x; oy = y; oz = z; }
+        }
+        // an unselected member adds +0.0: the running sum starts at +0.0 and x + 0.0 == x for every x it can hold
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            ax += __shfl(ox, k, 16);
+            ay += __shfl(oy, k, 16);
+            az += __shfl(oz, k, 16);
+        }
+    }
+    ax += sx; ay += sy; az += sz;                      // .chain(once(central))
+    const float n = nrm3(ax, ay, az);
+    rx = ax / n; ry = ay / n; rz = az / n;
+}
+
+// first pass (lib.rs:464-484): every lipid from the tail->head vectors, independent of each other
+__global__ __launch_bounds__(256) void k_normals_pass1(uint32_t K, const uint8_t *__restrict__ valid, const uint64_t *__restrict__ poff,
+                                                       const uint64_t *__restrict__ pids, const float *__restrict__ thv,
+                                                       float *__restrict__ nrm, float cos_min) {
+    const uint32_t i = blockIdx.x * 16u + (threadIdx.x >> 4), sub = threadIdx.x & 15u;
+    if (i >= K || !valid[i]) return;
+    const uint64_t p0 = poff[i];
+    float x, y, z;
+    patch_average16(i, sub, p0, (uint32_t)(poff[i + 1] - p0), pids,
+                    [&](uint32_t l, float &a, float &b, float &c) { a = thv[3 * l]; b = thv[3 * l + 1]; c = thv[3 * l + 2]; }, cos_min, x, y, z);
+    if (sub == 0) { nrm[3 * i] = x; nrm[3 * i + 1] = y; nrm[3 * i + 2] = z; }
+}
+
+// Second pass (lib.rs:486-505): the reference loop overwrites normals in place while it walks the lipids in id order, so
+// lipid i sees the new normals of its patch members below i and the old ones of those above.  Groups of 16 lanes take
+// lipids in ascending order (group g: g, g + G, ...) and start one when every member below it is finished; a member
+// above it cannot have started (it has i below it), so the update is in place here as well.  IN_LDS: the normals and the
+// flags of the whole bilayer sit in the LDS of one workgroup (what makes a step of the chain cheap); otherwise in HBM,
+// with one workgroup per compute unit at most so that every group is resident.
+template <bool IN_LDS>
+__global__ __launch_bounds__(1024) void k_normals_pass2(uint32_t K, const uint8_t *__restrict__ valid, const uint64_t *__restrict__ poff,
+                                                        const uint64_t *__restrict__ pids, float *nrm, uint32_t *done_g, float cos_min) {
+    extern __shared__ float lds[];
+    float *cur;
+    uint32_t *done;
+    if constexpr (IN_LDS) {
+        cur = lds;
+        done = reinterpret_cast<uint32_t *>(lds + 3 * (size_t)K);
+        for (uint32_t t = threadIdx.x; t < 3u * K; t += 1024u) cur[t] = nrm[t];
+        for (uint32_t t = threadIdx.x; t < K; t += 1024u) done[t] = 0u;
+        __syncthreads();
+    } else {
+        cur = nrm;
+        done = done_g;          // zeroed by the host before the launch
+    }
+    const uint32_t G = gridDim.x * 64u;
+    const uint32_t sub = threadIdx.x & 15u, seg = (threadIdx.x & 63u) & ~15u;
+    uint32_t i = blockIdx.x * 64u + (threadIdx.x >> 4);
+    for (;;) {
+        const bool have = i < K;
+        if (__ballot(have) == 0ull) break;
+        bool ok = have;
+        uint64_t p0 = 0;
+        uint32_t np = 0;
+        if (have && valid[i]) {
+            p0 = poff[i];
+            np = (uint32_t)(poff[i + 1] - p0);
+            for (uint32_t q = sub; q < np; q += 16u) {
+                const uint32_t l = (uint32_t)pids[p0 + q];
+                if (l < i && __hip_atomic_load(&done[l], __ATOMIC_RELAXED, IN_LDS ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                    ok = false;
+            }
+        }
+        const bool ready = have && ((uint32_t)(__ballot(ok) >> seg) & 0xFFFFu) == 0xFFFFu;
+        if (ready) {
+            if constexpr (IN_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (valid[i]) {
+                float x, y, z;
+                patch_average16(i, sub, p0, np, pids,
+                                [&](uint32_t l, float &a, float &b, float &c) {
+                                    if constexpr (IN_LDS) { a = cur[3 * l]; b = cur[3 * l + 1]; c = cur[3 * l + 2]; }
+                                    else {
+                                        a = __builtin_nontemporal_load(&cur[3 * l]);
+                                        b = __builtin_nontemporal_load(&cur[3 * l + 1]);
+                                        c = __builtin_nontemporal_load(&cur[3 * l + 2]);
+                                    }
+                                }, cos_min, x, y, z);
+                if (sub == 0) {
+                    cur[3 * i] = x; cur[3 * i + 1] = y; cur[3 * i + 2] = z;
+                    if constexpr (IN_LDS) { nrm[3 * i] = x; nrm[3 * i + 1] = y; nrm[3 * i + 2] = z; }
+                }
+            }
+            if (sub == 0)
+                __hip_atomic_store(&done[i], 1u, __ATOMIC_RELEASE, IN_LDS ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT);
+            i += G;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_state_defaults(uint32_t K, float *__restrict__ mean, float *__restrict__ gauss) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= K) return;
+    mean[i] = -100.0f;          // LipidMolecule defaults of Membrane::new (lib.rs:152-177)
+    gauss[i] = -100.0f;
+}
+
+__global__ __launch_bounds__(256) void k_tail_normals(uint32_t ntails, const uint32_t *__restrict__ tail_lipid,
+                                                      const float *__restrict__ normals, int use_global, float gx, float gy, float gz,
+                                                      float *__restrict__ out) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= ntails) return;
+    const uint32_t l = tail_lipid[t];
+    out[3 * t] = use_global ? gx : normals[3 * l];
+    out[3 * t + 1] = use_global ? gy : normals[3 * l + 1];
+    out[3 * t + 2] = use_global ? gz : normals[3 * l + 2];
+}
+
+// smallest f32 c with acosf(c) <= pi/2 (f32): the comparison compute_initial_normals makes, decided by the host's libm
+// like MolAR's f32::acos; acos is monotone, the boundary sits a fraction of an ulp of pi/2 below zero
+float half_pi_cos_threshold() {
+    const float half_pi = 1.57079632679489661923f;
+    auto ok = [&](float c) { return std::acos(c) <= half_pi; };
+    float lo = -1.0e-6f, hi = 0.0f;      // !ok(lo), ok(hi)
+    if (ok(lo) || !ok(hi)) return 0.0f;  // not a libm this code knows: the plain sign test
+    while (std::nextafter(lo, hi) != hi) {
+        // bisect on the bit patterns (negative floats: larger pattern = smaller value)
+        uint32_t a, b;
+        std::memcpy(&a, &lo, 4);
+        std::memcpy(&b, &hi, 4);
+        if (hi == 0.0f) b = 0x80000000u;
+        const uint32_t m = b + (a - b) / 2u;
+        float mid;
+        std::memcpy(&mid, &m, 4);
+        if (mid == lo || mid == hi) break;
+        if (ok(mid)) hi = mid; else lo = mid;
+    }
+    return hi;
+}
+
+struct Blob2 {
+    size_t size = 0;
+    size_t take(size_t bytes) {
+        const size_t at = size;
+        size += (bytes + 255) & ~size_t(255);
+        return at;
+    }
+};
+
+struct FrameLayout {       // byte offsets inside a frame slot's device blob, for K lipids and room for Ecap patch entries
+    size_t info, box, mk, head, mid, tail, head_search, valid_prev, valid_out, thv, normals0, poff, roff, pids, owner, rev_entry, rev_owner;
+    size_t zero_begin, s_head, s_normals, coefs, pcurv, pdirs, area, nvert, neib, voro, fitted, zero_end, mean, gauss;
+    size_t saved, fh, vwork, tnorm, order, bytes;
+};
+
+FrameLayout frame_layout(size_t K, size_t Ecap, size_t ntails, size_t norder) {
+    FrameLayout L{};
+    Blob2 B;
+    const size_t slots = Ecap + 4 * K;
+    L.info = B.take(sizeof(FrameInfo));
+    L.box = B.take(sizeof(molar_hip_box));
+    L.mk = B.take(K * 36); L.head = B.take(K * 12); L.mid = B.take(K * 12); L.tail = B.take(K * 12); L.head_search = B.take(K * 12);
+    L.valid_prev = B.take(K); L.valid_out = B.take(K);
+    L.thv = B.take(K * 12); L.normals0 = B.take(K * 12);
+    L.poff = B.take((K + 1) * 8); L.roff = B.take((K + 1) * 4);
+    L.pids = B.take(Ecap * 8); L.owner = B.take(Ecap * 4); L.rev_entry = B.take(Ecap * 4); L.rev_owner = B.take(Ecap * 4);
+    L.s_head = B.take(K * 12); L.s_normals = B.take(K * 12);
+    L.zero_begin = B.size;
+    L.coefs = B.take(K * 24); L.pcurv = B.take(K * 8); L.pdirs = B.take(K * 24); L.area = B.take(K * 4); L.nvert = B.take(K * 4);
+    L.neib = B.take(slots * 8); L.voro = B.take(slots * 12); L.fitted = B.take(Ecap * 12);
+    L.zero_end = B.size;
+    L.mean = B.take(K * 4); L.gauss = B.take(K * 4);
+    L.saved = B.take(K * 12); L.fh = B.take(K * 12); L.vwork = B.take(slots * 16);
+    L.tnorm = B.take(ntails * 12); L.order = B.take(norder * 4 + 16);
+    L.bytes = B.size;
+    return L;
+}
+
+}  // namespace
+
+struct molar_hip_membrane_plan {
+    molar_hip_ctx *c = nullptr;
+    size_t K = 0, natoms = 0, ntails = 0, nidx_lipid = 0, nidx_marker = 0, nidx_tail = 0, norder = 0;
+    float cutoff = 0.f;
+    int order_type = 0, max_iter = 1, unwrap = 0, use_global = 0;
+    float gn[3] = {0, 0, 1};
+    float cos_min = 0.f;
+    // constants of the trajectory, device
+    DevBuf consts;
+    const uint64_t *lipid_idx = nullptr, *lipid_off = nullptr, *marker_idx = nullptr, *marker_off = nullptr, *tail_idx = nullptr,
+                   *tail_off = nullptr, *noff = nullptr;
+    const float *masses = nullptr;
+    const uint32_t *tail_lipid = nullptr;
+    const uint8_t *tail_bonds = nullptr;
+    // carried from frame to frame, device
+    DevBuf valid;                 // [K]
+    DevBuf work;                  // deg[K+1] | cursor[K] | done[K] | t_ord / t_oth / t_grp [Ecap]
+    DevBuf xyz_stage;             // host frames are staged here
+    size_t Ecap = 0;              // patch entries the slot blobs and `work` are laid out for
+    bool pass2_lds_ready = false;
+    hipStream_t copy_stream = nullptr;
+    struct Slot {
+        DevBuf blob;
+        FrameLayout lay{};
+        size_t Ecap = 0;
+        void *h = nullptr;        // pinned: 16 bytes of search sizes | FrameInfo | molar_hip_box
+        hipEvent_t done = nullptr;
+        bool pending = false, ended = false;
+        unsigned long long serial = 0;
+        ResidentLaunch L;
+        unsigned long long cap_pairs = 0;
+        float *xyz_dev = nullptr, *xyz_host = nullptr;
+        float box9[9] = {};
+        FrameInfo info{};
+    } slot[2];
+    int next = 0;
+    unsigned long long serial = 0;
+};
+
+namespace {
+
+constexpr size_t H_SIZES = 0, H_INFO = 64, H_BOX = 128, H_BYTES = 128 + ((sizeof(molar_hip_box) + 63) & ~size_t(63));
+
+int ensure_capacity(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
+    if (S.Ecap == P->Ecap && S.blob.p) return 0;
+    S.lay = frame_layout(P->K, P->Ecap, P->ntails, P->norder);
+    MH_TRY(S.blob.reserve(S.lay.bytes));
+    S.Ecap = P->Ecap;
+    return 0;
+}
+
+int ensure_work(molar_hip_membrane_plan *P) {
+    const size_t K = P->K;
+    return P->work.reserve(((K + 1) + K + K) * 4 + 3 * P->Ecap * 4 + 1024);
+}
+
+// Enqueue a frame from the marker search on (`restore`: put the valid flags back to what they were when this frame was
+// first enqueued - a repeat after its buffers were grown; otherwise remember them).
+int enqueue_from_search(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool restore) {
+    molar_hip_ctx *c = P->c;
+    const size_t K = P->K;
+    const uint32_t K32 = (uint32_t)K;
+    MH_TRY(ensure_capacity(P, S));
+    MH_TRY(ensure_work(P));
+    char *d = S.blob.as<char>();
+    const FrameLayout &L = S.lay;
+    hipStream_t st = c->stream;
+    uint8_t *valid = P->valid.as<uint8_t>();
+    FrameInfo *info = reinterpret_cast<FrameInfo *>(d + L.info);
+    if (restore) MH_HIP(hipMemcpyAsync(valid, d + L.valid_prev, K, hipMemcpyDeviceToDevice, st));
+    else MH_HIP(hipMemcpyAsync(d + L.valid_prev, valid, K, hipMemcpyDeviceToDevice, st));
+    float *head = (float *)(d + L.head), *tail = (float *)(d + L.tail);
+    const uint32_t nbK = (K32 + 255u) / 256u;
+    // search input depends on `valid`: rebuilt on a repeat as well
+    hipLaunchKernelGGL(k_split_markers, dim3(nbK), dim3(256), 0, st, K32, (const float *)(d + L.mk), valid, head, (float *)(d + L.mid), tail,
+                       (float *)(d + L.head_search));
+    // ---- compute_patches (lib.rs:539-558)
+    molar_hip_search_desc q{};
+    q.kind = MOLAR_HIP_SEARCH_SINGLE;
+    q.cutoff = P->cutoff;
+    q.xyz1 = (const float *)(d + L.head_search);
+    q.natoms1 = K;
+    q.idx1 = nullptr;
+    q.n1 = K;
+    q.ids_local = 1;
+    q.box9 = S.box9;
+    q.pbc = MOLAR_HIP_PBC_FULL;
+    const unsigned long long *total_dev = nullptr;
+    const uint32_t *pairs_dev = nullptr;
+    MH_TRY(search_resident_enqueue(c, &q, (char *)S.h + H_SIZES, &S.L, &total_dev, &pairs_dev));
+    S.cap_pairs = S.L.cap0;
+    const size_t Ecap = S.Ecap;
+    uint32_t *deg = P->work.as<uint32_t>(), *cursor = deg + (K + 1), *done = cursor + K, *t_ord = done + K, *t_oth = t_ord + Ecap,
+             *t_grp = t_oth + Ecap;
+    MH_HIP(hipMemsetAsync(deg, 0, ((K + 1) + K + K) * 4, st));
+    hipLaunchKernelGGL(k_patch_begin, dim3(1), dim3(1), 0, st, total_dev, S.cap_pairs, (unsigned long long)Ecap, info);
+    uint64_t *poff = (uint64_t *)(d + L.poff), *pids = (uint64_t *)(d + L.pids);
+    uint32_t *roff = (uint32_t *)(d + L.roff), *owner = (uint32_t *)(d + L.owner), *rev_entry = (uint32_t *)(d + L.rev_entry),
+             *rev_owner = (uint32_t *)(d + L.rev_owner);
+    const size_t pair_room = std::min<size_t>((size_t)S.cap_pairs, Ecap / 2);
+    const uint32_t nbP = (uint32_t)((pair_room + 255) / 256), nbE = (uint32_t)((2 * pair_room + 255) / 256);
+    const uint2 *pairs = reinterpret_cast<const uint2 *>(pairs_dev);
+    if (nbP) hipLaunchKernelGGL(k_patch_degree, dim3(nbP), dim3(256), 0, st, pairs, info, deg);
+    hipLaunchKernelGGL(k_patch_scan, dim3(1), dim3(1024), 0, st, K32, deg, poff, roff);
+    if (nbP) {
+        hipLaunchKernelGGL(k_patch_bucket, dim3(nbP), dim3(256), 0, st, pairs, info, poff, cursor, t_ord, t_oth, t_grp);
+        hipLaunchKernelGGL(k_patch_rank, dim3(nbE), dim3(256), 0, st, info, poff, t_ord, t_oth, t_grp, pids, owner);
+        hipLaunchKernelGGL(k_patch_reverse, dim3(nbE), dim3(256), 0, st, info, poff, pids, owner, rev_entry, rev_owner);
+    }
+    // ---- compute_initial_normals (lib.rs:456-505)
+    float *thv = (float *)(d + L.thv), *n0 = (float *)(d + L.normals0);
+    hipLaunchKernelGGL(k_tail_head, dim3(nbK), dim3(256), 0, st, K32, head, tail, valid, thv, n0);
+    hipLaunchKernelGGL(k_normals_pass1, dim3((K32 + 15u) / 16u), dim3(256), 0, st, K32, valid, poff, pids, thv, n0, P->cos_min);
+    const size_t lds_bytes = K * 16;
+    if (lds_bytes <= 160u * 1024u - 1024u) {
+        if (!P->pass2_lds_ready) {
+            if (lds_bytes > 48u * 1024u)
+                MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_normals_pass2<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes));
+            P->pass2_lds_ready = true;
+        }
+        hipLaunchKernelGGL(k_normals_pass2<true>, dim3(1), dim3(1024), lds_bytes, st, K32, valid, poff, pids, n0, done, P->cos_min);
+    } else {
+        const uint32_t nb = (uint32_t)std::min<size_t>((K + 63) / 64, (size_t)std::max(c->num_cus, 1));
+        hipLaunchKernelGGL(k_normals_pass2<false>, dim3(nb), dim3(1024), 0, st, K32, valid, poff, pids, n0, done, P->cos_min);
+    }
+    // ---- smooth (lib.rs:661-812) on a fresh per-lipid state
+    MH_HIP(hipMemsetAsync(d + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
+    hipLaunchKernelGGL(k_state_defaults, dim3(nbK), dim3(256), 0, st, K32, (float *)(d + L.mean), (float *)(d + L.gauss));
+    MH_HIP(hipMemcpyAsync(d + L.s_head, head, K * 12, hipMemcpyDeviceToDevice, st));
+    MH_HIP(hipMemcpyAsync(d + L.s_normals, n0, K * 12, hipMemcpyDeviceToDevice, st));
+    SmoothDev A;
+    A.K = K32;
+    A.box = (const molar_hip_box *)(d + L.box);
+    A.saved = (const float *)(d + L.saved);
+    A.head = (float *)(d + L.s_head); A.normals = (float *)(d + L.s_normals); A.valid = valid;
+    A.poff = poff; A.pids = pids;
+    A.coefs = (float *)(d + L.coefs); A.mean = (float *)(d + L.mean); A.gauss = (float *)(d + L.gauss);
+    A.pcurv = (float *)(d + L.pcurv); A.pdirs = (float *)(d + L.pdirs); A.area = (float *)(d + L.area);
+    A.nvert = (uint32_t *)(d + L.nvert); A.neib = (uint64_t *)(d + L.neib); A.voro = (float *)(d + L.voro);
+    A.fitted = (float *)(d + L.fitted); A.vwork = (float4 *)(d + L.vwork);
+    A.rev_off = roff; A.rev_entry = rev_entry; A.rev_owner = rev_owner;
+    const uint32_t nbF = (K32 + 63u) / 64u;
+    for (int it = 0; it < P->max_iter; ++it) {
+        MH_HIP(hipMemcpyAsync(d + L.saved, d + L.s_head, K * 12, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_membrane_fit, dim3(nbF), dim3(64), 0, st, A);
+        MH_HIP(hipMemcpyAsync(d + L.fh, d + L.s_head, K * 12, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_membrane_average, dim3(nbF), dim3(64), 0, st, A, (const float *)(d + L.fh));
+    }
+    MH_HIP(hipMemcpyAsync(d + L.valid_out, valid, K, hipMemcpyDeviceToDevice, st));
+    // ---- compute_order (lib.rs:435-443)
+    if (P->ntails) {
+        hipLaunchKernelGGL(k_tail_normals, dim3((uint32_t)((P->ntails + 255) / 256)), dim3(256), 0, st, (uint32_t)P->ntails, P->tail_lipid,
+                           (const float *)(d + L.s_normals), P->use_global, P->gn[0], P->gn[1], P->gn[2], (float *)(d + L.tnorm));
+        MH_TRY(enqueue_lipid_order(c, S.xyz_dev, P->tail_idx, P->tail_off, (uint32_t)P->ntails, P->order_type, (const float *)(d + L.tnorm),
+                                   P->noff, P->tail_bonds, (float *)(d + L.order), &info->st_order));
+    }
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipMemcpyAsync((char *)S.h + H_INFO, info, sizeof(FrameInfo), hipMemcpyDeviceToHost, st));
+    MH_HIP(hipEventRecord(S.done, st));
+    return 0;
+}
+
+int enqueue_frame(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
+    molar_hip_ctx *c = P->c;
+    MH_TRY(ensure_capacity(P, S));
+    char *d = S.blob.as<char>();
+    const FrameLayout &L = S.lay;
+    hipStream_t st = c->stream;
+    molar_hip_box box;
+    MH_TRY(molar_hip_box_from_matrix(S.box9, &box));
+    std::memcpy((char *)S.h + H_BOX, &box, sizeof box);
+    MH_HIP(hipMemcpyAsync(d + L.box, (char *)S.h + H_BOX, sizeof box, hipMemcpyHostToDevice, st));
+    MH_HIP(hipMemsetAsync(d + L.info, 0, sizeof(FrameInfo), st));
+    FrameInfo *info = reinterpret_cast<FrameInfo *>(d + L.info);
+    if (P->unwrap) {
+        MH_TRY(enqueue_unwrap_batch(c, S.xyz_dev, P->lipid_idx, P->lipid_off, (uint32_t)P->K, box, MOLAR_HIP_PBC_FULL));
+        if (S.xyz_host)      // the caller's frame is unwrapped in place, like Modify::unwrap_simple on the System
+            MH_HIP(hipMemcpyAsync(S.xyz_host, S.xyz_dev, P->natoms * 12, hipMemcpyDeviceToHost, st));
+    }
+    MH_TRY(enqueue_center_batch(c, S.xyz_dev, P->marker_idx, P->marker_off, (uint32_t)(3 * P->K), P->masses, (float *)(d + L.mk),
+                                &info->st_center));
+    return enqueue_from_search(P, S, /*restore=*/false);
+}
+
+// wait for a slot's frame; if it outgrew a buffer, grow and repeat it (and the younger frame behind it)
+int settle(molar_hip_membrane_plan *P, int t) {
+    molar_hip_ctx *c = P->c;
+    auto &S = P->slot[t];
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        MH_HIP(hipEventSynchronize(S.done));
+        std::memcpy(&S.info, (char *)S.h + H_INFO, sizeof(FrameInfo));
+        bool fits = true;
+        MH_TRY(search_resident_fits(c, (char *)S.h + H_SIZES, S.L, &fits));
+        unsigned long long sizes[2];
+        std::memcpy(sizes, (char *)S.h + H_SIZES, 16);
+        if (2ull * sizes[0] > P->Ecap) {
+            P->Ecap = (size_t)(2ull * sizes[0] + sizes[0] / 4u + 1024u);
+            fits = false;
+        }
+        if (fits && !S.info.overflow) return 0;
+        // drain the stream (the younger frame may be running), then repeat: this frame with its own valid flags, the
+        // younger one after it with the flags this one leaves
+        MH_HIP(hipStreamSynchronize(c->stream));
+        auto &Y = P->slot[t ^ 1];
+        const bool younger = Y.pending && Y.serial > S.serial;
+        if (S.Ecap != P->Ecap) {
+            // the layout changes with the capacity: carry what the repeat needs (markers, box, valid_prev) over
+            const FrameLayout old = S.lay;
+            DevBuf keep;
+            MH_TRY(keep.reserve(P->K * 36 + P->K + sizeof(molar_hip_box)));
+            char *k = keep.as<char>(), *d0 = S.blob.as<char>();
+            MH_HIP(hipMemcpy(k, d0 + old.mk, P->K * 36, hipMemcpyDeviceToDevice));
+            MH_HIP(hipMemcpy(k + P->K * 36, d0 + old.valid_prev, P->K, hipMemcpyDeviceToDevice));
+            MH_HIP(hipMemcpy(k + P->K * 37, d0 + old.box, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
+            int st_center = 0;
+            MH_HIP(hipMemcpy(&st_center, d0 + old.info + offsetof(FrameInfo, st_center), 4, hipMemcpyDeviceToHost));
+            MH_TRY(ensure_capacity(P, S));
+            char *d1 = S.blob.as<char>();
+            MH_HIP(hipMemset(d1 + S.lay.info, 0, sizeof(FrameInfo)));
+            MH_HIP(hipMemcpy(d1 + S.lay.info + offsetof(FrameInfo, st_center), &st_center, 4, hipMemcpyHostToDevice));
+            MH_HIP(hipMemcpy(d1 + S.lay.mk, k, P->K * 36, hipMemcpyDeviceToDevice));
+            MH_HIP(hipMemcpy(d1 + S.lay.valid_prev, k + P->K * 36, P->K, hipMemcpyDeviceToDevice));
+            MH_HIP(hipMemcpy(d1 + S.lay.box, k + P->K * 37, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
+            keep.release();
+        } else {
+            // same layout: only the status words of the stages that are repeated start over
+            int zero = 0;
+            MH_HIP(hipMemcpy(S.blob.as<char>() + S.lay.info + offsetof(FrameInfo, st_order), &zero, 4, hipMemcpyHostToDevice));
+        }
+        MH_TRY(enqueue_from_search(P, S, /*restore=*/true));
+        if (younger) {
+            if (Y.Ecap != P->Ecap) {
+                const FrameLayout old = Y.lay;
+                DevBuf keep;
+                MH_TRY(keep.reserve(P->K * 36 + sizeof(molar_hip_box)));
+                char *k = keep.as<char>(), *d0 = Y.blob.as<char>();
+                MH_HIP(hipMemcpy(k, d0 + old.mk, P->K * 36, hipMemcpyDeviceToDevice));
+                MH_HIP(hipMemcpy(k + P->K * 36, d0 + old.box, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
+                int st_center = 0;
+                MH_HIP(hipMemcpy(&st_center, d0 + old.info + offsetof(FrameInfo, st_center), 4, hipMemcpyDeviceToHost));
+                MH_TRY(ensure_capacity(P, Y));
+                char *d1 = Y.blob.as<char>();
+                MH_HIP(hipMemset(d1 + Y.lay.info, 0, sizeof(FrameInfo)));
+                MH_HIP(hipMemcpy(d1 + Y.lay.info + offsetof(FrameInfo, st_center), &st_center, 4, hipMemcpyHostToDevice));
+                MH_HIP(hipMemcpy(d1 + Y.lay.mk, k, P->K * 36, hipMemcpyDeviceToDevice));
+                MH_HIP(hipMemcpy(d1 + Y.lay.box, k + P->K * 36, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
+                keep.release();
+            } else {
+                int zero = 0;
+                MH_HIP(hipMemcpy(Y.blob.as<char>() + Y.lay.info + offsetof(FrameInfo, st_order), &zero, 4, hipMemcpyHostToDevice));
+            }
+            MH_TRY(enqueue_from_search(P, Y, /*restore=*/false));
+        }
+    }
+    return fail(MOLAR_HIP_ERR_HIP, "membrane frame: buffers did not settle");
+}
+
+int check_ticket(molar_hip_membrane_plan *P, int32_t t, bool want_ended) {
+    if (!P) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane frame: null plan");
+    if (t < 0 || t > 1) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane frame: unknown ticket %d", (int)t);
+    if (want_ended && !P->slot[t].ended) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane frame: ticket %d holds no ended frame", (int)t);
+    if (!want_ended && !P->slot[t].pending) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane frame: ticket %d is not in flight", (int)t);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int molar_hip_membrane_plan_create(molar_hip_ctx *c, const molar_hip_membrane_desc *D, molar_hip_membrane_plan **out) {
+    if (!c || !D || !out) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: null argument");
+    *out = nullptr;
+    MH_HIP(hipSetDevice(c->device));
+    const size_t K = D->nlipids;
+    if (K == 0) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: no lipids");
+    if (K >= (1ull << 31)) return fail(MOLAR_HIP_ERR_TOO_LARGE, "membrane_plan_create: lipid ids must fit i32 (voronoi_cell.rs:17)");
+    if (!D->lipid_idx || !D->lipid_offsets || !D->marker_idx || !D->marker_offsets || !D->masses)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: null index list");
+    if (D->ntails && (!D->tail_idx || !D->tail_offsets || !D->tail_lipid))
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: null tail list");
+    if (D->ntails >= 0xFFFFFFFFull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "membrane_plan_create: too many tails");
+    if (D->ntails && !D->tail_bonds && D->order_type != 0) return fail(MOLAR_HIP_ERR_LIPID_BOND_ORDER_COUNT, "bond orders missing");
+    if (D->order_type < 0 || D->order_type > 2) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: order_type %d", (int)D->order_type);
+    if (D->max_smooth_iter < 1) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: max_smooth_iter %d", (int)D->max_smooth_iter);
+    if (!(D->cutoff > 0.0f)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: cutoff %g", (double)D->cutoff);
+    auto check_csr = [&](const uint64_t *idx, const uint64_t *off, size_t n, const char *what) {
+        if (off[0] != 0) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: %s offsets do not start at 0", what);
+        for (size_t k = 0; k < n; ++k)
+            if (off[k + 1] < off[k]) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: %s offsets not monotone", what);
+        for (uint64_t q = 0; q < off[n]; ++q)
+            if (idx[q] >= D->natoms) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: %s index %llu out of range", what,
+                                                 (unsigned long long)idx[q]);
+        return 0;
+    };
+    MH_TRY(check_csr(D->lipid_idx, D->lipid_offsets, K, "lipid"));
+    MH_TRY(check_csr(D->marker_idx, D->marker_offsets, 3 * K, "marker"));
+    if (D->ntails) {
+        MH_TRY(check_csr(D->tail_idx, D->tail_offsets, D->ntails, "tail"));
+        for (size_t t = 0; t < D->ntails; ++t) {
+            if (D->tail_lipid[t] >= K) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: tail %zu belongs to no lipid", t);
+            if (D->tail_offsets[t + 1] - D->tail_offsets[t] < 3) return fail(MOLAR_HIP_ERR_LIPID_TAIL_TOO_SHORT, "tail should have at least 3 carbons");
+        }
+    }
+    auto *P = new molar_hip_membrane_plan();
+    P->c = c;
+    P->K = K; P->natoms = D->natoms; P->ntails = D->ntails;
+    P->nidx_lipid = (size_t)D->lipid_offsets[K]; P->nidx_marker = (size_t)D->marker_offsets[3 * K];
+    P->nidx_tail = D->ntails ? (size_t)D->tail_offsets[D->ntails] : 0;
+    P->norder = P->nidx_tail - 2 * D->ntails;
+    P->cutoff = D->cutoff; P->order_type = D->order_type; P->max_iter = D->max_smooth_iter; P->unwrap = D->unwrap;
+    P->use_global = D->use_global_normal;
+    std::memcpy(P->gn, D->global_normal, 12);
+    P->cos_min = half_pi_cos_threshold();
+    int rc = [&]() -> int {
+        Blob2 B;
+        const size_t o_li = B.take(P->nidx_lipid * 8), o_lo = B.take((K + 1) * 8), o_mi = B.take(P->nidx_marker * 8),
+                     o_mo = B.take((3 * K + 1) * 8), o_ms = B.take(D->natoms * 4), o_ti = B.take(P->nidx_tail * 8),
+                     o_to = B.take((D->ntails + 1) * 8), o_no = B.take((D->ntails + 1) * 8), o_tl = B.take(D->ntails * 4),
+                     o_tb = B.take(P->nidx_tail + 16);
+        MH_TRY(P->consts.reserve(B.size));
+        std::vector<char> h(B.size, 0);
+        std::memcpy(h.data() + o_li, D->lipid_idx, P->nidx_lipid * 8);
+        std::memcpy(h.data() + o_lo, D->lipid_offsets, (K + 1) * 8);
+        std::memcpy(h.data() + o_mi, D->marker_idx, P->nidx_marker * 8);
+        std::memcpy(h.data() + o_mo, D->marker_offsets, (3 * K + 1) * 8);
+        std::memcpy(h.data() + o_ms, D->masses, D->natoms * 4);
+        if (D->ntails) {
+            std::memcpy(h.data() + o_ti, D->tail_idx, P->nidx_tail * 8);
+            std::memcpy(h.data() + o_to, D->tail_offsets, (D->ntails + 1) * 8);
+            std::memcpy(h.data() + o_tl, D->tail_lipid, D->ntails * 4);
+            if (D->tail_bonds) std::memcpy(h.data() + o_tb, D->tail_bonds, P->nidx_tail - D->ntails);
+            else std::memset(h.data() + o_tb, 1, P->nidx_tail);
+        }
+        uint64_t *no = reinterpret_cast<uint64_t *>(h.data() + o_no);
+        for (size_t t = 0; t <= D->ntails; ++t) no[t] = t;           // one normal per tail
+        MH_HIP(hipMemcpy(P->consts.p, h.data(), B.size, hipMemcpyHostToDevice));
+        char *d = P->consts.as<char>();
+        P->lipid_idx = (const uint64_t *)(d + o_li); P->lipid_off = (const uint64_t *)(d + o_lo);
+        P->marker_idx = (const uint64_t *)(d + o_mi); P->marker_off = (const uint64_t *)(d + o_mo);
+        P->masses = (const float *)(d + o_ms);
+        P->tail_idx = (const uint64_t *)(d + o_ti); P->tail_off = (const uint64_t *)(d + o_to); P->noff = (const uint64_t *)(d + o_no);
+        P->tail_lipid = (const uint32_t *)(d + o_tl); P->tail_bonds = (const uint8_t *)(d + o_tb);
+        MH_TRY(P->valid.reserve(K));
+        MH_HIP(hipMemset(P->valid.p, 1, K));
+        MH_HIP(hipStreamCreateWithFlags(&P->copy_stream, hipStreamNonBlocking));
+        for (auto &S : P->slot) {
+            MH_HIP(hipHostMalloc(&S.h, H_BYTES, hipHostMallocDefault));
+            std::memset(S.h, 0, H_BYTES);
+            MH_HIP(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+        }
+        P->Ecap = 64 * K;          // room for 32 patch members per lipid to start with
+        return 0;
+    }();
+    if (rc) {
+        molar_hip_membrane_plan_destroy(P);
+        return rc;
+    }
+    *out = P;
+    return MOLAR_HIP_OK;
+}
+
+extern "C" void molar_hip_membrane_plan_destroy(molar_hip_membrane_plan *P) {
+    if (!P) return;
+    (void)hipSetDevice(P->c->device);
+    (void)hipStreamSynchronize(P->c->stream);
+    if (P->copy_stream) {
+        (void)hipStreamSynchronize(P->copy_stream);
+        (void)hipStreamDestroy(P->copy_stream);
+    }
+    for (auto &S : P->slot) {
+        S.blob.release();
+        if (S.h) (void)hipHostFree(S.h);
+        if (S.done) (void)hipEventDestroy(S.done);
+    }
+    P->consts.release(); P->valid.release(); P->work.release(); P->xyz_stage.release();
+    delete P;
+}
+
+extern "C" int molar_hip_membrane_plan_set_valid(molar_hip_membrane_plan *P, const uint8_t *valid) {
+    if (!P) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_set_valid: null plan");
+    MH_HIP(hipSetDevice(P->c->device));
+    for (int t = 0; t < 2; ++t)
+        if (P->slot[t].pending) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_set_valid: frame %d is in flight: end it first", t);
+    MH_HIP(hipStreamSynchronize(P->c->stream));
+    if (!valid) {
+        MH_HIP(hipMemset(P->valid.p, 1, P->K));
+    } else {
+        std::vector<uint8_t> v(valid, valid + P->K);
+        for (auto &b : v) b = b ? 1 : 0;
+        MH_HIP(hipMemcpy(P->valid.p, v.data(), P->K, hipMemcpyHostToDevice));
+    }
+    return MOLAR_HIP_OK;
+}
+
+extern "C" int molar_hip_membrane_frame_begin(molar_hip_membrane_plan *P, float *xyz, const float *box9, int32_t *ticket) {
+    if (!P || !xyz || !box9 || !ticket) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_begin: null argument");
+    molar_hip_ctx *c = P->c;
+    MH_HIP(hipSetDevice(c->device));
+    const int t = P->next;
+    auto &S = P->slot[t];
+    if (S.pending) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "both frames are in flight: call molar_hip_membrane_frame_end first");
+    std::memcpy(S.box9, box9, 36);
+    if (is_device_ptr(xyz)) {
+        S.xyz_dev = xyz;
+        S.xyz_host = nullptr;
+    } else {
+        // one staging buffer: the frame in flight may still read it
+        auto &Y = P->slot[t ^ 1];
+        if (Y.pending && Y.xyz_host) MH_HIP(hipEventSynchronize(Y.done));
+        MH_TRY(P->xyz_stage.reserve(P->natoms * 12));
+        MH_HIP(hipMemcpyAsync(P->xyz_stage.p, xyz, P->natoms * 12, hipMemcpyHostToDevice, c->stream));
+        S.xyz_dev = P->xyz_stage.as<float>();
+        S.xyz_host = xyz;
+    }
+    S.ended = false;
+    S.serial = ++P->serial;
+    MH_TRY(enqueue_frame(P, S));
+    S.pending = true;
+    P->next = t ^ 1;
+    *ticket = t;
+    return MOLAR_HIP_OK;
+}
+
+static void fill_view(molar_hip_membrane_plan *P, const molar_hip_membrane_plan::Slot &S, molar_hip_membrane_view *V) {
+    const char *d = S.blob.as<char>();
+    const FrameLayout &L = S.lay;
+    V->nlipids = P->K; V->patch_entries = (size_t)S.info.E; V->npairs = (size_t)S.info.npairs;
+    V->head = (const float *)(d + L.head); V->mid = (const float *)(d + L.mid); V->tail = (const float *)(d + L.tail);
+    V->patch_offsets = (const uint64_t *)(d + L.poff); V->patch_ids = (const uint64_t *)(d + L.pids);
+    V->initial_normals = (const float *)(d + L.normals0);
+    V->valid = (const uint8_t *)(d + L.valid_out);
+    V->smoothed_head = (const float *)(d + L.s_head); V->normals = (const float *)(d + L.s_normals);
+    V->quad_coefs = (const float *)(d + L.coefs); V->mean_curv = (const float *)(d + L.mean); V->gauss_curv = (const float *)(d + L.gauss);
+    V->princ_curvs = (const float *)(d + L.pcurv); V->princ_dirs = (const float *)(d + L.pdirs); V->area = (const float *)(d + L.area);
+    V->nvert = (const uint32_t *)(d + L.nvert); V->neib_ids = (const uint64_t *)(d + L.neib); V->voro_vertexes = (const float *)(d + L.voro);
+    V->fitted_patch_points = (const float *)(d + L.fitted);
+    V->order = (const float *)(d + L.order); V->norder = P->norder;
+}
+
+extern "C" int molar_hip_membrane_frame_end(molar_hip_membrane_plan *P, int32_t ticket, molar_hip_membrane_view *view) {
+    MH_TRY(check_ticket(P, ticket, /*want_ended=*/false));
+    MH_HIP(hipSetDevice(P->c->device));
+    auto &S = P->slot[ticket];
+    // frames end in begin order: the older one first
+    auto &O = P->slot[ticket ^ 1];
+    if (O.pending && O.serial < S.serial) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_end: end the older frame (ticket %d) first", ticket ^ 1);
+    MH_TRY(settle(P, ticket));
+    S.pending = false;
+    S.ended = true;
+    if (view) fill_view(P, S, view);
+    if (S.info.st_center) return fail(S.info.st_center, "membrane frame: a marker selection has zero mass");
+    if (S.info.st_order) return fail(S.info.st_order, "membrane frame: lipid order error (status %d)", S.info.st_order);
+    return MOLAR_HIP_OK;
+}
+
+extern "C" int molar_hip_membrane_frame_fetch(molar_hip_membrane_plan *P, int32_t ticket, const molar_hip_membrane_out *O) {
+    MH_TRY(check_ticket(P, ticket, /*want_ended=*/true));
+    if (!O) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_fetch: null argument");
+    MH_HIP(hipSetDevice(P->c->device));
+    const auto &S = P->slot[ticket];
+    molar_hip_membrane_view V;
+    fill_view(P, S, &V);
+    const size_t K = P->K, E = V.patch_entries, slots = E + 4 * K;
+    hipStream_t cs = P->copy_stream;
+    auto get = [&](void *dst, const void *src, size_t bytes) -> int {
+        if (dst && bytes) MH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cs));
+        return 0;
+    };
+    MH_TRY(get(O->head, V.head, K * 12)); MH_TRY(get(O->mid, V.mid, K * 12)); MH_TRY(get(O->tail, V.tail, K * 12));
+    MH_TRY(get(O->patch_offsets, V.patch_offsets, (K + 1) * 8)); MH_TRY(get(O->patch_ids, V.patch_ids, E * 8));
+    MH_TRY(get(O->initial_normals, V.initial_normals, K * 12)); MH_TRY(get(O->valid, V.valid, K));
+    MH_TRY(get(O->smoothed_head, V.smoothed_head, K * 12)); MH_TRY(get(O->normals, V.normals, K * 12));
+    MH_TRY(get(O->quad_coefs, V.quad_coefs, K * 24)); MH_TRY(get(O->mean_curv, V.mean_curv, K * 4)); MH_TRY(get(O->gauss_curv, V.gauss_curv, K * 4));
+    MH_TRY(get(O->princ_curvs, V.princ_curvs, K * 8)); MH_TRY(get(O->princ_dirs, V.princ_dirs, K * 24)); MH_TRY(get(O->area, V.area, K * 4));
+    MH_TRY(get(O->nvert, V.nvert, K * 4)); MH_TRY(get(O->neib_ids, V.neib_ids, slots * 8)); MH_TRY(get(O->voro_vertexes, V.voro_vertexes, slots * 12));
+    MH_TRY(get(O->fitted_patch_points, V.fitted_patch_points, E * 12)); MH_TRY(get(O->order, V.order, P->norder * 4));
+    MH_HIP(hipStreamSynchronize(cs));
     return MOLAR_HIP_OK;
 }

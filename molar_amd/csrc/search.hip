@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "hoststream.hpp"
 #include "pair_kernels.hpp"
+#include "stages.hpp"
 
 using namespace mh;
 using namespace mh::pairk;
@@ -1211,11 +1212,7 @@ int molar_hip_search_fill_device(molar_hip_ctx *c, const uint32_t **d_pairs, con
 
 // Enqueue one whole resident search (grid, plan, count, offset scan, fill into outP/outD against their present
 // capacity) and the async read-back of its two sizes into `sizes` (pinned, 16 bytes).  No host wait.
-struct ResidentLaunch {
-    unsigned long long cap0 = 0;      // result capacity the fill pass was launched with (0: the fill was skipped)
-    unsigned long long maskcap0 = 0;  // hit-history units the count pass could record
-    bool degenerate = false;          // empty vdw input: nothing was enqueued, the result is empty
-};
+// (struct ResidentLaunch: stages.hpp)
 
 static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::DevBuf &outP, mh::DevBuf &outD,
                             void *sizes, ResidentLaunch *L) {
@@ -1273,6 +1270,38 @@ static int resident_settle(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD,
     }
     return 0;
 }
+
+}  // extern "C"
+
+// stages.hpp: the resident search for callers that chain device work behind it
+int mh::search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, void *sizes_pinned, ResidentLaunch *L,
+                                const unsigned long long **total_dev, const uint32_t **pairs_dev) {
+    std::memset(sizes_pinned, 0, 16);
+    MH_TRY(resident_enqueue(c, q, c->out_pairs, c->out_dist, sizes_pinned, L));
+    c->have_search = false;              // the sizes are not known to the host: not a cached search for the fill calls
+    *total_dev = L->degenerate ? nullptr : c->slot_base.as<unsigned long long>() + c->nslots_bound;
+    *pairs_dev = c->out_pairs.as<uint32_t>();
+    return 0;
+}
+
+int mh::search_resident_fits(molar_hip_ctx *c, const void *sizes_pinned, const ResidentLaunch &L, bool *fits) {
+    unsigned long long res[2] = {0, 0};
+    std::memcpy(res, sizes_pinned, 16);
+    *fits = true;
+    if (L.degenerate) return 0;
+    if (res[1] > L.maskcap0) {
+        MH_TRY(c->maskbuf.reserve((size_t)(res[1] + res[1] / 4u) * 256u + 256u));
+        *fits = false;
+    }
+    if (res[0] > L.cap0) {
+        MH_TRY(c->out_pairs.reserve((size_t)(res[0] + res[0] / 16u) * 8));
+        MH_TRY(c->out_dist.reserve((size_t)(res[0] + res[0] / 16u) * 4));
+        *fits = false;
+    }
+    return 0;
+}
+
+extern "C" {
 
 int molar_hip_search_resident(molar_hip_ctx *c, const molar_hip_search_desc *q, uint64_t *out_count,
                               const uint32_t **d_pairs, const float **d_dist) {

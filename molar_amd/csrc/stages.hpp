@@ -1,0 +1,35 @@
+// stages.hpp - launch-only forms of stages that other translation units chain on the context's stream without a host
+// round trip in between (membrane.hip: one bilayer frame = unwrap -> markers -> marker search -> patches -> normals ->
+// smoothing -> order, a single wait at the end).  Every pointer is device memory; nothing here synchronises.
+#pragma once
+
+#include "common.hpp"
+
+namespace mh {
+
+// measure.hip: the kernels behind molar_hip_unwrap_simple_batch / _center_batch / _lipid_tail_order.
+// `status` is a device int raised (atomicMax) to the MOLAR_HIP_ERR_* code of the first kind of failure.
+int enqueue_unwrap_batch(molar_hip_ctx *c, float *xyz, const uint64_t *idx, const uint64_t *off, uint32_t nsel,
+                         const molar_hip_box &box, uint32_t pbc);
+int enqueue_center_batch(molar_hip_ctx *c, const float *xyz, const uint64_t *idx, const uint64_t *off, uint32_t nsel,
+                         const float *mass, float *out, int *status);
+int enqueue_lipid_order(molar_hip_ctx *c, const float *xyz, const uint64_t *idx, const uint64_t *toff, uint32_t ntails,
+                        int order_type, const float *normals, const uint64_t *noff, const uint8_t *bonds, float *out,
+                        int *status);
+
+// search.hip: the resident search (molar_hip_search_resident) without its wait.  Count, offset scan and fill go to the
+// context's result buffers against their present capacity; the number of results stays in device memory
+// (*total_dev, u64) for kernels enqueued behind it, and the two sizes the host needs to judge the capacities are
+// copied to `sizes_pinned` (16 bytes: results, hit-history units).
+struct ResidentLaunch {
+    unsigned long long cap0 = 0;      // result capacity the fill pass was launched with (0: the fill was skipped)
+    unsigned long long maskcap0 = 0;  // hit-history units the count pass could record
+    bool degenerate = false;          // empty vdw input: nothing was enqueued, the result is empty
+};
+int search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, void *sizes_pinned, ResidentLaunch *L,
+                            const unsigned long long **total_dev, const uint32_t **pairs_dev);
+// true if the sizes delivered for launch L fitted; otherwise the buffers have been grown and the search must be
+// enqueued again
+int search_resident_fits(molar_hip_ctx *c, const void *sizes_pinned, const ResidentLaunch &L, bool *fits);
+
+}  // namespace mh

@@ -43,6 +43,7 @@ class MembraneOptions:          # molar_membrane/src/lib.rs:53-85 (subset)
     n_shells_smoothing: int = 0 # >0: average curvatures over the n-th neighbour shell
     global_normal: object = None
     unwrap: bool = True
+    fused: bool = True          # one chained call per frame (molar_hip_membrane_frame_*) where the options allow it
 
 
 def pope_like_template() -> LipidTemplate:
@@ -154,6 +155,7 @@ class Membrane:
 
     def reset_valid_lipids(self):                                               # lib.rs:269-273
         self.valid[:] = 1
+        self._valid_pushed = None
 
     @staticmethod
     def _patch_csr(K, i, j):
@@ -198,10 +200,63 @@ class Membrane:
                              masses=up(self.masses), tail_idx=up(self.tail_idx), tail_bonds=up(self.tail_bonds))
         return self._dev
 
+    # ---- the chained form: one begin/end pair per frame, two frames in flight
+    def fusable(self):
+        """The options the chained call covers (everything but the n-th shell variants, lib.rs:562-621)."""
+        return self.opt.fused and self.opt.n_shells_patch == 0 and self.opt.n_shells_smoothing == 0
+
+    def _plan(self):
+        if getattr(self, "_plan_obj", None) is None:
+            tail_lipid = np.repeat(np.arange(self.K, dtype=np.uint32), self.ntails)
+            self._plan_obj = api.MembranePlan(self.eng, len(self.masses), self.lipid_idx, self.lipid_off, self.marker_idx,
+                                              self.marker_off, self.masses, self.tail_idx, self.tail_off, tail_lipid,
+                                              self.tail_bonds, self.opt.cutoff, self.opt.order_type, self.opt.max_smooth_iter,
+                                              self.opt.unwrap, self.opt.global_normal)
+            self._valid_pushed = None
+        return self._plan_obj
+
+    def compute_begin(self, xyz, box):
+        """Enqueue one frame without waiting for it; returns a ticket for compute_end.  Frames are chained in begin
+        order, the valid flags included, so begin(k+1) may come before end(k)."""
+        plan = self._plan()
+        if self._valid_pushed is None or not np.array_equal(self._valid_pushed, self.valid):
+            plan.set_valid(self.valid)              # first frame, reset_valid_lipids, or flags edited by the caller
+        t = plan.begin(xyz, box)
+        self._valid_pushed = False                  # the device copy is ahead of self.valid until the frame ends
+        return t
+
+    def compute_end(self, ticket, names=None):
+        """Wait for a frame begun with compute_begin; returns the same dict as compute (all arrays, or only `names`)."""
+        plan = self._plan()
+        plan.end(ticket)
+        want = list(api.MEMBRANE_ARRAYS) if names is None else list(dict.fromkeys(list(names) + ["valid"]))
+        r = plan.fetch(ticket, want)
+        self.valid[:] = r["valid"]
+        if len(plan._keep) == 0:                    # no younger frame in flight: host and device flags agree again
+            self._valid_pushed = self.valid.copy()
+        res = dict(r)
+        if "order" in r:
+            per_lipid = sum(l - 2 for l in self.tail_lens)
+            flat = r["order"].reshape(self.K, per_lipid)
+            out, pos = [], 0
+            for l in self.tail_lens:
+                out.append(flat[:, pos:pos + l - 2].copy()); pos += l - 2
+            res["order"] = out
+        if "patch_offsets" in r:
+            res["patch_off"] = res.pop("patch_offsets")
+        if self.groups and names is None:
+            d = (res["head"] - res["tail"]).astype(np.float32)
+            thv = d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]
+            for g in self.groups.values():
+                g.frame_update(res, self.species_of_lipid, thv)
+        return res
+
     def compute(self, xyz, box):
         """One frame (Membrane::compute, lib.rs:410-454).  xyz: float32 [N,3] (numpy; unwrapped in place when
         options.unwrap).  Returns a dict: markers, patch CSR, per-lipid state (valid, normals, curvatures, area,
         Voronoi neighbours/vertices) and order: list over tails of [K, n_t-2]."""
+        if self.fusable():
+            return self.compute_end(self.compute_begin(xyz, box))
         e, K, opt = self.eng, self.K, self.opt
         pb = box if isinstance(box, api.PeriodicBox) else api.PeriodicBox.from_matrix(box)
         cst = self._constants(xyz)

@@ -61,12 +61,14 @@ def check_smooth(got, want, patch_off, K, tol=2e-5):
         assert np.allclose(got[g][ok], want[w][ok], rtol=tol, atol=tol), g
 
 
-def run_pipeline_check(eng, orc32, per_leaflet, natoms):
-    """Membrane.compute on a synthetic bilayer against the same pipeline assembled from the oracle's primitives."""
+def run_pipeline_check(eng, orc32, per_leaflet, natoms, fused=True):
+    """Membrane.compute on a synthetic bilayer against the same pipeline assembled from the oracle's primitives
+    (fused: the chained molar_hip_membrane_frame_* call; otherwise one call per stage)."""
     from molar_amd import membrane as mb
     xyz, box, first, tpl, masses = mb.build_bilayer(per_leaflet, natoms)
     K = len(first)
-    m = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(cutoff=1.5, order_type=1))
+    m = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(cutoff=1.5, order_type=1, fused=fused))
+    assert m.fusable() == fused
     work = xyz.copy()
     res = m.compute(work, box)
     ob = orc32.box_from_matrix(box)
@@ -114,8 +116,9 @@ def run_pipeline_check(eng, orc32, per_leaflet, natoms):
     return K, int(np.count_nonzero(res["valid"]))
 
 
-def test_membrane_pipeline_matches_oracle(eng, orc32):
-    run_pipeline_check(eng, orc32, 200, 40000)
+@pytest.mark.parametrize("fused", [True, False])
+def test_membrane_pipeline_matches_oracle(eng, orc32, fused):
+    run_pipeline_check(eng, orc32, 200, 40000, fused)
 
 
 @pytest.mark.timeout(1500)
