@@ -183,6 +183,10 @@ class Engine:
 
     def close(self):
         if getattr(self, "ctx", None):
+            for ref in list(getattr(self, "_plans", ())):        # plans hold the context: they go first
+                plan = ref()
+                if plan is not None:
+                    plan.close()
             self.lib.molar_hip_destroy(self.ctx)
             self.ctx = None
 
@@ -191,6 +195,12 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def _adopt(self, plan):
+        import weakref
+        if not hasattr(self, "_plans"):
+            self._plans = []
+        self._plans = [r for r in self._plans if r() is not None] + [weakref.ref(plan)]
 
     def synchronize(self):
         check(self.lib.molar_hip_synchronize(self.ctx))
@@ -958,13 +968,14 @@ class MembranePlan:
         self.norder = int(keep[6][-1]) - 2 * int(d.ntails)
         self.handle = C.c_void_p()
         check(self.lib.molar_hip_membrane_plan_create(engine.ctx, C.byref(d), C.byref(self.handle)))
+        engine._adopt(self)
         self._views = {}
         self._keep = {}
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and getattr(self.eng, "ctx", None):
             self.lib.molar_hip_membrane_plan_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:

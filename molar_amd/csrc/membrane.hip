@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_patch_bucket(const uint2 *__restrict__ 
 __global__ __launch_bounds__(256) void k_patch_rank(const FrameInfo *__restrict__ info, const uint64_t *__restrict__ poff,
                                                     const uint32_t *__restrict__ t_ord, const uint32_t *__restrict__ t_oth,
                                                     const uint32_t *__restrict__ t_grp, uint64_t *__restrict__ pids,
-                                                    uint32_t *__restrict__ owner) {
+                                                    uint32_t *__restrict__ pids32, uint32_t *__restrict__ owner) {
     const unsigned long long e = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
     if (e >= info->E) return;
     const uint32_t g = t_grp[e], mine = t_ord[e];
@@ -554,6 +554,7 @@ __global__ __launch_bounds__(256) void k_patch_rank(const FrameInfo *__restrict_
     uint64_t rank = 0;
     for (uint64_t q = a; q < b; ++q) rank += t_ord[q] < mine ? 1u : 0u;
     pids[a + rank] = t_oth[e];
+    pids32[a + rank] = t_oth[e];          // what the host pass of the normals reads
     owner[a + rank] = g;
 }
 
@@ -647,69 +648,42 @@ __global__ __launch_bounds__(256) void k_normals_pass1(uint32_t K, const uint8_t
 }
 
 // Second pass (lib.rs:486-505): the reference loop overwrites normals in place while it walks the lipids in id order, so
-// lipid i sees the new normals of its patch members below i and the old ones of those above.  Groups of 16 lanes take
-// lipids in ascending order (group g: g, g + G, ...) and start one when every member below it is finished; a member
-// above it cannot have started (it has i below it), so the update is in place here as well.  IN_LDS: the normals and the
-// flags of the whole bilayer sit in the LDS of one workgroup (what makes a step of the chain cheap); otherwise in HBM,
-// with one workgroup per compute unit at most so that every group is resident.
-template <bool IN_LDS>
-__global__ __launch_bounds__(1024) void k_normals_pass2(uint32_t K, const uint8_t *__restrict__ valid, const uint64_t *__restrict__ poff,
-                                                        const uint64_t *__restrict__ pids, float *nrm, uint32_t *done_g, float cos_min) {
-    extern __shared__ float lds[];
-    float *cur;
-    uint32_t *done;
-    if constexpr (IN_LDS) {
-        cur = lds;
-        done = reinterpret_cast<uint32_t *>(lds + 3 * (size_t)K);
-        for (uint32_t t = threadIdx.x; t < 3u * K; t += 1024u) cur[t] = nrm[t];
-        for (uint32_t t = threadIdx.x; t < K; t += 1024u) done[t] = 0u;
-        __syncthreads();
-    } else {
-        cur = nrm;
-        done = done_g;          // zeroed by the host before the launch
-    }
-    const uint32_t G = gridDim.x * 64u;
-    const uint32_t sub = threadIdx.x & 15u, seg = (threadIdx.x & 63u) & ~15u;
-    uint32_t i = blockIdx.x * 64u + (threadIdx.x >> 4);
-    for (;;) {
-        const bool have = i < K;
-        if (__ballot(have) == 0ull) break;
-        bool ok = have;
-        uint64_t p0 = 0;
-        uint32_t np = 0;
-        if (have && valid[i]) {
-            p0 = poff[i];
-            np = (uint32_t)(poff[i + 1] - p0);
-            for (uint32_t q = sub; q < np; q += 16u) {
-                const uint32_t l = (uint32_t)pids[p0 + q];
-                if (l < i && __hip_atomic_load(&done[l], __ATOMIC_RELAXED, IN_LDS ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT) == 0u)
-                    ok = false;
-            }
-        }
-        const bool ready = have && ((uint32_t)(__ballot(ok) >> seg) & 0xFFFFu) == 0xFFFFu;
-        if (ready) {
-            if constexpr (IN_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (valid[i]) {
-                float x, y, z;
-                patch_average16(i, sub, p0, np, pids,
-                                [&](uint32_t l, float &a, float &b, float &c) {
-                                    if constexpr (IN_LDS) { a = cur[3 * l]; b = cur[3 * l + 1]; c = cur[3 * l + 2]; }
-                                    else {
-                                        a = __builtin_nontemporal_load(&cur[3 * l]);
-                                        b = __builtin_nontemporal_load(&cur[3 * l + 1]);
-                                        c = __builtin_nontemporal_load(&cur[3 * l + 2]);
-                                    }
-                                }, cos_min, x, y, z);
-                if (sub == 0) {
-                    cur[3 * i] = x; cur[3 * i + 1] = y; cur[3 * i + 2] = z;
-                    if constexpr (IN_LDS) { nrm[3 * i] = x; nrm[3 * i + 1] = y; nrm[3 * i + 2] = z; }
+// lipid i sees the new normals of its patch members below i and the old ones of those above: a chain through the lipid
+// ids.  With ids laid out along a periodic lattice that chain is K/2 links long, and a link costs a GPU microseconds
+// (a dependency-driven kernel, 16 lanes per lipid, normals and flags in LDS: bit-identical, 10.3 ms for 4000 lipids)
+// where a CPU core takes 50 ns.  So this pass - and only this one - runs on the host, between two halves of the frame.
+// Same arithmetic as molar_hip_membrane_initial_normals (measure.hip).
+void normals_pass2_host(size_t K, const uint32_t *poff, const uint32_t *pids, const uint8_t *valid, const float *n1, float *nv,
+                        std::vector<float> &len) {
+    const float half_pi = 1.57079632679489661923f;
+    auto nrm = [](const float *a) { return std::sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); };
+    len.resize(K);
+    std::memcpy(nv, n1, K * 12);
+    for (size_t i = 0; i < K; ++i) len[i] = nrm(nv + 3 * i);
+    for (size_t i = 0; i < K; ++i) {
+        if (!valid[i]) continue;
+        const float sx = nv[3 * i], sy = nv[3 * i + 1], sz = nv[3 * i + 2], ns = len[i];
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        for (uint32_t q = poff[i]; q < poff[i + 1]; ++q) {
+            const uint32_t l = pids[q];
+            const float *o = nv + 3 * l;
+            const float no = len[l];
+            bool in = true;                                    // Vector::angle is 0 for a zero vector
+            if (no != 0.0f && ns != 0.0f) {
+                float cc = ((o[0] * sx + o[1] * sy) + o[2] * sz) / (no * ns);
+                if (cc > 1.0e-6f) in = true;
+                else if (cc < -1.0e-6f) in = false;
+                else {
+                    cc = cc < -1.0f ? -1.0f : (cc > 1.0f ? 1.0f : cc);
+                    in = std::acos(cc) <= half_pi;
                 }
             }
-            if (sub == 0)
-                __hip_atomic_store(&done[i], 1u, __ATOMIC_RELEASE, IN_LDS ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT);
-            i += G;
+            if (in) { ax += o[0]; ay += o[1]; az += o[2]; }
         }
+        ax += sx; ay += sy; az += sz;
+        const float n = std::sqrt((ax * ax + ay * ay) + az * az);
+        nv[3 * i] = ax / n; nv[3 * i + 1] = ay / n; nv[3 * i + 2] = az / n;
+        len[i] = nrm(nv + 3 * i);
     }
 }
 
@@ -763,7 +737,7 @@ struct Blob2 {
 };
 
 struct FrameLayout {       // byte offsets inside a frame slot's device blob, for K lipids and room for Ecap patch entries
-    size_t info, box, mk, head, mid, tail, head_search, valid_prev, valid_out, thv, normals0, poff, roff, pids, owner, rev_entry, rev_owner;
+    size_t info, box, mk, head, mid, tail, head_search, valid_prev, valid_out, thv, normals0, poff, roff, pids, pids32, owner, rev_entry, rev_owner;
     size_t zero_begin, s_head, s_normals, coefs, pcurv, pdirs, area, nvert, neib, voro, fitted, zero_end, mean, gauss;
     size_t saved, fh, vwork, tnorm, order, bytes;
 };
@@ -778,7 +752,8 @@ FrameLayout frame_layout(size_t K, size_t Ecap, size_t ntails, size_t norder) {
     L.valid_prev = B.take(K); L.valid_out = B.take(K);
     L.thv = B.take(K * 12); L.normals0 = B.take(K * 12);
     L.poff = B.take((K + 1) * 8); L.roff = B.take((K + 1) * 4);
-    L.pids = B.take(Ecap * 8); L.owner = B.take(Ecap * 4); L.rev_entry = B.take(Ecap * 4); L.rev_owner = B.take(Ecap * 4);
+    L.pids = B.take(Ecap * 8); L.pids32 = B.take(Ecap * 4); L.owner = B.take(Ecap * 4); L.rev_entry = B.take(Ecap * 4);
+    L.rev_owner = B.take(Ecap * 4);
     L.s_head = B.take(K * 12); L.s_normals = B.take(K * 12);
     L.zero_begin = B.size;
     L.coefs = B.take(K * 24); L.pcurv = B.take(K * 8); L.pdirs = B.take(K * 24); L.area = B.take(K * 4); L.nvert = B.take(K * 4);
@@ -793,6 +768,13 @@ FrameLayout frame_layout(size_t K, size_t Ecap, size_t ntails, size_t norder) {
 
 }  // namespace
 
+// A frame runs in three pieces on the context's stream:
+//   A  unwrap, markers                                     (independent of every other frame)
+//   B  marker search, patches, first normals pass          (needs the valid flags the frame before it leaves)
+//   -  second normals pass on the host                     (normals_pass2_host)
+//   C  smoothing, order                                    (leaves the valid flags for the next frame)
+// _begin enqueues A, and B if no older frame is still ahead of its C; _end waits for B, runs the host pass, enqueues C
+// and - before it waits for C - the B of the younger frame, so that the GPU works on that while the host collects.
 struct molar_hip_membrane_plan {
     molar_hip_ctx *c = nullptr;
     size_t K = 0, natoms = 0, ntails = 0, nidx_lipid = 0, nidx_marker = 0, nidx_tail = 0, norder = 0;
@@ -809,18 +791,20 @@ struct molar_hip_membrane_plan {
     const uint8_t *tail_bonds = nullptr;
     // carried from frame to frame, device
     DevBuf valid;                 // [K]
-    DevBuf work;                  // deg[K+1] | cursor[K] | done[K] | t_ord / t_oth / t_grp [Ecap]
-    DevBuf xyz_stage;             // host frames are staged here
+    DevBuf work;                  // deg[K+1] | cursor[K] | t_ord / t_oth / t_grp [Ecap]
     size_t Ecap = 0;              // patch entries the slot blobs and `work` are laid out for
-    bool pass2_lds_ready = false;
     hipStream_t copy_stream = nullptr;
+    std::vector<float> len_scratch;
     struct Slot {
         DevBuf blob;
+        DevBuf xyz_stage;         // a frame handed over in host memory is staged here
         FrameLayout lay{};
         size_t Ecap = 0;
         void *h = nullptr;        // pinned: 16 bytes of search sizes | FrameInfo | molar_hip_box
-        hipEvent_t done = nullptr;
-        bool pending = false, ended = false;
+        void *h_mid = nullptr;    // pinned: what the host pass reads (roff | n1 | valid_prev | pids32) and writes (n2)
+        size_t h_mid_cap = 0;
+        hipEvent_t mid = nullptr, done = nullptr;
+        bool pending = false, ended = false, b_enqueued = false;
         unsigned long long serial = 0;
         ResidentLaunch L;
         unsigned long long cap_pairs = 0;
@@ -836,26 +820,86 @@ namespace {
 
 constexpr size_t H_SIZES = 0, H_INFO = 64, H_BOX = 128, H_BYTES = 128 + ((sizeof(molar_hip_box) + 63) & ~size_t(63));
 
+struct MidLayout {
+    size_t roff, n1, valid, pids, n2, bytes;
+};
+MidLayout mid_layout(size_t K, size_t Ecap) {
+    MidLayout M{};
+    Blob2 B;
+    M.roff = B.take((K + 1) * 4); M.n1 = B.take(K * 12); M.valid = B.take(K); M.n2 = B.take(K * 12); M.pids = B.take(Ecap * 4);
+    M.bytes = B.size;
+    return M;
+}
+
 int ensure_capacity(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
     if (S.Ecap == P->Ecap && S.blob.p) return 0;
     S.lay = frame_layout(P->K, P->Ecap, P->ntails, P->norder);
     MH_TRY(S.blob.reserve(S.lay.bytes));
     S.Ecap = P->Ecap;
+    const size_t need = mid_layout(P->K, P->Ecap).bytes;
+    if (need > S.h_mid_cap) {
+        if (S.h_mid) (void)hipHostFree(S.h_mid);
+        S.h_mid = nullptr;
+        S.h_mid_cap = 0;
+        MH_HIP(hipHostMalloc(&S.h_mid, need + need / 8, hipHostMallocDefault));
+        S.h_mid_cap = need + need / 8;
+    }
     return 0;
 }
 
 int ensure_work(molar_hip_membrane_plan *P) {
     const size_t K = P->K;
-    return P->work.reserve(((K + 1) + K + K) * 4 + 3 * P->Ecap * 4 + 1024);
+    return P->work.reserve(((K + 1) + K) * 4 + 3 * P->Ecap * 4 + 1024);
 }
 
-// Enqueue a frame from the marker search on (`restore`: put the valid flags back to what they were when this frame was
-// first enqueued - a repeat after its buffers were grown; otherwise remember them).
-int enqueue_from_search(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool restore) {
+// A: unwrap and markers
+int enqueue_a(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
+    molar_hip_ctx *c = P->c;
+    MH_TRY(ensure_capacity(P, S));
+    char *d = S.blob.as<char>();
+    const FrameLayout &L = S.lay;
+    hipStream_t st = c->stream;
+    molar_hip_box box;
+    MH_TRY(molar_hip_box_from_matrix(S.box9, &box));
+    std::memcpy((char *)S.h + H_BOX, &box, sizeof box);
+    MH_HIP(hipMemcpyAsync(d + L.box, (char *)S.h + H_BOX, sizeof box, hipMemcpyHostToDevice, st));
+    MH_HIP(hipMemsetAsync(d + L.info, 0, sizeof(FrameInfo), st));
+    FrameInfo *info = reinterpret_cast<FrameInfo *>(d + L.info);
+    if (P->unwrap) {
+        MH_TRY(enqueue_unwrap_batch(c, S.xyz_dev, P->lipid_idx, P->lipid_off, (uint32_t)P->K, box, MOLAR_HIP_PBC_FULL));
+        if (S.xyz_host)      // the caller's frame is unwrapped in place, like Modify::unwrap_simple on the System
+            MH_HIP(hipMemcpyAsync(S.xyz_host, S.xyz_dev, P->natoms * 12, hipMemcpyDeviceToHost, st));
+    }
+    MH_TRY(enqueue_center_batch(c, S.xyz_dev, P->marker_idx, P->marker_off, (uint32_t)(3 * P->K), P->masses, (float *)(d + L.mk),
+                                &info->st_center));
+    return 0;
+}
+
+// B: marker search, patch lists, tail->head vectors and the first normals pass; what the host pass needs goes to the
+// slot's pinned block.  `restore`: a repeat after the buffers were grown - the valid flags go back to what they were.
+int enqueue_b(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool restore) {
     molar_hip_ctx *c = P->c;
     const size_t K = P->K;
     const uint32_t K32 = (uint32_t)K;
-    MH_TRY(ensure_capacity(P, S));
+    if (S.Ecap != P->Ecap) {
+        // the layout changes with the capacity: carry the results of A (markers, box, status) over
+        const FrameLayout old = S.lay;
+        DevBuf keep;
+        MH_TRY(keep.reserve(K * 37 + sizeof(molar_hip_box) + sizeof(FrameInfo)));
+        char *k = keep.as<char>(), *d0 = S.blob.as<char>();
+        MH_HIP(hipStreamSynchronize(c->stream));
+        MH_HIP(hipMemcpy(k, d0 + old.mk, K * 36, hipMemcpyDeviceToDevice));
+        MH_HIP(hipMemcpy(k + K * 36, d0 + old.valid_prev, K, hipMemcpyDeviceToDevice));
+        MH_HIP(hipMemcpy(k + K * 37, d0 + old.box, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
+        MH_HIP(hipMemcpy(k + K * 37 + sizeof(molar_hip_box), d0 + old.info, sizeof(FrameInfo), hipMemcpyDeviceToDevice));
+        MH_TRY(ensure_capacity(P, S));
+        char *d1 = S.blob.as<char>();
+        MH_HIP(hipMemcpy(d1 + S.lay.mk, k, K * 36, hipMemcpyDeviceToDevice));
+        MH_HIP(hipMemcpy(d1 + S.lay.valid_prev, k + K * 36, K, hipMemcpyDeviceToDevice));
+        MH_HIP(hipMemcpy(d1 + S.lay.box, k + K * 37, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
+        MH_HIP(hipMemcpy(d1 + S.lay.info, k + K * 37 + sizeof(molar_hip_box), sizeof(FrameInfo), hipMemcpyDeviceToDevice));
+        keep.release();
+    }
     MH_TRY(ensure_work(P));
     char *d = S.blob.as<char>();
     const FrameLayout &L = S.lay;
@@ -866,7 +910,6 @@ int enqueue_from_search(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slo
     else MH_HIP(hipMemcpyAsync(d + L.valid_prev, valid, K, hipMemcpyDeviceToDevice, st));
     float *head = (float *)(d + L.head), *tail = (float *)(d + L.tail);
     const uint32_t nbK = (K32 + 255u) / 256u;
-    // search input depends on `valid`: rebuilt on a repeat as well
     hipLaunchKernelGGL(k_split_markers, dim3(nbK), dim3(256), 0, st, K32, (const float *)(d + L.mk), valid, head, (float *)(d + L.mid), tail,
                        (float *)(d + L.head_search));
     // ---- compute_patches (lib.rs:539-558)
@@ -885,13 +928,12 @@ int enqueue_from_search(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slo
     MH_TRY(search_resident_enqueue(c, &q, (char *)S.h + H_SIZES, &S.L, &total_dev, &pairs_dev));
     S.cap_pairs = S.L.cap0;
     const size_t Ecap = S.Ecap;
-    uint32_t *deg = P->work.as<uint32_t>(), *cursor = deg + (K + 1), *done = cursor + K, *t_ord = done + K, *t_oth = t_ord + Ecap,
-             *t_grp = t_oth + Ecap;
-    MH_HIP(hipMemsetAsync(deg, 0, ((K + 1) + K + K) * 4, st));
+    uint32_t *deg = P->work.as<uint32_t>(), *cursor = deg + (K + 1), *t_ord = cursor + K, *t_oth = t_ord + Ecap, *t_grp = t_oth + Ecap;
+    MH_HIP(hipMemsetAsync(deg, 0, ((K + 1) + K) * 4, st));
     hipLaunchKernelGGL(k_patch_begin, dim3(1), dim3(1), 0, st, total_dev, S.cap_pairs, (unsigned long long)Ecap, info);
     uint64_t *poff = (uint64_t *)(d + L.poff), *pids = (uint64_t *)(d + L.pids);
-    uint32_t *roff = (uint32_t *)(d + L.roff), *owner = (uint32_t *)(d + L.owner), *rev_entry = (uint32_t *)(d + L.rev_entry),
-             *rev_owner = (uint32_t *)(d + L.rev_owner);
+    uint32_t *roff = (uint32_t *)(d + L.roff), *pids32 = (uint32_t *)(d + L.pids32), *owner = (uint32_t *)(d + L.owner),
+             *rev_entry = (uint32_t *)(d + L.rev_entry), *rev_owner = (uint32_t *)(d + L.rev_owner);
     const size_t pair_room = std::min<size_t>((size_t)S.cap_pairs, Ecap / 2);
     const uint32_t nbP = (uint32_t)((pair_room + 255) / 256), nbE = (uint32_t)((2 * pair_room + 255) / 256);
     const uint2 *pairs = reinterpret_cast<const uint2 *>(pairs_dev);
@@ -899,42 +941,84 @@ int enqueue_from_search(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slo
     hipLaunchKernelGGL(k_patch_scan, dim3(1), dim3(1024), 0, st, K32, deg, poff, roff);
     if (nbP) {
         hipLaunchKernelGGL(k_patch_bucket, dim3(nbP), dim3(256), 0, st, pairs, info, poff, cursor, t_ord, t_oth, t_grp);
-        hipLaunchKernelGGL(k_patch_rank, dim3(nbE), dim3(256), 0, st, info, poff, t_ord, t_oth, t_grp, pids, owner);
+        hipLaunchKernelGGL(k_patch_rank, dim3(nbE), dim3(256), 0, st, info, poff, t_ord, t_oth, t_grp, pids, pids32, owner);
         hipLaunchKernelGGL(k_patch_reverse, dim3(nbE), dim3(256), 0, st, info, poff, pids, owner, rev_entry, rev_owner);
     }
-    // ---- compute_initial_normals (lib.rs:456-505)
+    // ---- compute_initial_normals, first pass (lib.rs:456-484)
     float *thv = (float *)(d + L.thv), *n0 = (float *)(d + L.normals0);
     hipLaunchKernelGGL(k_tail_head, dim3(nbK), dim3(256), 0, st, K32, head, tail, valid, thv, n0);
     hipLaunchKernelGGL(k_normals_pass1, dim3((K32 + 15u) / 16u), dim3(256), 0, st, K32, valid, poff, pids, thv, n0, P->cos_min);
-    const size_t lds_bytes = K * 16;
-    if (lds_bytes <= 160u * 1024u - 1024u) {
-        if (!P->pass2_lds_ready) {
-            if (lds_bytes > 48u * 1024u)
-                MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_normals_pass2<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes));
-            P->pass2_lds_ready = true;
+    MH_HIP(hipGetLastError());
+    // ---- to the host: sizes, offsets, ids, first-pass normals, flags
+    const MidLayout M = mid_layout(K, Ecap);
+    char *hm = (char *)S.h_mid;
+    MH_HIP(hipMemcpyAsync((char *)S.h + H_INFO, info, sizeof(FrameInfo), hipMemcpyDeviceToHost, st));
+    MH_HIP(hipMemcpyAsync(hm + M.roff, roff, (K + 1) * 4, hipMemcpyDeviceToHost, st));
+    MH_HIP(hipMemcpyAsync(hm + M.n1, n0, K * 12, hipMemcpyDeviceToHost, st));
+    MH_HIP(hipMemcpyAsync(hm + M.valid, d + L.valid_prev, K, hipMemcpyDeviceToHost, st));
+    if (pair_room) MH_HIP(hipMemcpyAsync(hm + M.pids, pids32, std::min(Ecap, 2 * pair_room) * 4, hipMemcpyDeviceToHost, st));
+    MH_HIP(hipEventRecord(S.mid, st));
+    S.b_enqueued = true;
+    return 0;
+}
+
+// the host in the middle: wait for B, make sure it fitted (else grow and repeat it), second normals pass
+int host_pass(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
+    molar_hip_ctx *c = P->c;
+    for (int attempt = 0;; ++attempt) {
+        MH_HIP(hipEventSynchronize(S.mid));
+        std::memcpy(&S.info, (char *)S.h + H_INFO, sizeof(FrameInfo));
+        bool fits = true;
+        MH_TRY(search_resident_fits(c, (char *)S.h + H_SIZES, S.L, &fits));
+        unsigned long long sizes[2];
+        std::memcpy(sizes, (char *)S.h + H_SIZES, 16);
+        if (2ull * sizes[0] > P->Ecap) {
+            P->Ecap = (size_t)(2ull * sizes[0] + sizes[0] / 4u + 1024u);
+            fits = false;
         }
-        hipLaunchKernelGGL(k_normals_pass2<true>, dim3(1), dim3(1024), lds_bytes, st, K32, valid, poff, pids, n0, done, P->cos_min);
-    } else {
-        const uint32_t nb = (uint32_t)std::min<size_t>((K + 63) / 64, (size_t)std::max(c->num_cus, 1));
-        hipLaunchKernelGGL(k_normals_pass2<false>, dim3(nb), dim3(1024), 0, st, K32, valid, poff, pids, n0, done, P->cos_min);
+        if (fits && !S.info.overflow) break;
+        if (attempt >= 3) return fail(MOLAR_HIP_ERR_HIP, "membrane frame: buffers did not settle");
+        MH_TRY(enqueue_b(P, S, /*restore=*/true));
     }
-    // ---- smooth (lib.rs:661-812) on a fresh per-lipid state
+    const size_t K = P->K;
+    const MidLayout M = mid_layout(K, S.Ecap);
+    char *hm = (char *)S.h_mid;
+    normals_pass2_host(K, (const uint32_t *)(hm + M.roff), (const uint32_t *)(hm + M.pids), (const uint8_t *)(hm + M.valid),
+                       (const float *)(hm + M.n1), (float *)(hm + M.n2), P->len_scratch);
+    return 0;
+}
+
+// C: smoothing on a fresh per-lipid state, order
+int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
+    molar_hip_ctx *c = P->c;
+    const size_t K = P->K;
+    const uint32_t K32 = (uint32_t)K;
+    char *d = S.blob.as<char>();
+    const FrameLayout &L = S.lay;
+    hipStream_t st = c->stream;
+    uint8_t *valid = P->valid.as<uint8_t>();
+    FrameInfo *info = reinterpret_cast<FrameInfo *>(d + L.info);
+    const MidLayout M = mid_layout(K, S.Ecap);
+    float *n0 = (float *)(d + L.normals0);
+    MH_HIP(hipMemcpyAsync(n0, (char *)S.h_mid + M.n2, K * 12, hipMemcpyHostToDevice, st));
+    const uint32_t nbK = (K32 + 255u) / 256u;
+    // ---- smooth (lib.rs:661-812)
     MH_HIP(hipMemsetAsync(d + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
     hipLaunchKernelGGL(k_state_defaults, dim3(nbK), dim3(256), 0, st, K32, (float *)(d + L.mean), (float *)(d + L.gauss));
-    MH_HIP(hipMemcpyAsync(d + L.s_head, head, K * 12, hipMemcpyDeviceToDevice, st));
+    MH_HIP(hipMemcpyAsync(d + L.s_head, d + L.head, K * 12, hipMemcpyDeviceToDevice, st));
     MH_HIP(hipMemcpyAsync(d + L.s_normals, n0, K * 12, hipMemcpyDeviceToDevice, st));
     SmoothDev A;
     A.K = K32;
     A.box = (const molar_hip_box *)(d + L.box);
     A.saved = (const float *)(d + L.saved);
     A.head = (float *)(d + L.s_head); A.normals = (float *)(d + L.s_normals); A.valid = valid;
-    A.poff = poff; A.pids = pids;
+    A.poff = (const uint64_t *)(d + L.poff); A.pids = (const uint64_t *)(d + L.pids);
     A.coefs = (float *)(d + L.coefs); A.mean = (float *)(d + L.mean); A.gauss = (float *)(d + L.gauss);
     A.pcurv = (float *)(d + L.pcurv); A.pdirs = (float *)(d + L.pdirs); A.area = (float *)(d + L.area);
     A.nvert = (uint32_t *)(d + L.nvert); A.neib = (uint64_t *)(d + L.neib); A.voro = (float *)(d + L.voro);
     A.fitted = (float *)(d + L.fitted); A.vwork = (float4 *)(d + L.vwork);
-    A.rev_off = roff; A.rev_entry = rev_entry; A.rev_owner = rev_owner;
+    A.rev_off = (const uint32_t *)(d + L.roff); A.rev_entry = (const uint32_t *)(d + L.rev_entry);
+    A.rev_owner = (const uint32_t *)(d + L.rev_owner);
     const uint32_t nbF = (K32 + 63u) / 64u;
     for (int it = 0; it < P->max_iter; ++it) {
         MH_HIP(hipMemcpyAsync(d + L.saved, d + L.s_head, K * 12, hipMemcpyDeviceToDevice, st));
@@ -954,101 +1038,6 @@ int enqueue_from_search(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slo
     MH_HIP(hipMemcpyAsync((char *)S.h + H_INFO, info, sizeof(FrameInfo), hipMemcpyDeviceToHost, st));
     MH_HIP(hipEventRecord(S.done, st));
     return 0;
-}
-
-int enqueue_frame(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
-    molar_hip_ctx *c = P->c;
-    MH_TRY(ensure_capacity(P, S));
-    char *d = S.blob.as<char>();
-    const FrameLayout &L = S.lay;
-    hipStream_t st = c->stream;
-    molar_hip_box box;
-    MH_TRY(molar_hip_box_from_matrix(S.box9, &box));
-    std::memcpy((char *)S.h + H_BOX, &box, sizeof box);
-    MH_HIP(hipMemcpyAsync(d + L.box, (char *)S.h + H_BOX, sizeof box, hipMemcpyHostToDevice, st));
-    MH_HIP(hipMemsetAsync(d + L.info, 0, sizeof(FrameInfo), st));
-    FrameInfo *info = reinterpret_cast<FrameInfo *>(d + L.info);
-    if (P->unwrap) {
-        MH_TRY(enqueue_unwrap_batch(c, S.xyz_dev, P->lipid_idx, P->lipid_off, (uint32_t)P->K, box, MOLAR_HIP_PBC_FULL));
-        if (S.xyz_host)      // the caller's frame is unwrapped in place, like Modify::unwrap_simple on the System
-            MH_HIP(hipMemcpyAsync(S.xyz_host, S.xyz_dev, P->natoms * 12, hipMemcpyDeviceToHost, st));
-    }
-    MH_TRY(enqueue_center_batch(c, S.xyz_dev, P->marker_idx, P->marker_off, (uint32_t)(3 * P->K), P->masses, (float *)(d + L.mk),
-                                &info->st_center));
-    return enqueue_from_search(P, S, /*restore=*/false);
-}
-
-// wait for a slot's frame; if it outgrew a buffer, grow and repeat it (and the younger frame behind it)
-int settle(molar_hip_membrane_plan *P, int t) {
-    molar_hip_ctx *c = P->c;
-    auto &S = P->slot[t];
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        MH_HIP(hipEventSynchronize(S.done));
-        std::memcpy(&S.info, (char *)S.h + H_INFO, sizeof(FrameInfo));
-        bool fits = true;
-        MH_TRY(search_resident_fits(c, (char *)S.h + H_SIZES, S.L, &fits));
-        unsigned long long sizes[2];
-        std::memcpy(sizes, (char *)S.h + H_SIZES, 16);
-        if (2ull * sizes[0] > P->Ecap) {
-            P->Ecap = (size_t)(2ull * sizes[0] + sizes[0] / 4u + 1024u);
-            fits = false;
-        }
-        if (fits && !S.info.overflow) return 0;
-        // drain the stream (the younger frame may be running), then repeat: this frame with its own valid flags, the
-        // younger one after it with the flags this one leaves
-        MH_HIP(hipStreamSynchronize(c->stream));
-        auto &Y = P->slot[t ^ 1];
-        const bool younger = Y.pending && Y.serial > S.serial;
-        if (S.Ecap != P->Ecap) {
-            // the layout changes with the capacity: carry what the repeat needs (markers, box, valid_prev) over
-            const FrameLayout old = S.lay;
-            DevBuf keep;
-            MH_TRY(keep.reserve(P->K * 36 + P->K + sizeof(molar_hip_box)));
-            char *k = keep.as<char>(), *d0 = S.blob.as<char>();
-            MH_HIP(hipMemcpy(k, d0 + old.mk, P->K * 36, hipMemcpyDeviceToDevice));
-            MH_HIP(hipMemcpy(k + P->K * 36, d0 + old.valid_prev, P->K, hipMemcpyDeviceToDevice));
-            MH_HIP(hipMemcpy(k + P->K * 37, d0 + old.box, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
-            int st_center = 0;
-            MH_HIP(hipMemcpy(&st_center, d0 + old.info + offsetof(FrameInfo, st_center), 4, hipMemcpyDeviceToHost));
-            MH_TRY(ensure_capacity(P, S));
-            char *d1 = S.blob.as<char>();
-            MH_HIP(hipMemset(d1 + S.lay.info, 0, sizeof(FrameInfo)));
-            MH_HIP(hipMemcpy(d1 + S.lay.info + offsetof(FrameInfo, st_center), &st_center, 4, hipMemcpyHostToDevice));
-            MH_HIP(hipMemcpy(d1 + S.lay.mk, k, P->K * 36, hipMemcpyDeviceToDevice));
-            MH_HIP(hipMemcpy(d1 + S.lay.valid_prev, k + P->K * 36, P->K, hipMemcpyDeviceToDevice));
-            MH_HIP(hipMemcpy(d1 + S.lay.box, k + P->K * 37, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
-            keep.release();
-        } else {
-            // same layout: only the status words of the stages that are repeated start over
-            int zero = 0;
-            MH_HIP(hipMemcpy(S.blob.as<char>() + S.lay.info + offsetof(FrameInfo, st_order), &zero, 4, hipMemcpyHostToDevice));
-        }
-        MH_TRY(enqueue_from_search(P, S, /*restore=*/true));
-        if (younger) {
-            if (Y.Ecap != P->Ecap) {
-                const FrameLayout old = Y.lay;
-                DevBuf keep;
-                MH_TRY(keep.reserve(P->K * 36 + sizeof(molar_hip_box)));
-                char *k = keep.as<char>(), *d0 = Y.blob.as<char>();
-                MH_HIP(hipMemcpy(k, d0 + old.mk, P->K * 36, hipMemcpyDeviceToDevice));
-                MH_HIP(hipMemcpy(k + P->K * 36, d0 + old.box, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
-                int st_center = 0;
-                MH_HIP(hipMemcpy(&st_center, d0 + old.info + offsetof(FrameInfo, st_center), 4, hipMemcpyDeviceToHost));
-                MH_TRY(ensure_capacity(P, Y));
-                char *d1 = Y.blob.as<char>();
-                MH_HIP(hipMemset(d1 + Y.lay.info, 0, sizeof(FrameInfo)));
-                MH_HIP(hipMemcpy(d1 + Y.lay.info + offsetof(FrameInfo, st_center), &st_center, 4, hipMemcpyHostToDevice));
-                MH_HIP(hipMemcpy(d1 + Y.lay.mk, k, P->K * 36, hipMemcpyDeviceToDevice));
-                MH_HIP(hipMemcpy(d1 + Y.lay.box, k + P->K * 36, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
-                keep.release();
-            } else {
-                int zero = 0;
-                MH_HIP(hipMemcpy(Y.blob.as<char>() + Y.lay.info + offsetof(FrameInfo, st_order), &zero, 4, hipMemcpyHostToDevice));
-            }
-            MH_TRY(enqueue_from_search(P, Y, /*restore=*/false));
-        }
-    }
-    return fail(MOLAR_HIP_ERR_HIP, "membrane frame: buffers did not settle");
 }
 
 int check_ticket(molar_hip_membrane_plan *P, int32_t t, bool want_ended) {
@@ -1141,6 +1130,7 @@ extern "C" int molar_hip_membrane_plan_create(molar_hip_ctx *c, const molar_hip_
             MH_HIP(hipHostMalloc(&S.h, H_BYTES, hipHostMallocDefault));
             std::memset(S.h, 0, H_BYTES);
             MH_HIP(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+            MH_HIP(hipEventCreateWithFlags(&S.mid, hipEventDisableTiming));
         }
         P->Ecap = 64 * K;          // room for 32 patch members per lipid to start with
         return 0;
@@ -1163,10 +1153,13 @@ extern "C" void molar_hip_membrane_plan_destroy(molar_hip_membrane_plan *P) {
     }
     for (auto &S : P->slot) {
         S.blob.release();
+        S.xyz_stage.release();
         if (S.h) (void)hipHostFree(S.h);
+        if (S.h_mid) (void)hipHostFree(S.h_mid);
         if (S.done) (void)hipEventDestroy(S.done);
+        if (S.mid) (void)hipEventDestroy(S.mid);
     }
-    P->consts.release(); P->valid.release(); P->work.release(); P->xyz_stage.release();
+    P->consts.release(); P->valid.release(); P->work.release();
     delete P;
 }
 
@@ -1198,17 +1191,18 @@ extern "C" int molar_hip_membrane_frame_begin(molar_hip_membrane_plan *P, float 
         S.xyz_dev = xyz;
         S.xyz_host = nullptr;
     } else {
-        // one staging buffer: the frame in flight may still read it
-        auto &Y = P->slot[t ^ 1];
-        if (Y.pending && Y.xyz_host) MH_HIP(hipEventSynchronize(Y.done));
-        MH_TRY(P->xyz_stage.reserve(P->natoms * 12));
-        MH_HIP(hipMemcpyAsync(P->xyz_stage.p, xyz, P->natoms * 12, hipMemcpyHostToDevice, c->stream));
-        S.xyz_dev = P->xyz_stage.as<float>();
+        MH_TRY(S.xyz_stage.reserve(P->natoms * 12));
+        MH_HIP(hipMemcpyAsync(S.xyz_stage.p, xyz, P->natoms * 12, hipMemcpyHostToDevice, c->stream));
+        S.xyz_dev = S.xyz_stage.as<float>();
         S.xyz_host = xyz;
     }
     S.ended = false;
+    S.b_enqueued = false;
     S.serial = ++P->serial;
-    MH_TRY(enqueue_frame(P, S));
+    MH_TRY(enqueue_a(P, S));
+    // B needs the valid flags the older frame's C leaves: if that C is not enqueued yet (it follows the host pass in
+    // the older frame's _end), B goes in behind it there
+    if (!P->slot[t ^ 1].pending) MH_TRY(enqueue_b(P, S, /*restore=*/false));
     S.pending = true;
     P->next = t ^ 1;
     *ticket = t;
@@ -1238,7 +1232,12 @@ extern "C" int molar_hip_membrane_frame_end(molar_hip_membrane_plan *P, int32_t 
     // frames end in begin order: the older one first
     auto &O = P->slot[ticket ^ 1];
     if (O.pending && O.serial < S.serial) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_end: end the older frame (ticket %d) first", ticket ^ 1);
-    MH_TRY(settle(P, ticket));
+    if (!S.b_enqueued) MH_TRY(enqueue_b(P, S, /*restore=*/false));     // (only after an error left the chain short)
+    MH_TRY(host_pass(P, S));
+    MH_TRY(enqueue_c(P, S));
+    if (O.pending && !O.b_enqueued) MH_TRY(enqueue_b(P, O, /*restore=*/false));
+    MH_HIP(hipEventSynchronize(S.done));
+    std::memcpy(&S.info, (char *)S.h + H_INFO, sizeof(FrameInfo));
     S.pending = false;
     S.ended = true;
     if (view) fill_view(P, S, view);

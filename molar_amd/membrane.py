@@ -155,7 +155,7 @@ class Membrane:
 
     def reset_valid_lipids(self):                                               # lib.rs:269-273
         self.valid[:] = 1
-        self._valid_pushed = None
+        self._valid_dev = None
 
     @staticmethod
     def _patch_csr(K, i, j):
@@ -212,17 +212,18 @@ class Membrane:
                                               self.marker_off, self.masses, self.tail_idx, self.tail_off, tail_lipid,
                                               self.tail_bonds, self.opt.cutoff, self.opt.order_type, self.opt.max_smooth_iter,
                                               self.opt.unwrap, self.opt.global_normal)
-            self._valid_pushed = None
+            self._valid_dev = None              # the flags the plan is known to hold (None: push self.valid first)
+            self._inflight = 0
         return self._plan_obj
 
     def compute_begin(self, xyz, box):
         """Enqueue one frame without waiting for it; returns a ticket for compute_end.  Frames are chained in begin
         order, the valid flags included, so begin(k+1) may come before end(k)."""
         plan = self._plan()
-        if self._valid_pushed is None or not np.array_equal(self._valid_pushed, self.valid):
+        if self._inflight == 0 and (self._valid_dev is None or not np.array_equal(self._valid_dev, self.valid)):
             plan.set_valid(self.valid)              # first frame, reset_valid_lipids, or flags edited by the caller
         t = plan.begin(xyz, box)
-        self._valid_pushed = False                  # the device copy is ahead of self.valid until the frame ends
+        self._inflight += 1
         return t
 
     def compute_end(self, ticket, names=None):
@@ -232,8 +233,8 @@ class Membrane:
         want = list(api.MEMBRANE_ARRAYS) if names is None else list(dict.fromkeys(list(names) + ["valid"]))
         r = plan.fetch(ticket, want)
         self.valid[:] = r["valid"]
-        if len(plan._keep) == 0:                    # no younger frame in flight: host and device flags agree again
-            self._valid_pushed = self.valid.copy()
+        self._inflight -= 1
+        self._valid_dev = self.valid.copy() if self._inflight == 0 else None     # a younger frame is ahead of self.valid
         res = dict(r)
         if "order" in r:
             per_lipid = sum(l - 2 for l in self.tail_lens)
