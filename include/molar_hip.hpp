@@ -608,6 +608,49 @@ inline std::vector<usize> distance_search_within_pbc(Float cutoff, const SelBoun
     return detail::run_search<usize>(d1.ctx(), detail::desc(MOLAR_HIP_SEARCH_WITHIN, cutoff, d1, &d2, false, &pbox, pbc_dims));
 }
 
+// ---------------------------------------------------------------- bilayer frames (molar_membrane/src/lib.rs:410-454)
+// One frame of Membrane::compute per push, chained on the engine's stream (molar_hip_membrane_frame_begin / _end):
+// unwrap -> markers -> patches -> initial normals -> smoothing -> tail order, two frames in flight, the valid flags of
+// the lipids carried from frame to frame like LipidMolecule::valid.
+//     MembraneFrames mem(eng, desc);
+//     for (frame : trajectory) { if (auto v = mem.push(frame.xyz, frame.box)) consume(*v, mem); }
+//     if (auto v = mem.finish()) consume(*v, mem);
+// push() hands back the view (device addresses, sizes) of the frame pushed before; fetch() copies chosen arrays of that
+// frame to host memory.  A view stays valid until the second push after the one that produced it.
+class MembraneFrames {
+  public:
+    MembraneFrames(Engine &eng, const molar_hip_membrane_desc &desc) { check(molar_hip_membrane_plan_create(eng.ctx(), &desc, &plan_)); }
+    MembraneFrames(const MembraneFrames &) = delete;
+    MembraneFrames &operator=(const MembraneFrames &) = delete;
+    ~MembraneFrames() { molar_hip_membrane_plan_destroy(plan_); }      // waits for the frames in flight
+    // reset_valid_lipids (lib.rs:269-273) with nullptr, or the caller's flags; no frame may be in flight
+    void set_valid(const uint8_t *valid) { check(molar_hip_membrane_plan_set_valid(plan_, valid)); }
+    // xyz: float[natoms][3] in device memory (unwrapped in place, read until the frame has been handed back) or host memory
+    std::optional<molar_hip_membrane_view> push(float *xyz, const PeriodicBox &pbox) {
+        int32_t t = -1;
+        check(molar_hip_membrane_frame_begin(plan_, xyz, pbox.colmajor9(), &t));
+        std::optional<molar_hip_membrane_view> out = finish();
+        ticket_ = t;
+        pending_ = true;
+        return out;
+    }
+    std::optional<molar_hip_membrane_view> finish() {
+        if (!pending_) return std::nullopt;
+        pending_ = false;
+        molar_hip_membrane_view v{};
+        last_ = ticket_;
+        check(molar_hip_membrane_frame_end(plan_, ticket_, &v));
+        return v;
+    }
+    // arrays of the frame handed back last (null members of `out` are skipped)
+    void fetch(const molar_hip_membrane_out &out) { check(molar_hip_membrane_frame_fetch(plan_, last_, &out)); }
+
+  private:
+    molar_hip_membrane_plan *plan_ = nullptr;
+    int32_t ticket_ = -1, last_ = -1;
+    bool pending_ = false;
+};
+
 // ---------------------------------------------------------------- analysis task driver (analysis_task.rs)
 
 struct AnalysisError : MolarError {          // analysis_task.rs:40-75

@@ -459,7 +459,7 @@ struct FrameInfo {                 // device block of a frame, read back with it
     unsigned long long E;          // patch entries (2 * npairs)
     int overflow;                  // more pairs than the search buffers, or more entries than the patch arrays, hold
     int st_center, st_order;       // MOLAR_HIP_ERR_* raised by the marker / order kernels
-    int pad;
+    int changed;                   // the smoothing of this frame dropped a lipid (the valid flags it leaves differ from those it found)
 };
 
 __global__ __launch_bounds__(256) void k_split_markers(uint32_t K, const float *__restrict__ mk, const uint8_t *__restrict__ valid,
@@ -687,11 +687,29 @@ void normals_pass2_host(size_t K, const uint32_t *poff, const uint32_t *pids, co
     }
 }
 
-__global__ __launch_bounds__(256) void k_state_defaults(uint32_t K, float *__restrict__ mean, float *__restrict__ gauss) {
+// fresh per-lipid state of a frame: the LipidMolecule defaults of Membrane::new (lib.rs:152-177; the rest is zeroed by a
+// memset), the working copy of the head markers and the initial normals
+__global__ __launch_bounds__(256) void k_state_defaults(uint32_t K, float *__restrict__ mean, float *__restrict__ gauss,
+                                                        const float *__restrict__ head, const float *__restrict__ n0,
+                                                        float *__restrict__ s_head, float *__restrict__ s_normals) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= K) return;
-    mean[i] = -100.0f;          // LipidMolecule defaults of Membrane::new (lib.rs:152-177)
+    mean[i] = -100.0f;
     gauss[i] = -100.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        s_head[3 * i + d] = head[3 * i + d];
+        s_normals[3 * i + d] = n0[3 * i + d];
+    }
+}
+
+// the flags a frame leaves, for its results; and whether its smoothing changed any
+__global__ __launch_bounds__(256) void k_valid_out(uint32_t K, const uint8_t *__restrict__ before, const uint8_t *__restrict__ after,
+                                                   uint8_t *__restrict__ out, int *__restrict__ changed) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= K) return;
+    out[i] = after[i];
+    if (before[i] != after[i]) *changed = 1;
 }
 
 __global__ __launch_bounds__(256) void k_tail_normals(uint32_t ntails, const uint32_t *__restrict__ tail_lipid,
@@ -773,8 +791,9 @@ FrameLayout frame_layout(size_t K, size_t Ecap, size_t ntails, size_t norder) {
 //   B  marker search, patches, first normals pass          (needs the valid flags the frame before it leaves)
 //   -  second normals pass on the host                     (normals_pass2_host)
 //   C  smoothing, order                                    (leaves the valid flags for the next frame)
-// _begin enqueues A, and B if no older frame is still ahead of its C; _end waits for B, runs the host pass, enqueues C
-// and - before it waits for C - the B of the younger frame, so that the GPU works on that while the host collects.
+// _begin enqueues A and B; _end waits for B, runs the host pass, enqueues C and waits for it.  With two frames in flight
+// the younger frame's B is on the stream ahead of the older frame's C and keeps the GPU busy during the older frame's
+// host pass; it has then seen the flags of the frame before, and is repeated if C changed them (FrameInfo::changed).
 struct molar_hip_membrane_plan {
     molar_hip_ctx *c = nullptr;
     size_t K = 0, natoms = 0, ntails = 0, nidx_lipid = 0, nidx_marker = 0, nidx_tail = 0, norder = 0;
@@ -794,6 +813,8 @@ struct molar_hip_membrane_plan {
     DevBuf work;                  // deg[K+1] | cursor[K] | t_ord / t_oth / t_grp [Ecap]
     size_t Ecap = 0;              // patch entries the slot blobs and `work` are laid out for
     hipStream_t copy_stream = nullptr;
+    void *h_fetch = nullptr;      // pinned staging of molar_hip_membrane_frame_fetch
+    size_t h_fetch_cap = 0;
     std::vector<float> len_scratch;
     struct Slot {
         DevBuf blob;
@@ -805,6 +826,7 @@ struct molar_hip_membrane_plan {
         size_t h_mid_cap = 0;
         hipEvent_t mid = nullptr, done = nullptr;
         bool pending = false, ended = false, b_enqueued = false;
+        bool speculative = false;  // B ran on the flags of the frame before the older one, ahead of the older frame's C
         unsigned long long serial = 0;
         ResidentLaunch L;
         unsigned long long cap_pairs = 0;
@@ -1004,13 +1026,11 @@ int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
     const uint32_t nbK = (K32 + 255u) / 256u;
     // ---- smooth (lib.rs:661-812)
     MH_HIP(hipMemsetAsync(d + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
-    hipLaunchKernelGGL(k_state_defaults, dim3(nbK), dim3(256), 0, st, K32, (float *)(d + L.mean), (float *)(d + L.gauss));
-    MH_HIP(hipMemcpyAsync(d + L.s_head, d + L.head, K * 12, hipMemcpyDeviceToDevice, st));
-    MH_HIP(hipMemcpyAsync(d + L.s_normals, n0, K * 12, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_state_defaults, dim3(nbK), dim3(256), 0, st, K32, (float *)(d + L.mean), (float *)(d + L.gauss),
+                       (const float *)(d + L.head), (const float *)n0, (float *)(d + L.s_head), (float *)(d + L.s_normals));
     SmoothDev A;
     A.K = K32;
     A.box = (const molar_hip_box *)(d + L.box);
-    A.saved = (const float *)(d + L.saved);
     A.head = (float *)(d + L.s_head); A.normals = (float *)(d + L.s_normals); A.valid = valid;
     A.poff = (const uint64_t *)(d + L.poff); A.pids = (const uint64_t *)(d + L.pids);
     A.coefs = (float *)(d + L.coefs); A.mean = (float *)(d + L.mean); A.gauss = (float *)(d + L.gauss);
@@ -1021,12 +1041,18 @@ int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
     A.rev_owner = (const uint32_t *)(d + L.rev_owner);
     const uint32_t nbF = (K32 + 63u) / 64u;
     for (int it = 0; it < P->max_iter; ++it) {
-        MH_HIP(hipMemcpyAsync(d + L.saved, d + L.s_head, K * 12, hipMemcpyDeviceToDevice, st));
+        // the markers before the iteration: the frame's own for the first one (the working copy starts as their image)
+        if (it == 0) A.saved = (const float *)(d + L.head);
+        else {
+            MH_HIP(hipMemcpyAsync(d + L.saved, d + L.s_head, K * 12, hipMemcpyDeviceToDevice, st));
+            A.saved = (const float *)(d + L.saved);
+        }
         hipLaunchKernelGGL(k_membrane_fit, dim3(nbF), dim3(64), 0, st, A);
-        MH_HIP(hipMemcpyAsync(d + L.fh, d + L.s_head, K * 12, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_membrane_average, dim3(nbF), dim3(64), 0, st, A, (const float *)(d + L.fh));
+        // (a lane of the averaging kernel reads the fitted marker of its own lipid only, before it overwrites it)
+        hipLaunchKernelGGL(k_membrane_average, dim3(nbF), dim3(64), 0, st, A, (const float *)A.head);
     }
-    MH_HIP(hipMemcpyAsync(d + L.valid_out, valid, K, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_valid_out, dim3(nbK), dim3(256), 0, st, K32, (const uint8_t *)(d + L.valid_prev), valid, (uint8_t *)(d + L.valid_out),
+                       &info->changed);
     // ---- compute_order (lib.rs:435-443)
     if (P->ntails) {
         hipLaunchKernelGGL(k_tail_normals, dim3((uint32_t)((P->ntails + 255) / 256)), dim3(256), 0, st, (uint32_t)P->ntails, P->tail_lipid,
@@ -1159,6 +1185,7 @@ extern "C" void molar_hip_membrane_plan_destroy(molar_hip_membrane_plan *P) {
         if (S.done) (void)hipEventDestroy(S.done);
         if (S.mid) (void)hipEventDestroy(S.mid);
     }
+    if (P->h_fetch) (void)hipHostFree(P->h_fetch);
     P->consts.release(); P->valid.release(); P->work.release();
     delete P;
 }
@@ -1200,9 +1227,11 @@ extern "C" int molar_hip_membrane_frame_begin(molar_hip_membrane_plan *P, float 
     S.b_enqueued = false;
     S.serial = ++P->serial;
     MH_TRY(enqueue_a(P, S));
-    // B needs the valid flags the older frame's C leaves: if that C is not enqueued yet (it follows the host pass in
-    // the older frame's _end), B goes in behind it there
-    if (!P->slot[t ^ 1].pending) MH_TRY(enqueue_b(P, S, /*restore=*/false));
+    // B needs the valid flags the older frame's C will leave, and that C is not enqueued yet (it follows the host pass in
+    // the older frame's _end).  Smoothing rarely drops a lipid, so B runs now on the flags as they are - the GPU works on
+    // it while the host is busy with the older frame - and is repeated behind that C if it did change them.
+    S.speculative = P->slot[t ^ 1].pending;
+    MH_TRY(enqueue_b(P, S, /*restore=*/false));
     S.pending = true;
     P->next = t ^ 1;
     *ticket = t;
@@ -1235,9 +1264,10 @@ extern "C" int molar_hip_membrane_frame_end(molar_hip_membrane_plan *P, int32_t 
     if (!S.b_enqueued) MH_TRY(enqueue_b(P, S, /*restore=*/false));     // (only after an error left the chain short)
     MH_TRY(host_pass(P, S));
     MH_TRY(enqueue_c(P, S));
-    if (O.pending && !O.b_enqueued) MH_TRY(enqueue_b(P, O, /*restore=*/false));
     MH_HIP(hipEventSynchronize(S.done));
     std::memcpy(&S.info, (char *)S.h + H_INFO, sizeof(FrameInfo));
+    if (O.pending && (!O.b_enqueued || (O.speculative && S.info.changed))) MH_TRY(enqueue_b(P, O, /*restore=*/false));
+    O.speculative = false;
     S.pending = false;
     S.ended = true;
     if (view) fill_view(P, S, view);
@@ -1255,18 +1285,35 @@ extern "C" int molar_hip_membrane_frame_fetch(molar_hip_membrane_plan *P, int32_
     fill_view(P, S, &V);
     const size_t K = P->K, E = V.patch_entries, slots = E + 4 * K;
     hipStream_t cs = P->copy_stream;
-    auto get = [&](void *dst, const void *src, size_t bytes) -> int {
-        if (dst && bytes) MH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cs));
-        return 0;
+    // everything through one pinned block: the copies run back to back on the copy stream (beside the kernels of the
+    // frame in flight), one wait, then plain memcpy into the caller's arrays
+    struct Item { void *dst; const void *src; size_t bytes, at; };
+    std::vector<Item> items;
+    size_t total = 0;
+    auto want = [&](void *dst, const void *src, size_t bytes) {
+        if (!dst || !bytes) return;
+        items.push_back(Item{dst, src, bytes, total});
+        total += (bytes + 63) & ~size_t(63);
     };
-    MH_TRY(get(O->head, V.head, K * 12)); MH_TRY(get(O->mid, V.mid, K * 12)); MH_TRY(get(O->tail, V.tail, K * 12));
-    MH_TRY(get(O->patch_offsets, V.patch_offsets, (K + 1) * 8)); MH_TRY(get(O->patch_ids, V.patch_ids, E * 8));
-    MH_TRY(get(O->initial_normals, V.initial_normals, K * 12)); MH_TRY(get(O->valid, V.valid, K));
-    MH_TRY(get(O->smoothed_head, V.smoothed_head, K * 12)); MH_TRY(get(O->normals, V.normals, K * 12));
-    MH_TRY(get(O->quad_coefs, V.quad_coefs, K * 24)); MH_TRY(get(O->mean_curv, V.mean_curv, K * 4)); MH_TRY(get(O->gauss_curv, V.gauss_curv, K * 4));
-    MH_TRY(get(O->princ_curvs, V.princ_curvs, K * 8)); MH_TRY(get(O->princ_dirs, V.princ_dirs, K * 24)); MH_TRY(get(O->area, V.area, K * 4));
-    MH_TRY(get(O->nvert, V.nvert, K * 4)); MH_TRY(get(O->neib_ids, V.neib_ids, slots * 8)); MH_TRY(get(O->voro_vertexes, V.voro_vertexes, slots * 12));
-    MH_TRY(get(O->fitted_patch_points, V.fitted_patch_points, E * 12)); MH_TRY(get(O->order, V.order, P->norder * 4));
+    want(O->head, V.head, K * 12); want(O->mid, V.mid, K * 12); want(O->tail, V.tail, K * 12);
+    want(O->patch_offsets, V.patch_offsets, (K + 1) * 8); want(O->patch_ids, V.patch_ids, E * 8);
+    want(O->initial_normals, V.initial_normals, K * 12); want(O->valid, V.valid, K);
+    want(O->smoothed_head, V.smoothed_head, K * 12); want(O->normals, V.normals, K * 12);
+    want(O->quad_coefs, V.quad_coefs, K * 24); want(O->mean_curv, V.mean_curv, K * 4); want(O->gauss_curv, V.gauss_curv, K * 4);
+    want(O->princ_curvs, V.princ_curvs, K * 8); want(O->princ_dirs, V.princ_dirs, K * 24); want(O->area, V.area, K * 4);
+    want(O->nvert, V.nvert, K * 4); want(O->neib_ids, V.neib_ids, slots * 8); want(O->voro_vertexes, V.voro_vertexes, slots * 12);
+    want(O->fitted_patch_points, V.fitted_patch_points, E * 12); want(O->order, V.order, P->norder * 4);
+    if (items.empty()) return MOLAR_HIP_OK;
+    if (total > P->h_fetch_cap) {
+        if (P->h_fetch) (void)hipHostFree(P->h_fetch);
+        P->h_fetch = nullptr;
+        P->h_fetch_cap = 0;
+        MH_HIP(hipHostMalloc(&P->h_fetch, total + total / 4, hipHostMallocDefault));
+        P->h_fetch_cap = total + total / 4;
+    }
+    for (const Item &it : items) MH_HIP(hipMemcpyAsync((char *)P->h_fetch + it.at, it.src, it.bytes, hipMemcpyDeviceToHost, cs));
     MH_HIP(hipStreamSynchronize(cs));
+    for (const Item &it : items) std::memcpy(it.dst, (const char *)P->h_fetch + it.at, it.bytes);
     return MOLAR_HIP_OK;
 }
+

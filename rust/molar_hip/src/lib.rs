@@ -435,6 +435,157 @@ impl Engine {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Bilayer frames: `Membrane::compute` (molar_membrane/src/lib.rs:410-454) as one chained call per frame
+// (molar_hip_membrane_frame_begin / _end / _fetch), the Rust side of `MembraneFrames` in include/molar_hip.hpp.
+
+/// Index lists of a bilayer, as `Membrane::new` collects them per lipid (lib.rs:120-177): whole lipids, the three marker
+/// sub-selections (head, mid, tail end) per lipid, and the tails' carbons with their bond orders.
+pub struct MembraneLayout<'a> {
+    pub natoms: usize,
+    pub lipid_idx: &'a [usize],
+    pub lipid_offsets: &'a [usize],
+    pub marker_idx: &'a [usize],
+    pub marker_offsets: &'a [usize],
+    pub masses: &'a [f32],
+    pub tail_idx: &'a [usize],
+    pub tail_offsets: &'a [usize],
+    pub tail_lipid: &'a [u32],
+    pub tail_bonds: &'a [u8],
+    pub cutoff: f32,
+    pub order_type: i32,
+    pub max_smooth_iter: i32,
+    pub unwrap: bool,
+    pub global_normal: Option<[f32; 3]>,
+}
+
+/// Per-lipid results of one frame copied to the host (the arrays `LipidGroup::frame_update` reads, lipid_group.rs).
+pub struct MembraneFrame {
+    pub valid: Vec<u8>,
+    pub normals: Vec<[f32; 3]>,
+    pub mean_curv: Vec<f32>,
+    pub gauss_curv: Vec<f32>,
+    pub area: Vec<f32>,
+    pub nvert: Vec<u32>,
+    pub neib_ids: Vec<u64>,
+    pub patch_offsets: Vec<u64>,
+    pub order: Vec<f32>,
+}
+
+/// Two frames in flight on one engine: `push(frame k+1)` returns the results of frame k.
+pub struct MembraneFrames<'e> {
+    engine: &'e Engine,
+    plan: *mut MolarHipMembranePlan,
+    nlipids: usize,
+    natoms: usize,
+    pending: Option<i32>,
+}
+
+impl<'e> MembraneFrames<'e> {
+    pub fn new(engine: &'e Engine, l: &MembraneLayout) -> Result<Self, EngineError> {
+        let k = l.lipid_offsets.len().saturating_sub(1);
+        check_offsets(l.lipid_offsets, l.lipid_idx.len(), "MembraneFrames: lipids")?;
+        check_offsets(l.marker_offsets, l.marker_idx.len(), "MembraneFrames: markers")?;
+        check_offsets(l.tail_offsets, l.tail_idx.len(), "MembraneFrames: tails")?;
+        check_index(Some(l.lipid_idx), l.natoms, "MembraneFrames: lipids")?;
+        check_index(Some(l.marker_idx), l.natoms, "MembraneFrames: markers")?;
+        check_index(Some(l.tail_idx), l.natoms, "MembraneFrames: tails")?;
+        check_column(l.masses.len(), l.natoms, "MembraneFrames: masses")?;
+        let ntails = l.tail_offsets.len().saturating_sub(1);
+        if l.marker_offsets.len() != 3 * k + 1 || l.tail_lipid.len() != ntails || l.tail_bonds.len() + ntails < l.tail_idx.len() {
+            return Err(EngineError::Sizes("MembraneFrames: three marker selections per lipid, one lipid and n-1 bond orders per tail".into()));
+        }
+        let d = MolarHipMembraneDesc {
+            natoms: l.natoms,
+            nlipids: k,
+            lipid_idx: l.lipid_idx.as_ptr() as *const u64,
+            lipid_offsets: l.lipid_offsets.as_ptr() as *const u64,
+            marker_idx: l.marker_idx.as_ptr() as *const u64,
+            marker_offsets: l.marker_offsets.as_ptr() as *const u64,
+            masses: l.masses.as_ptr(),
+            ntails,
+            tail_idx: l.tail_idx.as_ptr() as *const u64,
+            tail_offsets: l.tail_offsets.as_ptr() as *const u64,
+            tail_lipid: l.tail_lipid.as_ptr(),
+            tail_bonds: l.tail_bonds.as_ptr(),
+            cutoff: l.cutoff,
+            order_type: l.order_type,
+            max_smooth_iter: l.max_smooth_iter,
+            unwrap: l.unwrap as i32,
+            use_global_normal: l.global_normal.is_some() as i32,
+            global_normal: l.global_normal.unwrap_or([0.0; 3]),
+        };
+        let mut plan = std::ptr::null_mut();
+        engine.plugin.check(unsafe { (engine.plugin.fns.membrane_plan_create)(engine.ctx, &d, &mut plan) })?;
+        Ok(MembraneFrames { engine, plan, nlipids: k, natoms: l.natoms, pending: None })
+    }
+
+    /// `reset_valid_lipids` (lib.rs:269-273) with `None`, or the caller's flags; ends the frame in flight first.
+    pub fn set_valid(&mut self, valid: Option<&[u8]>) -> Result<Option<MembraneFrame>, EngineError> {
+        let last = self.finish()?;
+        if let Some(v) = valid {
+            if v.len() != self.nlipids {
+                return Err(EngineError::Sizes(format!("set_valid: {} flags for {} lipids", v.len(), self.nlipids)));
+            }
+        }
+        let p = valid.map_or(std::ptr::null(), |v| v.as_ptr());
+        self.engine.plugin.check(unsafe { (self.engine.plugin.fns.membrane_plan_set_valid)(self.plan, p) })?;
+        Ok(last)
+    }
+
+    /// Enqueue one frame (coordinates are unwrapped in place) and collect the frame pushed before it.
+    pub fn push(&mut self, coords: &mut [[f32; 3]], box9: &[f32; 9]) -> Result<Option<MembraneFrame>, EngineError> {
+        if coords.len() != self.natoms {
+            return Err(EngineError::Sizes(format!("push: {} atoms, the layout was made for {}", coords.len(), self.natoms)));
+        }
+        let mut t = -1i32;
+        self.engine.plugin.check(unsafe {
+            (self.engine.plugin.fns.membrane_frame_begin)(self.plan, coords.as_mut_ptr() as *mut f32, box9.as_ptr(), &mut t)
+        })?;
+        let last = self.finish()?;
+        self.pending = Some(t);
+        Ok(last)
+    }
+
+    /// Collect the frame in flight, if any.
+    pub fn finish(&mut self) -> Result<Option<MembraneFrame>, EngineError> {
+        let Some(t) = self.pending.take() else { return Ok(None) };
+        let f = &self.engine.plugin.fns;
+        let mut v: MolarHipMembraneView = unsafe { std::mem::zeroed() };
+        self.engine.plugin.check(unsafe { (f.membrane_frame_end)(self.plan, t, &mut v) })?;
+        let k = self.nlipids;
+        let mut r = MembraneFrame {
+            valid: vec![0; k],
+            normals: vec![[0.0; 3]; k],
+            mean_curv: vec![0.0; k],
+            gauss_curv: vec![0.0; k],
+            area: vec![0.0; k],
+            nvert: vec![0; k],
+            neib_ids: vec![0; v.patch_entries + 4 * k],
+            patch_offsets: vec![0; k + 1],
+            order: vec![0.0; v.norder],
+        };
+        let mut o: MolarHipMembraneOut = unsafe { std::mem::zeroed() };
+        o.valid = r.valid.as_mut_ptr();
+        o.normals = r.normals.as_mut_ptr() as *mut f32;
+        o.mean_curv = r.mean_curv.as_mut_ptr();
+        o.gauss_curv = r.gauss_curv.as_mut_ptr();
+        o.area = r.area.as_mut_ptr();
+        o.nvert = r.nvert.as_mut_ptr();
+        o.neib_ids = r.neib_ids.as_mut_ptr();
+        o.patch_offsets = r.patch_offsets.as_mut_ptr();
+        o.order = r.order.as_mut_ptr();
+        self.engine.plugin.check(unsafe { (f.membrane_frame_fetch)(self.plan, t, &o) })?;
+        Ok(Some(r))
+    }
+}
+
+impl Drop for MembraneFrames<'_> {
+    fn drop(&mut self) {
+        unsafe { (self.engine.plugin.fns.membrane_plan_destroy)(self.plan) }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Frame-parallel driver for one node with several GPUs - the Rust side of `AnalysisTask::run_sharded` in
 // include/molar_hip.hpp.  MolAR's `AnalysisTask::run` (analysis_task.rs:202-267) is a serial loop over frames whose
 // body does not depend on earlier frames for the analyses on this path (search, fit/RMSD, Measure); frames therefore

@@ -110,6 +110,90 @@ pub struct MolarHipMembraneState {
     pub fitted_patch_points: *mut f32,
 }
 
+/// `molar_hip_membrane_plan`: opaque handle of the chained bilayer frame call (molar_hip_membrane_frame_*).
+#[repr(C)]
+pub struct MolarHipMembranePlan {
+    _private: [u8; 0],
+}
+
+/// `molar_hip_membrane_desc`: what is constant over a trajectory - index lists (host memory, copied at creation) and the
+/// options of Membrane::compute the chained call covers (molar_membrane/src/lib.rs:53-85, 410-454).
+#[repr(C)]
+pub struct MolarHipMembraneDesc {
+    pub natoms: usize,
+    pub nlipids: usize,
+    pub lipid_idx: *const u64,
+    pub lipid_offsets: *const u64,
+    pub marker_idx: *const u64,
+    pub marker_offsets: *const u64,
+    pub masses: *const f32,
+    pub ntails: usize,
+    pub tail_idx: *const u64,
+    pub tail_offsets: *const u64,
+    pub tail_lipid: *const u32,
+    pub tail_bonds: *const u8,
+    pub cutoff: f32,
+    pub order_type: i32,
+    pub max_smooth_iter: i32,
+    pub unwrap: i32,
+    pub use_global_normal: i32,
+    pub global_normal: [f32; 3],
+}
+
+/// `molar_hip_membrane_view`: device addresses and sizes of one frame's results.
+#[repr(C)]
+pub struct MolarHipMembraneView {
+    pub nlipids: usize,
+    pub patch_entries: usize,
+    pub npairs: usize,
+    pub head: *const f32,
+    pub mid: *const f32,
+    pub tail: *const f32,
+    pub patch_offsets: *const u64,
+    pub patch_ids: *const u64,
+    pub initial_normals: *const f32,
+    pub valid: *const u8,
+    pub smoothed_head: *const f32,
+    pub normals: *const f32,
+    pub quad_coefs: *const f32,
+    pub mean_curv: *const f32,
+    pub gauss_curv: *const f32,
+    pub princ_curvs: *const f32,
+    pub princ_dirs: *const f32,
+    pub area: *const f32,
+    pub nvert: *const u32,
+    pub neib_ids: *const u64,
+    pub voro_vertexes: *const f32,
+    pub fitted_patch_points: *const f32,
+    pub order: *const f32,
+    pub norder: usize,
+}
+
+/// `molar_hip_membrane_out`: host destinations of `molar_hip_membrane_frame_fetch` (null = skip).
+#[repr(C)]
+pub struct MolarHipMembraneOut {
+    pub head: *mut f32,
+    pub mid: *mut f32,
+    pub tail: *mut f32,
+    pub patch_offsets: *mut u64,
+    pub patch_ids: *mut u64,
+    pub initial_normals: *mut f32,
+    pub valid: *mut u8,
+    pub smoothed_head: *mut f32,
+    pub normals: *mut f32,
+    pub quad_coefs: *mut f32,
+    pub mean_curv: *mut f32,
+    pub gauss_curv: *mut f32,
+    pub princ_curvs: *mut f32,
+    pub princ_dirs: *mut f32,
+    pub area: *mut f32,
+    pub nvert: *mut u32,
+    pub neib_ids: *mut u64,
+    pub voro_vertexes: *mut f32,
+    pub fitted_patch_points: *mut f32,
+    pub order: *mut f32,
+}
+
 /// Search kinds (header :124-129) = the four driver families of distance_search.rs.
 pub const SEARCH_SINGLE: i32 = 0;
 pub const SEARCH_DOUBLE: i32 = 1;

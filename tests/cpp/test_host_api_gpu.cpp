@@ -403,12 +403,130 @@ static void sharded_task_tests() {
     EXPECT(threw);
 }
 
+// The chained bilayer frame (MembraneFrames over molar_hip_membrane_frame_*) against the stage-by-stage C calls it
+// replaces: the same kernels in the same order, so every array has to be bit-identical.
+static void membrane_frames_tests() {
+    Engine &eng = Engine::global();
+    // a small bilayer: 2 x (12 x 12) lipids of 8 beads on a jittered lattice, heads out, tails towards the mid-plane
+    const int side = 12, per = 8, K = 2 * side * side;
+    const float L = side * 0.8f, Lz = 9.0f;
+    const size_t natoms = (size_t)K * per;
+    std::vector<float> xyz0(natoms * 3);
+    uint32_t seed = 12345u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+    for (int k = 0; k < K; ++k) {
+        const int leaf = k / (side * side), a = k % (side * side);
+        const float sgn = leaf == 0 ? 1.0f : -1.0f;
+        const float cx = (a % side + 0.5f + 0.3f * rnd()) * 0.8f, cy = (a / side + 0.5f + 0.3f * rnd()) * 0.8f;
+        for (int b = 0; b < per; ++b) {
+            float *p = &xyz0[3 * ((size_t)k * per + b)];
+            p[0] = cx + 0.05f * rnd(); p[1] = cy + 0.05f * rnd();
+            p[2] = Lz / 2 + sgn * (2.0f - 0.25f * b) + 0.03f * rnd();
+            for (int d = 0; d < 2; ++d) p[d] = p[d] - L * std::floor(p[d] / L);      // wrap: edge lipids get split
+        }
+    }
+    const float box9[9] = {L, 0, 0, 0, L, 0, 0, 0, Lz};
+    std::vector<uint64_t> lipid_idx(natoms), lipid_off(K + 1), marker_idx, marker_off{0}, tail_idx, tail_off{0};
+    std::vector<uint32_t> tail_lipid;
+    std::vector<float> masses(natoms);
+    for (size_t i = 0; i < natoms; ++i) { lipid_idx[i] = i; masses[i] = 12.0f + (i % 3); }
+    for (int k = 0; k <= K; ++k) lipid_off[k] = (uint64_t)k * per;
+    for (int k = 0; k < K; ++k) {
+        const uint64_t f = (uint64_t)k * per;
+        for (uint64_t b : {0, 1}) marker_idx.push_back(f + b);
+        marker_off.push_back(marker_idx.size());
+        for (uint64_t b : {2, 3}) marker_idx.push_back(f + b);
+        marker_off.push_back(marker_idx.size());
+        for (uint64_t b : {6, 7}) marker_idx.push_back(f + b);
+        marker_off.push_back(marker_idx.size());
+        for (uint64_t b = 2; b < 8; ++b) tail_idx.push_back(f + b);
+        tail_off.push_back(tail_idx.size());
+        tail_lipid.push_back((uint32_t)k);
+    }
+    std::vector<uint8_t> bonds(tail_idx.size() - K, 1);
+    molar_hip_membrane_desc D{};
+    D.natoms = natoms; D.nlipids = K;
+    D.lipid_idx = lipid_idx.data(); D.lipid_offsets = lipid_off.data(); D.marker_idx = marker_idx.data(); D.marker_offsets = marker_off.data();
+    D.masses = masses.data(); D.ntails = K; D.tail_idx = tail_idx.data(); D.tail_offsets = tail_off.data(); D.tail_lipid = tail_lipid.data();
+    D.tail_bonds = bonds.data(); D.cutoff = 1.6f; D.order_type = 1; D.max_smooth_iter = 1; D.unwrap = 1;
+    MembraneFrames mem(eng, D);
+    const PeriodicBox pbox = PeriodicBox::from_matrix(Matrix3f{{box9[0], box9[1], box9[2], box9[3], box9[4], box9[5], box9[6], box9[7], box9[8]}});
+    std::vector<uint8_t> valid(K, 1);                     // the staged chain keeps its flags on the host
+    const size_t norder = tail_idx.size() - 2 * K;
+    std::vector<uint64_t> noff(K + 1);
+    for (int k = 0; k <= K; ++k) noff[k] = k;
+    for (int frame = 0; frame < 3; ++frame) {
+        std::vector<float> a(xyz0), b(xyz0);
+        for (size_t i = 0; i < a.size(); ++i) { const float j = 0.02f * rnd(); a[i] += j; b[i] += j; }
+        // ---- chained
+        auto none = mem.push(a.data(), pbox);
+        EXPECT(!none.has_value());
+        auto v = mem.finish();
+        EXPECT(v.has_value() && v->nlipids == (size_t)K);
+        const size_t E = v->patch_entries, slots = E + 4 * (size_t)K;
+        std::vector<float> head(K * 3), tail(K * 3), n0(K * 3), nrm(K * 3), area(K), order(norder), fitted(E * 3), voro(slots * 3), sh(K * 3);
+        std::vector<uint64_t> poff(K + 1), pids(E), neib(slots);
+        std::vector<uint8_t> vout(K);
+        std::vector<uint32_t> nvert(K);
+        molar_hip_membrane_out O{};
+        O.head = head.data(); O.tail = tail.data(); O.initial_normals = n0.data(); O.normals = nrm.data(); O.area = area.data();
+        O.order = order.data(); O.fitted_patch_points = fitted.data(); O.voro_vertexes = voro.data(); O.smoothed_head = sh.data();
+        O.patch_offsets = poff.data(); O.patch_ids = pids.data(); O.neib_ids = neib.data(); O.valid = vout.data(); O.nvert = nvert.data();
+        mem.fetch(O);
+        // ---- stage by stage
+        check(molar_hip_unwrap_simple_batch(eng.ctx(), b.data(), natoms, lipid_idx.data(), lipid_off.data(), K, box9, 7));
+        EXPECT(std::memcmp(a.data(), b.data(), a.size() * 4) == 0);
+        std::vector<float> mk(K * 9);
+        check(molar_hip_center_batch(eng.ctx(), b.data(), natoms, marker_idx.data(), marker_off.data(), 3 * K, masses.data(), mk.data()));
+        std::vector<float> h2(K * 3), t2(K * 3);
+        for (int k = 0; k < K; ++k)
+            for (int d = 0; d < 3; ++d) { h2[3 * k + d] = mk[9 * k + d]; t2[3 * k + d] = mk[9 * k + 6 + d]; }
+        EXPECT(std::memcmp(h2.data(), head.data(), h2.size() * 4) == 0 && std::memcmp(t2.data(), tail.data(), t2.size() * 4) == 0);
+        std::vector<uint64_t> vidx;
+        for (int k = 0; k < K; ++k) if (valid[k]) vidx.push_back(k);
+        molar_hip_search_desc q{};
+        q.kind = MOLAR_HIP_SEARCH_SINGLE; q.cutoff = D.cutoff; q.xyz1 = h2.data(); q.natoms1 = K; q.idx1 = vidx.data(); q.n1 = vidx.size();
+        q.ids_local = 0; q.box9 = box9; q.pbc = 7;
+        uint64_t np = 0;
+        check(molar_hip_search_count(eng.ctx(), &q, &np));
+        std::vector<uint32_t> pairs(2 * np + 2);
+        check(molar_hip_search_fill(eng.ctx(), pairs.data(), nullptr));
+        EXPECT(2 * np == E && np == v->npairs);
+        std::vector<uint64_t> poff2(K + 1), pids2(2 * np + 1);
+        check(molar_hip_membrane_patches_from_pairs(pairs.data(), np, K, poff2.data(), pids2.data()));
+        EXPECT(poff2 == poff && std::memcmp(pids2.data(), pids.data(), E * 8) == 0);
+        std::vector<float> n02(K * 3, 0.f);
+        check(molar_hip_membrane_initial_normals(K, h2.data(), t2.data(), poff2.data(), pids2.data(), valid.data(), n02.data()));
+        EXPECT(std::memcmp(n02.data(), n0.data(), n0.size() * 4) == 0);
+        std::vector<float> sh2(h2), nrm2(n02), area2(K, 0.f), fitted2(std::max<size_t>(E, 1) * 3, 0.f), voro2(slots * 3, 0.f);
+        std::vector<uint64_t> neib2(slots, 0);
+        std::vector<uint32_t> nvert2(K, 0);
+        molar_hip_membrane_patches PP{(size_t)K, poff2.data(), pids2.data()};
+        molar_hip_membrane_state S{};
+        S.head_markers = sh2.data(); S.normals = nrm2.data(); S.valid = valid.data(); S.area = area2.data(); S.nvert = nvert2.data();
+        S.neib_ids = neib2.data(); S.voro_vertexes = voro2.data(); S.fitted_patch_points = fitted2.data();
+        check(molar_hip_membrane_smooth(eng.ctx(), &PP, box9, &S));
+        EXPECT(std::memcmp(valid.data(), vout.data(), K) == 0);
+        EXPECT(std::memcmp(sh2.data(), sh.data(), sh.size() * 4) == 0 && std::memcmp(nrm2.data(), nrm.data(), nrm.size() * 4) == 0);
+        EXPECT(std::memcmp(area2.data(), area.data(), K * 4) == 0 && nvert2 == nvert && neib2 == neib);
+        EXPECT(std::memcmp(voro2.data(), voro.data(), voro.size() * 4) == 0 && std::memcmp(fitted2.data(), fitted.data(), E * 12) == 0);
+        std::vector<float> order2(norder);
+        check(molar_hip_lipid_tail_order(eng.ctx(), b.data(), natoms, tail_idx.data(), tail_off.data(), K, 1, nrm2.data(), noff.data(), bonds.data(),
+                                         order2.data()));
+        EXPECT(std::memcmp(order2.data(), order.data(), norder * 4) == 0);
+        size_t nvalid = 0;
+        for (auto f : valid) nvalid += f;
+        EXPECT(nvalid > (size_t)K / 2);
+    }
+}
+
 int main() {
     try {
         search_tests();
         measure_tests();
         task_tests();
         sharded_task_tests();
+        membrane_frames_tests();
     } catch (const std::exception &e) {
         std::printf("exception: %s\n", e.what());
         return 2;

@@ -68,7 +68,9 @@ def test_repr_c_structs_match_the_header():
     for cname, rname in (("molar_hip_box", "MolarHipBox"), ("molar_hip_search_desc", "MolarHipSearchDesc"),
                          ("molar_hip_search_desc_f64", "MolarHipSearchDescF64"),
                          ("molar_hip_membrane_patches", "MolarHipMembranePatches"),
-                         ("molar_hip_membrane_state", "MolarHipMembraneState")):
+                         ("molar_hip_membrane_state", "MolarHipMembraneState"),
+                         ("molar_hip_membrane_desc", "MolarHipMembraneDesc"), ("molar_hip_membrane_view", "MolarHipMembraneView"),
+                         ("molar_hip_membrane_out", "MolarHipMembraneOut")):
         body = re.search(r"typedef\s+struct\s*\{([^{}]*)\}\s*" + cname + r"\s*;", hdr).group(1)
         cfields = []
         for decl in body.split(";"):
@@ -86,9 +88,9 @@ def test_repr_c_structs_match_the_header():
 def test_safe_wrappers_call_existing_entries_with_the_right_arity():
     funcs = {n[len("molar_hip_"):]: len(p) for n, _, p in header_functions()}
     src = open(os.path.join(CRATE, "src", "lib.rs")).read()
-    calls = re.findall(r"\((?:self\.plugin\.fns|f|plugin\.fns|self\.fns)\.(\w+)\)\(", src)
+    calls = re.findall(r"\((?:self\.plugin\.fns|self\.engine\.plugin\.fns|engine\.plugin\.fns|f|plugin\.fns|self\.fns)\.(\w+)\)\(", src)
     assert len(calls) >= 15
-    for m in re.finditer(r"\((?:self\.plugin\.fns|f|plugin\.fns|self\.fns)\.(\w+)\)\(", src):
+    for m in re.finditer(r"\((?:self\.plugin\.fns|self\.engine\.plugin\.fns|engine\.plugin\.fns|f|plugin\.fns|self\.fns)\.(\w+)\)\(", src):
         name = m.group(1)
         assert name in funcs, name
         # argument list up to the matching parenthesis
