@@ -27,7 +27,7 @@ using namespace mh;
 
 struct SmoothDev {
     uint32_t K;
-    const molar_hip_box *box;
+    molar_hip_box box;         // by value: read through the scalar cache, never reloaded behind a store
     const float *saved;        // [K][3] markers before the iteration
     float *head;               // [K][3] in/out
     float *normals;            // [K][3] in/out
@@ -38,8 +38,9 @@ struct SmoothDev {
     uint32_t *nvert;
     uint64_t *neib;            // [E+4K]
     float *voro;               // [E+4K][3]
-    float *fitted;             // [E][3]  (holds the local points while the lane works)
-    float4 *vwork;             // [E+4K]  Voronoi vertices {x, y, next, id}
+    float *fitted;             // [E][3]
+    float4 *vwork;             // [E+4K]  Voronoi vertices {x, y, next, id} of the patches too long for LDS
+    float4 *pwork;             // [E]     local points {x, y, z, id} of those patches
     const uint32_t *rev_off;   // [K+1]   transpose of the patch CSR
     const uint32_t *rev_entry; // [E]     flat patch entry
     const uint32_t *rev_owner; // [E]     lipid owning that entry
@@ -99,34 +100,43 @@ __device__ __forceinline__ float z_surf(float x, float y, const float *c) {   //
     return ((((c[0] * x * x + c[1] * y * y) + c[2] * x * y) + c[3] * x) + c[4] * y) + c[5];
 }
 
-// Voronoi vertex in the lane's HBM slice: {x, y, ccw neighbour, id of the point that made the ccw edge}
+// Voronoi vertex {x, y, ccw neighbour, id of the point that made the ccw edge}.  A lane's vertices sit either in the
+// workgroup's LDS, vertex-major (element v of lane l at [v * 64 + l]: the cell is a linked list walked with dependent
+// loads, ~30 ns a step there against ~500 ns in HBM), or, for patches of more than VORO_LDS - 4 members, in the lane's
+// slice of `vwork` in HBM.  `Verts` hides which: base pointer (generic address space) + element stride.
+constexpr uint32_t VORO_LDS = 64;        // vertices per lane held in LDS (64 lanes x 64 x 16 B = 64 KB per workgroup)
 struct Vert {
     float x, y;
     uint32_t next;
     int32_t id;
 };
-__device__ __forceinline__ Vert vload(const float4 *w, uint32_t i) {
-    const float4 q = w[i];
+struct Verts {
+    float4 *p;
+    uint32_t stride;
+    __device__ __forceinline__ float4 &at(uint32_t i) const { return p[(size_t)i * stride]; }
+};
+__device__ __forceinline__ Vert vload(const Verts &w, uint32_t i) {
+    const float4 q = w.at(i);
     return Vert{q.x, q.y, __float_as_uint(q.z), (int32_t)__float_as_uint(q.w)};
 }
-__device__ __forceinline__ void vstore(float4 *w, uint32_t i, Vert v) {
-    w[i] = make_float4(v.x, v.y, __uint_as_float(v.next), __uint_as_float((uint32_t)v.id));
+__device__ __forceinline__ void vstore(const Verts &w, uint32_t i, Vert v) {
+    w.at(i) = make_float4(v.x, v.y, __uint_as_float(v.next), __uint_as_float((uint32_t)v.id));
 }
-__device__ __forceinline__ float vdist(const float4 *w, uint32_t i, float lx, float ly, float r2) {
-    const float4 q = w[i];
+__device__ __forceinline__ float vdist(const Verts &w, uint32_t i, float lx, float ly, float r2) {
+    const float4 q = w.at(i);
     return (lx * q.x + ly * q.y) - r2;     // line.pos.dot(pos) - r2  (voronoi_cell.rs:83-85)
 }
 
 // VoronoiCell::add_point (voronoi_cell.rs:107-205).  Returns false only where the reference would never
 // return (no vertex on the inner side, e.g. NaN input) - the caller then drops the lipid.
-__device__ bool voro_add_point(float4 *w, uint32_t &nv, uint32_t &init, float px, float py, int32_t id) {
+__device__ bool voro_add_point(const Verts &w, uint32_t &nv, uint32_t &init, float px, float py, int32_t id) {
     const float TOL = 1e-10f;
     const float lx = 0.5f * px, ly = 0.5f * py;
     const float r2 = lx * lx + ly * ly;
     uint32_t cur = init, guard = 0;
     float cur_d = vdist(w, cur, lx, ly, r2);
     while (cur_d >= TOL) {
-        cur = __float_as_uint(w[cur].z);
+        cur = __float_as_uint(w.at(cur).z);
         cur_d = vdist(w, cur, lx, ly, r2);
         if (++guard > nv) return false;
     }
@@ -134,7 +144,7 @@ __device__ bool voro_add_point(float4 *w, uint32_t &nv, uint32_t &init, float px
     uint32_t c1_in, c1_out, c2_in, c2_out;
     float c1_ind, c1_outd, c2_ind, c2_outd;
     for (;;) {
-        const uint32_t nx = __float_as_uint(w[cur].z);
+        const uint32_t nx = __float_as_uint(w.at(cur).z);
         if (nx == init) return true;               // every vertex is inside: nothing to cut
         const float nd = vdist(w, nx, lx, ly, r2);
         if (nd >= TOL) {
@@ -146,7 +156,7 @@ __device__ bool voro_add_point(float4 *w, uint32_t &nv, uint32_t &init, float px
     }
     guard = 0;
     for (;;) {
-        const uint32_t nx = __float_as_uint(w[cur].z);
+        const uint32_t nx = __float_as_uint(w.at(cur).z);
         const float nd = vdist(w, nx, lx, ly, r2);
         if (nd < TOL) {
             c2_out = cur; c2_outd = cur_d; c2_in = nx; c2_ind = nd;
@@ -205,7 +215,20 @@ __device__ void eig2_sym(float a, float b, float c, float *w, float *v) {
     v[2] = x2; v[3] = y2;
 }
 
+// A patch member in the lipid's local frame {x, y, z, id}: in LDS beside the Voronoi vertices (patches of up to PTS_LDS
+// members), else in the lane's slice of `pwork`.
+constexpr uint32_t PTS_LDS = 60;
+constexpr size_t FIT_LDS_BYTES = (size_t)(VORO_LDS + PTS_LDS) * 64 * sizeof(float4);      // 124 KB: one workgroup per compute unit
+struct Pts {
+    float4 *p;
+    uint32_t stride;
+    __device__ __forceinline__ float4 &at(uint32_t i) const { return p[(size_t)i * stride]; }
+};
+
+// One lane per lipid; every loop over the patch is a chain of dependent steps, so what a lane touches more than once
+// (local points, cell vertices) sits in LDS and the gathers of the neighbours' markers are issued four at a time.
 __global__ __launch_bounds__(64) void k_membrane_fit(SmoothDev A) {
+    extern __shared__ float4 fit_lds[];
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= A.K || !A.valid[i]) return;
     const uint64_t p0 = A.poff[i];
@@ -222,34 +245,44 @@ __global__ __launch_bounds__(64) void k_membrane_fit(SmoothDev A) {
     }
     if (!inverse3(to_lab, to_local)) { A.valid[i] = 0; return; }
     const V3 c = v3(A.saved[3 * i], A.saved[3 * i + 1], A.saved[3 * i + 2]);
-    const molar_hip_box &box = *A.box;
-    float *lp = A.fitted + 3 * p0;
+    const molar_hip_box &box = A.box;
+    const bool in_lds = np + 4u <= VORO_LDS && np <= PTS_LDS;
+    const Verts w = in_lds ? Verts{fit_lds + threadIdx.x, 64u} : Verts{A.vwork + slot, 1u};
+    const Pts pt = in_lds ? Pts{fit_lds + VORO_LDS * 64u + threadIdx.x, 64u} : Pts{A.pwork + p0, 1u};
     float m[36], cf[6];
     for (int k = 0; k < 36; ++k) m[k] = 0.0f;
     for (int k = 0; k < 6; ++k) cf[k] = 0.0f;
-    for (uint32_t q = 0; q < np; ++q) {   // local points + normal equations (lib.rs:685-689, 851-860)
-        const uint64_t j = A.pids[p0 + q];
-        const V3 s = v3(A.saved[3 * j], A.saved[3 * j + 1], A.saved[3 * j + 2]);
-        const V3 l = mat_vec(to_local, shortest_vector(box, s - c, MOLAR_HIP_PBC_FULL));
-        lp[3 * q] = l.x; lp[3 * q + 1] = l.y; lp[3 * q + 2] = l.z;
-        const float pw[6] = {l.x * l.x, l.y * l.y, l.x * l.y, l.x, l.y, 1.0f};
+    for (uint32_t q0 = 0; q0 < np; q0 += 4u) {   // local points + normal equations (lib.rs:685-689, 851-860)
+        uint32_t jj[4];
+        V3 ss[4];
 #pragma unroll
-        for (int cc = 0; cc < 6; ++cc)
+        for (uint32_t u = 0; u < 4u; ++u) jj[u] = (uint32_t)A.pids[p0 + (q0 + u < np ? q0 + u : np - 1u)];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) m[cc * 6 + r] += pw[r] * pw[cc];
+        for (uint32_t u = 0; u < 4u; ++u) ss[u] = v3(A.saved[3 * jj[u]], A.saved[3 * jj[u] + 1], A.saved[3 * jj[u] + 2]);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) cf[r] += pw[r] * l.z;
+        for (uint32_t u = 0; u < 4u; ++u) {
+            if (q0 + u >= np) break;
+            const V3 l = mat_vec(to_local, shortest_vector(box, ss[u] - c, MOLAR_HIP_PBC_FULL));
+            pt.at(q0 + u) = make_float4(l.x, l.y, l.z, __uint_as_float(jj[u]));
+            const float pw[6] = {l.x * l.x, l.y * l.y, l.x * l.y, l.x, l.y, 1.0f};
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) m[cc * 6 + r] += pw[r] * pw[cc];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) cf[r] += pw[r] * l.z;
+        }
     }
     if (!cholesky6_solve(m, cf)) { A.valid[i] = 0; return; }
 
-    float4 *w = A.vwork + slot;
     vstore(w, 0, Vert{-10.0f, -10.0f, 1u, -1});     // VoronoiCell::new(-10, 10, -10, 10)  (voronoi_cell.rs:62-80)
     vstore(w, 1, Vert{10.0f, -10.0f, 2u, -2});
     vstore(w, 2, Vert{10.0f, 10.0f, 3u, -3});
     vstore(w, 3, Vert{-10.0f, 10.0f, 0u, -4});
     uint32_t nv = 4, init = 0;
     for (uint32_t q = 0; q < np; ++q) {
-        if (!voro_add_point(w, nv, init, lp[3 * q], lp[3 * q + 1], (int32_t)A.pids[p0 + q])) { A.valid[i] = 0; return; }
+        const float4 r = pt.at(q);
+        if (!voro_add_point(w, nv, init, r.x, r.y, (int32_t)__float_as_uint(r.w))) { A.valid[i] = 0; return; }
     }
     uint32_t n_vert = 0, n_neib = 0;                 // direct neighbours (lib.rs:706-726)
     {
@@ -300,17 +333,41 @@ __global__ __launch_bounds__(64) void k_membrane_fit(SmoothDev A) {
         ar += 0.5f * __builtin_sqrtf(norm2(cross(prev, first)));
         A.area[i] = ar;
     }
-    for (uint32_t q = 0; q < np; ++q) {   // fitted patch points (lib.rs:760-768); overwrites the local point in place
-        const float x = lp[3 * q], y = lp[3 * q + 1], z = lp[3 * q + 2];
-        const V3 t = mat_vec(to_lab, v3(0.0f, 0.0f, z_surf(x, y, cf) - z));
-        const uint64_t j = A.pids[p0 + q];
-        lp[3 * q] = A.saved[3 * j] + t.x;
-        lp[3 * q + 1] = A.saved[3 * j + 1] + t.y;
-        lp[3 * q + 2] = A.saved[3 * j + 2] + t.z;
+    float *fp = A.fitted + 3 * p0;
+    for (uint32_t q0 = 0; q0 < np; q0 += 4u) {   // fitted patch points (lib.rs:760-768)
+        float4 r[4];
+        V3 ss[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) r[u] = pt.at(q0 + u < np ? q0 + u : np - 1u);
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t j = __float_as_uint(r[u].w);
+            ss[u] = v3(A.saved[3 * j], A.saved[3 * j + 1], A.saved[3 * j + 2]);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            if (q0 + u >= np) break;
+            const V3 t = mat_vec(to_lab, v3(0.0f, 0.0f, z_surf(r[u].x, r[u].y, cf) - r[u].z));
+            fp[3 * (q0 + u)] = ss[u].x + t.x;
+            fp[3 * (q0 + u) + 1] = ss[u].y + t.y;
+            fp[3 * (q0 + u) + 2] = ss[u].z + t.z;
+        }
     }
     if (fabsf(cf[5]) > 0.5f) { A.valid[i] = 0; return; }   // fitted surface too far from the marker (lib.rs:774-777)
     const V3 t = mat_vec(to_lab, v3(0.0f, 0.0f, cf[5]));
     A.head[3 * i] += t.x; A.head[3 * i + 1] += t.y; A.head[3 * i + 2] += t.z;
+}
+
+// the fit kernel needs more LDS than a kernel gets by default
+int launch_fit(molar_hip_ctx *c, const SmoothDev &A) {
+    static bool ready[64] = {};          // per device: the attribute belongs to the device's copy of the kernel
+    const int dev = c->device & 63;
+    if (!ready[dev]) {
+        MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_membrane_fit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FIT_LDS_BYTES));
+        ready[dev] = true;
+    }
+    hipLaunchKernelGGL(k_membrane_fit, dim3((A.K + 63u) / 64u), dim3(64), FIT_LDS_BYTES, c->stream, A);
+    return 0;
 }
 
 // lib.rs:781-809.  `fitted_head` holds the markers after k_membrane_fit; the average is written to `head`.
@@ -392,9 +449,9 @@ extern "C" int molar_hip_membrane_smooth(molar_hip_ctx *c, const molar_hip_membr
                  o_fitted = L.take(E * 12);
     const size_t io_bytes = L.size;
     const size_t o_poff = L.take((K + 1) * 8), o_pids = L.take(E * 8), o_roff = L.take((K + 1) * 4), o_rent = L.take(E * 4),
-                 o_rown = L.take(E * 4), o_box = L.take(sizeof box);
+                 o_rown = L.take(E * 4);
     const size_t up_bytes = L.size;
-    const size_t o_saved = L.take(K * 12), o_fh = L.take(K * 12), o_vwork = L.take(slots * 16);
+    const size_t o_saved = L.take(K * 12), o_fh = L.take(K * 12), o_vwork = L.take(slots * 16), o_pwork = L.take(E * 16 + 16);
     MH_TRY(c->m_partials.reserve(L.size));
     MH_TRY(ensure_pinned(c, up_bytes));
     char *h = (char *)c->h_pinned, *d = c->m_partials.as<char>();
@@ -409,25 +466,24 @@ extern "C" int molar_hip_membrane_smooth(molar_hip_ctx *c, const molar_hip_membr
     put(o_fitted, S->fitted_patch_points, E * 12);
     put(o_poff, P->patch_offsets, (K + 1) * 8); put(o_pids, P->patch_ids, E * 8);
     put(o_roff, rev_off.data(), (K + 1) * 4); put(o_rent, rev_entry.data(), E * 4); put(o_rown, rev_owner.data(), E * 4);
-    put(o_box, &box, sizeof box);
     {
         Prof span(c, 4);
         MH_HIP(hipMemcpyAsync(d, h, up_bytes, hipMemcpyHostToDevice, c->stream));
         MH_HIP(hipMemcpyAsync(d + o_saved, d + o_head, K * 12, hipMemcpyDeviceToDevice, c->stream));
         SmoothDev A;
         A.K = (uint32_t)K;
-        A.box = (const molar_hip_box *)(d + o_box);
+        A.box = box;
         A.saved = (const float *)(d + o_saved);
         A.head = (float *)(d + o_head); A.normals = (float *)(d + o_norm); A.valid = (uint8_t *)(d + o_valid);
         A.poff = (const uint64_t *)(d + o_poff); A.pids = (const uint64_t *)(d + o_pids);
         A.coefs = (float *)(d + o_coefs); A.mean = (float *)(d + o_mean); A.gauss = (float *)(d + o_gauss);
         A.pcurv = (float *)(d + o_pcurv); A.pdirs = (float *)(d + o_pdirs); A.area = (float *)(d + o_area);
         A.nvert = (uint32_t *)(d + o_nvert); A.neib = (uint64_t *)(d + o_neib); A.voro = (float *)(d + o_voro);
-        A.fitted = (float *)(d + o_fitted); A.vwork = (float4 *)(d + o_vwork);
+        A.fitted = (float *)(d + o_fitted); A.vwork = (float4 *)(d + o_vwork); A.pwork = (float4 *)(d + o_pwork);
         A.rev_off = (const uint32_t *)(d + o_roff); A.rev_entry = (const uint32_t *)(d + o_rent);
         A.rev_owner = (const uint32_t *)(d + o_rown);
         const uint32_t nb = (uint32_t)((K + 63) / 64);
-        hipLaunchKernelGGL(k_membrane_fit, dim3(nb), dim3(64), 0, c->stream, A);
+        MH_TRY(launch_fit(c, A));
         MH_HIP(hipMemcpyAsync(d + o_fh, d + o_head, K * 12, hipMemcpyDeviceToDevice, c->stream));
         hipLaunchKernelGGL(k_membrane_average, dim3(nb), dim3(64), 0, c->stream, A, (const float *)(d + o_fh));
         MH_HIP(hipGetLastError());
@@ -757,7 +813,7 @@ struct Blob2 {
 struct FrameLayout {       // byte offsets inside a frame slot's device blob, for K lipids and room for Ecap patch entries
     size_t info, box, mk, head, mid, tail, head_search, valid_prev, valid_out, thv, normals0, poff, roff, pids, pids32, owner, rev_entry, rev_owner;
     size_t zero_begin, s_head, s_normals, coefs, pcurv, pdirs, area, nvert, neib, voro, fitted, zero_end, mean, gauss;
-    size_t saved, fh, vwork, tnorm, order, bytes;
+    size_t saved, fh, vwork, pwork, tnorm, order, bytes;
 };
 
 FrameLayout frame_layout(size_t K, size_t Ecap, size_t ntails, size_t norder) {
@@ -778,7 +834,7 @@ FrameLayout frame_layout(size_t K, size_t Ecap, size_t ntails, size_t norder) {
     L.neib = B.take(slots * 8); L.voro = B.take(slots * 12); L.fitted = B.take(Ecap * 12);
     L.zero_end = B.size;
     L.mean = B.take(K * 4); L.gauss = B.take(K * 4);
-    L.saved = B.take(K * 12); L.fh = B.take(K * 12); L.vwork = B.take(slots * 16);
+    L.saved = B.take(K * 12); L.fh = B.take(K * 12); L.vwork = B.take(slots * 16); L.pwork = B.take(Ecap * 16 + 16);
     L.tnorm = B.take(ntails * 12); L.order = B.take(norder * 4 + 16);
     L.bytes = B.size;
     return L;
@@ -791,9 +847,9 @@ FrameLayout frame_layout(size_t K, size_t Ecap, size_t ntails, size_t norder) {
 //   B  marker search, patches, first normals pass          (needs the valid flags the frame before it leaves)
 //   -  second normals pass on the host                     (normals_pass2_host)
 //   C  smoothing, order                                    (leaves the valid flags for the next frame)
-// _begin enqueues A and B; _end waits for B, runs the host pass, enqueues C and waits for it.  With two frames in flight
-// the younger frame's B is on the stream ahead of the older frame's C and keeps the GPU busy during the older frame's
-// host pass; it has then seen the flags of the frame before, and is repeated if C changed them (FrameInfo::changed).
+// _begin enqueues A and B; _end runs the host pass (unless done), enqueues C, and waits for it.  With two frames in
+// flight the younger frame's B is on the stream ahead of the older frame's C, and its host pass runs while the GPU is
+// busy with that C; it has then seen the flags of the frame before, and is repeated if C changed them (FrameInfo::changed).
 struct molar_hip_membrane_plan {
     molar_hip_ctx *c = nullptr;
     size_t K = 0, natoms = 0, ntails = 0, nidx_lipid = 0, nidx_marker = 0, nidx_tail = 0, norder = 0;
@@ -827,6 +883,7 @@ struct molar_hip_membrane_plan {
         hipEvent_t mid = nullptr, done = nullptr;
         bool pending = false, ended = false, b_enqueued = false;
         bool speculative = false;  // B ran on the flags of the frame before the older one, ahead of the older frame's C
+        bool passed = false;       // the host pass is done for the B that is on the stream
         unsigned long long serial = 0;
         ResidentLaunch L;
         unsigned long long cap_pairs = 0;
@@ -981,11 +1038,13 @@ int enqueue_b(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
     if (pair_room) MH_HIP(hipMemcpyAsync(hm + M.pids, pids32, std::min(Ecap, 2 * pair_room) * 4, hipMemcpyDeviceToHost, st));
     MH_HIP(hipEventRecord(S.mid, st));
     S.b_enqueued = true;
+    S.passed = false;
     return 0;
 }
 
-// the host in the middle: wait for B, make sure it fitted (else grow and repeat it), second normals pass
-int host_pass(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
+// the host in the middle: wait for B, make sure it fitted (else grow and repeat it - or, with `may_repeat` off, leave
+// the frame as it is for a later call), second normals pass
+int host_pass(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool may_repeat) {
     molar_hip_ctx *c = P->c;
     for (int attempt = 0;; ++attempt) {
         MH_HIP(hipEventSynchronize(S.mid));
@@ -999,6 +1058,7 @@ int host_pass(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
             fits = false;
         }
         if (fits && !S.info.overflow) break;
+        if (!may_repeat) return 0;
         if (attempt >= 3) return fail(MOLAR_HIP_ERR_HIP, "membrane frame: buffers did not settle");
         MH_TRY(enqueue_b(P, S, /*restore=*/true));
     }
@@ -1007,6 +1067,7 @@ int host_pass(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
     char *hm = (char *)S.h_mid;
     normals_pass2_host(K, (const uint32_t *)(hm + M.roff), (const uint32_t *)(hm + M.pids), (const uint8_t *)(hm + M.valid),
                        (const float *)(hm + M.n1), (float *)(hm + M.n2), P->len_scratch);
+    S.passed = true;
     return 0;
 }
 
@@ -1030,13 +1091,13 @@ int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
                        (const float *)(d + L.head), (const float *)n0, (float *)(d + L.s_head), (float *)(d + L.s_normals));
     SmoothDev A;
     A.K = K32;
-    A.box = (const molar_hip_box *)(d + L.box);
+    MH_TRY(molar_hip_box_from_matrix(S.box9, &A.box));
     A.head = (float *)(d + L.s_head); A.normals = (float *)(d + L.s_normals); A.valid = valid;
     A.poff = (const uint64_t *)(d + L.poff); A.pids = (const uint64_t *)(d + L.pids);
     A.coefs = (float *)(d + L.coefs); A.mean = (float *)(d + L.mean); A.gauss = (float *)(d + L.gauss);
     A.pcurv = (float *)(d + L.pcurv); A.pdirs = (float *)(d + L.pdirs); A.area = (float *)(d + L.area);
     A.nvert = (uint32_t *)(d + L.nvert); A.neib = (uint64_t *)(d + L.neib); A.voro = (float *)(d + L.voro);
-    A.fitted = (float *)(d + L.fitted); A.vwork = (float4 *)(d + L.vwork);
+    A.fitted = (float *)(d + L.fitted); A.vwork = (float4 *)(d + L.vwork); A.pwork = (float4 *)(d + L.pwork);
     A.rev_off = (const uint32_t *)(d + L.roff); A.rev_entry = (const uint32_t *)(d + L.rev_entry);
     A.rev_owner = (const uint32_t *)(d + L.rev_owner);
     const uint32_t nbF = (K32 + 63u) / 64u;
@@ -1047,7 +1108,7 @@ int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
             MH_HIP(hipMemcpyAsync(d + L.saved, d + L.s_head, K * 12, hipMemcpyDeviceToDevice, st));
             A.saved = (const float *)(d + L.saved);
         }
-        hipLaunchKernelGGL(k_membrane_fit, dim3(nbF), dim3(64), 0, st, A);
+        MH_TRY(launch_fit(c, A));
         // (a lane of the averaging kernel reads the fitted marker of its own lipid only, before it overwrites it)
         hipLaunchKernelGGL(k_membrane_average, dim3(nbF), dim3(64), 0, st, A, (const float *)A.head);
     }
@@ -1262,8 +1323,11 @@ extern "C" int molar_hip_membrane_frame_end(molar_hip_membrane_plan *P, int32_t 
     auto &O = P->slot[ticket ^ 1];
     if (O.pending && O.serial < S.serial) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_end: end the older frame (ticket %d) first", ticket ^ 1);
     if (!S.b_enqueued) MH_TRY(enqueue_b(P, S, /*restore=*/false));     // (only after an error left the chain short)
-    MH_TRY(host_pass(P, S));
+    if (!S.passed) MH_TRY(host_pass(P, S, /*may_repeat=*/true));
     MH_TRY(enqueue_c(P, S));
+    // while the GPU smooths this frame: the host pass of the younger one, whose B is already through (it sits ahead of
+    // this C on the stream)
+    if (O.pending && O.b_enqueued && !O.passed) MH_TRY(host_pass(P, O, /*may_repeat=*/false));
     MH_HIP(hipEventSynchronize(S.done));
     std::memcpy(&S.info, (char *)S.h + H_INFO, sizeof(FrameInfo));
     if (O.pending && (!O.b_enqueued || (O.speculative && S.info.changed))) MH_TRY(enqueue_b(P, O, /*restore=*/false));
