@@ -518,12 +518,17 @@ struct FrameInfo {                 // device block of a frame, read back with it
     int changed;                   // the smoothing of this frame dropped a lipid (the valid flags it leaves differ from those it found)
 };
 
-__global__ __launch_bounds__(256) void k_split_markers(uint32_t K, const float *__restrict__ mk, const uint8_t *__restrict__ valid,
-                                                       float *__restrict__ head, float *__restrict__ mid, float *__restrict__ tail,
-                                                       float *__restrict__ head_search) {
+// first kernel of a frame's B part: the valid flags as this frame finds them are remembered (or, on a repeat of B after
+// its buffers were grown, put back), markers split into their arrays, the search input made
+__global__ __launch_bounds__(256) void k_split_markers(uint32_t K, const float *__restrict__ mk, uint8_t *__restrict__ valid,
+                                                       uint8_t *__restrict__ valid_prev, int restore, float *__restrict__ head,
+                                                       float *__restrict__ mid, float *__restrict__ tail, float *__restrict__ head_search) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= K) return;
-    const bool ok = valid[i] != 0;
+    uint8_t v;
+    if (restore) { v = valid_prev[i]; valid[i] = v; }
+    else { v = valid[i]; valid_prev[i] = v; }
+    const bool ok = v != 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float h = mk[9 * i + d];
@@ -811,22 +816,24 @@ struct Blob2 {
 };
 
 struct FrameLayout {       // byte offsets inside a frame slot's device blob, for K lipids and room for Ecap patch entries
-    size_t info, box, mk, head, mid, tail, head_search, valid_prev, valid_out, thv, normals0, poff, roff, pids, pids32, owner, rev_entry, rev_owner;
+    size_t info, roff, normals0, valid_prev, pids32;       // (one block, see frame_layout)
+    size_t mk, head, mid, tail, head_search, valid_out, thv, poff, pids, owner, rev_entry, rev_owner;
     size_t zero_begin, s_head, s_normals, coefs, pcurv, pdirs, area, nvert, neib, voro, fitted, zero_end, mean, gauss;
-    size_t saved, fh, vwork, pwork, tnorm, order, bytes;
+    size_t saved, vwork, pwork, tnorm, order, bytes;
 };
 
 FrameLayout frame_layout(size_t K, size_t Ecap, size_t ntails, size_t norder) {
     FrameLayout L{};
     Blob2 B;
     const size_t slots = Ecap + 4 * K;
+    // [info | roff | normals0 | valid_prev | pids32]: what the host pass of the normals reads, brought over in one copy
     L.info = B.take(sizeof(FrameInfo));
-    L.box = B.take(sizeof(molar_hip_box));
+    L.roff = B.take((K + 1) * 4); L.normals0 = B.take(K * 12); L.valid_prev = B.take(K); L.pids32 = B.take(Ecap * 4);
     L.mk = B.take(K * 36); L.head = B.take(K * 12); L.mid = B.take(K * 12); L.tail = B.take(K * 12); L.head_search = B.take(K * 12);
-    L.valid_prev = B.take(K); L.valid_out = B.take(K);
-    L.thv = B.take(K * 12); L.normals0 = B.take(K * 12);
-    L.poff = B.take((K + 1) * 8); L.roff = B.take((K + 1) * 4);
-    L.pids = B.take(Ecap * 8); L.pids32 = B.take(Ecap * 4); L.owner = B.take(Ecap * 4); L.rev_entry = B.take(Ecap * 4);
+    L.valid_out = B.take(K);
+    L.thv = B.take(K * 12);
+    L.poff = B.take((K + 1) * 8);
+    L.pids = B.take(Ecap * 8); L.owner = B.take(Ecap * 4); L.rev_entry = B.take(Ecap * 4);
     L.rev_owner = B.take(Ecap * 4);
     L.s_head = B.take(K * 12); L.s_normals = B.take(K * 12);
     L.zero_begin = B.size;
@@ -834,7 +841,7 @@ FrameLayout frame_layout(size_t K, size_t Ecap, size_t ntails, size_t norder) {
     L.neib = B.take(slots * 8); L.voro = B.take(slots * 12); L.fitted = B.take(Ecap * 12);
     L.zero_end = B.size;
     L.mean = B.take(K * 4); L.gauss = B.take(K * 4);
-    L.saved = B.take(K * 12); L.fh = B.take(K * 12); L.vwork = B.take(slots * 16); L.pwork = B.take(Ecap * 16 + 16);
+    L.saved = B.take(K * 12); L.vwork = B.take(slots * 16); L.pwork = B.take(Ecap * 16 + 16);
     L.tnorm = B.take(ntails * 12); L.order = B.take(norder * 4 + 16);
     L.bytes = B.size;
     return L;
@@ -877,7 +884,7 @@ struct molar_hip_membrane_plan {
         DevBuf xyz_stage;         // a frame handed over in host memory is staged here
         FrameLayout lay{};
         size_t Ecap = 0;
-        void *h = nullptr;        // pinned: 16 bytes of search sizes | FrameInfo | molar_hip_box
+        void *h = nullptr;        // pinned: 16 bytes of search sizes | FrameInfo at the end of the frame
         void *h_mid = nullptr;    // pinned: what the host pass reads (roff | n1 | valid_prev | pids32) and writes (n2)
         size_t h_mid_cap = 0;
         hipEvent_t mid = nullptr, done = nullptr;
@@ -897,25 +904,19 @@ struct molar_hip_membrane_plan {
 
 namespace {
 
-constexpr size_t H_SIZES = 0, H_INFO = 64, H_BOX = 128, H_BYTES = 128 + ((sizeof(molar_hip_box) + 63) & ~size_t(63));
+constexpr size_t H_SIZES = 0, H_INFO = 64, H_BYTES = 128;
 
-struct MidLayout {
-    size_t roff, n1, valid, pids, n2, bytes;
-};
-MidLayout mid_layout(size_t K, size_t Ecap) {
-    MidLayout M{};
-    Blob2 B;
-    M.roff = B.take((K + 1) * 4); M.n1 = B.take(K * 12); M.valid = B.take(K); M.n2 = B.take(K * 12); M.pids = B.take(Ecap * 4);
-    M.bytes = B.size;
-    return M;
-}
+// the slot's pinned block mirrors the head of the device blob [info .. pids32 + Ecap] at the same offsets; the normals
+// the host pass produces follow
+size_t mid_bytes(const FrameLayout &L, size_t Ecap) { return L.pids32 + Ecap * 4; }
+size_t mid_n2(const FrameLayout &L, size_t Ecap) { return (mid_bytes(L, Ecap) + 255) & ~size_t(255); }
 
 int ensure_capacity(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
     if (S.Ecap == P->Ecap && S.blob.p) return 0;
     S.lay = frame_layout(P->K, P->Ecap, P->ntails, P->norder);
     MH_TRY(S.blob.reserve(S.lay.bytes));
     S.Ecap = P->Ecap;
-    const size_t need = mid_layout(P->K, P->Ecap).bytes;
+    const size_t need = mid_n2(S.lay, P->Ecap) + P->K * 12;
     if (need > S.h_mid_cap) {
         if (S.h_mid) (void)hipHostFree(S.h_mid);
         S.h_mid = nullptr;
@@ -940,8 +941,6 @@ int enqueue_a(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
     hipStream_t st = c->stream;
     molar_hip_box box;
     MH_TRY(molar_hip_box_from_matrix(S.box9, &box));
-    std::memcpy((char *)S.h + H_BOX, &box, sizeof box);
-    MH_HIP(hipMemcpyAsync(d + L.box, (char *)S.h + H_BOX, sizeof box, hipMemcpyHostToDevice, st));
     MH_HIP(hipMemsetAsync(d + L.info, 0, sizeof(FrameInfo), st));
     FrameInfo *info = reinterpret_cast<FrameInfo *>(d + L.info);
     if (P->unwrap) {
@@ -961,22 +960,20 @@ int enqueue_b(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
     const size_t K = P->K;
     const uint32_t K32 = (uint32_t)K;
     if (S.Ecap != P->Ecap) {
-        // the layout changes with the capacity: carry the results of A (markers, box, status) over
+        // the layout changes with the capacity: carry the results of A (markers, status) and the remembered flags over
         const FrameLayout old = S.lay;
         DevBuf keep;
-        MH_TRY(keep.reserve(K * 37 + sizeof(molar_hip_box) + sizeof(FrameInfo)));
+        MH_TRY(keep.reserve(K * 37 + sizeof(FrameInfo)));
         char *k = keep.as<char>(), *d0 = S.blob.as<char>();
         MH_HIP(hipStreamSynchronize(c->stream));
         MH_HIP(hipMemcpy(k, d0 + old.mk, K * 36, hipMemcpyDeviceToDevice));
         MH_HIP(hipMemcpy(k + K * 36, d0 + old.valid_prev, K, hipMemcpyDeviceToDevice));
-        MH_HIP(hipMemcpy(k + K * 37, d0 + old.box, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
-        MH_HIP(hipMemcpy(k + K * 37 + sizeof(molar_hip_box), d0 + old.info, sizeof(FrameInfo), hipMemcpyDeviceToDevice));
+        MH_HIP(hipMemcpy(k + K * 37, d0 + old.info, sizeof(FrameInfo), hipMemcpyDeviceToDevice));
         MH_TRY(ensure_capacity(P, S));
         char *d1 = S.blob.as<char>();
         MH_HIP(hipMemcpy(d1 + S.lay.mk, k, K * 36, hipMemcpyDeviceToDevice));
         MH_HIP(hipMemcpy(d1 + S.lay.valid_prev, k + K * 36, K, hipMemcpyDeviceToDevice));
-        MH_HIP(hipMemcpy(d1 + S.lay.box, k + K * 37, sizeof(molar_hip_box), hipMemcpyDeviceToDevice));
-        MH_HIP(hipMemcpy(d1 + S.lay.info, k + K * 37 + sizeof(molar_hip_box), sizeof(FrameInfo), hipMemcpyDeviceToDevice));
+        MH_HIP(hipMemcpy(d1 + S.lay.info, k + K * 37, sizeof(FrameInfo), hipMemcpyDeviceToDevice));
         keep.release();
     }
     MH_TRY(ensure_work(P));
@@ -985,12 +982,10 @@ int enqueue_b(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
     hipStream_t st = c->stream;
     uint8_t *valid = P->valid.as<uint8_t>();
     FrameInfo *info = reinterpret_cast<FrameInfo *>(d + L.info);
-    if (restore) MH_HIP(hipMemcpyAsync(valid, d + L.valid_prev, K, hipMemcpyDeviceToDevice, st));
-    else MH_HIP(hipMemcpyAsync(d + L.valid_prev, valid, K, hipMemcpyDeviceToDevice, st));
     float *head = (float *)(d + L.head), *tail = (float *)(d + L.tail);
     const uint32_t nbK = (K32 + 255u) / 256u;
-    hipLaunchKernelGGL(k_split_markers, dim3(nbK), dim3(256), 0, st, K32, (const float *)(d + L.mk), valid, head, (float *)(d + L.mid), tail,
-                       (float *)(d + L.head_search));
+    hipLaunchKernelGGL(k_split_markers, dim3(nbK), dim3(256), 0, st, K32, (const float *)(d + L.mk), valid, (uint8_t *)(d + L.valid_prev),
+                       restore ? 1 : 0, head, (float *)(d + L.mid), tail, (float *)(d + L.head_search));
     // ---- compute_patches (lib.rs:539-558)
     molar_hip_search_desc q{};
     q.kind = MOLAR_HIP_SEARCH_SINGLE;
@@ -1028,14 +1023,8 @@ int enqueue_b(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
     hipLaunchKernelGGL(k_tail_head, dim3(nbK), dim3(256), 0, st, K32, head, tail, valid, thv, n0);
     hipLaunchKernelGGL(k_normals_pass1, dim3((K32 + 15u) / 16u), dim3(256), 0, st, K32, valid, poff, pids, thv, n0, P->cos_min);
     MH_HIP(hipGetLastError());
-    // ---- to the host: sizes, offsets, ids, first-pass normals, flags
-    const MidLayout M = mid_layout(K, Ecap);
-    char *hm = (char *)S.h_mid;
-    MH_HIP(hipMemcpyAsync((char *)S.h + H_INFO, info, sizeof(FrameInfo), hipMemcpyDeviceToHost, st));
-    MH_HIP(hipMemcpyAsync(hm + M.roff, roff, (K + 1) * 4, hipMemcpyDeviceToHost, st));
-    MH_HIP(hipMemcpyAsync(hm + M.n1, n0, K * 12, hipMemcpyDeviceToHost, st));
-    MH_HIP(hipMemcpyAsync(hm + M.valid, d + L.valid_prev, K, hipMemcpyDeviceToHost, st));
-    if (pair_room) MH_HIP(hipMemcpyAsync(hm + M.pids, pids32, std::min(Ecap, 2 * pair_room) * 4, hipMemcpyDeviceToHost, st));
+    // ---- to the host, in one copy: status, offsets, first-pass normals, flags, ids
+    MH_HIP(hipMemcpyAsync((char *)S.h_mid + L.info, d + L.info, L.pids32 - L.info + std::min(Ecap, 2 * pair_room) * 4, hipMemcpyDeviceToHost, st));
     MH_HIP(hipEventRecord(S.mid, st));
     S.b_enqueued = true;
     S.passed = false;
@@ -1048,7 +1037,7 @@ int host_pass(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
     molar_hip_ctx *c = P->c;
     for (int attempt = 0;; ++attempt) {
         MH_HIP(hipEventSynchronize(S.mid));
-        std::memcpy(&S.info, (char *)S.h + H_INFO, sizeof(FrameInfo));
+        std::memcpy(&S.info, (char *)S.h_mid + S.lay.info, sizeof(FrameInfo));
         bool fits = true;
         MH_TRY(search_resident_fits(c, (char *)S.h + H_SIZES, S.L, &fits));
         unsigned long long sizes[2];
@@ -1063,10 +1052,10 @@ int host_pass(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
         MH_TRY(enqueue_b(P, S, /*restore=*/true));
     }
     const size_t K = P->K;
-    const MidLayout M = mid_layout(K, S.Ecap);
+    const FrameLayout &L = S.lay;
     char *hm = (char *)S.h_mid;
-    normals_pass2_host(K, (const uint32_t *)(hm + M.roff), (const uint32_t *)(hm + M.pids), (const uint8_t *)(hm + M.valid),
-                       (const float *)(hm + M.n1), (float *)(hm + M.n2), P->len_scratch);
+    normals_pass2_host(K, (const uint32_t *)(hm + L.roff), (const uint32_t *)(hm + L.pids32), (const uint8_t *)(hm + L.valid_prev),
+                       (const float *)(hm + L.normals0), (float *)(hm + mid_n2(L, S.Ecap)), P->len_scratch);
     S.passed = true;
     return 0;
 }
@@ -1081,9 +1070,8 @@ int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
     hipStream_t st = c->stream;
     uint8_t *valid = P->valid.as<uint8_t>();
     FrameInfo *info = reinterpret_cast<FrameInfo *>(d + L.info);
-    const MidLayout M = mid_layout(K, S.Ecap);
     float *n0 = (float *)(d + L.normals0);
-    MH_HIP(hipMemcpyAsync(n0, (char *)S.h_mid + M.n2, K * 12, hipMemcpyHostToDevice, st));
+    MH_HIP(hipMemcpyAsync(n0, (char *)S.h_mid + mid_n2(L, S.Ecap), K * 12, hipMemcpyHostToDevice, st));
     const uint32_t nbK = (K32 + 255u) / 256u;
     // ---- smooth (lib.rs:661-812)
     MH_HIP(hipMemsetAsync(d + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
