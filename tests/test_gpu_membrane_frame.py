@@ -161,6 +161,44 @@ def test_chained_frame_with_ten_thousand_lipids(eng):
     assert np.count_nonzero(got["valid"]) > 10000
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_bilayers_sheared_boxes_pipelined(eng, seed):
+    """Random size, cutoff, order type, iterations, switched-off lipids and a sheared (triclinic) box; three frames with two
+    in flight against the stage-by-stage path."""
+    from molar_amd import membrane as mb
+    rng = np.random.default_rng(1000 + seed)
+    per = int(rng.integers(30, 320))
+    natoms = 2 * per * 52 + int(rng.integers(0, 20000))
+    xyz, box, first, tpl, masses = mb.build_bilayer(per, natoms, seed=int(rng.integers(1 << 30)))
+    shear = np.eye(3, dtype=np.float64)
+    if seed % 2:
+        shear[0, 1], shear[0, 2], shear[1, 2] = rng.uniform(-0.4, 0.4, 3)
+    xyz = (xyz.astype(np.float64) @ shear.T).astype(np.float32)
+    box = (shear @ box.astype(np.float64)).astype(np.float32)
+    opts = dict(cutoff=float(rng.uniform(1.0, 2.8)), order_type=int(rng.integers(0, 3)), max_smooth_iter=int(rng.integers(1, 3)),
+                unwrap=True)
+    if seed % 3 == 0:
+        opts["global_normal"] = (0.0, 0.0, 1.0)
+    fused = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(**opts))
+    staged = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(fused=False, **opts))
+    off = rng.choice(2 * per, size=int(rng.integers(0, 6)), replace=False)
+    for m in (fused, staged):
+        m.valid[off] = 0
+    fr = frames_of(xyz, 3, seed=seed)
+    want = [staged.compute(f.copy(), box) for f in fr]
+    bufs = [f.copy() for f in fr]
+    got = []
+    t_prev = fused.compute_begin(bufs[0], box)
+    for k in range(1, 3):
+        t = fused.compute_begin(bufs[k], box)
+        got.append(fused.compute_end(t_prev))
+        t_prev = t
+    got.append(fused.compute_end(t_prev))
+    for k, (g, w) in enumerate(zip(got, want)):
+        same_result(g, w, f"seed {seed} frame {k}: ")
+    assert np.array_equal(fused.valid, staged.valid)
+
+
 def test_plan_argument_errors(eng):
     from molar_amd import api, membrane as mb
     xyz, box, first, tpl, masses = mb.build_bilayer(20, 3000)
