@@ -10,7 +10,7 @@ already resident in HBM, through the whole hot path:
 Frames shard embarrassingly over ranks (one process per GPU, weak scaling: each rank owns K frames);
 the only collective is the end-of-run reduction of the pair count / RMSD sum (RCCL all_reduce).
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload search_fit|rdf]
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload search_fit|rdf|membrane]
         N>1 from a bare shell: the script re-launches itself as N ranks through torch.distributed.run
         (127.0.0.1 rendezvous); under torch.distributed.run it uses the RANK/LOCAL_RANK/WORLD_SIZE it finds.
         --workload rdf is BASELINE.json configs[3] in the same frame-sharded shape: 250k-atom frames, fused
@@ -245,6 +245,127 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
             raise SystemExit(1)
 
 
+def run_membrane(args, rank, local_rank, world, device, cdev):
+    """BASELINE.json configs[4] shape: each rank owns K frames of the 500k-atom bilayer (4000 lipids, resident in HBM).  A
+    frame is one chained call (molar_hip_membrane_frame_*: unwrap, markers, patches with rc 2.5 nm, initial normals, one
+    smoothing pass, Scd of the 8000 tails), two frames in flight; the per-lipid results (flags, normals, curvatures, areas,
+    vertex counts, order parameters) come to the host every frame and are accumulated there like LipidGroup::frame_update
+    does; ONE all_reduce of the accumulated sums combines the ranks at the end."""
+    import torch
+    import torch.distributed as dist
+    from molar_amd import api, build
+    from molar_amd import membrane as mb
+    from molar_amd.distributed import max_over_ranks, reduce_counts
+    build.build_library()
+    K, W = args.steps, args.warmup
+    xyz, box, first, tpl, masses = mb.build_bilayer(2000, 500_000)
+    nl = len(first)
+    pbox = api.PeriodicBox.from_matrix(box)
+    small = ["valid", "normals", "mean_curv", "gauss_curv", "area", "nvert", "order"]
+
+    def frame_of(r, f):
+        rng = np.random.default_rng(20240607 + 1 + r * 100003 + f)
+        return (xyz + rng.normal(0, 0.02, xyz.shape).astype(np.float32)).astype(np.float32)
+
+    nres = min(K + W, 16)
+    src = [torch.from_numpy(frame_of(rank, f)).to(device) for f in range(nres)]
+
+    def trajectory(eng, frames_dev, count, first_frame=0):
+        """count frames through one plan, two in flight; returns the accumulated sums (float64; integers exactly)."""
+        m = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(cutoff=2.5, order_type=1))
+        plan = m._plan()
+        plan.set_valid(None)
+        norder = plan.norder // nl
+        acc = np.zeros(4 + norder, np.float64)        # valid lipid-frames, vertices, area, |mean curvature|, order per carbon
+
+        def take(t):
+            r = plan.fetch(t, small)
+            ok = r["valid"].astype(bool)
+            acc[0] += int(ok.sum())
+            acc[1] += int(r["nvert"][ok].sum())
+            acc[2] += float(r["area"][ok].sum(dtype=np.float64))
+            acc[3] += float(np.abs(r["mean_curv"][ok]).sum(dtype=np.float64))
+            acc[4:] += r["order"].reshape(nl, norder)[ok].sum(axis=0, dtype=np.float64)
+
+        bufs = [frames_dev[(first_frame + s) % len(frames_dev)].clone() for s in range(count)]     # unwrapped in place: fresh copies
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        prev = None
+        for s in range(count):
+            t = plan.begin(bufs[s], pbox)
+            if prev is not None:
+                plan.end(prev)
+                take(prev)
+            prev = t
+        if prev is not None:
+            plan.end(prev)
+            take(prev)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        plan.close()
+        return acc, dt
+
+    eng = api.Engine(local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        eng.synchronize()
+        torch.cuda.synchronize()
+
+    t_pre = time.perf_counter()
+    while args.preheat > 0 and time.perf_counter() - t_pre < args.preheat:
+        trajectory(eng, src, 16)
+    trajectory(eng, src, max(W, 1))
+    barrier()
+    acc, elapsed = trajectory(eng, src, K, first_frame=W)
+    barrier()
+    # sums over ranks: the integer entries exactly, the float sums in rank order on rank 0
+    from molar_amd.distributed import gather_float64
+    parts = gather_float64(acc, device=cdev)
+    t = max_over_ranks(elapsed, device=cdev)
+    if rank == 0:
+        total = np.sum(np.stack(parts), axis=0)
+        check = None
+        if args.verify:        # rank 0 alone: every rank's frames through a fresh plan, stage by stage instead of chained
+            e2 = api.Engine(local_rank)
+            chk = []
+            for r in range(world):
+                fr = [torch.from_numpy(frame_of(r, f)).to(device) for f in range(nres)]
+                m2 = mb.Membrane(e2, len(xyz), first, tpl, masses, mb.MembraneOptions(cutoff=2.5, order_type=1, fused=False))
+                a2 = np.zeros_like(acc)
+                norder = (len(acc) - 4)
+                for s in range(K):
+                    res = m2.compute(fr[(W + s) % nres].clone(), box)
+                    ok = res["valid"].astype(bool)
+                    a2[0] += int(ok.sum()); a2[1] += int(res["nvert"][ok].sum())
+                    a2[2] += float(res["area"][ok].sum(dtype=np.float64)); a2[3] += float(np.abs(res["mean_curv"][ok]).sum(dtype=np.float64))
+                    a2[4:] += np.concatenate(res["order"], axis=1)[ok].sum(axis=0, dtype=np.float64)
+                chk.append(a2)
+            check = bool(np.array_equal(np.sum(np.stack(chk), axis=0), total))
+        nvalid = total[0]
+        print(json.dumps({
+            "metric": "frames/sec, 500k-atom bilayer (4000 lipids): per-lipid order parameters + neighbour analysis per frame, sums reduced over ranks",
+            "value": K * world / t, "unit": "frames/s", "lipid_frames_per_sec": nl * K * world / t,
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": t / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C5 shape: 500k-atom synthetic bilayer frames resident in HBM, 2 x 2000 lipids of 52 atoms: unwrap, "
+                                   "head / mid / tail markers, patches (rc 2.5 nm), initial normals, one smoothing pass (quadric fit, "
+                                   "Voronoi cell, curvatures, area), Scd of 8000 tails; one chained call per frame, two frames in flight, "
+                                   "per-lipid results fetched and accumulated on the host every frame; frames sharded over ranks, one "
+                                   "gather of the accumulated sums", "natoms": len(xyz), "nlipids": nl, "frames_per_gpu": K},
+            "results": {"valid_lipid_frames": int(nvalid), "mean_vertices": total[1] / max(nvalid, 1), "mean_area_nm2": total[2] / max(nvalid, 1),
+                        "mean_abs_mean_curvature": total[3] / max(nvalid, 1), "mean_abs_scd": float(np.abs(total[4:] / max(nvalid, 1)).mean())},
+            "roofline": None,
+            "roofline_note": "no roofline claim: ~35 latency-bound launches per frame over 4000 lipids (the largest, the per-lipid fit, runs "
+                             "63 waves for 0.11 ms) and a serial host pass of 0.2 ms hidden behind them; profiles/r03_membrane_frame_kernel_stats.csv",
+            "sums_equal_stage_by_stage_single_rank": check,
+        }))
+        if check is False:
+            raise SystemExit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,7 +384,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one search at a time (molar_hip_search_resident) instead of the begin/end form that keeps two "
                          "frames queued on the engine's stream (kernels still run one after the other, in order)")
-    ap.add_argument("--workload", choices=("search_fit", "rdf"), default="search_fit",
+    ap.add_argument("--workload", choices=("search_fit", "rdf", "membrane"), default="search_fit",
                     help="search_fit: the headline (configs[1]+[2]); rdf: configs[3] shape (fused histogram + all_reduce)")
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 recomputes all ranks' frames alone and compares (rdf: the reduced bins; search_fit: every "
@@ -311,8 +432,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    if args.workload == "rdf":
-        run_rdf(args, rank, local_rank, world, device, cdev)
+    if args.workload in ("rdf", "membrane"):
+        (run_rdf if args.workload == "rdf" else run_membrane)(args, rank, local_rank, world, device, cdev)
         if world > 1:
             dist.destroy_process_group()
         return

@@ -62,6 +62,22 @@ def gather_series(local, nframes: int, device=None):
     return full.reshape((nframes,) + local.shape[1:]) if local.ndim > 1 else full.reshape(nframes)
 
 
+def gather_float64(local, device=None):
+    """Every rank's float64 vector (same length on all ranks), as a list in rank order, on every rank.  Floating-point
+    accumulators are combined by the caller in rank order, so the result does not depend on the reduction tree."""
+    import torch
+    dist = _dist()
+    local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [local]
+    t = torch.as_tensor(local)
+    if device is not None:
+        t = t.to(device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [p.cpu().numpy() for p in parts]
+
+
 def max_over_ranks(value: float, device=None) -> float:
     import torch
     dist = _dist()

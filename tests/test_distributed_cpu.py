@@ -45,7 +45,7 @@ def _frame_results(f, n=1500, nbins=60, cutoff=0.6):
 
 def _worker(rank, world, port, nframes, q):
     import torch.distributed as dist
-    from molar_amd.distributed import gather_series, max_over_ranks, reduce_counts
+    from molar_amd.distributed import gather_float64, gather_series, max_over_ranks, reduce_counts
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -62,9 +62,10 @@ def _worker(rank, world, port, nframes, q):
     pairs = int(reduce_counts([pairs])[0])
     full = gather_series(series, nframes)
     tmax = max_over_ranks(float(rank + 1))
+    parts = gather_float64(np.array([rank + 0.25, 1.0 / (rank + 3)]))       # the membrane workload's accumulators travel like this
     dist.barrier()
     if rank == 0:
-        q.put((hist, pairs, full, tmax))
+        q.put((hist, pairs, full, tmax, parts))
     dist.destroy_process_group()
 
 
@@ -78,7 +79,7 @@ def test_two_rank_gloo_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, q)) for r in range(world)]
     for p in procs:
         p.start()
-    hist, pairs, series, tmax = q.get(timeout=240)
+    hist, pairs, series, tmax, parts = q.get(timeout=240)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -94,3 +95,4 @@ def test_two_rank_gloo_matches_single_process():
     assert pairs == ref_pairs
     assert np.array_equal(series, np.array(ref_series))
     assert tmax == 2.0
+    assert len(parts) == world and all(np.array_equal(parts[r], np.array([r + 0.25, 1.0 / (r + 3)])) for r in range(world))
