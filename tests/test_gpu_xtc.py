@@ -90,3 +90,42 @@ def test_c4_shape_xtc_window_to_fused_histogram(eng, orc32):
         want += orc32.histogram_add(0.0, rc, nbins, ref["d"]).astype(np.uint64)
         del ref
     assert want.sum() > 2.5e8 and np.array_equal(got, want)
+
+
+@pytest.mark.timeout(900)
+def test_c5_shape_xtc_window_to_chained_membrane_frames(eng, orc32):
+    """BASELINE.json configs[4] fed the way a trajectory arrives: a window of XTC frames of the 500k-atom bilayer decoded
+    by host threads into HBM, every frame through the chained membrane call with two in flight.  The decode is compared
+    with the CPU checker's, the analysis with the stage-by-stage path on the same decoded coordinates."""
+    import torch
+    from molar_amd import membrane as mb
+    from molar_amd.xtc import XtcReader
+    xyz, box, first, tpl, masses = mb.build_bilayer(2000, 500_000)
+    n, nfr = len(xyz), 3
+    rng = np.random.default_rng(11)
+    frames = [(xyz + rng.normal(0, 0.02, xyz.shape)).astype(np.float32) for _ in range(nfr)]
+    box9 = np.ascontiguousarray(box.T.reshape(-1), np.float32)             # column-major, columns a, b, c
+    blob = b"".join(orc32.xtc_encode(f, box9, step=k, time=float(k)) for k, f in enumerate(frames))
+    r = XtcReader(blob, engine=eng, nthreads=8)
+    dev = torch.empty((nfr, n, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    r.read_frames(0, nfr, out=dev)
+    host = dev.cpu().numpy()
+    offs = orc32.xtc_index(blob)
+    assert np.array_equal(host[1], orc32.xtc_decode(blob, offs[1])[0])     # (XTC rounds to 0.001 nm: not the input bits)
+    fused = mb.Membrane(eng, n, first, tpl, masses, mb.MembraneOptions(cutoff=2.5, order_type=1))
+    staged = mb.Membrane(eng, n, first, tpl, masses, mb.MembraneOptions(cutoff=2.5, order_type=1, fused=False))
+    got = []
+    prev = fused.compute_begin(dev[0], box)
+    for k in range(1, nfr):
+        t = fused.compute_begin(dev[k], box)
+        got.append(fused.compute_end(prev))
+        prev = t
+    got.append(fused.compute_end(prev))
+    for k in range(nfr):
+        want = staged.compute(host[k].copy(), box)
+        for key in ("patch_off", "patch_ids", "valid", "normals", "mean_curv", "gauss_curv", "area", "nvert", "neib_ids", "smoothed_head"):
+            assert np.ascontiguousarray(got[k][key]).tobytes() == np.ascontiguousarray(want[key]).tobytes(), (k, key)
+        for a, b in zip(got[k]["order"], want["order"]):
+            assert a.tobytes() == b.tobytes()
+        assert np.count_nonzero(got[k]["valid"]) > 3900
