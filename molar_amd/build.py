@@ -109,6 +109,9 @@ def _build_locked(verbose: bool) -> str:
     import shutil
     import tempfile
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # the hash that will vouch for this build is the one of the sources as they are NOW: a file edited while the
+    # compilers run must leave a library that needs_build() sends back here
+    source_hash = _source_hash()
     objs = []
     procs = []
     tmp = tempfile.mkdtemp(prefix="molar_hip_build_")      # compiler temporaries (the device ISA is audited below)
@@ -139,7 +142,7 @@ def _build_locked(verbose: bool) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed: {' '.join(cmd)}\n{r.stdout}{r.stderr}")
     with open(HASH_FILE, "w") as f:
-        f.write(_source_hash())
+        f.write(source_hash)
     return LIB
 
 

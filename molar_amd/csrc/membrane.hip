@@ -101,10 +101,10 @@ __device__ __forceinline__ float z_surf(float x, float y, const float *c) {   //
 }
 
 // Voronoi vertex {x, y, ccw neighbour, id of the point that made the ccw edge}.  A lane's vertices sit either in the
-// workgroup's LDS, vertex-major (element v of lane l at [v * 64 + l]: the cell is a linked list walked with dependent
+// workgroup's LDS, vertex-major (element v of lane l at [v * lanes + l]: the cell is a linked list walked with dependent
 // loads, ~30 ns a step there against ~500 ns in HBM), or, for patches of more than VORO_LDS - 4 members, in the lane's
 // slice of `vwork` in HBM.  `Verts` hides which: base pointer (generic address space) + element stride.
-constexpr uint32_t VORO_LDS = 64;        // vertices per lane held in LDS (64 lanes x 64 x 16 B = 64 KB per workgroup)
+constexpr uint32_t VORO_LDS = 64;        // vertices per lane held in LDS (1 KB per lane)
 struct Vert {
     float x, y;
     uint32_t next;
@@ -218,7 +218,7 @@ __device__ void eig2_sym(float a, float b, float c, float *w, float *v) {
 // A patch member in the lipid's local frame {x, y, z, id}: in LDS beside the Voronoi vertices (patches of up to PTS_LDS
 // members), else in the lane's slice of `pwork`.
 constexpr uint32_t PTS_LDS = 60;
-constexpr size_t FIT_LDS_BYTES = (size_t)(VORO_LDS + PTS_LDS) * 64 * sizeof(float4);      // 124 KB: one workgroup per compute unit
+constexpr size_t FIT_LDS_BYTES = (size_t)(VORO_LDS + PTS_LDS) * 64 * sizeof(float4);      // 124 KB for a 64-lane workgroup
 struct Pts {
     float4 *p;
     uint32_t stride;
@@ -229,7 +229,8 @@ struct Pts {
 // (local points, cell vertices) sits in LDS and the gathers of the neighbours' markers are issued four at a time.
 __global__ __launch_bounds__(64) void k_membrane_fit(SmoothDev A) {
     extern __shared__ float4 fit_lds[];
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t lanes = blockDim.x;               // lipids per workgroup (16, 32 or 64: launch_fit)
+    const uint32_t i = blockIdx.x * lanes + threadIdx.x;
     if (i >= A.K || !A.valid[i]) return;
     const uint64_t p0 = A.poff[i];
     const uint32_t np = (uint32_t)(A.poff[i + 1] - p0);
@@ -247,8 +248,8 @@ __global__ __launch_bounds__(64) void k_membrane_fit(SmoothDev A) {
     const V3 c = v3(A.saved[3 * i], A.saved[3 * i + 1], A.saved[3 * i + 2]);
     const molar_hip_box &box = A.box;
     const bool in_lds = np + 4u <= VORO_LDS && np <= PTS_LDS;
-    const Verts w = in_lds ? Verts{fit_lds + threadIdx.x, 64u} : Verts{A.vwork + slot, 1u};
-    const Pts pt = in_lds ? Pts{fit_lds + VORO_LDS * 64u + threadIdx.x, 64u} : Pts{A.pwork + p0, 1u};
+    const Verts w = in_lds ? Verts{fit_lds + threadIdx.x, lanes} : Verts{A.vwork + slot, 1u};
+    const Pts pt = in_lds ? Pts{fit_lds + VORO_LDS * lanes + threadIdx.x, lanes} : Pts{A.pwork + p0, 1u};
     float m[36], cf[6];
     for (int k = 0; k < 36; ++k) m[k] = 0.0f;
     for (int k = 0; k < 6; ++k) cf[k] = 0.0f;
@@ -366,7 +367,12 @@ int launch_fit(molar_hip_ctx *c, const SmoothDev &A) {
         MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_membrane_fit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FIT_LDS_BYTES));
         ready[dev] = true;
     }
-    hipLaunchKernelGGL(k_membrane_fit, dim3((A.K + 63u) / 64u), dim3(64), FIT_LDS_BYTES, c->stream, A);
+    // A wave costs the same whether 16 or 64 of its lanes hold a lipid, and its time is that of its slowest lane: small
+    // bilayers go 16 lipids to a workgroup (4000 lipids: 250 workgroups on 256 compute units instead of 63), large ones fill
+    // the waves
+    const uint32_t cus = (uint32_t)std::max(c->num_cus, 1);
+    const uint32_t lanes = A.K <= 16u * 2u * cus ? 16u : (A.K <= 32u * 2u * cus ? 32u : 64u);
+    hipLaunchKernelGGL(k_membrane_fit, dim3((A.K + lanes - 1u) / lanes), dim3(lanes), FIT_LDS_BYTES / 64u * lanes, c->stream, A);
     return 0;
 }
 
@@ -1131,7 +1137,7 @@ extern "C" int molar_hip_membrane_plan_create(molar_hip_ctx *c, const molar_hip_
     MH_HIP(hipSetDevice(c->device));
     const size_t K = D->nlipids;
     if (K == 0) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: no lipids");
-    if (K >= (1ull << 31)) return fail(MOLAR_HIP_ERR_TOO_LARGE, "membrane_plan_create: lipid ids must fit i32 (voronoi_cell.rs:17)");
+    if (K >= (1ull << 30)) return fail(MOLAR_HIP_ERR_TOO_LARGE, "membrane_plan_create: %zu lipids (ids must fit i32, voronoi_cell.rs:17; three markers each are counted in 32 bits)", K);
     if (!D->lipid_idx || !D->lipid_offsets || !D->marker_idx || !D->marker_offsets || !D->masses)
         return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_plan_create: null index list");
     if (D->ntails && (!D->tail_idx || !D->tail_offsets || !D->tail_lipid))

@@ -155,6 +155,11 @@ inline void unpack3_small(Bits &b, int nbits, uint32_t m, int out[3]) {
     unpack3(b, nbits, s, out);
 }
 
+// Integer coordinates of a corrupt stream can be anything: additions wrap (two's complement) instead of overflowing a
+// signed int - the same values for every well-formed file, defined behaviour for the others (found by UBSan over
+// tests/test_xtc_cpu.py::test_corrupt_streams_do_not_crash, tools/asan_host.sh).
+inline int wrap_add(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+
 int decode_frame(const uint8_t *file, const FrameInfo &fi, float *out) {
     const int natoms = fi.natoms;
     const uint8_t *h = file + fi.offset;
@@ -171,7 +176,8 @@ int decode_frame(const uint8_t *file, const FrameInfo &fi, float *out) {
     if (smallidx < FIRSTIDX || smallidx > LASTIDX) return 2;
     uint32_t sizeint[3];
     int bitsizeint[3] = {0, 0, 0}, bitsize;
-    for (int k = 0; k < 3; ++k) sizeint[k] = (uint32_t)(maxint[k] - minint[k] + 1);
+    for (int k = 0; k < 3; ++k) sizeint[k] = (uint32_t)maxint[k] - (uint32_t)minint[k] + 1u;
+    if (sizeint[0] == 0u || sizeint[1] == 0u || sizeint[2] == 0u) return 2;      // maxint = minint - 1: no well-formed frame has that (and the radix would divide by zero)
     if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffffu) {
         for (int k = 0; k < 3; ++k) bitsizeint[k] = bits_for(sizeint[k]);
         bitsize = 0;
@@ -195,7 +201,7 @@ int decode_frame(const uint8_t *file, const FrameInfo &fi, float *out) {
             unpack3(b, bitsize, sizeint, cur);
         }
         ++i;
-        int px = cur[0] + minint[0], py = cur[1] + minint[1], pz = cur[2] + minint[2];
+        int px = wrap_add(cur[0], minint[0]), py = wrap_add(cur[1], minint[1]), pz = wrap_add(cur[2], minint[2]);
         int is_smaller = 0;
         if (b.get(1)) {
             run = (int)b.get(5);
@@ -209,14 +215,14 @@ int decode_frame(const uint8_t *file, const FrameInfo &fi, float *out) {
             int d[3];
             unpack3_small(b, smallidx, sizesmall, d);
             ++i;
-            int qx = d[0] + px - smallnum, qy = d[1] + py - smallnum, qz = d[2] + pz - smallnum;
+            int qx = wrap_add(px, d[0] - smallnum), qy = wrap_add(py, d[1] - smallnum), qz = wrap_add(pz, d[2] - smallnum);
             o[0] = (float)qx * inv_precision; o[1] = (float)qy * inv_precision; o[2] = (float)qz * inv_precision;
             o[3] = (float)px * inv_precision; o[4] = (float)py * inv_precision; o[5] = (float)pz * inv_precision;
             o += 6;
             for (int k = 3; k < run; k += 3) {
                 unpack3_small(b, smallidx, sizesmall, d);
                 ++i;
-                qx += d[0] - smallnum; qy += d[1] - smallnum; qz += d[2] - smallnum;
+                qx = wrap_add(qx, d[0] - smallnum); qy = wrap_add(qy, d[1] - smallnum); qz = wrap_add(qz, d[2] - smallnum);
                 o[0] = (float)qx * inv_precision; o[1] = (float)qy * inv_precision; o[2] = (float)qz * inv_precision;
                 o += 3;
             }

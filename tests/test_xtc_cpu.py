@@ -171,6 +171,25 @@ def test_corrupt_streams_do_not_crash(reader_cls, orc32):
             outcomes["error"] += 1
         r.close()
     assert outcomes["error"] > 0 and outcomes["ok"] > 0 and outcomes["short"] > 0
+    # a coordinate range of zero size (maxint = minint - 1) would make a radix of the mixed-radix triples zero
+    for k in range(3):
+        b = bytearray(good)
+        lo = int.from_bytes(b[60 + 4 * k: 64 + 4 * k], "big", signed=True)
+        b[72 + 4 * k: 76 + 4 * k] = (lo - 1).to_bytes(4, "big", signed=True)
+        r = reader_cls(bytes(b), nthreads=1)
+        with pytest.raises(MolarHipError):
+            r.read_frames(0, 1)
+        r.close()
+    # extreme ranges: the integer arithmetic of the decoder wraps, it does not overflow (run under UBSan by tools/asan_host.sh)
+    b = bytearray(good)
+    b[60:64] = (2**31 - 5).to_bytes(4, "big", signed=True)
+    b[72:76] = (2**31 - 1).to_bytes(4, "big", signed=True)
+    r = reader_cls(bytes(b), nthreads=1)
+    try:
+        r.read_frames(0, 1)
+    except MolarHipError:
+        pass
+    r.close()
 
 
 def test_xtc_randomised_differential():
