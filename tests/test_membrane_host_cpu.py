@@ -1,0 +1,108 @@
+"""The two host-arithmetic entry points of the membrane path (no GPU needed): patch lists from the marker pairs in push
+order (molar_membrane/src/lib.rs:548-557) and compute_initial_normals (:456-505, second pass in place in lipid order)
+against plain restatements of the reference loops.  Also what tools/asan_host.sh runs under ASan + UBSan."""
+import numpy as np
+import pytest
+
+from molar_amd import api
+from molar_amd._lib import MolarHipError
+
+
+def patches_loop(pairs, K):
+    lists = [[] for _ in range(K)]
+    for i, j in pairs:
+        lists[i].append(j); lists[j].append(i)
+    off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.uint64)
+    return off, np.array([x for l in lists for x in l], np.uint64)
+
+
+def normals_loop(head, tail, lists, valid):
+    """lib.rs:456-505 with every operation rounded to f32; pass 2 reads the normals pass 2 has already written"""
+    f = np.float32
+    K = len(head)
+
+    def norm(v):
+        return f(np.sqrt(f(f(v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])))
+
+    def within(a, b):
+        n1, n2 = norm(a), norm(b)
+        if n1 == 0 or n2 == 0:
+            return True
+        c = f(f(f(a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) / f(n1 * n2))
+        return bool(f(np.arccos(np.clip(c, f(-1), f(1)))) <= f(np.pi / 2))
+    thv = np.zeros((K, 3), f)
+    for i in range(K):
+        if valid[i]:
+            v = (head[i] - tail[i]).astype(f)
+            thv[i] = v / norm(v)
+    nv = np.zeros((K, 3), f)
+    for p in range(2):
+        src = thv if p == 0 else nv
+        for i in range(K):
+            if not valid[i]:
+                continue
+            s = np.zeros(3, f)
+            for l in lists[i]:
+                if within(src[l], src[i]):
+                    s = (s + src[l]).astype(f)
+            s = (s + src[i]).astype(f)
+            nv[i] = s / norm(s)
+    return nv
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_patch_lists_in_push_order(seed):
+    rng = np.random.default_rng(seed)
+    K = int(rng.integers(1, 200))
+    n = int(rng.integers(0, 2000))
+    i = rng.integers(0, K, n); j = rng.integers(0, K, n)
+    pairs = np.stack([i, j], 1).astype(np.uint32)
+    off, ids = api.membrane_patches_from_pairs(pairs, K)
+    woff, wids = patches_loop(pairs.tolist(), K)
+    assert np.array_equal(off, woff) and np.array_equal(ids, wids)
+
+
+def test_patch_lists_refuse_ids_out_of_range():
+    with pytest.raises(MolarHipError):
+        api.membrane_patches_from_pairs(np.array([[0, 7]], np.uint32), 7)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_initial_normals_follow_the_reference_loops(seed):
+    rng = np.random.default_rng(100 + seed)
+    side = int(rng.integers(4, 12))
+    K = side * side
+    g = (np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 2) + rng.normal(0, 0.2, (K, 2))) * 0.8
+    order = rng.permutation(K) if seed % 2 else np.arange(K)            # lattice order: the longest chains through pass 2
+    g = g[order]
+    z = 0.4 * np.sin(g[:, 0]) + rng.normal(0, 0.05, K)
+    head = np.concatenate([g, z[:, None] + 2.0], 1).astype(np.float32)
+    tilt = rng.normal(0, 0.5, (K, 3)); tilt[:, 2] = -1.5
+    if seed == 3:
+        tilt[::5] *= -1.0                                               # some lipids upside down: the 90-degree filter decides
+    tail = (head + tilt).astype(np.float32)
+    d = np.linalg.norm(g[:, None, :] - g[None, :, :], axis=2)
+    ii, jj = np.nonzero(np.triu(d < 1.7, 1))
+    perm = rng.permutation(len(ii))
+    pairs = np.stack([ii[perm], jj[perm]], 1).astype(np.uint32)
+    valid = np.ones(K, np.uint8)
+    valid[rng.choice(K, K // 10, replace=False)] = 0
+    pairs = pairs[valid[pairs[:, 0]].astype(bool) & valid[pairs[:, 1]].astype(bool)]      # patches hold valid lipids only (lib.rs:540-546)
+    off, ids = api.membrane_patches_from_pairs(pairs, K)
+    got = api.membrane_initial_normals(head, tail, off, ids, valid=valid)
+    lists = [ids[int(off[k]): int(off[k + 1])].astype(int).tolist() for k in range(K)]
+    want = normals_loop(head, tail, lists, valid)
+    assert np.allclose(got, want, atol=2e-6)
+    ok = valid.astype(bool)
+    assert np.allclose(np.linalg.norm(got[ok], axis=1), 1.0, atol=1e-5) and not got[~ok].any()
+
+
+def test_initial_normals_at_exactly_ninety_degrees():
+    """angle <= FRAC_PI_2 includes the right angle itself (acos(0) rounds to the f32 pi/2)."""
+    head = np.array([[0, 0, 1], [1, 0, 0]], np.float32)
+    tail = np.zeros((2, 3), np.float32)
+    off = np.array([0, 1, 2], np.uint64); ids = np.array([1, 0], np.uint64)
+    got = api.membrane_initial_normals(head, tail, off, ids)
+    s = np.float32(1) / np.sqrt(np.float32(2))
+    assert np.allclose(got[0], [s, 0, s], atol=1e-6)                    # pass 1: both unit vectors summed, then pass 2 of equal normals
+    assert np.allclose(got[1], [s, 0, s], atol=1e-6)

@@ -23,5 +23,5 @@ $HIPCC --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 cd $R
 export MOLAR_HIP_PLUGIN=$O/libmolar_hip.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
-python -m pytest tests/test_xtc_cpu.py tests/test_abi_cpu.py tests/test_analysis_task_py_cpu.py -x -q -s -p no:cacheprovider > $O/pytest.log 2>&1 || true
+python -m pytest tests/test_xtc_cpu.py tests/test_abi_cpu.py tests/test_analysis_task_py_cpu.py tests/test_membrane_host_cpu.py -x -q -s -p no:cacheprovider > $O/pytest.log 2>&1 || true
 grep -n "runtime error\|AddressSanitizer\|passed\|failed\|Fatal" $O/pytest.log | head -20
