@@ -25,3 +25,9 @@ cd $R
 export MOLAR_HIP_PLUGIN=$O/libmolar_hip.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 python -m pytest tests/test_xtc_cpu.py tests/test_abi_cpu.py tests/test_analysis_task_py_cpu.py tests/test_membrane_host_cpu.py -x -q -s -p no:cacheprovider > $O/pytest.log 2>&1 || true
 grep -n "runtime error\|AddressSanitizer\|passed\|failed\|Fatal" $O/pytest.log | head -20
+# the C++ host mirror (include/molar_hip.hpp: task driver, frame windows, XTC reader) over the same library
+unset LD_PRELOAD
+CXX=/opt/rocm/lib/llvm/bin/clang++
+$CXX -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -shared-libsan -I $R/include $R/tests/cpp/test_analysis_task.cpp \
+  -o $O/test_analysis_task -L $O -lmolar_hip -Wl,-rpath,$O -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,$(dirname $RT)
+ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 $O/test_analysis_task $R/tests/golden/benzene.xtc 2>&1 | tail -3
