@@ -396,6 +396,23 @@ typedef struct {
 int molar_hip_membrane_smooth(molar_hip_ctx *ctx, const molar_hip_membrane_patches *patches, const float *box9,
                               molar_hip_membrane_state *state);
 
+/* patches_from_nth_shell (molar_membrane/src/lib.rs:562-583), host arithmetic: from the Voronoi neighbours a smoothing
+ * pass left (nvert / neib_ids of molar_hip_membrane_state, slotted by patch_offsets), the patch of every valid lipid
+ * becomes its n-th neighbour shell - the direct neighbours widened (n_shells - 2) times by the neighbours of every
+ * member, the lipid itself included from n_shells = 3 on as in the reference; lipids that are not valid keep the patch
+ * they have.  The reference collects a HashSet (order unspecified); here ids ascend.  Count-then-fill: with out_ids ==
+ * NULL (or too small a capacity) only out_offsets[nlipids + 1] and *needed are written. */
+int molar_hip_membrane_nth_shell_patches(size_t nlipids, const uint8_t *valid, const uint64_t *patch_offsets,
+                                         const uint64_t *patch_ids, const uint32_t *nvert, const uint64_t *neib_ids,
+                                         size_t n_shells, uint64_t *out_offsets, uint64_t *out_ids, size_t capacity,
+                                         size_t *needed);
+/* smooth_curvature (lib.rs:584-621), host arithmetic, in place: mean and Gaussian curvature of every valid lipid
+ * averaged with those of the valid members of its n-th neighbour shell (sums in ascending id, f32, from the values
+ * before the call); n_shells == 0 leaves everything as it is. */
+int molar_hip_membrane_smooth_curvature(size_t nlipids, const uint8_t *valid, const uint64_t *patch_offsets,
+                                        const uint32_t *nvert, const uint64_t *neib_ids, size_t n_shells,
+                                        float *mean_curv, float *gauss_curv);
+
 /* One whole frame of Membrane::compute (molar_membrane/src/lib.rs:410-454) as a chain of kernels with no host round
  * trip inside: unwrap of every lipid (lipid_molecule.rs:75-76) -> head / mid / tail-end markers (:65-99) -> PBC search
  * among the valid lipids' head markers and the patch lists in push order (compute_patches, lib.rs:539-558) ->

@@ -155,6 +155,8 @@ SYMBOLS = {
     "molar_hip_membrane_initial_normals": (_I, [_SZ, _P, _P, _P, _P, _P, _P]),
     "molar_hip_membrane_smooth": (_I, [_P, _P, _P, _P]),
     "molar_hip_membrane_patches_from_pairs": (_I, [_P, _SZ, _SZ, _P, _P]),
+    "molar_hip_membrane_nth_shell_patches": (_I, [_SZ, _P, _P, _P, _P, _P, _SZ, _P, _P, _SZ, _P]),
+    "molar_hip_membrane_smooth_curvature": (_I, [_SZ, _P, _P, _P, _P, _SZ, _P, _P]),
     "molar_hip_membrane_plan_create": (_I, [_P, _P, _P]),
     "molar_hip_membrane_plan_destroy": (None, [_P]),
     "molar_hip_membrane_plan_set_valid": (_I, [_P, _P]),

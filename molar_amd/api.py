@@ -1040,6 +1040,34 @@ def membrane_patches_from_pairs(pairs, nlipids):
     return off, ids[: 2 * len(pairs)]
 
 
+def membrane_nth_shell_patches(valid, patch_offsets, patch_ids, nvert, neib_ids, n_shells):
+    """patches_from_nth_shell (molar_membrane/src/lib.rs:562-583): new patch CSR (offsets, ids) - the n-th Voronoi
+    neighbour shell for valid lipids (ids ascending), the old patch for the others.  Host arithmetic of the engine."""
+    lib = _lib.load()
+    v = np.ascontiguousarray(valid, np.uint8); po = np.ascontiguousarray(patch_offsets, np.uint64)
+    pi = np.ascontiguousarray(patch_ids, np.uint64); nv = np.ascontiguousarray(nvert, np.uint32)
+    nb = np.ascontiguousarray(neib_ids, np.uint64)
+    K = len(v)
+    off = np.zeros(K + 1, np.uint64)
+    need = C.c_size_t(0)
+    args = (K, v.ctypes.data, po.ctypes.data, pi.ctypes.data if len(pi) else None, nv.ctypes.data, nb.ctypes.data, int(n_shells))
+    check(lib.molar_hip_membrane_nth_shell_patches(*args, off.ctypes.data, None, 0, C.byref(need)))
+    ids = np.zeros(max(need.value, 1), np.uint64)
+    check(lib.molar_hip_membrane_nth_shell_patches(*args, off.ctypes.data, ids.ctypes.data, need.value, C.byref(need)))
+    return off, ids[: need.value]
+
+
+def membrane_smooth_curvature(valid, patch_offsets, nvert, neib_ids, n_shells, mean_curv, gauss_curv):
+    """smooth_curvature (lib.rs:584-621): returns the smoothed (mean, gaussian) curvature arrays."""
+    lib = _lib.load()
+    v = np.ascontiguousarray(valid, np.uint8); po = np.ascontiguousarray(patch_offsets, np.uint64)
+    nv = np.ascontiguousarray(nvert, np.uint32); nb = np.ascontiguousarray(neib_ids, np.uint64)
+    m = np.array(mean_curv, np.float32, order="C"); g = np.array(gauss_curv, np.float32, order="C")
+    check(lib.molar_hip_membrane_smooth_curvature(len(v), v.ctypes.data, po.ctypes.data, nv.ctypes.data, nb.ctypes.data, int(n_shells),
+                                                  m.ctypes.data, g.ctypes.data))
+    return m, g
+
+
 def membrane_initial_normals(head_markers, tail_markers, patch_offsets, patch_ids, valid=None, normals=None):
     """Membrane::compute_initial_normals (molar_membrane/src/lib.rs:456-505); host arithmetic of the engine."""
     lib = _lib.load()

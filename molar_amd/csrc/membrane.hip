@@ -508,6 +508,106 @@ extern "C" int molar_hip_membrane_smooth(molar_hip_ctx *c, const molar_hip_membr
 }
 
 
+// ================================================================ neighbour shells (host arithmetic)
+//
+// patches_from_nth_shell and smooth_curvature (molar_membrane/src/lib.rs:562-621) walk the Voronoi neighbour graph the
+// smoothing pass left in neib_ids: per valid lipid the set of its direct neighbours, widened (n - 2) times by the
+// neighbours of every member (so from n = 3 on a lipid is a member of its own set - the reference's HashSet picks it up on
+// the way back, and so does this).  The reference iterates a HashSet, whose order is unspecified; here members are in
+// ascending lipid id.  Graph bookkeeping over a few thousand short lists per frame: host loops, like the reference's.
+
+namespace {
+
+// members of lipid i's n-th shell, ascending; `stamp` (K entries, values < 2 * (i + 1) on entry) marks membership
+void nth_shell_of(size_t i, size_t n_shells, const uint64_t *slot_off, const uint32_t *nvert, const uint64_t *neib, size_t K,
+                  std::vector<uint32_t> &stamp, std::vector<uint32_t> &members, std::vector<uint32_t> &frontier) {
+    const uint32_t mark = (uint32_t)i + 1u;
+    members.clear();
+    auto add_neighbours_of = [&](size_t l) {
+        const uint64_t s0 = slot_off[l] + 4ull * l;
+        for (uint32_t k = 0; k < nvert[l]; ++k) {
+            const uint64_t id = neib[s0 + k];
+            if (id < K && stamp[id] != mark) {
+                stamp[id] = mark;
+                members.push_back((uint32_t)id);
+            }
+        }
+    };
+    add_neighbours_of(i);
+    for (size_t round = 2; round < n_shells; ++round) {
+        frontier.assign(members.begin(), members.end());          // `old_neib_list`: the set as it was before this round
+        for (uint32_t l : frontier) add_neighbours_of(l);
+    }
+    std::sort(members.begin(), members.end());
+}
+
+int check_shell_args(size_t K, const uint8_t *valid, const uint64_t *patch_offsets, const uint32_t *nvert, const uint64_t *neib_ids,
+                     const char *what) {
+    if (!valid || !patch_offsets || !nvert || !neib_ids) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "%s: null argument", what);
+    if (K >= (1ull << 31)) return fail(MOLAR_HIP_ERR_TOO_LARGE, "%s: too many lipids", what);
+    for (size_t i = 0; i < K; ++i) {
+        if (patch_offsets[i + 1] < patch_offsets[i]) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "%s: offsets not monotone", what);
+        if (valid[i] && nvert[i] > patch_offsets[i + 1] - patch_offsets[i] + 4u)
+            return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "%s: lipid %zu has more vertices than its slots hold", what, i);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int molar_hip_membrane_nth_shell_patches(size_t K, const uint8_t *valid, const uint64_t *patch_offsets, const uint64_t *patch_ids,
+                                                    const uint32_t *nvert, const uint64_t *neib_ids, size_t n_shells,
+                                                    uint64_t *out_offsets, uint64_t *out_ids, size_t capacity, size_t *needed) {
+    MH_TRY(check_shell_args(K, valid, patch_offsets, nvert, neib_ids, "membrane_nth_shell_patches"));
+    if (!out_offsets || !needed) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_nth_shell_patches: null output");
+    if (n_shells < 1) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_nth_shell_patches: n_shells must be at least 1 (lib.rs:563)");
+    if (patch_offsets[K] && !patch_ids) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_nth_shell_patches: patch_ids missing");
+    std::vector<uint32_t> stamp(K, 0u), members, frontier;
+    size_t total = 0;
+    out_offsets[0] = 0;
+    for (size_t i = 0; i < K; ++i) {
+        if (valid[i]) {
+            // zero-initialised stamps are never equal to a mark (marks are i + 1 >= 1), and marks differ from lipid to lipid
+            nth_shell_of(i, n_shells, patch_offsets, nvert, neib_ids, K, stamp, members, frontier);
+            if (out_ids && total + members.size() <= capacity)
+                for (size_t k = 0; k < members.size(); ++k) out_ids[total + k] = members[k];
+            total += members.size();
+        } else {                                   // not touched by the reference loop: the lipid keeps the patch it has
+            const size_t n = (size_t)(patch_offsets[i + 1] - patch_offsets[i]);
+            if (out_ids && total + n <= capacity)
+                for (size_t k = 0; k < n; ++k) out_ids[total + k] = patch_ids[patch_offsets[i] + k];
+            total += n;
+        }
+        out_offsets[i + 1] = total;
+    }
+    *needed = total;
+    return MOLAR_HIP_OK;
+}
+
+extern "C" int molar_hip_membrane_smooth_curvature(size_t K, const uint8_t *valid, const uint64_t *patch_offsets, const uint32_t *nvert,
+                                                   const uint64_t *neib_ids, size_t n_shells, float *mean_curv, float *gauss_curv) {
+    MH_TRY(check_shell_args(K, valid, patch_offsets, nvert, neib_ids, "membrane_smooth_curvature"));
+    if (!mean_curv || !gauss_curv) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_smooth_curvature: null argument");
+    if (n_shells < 1) return MOLAR_HIP_OK;                         // lib.rs:585-587
+    const std::vector<float> mean(mean_curv, mean_curv + K), gauss(gauss_curv, gauss_curv + K);      // the values before smoothing (:589-590)
+    std::vector<uint32_t> stamp(K, 0u), members, frontier;
+    for (size_t i = 0; i < K; ++i) {
+        if (!valid[i]) continue;
+        nth_shell_of(i, n_shells, patch_offsets, nvert, neib_ids, K, stamp, members, frontier);
+        float m = 0.0f, g = 0.0f;
+        uint32_t n_valid = 0;
+        for (uint32_t id : members) {
+            if (!valid[id]) continue;
+            m += mean[id];
+            g += gauss[id];
+            ++n_valid;
+        }
+        mean_curv[i] = (mean[i] + m) / (float)(n_valid + 1u);
+        gauss_curv[i] = (gauss[i] + g) / (float)(n_valid + 1u);
+    }
+    return MOLAR_HIP_OK;
+}
+
 // ================================================================ one whole frame of Membrane::compute on the stream
 //
 // Everything between the coordinates of a frame and its per-lipid results, enqueued without a host wait: the number of

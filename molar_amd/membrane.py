@@ -11,7 +11,8 @@
 All per-lipid loops are batched: one launch per stage for all lipids of a frame.  The reference computes the
 markers once in Membrane::new and its per-frame refresh is commented out (lipid_molecule.rs:65-99); this class
 refreshes them every frame, which is what the commented code does.  Where the reference iterates a HashSet
-(n-th shell patches, curvature averaging) the order is unspecified there; here it is ascending lipid id.
+(n-th shell patches, curvature averaging: molar_hip_membrane_nth_shell_patches / _smooth_curvature, host arithmetic of the
+engine) the order is unspecified there; here it is ascending lipid id.
 Group statistics and their text output (stats.rs, lipid_group.rs) are host bookkeeping: membrane_stats.py.
 """
 from __future__ import annotations
@@ -165,28 +166,6 @@ class Membrane:
         return (np.concatenate([[0], np.cumsum(np.bincount(src, minlength=K))]).astype(np.uint64),
                 dst[order].astype(np.uint64))
 
-    def _neighbour_matrix(self, st, patch_off):
-        """Voronoi neighbours of the valid lipids as a K x K boolean CSR matrix."""
-        from scipy import sparse
-        K = self.K
-        ok = st["valid"].astype(bool)
-        cnt = np.where(ok, st["nvert"], 0).astype(np.int64)
-        slot0 = patch_off[:-1].astype(np.int64) + 4 * np.arange(K)
-        indptr = np.concatenate([[0], np.cumsum(cnt)])
-        pos = np.arange(indptr[-1]) - np.repeat(indptr[:-1], cnt) + np.repeat(slot0, cnt)
-        cols = st["neib_ids"][pos].astype(np.int64)
-        return sparse.csr_matrix((np.ones(len(cols), np.int32), cols, indptr), shape=(K, K))
-
-    @staticmethod
-    def _nth_shell(A, n):
-        """lib.rs:572-578 / 597-603: start from the direct neighbours, extend (n-2) times."""
-        R = A.copy()
-        for _ in range(2, n):
-            R = R + R @ A
-            R.data[:] = 1
-        R.sum_duplicates(); R.sort_indices()
-        return R
-
     def _constants(self, xyz):
         """The per-trajectory index / mass columns: with frames resident on the GPU they are uploaded once and stay
         there (the C ABI takes device pointers); with host frames they are the numpy arrays."""
@@ -276,16 +255,9 @@ class Membrane:
         while True:                                                             # lib.rs:417-432 (at least one pass)
             if opt.n_shells_patch > 0 and it == 0:
                 e.membrane_smooth(pb, st, patch_off, patch_ids)
-                R = self._nth_shell(self._neighbour_matrix(st, patch_off), opt.n_shells_patch)
-                ok = st["valid"].astype(bool)
-                keep_off, keep_ids = patch_off, patch_ids                       # invalid lipids keep their patch
-                cnt = np.where(ok, np.diff(R.indptr), np.diff(keep_off.astype(np.int64)))
-                new_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
-                new_ids = np.empty(int(new_off[-1]), np.uint64)
-                for k in range(K):                                              # host bookkeeping, once per frame
-                    a, b = int(new_off[k]), int(new_off[k + 1])
-                    new_ids[a:b] = R.indices[R.indptr[k]:R.indptr[k + 1]] if ok[k] else keep_ids[int(keep_off[k]):int(keep_off[k + 1])]
-                patch_off, patch_ids = new_off, new_ids
+                # patches_from_nth_shell (lib.rs:562-583); the slots of neib_ids follow the patch lists they were made with
+                patch_off, patch_ids = api.membrane_nth_shell_patches(st["valid"], patch_off, patch_ids, st["nvert"], st["neib_ids"],
+                                                                      opt.n_shells_patch)
             e.membrane_smooth(pb, st, patch_off, patch_ids)
             it += 1
             if it >= opt.max_smooth_iter:
@@ -302,14 +274,8 @@ class Membrane:
         for l in self.tail_lens:
             out.append(flat[:, pos:pos + l - 2].copy()); pos += l - 2
         if opt.n_shells_smoothing > 0:              # smooth_curvature (lib.rs:584-621)
-            R = self._nth_shell(self._neighbour_matrix(st, patch_off), opt.n_shells_smoothing)
-            ok = st["valid"].astype(np.float32)
-            Rv = R.multiply(ok[None, :]).tocsr()
-            nval = np.asarray(Rv.sum(1)).reshape(-1).astype(np.float32)
-            for key in ("mean_curv", "gauss_curv"):
-                v = st[key].copy()
-                sm = (v + Rv @ v) / (nval + 1.0)
-                st[key] = np.where(ok > 0, sm, v).astype(np.float32)
+            st["mean_curv"], st["gauss_curv"] = api.membrane_smooth_curvature(st["valid"], patch_off, st["nvert"], st["neib_ids"],
+                                                                              opt.n_shells_smoothing, st["mean_curv"], st["gauss_curv"])
         res = dict(head=head, mid=mid, tail=tail, patch_off=patch_off, patch_ids=patch_ids, normals=st["normals"],
                    initial_normals=normals, order=out, valid=st["valid"].copy(), smoothed_head=st["head_markers"])
         for k in ("quad_coefs", "mean_curv", "gauss_curv", "princ_curvs", "princ_dirs", "area", "nvert", "neib_ids",

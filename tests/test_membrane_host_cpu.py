@@ -106,3 +106,81 @@ def test_initial_normals_at_exactly_ninety_degrees():
     s = np.float32(1) / np.sqrt(np.float32(2))
     assert np.allclose(got[0], [s, 0, s], atol=1e-6)                    # pass 1: both unit vectors summed, then pass 2 of equal normals
     assert np.allclose(got[1], [s, 0, s], atol=1e-6)
+
+
+def random_neighbour_state(rng, K):
+    """A Voronoi-like neighbour graph in the slotted layout of molar_hip_membrane_state: lipid i owns slots
+    [patch_off[i] + 4 i, ...) of neib_ids and fills the first nvert[i]."""
+    plen = rng.integers(0, 9, K)
+    patch_off = np.concatenate([[0], np.cumsum(plen)]).astype(np.uint64)
+    patch_ids = rng.integers(0, K, int(patch_off[-1])).astype(np.uint64)
+    valid = (rng.random(K) < 0.85).astype(np.uint8)
+    nvert = np.zeros(K, np.uint32)
+    neib = np.zeros(int(patch_off[-1]) + 4 * K, np.uint64)
+    lists = []
+    for i in range(K):
+        room = int(plen[i]) + 4
+        n = int(rng.integers(0, room + 1)) if (valid[i] or rng.random() < 0.5) else 0        # lipids dropped late keep their neighbours
+        ids = rng.choice(K, size=min(n, K), replace=False)
+        nvert[i] = len(ids)
+        s0 = int(patch_off[i]) + 4 * i
+        neib[s0:s0 + len(ids)] = ids
+        lists.append([int(x) for x in ids])
+    return valid, patch_off, patch_ids, nvert, neib, lists
+
+
+def shell_of(i, lists, n):
+    """lib.rs:572-578: a set of the direct neighbours, extended (n - 2) times by the neighbours of its members"""
+    s = set(lists[i])
+    for _ in range(2, n):
+        for m in list(s):
+            s.update(lists[m])
+    return sorted(s)
+
+
+@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("n_shells", [1, 2, 3, 4])
+def test_nth_shell_patches(seed, n_shells):
+    rng = np.random.default_rng(300 + seed)
+    K = int(rng.integers(1, 120))
+    valid, patch_off, patch_ids, nvert, neib, lists = random_neighbour_state(rng, K)
+    off, ids = api.membrane_nth_shell_patches(valid, patch_off, patch_ids, nvert, neib, n_shells)
+    for i in range(K):
+        got = ids[int(off[i]): int(off[i + 1])].astype(int).tolist()
+        want = shell_of(i, lists, n_shells) if valid[i] else patch_ids[int(patch_off[i]): int(patch_off[i + 1])].astype(int).tolist()
+        assert got == want, (i, n_shells)
+    if n_shells >= 3:       # a lipid with a neighbour that points back is a member of its own shell, as in the reference
+        back = [i for i in range(K) if valid[i] and any(i in lists[m] for m in lists[i])]
+        assert all(i in ids[int(off[i]): int(off[i + 1])] for i in back)
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_smooth_curvature(seed):
+    rng = np.random.default_rng(400 + seed)
+    K = int(rng.integers(2, 150))
+    valid, patch_off, patch_ids, nvert, neib, lists = random_neighbour_state(rng, K)
+    mean = rng.normal(0, 0.3, K).astype(np.float32); gauss = rng.normal(0, 0.1, K).astype(np.float32)
+    for n in (1, 2, 3):
+        gm, gg = api.membrane_smooth_curvature(valid, patch_off, nvert, neib, n, mean, gauss)
+        f = np.float32
+        for i in range(K):
+            if not valid[i]:
+                assert gm[i] == mean[i] and gg[i] == gauss[i]
+                continue
+            m = g = f(0)
+            nv = 0
+            for l in shell_of(i, lists, n):
+                if valid[l]:
+                    m = f(m + mean[l]); g = f(g + gauss[l]); nv += 1
+            assert gm[i] == f(f(mean[i] + m) / f(nv + 1)) and gg[i] == f(f(gauss[i] + g) / f(nv + 1))
+    gm, gg = api.membrane_smooth_curvature(valid, patch_off, nvert, neib, 0, mean, gauss)
+    assert np.array_equal(gm, mean) and np.array_equal(gg, gauss)
+
+
+def test_shell_argument_errors():
+    v = np.ones(2, np.uint8); po = np.array([0, 1, 2], np.uint64); pi = np.array([1, 0], np.uint64)
+    nv = np.array([9, 1], np.uint32); nb = np.zeros(10, np.uint64)
+    with pytest.raises(MolarHipError):
+        api.membrane_nth_shell_patches(v, po, pi, nv, nb, 2)              # more vertices than the lipid's slots hold
+    with pytest.raises(MolarHipError):
+        api.membrane_nth_shell_patches(v, po, pi, np.array([1, 1], np.uint32), nb, 0)       # n_shells < 1
