@@ -51,6 +51,7 @@ def make_frames(nframes, rank, box, device):
         jit = torch.randn((NATOMS, 3), generator=g, device=device, dtype=torch.float32) * 0.05
         frames[f] = (base + jit.double()).float()
     ref = base.float().contiguous()
+    torch.cuda.synchronize()      # made on torch's stream; the engine reads them on its own
     return frames, ref
 
 
@@ -173,6 +174,7 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
         frames[f] = (base + (torch.randn((n, 3), generator=g, device=device, dtype=torch.float32) * 0.05).double()).float()
     eng = api.Engine(local_rank)
     bins = torch.zeros(nbins, dtype=torch.int64, device=device)
+    torch.cuda.synchronize()      # frames and bins were made on torch's stream; the engine works on its own
 
     def run(first, count):
         for s in range(count):
@@ -209,6 +211,7 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
                     f = (W + s) % nres
                     g.manual_seed(20240607 + 1 + r * 100003 + f)
                     fr = (base + (torch.randn((n, 3), generator=g, device=device, dtype=torch.float32) * 0.05).double()).float()
+                    torch.cuda.synchronize()       # torch made `fr` (and zeroed `chk`) on ITS stream; the engine reads on its own
                     e2.search_histogram(api.SEARCH_SINGLE, CUTOFF, 0.0, CUTOFF, nbins, fr, box=box, pbc=7, bins=chk, want_count=False)
                     e2.synchronize()
             check = bool(np.array_equal(chk.cpu().numpy(), total_bins))
@@ -337,7 +340,9 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
                 a2 = np.zeros_like(acc)
                 norder = (len(acc) - 4)
                 for s in range(K):
-                    res = m2.compute(fr[(W + s) % nres].clone(), box)
+                    work = fr[(W + s) % nres].clone()
+                    torch.cuda.synchronize()       # the copy runs on torch's stream, the engine on its own
+                    res = m2.compute(work, box)
                     ok = res["valid"].astype(bool)
                     a2[0] += int(ok.sum()); a2[1] += int(res["nvert"][ok].sum())
                     a2[2] += float(res["area"][ok].sum(dtype=np.float64)); a2[3] += float(np.abs(res["mean_curv"][ok]).sum(dtype=np.float64))
@@ -638,6 +643,7 @@ def main():
                 fr_r, _ = (frames, None) if r == rank else make_frames(nres, r, box, device)
                 for s_ in range(K):
                     fr = fr_r[(W + s_) % nres].clone()
+                    torch.cuda.synchronize()       # the copy runs on torch's stream, the engine on its own
                     cnt, _, _ = e2.search_resident(api.SEARCH_SINGLE, CUTOFF, fr, box=box, pbc=7)
                     out = e2.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
                     ok = int(cnt) == int(tab[r, s_]) and abs(float(out["rmsd"][0]) * 1e9 - float(rtab[r, s_])) <= 1e-6 * abs(float(rtab[r, s_])) + 2.0

@@ -170,7 +170,12 @@ class PeriodicBox:
 
 
 class Engine:
-    """One molar_hip_ctx: a GPU, a stream and reusable device buffers."""
+    """One molar_hip_ctx: a GPU, a stream and reusable device buffers.
+
+    The context runs on a stream of its own unless `stream` is given (e.g. `torch.cuda.current_stream().cuda_stream`).
+    Device tensors handed to it are read where they are, on THAT stream: a tensor another stream is still producing (a
+    `.clone()`, a `torch.randn(...)` enqueued a moment ago) has to be complete first - `torch.cuda.synchronize()`, or one
+    shared stream."""
 
     def __init__(self, device: int = 0, stream=None):
         self.lib = _lib.load()

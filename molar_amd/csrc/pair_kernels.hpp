@@ -87,7 +87,8 @@ struct SearchParams {
     float band_lo, band_hi;  // band around cutoff^2 inside which the exact formula decides
     uint32_t hist_nbins;     // != 0: the fill traversal feeds a histogram instead of writing pairs
     float hist_min, hist_max;
-    unsigned long long *hist_bins;    // [nbins] + [1] total
+    unsigned long long *hist_bins;    // [nbins]
+    unsigned long long *hist_total;   // number of distances binned or out of range (NULL: not wanted)
     const float *hist_edges; // f32[nbins + 1], see histogram_edges() in search.hip; NULL: hist_kernel evaluates the formula per hit
     float hist_scale;        // nbins / (max - min), for the first guess of the bin
     uint32_t hist_lean;      // histogram mode: hist_kernel takes the slots hist_lean_slot() accepts, pair_kernel<MODE_HIST> the rest
@@ -1513,7 +1514,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
             const uint32_t v = lds_hist[b];
             if (v) atomicAdd(&P.hist_bins[b], (unsigned long long)v);
         }
-        if (lane == 0 && wave_total) atomicAdd(&P.hist_bins[P.hist_nbins], wave_total);
+        if (lane == 0 && wave_total && P.hist_total) atomicAdd(P.hist_total, wave_total);
     }
 }
 
@@ -1865,7 +1866,7 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         const uint32_t v = lds_hist[b];
         if (v) atomicAdd(&P.hist_bins[b], (unsigned long long)v);
     }
-    if (lane == 0 && wave_total) atomicAdd(&P.hist_bins[P.hist_nbins], wave_total);
+    if (lane == 0 && wave_total && P.hist_total) atomicAdd(P.hist_total, wave_total);
 }
 
 template <int KIND>

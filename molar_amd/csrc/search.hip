@@ -725,6 +725,7 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.hist_nbins = 0u;
     P.hist_min = P.hist_max = 0.f;
     P.hist_bins = nullptr;
+    P.hist_total = nullptr;
     // zero pattern shared by the matrix and its inverse -> which products a wrapped pair may skip
     P.wrap_kind = 3u;   // WK_GENERAL
     if (c->use_box) {
@@ -812,7 +813,7 @@ SearchParams make_params(molar_hip_ctx *c) {
 template <bool FILL>
 int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uint32_t hist_nbins = 0, float hmin = 0.f,
                  float hmax = 0.f, unsigned long long *hist_bins = nullptr, unsigned long long out_cap = ~0ull,
-                 bool params_resident = false) {
+                 bool params_resident = false, unsigned long long *hist_total = nullptr) {
     Prof prof(c, FILL ? 3 : 1);
     SearchParams P = make_params(c);
     if (P.nblocks == 0) return 0;
@@ -821,6 +822,7 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     P.hist_min = hmin;
     P.hist_max = hmax;
     P.hist_bins = hist_bins;
+    P.hist_total = hist_total;
     size_t dyn_lds = 0;
     P.hist_lean = 0u;
     P.hist_edges = nullptr;
@@ -1513,23 +1515,32 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
     if (c->have_search) return MOLAR_HIP_OK;     // degenerate (empty vdw input)
     // single pass: no counts, no offsets - every emitted distance goes straight into the histogram
     MH_TRY(ensure_hist_edges(c, hmin, hmax, nbins));
+    static const bool scratch_always = std::getenv("MOLAR_HIP_HIST_SCRATCH") != nullptr;      // A/B knob
+    if (async && !scratch_always) {
+        // bins in device memory and no count wanted: the kernels add straight into the caller's bins (integer atomics:
+        // the same sums) - no scratch histogram to zero before and to add after, two launches less per frame
+        MH_TRY(launch_pairs<true>(c, nullptr, nullptr, nullptr, (uint32_t)nbins, hmin, hmax, reinterpret_cast<unsigned long long *>(bins)));
+        if (!c->gen_free[gen]) MH_HIP(hipEventCreateWithFlags(&c->gen_free[gen], hipEventDisableTiming));
+        MH_HIP(hipEventRecord(c->gen_free[gen], c->stream));
+        return MOLAR_HIP_OK;
+    }
     MH_TRY(c->hist.reserve((nbins + 1) * 8));
     hipLaunchKernelGGL(zero2_kernel, dim3(1), dim3(256), 0, c->stream, c->hist.as<uint32_t>(), (nbins + 1) * 2, (uint32_t *)nullptr,
                        (size_t)0);
-    MH_TRY(launch_pairs<true>(c, nullptr, nullptr, nullptr, (uint32_t)nbins, hmin, hmax, c->hist.as<unsigned long long>()));
+    MH_TRY(launch_pairs<true>(c, nullptr, nullptr, nullptr, (uint32_t)nbins, hmin, hmax, c->hist.as<unsigned long long>(), ~0ull, false,
+                              c->hist.as<unsigned long long>() + nbins));
     if (is_device_ptr(bins)) {
-        // device-resident accumulator: added on the GPU; without out_count the call does not wait for the kernels
         hipLaunchKernelGGL(add_u64_kernel, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, c->stream,
                            reinterpret_cast<unsigned long long *>(bins), c->hist.as<unsigned long long>(), nbins);
         MH_HIP(hipGetLastError());
-        if (async) {
-            if (!c->gen_free[gen]) MH_HIP(hipEventCreateWithFlags(&c->gen_free[gen], hipEventDisableTiming));
-            MH_HIP(hipEventRecord(c->gen_free[gen], c->stream));
-        }
         if (out_count) {
             unsigned long long tot = 0;
             MH_TRY(read_back(c, &tot, c->hist.as<unsigned long long>() + nbins, 8));
             *out_count = tot;
+        }
+        if (async) {
+            if (!c->gen_free[gen]) MH_HIP(hipEventCreateWithFlags(&c->gen_free[gen], hipEventDisableTiming));
+            MH_HIP(hipEventRecord(c->gen_free[gen], c->stream));
         }
         return MOLAR_HIP_OK;
     }
