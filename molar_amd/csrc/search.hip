@@ -1515,8 +1515,7 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
     if (c->have_search) return MOLAR_HIP_OK;     // degenerate (empty vdw input)
     // single pass: no counts, no offsets - every emitted distance goes straight into the histogram
     MH_TRY(ensure_hist_edges(c, hmin, hmax, nbins));
-    static const bool scratch_always = std::getenv("MOLAR_HIP_HIST_SCRATCH") != nullptr;      // A/B knob
-    if (async && !scratch_always) {
+    if (async) {
         // bins in device memory and no count wanted: the kernels add straight into the caller's bins (integer atomics:
         // the same sums) - no scratch histogram to zero before and to add after, two launches less per frame
         MH_TRY(launch_pairs<true>(c, nullptr, nullptr, nullptr, (uint32_t)nbins, hmin, hmax, reinterpret_cast<unsigned long long *>(bins)));
@@ -1537,10 +1536,6 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
             unsigned long long tot = 0;
             MH_TRY(read_back(c, &tot, c->hist.as<unsigned long long>() + nbins, 8));
             *out_count = tot;
-        }
-        if (async) {
-            if (!c->gen_free[gen]) MH_HIP(hipEventCreateWithFlags(&c->gen_free[gen], hipEventDisableTiming));
-            MH_HIP(hipEventRecord(c->gen_free[gen], c->stream));
         }
         return MOLAR_HIP_OK;
     }

@@ -1,3 +1,6 @@
+"""Fused histogram with device-resident bins: 64 frames queued back to back against the same frames with a wait after
+each, twelve times - the bins have to be identical (integer atomics into the caller's bins, two grid generations in
+flight).  python tools/hist_race_check.py"""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
