@@ -199,6 +199,29 @@ def test_randomised_bilayers_sheared_boxes_pipelined(eng, seed):
     assert np.array_equal(fused.valid, staged.valid)
 
 
+@pytest.mark.parametrize("per", [1, 2, 5])
+def test_degenerate_bilayers(eng, per):
+    """One, two, five lipids per leaflet (no patch at all, or patches too short for the quadric fit): every lipid drops out,
+    the same way on both paths; and a bilayer whose lipids are all switched off from the start."""
+    from molar_amd import membrane as mb
+    xyz, box, first, tpl, masses = mb.build_bilayer(per, 2 * per * 52 + 500)
+    big = (box * np.float32(3.0)).astype(np.float32)            # room for the cutoff: the search needs a box of >= 2 cutoffs
+    fused = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(cutoff=1.5, order_type=1))
+    staged = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(cutoff=1.5, order_type=1, fused=False))
+    for f in frames_of(xyz, 2):
+        got, want = fused.compute(f.copy(), big), staged.compute(f.copy(), big)
+        for k in ARRAYS:
+            a, b = np.ascontiguousarray(got[k]), np.ascontiguousarray(want[k])
+            if k == "fitted_patch_points":
+                a, b = a[: len(want["patch_ids"])], b[: len(want["patch_ids"])]
+            assert a.tobytes() == b.tobytes(), k
+    assert np.array_equal(fused.valid, staged.valid)
+    for m in (fused, staged):
+        m.valid[:] = 0
+    got, want = fused.compute(xyz.copy(), big), staged.compute(xyz.copy(), big)
+    assert len(got["patch_ids"]) == 0 and not got["valid"].any() and np.array_equal(got["normals"], want["normals"])
+
+
 def test_plan_argument_errors(eng):
     from molar_amd import api, membrane as mb
     xyz, box, first, tpl, masses = mb.build_bilayer(20, 3000)
