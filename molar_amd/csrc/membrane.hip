@@ -1153,6 +1153,7 @@ int host_pass(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
         MH_TRY(search_resident_fits(c, (char *)S.h + H_SIZES, S.L, &fits));
         unsigned long long sizes[2];
         std::memcpy(sizes, (char *)S.h + H_SIZES, 16);
+        if (2ull * sizes[0] >= (1ull << 32)) return fail(MOLAR_HIP_ERR_TOO_LARGE, "membrane frame: %llu patch entries (32-bit entry indices)", 2ull * sizes[0]);
         if (2ull * sizes[0] > P->Ecap) {
             P->Ecap = (size_t)(2ull * sizes[0] + sizes[0] / 4u + 1024u);
             fits = false;
