@@ -1,0 +1,61 @@
+"""The GPU bilayer analysis on the fixture the Rust-side parity test feeds to MolAR's own molar_membrane
+(rust/molar_hip/tests/fixtures/membrane_cg/, rust/molar_hip/tests/membrane.rs): the structure is read from the GRO file the
+way MolAR reads it, the lipid description is the one of options.toml, and every number the Rust test compares is compared
+here - so the day `cargo test --test membrane` is green, these rows of the GPU path are pinned by the reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = os.path.join(ROOT, "rust", "molar_hip", "tests", "fixtures", "membrane_cg")
+
+
+def load(key, man):
+    d = man["arrays"][key]
+    return np.fromfile(os.path.join(FIX, key + ".bin"), dtype=np.dtype(d["dtype"]).newbyteorder("<")).reshape(d["shape"])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_gpu_membrane_on_the_rust_fixture(fused):
+    from molar_amd import build, gro
+    from molar_amd import membrane as mb
+    from molar_amd.api import Engine
+    build.build_library()
+    eng = Engine(0)
+    man = json.load(open(os.path.join(FIX, "manifest.json")))
+    top, st = gro.read_gro(os.path.join(FIX, "bilayer.gro"))
+    # the lipid of options.toml: head "name P N", mid "name C1 C2", tails C1A-C2A-C3A-C4A / C1B-C2B-C3B-C4B, tail marker =
+    # the last carbon of each tail (lib.rs:127-133)
+    names = top.names[:12]
+    at = {n: i for i, n in enumerate(names)}
+    tails = [np.array([at[n] for n in t.split("-")]) for t in ("C1A-C2A-C3A-C4A", "C1B-C2B-C3B-C4B")]
+    tpl = mb.LipidTemplate(12, np.array([at["N"], at["P"]]), np.array([at["C1"], at["C2"]]), np.array([t[-1] for t in tails]), tails,
+                           [np.ones(3, np.uint8), np.ones(3, np.uint8)])
+    K = man["nlipids"]
+    first = np.arange(K) * 12
+    m = mb.Membrane(eng, len(st.coords), first, tpl, top.masses, mb.MembraneOptions(cutoff=man["cutoff"], order_type=2, fused=fused))
+    xyz = np.ascontiguousarray(st.coords, np.float32).copy()
+    box = st.pbox.get_matrix()
+    res = m.compute(xyz, box)
+    tol = dict(rtol=2e-5, atol=2e-5)
+    assert np.allclose(res["head"], load("head_marker_new", man), **tol)
+    assert np.allclose(res["mid"], load("mid_marker_new", man), **tol)
+    assert np.allclose(res["tail"], load("tail_marker_new", man), **tol)
+    assert np.array_equal(res["patch_off"], load("patch_offsets", man)) and np.array_equal(res["patch_ids"], load("patch_ids", man))
+    valid = load("valid", man)
+    assert np.array_equal(res["valid"], valid)
+    ok = valid.astype(bool)
+    assert np.array_equal(res["nvert"][ok], load("nvert", man)[ok])
+    noff, nids = load("neib_offsets", man), load("neib_ids", man)
+    for k in np.flatnonzero(ok):
+        s0 = int(res["patch_off"][k]) + 4 * k
+        assert np.array_equal(res["neib_ids"][s0:s0 + int(res["nvert"][k])], nids[int(noff[k]): int(noff[k + 1])]), k
+    for got, want in (("smoothed_head", "head_marker"), ("normals", "normal"), ("mean_curv", "mean_curv"), ("gauss_curv", "gaussian_curv"),
+                      ("area", "area")):
+        assert np.allclose(res[got][ok], load(want, man)[ok], **tol), got
+    order = load("order", man)
+    for t in range(2):
+        assert np.allclose(res["order"][t][ok], order[ok, t], rtol=3e-5, atol=3e-5)

@@ -35,6 +35,7 @@ def test_no_stray_files_in_the_export():
     m = manifest()
     listed = {d["file"] for e in m.values() for d in e.values()}
     found = {os.path.relpath(os.path.join(r, f), FIX) for r, _, fs in os.walk(FIX) for f in fs if f.endswith(".bin")}
+    found = {f for f in found if not f.startswith("membrane_cg" + os.sep)}      # tests/membrane.rs' fixture has its own manifest and test
     assert listed == found
 
 
