@@ -3,7 +3,7 @@
 //! SOURCE ONLY - the image this repository is built in has no Rust toolchain, so this file has never been compiled or run.
 //! Why it exists: the reference holds no asserting test for any number `Membrane::compute` produces (its tests print), so the
 //! CPU checker this repository's GPU path is compared with is, for the membrane, a careful reading pinned only against
-//! independent geometry (qhull, least squares).  `tests/fixtures/membrane_cg/` holds a 128-lipid coarse-grained bilayer
+//! independent geometry (qhull, least squares).  `tests/fixtures/membrane_cg/` holds a 200-lipid coarse-grained bilayer
 //! (`bilayer.gro`, lipids at the edges split over the periodic boundary), the options (`options.toml`) and what the checker's
 //! primitives, assembled in the reference's order, say `Membrane::new` + one `Membrane::compute` leave in every
 //! `LipidMolecule` (`tests/golden/make_membrane_fixture.py`; `tests/test_rust_membrane_fixture_cpu.py` keeps the files equal
@@ -113,5 +113,5 @@ fn membrane_new_and_compute() {
     }
     // identical arithmetic gives identical cells: if MolAR and the checker round alike, every cell agrees vertex for vertex
     println!("{exact} of {k} cells identical vertex for vertex");
-    assert!(2 * exact > k, "fewer than half of the cells agree vertex for vertex");
+    assert!(20 * exact >= 19 * k, "fewer than 95 % of the cells agree vertex for vertex");
 }

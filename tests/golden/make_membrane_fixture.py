@@ -41,9 +41,12 @@ tails = [
 '''
 
 
-def bilayer(side=8, seed=20240611):
+def bilayer(side=10, seed=20240611):
     """2 x side^2 lipids on a jittered square lattice of 0.8 nm, a gentle undulation, wrapped into the box so that the
-    lipids at the edges are split over the periodic boundary (Membrane::new makes them whole, lib.rs:116-118)."""
+    lipids at the edges are split over the periodic boundary (Membrane::new makes them whole, lib.rs:116-118).  The box is
+    8 nm across: more than three cutoffs, so the search grid has three cells per dimension and the pair list holds no
+    duplicates (with two cells the reference emits pairs twice, a patch then holds a neighbour twice, and the second
+    insertion of the same point into a Voronoi cell doubles vertices at random)."""
     rng = np.random.default_rng(seed)
     L, Lz = side * 0.8, 9.0
     per = side * side

@@ -68,7 +68,7 @@ def test_gpu_membrane_on_the_rust_fixture(fused):
         got, want = res["neib_ids"][s0:s0 + int(res["nvert"][k])], nids[int(noff[k]): int(noff[k + 1])]
         assert ring(got) == ring(want), k
         exact += int(res["nvert"][k] == nvert[k] and np.array_equal(got, want))
-    assert exact > 0.5 * ok.sum()            # most cells come out vertex for vertex
+    assert exact >= 0.95 * ok.sum(), exact      # nearly every cell comes out vertex for vertex
     for got, want in (("smoothed_head", "head_marker"), ("normals", "normal"), ("mean_curv", "mean_curv"), ("gauss_curv", "gaussian_curv")):
         assert np.allclose(res[got][ok], load(want, man)[ok], **tol), got
     assert np.allclose(res["area"][ok], load("area", man)[ok], rtol=1e-3, atol=0)        # the fan area sees the doubled vertices
