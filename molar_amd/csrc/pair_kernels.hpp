@@ -325,7 +325,7 @@ __device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint3
         // the kernel's output pointers need not stay in (spilled) SGPRs
         const uint32_t pos = F.head;
         if (KIND == MOLAR_HIP_SEARCH_WITHIN) {
-            F.ids[pos] = F.fi[s];
+            __builtin_nontemporal_store(F.fi[s], &F.ids[pos]);
         } else if (F.hist) {
             // Histogram1D::add_one (molar_membrane/src/stats.rs:29-35) on d = sqrt(d2):
             //   b = (n as Float * (val - min) / (max - min)).floor() as isize;  if 0 <= b < n: bins[b] += 1
@@ -335,9 +335,13 @@ __device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint3
             if (fb >= 0.0f && fb < F.hn) atomicAdd(&F.hist[(uint32_t)fb], 1u);
         } else {
             const Hit h = fifo_hit(P, F, s);
-            if (F.has_pairs) F.pairs[pos] = make_uint2(h.i, h.j);
+            // The result stream is written once and read by nobody on this chip before the kernel ends: marked non-temporal
+            // (global_store ... nt) it does not take L2 lines from the second cell's records.  Fill pass 1.05 -> 0.98 ms,
+            // 655-660 -> 680-695 frames/s on one box, alternating runs; "sc0 nt", "sc1 nt", "sc0 sc1 nt" the same, "sc1"
+            // alone slower than plain stores (profiles/r03_store_policy_ab.txt).
+            if (F.has_pairs) __builtin_nontemporal_store(((unsigned long long)h.j << 32) | h.i, reinterpret_cast<unsigned long long *>(&F.pairs[pos]));
             // d2.sqrt() (:448): llvm.sqrt.f32 without fpmath metadata = IEEE correctly rounded
-            if (F.has_dist) F.dist[pos] = __builtin_sqrtf(h.d2);
+            if (F.has_dist) __builtin_nontemporal_store(__builtin_sqrtf(h.d2), &F.dist[pos]);
         }
     }
     F.head += count;
