@@ -1794,7 +1794,8 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
     F.hn1 = uniform_f32((float)P.hist_nbins - 1.0f);
     F.nbins = P.hist_nbins;
     unsigned long long wave_total = 0;
-    // A workgroup owns every gridDim.x-th slot and hands them to its waves one at a time through a counter in LDS:
+    // A workgroup owns every gridDim.x-th slot and hands them to its waves one at a time through a counter in LDS
+    // (runs of 4 / 16 / 64 consecutive slots per workgroup, for the second cells in its CU's cache: 0 / -1 / -5 %):
     // slots differ ~10x in work, and with a fixed share of ~9 slots per wave the slowest wave took 1.7x the mean.
     // (One counter in memory for the whole grid serialises: 7*10^4 device-scope atomics on one address took 1.1 ms.)
     for (;;) {
