@@ -382,10 +382,13 @@ def main():
     ap.add_argument("--serial-measure", action="store_true",
                     help="run the Kabsch fit/RMSD/COM/gyration of a frame after its search on the same stream instead of "
                          "concurrently on a second engine context (HIP stream) of the same GPU")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MOLAR_BENCH_STREAMS", "2")),
-                    help="engine contexts (HIP streams) per GPU working on different frames concurrently in the timed region: "
-                         "the plan / count kernels of one frame fill the tail of the other frame's fill kernel (+3..5 %% frames/s "
-                         "over 1).  The per-kernel event times and the roofline come from a separate single-context pass.")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MOLAR_BENCH_STREAMS", "1")),
+                    help="engine contexts (HIP streams) per GPU working on different frames in the timed region.  1 (default): one "
+                         "context, two frames in flight through molar_hip_search_resident_begin / _end, the next frame's grid built on "
+                         "the side stream under the fill pass.  2: two contexts on alternate frames, one host thread each (until the "
+                         "end of round 3 the default: +3..5 %% then; since the non-temporal result stores and the late grid start the "
+                         "single context is as fast at 200 steps and 1.5 %% faster at 20).  The per-kernel event times and the roofline "
+                         "come from a separate single-context pass either way.")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one search at a time (molar_hip_search_resident) instead of the begin/end form that keeps two "
                          "frames queued on the engine's stream (kernels still run one after the other, in order)")

@@ -156,6 +156,7 @@ molar_hip_ctx *molar_hip_create(int device) {
     c->env_no_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") != nullptr;
     c->env_no_mfma = std::getenv("MOLAR_HIP_NO_MFMA_COUNT") != nullptr;
     c->env_no_mfma_wrapped = std::getenv("MOLAR_HIP_NO_MFMA_WRAPPED") != nullptr;
+    c->env_grid_early = std::getenv("MOLAR_HIP_GRID_EARLY") != nullptr;
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     if (const char *dbg = std::getenv("MOLAR_HIP_DEBUG_SKIP")) c->env_debug_skip = (uint32_t)std::atoi(dbg);
 #endif
@@ -193,6 +194,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
     for (auto &t : c->tickets)
         if (t.done) (void)hipEventDestroy(t.done);
     if (c->grid_done) (void)hipEventDestroy(c->grid_done);
+    if (c->count_done) (void)hipEventDestroy(c->count_done);
     for (auto e : c->gen_free)
         if (e) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);

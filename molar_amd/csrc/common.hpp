@@ -152,6 +152,11 @@ struct molar_hip_ctx {
     hipEvent_t gen_free[2] = {nullptr, nullptr};   // recorded on the main stream behind the last asynchronous reader of
                                                    // a grid generation (histogram calls that do not wait)
     hipEvent_t side_wait = nullptr;      // what the side stream has to wait for before it rebuilds the generation
+    hipEvent_t side_wait2 = nullptr;     // ... and a second event (the count pass of the frame in flight, see count_done)
+    hipEvent_t count_done = nullptr;     // recorded behind the count pass of every pipelined search (molar_hip_search_resident_begin)
+    bool count_done_set = false;
+    bool record_count_done = false;      // set around the enqueue of a pipelined search
+    bool env_grid_early = false;         // MOLAR_HIP_GRID_EARLY: the next frame's grid starts as soon as its buffers are free (A/B runs)
     int hist_gen = 0;                    // generation of the last asynchronous histogram call
     bool on_side = false;                // launches currently go to side_stream (scans then use scan_tmp_side)
     mh::DevBuf scan_tmp_side;

@@ -1036,6 +1036,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
             MH_HIP(hipEventCreateWithFlags(&c->grid_done, hipEventDisableTiming));
         }
         if (c->side_wait) MH_HIP(hipStreamWaitEvent(c->side_stream, c->side_wait, 0));
+        if (c->side_wait2) MH_HIP(hipStreamWaitEvent(c->side_stream, c->side_wait2, 0));
         hipStream_t main_stream = c->stream;
         c->stream = c->side_stream;
         c->on_side = true;
@@ -1231,6 +1232,10 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     L->maskcap0 = c->maskbuf.cap / 256u;
     // one parameter block serves both passes: the count pass ignores the output capacity
     MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, cap0));
+    if (c->record_count_done) {
+        MH_HIP(hipEventRecord(c->count_done, c->stream));
+        c->count_done_set = true;
+    }
     {
         Prof prof(c, 2);
         MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(),
@@ -1337,9 +1342,17 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     c->set = c->set_store[slot];         // this ticket's grid generation (the other one may still be read by the frame in flight)
     c->want_side = !c->env_no_side;
     c->side_wait = c->gen_free[slot];    // an asynchronous histogram call may have been the last reader of this generation
+    // The grid of this frame is built on the side stream beside the kernels of the frame in flight.  Beside that frame's
+    // COUNT pass it is a competitor (both are bound by instruction issue); beside its FILL pass, which waits on its stores, it
+    // is nearly free: so it starts when that count pass has ended.
+    c->side_wait2 = (c->count_done_set && !c->env_grid_early) ? c->count_done : nullptr;
+    if (!c->count_done) MH_HIP(hipEventCreateWithFlags(&c->count_done, hipEventDisableTiming));
+    c->record_count_done = true;
     const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 16 * slot, &L);
+    c->record_count_done = false;
     c->want_side = false;
     c->side_wait = nullptr;
+    c->side_wait2 = nullptr;
     MH_TRY(erc);
     MH_HIP(hipEventRecord(T.done, c->stream));
     T.cap0 = L.cap0;
