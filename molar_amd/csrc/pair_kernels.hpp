@@ -1803,7 +1803,13 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         if (lane == 0) tk = atomicAdd(&lds_next, 1u);
         const unsigned long long w64 = blockIdx.x + (unsigned long long)__builtin_amdgcn_readfirstlane(tk) * gridDim.x;
         if (w64 >= nslots) break;
-        const uint32_t w = (uint32_t)w64;
+        uint32_t w = (uint32_t)w64;
+        {   // as pair_kernel: an XCD (workgroup index mod 8; the grid is a multiple of 8 wide) takes runs of consecutive slots
+            // (six alternations on one box: 2142 against 2056 frames/s on average, never behind by more than 1 %)
+            const uint32_t x = w & 7u, q = w >> 3;
+            const uint32_t full = (nslots / (8u * XCD_RUN)) * (8u * XCD_RUN);
+            if (w < full) w = ((q / XCD_RUN) * 8u + x) * XCD_RUN + (q % XCD_RUN);
+        }
         const uint32_t slot = nslots - 1u - w;       // reverse plan order, as pair_kernel
         Task T;
         uint32_t i0, fl;
