@@ -280,6 +280,9 @@ struct Fifo {
     uint32_t quota;             // entries the next full flush writes: 64 - (base % 64) for the first flush of a slot, so
                                 // that every later flush is one naturally aligned 512-byte / 256-byte block; then 64
     uint64_t base;              // output offset of this slot
+    uint32_t room;              // entries this slot owns in the output (what the count pass found): a flush never writes past
+                                // them, whatever the two passes may disagree on - the neighbours' results and the buffer's end
+                                // are out of reach of a slot
     bool has_pairs, has_dist;   // which of the two planes the caller wants (wave-uniform)
     uint2 *pairs;
     float *dist;
@@ -320,7 +323,7 @@ __device__ __forceinline__ Hit fifo_hit(const SearchParams &P, const Fifo &F, ui
 
 template <int KIND>
 __device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint32_t count, uint32_t lane) {
-    if (lane < count) {
+    if (lane < count && (F.hist || F.head + lane < F.room)) {
         const uint32_t s = (F.head + lane) & (FIFO_CAP - 1);
         // F.pairs / F.dist / F.ids are per-lane pointers to entry (slot base + lane): the flush adds the FIFO head, and
         // the kernel's output pointers need not stay in (spilled) SGPRs
@@ -1471,6 +1474,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         F.dist = nullptr;
         F.ids = nullptr;
         F.base = 0;
+        F.room = 0xFFFFFFFFu;
         F.hist = hist ? lds_hist : nullptr;
         F.recompute = 0u;
         F.la = lds_a[wave];
@@ -1486,6 +1490,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
             F.quota = 64u - ((uint32_t)F.base & 63u);
             const unsigned long long end = slot_base[slot + 1];
             if (end == F.base || end > P.out_cap) return;  // nothing to emit / no room (the host grows and repeats)
+            F.room = end - F.base < 0xFFFFFFFFull ? (uint32_t)(end - F.base) : 0xFFFFFFFFu;
             if (out_pairs) F.pairs = out_pairs + F.base + lane;
             if (out_dist) F.dist = out_dist + F.base + lane;
             if (out_ids) F.ids = out_ids + F.base + lane;
