@@ -1074,10 +1074,6 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
         F.recompute = WRAPPED ? 1u : 2u;
         F.la = la;
         F.wrap = T.wrap;
-#ifdef MOLAR_AB_COMPACT
-        F.fq = nullptr;
-        const uint32_t pos0 = T.b0 + lane;
-#else
         F.fq = F.fq_store;
         float4 q[NCH];                         // second-cell atoms of this lane, unshifted
 #pragma unroll
@@ -1086,7 +1082,6 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
             q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (jj < T.n2) q[k] = gload4(P.sb, T.b0 + jj);
         }
-#endif
         uint32_t w[NCH];
         uint32_t nrow = 0;
         while (live) {
@@ -1097,10 +1092,6 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
             ++nrow;
             const uint32_t r = (uint32_t)__builtin_ctzll(live);
             live &= ~(1ull << r);
-#if defined(MOLAR_AB_RANK) && MOLAR_AB_RANK == 2
-            uint32_t rv;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(rv) : "s"(r));
-#endif
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 const bool hit = (int32_t)w[k] < 0;
@@ -1109,40 +1100,15 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
                 if (mask) {
                     const uint32_t cnt = (uint32_t)__popcll(mask);
                     if (hit) {
-#ifdef MOLAR_AB_COMPACT
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                        const uint32_t off = ((rank + F.tail) << 2) & ((FIFO_CAP - 1u) << 2);
-                        typedef __attribute__((address_space(3))) uint32_t lds_u32;
-                        *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fd + off) = (r << 26) | (pos0 + (uint32_t)k * 64u);
-#elif defined(MOLAR_AB_RANK)
-                        // rank first, the tail joins in the shift (v_add_lshl_u32 takes the SGPR: no v_mov of the tail for
-                        // v_mbcnt's accumulator, whose other operand already holds the constant bus)
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                        const uint32_t off = ((rank + F.tail) << 2) & ((FIFO_CAP - 1u) << 2);
-                        typedef __attribute__((address_space(3))) uint32_t lds_u32;
-                        typedef float f4v __attribute__((ext_vector_type(4)));
-                        typedef __attribute__((address_space(3))) f4v lds_f4;
-                        *(lds_f4 *)((__attribute__((address_space(3))) char *)F.fq + (off << 2)) = f4v{q[k].x, q[k].y, q[k].z, q[k].w};
-#if MOLAR_AB_RANK == 2
-                        *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fd + off) = rv;
-#else
-                        *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fd + off) = r;
-#endif
-#else
                         const uint32_t s = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, F.tail)) &
                                            (FIFO_CAP - 1);
                         F.fq[s] = q[k];
                         F.fd[s] = r;
-#endif
                     }
                     F.tail += cnt;
                     total += cnt;
-#ifdef MOLAR_AB_EXPECT
-                    if (__builtin_expect(F.tail - F.head >= 64u, 0)) fifo_drain<KIND>(P, F, lane);
-#else
                     if (F.tail - F.head >= 64u) fifo_drain<KIND>(P, F, lane);
-#endif
                 }
             }
         }
