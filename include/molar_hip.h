@@ -401,7 +401,9 @@ int molar_hip_membrane_smooth(molar_hip_ctx *ctx, const molar_hip_membrane_patch
  * becomes its n-th neighbour shell - the direct neighbours widened (n_shells - 2) times by the neighbours of every
  * member, the lipid itself included from n_shells = 3 on as in the reference; lipids that are not valid keep the patch
  * they have.  The reference collects a HashSet (order unspecified); here ids ascend.  Count-then-fill: with out_ids ==
- * NULL (or too small a capacity) only out_offsets[nlipids + 1] and *needed are written. */
+ * NULL (or too small a capacity) only out_offsets[nlipids + 1] and *needed are written.  nvert[i] of a VALID lipid above
+ * its slots (patch length + 4) is an error; a lipid that is not valid may still be walked as a member of a shell (it
+ * keeps the neighbours an earlier pass left, as in the reference) and its count is clamped to its slots. */
 int molar_hip_membrane_nth_shell_patches(size_t nlipids, const uint8_t *valid, const uint64_t *patch_offsets,
                                          const uint64_t *patch_ids, const uint32_t *nvert, const uint64_t *neib_ids,
                                          size_t n_shells, uint64_t *out_offsets, uint64_t *out_ids, size_t capacity,
@@ -485,7 +487,9 @@ typedef struct {
 } molar_hip_membrane_out;
 int molar_hip_membrane_plan_create(molar_hip_ctx *ctx, const molar_hip_membrane_desc *desc, molar_hip_membrane_plan **out);
 void molar_hip_membrane_plan_destroy(molar_hip_membrane_plan *plan);
-/* valid[nlipids] from host memory (NULL: all valid = reset_valid_lipids, lib.rs:269-273); ends the frames in flight. */
+/* valid[nlipids] from host memory (NULL: all valid = reset_valid_lipids, lib.rs:269-273).  No frame may be in flight: with
+ * a ticket pending the call changes nothing and returns MOLAR_HIP_ERR_INVALID_ARGUMENT - end the frames first (the flags
+ * feed the kernels of a frame from its first launch on). */
 int molar_hip_membrane_plan_set_valid(molar_hip_membrane_plan *plan, const uint8_t *valid);
 /* xyz: float[natoms][3], device memory (unwrapped in place, and read until the frame ends) or host memory (uploaded;
  * the unwrapped frame is written back before _begin returns).  box9: column-major box matrix.  Returns with a ticket

@@ -156,7 +156,9 @@ molar_hip_ctx *molar_hip_create(int device) {
     c->env_no_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") != nullptr;
     c->env_no_mfma = std::getenv("MOLAR_HIP_NO_MFMA_COUNT") != nullptr;
     c->env_no_mfma_wrapped = std::getenv("MOLAR_HIP_NO_MFMA_WRAPPED") != nullptr;
-    c->env_grid_early = std::getenv("MOLAR_HIP_GRID_EARLY") != nullptr;
+    c->env_no_tile_sum = std::getenv("MOLAR_HIP_NO_TILE_SUM") != nullptr;
+    c->env_host_grid_wait = std::getenv("MOLAR_HIP_HOST_GRID_WAIT") != nullptr;
+    c->env_grid_late = std::getenv("MOLAR_HIP_GRID_LATE") != nullptr;
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     if (const char *dbg = std::getenv("MOLAR_HIP_DEBUG_SKIP")) c->env_debug_skip = (uint32_t)std::atoi(dbg);
 #endif
@@ -178,7 +180,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
                           &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb, &s.h16, &s.cell_org})
             b->release();
     }
-    for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->scan_tmp, &c->scan_tmp_side, &c->scan_state, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
+    for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->tile_sum, &c->scan_tmp, &c->scan_tmp_side, &c->scan_state, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
                       &c->wide_i, &c->wide_j, &c->hist, &c->task_mu, &c->task_moff, &c->maskbuf, &c->m_xyz1, &c->m_xyz2, &c->m_idx1, &c->m_idx2,
                       &c->m_mass1, &c->m_mass2, &c->m_partials, &c->m_results, &c->m_out})
         b->release();

@@ -148,6 +148,8 @@ struct molar_hip_ctx {
     bool env_no_side = false;            // MOLAR_HIP_NO_SIDE_STREAM, read once in molar_hip_create
     bool env_no_mfma = false;            // MOLAR_HIP_NO_MFMA_COUNT: count pass of plain entries on the vector ALUs (A/B runs)
     bool env_no_mfma_wrapped = false;    // MOLAR_HIP_NO_MFMA_WRAPPED: count pass of wrapped entries on the vector ALUs (A/B runs)
+    bool env_host_grid_wait = false;     // MOLAR_HIP_HOST_GRID_WAIT: the host, not the main stream, waits for the side stream's grid
+    bool env_no_tile_sum = false;        // MOLAR_HIP_NO_TILE_SUM: slot offsets by the general three-kernel scan (A/B runs)
     uint32_t env_debug_skip = 0;         // MOLAR_HIP_DEBUG_SKIP (builds with -DMOLAR_HIP_DEBUG_KNOBS only), read once
     hipEvent_t gen_free[2] = {nullptr, nullptr};   // recorded on the main stream behind the last asynchronous reader of
                                                    // a grid generation (histogram calls that do not wait)
@@ -156,7 +158,7 @@ struct molar_hip_ctx {
     hipEvent_t count_done = nullptr;     // recorded behind the count pass of every pipelined search (molar_hip_search_resident_begin)
     bool count_done_set = false;
     bool record_count_done = false;      // set around the enqueue of a pipelined search
-    bool env_grid_early = false;         // MOLAR_HIP_GRID_EARLY: the next frame's grid starts as soon as its buffers are free (A/B runs)
+    bool env_grid_late = false;          // MOLAR_HIP_GRID_LATE: the next frame's grid waits for the count pass of the frame in flight (A/B runs)
     int hist_gen = 0;                    // generation of the last asynchronous histogram call
     bool on_side = false;                // launches currently go to side_stream (scans then use scan_tmp_side)
     mh::DevBuf scan_tmp_side;
@@ -167,6 +169,10 @@ struct molar_hip_ctx {
     mh::DevBuf slot_desc;      // SlotDesc per slot (+1): what a wave of the pair kernels needs to start
     mh::DevBuf slot_cnt;       // u32 per slot (+1): results of the slot
     mh::DevBuf slot_base;      // u64 per slot (+1): output offset (last = grand total)
+    mh::DevBuf tile_sum;       // u64 per tile of 256 slots: results of the tile (tile_sums_kernel -> slot_offsets_kernel)
+    unsigned long long plan_out_cap = ~0ull;   // resident searches: the output capacity the plan kernel writes into the parameter block
+    bool params_fresh = false;                 // the plan kernel of this search left a parameter block the count pass can use as it is
+    unsigned long long *sizes_dev = nullptr;   // resident searches: device-side address of the pinned 16 bytes the kernels write the two sizes to
     mh::DevBuf scan_tmp;       // block sums for the scans
     mh::DevBuf scan_state;     // ticket + tile descriptors of the single-pass scans (zeroed by the plan kernel)
     mh::DevBuf out_pairs_set[2];   // ctx-owned result buffers (device-resident results / host staging); the second

@@ -33,15 +33,6 @@ struct RingJob {
     void *dst0, *dst1;
 };
 
-inline int ring_ensure(molar_hip_ctx *c) {
-    if (c->ring[0]) return 0;
-    for (int k = 0; k < RING_SLOTS; ++k) {
-        MH_HIP(hipHostMalloc(&c->ring[k], RING_CHUNK, hipHostMallocDefault));
-        MH_HIP(hipEventCreateWithFlags(&c->ring_ev[k], hipEventDisableTiming));
-    }
-    return 0;
-}
-
 inline void ring_release(molar_hip_ctx *c) {
     for (int k = 0; k < RING_SLOTS; ++k) {
         if (c->ring[k]) (void)hipHostFree(c->ring[k]);
@@ -49,6 +40,28 @@ inline void ring_release(molar_hip_ctx *c) {
         c->ring[k] = nullptr;
         c->ring_ev[k] = nullptr;
     }
+}
+
+// all slots and events, or none: an allocation that fails half way (128 MiB of pinned memory per context) releases what it
+// got, so that the next large fill tries again instead of finding ring[0] set and copying through null slots
+inline int ring_ensure(molar_hip_ctx *c) {
+    bool whole = true;
+    for (int k = 0; k < RING_SLOTS; ++k) whole = whole && c->ring[k] && c->ring_ev[k];
+    if (whole) return 0;
+    ring_release(c);
+    for (int k = 0; k < RING_SLOTS; ++k) {
+        hipError_t e = hipHostMalloc(&c->ring[k], RING_CHUNK, hipHostMallocDefault);
+        if (e != hipSuccess) c->ring[k] = nullptr;
+        if (e == hipSuccess) {
+            e = hipEventCreateWithFlags(&c->ring_ev[k], hipEventDisableTiming);
+            if (e != hipSuccess) c->ring_ev[k] = nullptr;
+        }
+        if (e != hipSuccess) {
+            ring_release(c);
+            MH_HIP(e);
+        }
+    }
+    return 0;
 }
 
 // Brings the jobs home, in order, on c->stream (so everything enqueued before - the fill kernel - is complete for them);

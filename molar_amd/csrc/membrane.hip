@@ -525,7 +525,12 @@ void nth_shell_of(size_t i, size_t n_shells, const uint64_t *slot_off, const uin
     members.clear();
     auto add_neighbours_of = [&](size_t l) {
         const uint64_t s0 = slot_off[l] + 4ull * l;
-        for (uint32_t k = 0; k < nvert[l]; ++k) {
+        // A member of the growing shell may be a lipid the smoothing pass dropped: its vertex count is whatever an earlier
+        // frame (or the caller) left there, and check_shell_args vouches for the valid lipids only.  Never read past the
+        // lipid's own slots (patch length + 4): the arrays carry no length across this ABI.
+        const uint64_t cap = slot_off[l + 1] - slot_off[l] + 4ull;
+        const uint32_t nv = nvert[l] < cap ? nvert[l] : (uint32_t)cap;
+        for (uint32_t k = 0; k < nv; ++k) {
             const uint64_t id = neib[s0 + k];
             if (id < K && stamp[id] != mark) {
                 stamp[id] = mark;
@@ -999,6 +1004,7 @@ struct molar_hip_membrane_plan {
         void *h_mid = nullptr;    // pinned: what the host pass reads (roff | n1 | valid_prev | pids32) and writes (n2)
         size_t h_mid_cap = 0;
         hipEvent_t mid = nullptr, done = nullptr;
+        hipEvent_t back = nullptr;   // the unwrapped frame is back in the caller's host array (frames handed over in host memory)
         bool pending = false, ended = false, b_enqueued = false;
         bool speculative = false;  // B ran on the flags of the frame before the older one, ahead of the older frame's C
         bool passed = false;       // the host pass is done for the B that is on the stream
@@ -1056,8 +1062,11 @@ int enqueue_a(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
     FrameInfo *info = reinterpret_cast<FrameInfo *>(d + L.info);
     if (P->unwrap) {
         MH_TRY(enqueue_unwrap_batch(c, S.xyz_dev, P->lipid_idx, P->lipid_off, (uint32_t)P->K, box, MOLAR_HIP_PBC_FULL));
-        if (S.xyz_host)      // the caller's frame is unwrapped in place, like Modify::unwrap_simple on the System
+        if (S.xyz_host) {    // the caller's frame is unwrapped in place, like Modify::unwrap_simple on the System
             MH_HIP(hipMemcpyAsync(S.xyz_host, S.xyz_dev, P->natoms * 12, hipMemcpyDeviceToHost, st));
+            if (!S.back) MH_HIP(hipEventCreateWithFlags(&S.back, hipEventDisableTiming));
+            MH_HIP(hipEventRecord(S.back, st));
+        }
     }
     MH_TRY(enqueue_center_batch(c, S.xyz_dev, P->marker_idx, P->marker_off, (uint32_t)(3 * P->K), P->masses, (float *)(d + L.mk),
                                 &info->st_center));
@@ -1345,6 +1354,7 @@ extern "C" void molar_hip_membrane_plan_destroy(molar_hip_membrane_plan *P) {
         if (S.h_mid) (void)hipHostFree(S.h_mid);
         if (S.done) (void)hipEventDestroy(S.done);
         if (S.mid) (void)hipEventDestroy(S.mid);
+        if (S.back) (void)hipEventDestroy(S.back);
     }
     if (P->h_fetch) (void)hipHostFree(P->h_fetch);
     P->consts.release(); P->valid.release(); P->work.release();
@@ -1393,6 +1403,10 @@ extern "C" int molar_hip_membrane_frame_begin(molar_hip_membrane_plan *P, float 
     // it while the host is busy with the older frame - and is repeated behind that C if it did change them.
     S.speculative = P->slot[t ^ 1].pending;
     MH_TRY(enqueue_b(P, S, /*restore=*/false));
+    // The header promises that a host frame holds its unwrapped coordinates when this call returns.  Into pageable memory
+    // the runtime's copy blocks anyway; into pinned / registered memory it is asynchronous and would land after a caller
+    // (the Rust wrapper's `&mut [f32]`) has given up the array - wait for that copy alone, with B already queued behind it.
+    if (S.xyz_host && P->unwrap && S.back) MH_HIP(hipEventSynchronize(S.back));
     S.pending = true;
     P->next = t ^ 1;
     *ticket = t;

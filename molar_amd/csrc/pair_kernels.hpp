@@ -714,6 +714,21 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
     const float4 org = gload4(P.cell_org_b, T.cb);
+    // Rows that cannot have a hit (run_fast's exact pruning against the second cell's bounding box: the same f32
+    // expression on the point-to-box distances bounds every d2 of the row from below) are left out, and the rows that
+    // remain are COMPACTED in front of the instruction - a count does not care in which order its rows are visited.  With
+    // at most 32 live rows the slot needs one row block instead of two: most slots of the corner entries (~2/3 of their
+    // rows pruned) and a third of the edge entries'.  Same-cell entries keep their rows in place (the j > i mask below
+    // argues with positions, and a row inside its own cell's box is never pruned).
+    bool need = lane < rows;
+    if (!TRI) {
+        const float4 blo = gload4(P.aabb_b, 2 * T.cb), bhi = gload4(P.aabb_b, 2 * T.cb + 1);
+        need = need && !(aabb_d2(a.x, a.y, a.z, blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z) > cutoff2);
+    }
+    const unsigned long long live = __builtin_amdgcn_ballot_w64(need);
+    const uint32_t nlive = TRI ? rows : (uint32_t)__popcll(live);
+    if (!TRI && nlive == 0u) return 0u;
+    const uint32_t rank = TRI ? lane : __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
     u4_t bq[MFMA_TILES];
 #pragma unroll
     for (int t = 0; t < MFMA_TILES; ++t) {
@@ -724,9 +739,9 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
         // NaN or inf), but its accumulators would be NaNs of either sign
         if ((bq[t].w & 0x7C00u) == 0x7C00u) bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};
     }
-    la[lane] = a;                                   // f32 rows, for the exact decision inside the band
+    if (TRI || need) la[rank] = a;                  // f32 rows (compacted), for the exact decision inside the band
     const float r0 = a.x - org.x, r1 = a.y - org.y, r2 = a.z - org.z;
-    float ra2 = lane < rows ? (r0 * r0 + r1 * r1) + r2 * r2 : 0.0f;
+    float ra2 = need ? (r0 * r0 + r1 * r1) + r2 * r2 : 0.0f;
     const bool fin = ra2 == ra2;
     for (int off = 32; off > 0; off >>= 1) ra2 = fmaxf(ra2, __shfl_xor(ra2, off, 64));
     const float R = 1.0001f * __builtin_sqrtf(ra2) + org.w;
@@ -736,9 +751,14 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
         done = false;                               // not finite / not small: the exact path takes the slot
         return 0u;
     }
-    {   // A records of this lane's row: k = 0..7 and k = 8..15
+    {   // A records of this lane's row: k = 0..7 and k = 8..15, stored at the row's rank among the live rows
         u4_t k0 = {0u, 0u, 0u, 0x00007BFFu}, k1 = {0u, 0u, 0u, 0x3C003C00u};      // row past the end: +65504
-        if (lane < rows) {
+        if (!TRI) {
+            ((lds_u4 *)lh)[2u * lane] = k0;
+            ((lds_u4 *)lh)[2u * lane + 1u] = k1;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (need) {
             const _Float16 h0 = (_Float16)r0, h1 = (_Float16)r1, h2 = (_Float16)r2;
             const _Float16 l0 = (_Float16)(r0 - (float)h0), l1 = (_Float16)(r1 - (float)h1), l2 = (_Float16)(r2 - (float)h2);
             const float e0 = (float)h0 + (float)l0, e1 = (float)h1 + (float)l1, e2 = (float)h2 + (float)l2;
@@ -749,8 +769,10 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
             k0 = u4_t{pack_h2(g0, g1), pack_h2(g2, g0), pack_h2(g1, g2), pack_h2(nh, nl)};
             k1 = u4_t{pack_h2(s0, s1), pack_h2(s2, s0), pack_h2(s1, s2), 0x3C003C00u};
         }
-        ((lds_u4 *)lh)[2u * lane] = k0;
-        ((lds_u4 *)lh)[2u * lane + 1u] = k1;
+        if (TRI || need) {
+            ((lds_u4 *)lh)[2u * rank] = k0;
+            ((lds_u4 *)lh)[2u * rank + 1u] = k1;
+        }
     }
     __builtin_amdgcn_wave_barrier();
     const u4_t a0q = ((const lds_u4 *)lh)[2u * cl + kh], a1q = ((const lds_u4 *)lh)[2u * (32u + cl) + kh];
@@ -772,6 +794,7 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
                 // same-cell entries (j > i, :443; B records are in the reference's order, so atom `col` has position col):
                 // blocks below the diagonal hold no pair, blocks above it all of theirs, blocks on it are masked
                 bool diag = false;
+                if (32u * (uint32_t)rt >= nlive) continue;                                   // no live row in this block
                 if (TRI) {
                     const uint32_t row0 = i0 + 32u * (uint32_t)rt;
                     if (32u * (uint32_t)t + 31u <= row0) continue;                       // every j <= every i
@@ -815,7 +838,7 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
                 const float4 p = lload4(la, row);
                 const float dx = b.x - p.x, dy = b.y - p.y, dz = b.z - p.z;     // p2 - p1
                 const float d2 = (dx * dx + dy * dy) + dz * dz;                // |p2-p1|^2 (:446, :460)
-                cnt += (row < rows && (!TRI || col > i0 + row) && d2 <= cutoff2) ? 1u : 0u;
+                cnt += (row < nlive && (!TRI || col > i0 + row) && d2 <= cutoff2) ? 1u : 0u;
             }
         }
     }
@@ -1328,10 +1351,18 @@ template <int KIND>
 __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__restrict__ task_nb,
                                                    TaskDesc *__restrict__ task_desc, uint32_t *__restrict__ task_mu,
                                                    uint32_t fast_kind, uint32_t *__restrict__ slot_cnt, uint64_t nslot_cnt,
-                                                   unsigned long long *__restrict__ scan_state, uint64_t nstate) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+                                                   unsigned long long *__restrict__ scan_state, uint64_t nstate,
+                                                   SearchParams *__restrict__ params_dst) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < nslot_cnt) slot_cnt[t] = 0u;     // the count kernel writes the slots that exist; the scan runs over the bound
     if (t < nstate) scan_state[t] = 0ull;    // ticket + tile descriptors of this search's look-back scans
+    if (params_dst && blockIdx.x == 0) {
+        // the parameter block of the pair kernels, straight from this kernel's own argument segment (P is its first
+        // argument): one launch less in front of the count pass than a kernel of its own
+        const uint32_t *src = (const uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t *d = (uint32_t *)params_dst;
+        for (uint32_t w = threadIdx.x; w < (uint32_t)(sizeof(SearchParams) / 4u); w += blockDim.x) d[w] = src[w];
+    }
     if (t == P.ntasks) {                 // terminators of the two exclusive scans (the grid covers ntasks + 1)
         task_nb[t] = 0u;
         task_mu[t] = 0u;
@@ -1356,8 +1387,10 @@ __global__ void __launch_bounds__(256) plan_kernel(SearchParams P, uint32_t *__r
 static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, const uint32_t *__restrict__ task_first,
                                                       const TaskDesc *__restrict__ task_desc,
                                                       const unsigned long long *__restrict__ task_moff,   // NULL: no hit history
-                                                      SlotDesc *__restrict__ slot_desc, uint64_t nslots_bound) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+                                                      SlotDesc *__restrict__ slot_desc, uint64_t nslots_bound,
+                                                      unsigned long long *__restrict__ sizes_host) {   // pinned, or NULL
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && sizes_host) sizes_host[1] = task_moff ? task_moff[ntasks] : 0ull;   // hit-history units of this search
     if (t >= ntasks) {
         // slots between the real count and the host's bound: waves launched for them leave at once
         const uint64_t s = (uint64_t)task_first[ntasks] + (t - ntasks);

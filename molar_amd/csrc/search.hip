@@ -112,10 +112,14 @@ __device__ __forceinline__ V3 load_pos(const float *xyz, uint64_t a) {
 
 // `counters` holds one counter per cell at stride 1 << pad_shift words: with a few thousand cells and hundreds of
 // atoms per cell, 32 neighbouring counters in one 128-byte line serialise in L2; one counter per line does not.
+// (Round 4: the kernel takes 44 us alone on the 1M-atom frame and 8.7 us with the atomic taken out - it is bound by the
+// chip's rate of returning atomics, ~28 G/s, not by queues on single addresses: one set of counters per XCD, chosen by
+// HW_REG_XCC_ID and incremented at workgroup scope, left it at 41 us.  The compiler emits the same instruction -
+// global_atomic_add ... sc0 - for workgroup and agent scope on gfx950.)
 __global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restrict__ key,
                                                   uint32_t *__restrict__ arrival, uint32_t *__restrict__ counters,
                                                   uint32_t pad_shift) {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P.n) return;
     const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
     const CellOfAtom c = classify(P, load_pos(P.xyz, a));
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restr
 
 // one launch instead of hipMemsetAsync, which splits an unaligned range into up to three fill kernels (~5 us each)
 __global__ void __launch_bounds__(256) zero2_kernel(uint32_t *__restrict__ a, size_t na, uint32_t *__restrict__ b, size_t nb) {
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * 256u) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * blockDim.x) {
         if (i < na) a[i] = 0u;
         else b[i - na] = 0u;
     }
@@ -140,7 +144,7 @@ __global__ void __launch_bounds__(256) add_u64_kernel(unsigned long long *__rest
 
 __global__ void __launch_bounds__(256) unpad_kernel(uint32_t ncells, const uint32_t *__restrict__ padded, uint32_t pad_shift,
                                                     uint32_t *__restrict__ cell_count) {
-    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < ncells) cell_count[c] = padded[(size_t)c << pad_shift];
 }
 
@@ -148,7 +152,7 @@ __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t
                                                       const uint32_t *__restrict__ cell_start,
                                                       const uint32_t *__restrict__ arrival,
                                                       uint32_t *__restrict__ tmp_key) {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t ky = key[k];
     if (ky == DROPPED) return;
@@ -173,25 +177,29 @@ __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t
 //    Counting does not depend on the order in which candidates are visited, so the count pass walks compact
 //    chunks and skips (row, chunk) pairs by bounding box; the fill pass keeps the reference's order.
 constexpr uint32_t ORDER_MAX = 512;   // = KREG * 64 of the pair kernels
-__global__ void __launch_bounds__(256) place_order_kernel(BinParams P, uint32_t ncells, int ids_local,
+__global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t ncells, int ids_local,
                                                           const uint32_t *__restrict__ cell_start,
                                                           const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
                                                           float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
                                                           float4 *__restrict__ aabb, float4 *__restrict__ perm,
                                                           float4 *__restrict__ chunk_aabb, uint4 *__restrict__ h16,
                                                           float4 *__restrict__ cell_org) {
-    __shared__ uint32_t keys_s[4][ORDER_MAX];     // sort keys of the cell; reused as the Morton histogram
-    __shared__ uint32_t kr_s[4][ORDER_MAX];
-    __shared__ uint16_t perm_s[4][ORDER_MAX];
-    // (the placed records are read back from `sorted` - written by this wave - rather than kept in LDS: 8 KB per wave
-    // more would hold the kernel at 3 workgroups per CU and make a 1M-atom grid take two rounds)
-    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t c = blockIdx.x * 4u + w;
+    // One wave per workgroup (5 KB of LDS): the grid of the NEXT frame is built on the side stream while the fill pass of
+    // the frame in flight holds every wave slot of the chip with one-wave workgroups.  A freed slot takes a one-wave
+    // workgroup of either queue; a four-wave workgroup needs four free slots on ONE compute unit at the same moment and
+    // starves until the fill pass has nothing left to dispatch (round 3: the grid ended 5 us after the fill pass and the
+    // next frame's plan waited for it).
+    __shared__ uint32_t keys_s[ORDER_MAX];        // sort keys of the cell; reused as the Morton histogram
+    __shared__ uint32_t kr_s[ORDER_MAX];
+    __shared__ uint16_t perm_s[ORDER_MAX];
+    // (the placed records are read back from `sorted` - written by this wave - rather than kept in LDS)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t c = blockIdx.x;
     if (c >= ncells) return;
     const uint32_t s = cell_start[c], e = cell_start[c + 1], n = e - s;
     const bool small = n <= ORDER_MAX;
-    uint32_t *keys = keys_s[w], *kr = kr_s[w];
-    uint16_t *pl = perm_s[w];
+    uint32_t *keys = keys_s, *kr = kr_s;
+    uint16_t *pl = perm_s;
     const float4 *pos = sorted + s;               // valid once the placement loop's stores are visible (fence below)
     if (small) {
         for (uint32_t t = lane; t < n; t += 64u) keys[t] = tmp_key[s + t];
@@ -326,7 +334,7 @@ constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
 template <class T>
 __device__ __forceinline__ T block_exclusive_scan(T v, T *total) {
     __shared__ T wave_sums[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
     T inc = v;
     for (int off = 1; off < 64; off <<= 1) {
         T o = __shfl_up(inc, off, 64);
@@ -335,7 +343,7 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T *total) {
     if (lane == 63) wave_sums[wave] = inc;
     __syncthreads();
     T base = 0, tot = 0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < nw; ++w) {
         if (w < wave) base += wave_sums[w];
         tot += wave_sums[w];
     }
@@ -396,7 +404,7 @@ __global__ void __launch_bounds__(256) scan_lookback_kernel(const TIn1 *in1, TOu
     __syncthreads();
     const uint32_t tile = tile_s;
     unsigned long long *d1 = state + 1, *d2 = state + 1 + ntiles;
-    const uint64_t base = (uint64_t)tile * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    const uint64_t base = (uint64_t)tile * (blockDim.x * SCAN_ITEMS) + (uint64_t)threadIdx.x * SCAN_ITEMS;
     TOut1 a[SCAN_ITEMS];
     TOut2 b[SCAN_ITEMS];
     TOut1 sa = 0;
@@ -412,7 +420,7 @@ __global__ void __launch_bounds__(256) scan_lookback_kernel(const TIn1 *in1, TOu
     TOut2 tb = 0, rb = 0;
     if (in2) rb = block_exclusive_scan<TOut2>(sb, &tb);
     if (threadIdx.x == 0) pre_s[0] = lb_resolve(d1, tile, (unsigned long long)ta);
-    if (threadIdx.x == 64 && in2) pre_s[1] = lb_resolve(d2, tile, (unsigned long long)tb);
+    if (threadIdx.x == (blockDim.x > 64u ? 64u : 1u) && in2) pre_s[1] = lb_resolve(d2, tile, (unsigned long long)tb);
     __syncthreads();
     ra += (TOut1)pre_s[0];
     if (in2) rb += (TOut2)pre_s[1];
@@ -426,15 +434,16 @@ __global__ void __launch_bounds__(256) scan_lookback_kernel(const TIn1 *in1, TOu
     }
 }
 
-// state words needed by scan_lookback for n elements
-inline size_t lookback_state_words(uint64_t n) { return 1 + 2 * (size_t)((n + SCAN_TILE - 1) / SCAN_TILE); }
+// state words needed by scan_lookback for n elements (sized for the one-wave tiles of the side stream)
+inline size_t lookback_state_words(uint64_t n) { return 1 + 2 * (size_t)((n + 64 * SCAN_ITEMS - 1) / (64 * SCAN_ITEMS)); }
 
 template <class TIn1, class TOut1, class TIn2, class TOut2>
 int scan_lookback(molar_hip_ctx *c, const TIn1 *in1, TOut1 *out1, const TIn2 *in2, TOut2 *out2, uint64_t n,
                   unsigned long long *zeroed_state) {
     if (n == 0) return 0;
-    const uint32_t ntiles = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL((scan_lookback_kernel<TIn1, TOut1, TIn2, TOut2>), dim3(ntiles), dim3(256), 0, c->stream, in1, out1, in2, out2, n,
+    const uint32_t block = c->on_side ? 64u : 256u;           // one-wave workgroups on the side stream (place_order_kernel)
+    const uint32_t ntiles = (uint32_t)((n + block * SCAN_ITEMS - 1) / (block * SCAN_ITEMS));
+    hipLaunchKernelGGL((scan_lookback_kernel<TIn1, TOut1, TIn2, TOut2>), dim3(ntiles), dim3(block), 0, c->stream, in1, out1, in2, out2, n,
                        zeroed_state, ntiles);
     MH_HIP(hipGetLastError());
     return 0;
@@ -491,10 +500,38 @@ __global__ void __launch_bounds__(256) scan_small_kernel(const TIn *in, TOut *ou
     }
 }
 
+// the same with ONE wave (512 elements per step): a one-wave workgroup finds a wave slot on a chip that another stream's
+// kernel keeps full (grid build on the side stream, see place_order_kernel)
+template <class TIn, class TOut>
+__global__ void __launch_bounds__(64) scan_small_wave_kernel(const TIn *in, TOut *out, uint32_t n) {
+    TOut carry = 0;
+    for (uint32_t start = 0; start < n; start += 512u) {
+        const uint32_t base = start + threadIdx.x * 8u;
+        TOut item[8], sum = 0;
+        for (int q = 0; q < 8; ++q) {
+            item[q] = base + q < n ? (TOut)in[base + q] : (TOut)0;
+            sum += item[q];
+        }
+        TOut inc = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const TOut o = __shfl_up(inc, off, 64);
+            if ((int)threadIdx.x >= off) inc += o;
+        }
+        TOut run = carry + inc - sum;
+        for (int q = 0; q < 8; ++q) {
+            if (base + q < n) out[base + q] = run;
+            run += item[q];
+        }
+        carry += __shfl(inc, 63, 64);
+    }
+}
+
 template <class TIn, class TOut>
 int exclusive_scan(molar_hip_ctx *c, const TIn *in, TOut *out, uint64_t n) {
     if (n == 0) return 0;
     if (n <= 8192ull) {
+        if (c->on_side) hipLaunchKernelGGL((scan_small_wave_kernel<TIn, TOut>), dim3(1), dim3(64), 0, c->stream, in, out, (uint32_t)n);
+        else
         hipLaunchKernelGGL((scan_small_kernel<TIn, TOut>), dim3(1), dim3(256), 0, c->stream, in, out, (uint32_t)n);
         MH_HIP(hipGetLastError());
         return 0;
@@ -509,6 +546,64 @@ int exclusive_scan(molar_hip_ctx *c, const TIn *in, TOut *out, uint64_t n) {
         hipLaunchKernelGGL((scan_add_kernel<TOut>), dim3((unsigned)nb), dim3(256), 0, c->stream, out, sums, n);
     }
     MH_HIP(hipGetLastError());
+    return 0;
+}
+
+// Output offsets of the slots in two launches instead of the general scan's three (tile scan, scan of the block sums,
+// add - the last one alone took 39 us per frame in the round-3 trace): tile_sums_kernel adds up the counts of every tile
+// of 256 slots; in slot_offsets_kernel workgroup b owns tile b, takes as its base the sum of the b tile totals in front
+// of it (read from L2 by 256 threads: ~1100 tiles = 9 KB on the headline frame), and one block scan over the tile's own
+// 256 counts gives every slot its offset.  With `sizes_host` the grand total goes straight to the host's pinned block
+// (no copy command behind the fill pass).  (The tile totals as 64-bit atomics of the count pass itself - one launch
+// instead of two - cost that pass 70-85 us: 256 device-scope atomics per address from eight XCDs; measured, removed.)
+// Work grows with the square of the tile count: plans above SLOT_SCAN_MAX_TILES take exclusive_scan.
+constexpr uint64_t SLOT_SCAN_MAX_TILES = 4096;
+__global__ void __launch_bounds__(256) tile_sums_kernel(const uint32_t *__restrict__ slot_cnt, unsigned long long *__restrict__ tile_sum,
+                                                        uint64_t n) {
+    __shared__ unsigned long long part[4];
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    unsigned long long v = i < n ? (unsigned long long)slot_cnt[i] : 0ull;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ void __launch_bounds__(256) slot_offsets_kernel(const uint32_t *__restrict__ slot_cnt,
+                                                           const unsigned long long *__restrict__ tile_sum,
+                                                           unsigned long long *__restrict__ slot_base, uint64_t n,
+                                                           unsigned long long *__restrict__ sizes_host) {
+    __shared__ unsigned long long part[4];
+    unsigned long long pre = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += 256u) pre += tile_sum[t];
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = pre;
+    __syncthreads();
+    const unsigned long long base = (part[0] + part[1]) + (part[2] + part[3]);
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const unsigned long long v = i < n ? (unsigned long long)slot_cnt[i] : 0ull;
+    unsigned long long tot;
+    const unsigned long long ex = block_exclusive_scan<unsigned long long>(v, &tot);
+    if (i < n) slot_base[i] = base + ex;
+    if (i + 1 == n && sizes_host) sizes_host[0] = base + ex;      // slot_cnt[n - 1] is the terminator: its offset is the grand total
+}
+
+// slot counts -> output offsets (n = slots + 1 terminator), the grand total also to `sizes_host` (pinned, may be null)
+int scan_slot_counts(molar_hip_ctx *c, unsigned long long *sizes_host) {
+    const uint64_t n = c->nslots_bound + 1;
+    const uint64_t ntiles = (n + 255) / 256;
+    if (ntiles <= SLOT_SCAN_MAX_TILES && !c->env_no_tile_sum) {
+        MH_TRY(c->tile_sum.reserve(ntiles * 8));
+        hipLaunchKernelGGL(tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, c->stream, c->slot_cnt.as<uint32_t>(),
+                           c->tile_sum.as<unsigned long long>(), n);
+        hipLaunchKernelGGL(slot_offsets_kernel, dim3((unsigned)ntiles), dim3(256), 0, c->stream, c->slot_cnt.as<uint32_t>(),
+                           c->tile_sum.as<unsigned long long>(), c->slot_base.as<unsigned long long>(), n, sizes_host);
+        MH_HIP(hipGetLastError());
+        return 0;
+    }
+    MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(), n)));
+    if (sizes_host)
+        MH_HIP(hipMemcpyAsync(sizes_host, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8, hipMemcpyDefault, c->stream));
     return 0;
 }
 
@@ -651,23 +746,26 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     if (pad_shift) MH_TRY(S.cnt_pad.reserve(npad * 4));
     {
         const size_t nz = (size_t)ncells + 1 + npad;
-        const unsigned zb = (unsigned)std::min<size_t>((nz + 255) / 256, 2048);
-        hipLaunchKernelGGL(zero2_kernel, dim3(zb), dim3(256), 0, c->stream, S.cell_count.as<uint32_t>(), (size_t)ncells + 1,
+        // workgroup size: one wave on the side stream (see place_order_kernel), four otherwise
+        const unsigned bs = c->on_side ? 64u : 256u;
+        const unsigned zb = (unsigned)std::min<size_t>((nz + bs - 1) / bs, 2048u * (256u / bs));
+        hipLaunchKernelGGL(zero2_kernel, dim3(zb), dim3(bs), 0, c->stream, S.cell_count.as<uint32_t>(), (size_t)ncells + 1,
                            S.cnt_pad.as<uint32_t>(), npad);
     }
     if (S.n) {
-        const unsigned nb = (S.n + 255u) / 256u;
+        const unsigned bs = c->on_side ? 64u : 256u;
+        const unsigned nb = (S.n + bs - 1u) / bs;
         uint32_t *counters = pad_shift ? S.cnt_pad.as<uint32_t>() : S.cell_count.as<uint32_t>();
-        hipLaunchKernelGGL(bin_kernel, dim3(nb), dim3(256), 0, c->stream, P, S.key.as<uint32_t>(),
+        hipLaunchKernelGGL(bin_kernel, dim3(nb), dim3(bs), 0, c->stream, P, S.key.as<uint32_t>(),
                            S.cursor.as<uint32_t>(), counters, pad_shift);
         if (pad_shift)
-            hipLaunchKernelGGL(unpad_kernel, dim3((ncells + 255u) / 256u), dim3(256), 0, c->stream, ncells, counters, pad_shift,
+            hipLaunchKernelGGL(unpad_kernel, dim3((ncells + bs - 1u) / bs), dim3(bs), 0, c->stream, ncells, counters, pad_shift,
                                S.cell_count.as<uint32_t>());
         MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, S.cell_count.as<uint32_t>(), S.cell_count.as<uint32_t>(),
                                                    (uint64_t)ncells + 1)));
-        hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, c->stream, S.n, S.key.as<uint32_t>(),
+        hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(bs), 0, c->stream, S.n, S.key.as<uint32_t>(),
                            S.cell_count.as<uint32_t>(), S.cursor.as<uint32_t>(), S.tmp_key.as<uint32_t>());
-        hipLaunchKernelGGL(place_order_kernel, dim3((ncells + 3u) / 4u), dim3(256), 0, c->stream, P, ncells, ids_local,
+        hipLaunchKernelGGL(place_order_kernel, dim3(ncells), dim3(64), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
                            S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<float4>(),
                            S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>());
@@ -845,7 +943,10 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     // params_resident: the block uploaded for the previous pass of this search is still valid for this one
     // (a kernel argument, not a copy from pageable memory: the latter makes the host wait for the stream to drain,
     // which would serialise the begin/end pipelining of molar_hip_search_resident_begin)
-    if (!params_resident)
+    // (params_fresh: the plan kernel of this search has already written exactly this block - resident searches)
+    const bool plan_wrote = c->params_fresh && !FILL && !hist_nbins && out_cap == c->plan_out_cap;
+    c->params_fresh = false;
+    if (!params_resident && !plan_wrote)
         hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, c->stream, P, c->params.as<SearchParams>());
     const SearchParams *dP = c->params.as<SearchParams>();
     const SlotDesc *tf = c->slot_desc.as<SlotDesc>();
@@ -1022,6 +1123,67 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         for (int d = 0; d < 3; ++d) ext[d] = c->upper[d] - c->lower[d];   // from_cutoff_and_min_max :112-114
     }
     MH_TRY(dims_from_extents(c, cutoff, ext));
+    const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
+    c->ntasks = ncells * 14ull * (two ? 2ull : 1ull);
+    // every set-1 cell is the first cell of at most 14 (two grids: 28) tasks, so
+    // sum_t ceil(n1(t)/64) <= mult*N1/64 + ntasks
+    c->nslots_bound = (two ? 28ull : 14ull) * (((uint64_t)c->set[0].n + 63ull) / 64ull) + c->ntasks;
+    // entries wrapping in all three dims of a triclinic box use 2-row (<= 1024 rows) or 8-row slots: <= 28 tasks of <= 512 slots
+    c->nslots_bound += 28ull * 512ull;
+    if (c->ntasks >= 0xFFFFFFF0ull || c->nslots_bound >= 0xFFFFFFF0ull || c->ntasks + c->nslots_bound >= 0xFFFFFF00ull)
+        return fail(MOLAR_HIP_ERR_TOO_LARGE, "search plan too large (%llu entries)", (unsigned long long)c->ntasks);
+    MH_TRY(c->task_nb.reserve((c->ntasks + 1) * 4));
+    MH_TRY(c->task_desc.reserve((c->ntasks + 1) * sizeof(TaskDesc)));
+    MH_TRY(c->slot_desc.reserve((c->nslots_bound + 1) * sizeof(SlotDesc)));
+    MH_TRY(c->slot_cnt.reserve((c->nslots_bound + 1) * 4));
+    MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
+    MH_TRY(c->params.reserve(sizeof(SearchParams)));
+    const size_t st_tasks = lookback_state_words(c->ntasks + 1), st_slots = lookback_state_words(c->nslots_bound + 1);
+    MH_TRY(c->scan_state.reserve((st_tasks + st_slots) * 8));
+    MH_TRY(c->task_mu.reserve((c->ntasks + 1) * 4));
+    MH_TRY(c->task_moff.reserve((c->ntasks + 1) * 8));
+    const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
+    auto enqueue_plan = [&]() -> int {
+        Prof prof(c, 0);
+        SearchParams P = make_params(c);
+        // Resident searches (no host round trip between plan and count: the hit-history buffer keeps its size): the plan
+        // kernel also writes the parameter block the count and fill passes read, output capacity included.
+        SearchParams *params_dst = nullptr;
+        c->params_fresh = false;
+        if (!size_masks) {
+            P.out_cap = c->plan_out_cap;
+            params_dst = c->params.as<SearchParams>();
+            c->params_fresh = true;
+        }
+        // ntasks + 1 threads (the last one writes the scan terminators); the same grid zeroes the slot counters and the
+        // descriptors of the two look-back scans of this search
+        const uint64_t nplan = std::max<uint64_t>(std::max<uint64_t>(c->ntasks + 1, c->nslots_bound + 1), st_tasks + st_slots);
+        const unsigned pbs = c->on_side ? 64u : 256u;          // one-wave workgroups on the side stream (place_order_kernel)
+        const unsigned nb = (unsigned)((nplan + pbs - 1) / pbs);
+        switch (c->kind) {
+            case MOLAR_HIP_SEARCH_SINGLE:
+                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(pbs), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
+                                   c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots), params_dst);
+                break;
+            default:   // the three two-grid kinds decode tasks identically
+                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(pbs), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
+                                   c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots), params_dst);
+                break;
+        }
+        // slot index of every task and (fast kinds) its first hit-history unit: one single-pass scan over both
+        MH_TRY((scan_lookback<uint32_t, uint32_t, uint32_t, unsigned long long>(
+            c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), fast_kind ? c->task_mu.as<uint32_t>() : nullptr,
+            c->task_moff.as<unsigned long long>(), c->ntasks + 1, c->scan_state.as<unsigned long long>())));
+        // one record per slot (threads past the tasks blank the slots between the real count and the bound)
+        const unsigned nbs = (unsigned)((c->ntasks + c->nslots_bound + 1 + pbs - 1) / pbs);
+        hipLaunchKernelGGL(slotmap_kernel, dim3(nbs), dim3(pbs), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
+                           c->task_desc.as<TaskDesc>(), fast_kind ? c->task_moff.as<unsigned long long>() : nullptr,
+                           c->slot_desc.as<SlotDesc>(), c->nslots_bound, c->sizes_dev);
+        MH_HIP(hipGetLastError());
+        return 0;
+    };
     // Pipelined search on a context that owns its stream, inputs already in device memory: the grid build goes to the
     // side stream.  It touches only this generation's GridSet (last read by the search two frames back, which has been
     // ended) and its own scan scratch, so it needs to wait for nothing and overlaps the pair kernels of the frame in
@@ -1047,61 +1209,22 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         c->on_side = false;
         MH_TRY(rc);
         MH_HIP(e);
-        MH_HIP(hipStreamWaitEvent(c->stream, c->grid_done, 0));
+        // The plan and the pair kernels of this search need the grid.  A wait command on the main stream costs that stream
+        // ~25 us in front of the plan kernel even when the grid has long been finished (cross-queue barrier packet); the
+        // host waiting for the side stream instead costs nothing there: the frame in flight still has its fill pass
+        // (~1 ms) in front of this search, and what follows is enqueued well inside that time.
+        if (c->env_host_grid_wait) MH_HIP(hipEventSynchronize(c->grid_done));
+        else MH_HIP(hipStreamWaitEvent(c->stream, c->grid_done, 0));
     } else {
         MH_TRY(build_grid(c, c->set[0], q->ids_local || vdw));
         if (two) MH_TRY(build_grid(c, c->set[1], q->ids_local || vdw));
     }
 
-    const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
-    c->ntasks = ncells * 14ull * (two ? 2ull : 1ull);
-    // every set-1 cell is the first cell of at most 14 (two grids: 28) tasks, so
-    // sum_t ceil(n1(t)/64) <= mult*N1/64 + ntasks
-    c->nslots_bound = (two ? 28ull : 14ull) * (((uint64_t)c->set[0].n + 63ull) / 64ull) + c->ntasks;
-    // entries wrapping in all three dims of a triclinic box use 2-row (<= 1024 rows) or 8-row slots: <= 28 tasks of <= 512 slots
-    c->nslots_bound += 28ull * 512ull;
-    if (c->ntasks >= 0xFFFFFFF0ull || c->nslots_bound >= 0xFFFFFFF0ull || c->ntasks + c->nslots_bound >= 0xFFFFFF00ull)
-        return fail(MOLAR_HIP_ERR_TOO_LARGE, "search plan too large (%llu entries)", (unsigned long long)c->ntasks);
-    MH_TRY(c->task_nb.reserve((c->ntasks + 1) * 4));
-    MH_TRY(c->task_desc.reserve((c->ntasks + 1) * sizeof(TaskDesc)));
-    MH_TRY(c->slot_desc.reserve((c->nslots_bound + 1) * sizeof(SlotDesc)));
-    MH_TRY(c->slot_cnt.reserve((c->nslots_bound + 1) * 4));
-    MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
-    const size_t st_tasks = lookback_state_words(c->ntasks + 1), st_slots = lookback_state_words(c->nslots_bound + 1);
-    MH_TRY(c->scan_state.reserve((st_tasks + st_slots) * 8));
-    MH_TRY(c->task_mu.reserve((c->ntasks + 1) * 4));
-    MH_TRY(c->task_moff.reserve((c->ntasks + 1) * 8));
-    const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
-    {
-        Prof prof(c, 0);
-        const SearchParams P = make_params(c);
-        // ntasks + 1 threads (the last one writes the scan terminators); the same grid zeroes the slot counters and the
-        // descriptors of the two look-back scans of this search
-        const uint64_t nplan = std::max<uint64_t>(std::max<uint64_t>(c->ntasks + 1, c->nslots_bound + 1), st_tasks + st_slots);
-        const unsigned nb = (unsigned)((nplan + 255) / 256);
-        switch (c->kind) {
-            case MOLAR_HIP_SEARCH_SINGLE:
-                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
-                                   c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
-                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots));
-                break;
-            default:   // the three two-grid kinds decode tasks identically
-                hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(256), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
-                                   c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
-                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots));
-                break;
-        }
-        // slot index of every task and (fast kinds) its first hit-history unit: one single-pass scan over both
-        MH_TRY((scan_lookback<uint32_t, uint32_t, uint32_t, unsigned long long>(
-            c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), fast_kind ? c->task_mu.as<uint32_t>() : nullptr,
-            c->task_moff.as<unsigned long long>(), c->ntasks + 1, c->scan_state.as<unsigned long long>())));
-        // one record per slot (threads past the tasks blank the slots between the real count and the bound)
-        const unsigned nbs = (unsigned)((c->ntasks + c->nslots_bound + 1 + 255) / 256);
-        hipLaunchKernelGGL(slotmap_kernel, dim3(nbs), dim3(256), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
-                           c->task_desc.as<TaskDesc>(), fast_kind ? c->task_moff.as<unsigned long long>() : nullptr,
-                           c->slot_desc.as<SlotDesc>(), c->nslots_bound);
-        MH_HIP(hipGetLastError());
-    }
+    // (Round 4: the plan kernels - 32 us of small launches - on the side stream behind the grid, with a second generation
+    // of their buffers, one-wave workgroups: bit-identical, not faster; the fill pass of the frame in flight is stretched by
+    // more than the main stream gains, 1.03 -> 1.06-1.12 ms.  Whatever shares the chip with the fill pass costs it at least
+    // its own stand-alone duration.)
+    MH_TRY(enqueue_plan());
     // hit-history buffer of the count -> fill pair: sized exactly (one small read-back; the fused histogram
     // mode does not use it, but sizing it here keeps a later count/fill on the same cached search valid)
     c->mask_units = 0;
@@ -1117,8 +1240,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
 int finish_count(molar_hip_ctx *c) {
     Prof *prof = new Prof(c, 2);
     // (the look-back scan is slower here: ~140 chained tiles take 43 us against 14 us for the three-kernel scan)
-    int rc = (exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(),
-                                                           c->slot_base.as<unsigned long long>(), c->nslots_bound + 1));
+    int rc = scan_slot_counts(c, nullptr);
     delete prof;
     MH_TRY(rc);
     unsigned long long tot = 0;
@@ -1221,14 +1343,26 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
                             void *sizes, ResidentLaunch *L) {
     if (q && q->kind == MOLAR_HIP_SEARCH_WITHIN)
         return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within search yields ids: use molar_hip_search_count + fill_ids");
-    MH_TRY(prepare_search(c, q, /*size_masks=*/false));
+    const unsigned long long a = outP.cap / 8u, b = outD.cap / 4u;
+    const unsigned long long cap0 = a < b ? a : b;
+    // `sizes` is pinned host memory: the kernels write the two sizes there themselves (slotmap_kernel the hit-history
+    // units, slot_offsets_kernel the grand total) - no copy commands behind the fill pass
+    void *sizes_dev = nullptr;
+    if (hipHostGetDevicePointer(&sizes_dev, sizes, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        sizes_dev = nullptr;
+    }
+    c->plan_out_cap = cap0;
+    c->sizes_dev = (unsigned long long *)sizes_dev;
+    const int prc = prepare_search(c, q, /*size_masks=*/false);
+    c->plan_out_cap = ~0ull;
+    c->sizes_dev = nullptr;
+    MH_TRY(prc);
     ++c->search_serial;
     *L = ResidentLaunch{};
     L->degenerate = c->have_search;
     if (L->degenerate) return 0;
     const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
-    const unsigned long long a = outP.cap / 8u, b = outD.cap / 4u;
-    const unsigned long long cap0 = a < b ? a : b;
     L->maskcap0 = c->maskbuf.cap / 256u;
     // one parameter block serves both passes: the count pass ignores the output capacity
     MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, cap0));
@@ -1238,14 +1372,15 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     }
     {
         Prof prof(c, 2);
-        MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->slot_cnt.as<uint32_t>(), c->slot_base.as<unsigned long long>(),
-                                                             c->nslots_bound + 1)));
+        MH_TRY(scan_slot_counts(c, (unsigned long long *)sizes_dev));
     }
     if (cap0) MH_TRY(launch_pairs<true>(c, outP.as<uint2>(), outD.as<float>(), nullptr, 0, 0.f, 0.f, nullptr, cap0,
                                         /*params_resident=*/true));
-    MH_HIP(hipMemcpyAsync(sizes, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8, hipMemcpyDeviceToHost, c->stream));
-    if (fast_kind)
-        MH_HIP(hipMemcpyAsync((char *)sizes + 8, c->task_moff.as<unsigned long long>() + c->ntasks, 8, hipMemcpyDeviceToHost, c->stream));
+    if (!sizes_dev) {
+        MH_HIP(hipMemcpyAsync(sizes, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8, hipMemcpyDeviceToHost, c->stream));
+        if (fast_kind)
+            MH_HIP(hipMemcpyAsync((char *)sizes + 8, c->task_moff.as<unsigned long long>() + c->ntasks, 8, hipMemcpyDeviceToHost, c->stream));
+    }
     L->cap0 = cap0;
     return 0;
 }
@@ -1342,12 +1477,16 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     c->set = c->set_store[slot];         // this ticket's grid generation (the other one may still be read by the frame in flight)
     c->want_side = !c->env_no_side;
     c->side_wait = c->gen_free[slot];    // an asynchronous histogram call may have been the last reader of this generation
-    // The grid of this frame is built on the side stream beside the kernels of the frame in flight.  Beside that frame's
-    // COUNT pass it is a competitor (both are bound by instruction issue); beside its FILL pass, which waits on its stores, it
-    // is nearly free: so it starts when that count pass has ended.
-    c->side_wait2 = (c->count_done_set && !c->env_grid_early) ? c->count_done : nullptr;
-    if (!c->count_done) MH_HIP(hipEventCreateWithFlags(&c->count_done, hipEventDisableTiming));
-    c->record_count_done = true;
+    // The grid of this frame is built on the side stream beside the kernels of the frame in flight, in one-wave workgroups
+    // (place_order_kernel) so that it gets wave slots while they run.  Nothing about that is free: whatever shares the chip
+    // with a pair kernel stretches it by about its own stand-alone duration (round 4: 115 us of grid kernels cost the fill
+    // pass 40-60 us when they ran under it, the count pass 35-50 us when they run under that; frames/s the same in six
+    // alternations).  The grid starts as soon as its generation is free - it then runs under the COUNT pass of the frame in
+    // flight, whose workgroups leave one wave slot per SIMD open, and the fill pass has the chip and the write path to
+    // itself.  MOLAR_HIP_GRID_LATE holds it back until that count pass has ended (the round-3 order).
+    c->side_wait2 = (c->count_done_set && c->env_grid_late) ? c->count_done : nullptr;
+    if (c->env_grid_late && !c->count_done) MH_HIP(hipEventCreateWithFlags(&c->count_done, hipEventDisableTiming));
+    c->record_count_done = c->env_grid_late;
     const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 16 * slot, &L);
     c->record_count_done = false;
     c->want_side = false;

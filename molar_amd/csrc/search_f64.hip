@@ -450,8 +450,10 @@ int molar_hip_search_count_f64(molar_hip_ctx *c, const molar_hip_search_desc_f64
                     if (slots.size() >= 0x7FFFFF00ull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "search_f64: plan too large");
                 }
     Z.nslots = (uint32_t)slots.size();
-    Z.have = true;
+    Z.have = false;           // until the count below has gone through: a failed step must not leave a half-built cached search
+    Z.total = 0;
     if (Z.nslots == 0) {
+        Z.have = true;
         if (out_count) *out_count = 0;
         return MOLAR_HIP_OK;
     }
@@ -487,6 +489,7 @@ int molar_hip_search_count_f64(molar_hip_ctx *c, const molar_hip_search_desc_f64
     MH_HIP(hipMemcpyAsync(Z.slot_base.p, base.data(), base.size() * 8, hipMemcpyHostToDevice, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
     Z.total = run;
+    Z.have = true;
     if (out_count) *out_count = run;
     return MOLAR_HIP_OK;
 }

@@ -184,3 +184,22 @@ def test_shell_argument_errors():
         api.membrane_nth_shell_patches(v, po, pi, nv, nb, 2)              # more vertices than the lipid's slots hold
     with pytest.raises(MolarHipError):
         api.membrane_nth_shell_patches(v, po, pi, np.array([1, 1], np.uint32), nb, 0)       # n_shells < 1
+
+
+def test_invalid_lipid_with_oversized_vertex_count_is_not_read_past_its_slots():
+    """A lipid the smoothing pass dropped keeps whatever vertex count it had; as a member of a valid lipid's shell its
+    neighbour list is walked, and a stale / garbage count must not send the walk past the lipid's slots (the ABI has no
+    array lengths: round-3 advisor finding, a segfault with nvert = 4e8)."""
+    valid = np.array([1, 0], np.uint8)
+    po = np.array([0, 1, 2], np.uint64)
+    pi = np.array([1, 0], np.uint64)
+    nb = np.full(10, 2**40, np.uint64)            # ids >= K are skipped
+    nb[0] = 1                                     # lipid 0 (slots 0..4): neighbour 1
+    nb[5] = 0                                     # lipid 1 (slots 5..9): neighbour 0
+    for bad in (6, 400_000_000, 0xFFFFFFFF):
+        nv = np.array([1, bad], np.uint32)
+        off, ids = api.membrane_nth_shell_patches(valid, po, pi, nv, nb, 3)
+        assert ids[int(off[0]): int(off[1])].tolist() == [0, 1]
+        assert ids[int(off[1]): int(off[2])].tolist() == [0]          # not valid: keeps its patch
+        m, g = api.membrane_smooth_curvature(valid, po, nv, nb, 3, np.array([1.0, 5.0], np.float32), np.array([2.0, 7.0], np.float32))
+        assert m[0] == np.float32(1.0) and g[0] == np.float32(2.0) and m[1] == np.float32(5.0)   # own value + itself via the way back... 
