@@ -537,6 +537,23 @@ def main():
         torch.cuda.synchronize()
 
     fits = []
+    last_results = []      # (frame number, pair count, pairs device address, distances device address) of the newest results
+
+    def checksum_planes(cnt, pp, dp):
+        """Order-sensitive 64-bit checksums of a result's pair plane and distance plane where they lie in HBM: sum of
+        value_i * (2 i + 1) in wrapping int64 arithmetic over the (i, j) records as u64 words / the distances' bit patterns."""
+        if cnt == 0:
+            return 0, 0
+
+        class _Dev:
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+        w = torch.arange(cnt, device=device, dtype=torch.int64) * 2 + 1
+        pv = torch.as_tensor(_Dev(pp, cnt, "<i8"), device=device)
+        dv = torch.as_tensor(_Dev(dp, cnt, "<i4"), device=device).to(torch.int64)
+        a, b = int((pv * w).sum().item()), int((dv * w).sum().item())
+        del w, pv, dv
+        return a, b
 
     def run_steps(first, count):
         """`count` steps starting at frame `first`, dealt round-robin to the S contexts (one host thread each;
@@ -553,13 +570,18 @@ def main():
                 d.xyz1 = fr.data_ptr()
                 t = eng.search_resident_begin(d)
                 if prev is not None:
-                    res.append((eng.search_resident_end(prev)[0], None))
+                    r_ = eng.search_resident_end(prev)
+                    res.append((r_[0], None))
+                    last_results.append((first + s - 1,) + tuple(r_))
                 prev = t
                 if not overlap:      # the fit of frame s runs behind its search on the same stream
                     out = eng.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
                     fits.append(float(out["rmsd"][0]))
             if prev is not None:
-                res.append((eng.search_resident_end(prev)[0], None))
+                r_ = eng.search_resident_end(prev)
+                res.append((r_[0], None))
+                last_results.append((first + count - 1,) + tuple(r_))
+            del last_results[:-2]      # the two result sets of the context hold the last two frames
             rms = collect_fits(0, count) if overlap else fits[-count:]
         elif S == 1:
             res = [step(eng, first + s) for s in range(count)]
@@ -608,6 +630,30 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     pairs, rsum = sum(counts), sum(rms)
+    # ---- self-check of the timed code path (untimed, every run): the pair lists of the LAST TWO timed frames are still in
+    # the context's two result sets.  A fresh context recomputes those frames alone (one search at a time, fit on the same
+    # stream): pair counts, order-sensitive 64-bit checksums of both result planes and the RMSD must agree.  --verify
+    # additionally recomputes ALL frames' counts and RMSDs.
+    t_chk = time.perf_counter()
+    self_check = None
+    if S == 1 and pipelined and overlap and K >= 2 and len(last_results) == 2:
+        self_check = True
+        e3 = api.Engine(local_rank)
+        for (fno, cnt, pp, dp) in last_results:
+            mine = checksum_planes(cnt, pp, dp)
+            fr = frames[fno % nres].clone()
+            torch.cuda.synchronize()           # the copy runs on torch's stream, the engine on its own
+            c2, p2, d2 = e3.search_resident(api.SEARCH_SINGLE, CUTOFF, fr, box=box, pbc=7)
+            theirs = checksum_planes(c2, p2, d2)
+            out = e3.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
+            r_timed, r_alone = rms[fno - W], float(out["rmsd"][0])
+            ok = cnt == c2 and mine == theirs and abs(r_timed - r_alone) <= 1e-6 * abs(r_alone) + 1e-9
+            if not ok:
+                self_check = False
+                print(f"bench.py self-check: rank {rank} frame {fno}: pairs {cnt} vs {c2}, checksums {mine} vs {theirs}, "
+                      f"rmsd {r_timed!r} vs {r_alone!r}", file=sys.stderr)
+        del e3
+    self_check_s = time.perf_counter() - t_chk
     # ---- a second, untimed pass of the same steps with HIP events around every kernel group (per-kernel times and
     # the roofline of the fill kernel).  The events sit on each engine's own stream; with more than one context per GPU
     # the other contexts' kernels overlap the bracketed ones, so this pass runs the contexts one frame at a time.
@@ -628,8 +674,12 @@ def main():
 
     # end-of-run reductions (RCCL when world > 1): integer pair count, max-over-ranks wall time
     from molar_amd.distributed import max_over_ranks, reduce_counts
+    from molar_amd.distributed import gather_float64
     total_pairs = float(reduce_counts([pairs], device=cdev)[0])
     t = max_over_ranks(elapsed, device=cdev)
+    per_rank_s = [float(v[0]) for v in gather_float64([elapsed], device=cdev)]        # a straggling rank shows up here
+    checks = reduce_counts([0 if self_check is None else 1, 1 if self_check is False else 0], device=cdev)
+    self_check_all = None if int(checks[0]) == 0 else (int(checks[1]) == 0)
     verified = None
     if args.verify:
         # Every rank's per-frame results travel to rank 0 (one integer all_reduce of a [world, K] table of pair counts, and
@@ -698,7 +748,14 @@ def main():
                 "measure_overlapped_with_search": overlap,
             },
             "preheat_ms": preheat_ms,
-            "verified_against_single_context": verified,
+            "per_rank_fps": [K / v for v in per_rank_s],
+            "verified_against_single_context": self_check_all if verified is None else (verified and self_check_all is not False),
+            "verification": ("last two timed frames of every rank recomputed on a fresh single context after the timed region: "
+                             "pair counts, order-sensitive 64-bit checksums of the pair and distance planes in HBM, RMSD (1e-6 rel)"
+                             + ("; --verify: every frame's pair count and RMSD as well" if verified is not None else "")
+                             if self_check_all is not None else
+                             ("--verify: every frame's pair count and RMSD" if verified is not None else None)),
+            "self_check_s": self_check_s,
             "kernel_ms_per_frame": {k: v[0] / KP for k, v in prof.items()},
             "kernel_ms_note": f"HIP-event times from a separate untimed pass of {KP} of the same steps on one context (events are "
                               "not recorded inside the timed region); grid_build (side stream) and measure (second context) "
@@ -720,7 +777,7 @@ def main():
                                                 idx_np.astype(np.uint64))
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line))
-        if verified is False:
+        if verified is False or self_check_all is False:
             exit_code = 1
     if overlap:
         for q in jobs:

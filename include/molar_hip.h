@@ -168,6 +168,17 @@ int molar_hip_search_fill_usize(molar_hip_ctx *ctx, uint64_t *i, uint64_t *j, fl
 /* WITHIN results (DistanceSearchOutput for usize, :10-14): ids of set-1 atoms, duplicates kept
  * exactly as the reference emits them (callers sort+dedup, selection_expr.rs:112). */
 int molar_hip_search_fill_ids(molar_hip_ctx *ctx, uint64_t *ids);
+/* `within <cutoff> [pbc] of <inner>` as the SET its callers keep (LogicalNode::Within, selection/ast.rs:589-631): the raw
+ * stream of distance_search_within(_pbc) (distance_search.rs:519-598, one id per plan entry in which the atom has a hit)
+ * goes through SortedSet::from_unsorted (selection_expr.rs:112), so what reaches the user is the sorted, de-duplicated
+ * ids of the first-set atoms with a second-set atom within the cutoff.  This pair computes exactly that set without
+ * the stream: same grid, same plan entries (wrap / drop rules, wrapped entries through PeriodicBox::distance_squared
+ * over the entry's dims), but an atom stops looking at its first hit in ANY entry, and the set comes out of a flag
+ * array in ascending order.  `desc` must be of kind MOLAR_HIP_SEARCH_WITHIN (non-periodic: lower3 / upper3 as for the
+ * stream form); ids are what the stream would carry (idx1 values, or 0..n1 with ids_local).  The `self` keyword
+ * (:627-629) is the caller's union with the inner selection.  ids: uint64[count], host or device. */
+int molar_hip_within_count(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_count);
+int molar_hip_within_fill(molar_hip_ctx *ctx, uint64_t *ids);
 /* Grid dims of the cached search (Grid::get_dims, :212-214). */
 int molar_hip_search_grid_dims(molar_hip_ctx *ctx, uint64_t dims[3]);
 /* Device-resident result of the cached search: fills ctx-owned buffers (reused across frames)

@@ -608,6 +608,21 @@ inline std::vector<usize> distance_search_within_pbc(Float cutoff, const SelBoun
     return detail::run_search<usize>(d1.ctx(), detail::desc(MOLAR_HIP_SEARCH_WITHIN, cutoff, d1, &d2, false, &pbox, pbc_dims));
 }
 
+// `within <cutoff> [pbc] of <inner>` as the selection keeps it (LogicalNode::Within, selection/ast.rs:589-631): the sorted,
+// de-duplicated ids of the atoms of d1 with an atom of d2 within the cutoff - SortedSet::from_unsorted of the stream the
+// two functions above return (selection_expr.rs:112), computed without the stream (molar_hip_within_count / _fill).
+// lower / upper: the non-periodic form's extents (ast.rs:597-602); pbox: the periodic form.
+inline std::vector<usize> within_set(Float cutoff, const SelBound &d1, const SelBound &d2, const PeriodicBox *pbox, PbcDims pbc_dims,
+                                     const Vector3f *lower = nullptr, const Vector3f *upper = nullptr) {
+    auto d = detail::desc(MOLAR_HIP_SEARCH_WITHIN, cutoff, d1, &d2, false, pbox, pbc_dims);
+    if (lower && upper) { d.lower3 = &lower->x; d.upper3 = &upper->x; }
+    uint64_t n = 0;
+    check(molar_hip_within_count(d1.ctx(), &d, &n));
+    std::vector<uint64_t> ids(n);
+    if (n) check(molar_hip_within_fill(d1.ctx(), ids.data()));
+    return std::vector<usize>(ids.begin(), ids.end());
+}
+
 // ---------------------------------------------------------------- bilayer frames (molar_membrane/src/lib.rs:410-454)
 // One frame of Membrane::compute per push, chained on the engine's stream (molar_hip_membrane_frame_begin / _end):
 // unwrap -> markers -> patches -> initial normals -> smoothing -> tail order, two frames in flight, the valid flags of

@@ -306,6 +306,27 @@ class Engine:
         check(self.lib.molar_hip_search_fill_usize(self.ctx, i.ctypes.data, j.ctypes.data, d.ctypes.data))
         return i, j, d
 
+    def within_set(self, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, ids_local=False, lower=None,
+                   upper=None, device_out=None):
+        """`within` as the set its callers keep (molar_hip_within_count + _fill): sorted, de-duplicated ids of the atoms of
+        set 1 with an atom of set 2 within the cutoff - np.unique of the stream search_count(SEARCH_WITHIN) +
+        search_fill_ids returns, without the stream.  Returns a uint64 array (or, with `device_out` = a callable that
+        allocates a device int64 tensor of a given length, that tensor)."""
+        d, keep = self._search_desc(SEARCH_WITHIN, cutoff, xyz1, idx1, xyz2, idx2, box, pbc, None, None, ids_local, lower, upper)
+        cnt = C.c_uint64(0)
+        check(self.lib.molar_hip_within_count(self.ctx, C.byref(d), C.byref(cnt)))
+        self._keep = keep
+        n = int(cnt.value)
+        if device_out is not None:
+            out = device_out(n)
+            if n:
+                check(self.lib.molar_hip_within_fill(self.ctx, out.data_ptr()))
+            return out
+        ids = np.empty(n, np.uint64)
+        if n:
+            check(self.lib.molar_hip_within_fill(self.ctx, ids.ctypes.data))
+        return ids
+
     def search_fill_ids(self, count):
         ids = np.empty(count, np.uint64)
         check(self.lib.molar_hip_search_fill_ids(self.ctx, ids.ctypes.data))
@@ -1232,15 +1253,13 @@ class Sel:
             lo, up = self.min_max()                                   # ast.rs:600-602
             lo = lo + (np.float32(-cutoff) - np.float32(1.1920929e-07))
             up = up + (np.float32(cutoff) + np.float32(1.1920929e-07))
-            n = eng.search_count(SEARCH_WITHIN, cutoff, self.state.coords, self.index, inner.state.coords, inner.index,
-                                 lower=lo, upper=up)
+            ids = eng.within_set(cutoff, self.state.coords, self.index, inner.state.coords, inner.index, lower=lo, upper=up)
         else:
-            n = eng.search_count(SEARCH_WITHIN, cutoff, self.state.coords, self.index, inner.state.coords, inner.index,
+            ids = eng.within_set(cutoff, self.state.coords, self.index, inner.state.coords, inner.index,
                                  box=self.require_box(), pbc=mask)
-        ids = eng.search_fill_ids(n)
         if include_inner:
-            ids = np.concatenate([ids, inner.index])
-        return np.unique(ids)
+            ids = np.union1d(ids, inner.index)
+        return ids.astype(np.uint64)
 
     def unwrap_connectivity(self, cutoff, dims=PBC_FULL):
         """Modify::unwrap_connectivity_dim (modify.rs:72-131): neighbour search with LOCAL ids under full

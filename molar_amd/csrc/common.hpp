@@ -195,6 +195,11 @@ struct molar_hip_ctx {
     mh::DevBuf hist_edges;     // f32[nbins + 1]: smallest d2 that reaches each bin (hist_kernel), for the cached (min, max, nbins)
     float edges_min = 0.f, edges_max = 0.f;
     size_t edges_nbins = 0;    // 0: no table cached
+    // `within` as a set (molar_hip_within_count / _fill)
+    mh::DevBuf w_flags, w_part_cnt, w_part, w_tile_cnt, w_tile_off;
+    uint64_t within_nflags = 0, within_total = 0;
+    bool have_within = false;
+    bool skip_plan = false;    // set around prepare_search by callers that do not walk slots
     mh::DevBuf task_mu;        // u32 per task (+1): 64-word hit-history units of the task's slots
     mh::DevBuf task_moff;      // u64 per task (+1): exclusive scan of task_mu
     mh::DevBuf maskbuf;        // hit bits recorded by the count pass, replayed by the fill pass

@@ -121,6 +121,7 @@ struct Task {
     uint32_t rps;             // rows of the first cell per slot: 64, or 8 for entries that run the
                               // triclinic candidate loop (~50x the arithmetic per candidate)
     uint32_t cb;              // second cell (for its bounding box)
+    uint32_t ca;              // first cell (decode_task only; the slot records do not carry it)
     uint32_t wrap_b;          // dims in which the SECOND cell is the one that wrapped (subset of wrap)
     uint32_t wrap;
     bool tri;
@@ -138,6 +139,7 @@ __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     T.tri = false;
     T.a0 = T.b0 = T.n1 = T.n2 = 0;
     T.cb = 0;
+    T.ca = 0;
     T.wrap_b = 0;
     T.rps = 64u;
     T.wrap = 0;
@@ -189,6 +191,7 @@ __device__ __forceinline__ Task decode_task(const SearchParams &P, uint64_t t) {
     // is latency-bound, so these few tasks are cut into many short slots - 2 rows, or 8 for very large cells)
     T.rps = (P.use_box && wrap == MOLAR_HIP_PBC_FULL && P.box.nshift != 0 && T.n1 <= 4096u) ? (T.n1 <= 1024u ? 2u : 8u) : 64u;
     T.cb = cb;
+    T.ca = ca;
     if (UNIFORM) {
         T.cb = __builtin_amdgcn_readfirstlane(T.cb);
         T.rps = __builtin_amdgcn_readfirstlane(T.rps);   // one task per wave: keep the descriptor in SGPRs

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
                                                           float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
                                                           float4 *__restrict__ aabb, float4 *__restrict__ perm,
                                                           float4 *__restrict__ chunk_aabb, uint4 *__restrict__ h16,
-                                                          float4 *__restrict__ cell_org) {
+                                                          float4 *__restrict__ cell_org, int big_elsewhere) {
     // One wave per workgroup (5 KB of LDS): the grid of the NEXT frame is built on the side stream while the fill pass of
     // the frame in flight holds every wave slot of the chip with one-wave workgroups.  A freed slot takes a one-wave
     // workgroup of either queue; a four-wave workgroup needs four free slots on ONE compute unit at the same moment and
@@ -209,6 +209,17 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
     for (uint32_t t = lane; t < n; t += 64u) {
         const uint32_t mine = small ? keys[t] : tmp_key[s + t];
         uint32_t rank = 0;
+        if (!small && big_elsewhere) {
+            // a cell of more than 512 atoms: place_big_kernel ranks it with one wave per 64 atoms (this wave alone would
+            // walk n^2 / 64 keys per lane); here only the bounding box
+            const uint32_t k = mine & 0x7FFFFFFFu;
+            const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
+            const CellOfAtom ca = classify(P, load_pos(P.xyz, a));
+            lo[0] = fminf(lo[0], ca.pos.x); hi[0] = fmaxf(hi[0], ca.pos.x);
+            lo[1] = fminf(lo[1], ca.pos.y); hi[1] = fmaxf(hi[1], ca.pos.y);
+            lo[2] = fminf(lo[2], ca.pos.z); hi[2] = fmaxf(hi[2], ca.pos.z);
+            continue;
+        }
         if (small) {
             const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
             uint32_t q = 0;
@@ -322,6 +333,41 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
         if (lane == 0) {
             chunk_aabb[2 * (ubase + k)] = make_float4(l3[0], l3[1], l3[2], 0.f);
             chunk_aabb[2 * (ubase + k) + 1] = make_float4(h3[0], h3[1], h3[2], 0.f);
+        }
+    }
+}
+
+// Cells of more than ORDER_MAX atoms (a cutoff that is large against the box: a few cells of thousands of atoms): the
+// placement of place_order_kernel - rank by (wrapped, input index) among the cell's keys - with one wave per 64 ATOMS
+// instead of one per cell.  Wave (c, b) ranks atoms b*64 .. b*64+63 of cell c against all of its keys (wave-uniform
+// reads, L2-resident); cells within ORDER_MAX are left to place_order_kernel.  With eight cells of 12 500 atoms the
+// single wave per cell took 59 ms.
+__global__ void __launch_bounds__(64) place_big_kernel(BinParams P, uint32_t ncells, int ids_local, const uint32_t *__restrict__ cell_start,
+                                                       const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
+                                                       float4 *__restrict__ sorted, float *__restrict__ sorted_vdw) {
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    const uint32_t s = cell_start[c], e = cell_start[c + 1], n = e - s;
+    if (n <= ORDER_MAX) return;
+    for (uint32_t t0 = blockIdx.y * 64u; t0 < n; t0 += gridDim.y * 64u) {
+        const uint32_t t = t0 + lane;
+        const uint32_t mine = t < n ? tmp_key[s + t] : 0xFFFFFFFFu;
+        uint32_t rank = 0;
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(tmp_key + ((s + 3u) & ~3u));       // aligned middle part
+        const uint32_t head = ((s + 3u) & ~3u) - s < n ? ((s + 3u) & ~3u) - s : n;
+        for (uint32_t q = 0; q < head; ++q) rank += tmp_key[s + q] < mine ? 1u : 0u;
+        const uint32_t nq = (n - head) >> 2;
+        for (uint32_t q = 0; q < nq; ++q) {
+            const uint4 v = k4[q];
+            rank += (v.x < mine ? 1u : 0u) + (v.y < mine ? 1u : 0u) + (v.z < mine ? 1u : 0u) + (v.w < mine ? 1u : 0u);
+        }
+        for (uint32_t q = head + 4u * nq; q < n; ++q) rank += tmp_key[s + q] < mine ? 1u : 0u;
+        if (t < n) {
+            const uint32_t k = mine & 0x7FFFFFFFu;
+            const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
+            const CellOfAtom ca = classify(P, load_pos(P.xyz, a));
+            const uint32_t id = ids_local ? k : (uint32_t)a;
+            sorted[s + rank] = make_float4(ca.pos.x, ca.pos.y, ca.pos.z, __uint_as_float(id));
+            if (vdw) sorted_vdw[s + rank] = vdw[k];
         }
     }
 }
@@ -765,10 +811,21 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
                                                    (uint64_t)ncells + 1)));
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(bs), 0, c->stream, S.n, S.key.as<uint32_t>(),
                            S.cell_count.as<uint32_t>(), S.cursor.as<uint32_t>(), S.tmp_key.as<uint32_t>());
+        // cells of more than 512 atoms are the rule (mean population above 384; the headline frame has 261) and the grid
+        // is small enough for a (cell, 64-atom block) launch: such cells are ranked by place_big_kernel.  (Crowded cells
+        // in a grid that is sparse on average keep the single wave: correct, slow.)
+        const bool big = (uint64_t)S.n > 384ull * ncells && ncells <= 4096u;
         hipLaunchKernelGGL(place_order_kernel, dim3(ncells), dim3(64), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
                            S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<float4>(),
-                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>());
+                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>(), big ? 1 : 0);
+        if (big) {
+            unsigned by = (S.n + 63u) / 64u;
+            if (by > 2048u) by = 2048u;
+            while (by > 1u && (uint64_t)by * ncells > (1ull << 20)) by >>= 1;
+            hipLaunchKernelGGL(place_big_kernel, dim3(ncells, by), dim3(64), 0, c->stream, P, ncells, ids_local, S.cell_count.as<uint32_t>(),
+                               S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(), S.d_vdw ? S.sorted_vdw.as<float>() : nullptr);
+        }
         MH_HIP(hipGetLastError());
     }
     return 0;
@@ -1224,7 +1281,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     // of their buffers, one-wave workgroups: bit-identical, not faster; the fill pass of the frame in flight is stretched by
     // more than the main stream gains, 1.03 -> 1.06-1.12 ms.  Whatever shares the chip with the fill pass costs it at least
     // its own stand-alone duration.)
-    MH_TRY(enqueue_plan());
+    if (!c->skip_plan) MH_TRY(enqueue_plan());
     // hit-history buffer of the count -> fill pair: sized exactly (one small read-back; the fused histogram
     // mode does not use it, but sizing it here keeps a later count/fill on the same cached search valid)
     c->mask_units = 0;
@@ -1248,6 +1305,117 @@ int finish_count(molar_hip_ctx *c) {
     c->total = tot;
     c->have_search = true;
     return 0;
+}
+
+// ================================================================= `within` as a set (selection/ast.rs:589-631)
+//
+// What a caller of distance_search_within(_pbc) keeps is the SET of first-set atoms with a second-set atom in range: the
+// raw stream (one id per plan entry in which the atom has a hit, :271-322,519-598) goes through SortedSet::from_unsorted
+// (selection_expr.rs:112).  A set needs no stream, no offsets and no second pass - and an atom that has been found needs
+// no further candidates, in ANY of its up to 28 plan entries:
+//  * within_partners_kernel inverts the plan (same decode_task as every other kernel, so the same wrap / drop rules and
+//    the same incomplete neighbourhoods of sheared boxes): per first-set cell the list of (second-set cell, wrap dims)
+//    it meets, from both halves of every entry;
+//  * within_flags_kernel: one wave per (first-set cell, share of its 64-row blocks) walks that list with a mask of the
+//    rows still looking; per partner the rows that cannot reach its bounding box are left out (plain entries: the
+//    exact f32 lower bound of run_fast), the partner's atoms are loaded 64 at a time, every remaining row is fetched
+//    with one LDS broadcast and tested with the reference's arithmetic (PeriodicBox::distance_squared over the entry's
+//    wrap dims for wrapped entries); a row leaves the mask at its first hit, the wave leaves the list when the mask is
+//    empty; found rows set flags[id];
+//  * ids are indices into a sorted selection (or 0..n), so the flagged positions in ascending order ARE the sorted,
+//    de-duplicated result: a count per 2048-flag tile, a scan of the tile counts and one compaction pass.
+constexpr uint32_t WITHIN_MAX_PART = 28;
+
+__global__ void __launch_bounds__(256) within_partners_kernel(const SearchParams *__restrict__ Pp, uint32_t *__restrict__ part_cnt,
+                                                              uint32_t *__restrict__ part) {
+    const SearchParams &P = *Pp;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.ntasks) return;
+    const Task T = decode_task<MOLAR_HIP_SEARCH_WITHIN, false>(P, t);
+    if (!T.valid) return;
+    const uint32_t s = atomicAdd(&part_cnt[T.ca], 1u);
+    if (s < WITHIN_MAX_PART) part[(size_t)T.ca * WITHIN_MAX_PART + s] = T.cb | (T.wrap << 28);
+}
+
+__global__ void __launch_bounds__(64) within_flags_kernel(const SearchParams *__restrict__ Pp, const uint32_t *__restrict__ part_cnt,
+                                                          const uint32_t *__restrict__ part, uint8_t *__restrict__ flags,
+                                                          uint32_t nsplit) {
+    __shared__ float4 la[64];
+    const SearchParams &P = *Pp;
+    const uint32_t lane = threadIdx.x, ca = blockIdx.x, split = blockIdx.y;
+    const uint32_t a0 = P.csa[ca], n1 = P.csa[ca + 1] - a0;
+    uint32_t np = part_cnt[ca];
+    if (n1 == 0u || np == 0u) return;
+    if (np > WITHIN_MAX_PART) np = WITHIN_MAX_PART;
+    const float cutoff2 = P.cutoff2;
+    for (uint32_t i0 = split * 64u; i0 < n1; i0 += nsplit * 64u) {
+        const uint32_t rows = n1 - i0 < 64u ? n1 - i0 : 64u;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < rows) a = gload4(P.sa, a0 + i0 + lane);
+        __builtin_amdgcn_wave_barrier();
+        la[lane] = a;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long full = rows == 64u ? ~0ull : ((1ull << rows) - 1ull);
+        unsigned long long live = full;                      // rows still looking for a partner atom
+        for (uint32_t pi = 0; pi < np && live; ++pi) {
+            const uint32_t e = __builtin_amdgcn_readfirstlane(part[(size_t)ca * WITHIN_MAX_PART + pi]);
+            const uint32_t cb = e & 0x0FFFFFFFu, wrap = e >> 28;
+            const uint32_t b0 = P.csb[cb], n2 = P.csb[cb + 1] - b0;
+            unsigned long long cand = live;
+            if (!wrap) {       // rows that cannot reach the partner's box: the f32 lower bound of every d2 of the row (run_fast)
+                const float4 lo = gload4(P.aabb_b, 2 * cb), hi = gload4(P.aabb_b, 2 * cb + 1);
+                cand &= __builtin_amdgcn_ballot_w64(!(aabb_d2(a.x, a.y, a.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > cutoff2));
+            }
+            for (uint32_t j0 = 0; j0 < n2 && cand; j0 += 64u) {
+                const bool inb = j0 + lane < n2;
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inb) q = gload4(P.sb, b0 + j0 + lane);
+                unsigned long long rm = cand;
+                while (rm) {
+                    const uint32_t r = (uint32_t)__builtin_ctzll(rm);
+                    rm &= rm - 1ull;
+                    const float4 p = lload4(la, r);                                  // one broadcast ds_read per row
+                    const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;      // p2 - p1
+                    const float d2 = wrap ? wrapped_d2_exact(P, wrap, dx, dy, dz)    // :306-321 (distance_squared over the entry's dims)
+                                          : (dx * dx + dy * dy) + dz * dz;          // :281-292
+                    if (__builtin_amdgcn_ballot_w64(inb && d2 <= cutoff2)) {         // `break` at the first hit (:289, :318)
+                        live &= ~(1ull << r);
+                        cand &= ~(1ull << r);
+                    }
+                }
+            }
+        }
+        const unsigned long long found = full & ~live;
+        if ((found >> lane) & 1ull) flags[__float_as_uint(a.w)] = 1u;
+    }
+}
+
+// flags -> count per tile of 2048 (8 flags per thread)
+__global__ void __launch_bounds__(256) flag_tile_count_kernel(const uint8_t *__restrict__ flags, uint64_t n, uint32_t *__restrict__ tile_cnt) {
+    __shared__ uint32_t part[4];
+    const uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 8u;
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 8u; ++k) v += (i + k < n && flags[i + k]) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// positions of the set flags, ascending, as u64
+__global__ void __launch_bounds__(256) flag_compact_kernel(const uint8_t *__restrict__ flags, uint64_t n, const unsigned long long *__restrict__ tile_off,
+                                                           unsigned long long *__restrict__ out) {
+    const uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 8u;
+    uint32_t f[8], v = 0;
+    for (uint32_t k = 0; k < 8u; ++k) {
+        f[k] = (i + k < n && flags[i + k]) ? 1u : 0u;
+        v += f[k];
+    }
+    uint32_t tot;
+    uint32_t at = block_exclusive_scan<uint32_t>(v, &tot);
+    unsigned long long o = tile_off[blockIdx.x] + at;
+    for (uint32_t k = 0; k < 8u; ++k)
+        if (f[k]) out[o++] = i + k;
 }
 
 // the pinned ring is worth its host threads for results of some size that go to memory the runtime cannot DMA into
@@ -1698,4 +1866,76 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
     return MOLAR_HIP_OK;
 }
 
+int molar_hip_within_count(molar_hip_ctx *c, const molar_hip_search_desc *q, uint64_t *out_count) {
+    if (!c || !q) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within: null argument");
+    if (q->kind != MOLAR_HIP_SEARCH_WITHIN) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within: the request must be of kind MOLAR_HIP_SEARCH_WITHIN");
+    c->have_within = false;
+    c->skip_plan = true;                          // no slots, no offsets: this path walks cells
+    const int prc = prepare_search(c, q, /*size_masks=*/false);
+    c->skip_plan = false;
+    MH_TRY(prc);
+    c->have_search = false;                       // not a cached search for the fill calls of the stream form
+    const uint64_t nflags = q->ids_local ? c->set[0].n : (q->idx1 ? q->natoms1 : c->set[0].n);
+    c->within_nflags = nflags;
+    c->within_total = 0;
+    if (out_count) *out_count = 0;
+    if (c->set[0].n == 0 || c->set[1].n == 0 || nflags == 0) {
+        c->have_within = true;
+        return MOLAR_HIP_OK;
+    }
+    const uint32_t ncells = c->dims[0] * c->dims[1] * c->dims[2];
+    const uint64_t ntiles = (nflags + 2047) / 2048;
+    MH_TRY(c->w_flags.reserve(nflags));
+    MH_TRY(c->w_part_cnt.reserve((size_t)ncells * 4));
+    MH_TRY(c->w_part.reserve((size_t)ncells * WITHIN_MAX_PART * 4));
+    MH_TRY(c->w_tile_cnt.reserve((ntiles + 1) * 4));
+    MH_TRY(c->w_tile_off.reserve((ntiles + 1) * 8));
+    MH_TRY(c->params.reserve(sizeof(SearchParams)));
+    const SearchParams P = make_params(c);
+    hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, c->stream, P, c->params.as<SearchParams>());
+    MH_HIP(hipMemsetAsync(c->w_flags.p, 0, nflags, c->stream));
+    MH_HIP(hipMemsetAsync(c->w_part_cnt.p, 0, (size_t)ncells * 4, c->stream));
+    MH_HIP(hipMemsetAsync(c->w_tile_cnt.p, 0, (ntiles + 1) * 4, c->stream));
+    hipLaunchKernelGGL(within_partners_kernel, dim3((unsigned)((c->ntasks + 255) / 256)), dim3(256), 0, c->stream, c->params.as<SearchParams>(),
+                       c->w_part_cnt.as<uint32_t>(), c->w_part.as<uint32_t>());
+    // big cells get several waves (a share of their 64-row blocks each)
+    uint32_t nsplit = (uint32_t)(((uint64_t)c->set[0].n / 64u) / ncells) + 1u;
+    if (nsplit > 64u) nsplit = 64u;
+    hipLaunchKernelGGL(within_flags_kernel, dim3(ncells, nsplit), dim3(64), 0, c->stream, c->params.as<SearchParams>(),
+                       c->w_part_cnt.as<uint32_t>(), c->w_part.as<uint32_t>(), c->w_flags.as<uint8_t>(), nsplit);
+    hipLaunchKernelGGL(flag_tile_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, c->stream, c->w_flags.as<uint8_t>(), nflags,
+                       c->w_tile_cnt.as<uint32_t>());
+    MH_HIP(hipGetLastError());
+    MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->w_tile_cnt.as<uint32_t>(), c->w_tile_off.as<unsigned long long>(), ntiles + 1)));
+    unsigned long long tot = 0;
+    MH_TRY(read_back(c, &tot, c->w_tile_off.as<unsigned long long>() + ntiles, 8));
+    c->within_total = tot;
+    c->have_within = true;
+    if (out_count) *out_count = tot;
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_within_fill(molar_hip_ctx *c, uint64_t *ids) {
+    if (!c || !c->have_within) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached within set: call molar_hip_within_count first");
+    if (c->within_total == 0) return MOLAR_HIP_OK;
+    if (!ids) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within_fill: null output");
+    MH_HIP(hipSetDevice(c->device));
+    const bool dev = is_device_ptr(ids);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(ids);
+    if (!dev) {
+        MH_TRY(c->wide_i.reserve((size_t)c->within_total * 8));
+        dst = c->wide_i.as<unsigned long long>();
+    }
+    const uint64_t ntiles = (c->within_nflags + 2047) / 2048;
+    hipLaunchKernelGGL(flag_compact_kernel, dim3((unsigned)ntiles), dim3(256), 0, c->stream, c->w_flags.as<uint8_t>(), c->within_nflags,
+                       c->w_tile_off.as<unsigned long long>(), dst);
+    MH_HIP(hipGetLastError());
+    if (!dev) {
+        MH_HIP(hipMemcpyAsync(ids, dst, (size_t)c->within_total * 8, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return MOLAR_HIP_OK;
+}
+
 }  // extern "C"
+

@@ -266,6 +266,32 @@ impl Engine {
         Ok(ids.into_iter().map(|v| v as usize).collect())
     }
 
+    /// `within <cutoff> pbc of <inner>` as the selection keeps it (`LogicalNode::Within`, selection/ast.rs:589-631): what
+    /// `SortedSet::from_unsorted` (selection_expr.rs:112) makes of the stream above - sorted, de-duplicated - computed
+    /// without the stream: an atom stops looking at its first hit in any plan entry (molar_hip_within_count / _fill).
+    pub fn within_set_pbc(
+        &self, cutoff: f32, coords1: &[[f32; 3]], index1: Option<&[usize]>, coords2: &[[f32; 3]], index2: Option<&[usize]>,
+        box9: &[f32; 9], pbc: u8,
+    ) -> Result<Vec<usize>, EngineError> {
+        check_index(index1, coords1.len(), "within_set_pbc (set 1)")?;
+        check_index(index2, coords2.len(), "within_set_pbc (set 2)")?;
+        let (i1, n1) = idx_ptr(index1);
+        let (i2, n2) = idx_ptr(index2);
+        let d = MolarHipSearchDesc {
+            kind: SEARCH_WITHIN, cutoff, xyz1: coords1.as_ptr() as *const f32, natoms1: coords1.len(), idx1: i1, n1,
+            xyz2: coords2.as_ptr() as *const f32, natoms2: coords2.len(), idx2: i2, n2, box9: box9.as_ptr(), pbc,
+            ..Default::default()
+        };
+        let f = &self.plugin.fns;
+        let mut n = 0u64;
+        self.plugin.check(unsafe { (f.within_count)(self.ctx, &d, &mut n) })?;
+        let mut ids = vec![0u64; n as usize];
+        if n > 0 {
+            self.plugin.check(unsafe { (f.within_fill)(self.ctx, ids.as_mut_ptr()) })?;
+        }
+        Ok(ids.into_iter().map(|v| v as usize).collect())
+    }
+
     // ---------------------------------------------------------------- Measure (measure.rs:22-649)
 
     /// `Measure::center_of_mass` (:60-75)

@@ -121,6 +121,14 @@ static void search_tests() {
         bool okw = w.size() == rw->n;
         for (size_t k = 0; okw && k < rw->n; ++k) okw = w[k] == rw->i[k];
         EXPECT(okw);
+        // ... and the set the selection keeps of it (sorted, de-duplicated: selection_expr.rs:112), computed without the stream
+        {
+            std::vector<usize> want(rw->i, rw->i + rw->n);
+            std::sort(want.begin(), want.end());
+            want.erase(std::unique(want.begin(), want.end()), want.end());
+            auto ws = within_set(0.5f, s_ev, s_od, &pb, PBC_FULL);
+            EXPECT(ws == want && !ws.empty());
+        }
         orc_pairs_free(rw);
         // vdw: local ids (:791-792)
         std::vector<Float> v1(ev.size(), 0.17f), v2(od.size(), 0.15f);

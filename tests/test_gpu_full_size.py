@@ -153,3 +153,26 @@ def test_c3_fit_rmsd_com_gyration_at_baseline_size(eng, orc64):
         assert np.allclose(eng.center_of_mass(cur, mass, idx), want[f]["com"], rtol=1e-5, atol=1e-5)
         rm = eng.rmsd_mw(cur, mass, ref, idx, idx)
         assert abs(rm - orc64.rmsd_mw(cur, mass, ref, idx, idx)) <= 1e-5 * rm
+
+
+@pytest.mark.timeout(900)
+def test_within_set_at_1m_atoms_against_the_oracle(eng, orc32):
+    """`within 1.0 of <100k-atom selection>` on the 1M-atom frame (molar/benches/comparison_large.rs:29-40): the set form
+    (molar_hip_within_count / _fill) against np.unique of the oracle's distance_search_within_pbc stream, for a compact
+    solute and for a selection spread over the whole box; the engine's own stream form must give the same set."""
+    from molar_amd import api as a
+    n = 1_000_000
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 0)
+    ob = orc32.box_from_matrix(box)
+    all_idx = np.arange(n, dtype=np.uint64)
+    centre = (box @ np.array([0.5, 0.5, 0.5], np.float32)).astype(np.float32)
+    blob = np.sort(np.argsort(((pos - centre) ** 2).sum(1))[:100_000]).astype(np.uint64)
+    for idx2 in (blob, all_idx[::10]):
+        ref = orc32.search_within_pbc(1.0, pos, pos[idx2.astype(np.int64)], ob, 7, all_idx, idx2, nthreads=NCPU)
+        want = np.unique(ref["i"])
+        got = eng.within_set(1.0, pos, all_idx, pos, idx2, box=box, pbc=7)
+        assert np.array_equal(got, want), (len(got), len(want))
+        k = eng.search_count(a.SEARCH_WITHIN, 1.0, pos, all_idx, pos, idx2, box=box, pbc=7)
+        assert k == len(ref["i"])
+        assert np.array_equal(np.unique(eng.search_fill_ids(k)), want)
