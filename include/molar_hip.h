@@ -179,6 +179,17 @@ int molar_hip_search_fill_ids(molar_hip_ctx *ctx, uint64_t *ids);
  * (:627-629) is the caller's union with the inner selection.  ids: uint64[count], host or device. */
 int molar_hip_within_count(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_count);
 int molar_hip_within_fill(molar_hip_ctx *ctx, uint64_t *ids);
+/* Modify::unwrap_connectivity_dim (molar/src/modify.rs:72-131): neighbour search of the selection with local ids under
+ * full PBC on the GPU, SearchConnectivity's adjacency in pair order (connectivity.rs:19-35) and the reference's stack
+ * walk on the host - every atom is moved to the closest image (over `pbc_dims`) of the atom it was reached from.  xyz:
+ * float[natoms][3], host or device, modified in place.  Returns the selections of the reference's result as a CSR of
+ * LOCAL indices, each sorted (select(&sel_vec)); as there, the atom a connected component starts from is not a member
+ * of its group and one-atom components give no group.  group_offsets: capacity n + 1 (or natoms + 1 with idx == NULL),
+ * group_ids: capacity n; either may be NULL (the coordinates are unwrapped all the same, *ngroups is still counted).
+ * Errors: MOLAR_HIP_ERR_NO_PBC without a box. */
+int molar_hip_unwrap_connectivity(molar_hip_ctx *ctx, float *xyz, size_t natoms, const uint64_t *idx, size_t n,
+                                  const float *box9, float cutoff, uint8_t pbc_dims, uint64_t *group_offsets,
+                                  uint64_t *group_ids, size_t *ngroups);
 /* Grid dims of the cached search (Grid::get_dims, :212-214). */
 int molar_hip_search_grid_dims(molar_hip_ctx *ctx, uint64_t dims[3]);
 /* Device-resident result of the cached search: fills ctx-owned buffers (reused across frames)

@@ -341,6 +341,19 @@ class SelBound {
                                       require_box().colmajor9(), dims.raw()));
     }
     void unwrap_simple() { unwrap_simple_dim(PBC_FULL); }
+    // Modify::unwrap_connectivity(_dim) (modify.rs:65-131): the connected groups as LOCAL index lists (the reference returns
+    // them as selections of this selection)
+    std::vector<std::vector<usize>> unwrap_connectivity_dim(Float cutoff, PbcDims dims) {
+        const size_t n = index_.size();
+        std::vector<uint64_t> off(n + 1), ids(n ? n : 1);
+        size_t ng = 0;
+        check(molar_hip_unwrap_connectivity(ctx(), coords_ptr_mut(), natoms(), index_.data(), n, require_box().colmajor9(), cutoff,
+                                            dims.raw(), off.data(), ids.data(), &ng));
+        std::vector<std::vector<usize>> out(ng);
+        for (size_t g = 0; g < ng; ++g) out[g].assign(ids.begin() + off[g], ids.begin() + off[g + 1]);
+        return out;
+    }
+    std::vector<std::vector<usize>> unwrap_connectivity(Float cutoff) { return unwrap_connectivity_dim(cutoff, PBC_FULL); }
     void translate(const Vector3f &shift) {                       // modify.rs:16-23
         check(molar_hip_translate(ctx(), coords_ptr_mut(), natoms(), index_.data(), index_.size(), &shift.x));
     }

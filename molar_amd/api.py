@@ -538,6 +538,21 @@ class Engine:
         check(self.lib.molar_hip_unwrap_simple(self.ctx, xa, na, ia, n, ba, pbc_mask(dims)))
         return xyz
 
+    def unwrap_connectivity(self, xyz, box, cutoff, dims=PBC_FULL, idx=None):
+        """Modify::unwrap_connectivity_dim (modify.rs:72-131) in place: GPU neighbour search with local ids, adjacency in
+        pair order and the reference's stack walk inside the library (molar_hip_unwrap_connectivity).  Returns the list of
+        groups of LOCAL indices the reference returns as selections."""
+        if not _is_torch(xyz):
+            assert xyz.dtype == np.float32 and xyz.flags.c_contiguous, "unwrap_connectivity works in place"
+        xa, na, ia, n, k = self._sel_args(xyz, idx)
+        nsel = n if idx is not None else na
+        ba, kb = self._box9(box)
+        goff = np.zeros(nsel + 1, np.uint64); gids = np.zeros(max(nsel, 1), np.uint64)
+        ng = C.c_size_t(0)
+        check(self.lib.molar_hip_unwrap_connectivity(self.ctx, xa, na, ia, n, ba, float(cutoff), pbc_mask(dims), goff.ctypes.data,
+                                                     gids.ctypes.data, C.byref(ng)))
+        return [gids[int(goff[g]):int(goff[g + 1])].copy() for g in range(int(ng.value))]
+
     def center_batch(self, xyz, idx, offsets, mass=None):
         """Centres of K selections given as CSR (idx, offsets[K+1]): center_of_mass if `mass` is given,
         else center_of_geometry.  One wave per selection; returns float32 [K,3]."""
@@ -1265,48 +1280,9 @@ class Sel:
         """Modify::unwrap_connectivity_dim (modify.rs:72-131): neighbour search with LOCAL ids under full
         PBC (:77-78), adjacency in pair order (SearchConnectivity, connectivity.rs:19-35), then the
         reference's stack walk that pulls every connected atom to the closest image of the atom it was
-        reached from.  Coordinates are modified in place; returns the list of local-index groups the
-        reference returns as selections."""
-        box = self.require_box()
-        eng = self.engine
-        n = len(self.index)
-        cnt = eng.search_count(SEARCH_SINGLE, cutoff, self.state.coords, self.index, box=box, pbc=PBC_FULL,
-                               ids_local=True)
-        pairs, _ = eng.search_fill(cnt)
-        conn = [[] for _ in range(n)]
-        for i, j in pairs.tolist():                                   # from_iter: push j to i, then i to j
-            conn[i].append(j)
-            conn[j].append(i)
-        coords = self.state.coords
-        gidx = self.index.astype(np.int64)
-        used = np.zeros(n, bool)
-        todo = [0]
-        used[0] = True
-        sel_vec, res = [], []
-        mask = pbc_mask(dims)
-        while True:
-            while todo:
-                c = todo.pop()
-                p0 = coords[gidx[c]].copy()
-                for ind in conn[c]:
-                    if not used[ind]:
-                        coords[gidx[ind]] = box.closest_image(coords[gidx[ind]], p0, mask)
-                        todo.append(ind)
-                        used[ind] = True
-                        sel_vec.append(ind)
-            rest = np.nonzero(~used)[0]
-            if len(rest):
-                i = int(rest[0])
-                todo.append(i)
-                used[i] = True
-                if sel_vec:
-                    res.append(np.array(sorted(set(sel_vec)), dtype=np.uint64))
-                sel_vec = []
-            else:
-                if sel_vec:
-                    res.append(np.array(sorted(set(sel_vec)), dtype=np.uint64))
-                break
-        return res
+        reached from - all inside the library (molar_hip_unwrap_connectivity).  Coordinates are modified in place;
+        returns the list of local-index groups the reference returns as selections."""
+        return self.engine.unwrap_connectivity(self.state.coords, self.require_box(), cutoff, dims, self.index)
 
 
 def distance_search(cutoff, data1: Sel, data2: Sel | None = None, dims=None):

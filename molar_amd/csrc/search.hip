@@ -1937,5 +1937,120 @@ int molar_hip_within_fill(molar_hip_ctx *c, uint64_t *ids) {
     return MOLAR_HIP_OK;
 }
 
+// Modify::unwrap_connectivity_dim (molar/src/modify.rs:72-131).  The neighbour search - the heavy part - runs on the GPU
+// (distance_search_single_pbc over the selection with LOCAL ids under full PBC, :77-78); the adjacency lists in push
+// order (SearchConnectivity::from_iter, connectivity.rs:19-35: for (i, j) in pair order conn[i].push(j), conn[j].push(i))
+// are a counting sort of the pair list on the host, and the reference's stack walk (:84-128) - serial by nature: every
+// atom is pulled to the closest image of the atom it was REACHED FROM, whose position the walk may just have changed -
+// runs on the host over that CSR with the same f32 arithmetic (boxmath.hpp's closest_image, the one the kernels use).
+// Quirks kept: the atom a component starts from (0, then the lowest unused index) is not a member of the selection
+// the component returns (:97-98,111-113); a component of one atom returns no selection; members are emitted as the
+// reference's `select(&sel_vec)` makes them, sorted.
+int molar_hip_unwrap_connectivity(molar_hip_ctx *c, float *xyz, size_t natoms, const uint64_t *idx, size_t n, const float *box9,
+                                  float cutoff, uint8_t pbc_dims, uint64_t *group_offsets, uint64_t *group_ids, size_t *ngroups) {
+    if (!c || !xyz) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "unwrap_connectivity: null argument");
+    if (!box9) return fail(MOLAR_HIP_ERR_NO_PBC, "no periodic box");                               // require_box (:76)
+    const size_t nsel = idx ? n : natoms;
+    if (nsel == 0) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "unwrap_connectivity of an empty selection");
+    if (nsel >= 0x7FFFFFFFull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "unwrap_connectivity: %zu atoms exceed the 32-bit local ids", nsel);
+    MH_HIP(hipSetDevice(c->device));
+    molar_hip_box b;
+    MH_TRY(molar_hip_box_from_matrix(box9, &b));
+    // ---- the search, local ids (0..len), full PBC whatever `dims` (:77-78)
+    molar_hip_search_desc q{};
+    q.kind = MOLAR_HIP_SEARCH_SINGLE;
+    q.cutoff = cutoff;
+    q.xyz1 = xyz; q.natoms1 = natoms; q.idx1 = idx; q.n1 = n;
+    q.ids_local = 1;
+    q.box9 = box9;
+    q.pbc = MOLAR_HIP_PBC_FULL;
+    uint64_t npairs = 0;
+    MH_TRY(molar_hip_search_count(c, &q, &npairs));
+    std::vector<uint32_t> pairs((size_t)npairs * 2);
+    if (npairs) MH_TRY(molar_hip_search_fill(c, pairs.data(), nullptr));
+    // ---- adjacency in push order (counting sort, stable)
+    std::vector<uint64_t> off(nsel + 1, 0);
+    for (size_t p = 0; p < 2 * (size_t)npairs; ++p) off[pairs[p] + 1]++;
+    for (size_t i = 0; i < nsel; ++i) off[i + 1] += off[i];
+    std::vector<uint32_t> adj(2 * (size_t)npairs);
+    {
+        std::vector<uint64_t> cur(off.begin(), off.end() - 1);
+        for (size_t p = 0; p < (size_t)npairs; ++p) {
+            const uint32_t i = pairs[2 * p], j = pairs[2 * p + 1];
+            adj[cur[i]++] = j;
+            adj[cur[j]++] = i;
+        }
+    }
+    std::vector<uint32_t>().swap(pairs);
+    // ---- the coordinates of the frame on the host
+    const bool dev = is_device_ptr(xyz);
+    std::vector<float> hostcopy;
+    float *h = xyz;
+    if (dev) {
+        hostcopy.resize(natoms * 3);
+        MH_HIP(hipMemcpyAsync(hostcopy.data(), xyz, natoms * 12, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
+        h = hostcopy.data();
+    }
+    std::vector<uint64_t> hidx;
+    if (idx && is_device_ptr(idx)) {      // the walk reads the selection on the host
+        hidx.resize(n);
+        MH_HIP(hipMemcpy(hidx.data(), idx, n * 8, hipMemcpyDeviceToHost));
+    }
+    const uint64_t *ix = hidx.empty() ? idx : hidx.data();
+    auto pos = [&](size_t k) -> float * { return h + 3 * (ix ? ix[k] : (uint64_t)k); };
+    // ---- the walk (:80-128)
+    std::vector<uint8_t> used(nsel, 0);
+    std::vector<uint32_t> todo, sel_vec;
+    todo.reserve(1024);
+    size_t ng = 0, nids = 0, first_unused = 0;
+    if (group_offsets) group_offsets[0] = 0;
+    auto emit = [&]() {
+        if (sel_vec.empty()) return;
+        std::sort(sel_vec.begin(), sel_vec.end());
+        if (group_ids) for (uint32_t v : sel_vec) group_ids[nids++] = v;
+        else nids += sel_vec.size();
+        ++ng;
+        if (group_offsets) group_offsets[ng] = nids;
+        sel_vec.clear();
+    };
+    todo.push_back(0);
+    used[0] = 1;
+    const uint32_t dims = pbc_dims & 7u;
+    for (;;) {
+        while (!todo.empty()) {
+            const uint32_t cc = todo.back();
+            todo.pop_back();
+            const float *pc = pos(cc);
+            const V3 p0 = v3(pc[0], pc[1], pc[2]);
+            for (uint64_t e = off[cc]; e < off[cc + 1]; ++e) {
+                const uint32_t ind = adj[e];
+                if (used[ind]) continue;
+                float *pp = pos(ind);
+                const V3 r = closest_image(b, v3(pp[0], pp[1], pp[2]), p0, dims);
+                pp[0] = r.x; pp[1] = r.y; pp[2] = r.z;
+                todo.push_back(ind);
+                used[ind] = 1;
+                sel_vec.push_back(ind);
+            }
+        }
+        while (first_unused < nsel && used[first_unused]) ++first_unused;       // used.iter().find_position(false)
+        if (first_unused == nsel) {
+            emit();
+            break;
+        }
+        todo.push_back((uint32_t)first_unused);
+        used[first_unused] = 1;
+        emit();
+    }
+    if (ngroups) *ngroups = ng;
+    if (dev) {
+        MH_HIP(hipMemcpyAsync(xyz, hostcopy.data(), natoms * 12, hipMemcpyHostToDevice, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return MOLAR_HIP_OK;
+}
+
 }  // extern "C"
+
 

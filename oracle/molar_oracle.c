@@ -1232,6 +1232,80 @@ int orc_unwrap_simple_dim(REAL *xyz, const uint64_t *idx, size_t n, const orc_bo
     return ORC_OK;
 }
 
+static int cmp_u64(const void *a, const void *b) {
+    const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* Modify::unwrap_connectivity_dim, modify.rs:72-131.  The search runs over the selection's positions with LOCAL ids 0..n
+ * under PBC_FULL (:77-78); SearchConnectivity::from_iter (connectivity.rs:19-35) pushes j to i's list and i to j's in pair
+ * order; the walk (:80-128) pops a centre, moves every not-yet-used neighbour to its closest image (over `dims`) relative
+ * to the centre's CURRENT position, and pushes it.  A component starts from atom 0, later from the first unused atom
+ * (find_position, :107); start atoms are not members of the returned selections (:97-98), empty selections are not
+ * returned (:111-113,118-120).  select(&sel_vec) sorts.  Output: CSR of local indices (capacity n + 1 / n). */
+int orc_unwrap_connectivity_dim(REAL *xyz, const uint64_t *idx, size_t n, const orc_box *b, REAL cutoff, uint8_t dims,
+                                uint64_t *group_offsets, uint64_t *group_ids, size_t *ngroups, int nthreads) {
+    if (!b) return ORC_ERR_NO_PBC;
+    if (n == 0) return ORC_OK;
+    REAL *pos = (REAL *)malloc(n * 3 * sizeof(REAL));
+    for (size_t k = 0; k < n; ++k) memcpy(pos + 3 * k, POS(xyz, idx, k), 3 * sizeof(REAL));
+    orc_pairs *pr = orc_search_single_pbc(cutoff, pos, NULL, n, b, 7, nthreads);
+    free(pos);
+    if (!pr) return ORC_ERR_NO_PBC;
+    /* conn: i -> [j...] in push order */
+    size_t *off = (size_t *)calloc(n + 2, sizeof(size_t));
+    for (size_t p = 0; p < pr->n; ++p) { off[pr->i[p] + 1]++; off[pr->j[p] + 1]++; }
+    for (size_t i = 0; i < n; ++i) off[i + 1] += off[i];
+    uint64_t *adj = (uint64_t *)malloc((2 * pr->n + 1) * sizeof(uint64_t));
+    size_t *cur = (size_t *)malloc((n + 1) * sizeof(size_t));
+    memcpy(cur, off, (n + 1) * sizeof(size_t));
+    for (size_t p = 0; p < pr->n; ++p) {
+        adj[cur[pr->i[p]]++] = pr->j[p];
+        adj[cur[pr->j[p]]++] = pr->i[p];
+    }
+    free(cur);
+    orc_pairs_free(pr);
+    unsigned char *used = (unsigned char *)calloc(n, 1);
+    uint64_t *todo = (uint64_t *)malloc(n * sizeof(uint64_t)), *sel = (uint64_t *)malloc(n * sizeof(uint64_t));
+    size_t ntodo = 0, nsel = 0, ng = 0, nids = 0;
+    if (group_offsets) group_offsets[0] = 0;
+    todo[ntodo++] = 0;
+    used[0] = 1;
+    for (;;) {
+        while (ntodo) {
+            const uint64_t c = todo[--ntodo];
+            REAL p0[3];
+            memcpy(p0, POS(xyz, idx, c), sizeof p0);
+            for (size_t e = off[c]; e < off[c + 1]; ++e) {
+                const uint64_t ind = adj[e];
+                if (used[ind]) continue;
+                REAL *p = (REAL *)POS(xyz, idx, ind), o[3];
+                orc_closest_image_dims(b, p, p0, dims, o);
+                p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+                todo[ntodo++] = ind;
+                used[ind] = 1;
+                sel[nsel++] = ind;
+            }
+        }
+        size_t i = 0;
+        while (i < n && used[i]) ++i;
+        const int last = i == n;
+        if (!last) { todo[ntodo++] = i; used[i] = 1; }
+        if (nsel) {
+            /* select(&sel_vec): sorted */
+            qsort(sel, nsel, sizeof(uint64_t), cmp_u64);
+            for (size_t a = 0; a < nsel; ++a) { if (group_ids) group_ids[nids] = sel[a]; ++nids; }
+            ++ng;
+            if (group_offsets) group_offsets[ng] = nids;
+            nsel = 0;
+        }
+        if (last) break;
+    }
+    if (ngroups) *ngroups = ng;
+    free(used); free(todo); free(sel); free(off); free(adj);
+    return ORC_OK;
+}
+
 /* measure.rs:270-422 */
 int orc_lipid_tail_order(const REAL *xyz, const uint64_t *idx, size_t n, int order_type, const REAL *normals,
                          size_t n_normals, const uint8_t *bond_orders, size_t n_bonds, REAL *order) {

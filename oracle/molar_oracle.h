@@ -168,6 +168,9 @@ void orc_apply_transform(REAL *xyz, const uint64_t *idx, size_t n, const REAL R9
 void orc_translate(REAL *xyz, const uint64_t *idx, size_t n, const REAL shift[3]);     /* modify.rs:16-23 */
 int  orc_unwrap_simple_dim(REAL *xyz, const uint64_t *idx, size_t n, const orc_box *b,
                            uint8_t dims);                                               /* modify.rs:40-54 */
+int  orc_unwrap_connectivity_dim(REAL *xyz, const uint64_t *idx, size_t n, const orc_box *b, REAL cutoff, uint8_t dims,
+                                 uint64_t *group_offsets, uint64_t *group_ids, size_t *ngroups,
+                                 int nthreads);                                                 /* modify.rs:72-131 */
 /* order_type: 0 Sz, 1 Scd, 2 ScdCorr (measure.rs:708-716).  out has n-2 entries. */
 int  orc_lipid_tail_order(const REAL *xyz, const uint64_t *idx, size_t n, int order_type,
                           const REAL *normals, size_t n_normals, const uint8_t *bond_orders,

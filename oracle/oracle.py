@@ -400,6 +400,19 @@ class Oracle:
                                                  C.c_uint8(pbc_mask(dims))))
         return xyz
 
+    def unwrap_connectivity(self, xyz, box, cutoff, dims=PBC_FULL, idx=None, nthreads=1):
+        """modify.rs:72-131.  Returns (unwrapped copy of xyz, list of groups of LOCAL indices)."""
+        xyz, idx, n = self._sel(xyz, idx)
+        xyz = xyz.copy()
+        goff = np.zeros(n + 1, np.uint64); gids = np.zeros(max(n, 1), np.uint64)
+        ng = C.c_size_t(0)
+        fn = self.lib.orc_unwrap_connectivity_dim
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, self.creal, C.c_uint8, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self._chk(fn(self._p(xyz), self._p(idx), n, self._bp(box), cutoff, pbc_mask(dims), self._p(goff), self._p(gids), C.byref(ng), nthreads))
+        g = int(ng.value)
+        return xyz, [gids[int(goff[k]):int(goff[k + 1])].copy() for k in range(g)]
+
     def lipid_tail_order(self, xyz, order_type, normals, bond_orders, idx=None):
         xyz, idx, n = self._sel(xyz, idx)
         normals = self.arr(normals, (-1, 3))

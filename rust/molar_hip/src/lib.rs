@@ -434,6 +434,27 @@ impl Engine {
         })
     }
 
+    /// `Modify::unwrap_connectivity_dim` (modify.rs:72-131), in place: GPU neighbour search with local ids under full PBC,
+    /// `SearchConnectivity`'s adjacency in pair order, the reference's stack walk inside the plugin.  Returns the groups of
+    /// LOCAL indices the reference returns as selections (`self.select(&sel_vec)`).
+    pub fn unwrap_connectivity_dim(
+        &self, coords: &mut [[f32; 3]], index: Option<&[usize]>, box9: &[f32; 9], cutoff: f32, dims: u8,
+    ) -> Result<Vec<Vec<usize>>, EngineError> {
+        check_index(index, coords.len(), "unwrap_connectivity_dim")?;
+        let (ip, n) = idx_ptr(index);
+        let nsel = index.map_or(coords.len(), |i| i.len());
+        let mut off = vec![0u64; nsel + 1];
+        let mut ids = vec![0u64; nsel.max(1)];
+        let mut ng = 0usize;
+        self.plugin.check(unsafe {
+            (self.plugin.fns.unwrap_connectivity)(
+                self.ctx, coords.as_mut_ptr() as *mut f32, coords.len(), ip, n, box9.as_ptr(), cutoff, dims, off.as_mut_ptr(),
+                ids.as_mut_ptr(), &mut ng,
+            )
+        })?;
+        Ok((0..ng).map(|g| ids[off[g] as usize..off[g + 1] as usize].iter().map(|&v| v as usize).collect()).collect())
+    }
+
     /// `Measure::gyration` over a `ParSplit` (system.rs:193-213): selection k is `index[offsets[k]..offsets[k+1]]`.
     pub fn gyration_batch(
         &self, coords: &[[f32; 3]], index: &[usize], offsets: &[usize], masses: &[f32], box9: Option<&[f32; 9]>,

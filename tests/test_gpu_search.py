@@ -884,3 +884,57 @@ def test_histogram_device_bins_async(eng):
     eng.synchronize()
     assert np.array_equal(db.cpu().numpy().astype(np.uint64), hb)
     assert 0 < int(hb.sum()) <= tot and c_last > 0          # a distance equal to the upper edge falls outside the last bin
+
+
+def test_unwrap_connectivity_100k_atoms_against_the_oracle_entry(eng, orc32):
+    """molar_hip_unwrap_connectivity (GPU search + host walk in the library) against the oracle's
+    orc_unwrap_connectivity_dim (modify.rs:72-131): 2000 molecules of 60 atoms, wrapped into a triclinic box so that
+    hundreds of them are split over a boundary; coordinates bit-identical, group lists equal; also through a selection
+    and with the frame resident on the device."""
+    import torch
+    a = api()
+    rng = np.random.default_rng(11)
+    # helices of 60 atoms (radius 0.3, 27 degrees and 0.05 nm rise per atom: neighbours 0.15 nm apart, everything else > 0.17)
+    # on a 13 x 13 x 12 lattice, shifted as a whole so that the box faces cut through hundreds of them
+    nx, ny, nz, length = 13, 13, 12, 60
+    nmol = nx * ny * nz - 28
+    box = np.diag([nx * 2.4, ny * 2.4, nz * 3.6]).astype(np.float32)
+    box[0, 2] = -2.0; box[1, 2] = -1.5
+    k = np.arange(length)
+    th = np.deg2rad(27.0) * k
+    helix = np.stack([0.3 * np.cos(th), 0.3 * np.sin(th), 0.05 * k], 1)
+    parts = []
+    for m in range(nmol):
+        cx, cy, cz = m % nx, (m // nx) % ny, m // (nx * ny)
+        rot = rng.uniform(0, 2 * np.pi)
+        R = np.array([[np.cos(rot), -np.sin(rot), 0], [np.sin(rot), np.cos(rot), 0], [0, 0, 1.0]])
+        parts.append(helix @ R.T + np.array([cx * 2.4 + 1.2, cy * 2.4 + 1.2, cz * 3.6 + 0.3]) + rng.normal(0, 0.005, (length, 3)))
+    whole = np.concatenate(parts) + np.array([0.9, 1.1, 1.7])
+    fr = whole @ np.linalg.inv(box.astype(np.float64)).T
+    wrapped = ((fr - np.floor(fr)) @ box.astype(np.float64).T).astype(np.float32)
+    n = len(wrapped)
+    assert n >= 100_000
+    ob = orc32.box_from_matrix(box)
+    import os
+    ref, rgroups = orc32.unwrap_connectivity(wrapped, ob, 0.17, 7, nthreads=os.cpu_count() or 4)
+    assert len(rgroups) >= 1000
+    split = sum(1 for m in range(nmol) if np.abs(np.diff(wrapped[m * length:(m + 1) * length], axis=0)).max() > 1.0)
+    assert split > 200
+    got = wrapped.copy()
+    groups = eng.unwrap_connectivity(got, box, 0.17, 7)
+    assert np.array_equal(got, ref)
+    assert len(groups) == len(rgroups) and all(np.array_equal(x, y) for x, y in zip(groups, rgroups))
+    # device-resident frame
+    dgot = torch.from_numpy(wrapped.copy()).cuda()
+    torch.cuda.synchronize()
+    g2 = eng.unwrap_connectivity(dgot, box, 0.17, 7)
+    assert np.array_equal(dgot.cpu().numpy(), ref) and len(g2) == len(rgroups)
+    # through a selection (every other molecule), partial dims
+    idx = np.concatenate([np.arange(m * length, (m + 1) * length) for m in range(0, nmol, 2)]).astype(np.uint64)
+    ref3, rg3 = orc32.unwrap_connectivity(wrapped, ob, 0.17, 3, idx=idx, nthreads=os.cpu_count() or 4)
+    got3 = wrapped.copy()
+    g3 = eng.unwrap_connectivity(got3, box, 0.17, 3, idx=idx)
+    assert np.array_equal(got3, ref3) and len(g3) == len(rg3) and all(np.array_equal(x, y) for x, y in zip(g3, rg3))
+    # no box: the reference's require_box error
+    with pytest.raises(a.MolarHipError):
+        eng.unwrap_connectivity(wrapped.copy(), None, 0.17, 7)
