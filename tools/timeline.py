@@ -16,7 +16,13 @@ q = ev[fills[skip]][3]
 main = [e for e in ev if e[3] == q]
 fi = [i for i, e in enumerate(main) if e[2] == "FILL"]
 busy = collections.defaultdict(float); gaps = collections.defaultdict(float); n = 0
+# frames whose period is far above the median are pauses of the host (phases of the benchmark, its self-check), not the pipeline
+periods = sorted(main[b][0] - main[a][0] for a, b in zip(fi[skip:-1], fi[skip + 1:]))
+med = periods[len(periods) // 2]
+kept_ns = 0
 for a, b in zip(fi[skip:-1], fi[skip + 1:-0 or None]):
+    if main[b][0] - main[a][0] > 2 * med: continue
+    kept_ns += main[b][0] - main[a][0]
     seg = main[a:b + 1]
     for x, y in zip(seg[:-1], seg[1:]):
         busy[y[2]] += (y[1] - y[0]) / 1e3
@@ -26,4 +32,4 @@ print(f"{n} frames on queue {q}: per-frame busy us / gap us")
 tb = tg = 0
 for k, v in busy.items(): print(f"  busy {k:30s} {v / n:8.1f}"); tb += v / n
 for k, v in gaps.items(): print(f"  gap  {k:50s} {v / n:8.1f}"); tg += v / n
-print(f"  total busy {tb:.1f} us, gaps {tg:.1f} us, period {(main[fi[-1]][0] - main[fi[skip]][0]) / 1e3 / (len(fi) - 1 - skip):.1f} us")
+print(f"  total busy {tb:.1f} us, gaps {tg:.1f} us, period {kept_ns / 1e3 / max(n, 1):.1f} us (frames with more than twice the median period left out)")
