@@ -513,8 +513,8 @@ def main():
         if overlap:
             jobs[k].put(fr)
             descs[k][0][0].xyz1 = fr.data_ptr()
-            cnt, _, _ = e.search_resident_desc(descs[k][0][0])       # count + scan + fill, one round trip
-            return cnt, None
+            cnt, pp_, dp_ = e.search_resident_desc(descs[k][0][0])       # count + scan + fill, one round trip
+            return cnt, None, pp_, dp_
         cnt, _, _ = e.search_resident(api.SEARCH_SINGLE, CUTOFF, fr, box=box, pbc=7)
         out = e.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
         return cnt, float(out["rmsd"][0])
@@ -556,50 +556,58 @@ def main():
         return a, b
 
     def run_steps(first, count):
-        """`count` steps starting at frame `first`, dealt round-robin to the S contexts (one host thread each;
-        ctypes releases the GIL inside the library)."""
-        if S == 1 and pipelined:
-            # frame s+1 is enqueued (grid, plan, count, scan, fill: ~15 launches) before the result of frame s is
-            # waited for, so the stream never runs dry between frames; every frame is begun AND ended in here
-            res, prev = [], None
-            for s in range(count):
-                fr = frames[(first + s) % nres]
-                if overlap:
-                    jobs[0].put(fr)
-                d = descs[0][s & 1][0]
-                d.xyz1 = fr.data_ptr()
-                t = eng.search_resident_begin(d)
+        """`count` steps starting at frame `first`, dealt round-robin to the S contexts.  Every context runs its frames
+        through the begin / end form (two of ITS frames in flight: the next one is enqueued - grid, plan, count, offsets,
+        fill: ~14 launches - before the result of the one in front is waited for); with S > 1 one host thread per context
+        (ctypes releases the GIL inside the library).  Every frame is begun AND ended in here."""
+        res = [None] * count
+        rms = [0.0] * count
+        newest = [[] for _ in range(S)]       # per context: (frame number, pair count, device addresses) of its newest results
+
+        def context_loop(k):
+            e = engines[k]
+            mine = list(range(k, count, S))
+            if pipelined:
+                prev = None
+                for n_, s_ in enumerate(mine):
+                    fr = frames[(first + s_) % nres]
+                    if overlap:
+                        jobs[k].put(fr)
+                    d = descs[k][n_ & 1][0]
+                    d.xyz1 = fr.data_ptr()
+                    t = e.search_resident_begin(d)
+                    if prev is not None:
+                        r_ = e.search_resident_end(prev[1])
+                        res[prev[0]] = (r_[0], None)
+                        newest[k].append((first + prev[0],) + tuple(r_))
+                    prev = (s_, t)
+                    if not overlap:      # the fit of the frame runs behind its search on the same stream
+                        out = e.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
+                        rms[s_] = float(out["rmsd"][0])
                 if prev is not None:
-                    r_ = eng.search_resident_end(prev)
-                    res.append((r_[0], None))
-                    last_results.append((first + s - 1,) + tuple(r_))
-                prev = t
-                if not overlap:      # the fit of frame s runs behind its search on the same stream
-                    out = eng.fit_rmsd_batch(fr.unsqueeze(0), mass, ref, idx=idx, apply=True)
-                    fits.append(float(out["rmsd"][0]))
-            if prev is not None:
-                r_ = eng.search_resident_end(prev)
-                res.append((r_[0], None))
-                last_results.append((first + count - 1,) + tuple(r_))
-            del last_results[:-2]      # the two result sets of the context hold the last two frames
-            rms = collect_fits(0, count) if overlap else fits[-count:]
-        elif S == 1:
-            res = [step(eng, first + s) for s in range(count)]
-            rms = collect_fits(0, count) if overlap else [r[1] for r in res]
+                    r_ = e.search_resident_end(prev[1])
+                    res[prev[0]] = (r_[0], None)
+                    newest[k].append((first + prev[0],) + tuple(r_))
+                del newest[k][:-2]       # a context's two result sets hold its last two frames
+            else:
+                for s_ in mine:
+                    res[s_] = step(e, first + s_)
+                    if not overlap:
+                        rms[s_] = res[s_][1]
+                    elif len(res[s_]) == 4:
+                        newest[k] = [(first + s_, res[s_][0], res[s_][2], res[s_][3])]     # the context's one result set
+            if overlap:
+                for s_, v in zip(mine, collect_fits(k, len(mine))):
+                    rms[s_] = v
+
+        if S == 1:
+            context_loop(0)
         else:
-            import threading
-            res = [None] * count
-            rms = [0.0] * count
             errors = []
 
             def worker(k):
                 try:
-                    mine = list(range(k, count, S))
-                    for s in mine:
-                        res[s] = step(engines[k], first + s)
-                    vals = collect_fits(k, len(mine)) if overlap else [res[s][1] for s in mine]
-                    for s, v in zip(mine, vals):
-                        rms[s] = v
+                    context_loop(k)
                 except Exception as exc:       # a failure in a stream thread must end the run, not hang the join
                     errors.append(exc)
 
@@ -610,6 +618,7 @@ def main():
                 t_.join()
             if errors:
                 raise errors[0]
+        last_results[:] = sorted(x for k in range(S) for x in newest[k])[-2:]
         return [int(r[0]) for r in res], [float(v) for v in rms]
 
     # Untimed pre-heat: the same steps for --preheat seconds, so that the W warm-up steps and the K timed steps run at
@@ -636,7 +645,7 @@ def main():
     # additionally recomputes ALL frames' counts and RMSDs.
     t_chk = time.perf_counter()
     self_check = None
-    if S == 1 and pipelined and overlap and K >= 2 and len(last_results) == 2:
+    if overlap and K >= 2 * S and len(last_results) == 2 and (pipelined or S >= 2):
         self_check = True
         e3 = api.Engine(local_rank)
         for (fno, cnt, pp, dp) in last_results:
@@ -744,7 +753,7 @@ def main():
                 "parallelism": f"frames sharded over {world} rank(s), no data-path collective"
                                + (" - ranks SHARE the GPUs (functional check, not a scaling result)" if args.share_gpu else ""),
                 "streams_per_gpu": S * (2 if overlap else 1),
-                "frames_in_flight_per_stream": 2 if (S == 1 and pipelined) else 1,
+                "frames_in_flight_per_stream": 2 if pipelined else 1,
                 "measure_overlapped_with_search": overlap,
             },
             "preheat_ms": preheat_ms,
