@@ -557,6 +557,12 @@ int molar_hip_xtc_frame_info(const molar_hip_xtc *x, size_t frame, int32_t *nato
 int molar_hip_xtc_seek_time(const molar_hip_xtc *x, float t, size_t *frame);
 int molar_hip_xtc_read(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t first, size_t count, float *xyz,
                        int nthreads);
+/* The same window decoded ON THE DEVICE, one lane per frame (64 frames per wave): the window's compressed bytes go over the
+ * link (about a third of the decoded size), `xyz_dev` (device memory, float[count][natoms][3]) is written by the kernel.
+ * Bit-identical to molar_hip_xtc_read (one decoder, compiled for both sides).  A lane is far slower than a host core, so
+ * this pays for windows of hundreds to thousands of frames - when the consumers of a multi-GPU node outrun the host's
+ * decoder threads.  Frames whose packed triples exceed 64 bits fall back to the host decoder inside the call. */
+int molar_hip_xtc_read_device(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t first, size_t count, float *xyz_dev);
 
 /* ------------------------------------------------------------------ Modify (modify.rs) */
 

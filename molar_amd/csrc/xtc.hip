@@ -26,21 +26,38 @@ namespace {
 using namespace mh;
 
 constexpr int FIRSTIDX = 9;
-constexpr int MAGIC[] = {
-    0,       0,       0,       0,       0,       0,       0,       0,       0,       8,        10,       12,       16,
-    20,      25,      32,      40,      50,      64,      80,      101,     128,     161,      203,      256,      322,
-    406,     512,     645,     812,     1024,    1290,    1625,    2048,    2580,    3250,     4096,     5060,     6501,
-    8192,    10321,   13003,   16384,   20642,   26007,   32768,   41285,   52015,   65536,    82570,    104031,   131072,
-    165140,  208063,  262144,  330280,  416127,  524287,  660561,  832255,  1048576, 1321122,  1664510,  2097152,  2642245,
-    3329021, 4194304, 5284491, 6658042, 8388607, 10568983, 13316085, 16777216};
+#define MOLAR_XTC_MAGIC_TABLE                                                                                             \
+    0,       0,       0,       0,       0,       0,       0,       0,       0,       8,        10,       12,       16,       \
+    20,      25,      32,      40,      50,      64,      80,      101,     128,     161,      203,      256,      322,      \
+    406,     512,     645,     812,     1024,    1290,    1625,    2048,    2580,    3250,     4096,     5060,     6501,     \
+    8192,    10321,   13003,   16384,   20642,   26007,   32768,   41285,   52015,   65536,    82570,    104031,   131072,   \
+    165140,  208063,  262144,  330280,  416127,  524287,  660561,  832255,  1048576, 1321122,  1664510,  2097152,  2642245,  \
+    3329021, 4194304, 5284491, 6658042, 8388607, 10568983, 13316085, 16777216
+constexpr int MAGIC[] = {MOLAR_XTC_MAGIC_TABLE};
+__device__ const int MAGIC_DEV[] = {MOLAR_XTC_MAGIC_TABLE};       // the same table for the device decoder (xtc_decode_kernel)
 constexpr int LASTIDX = (int)(sizeof(MAGIC) / sizeof(*MAGIC)) - 1;
+__host__ __device__ inline int magic_at(int k) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return MAGIC_DEV[k];
+#else
+    return MAGIC[k];
+#endif
+}
 
-inline uint32_t be32(const uint8_t *p) { return __builtin_bswap32(*reinterpret_cast<const uint32_t *>(p)); }
-inline float bef(const uint8_t *p) {
+__host__ __device__ inline uint32_t be32(const uint8_t *p) {
+#ifdef __HIP_DEVICE_COMPILE__
+    // (a window copied to the device starts at a frame header, so words are 4-byte aligned there too - but a misaligned
+    // dword load faults on the device where the host merely slows down: byte loads)
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+#else
+    uint32_t w;
+    std::memcpy(&w, p, 4);
+    return __builtin_bswap32(w);
+#endif
+}
+__host__ __device__ inline float bef(const uint8_t *p) {
     const uint32_t u = be32(p);
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
+    return __builtin_bit_cast(float, u);
 }
 
 struct FrameInfo {
@@ -55,7 +72,7 @@ struct Bits {
     uint64_t acc = 0;      // valid bits are the top `have` bits
     int have = 0;
     uint64_t loaded = 0;   // bits moved into acc so far (phantom tail bits included)
-    inline void refill() {
+    __host__ __device__ inline void refill() {
         while (have <= 32) {
             uint32_t w;
             if (p + 4 <= end) {
@@ -70,7 +87,7 @@ struct Bits {
             loaded += 32;
         }
     }
-    inline uint32_t get(int n) {   // 0 <= n <= 32
+    __host__ __device__ inline uint32_t get(int n) {   // 0 <= n <= 32
         if (n == 0) return 0;
         if (have < n) refill();
         const uint32_t v = (uint32_t)(acc >> (64 - n));
@@ -78,11 +95,11 @@ struct Bits {
         have -= n;
         return v;
     }
-    inline uint64_t consumed_bits() const { return loaded - (uint64_t)have; }
+    __host__ __device__ inline uint64_t consumed_bits() const { return loaded - (uint64_t)have; }
 };
 
 // number of bits needed for the product of three sizes (the format's `sizeofints`)
-inline int bits_for_product(const uint32_t s[3]) {
+__host__ __device__ inline int bits_for_product(const uint32_t s[3]) {
     const unsigned __int128 prod = (unsigned __int128)s[0] * s[1] * s[2];
     // xdrfile counts bits of the little-endian byte array holding prod: 8*(nbytes-1) + bits of the top byte,
     // where the top byte's count is "while (top >= num) {nbits++; num*=2}" = bit length of top
@@ -100,7 +117,7 @@ inline int bits_for_product(const uint32_t s[3]) {
     return tb + 8 * (nbytes - 1);
 }
 
-inline int bits_for(uint32_t size) {
+__host__ __device__ inline int bits_for(uint32_t size) {
     int n = 0;
     uint64_t num = 1;
     while (size >= num && n < 32) {
@@ -111,7 +128,7 @@ inline int bits_for(uint32_t size) {
 }
 
 // Mixed-radix triple packed in `nbits` bits: the stream holds the number little-endian by bytes.
-inline void unpack3(Bits &b, int nbits, const uint32_t s[3], int out[3]) {
+__host__ __device__ inline bool unpack3(Bits &b, int nbits, const uint32_t s[3], int out[3]) {
     if (nbits <= 64) {
         uint64_t v = 0;
         int shift = 0, left = nbits;
@@ -131,36 +148,42 @@ inline void unpack3(Bits &b, int nbits, const uint32_t s[3], int out[3]) {
         const uint64_t q2 = q / s[1];
         out[1] = (int)(q - q2 * s[1]);
         out[0] = (int)q2;
-    } else {
-        unsigned __int128 v = 0;
-        int shift = 0, left = nbits;
-        while (left > 8) {
-            v |= (unsigned __int128)b.get(8) << shift;
-            shift += 8;
-            left -= 8;
-        }
-        if (left > 0) v |= (unsigned __int128)b.get(left) << shift;
-        const unsigned __int128 q = v / s[2];
-        out[2] = (int)(uint64_t)(v - q * s[2]);
-        const unsigned __int128 q2 = q / s[1];
-        out[1] = (int)(uint64_t)(q - q2 * s[1]);
-        out[0] = (int)(uint64_t)q2;
+        return true;
     }
+#ifdef __HIP_DEVICE_COMPILE__
+    return false;            // a triple wider than 64 bits (coordinates spanning > 2^21 grid units): the host decoder takes the frame
+#else
+    unsigned __int128 v = 0;
+    int shift = 0, left = nbits;
+    while (left > 8) {
+        v |= (unsigned __int128)b.get(8) << shift;
+        shift += 8;
+        left -= 8;
+    }
+    if (left > 0) v |= (unsigned __int128)b.get(left) << shift;
+    const unsigned __int128 q = v / s[2];
+    out[2] = (int)(uint64_t)(v - q * s[2]);
+    const unsigned __int128 q2 = q / s[1];
+    out[1] = (int)(uint64_t)(q - q2 * s[1]);
+    out[0] = (int)(uint64_t)q2;
+    return true;
+#endif
 }
 
 // Small-delta triple: all three radices equal `m` (< 2^24) and nbits <= 72; with m^3 < 2^64 for every index
 // below 2^21, and the 128-bit path otherwise.
-inline void unpack3_small(Bits &b, int nbits, uint32_t m, int out[3]) {
+__host__ __device__ inline bool unpack3_small(Bits &b, int nbits, uint32_t m, int out[3]) {
     const uint32_t s[3] = {m, m, m};
-    unpack3(b, nbits, s, out);
+    return unpack3(b, nbits, s, out);
 }
 
 // Integer coordinates of a corrupt stream can be anything: additions wrap (two's complement) instead of overflowing a
 // signed int - the same values for every well-formed file, defined behaviour for the others (found by UBSan over
 // tests/test_xtc_cpu.py::test_corrupt_streams_do_not_crash, tools/asan_host.sh).
-inline int wrap_add(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+__host__ __device__ inline int wrap_add(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
 
-int decode_frame(const uint8_t *file, const FrameInfo &fi, float *out) {
+// returns 0, or: 2-6 corrupt stream, 7 (device only) the frame needs the host decoder
+__host__ __device__ int decode_frame(const uint8_t *file, const FrameInfo &fi, float *out) {
     const int natoms = fi.natoms;
     const uint8_t *h = file + fi.offset;
     if (natoms <= 9) {
@@ -184,9 +207,9 @@ int decode_frame(const uint8_t *file, const FrameInfo &fi, float *out) {
     } else {
         bitsize = bits_for_product(sizeint);
     }
-    int smaller = MAGIC[smallidx - 1 > FIRSTIDX ? smallidx - 1 : FIRSTIDX] / 2;
-    int smallnum = MAGIC[smallidx] / 2;
-    uint32_t sizesmall = (uint32_t)MAGIC[smallidx];
+    int smaller = magic_at(smallidx - 1 > FIRSTIDX ? smallidx - 1 : FIRSTIDX) / 2;
+    int smallnum = magic_at(smallidx) / 2;
+    uint32_t sizesmall = (uint32_t)magic_at(smallidx);
     const float inv_precision = 1.0f / fi.precision;
     const uint8_t *start = file + fi.data_off;
     Bits b{start, start + fi.nbytes};
@@ -198,7 +221,7 @@ int decode_frame(const uint8_t *file, const FrameInfo &fi, float *out) {
         if (bitsize == 0) {
             for (int k = 0; k < 3; ++k) cur[k] = (int)b.get(bitsizeint[k]);
         } else {
-            unpack3(b, bitsize, sizeint, cur);
+            if (!unpack3(b, bitsize, sizeint, cur)) return 7;
         }
         ++i;
         int px = wrap_add(cur[0], minint[0]), py = wrap_add(cur[1], minint[1]), pz = wrap_add(cur[2], minint[2]);
@@ -213,14 +236,14 @@ int decode_frame(const uint8_t *file, const FrameInfo &fi, float *out) {
             if (i + run / 3 > natoms) return 3;
             // first small atom is written BEFORE the atom it is coded against (water O/H ordering)
             int d[3];
-            unpack3_small(b, smallidx, sizesmall, d);
+            if (!unpack3_small(b, smallidx, sizesmall, d)) return 7;
             ++i;
             int qx = wrap_add(px, d[0] - smallnum), qy = wrap_add(py, d[1] - smallnum), qz = wrap_add(pz, d[2] - smallnum);
             o[0] = (float)qx * inv_precision; o[1] = (float)qy * inv_precision; o[2] = (float)qz * inv_precision;
             o[3] = (float)px * inv_precision; o[4] = (float)py * inv_precision; o[5] = (float)pz * inv_precision;
             o += 6;
             for (int k = 3; k < run; k += 3) {
-                unpack3_small(b, smallidx, sizesmall, d);
+                if (!unpack3_small(b, smallidx, sizesmall, d)) return 7;
                 ++i;
                 qx = wrap_add(qx, d[0] - smallnum); qy = wrap_add(qy, d[1] - smallnum); qz = wrap_add(qz, d[2] - smallnum);
                 o[0] = (float)qx * inv_precision; o[1] = (float)qy * inv_precision; o[2] = (float)qz * inv_precision;
@@ -236,15 +259,28 @@ int decode_frame(const uint8_t *file, const FrameInfo &fi, float *out) {
             if (smallidx < FIRSTIDX || smallidx > LASTIDX) return 4;
             if (is_smaller < 0) {
                 smallnum = smaller;
-                smaller = smallidx > FIRSTIDX ? MAGIC[smallidx - 1] / 2 : 0;
+                smaller = smallidx > FIRSTIDX ? magic_at(smallidx - 1) / 2 : 0;
             } else {
                 smaller = smallnum;
-                smallnum = MAGIC[smallidx] / 2;
+                smallnum = magic_at(smallidx) / 2;
             }
-            sizesmall = (uint32_t)MAGIC[smallidx];
+            sizesmall = (uint32_t)magic_at(smallidx);
         }
     }
     return (b.consumed_bits() + 7) / 8 == fi.nbytes ? 0 : 6;      // the block must be consumed exactly
+}
+
+// The frame is the parallel axis of XTC (a frame's bit stream is serial): on the host one thread per frame, here ONE LANE
+// per frame - 64 frames per wave in lockstep, each lane walking its own stream and writing its own 12 * natoms bytes.  A lane
+// is ~25x slower than a host core on one stream (64-bit divisions in software, every load its own cache line), but a batch
+// of a thousand frames keeps a thousand of them going: where 8 GPUs want 8 x 2000 frames/s of 250k atoms - 300 host threads
+// by the per-thread rate, more than a 256-core node has - the consumers can decode for themselves (~1 % of their
+// instruction budget).  Same code as the host path (decode_frame is compiled for both sides), so the same bits.
+__global__ void __launch_bounds__(64) xtc_decode_kernel(const uint8_t *__restrict__ blob, const FrameInfo *__restrict__ fi, uint32_t count,
+                                                        float *__restrict__ out, size_t natoms, int *__restrict__ status) {
+    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+    if (k >= count) return;
+    status[k] = decode_frame(blob, fi[k], out + (size_t)k * natoms * 3);
 }
 
 }  // namespace
@@ -420,6 +456,46 @@ int molar_hip_xtc_read(molar_hip_ctx *c, const molar_hip_xtc *x, size_t first, s
     for (auto &t : pool) t.join();
     if (dev) MH_HIP(hipStreamSynchronize(c->stream));
     if (err.load()) return fail(MOLAR_HIP_ERR_IO, "xtc_read: corrupt compressed block (code %d)", err.load());
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_xtc_read_device(molar_hip_ctx *c, const molar_hip_xtc *x, size_t first, size_t count, float *xyz_dev) {
+    if (!c || !x || !xyz_dev) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "xtc_read_device: null argument");
+    if (count == 0) return MOLAR_HIP_OK;
+    if (!is_device_ptr(xyz_dev)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "xtc_read_device: the destination must be device memory");
+    if (first + count > x->frames.size()) return fail(MOLAR_HIP_ERR_IO, "xtc_read_device: frames %zu..%zu past the end (%zu frames)", first, first + count, x->frames.size());
+    if (count > 0xFFFFFFFFull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "xtc_read_device: too many frames in one call");
+    const size_t natoms = (size_t)x->frames[first].natoms;
+    for (size_t k = first; k < first + count; ++k)
+        if ((size_t)x->frames[k].natoms != natoms) return fail(MOLAR_HIP_ERR_SIZES, "xtc_read_device: frame %zu has %d atoms, frame %zu has %zu", k, x->frames[k].natoms, first, natoms);
+    MH_HIP(hipSetDevice(c->device));
+    // the window's bytes [first frame's header, end of the last frame's block) and its frame table, offsets relative to the window
+    const uint64_t off0 = x->frames[first].offset;
+    const FrameInfo &last = x->frames[first + count - 1];
+    const uint64_t end = last.natoms <= 9 ? last.data_off + last.nbytes : last.data_off + ((last.nbytes + 3) & ~(uint64_t)3);
+    std::vector<FrameInfo> tab(x->frames.begin() + first, x->frames.begin() + first + count);
+    for (auto &f : tab) { f.offset -= off0; f.data_off -= off0; }
+    const size_t tab_bytes = count * sizeof(FrameInfo), st_bytes = count * sizeof(int);
+    MH_TRY(c->m_xyz2.reserve((size_t)(end - off0) + 8));
+    MH_TRY(c->m_idx2.reserve(tab_bytes + st_bytes));
+    MH_HIP(hipMemcpyAsync(c->m_xyz2.p, x->data + off0, (size_t)(end - off0), hipMemcpyHostToDevice, c->stream));
+    MH_HIP(hipMemcpyAsync(c->m_idx2.p, tab.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
+    int *d_status = reinterpret_cast<int *>(c->m_idx2.as<char>() + tab_bytes);
+    hipLaunchKernelGGL(xtc_decode_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream, c->m_xyz2.as<uint8_t>(),
+                       c->m_idx2.as<FrameInfo>(), (uint32_t)count, xyz_dev, natoms, d_status);
+    MH_HIP(hipGetLastError());
+    std::vector<int> status(count);
+    MH_HIP(hipMemcpyAsync(status.data(), d_status, st_bytes, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    std::vector<float> tmp;
+    for (size_t k = 0; k < count; ++k) {
+        if (status[k] == 0) continue;
+        if (status[k] != 7) return fail(MOLAR_HIP_ERR_IO, "xtc_read_device: corrupt compressed block in frame %zu (code %d)", first + k, status[k]);
+        tmp.resize(natoms * 3);                   // triples wider than 64 bits: the host decoder takes this frame
+        const int rc = decode_frame(x->data, x->frames[first + k], tmp.data());
+        if (rc) return fail(MOLAR_HIP_ERR_IO, "xtc_read_device: corrupt compressed block in frame %zu (code %d)", first + k, rc);
+        MH_HIP(hipMemcpy(xyz_dev + k * natoms * 3, tmp.data(), natoms * 12, hipMemcpyHostToDevice));
+    }
     return MOLAR_HIP_OK;
 }
 

@@ -129,3 +129,51 @@ def test_c5_shape_xtc_window_to_chained_membrane_frames(eng, orc32):
         for a, b in zip(got[k]["order"], want["order"]):
             assert a.tobytes() == b.tobytes()
         assert np.count_nonzero(got[k]["valid"]) > 3900
+
+
+@pytest.mark.parametrize("natoms,magic,precision,nframes", [(5, 1995, 1000.0, 3), (9, 1995, 1000.0, 70), (10, 1995, 1000.0, 5), (3000, 1995, 1000.0, 130),
+                                                            (3001, 2023, 1000.0, 7), (20000, 1995, 100.0, 64), (1000, 1995, 100000.0, 9),
+                                                            (1000, 1995, 3.0e6, 4)])
+def test_device_decoder_gives_the_bits_of_the_host_decoder(eng, orc32, natoms, magic, precision, nframes):
+    """molar_hip_xtc_read_device (one lane per frame) against molar_hip_xtc_read and the oracle's codec: small frames stored as
+    plain floats, the adaptive small-delta index, both magics, the separately coded > 24-bit integers, and (last case)
+    triples wider than 64 bits, which the call hands to the host decoder frame by frame."""
+    import torch
+    from molar_amd.xtc import XtcReader
+    from test_xtc_cpu import synthetic_frames
+    base, box9 = synthetic_frames(natoms, min(nframes, 6))
+    if precision > 1e4:
+        base = [f * 300.0 for f in base]
+    blob = b"".join(orc32.xtc_encode(base[k % len(base)] + np.float32(0.001 * k), box9, step=k, time=float(k), precision=precision, magic=magic)
+                    for k in range(nframes))
+    r = XtcReader(blob, engine=eng, nthreads=4)
+    assert len(r) == nframes
+    host = r.read_frames(0, nframes)
+    dev = torch.full((nframes, natoms, 3), float("nan"), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    r.read_frames_device(0, nframes, dev)
+    assert np.array_equal(dev.cpu().numpy(), host)
+    off = orc32.xtc_index(blob)
+    for k in (0, nframes - 1):
+        assert np.array_equal(host[k], orc32.xtc_decode(blob, off[k])[0])
+    # a window in the middle of the file
+    if nframes > 4:
+        dev2 = torch.empty((nframes - 3, natoms, 3), dtype=torch.float32, device="cuda")
+        r.read_frames_device(2, nframes - 3, dev2)
+        assert np.array_equal(dev2.cpu().numpy(), host[2:nframes - 1])
+
+
+def test_device_decoder_reports_corrupt_streams(eng, orc32):
+    import torch
+    from molar_amd._lib import MolarHipError
+    from molar_amd.xtc import XtcReader
+    from test_xtc_cpu import synthetic_frames
+    frames, box9 = synthetic_frames(600, 3)
+    blob = bytearray(b"".join(orc32.xtc_encode(f, box9, step=k, time=float(k)) for k, f in enumerate(frames)))
+    off = orc32.xtc_index(bytes(blob))
+    blob[off[1] + 84 + 3] = 200                       # smallidx of frame 1 out of range
+    r = XtcReader(bytes(blob), engine=eng)
+    dev = torch.empty((3, 600, 3), dtype=torch.float32, device="cuda")
+    with pytest.raises(MolarHipError):
+        r.read_frames_device(0, 3, dev)
+    r.read_frames_device(0, 1, dev[:1])               # the intact frame in front still decodes

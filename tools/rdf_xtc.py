@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--window", type=int, default=16, help="frames decoded per call")
     ap.add_argument("--threads", type=int, default=0, help="decoder threads per rank (0 = cores / ranks)")
     ap.add_argument("--path", default="/tmp/molar_amd_rdf.xtc")
+    ap.add_argument("--decoder", choices=("host", "device"), default="host",
+                    help="host: decoder threads + pinned staging (molar_hip_xtc_read); device: one lane per frame on the GPU "
+                         "(molar_hip_xtc_read_device; use --window 1024 or more)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -75,20 +78,30 @@ def main():
     pool = ThreadPoolExecutor(1)
     windows = [(f, min(W, mine.stop - f)) for f in range(mine.start, mine.stop, W)]
 
+    t_decode = [0.0]
+
     def decode(w):
         f, k = windows[w]
-        rd_dec.read_frames(f, k, out=bufs[w % 2][:k])                 # returns when the frames are in HBM
+        td = time.perf_counter()
+        if args.decoder == "device":
+            rd_dec.read_frames_device(f, k, bufs[w % 2][:k])
+        else:
+            rd_dec.read_frames(f, k, out=bufs[w % 2][:k])             # returns when the frames are in HBM
+        t_decode[0] += time.perf_counter() - td
         return k
 
+    t_consume = 0.0
     t0 = time.perf_counter()
     fut = pool.submit(decode, 0) if windows else None
     for w in range(len(windows)):
         k = fut.result()
         if w + 1 < len(windows):
             fut = pool.submit(decode, w + 1)                            # overlaps with the histogram launches below
+        tc = time.perf_counter()
         for q in range(k):
             eng.search_histogram(api.SEARCH_SINGLE, 1.2, 0.0, 1.2, 1200, bufs[w % 2][q], box=box, pbc=7, bins=bins, want_count=False)
         eng.synchronize()                                              # this window's buffer is free again
+        t_consume += time.perf_counter() - tc
     total_bins = reduce_counts(bins.cpu().numpy(), device=dev)       # the only collective: 1200 x int64
     torch.cuda.synchronize()
     elapsed = max_over_ranks(time.perf_counter() - t0, device=dev)
@@ -105,6 +118,11 @@ def main():
             ok = bool(np.array_equal(total_bins.astype(np.uint64), chk * np.uint64(nf // 4)))
         print(json.dumps({"workload": f"C4 end to end: XTC decode ({threads} threads/rank) -> HBM -> fused RDF histogram, {nf} frames x {n} atoms",
                           "n_gpus": world, "frames_per_s": nf / elapsed, "pairs_in_histogram": int(total_bins.sum()),
+                          "decoder": args.decoder, "window_frames": W,
+                          # rank 0's two sides, each over the time it was busy (they overlap: the slower one sets frames_per_s)
+                          "decode_frames_per_s": len(mine) / max(t_decode[0], 1e-9),
+                          "decode_frames_per_s_per_thread": (len(mine) / max(t_decode[0], 1e-9) / threads) if args.decoder == "host" else None,
+                          "consumer_frames_per_s": len(mine) / max(t_consume, 1e-9),
                           "reduced_bins_exact": ok, "collective": "one all_reduce of 1200 x int64"}))
     if world > 1:
         dist.destroy_process_group()
