@@ -159,6 +159,15 @@ struct molar_hip_ctx {
     bool count_done_set = false;
     bool record_count_done = false;      // set around the enqueue of a pipelined search
     bool env_grid_late = false;          // MOLAR_HIP_GRID_LATE: the next frame's grid waits for the count pass of the frame in flight (A/B runs)
+    bool env_onepass = false;            // MOLAR_HIP_ONEPASS=1: resident searches of the fixed-cutoff kinds run the one-pass kernel
+                                         // (onepass.hpp; measured slower than count + fill, kept as an experiment)
+    uint32_t env_op_run = 16;            // MOLAR_HIP_OP_RUN: consecutive plan entries an XCD takes at a time in the one-pass kernel
+    uint32_t env_op_dbg = 0;             // MOLAR_HIP_OP_DBG: profiling knobs of the one-pass kernel (wrong results)
+    bool onepass_broken = false;         // a one-pass search gave up (look-back timeout): this context stays on the two-pass kernels
+    bool onepass_now = false;            // set around prepare_search by a one-pass resident search: plan kernel only, no slots
+    bool slots_valid = false;            // the cached search has its slots, counts and offsets (count / fill state)
+    uint64_t op_nnodes = 0, op_nreg = 0, op_ntask_reg = 0;   // node layout of the one-pass kernel for the present plan
+    size_t op_state_word = 0;            // first word of the node descriptors inside scan_state (then: status, total)
     int hist_gen = 0;                    // generation of the last asynchronous histogram call
     bool on_side = false;                // launches currently go to side_stream (scans then use scan_tmp_side)
     mh::DevBuf scan_tmp_side;
@@ -181,7 +190,7 @@ struct molar_hip_ctx {
     mh::DevBuf &out_dist = out_dist_set[0];
     // pipelined resident searches (molar_hip_search_resident_begin/_end): two result sets, two tickets
     struct Ticket {
-        bool pending = false, degenerate = false;
+        bool pending = false, degenerate = false, onepass = false;
         unsigned long long cap0 = 0, maskcap0 = 0, serial = 0;
         hipEvent_t done = nullptr;
         molar_hip_search_desc desc{};

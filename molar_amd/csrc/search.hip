@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "hoststream.hpp"
 #include "pair_kernels.hpp"
+#include "onepass.hpp"
 #include "stages.hpp"
 
 using namespace mh;
@@ -1117,6 +1118,25 @@ int device_fmax(molar_hip_ctx *c, const float *d_v, uint32_t n, float *out) {
     return 0;
 }
 
+// Second half of the plan, for the kernels that walk slots (count / fill / histogram): slot index of every plan entry and
+// (fast kinds) its first hit-history unit by one single-pass scan over both, then one record per slot.  The one-pass
+// resident search stops in front of this; a fill call on such a cached search catches up here (ensure_slots).
+int enqueue_plan_slots(molar_hip_ctx *c) {
+    const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
+    const unsigned pbs = c->on_side ? 64u : 256u;          // one-wave workgroups on the side stream (place_order_kernel)
+    MH_TRY((scan_lookback<uint32_t, uint32_t, uint32_t, unsigned long long>(
+        c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), fast_kind ? c->task_mu.as<uint32_t>() : nullptr,
+        c->task_moff.as<unsigned long long>(), c->ntasks + 1, c->scan_state.as<unsigned long long>())));
+    // one record per slot (threads past the tasks blank the slots between the real count and the bound)
+    const unsigned nbs = (unsigned)((c->ntasks + c->nslots_bound + 1 + pbs - 1) / pbs);
+    hipLaunchKernelGGL(slotmap_kernel, dim3(nbs), dim3(pbs), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
+                       c->task_desc.as<TaskDesc>(), fast_kind ? c->task_moff.as<unsigned long long>() : nullptr,
+                       c->slot_desc.as<SlotDesc>(), c->nslots_bound, c->sizes_dev);
+    MH_HIP(hipGetLastError());
+    c->slots_valid = true;
+    return 0;
+}
+
 int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_masks = true) {
     if (!c || !q) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: null argument");
     if (q->kind < 0 || q->kind > 3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: unknown kind %d", q->kind);
@@ -1196,7 +1216,21 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
     MH_TRY(c->params.reserve(sizeof(SearchParams)));
     const size_t st_tasks = lookback_state_words(c->ntasks + 1), st_slots = lookback_state_words(c->nslots_bound + 1);
-    MH_TRY(c->scan_state.reserve((st_tasks + st_slots) * 8));
+    // one-pass resident searches (onepass.hpp): OP_NW nodes per plan entry, OP_KC for the entries of the last home cell when
+    // those may run the triclinic candidate loop; their descriptors, the status word and the total follow the scans' state
+    {
+        const uint64_t mult = two ? 2ull : 1ull;
+        const uint64_t ncorner = (c->use_box && c->pbc == MOLAR_HIP_PBC_FULL && c->box.nshift != 0) ? 14ull * mult : 0ull;
+        c->op_ntask_reg = c->ntasks - ncorner;
+        c->op_nreg = c->op_ntask_reg * (uint64_t)pairk::OP_NW;
+        c->op_nnodes = c->op_nreg + ncorner * (uint64_t)pairk::OP_KC;
+        c->op_state_word = st_tasks + st_slots;
+    }
+    const bool op_layout = c->op_nnodes < 0xFFFFFF00ull;
+    if (c->onepass_now && !op_layout) c->onepass_now = false;
+    const size_t op_nblk = (size_t)((c->op_nnodes + 63) / 64);
+    const size_t st_nodes = op_layout ? (size_t)c->op_nnodes + 2 * op_nblk + 8 : 0;     // node words, 2 x block words, status, total
+    MH_TRY(c->scan_state.reserve((st_tasks + st_slots + st_nodes) * 8));
     MH_TRY(c->task_mu.reserve((c->ntasks + 1) * 4));
     MH_TRY(c->task_moff.reserve((c->ntasks + 1) * 8));
     const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
@@ -1214,32 +1248,25 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         }
         // ntasks + 1 threads (the last one writes the scan terminators); the same grid zeroes the slot counters and the
         // descriptors of the two look-back scans of this search
-        const uint64_t nplan = std::max<uint64_t>(std::max<uint64_t>(c->ntasks + 1, c->nslots_bound + 1), st_tasks + st_slots);
+        const uint64_t nplan = std::max<uint64_t>(std::max<uint64_t>(c->ntasks + 1, c->nslots_bound + 1), st_tasks + st_slots + st_nodes);
         const unsigned pbs = c->on_side ? 64u : 256u;          // one-wave workgroups on the side stream (place_order_kernel)
         const unsigned nb = (unsigned)((nplan + pbs - 1) / pbs);
         switch (c->kind) {
             case MOLAR_HIP_SEARCH_SINGLE:
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(pbs), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
                                    c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
-                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots), params_dst);
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots + st_nodes), params_dst);
                 break;
             default:   // the three two-grid kinds decode tasks identically
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(pbs), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
                                    c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
-                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots), params_dst);
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots + st_nodes), params_dst);
                 break;
         }
-        // slot index of every task and (fast kinds) its first hit-history unit: one single-pass scan over both
-        MH_TRY((scan_lookback<uint32_t, uint32_t, uint32_t, unsigned long long>(
-            c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), fast_kind ? c->task_mu.as<uint32_t>() : nullptr,
-            c->task_moff.as<unsigned long long>(), c->ntasks + 1, c->scan_state.as<unsigned long long>())));
-        // one record per slot (threads past the tasks blank the slots between the real count and the bound)
-        const unsigned nbs = (unsigned)((c->ntasks + c->nslots_bound + 1 + pbs - 1) / pbs);
-        hipLaunchKernelGGL(slotmap_kernel, dim3(nbs), dim3(pbs), 0, c->stream, c->ntasks, c->task_nb.as<uint32_t>(),
-                           c->task_desc.as<TaskDesc>(), fast_kind ? c->task_moff.as<unsigned long long>() : nullptr,
-                           c->slot_desc.as<SlotDesc>(), c->nslots_bound, c->sizes_dev);
         MH_HIP(hipGetLastError());
-        return 0;
+        c->slots_valid = false;
+        if (c->onepass_now) return 0;       // the one-pass kernel reads the plan entries themselves: no slots
+        return enqueue_plan_slots(c);
     };
     // Pipelined search on a context that owns its stream, inputs already in device memory: the grid build goes to the
     // side stream.  It touches only this generation's GridSet (last read by the search two frames back, which has been
@@ -1448,10 +1475,27 @@ int molar_hip_search_grid_dims(molar_hip_ctx *c, uint64_t dims[3]) {
     return MOLAR_HIP_OK;
 }
 
+// A cached search left by the one-pass resident kernel has its grid and plan entries but no slots, counts or offsets:
+// the fill calls of the count / fill ABI catch up (rest of the plan, count pass, offset scan).
+static int ensure_slots(molar_hip_ctx *c) {
+    if (c->slots_valid || c->ntasks == 0) return 0;
+    MH_TRY(enqueue_plan_slots(c));
+    c->mask_units = 0;
+    if (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) {
+        unsigned long long units = 0;
+        MH_TRY(read_back(c, &units, c->task_moff.as<unsigned long long>() + c->ntasks, 8));
+        c->mask_units = units;
+        MH_TRY(c->maskbuf.reserve((size_t)units * 256u + 256u));
+    }
+    MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr));
+    return finish_count(c);
+}
+
 static int fill_common(molar_hip_ctx *c, uint2 *d_pairs, float *d_dist, uint32_t *d_ids) {
     if (!c || !c->have_search) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached search: call molar_hip_search_count first");
     MH_HIP(hipSetDevice(c->device));
     if (c->total == 0 || c->ntasks == 0) return 0;
+    MH_TRY(ensure_slots(c));
     return launch_pairs<true>(c, d_pairs, d_dist, d_ids);
 }
 
@@ -1508,11 +1552,14 @@ int molar_hip_search_fill_device(molar_hip_ctx *c, const uint32_t **d_pairs, con
 // (struct ResidentLaunch: stages.hpp)
 
 static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::DevBuf &outP, mh::DevBuf &outD,
-                            void *sizes, ResidentLaunch *L) {
+                            void *sizes, ResidentLaunch *L, bool allow_onepass = true) {
     if (q && q->kind == MOLAR_HIP_SEARCH_WITHIN)
         return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within search yields ids: use molar_hip_search_count + fill_ids");
     const unsigned long long a = outP.cap / 8u, b = outD.cap / 4u;
     const unsigned long long cap0 = a < b ? a : b;
+    // fixed-cutoff kinds: one pass over the candidates (onepass.hpp) unless this context has had to give it up
+    c->onepass_now = allow_onepass && c->env_onepass && !c->onepass_broken && q &&
+                     (q->kind == MOLAR_HIP_SEARCH_SINGLE || q->kind == MOLAR_HIP_SEARCH_DOUBLE);
     // `sizes` is pinned host memory: the kernels write the two sizes there themselves (slotmap_kernel the hit-history
     // units, slot_offsets_kernel the grand total) - no copy commands behind the fill pass
     void *sizes_dev = nullptr;
@@ -1523,6 +1570,8 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     c->plan_out_cap = cap0;
     c->sizes_dev = (unsigned long long *)sizes_dev;
     const int prc = prepare_search(c, q, /*size_masks=*/false);
+    const bool onepass = c->onepass_now;       // (prepare_search declines it for plans with too many nodes)
+    c->onepass_now = false;
     c->plan_out_cap = ~0ull;
     c->sizes_dev = nullptr;
     MH_TRY(prc);
@@ -1530,6 +1579,43 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     *L = ResidentLaunch{};
     L->degenerate = c->have_search;
     if (L->degenerate) return 0;
+    if (onepass) {
+        // grid -> plan entries -> ONE kernel: classification on the matrix cores, offsets by look-back, results expanded from
+        // the classification.  The plan kernel has written the parameter block (output capacity included) and zeroed the
+        // node descriptors, the status word and the total.
+        c->params_fresh = false;
+        unsigned long long *st = c->scan_state.as<unsigned long long>() + c->op_state_word;
+        pairk::OnePassArgs A{};
+        A.state = st;
+        const size_t nblk = (size_t)((c->op_nnodes + 63) / 64);
+        A.blk = st + c->op_nnodes;
+        A.blkp = A.blk + nblk;
+        A.nnodes = (uint32_t)c->op_nnodes;
+        A.nreg = (uint32_t)c->op_nreg;
+        A.ntask_reg = (uint32_t)c->op_ntask_reg;
+        A.xcd_run = c->env_op_run;
+        A.dbg = c->env_op_dbg;
+        A.pairs = outP.as<uint2>();
+        A.dist = outD.as<float>();
+        A.sizes_host = (unsigned long long *)sizes_dev;
+        A.status = reinterpret_cast<uint32_t *>(A.blkp + nblk);
+        A.total_dev = A.blkp + nblk + 1;
+        std::memset((char *)sizes + 16, 0, 8);         // status: written by the kernel only when it gives up or finishes
+        {
+            Prof prof(c, 3);
+            launch_onepass(c->kind, c->stream, c->params.as<SearchParams>(), A);
+            MH_HIP(hipGetLastError());
+        }
+        if (!sizes_dev) {
+            std::memset((char *)sizes + 8, 0, 8);
+            MH_HIP(hipMemcpyAsync(sizes, A.total_dev, 8, hipMemcpyDeviceToHost, c->stream));
+            MH_HIP(hipMemcpyAsync((char *)sizes + 16, A.status, 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        L->cap0 = cap0;
+        L->onepass = true;
+        L->total_dev = A.total_dev;
+        return 0;
+    }
     const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
     L->maskcap0 = c->maskbuf.cap / 256u;
     // one parameter block serves both passes: the count pass ignores the output capacity
@@ -1581,13 +1667,59 @@ static int resident_settle(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD,
     return 0;
 }
 
+// The sizes of a one-pass search have arrived: accept the result, or prepare the repeat (grow the result buffers; after a
+// look-back timeout keep this context on the two-pass kernels).
+static int onepass_accept(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD, const void *sizes, const ResidentLaunch &L, bool *ok) {
+    unsigned long long res[3] = {0, 0, 0};
+    std::memcpy(res, sizes, 24);
+    *ok = false;
+    if (res[2] != 0ull) {
+        c->onepass_broken = true;
+        return 0;
+    }
+    if (res[0] > L.cap0) {
+        MH_TRY(outP.reserve((size_t)(res[0] + res[0] / 16u) * 8));
+        MH_TRY(outD.reserve((size_t)(res[0] + res[0] / 16u) * 4));
+        return 0;
+    }
+    c->total = res[0];
+    c->mask_units = 0;
+    c->have_search = true;             // grid and plan entries are cached; the slots are built when a fill call asks (ensure_slots)
+    *ok = true;
+    return 0;
+}
+
+// One whole resident search, complete when the call returns (the stream has been waited for).
+static int resident_run(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::DevBuf &outP, mh::DevBuf &outD) {
+    MH_TRY(ensure_pinned(c, 64));
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        ResidentLaunch L;
+        MH_TRY(resident_enqueue(c, q, outP, outD, c->h_pinned, &L));
+        if (L.degenerate) return 0;
+        MH_HIP(hipStreamSynchronize(c->stream));
+        if (!L.onepass) return resident_settle(c, outP, outD, c->h_pinned, L);
+        bool ok = false;
+        MH_TRY(onepass_accept(c, outP, outD, c->h_pinned, L, &ok));
+        if (c->env_op_dbg & 8u) {      // look-back statistics of this frame (onepass.hpp, op_lookback)
+            unsigned long long w[6] = {0, 0, 0, 0, 0, 0};
+            MH_TRY(read_back(c, w, L.total_dev + 1, sizeof w));
+            std::fprintf(stderr, "onepass look-back: block wait %.3f us/node, prefix wait %.3f us/node, polls %.2f + %.2f per node, %.2f windows, longest %.1f us (%llu nodes)\n",
+                         w[0] * 0.01 / (double)c->op_nnodes, w[1] * 0.01 / (double)c->op_nnodes, (double)w[2] / (double)c->op_nnodes,
+                         (double)w[3] / (double)c->op_nnodes, (double)w[4] / (double)c->op_nnodes, w[5] * 0.01, (unsigned long long)c->op_nnodes);
+        }
+        if (ok) return 0;
+    }
+    return fail(MOLAR_HIP_ERR_HIP, "resident search: the result did not settle");
+}
+
 }  // extern "C"
 
 // stages.hpp: the resident search for callers that chain device work behind it
 int mh::search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, void *sizes_pinned, ResidentLaunch *L,
                                 const unsigned long long **total_dev, const uint32_t **pairs_dev) {
     std::memset(sizes_pinned, 0, 16);
-    MH_TRY(resident_enqueue(c, q, c->out_pairs, c->out_dist, sizes_pinned, L));
+    // (callers chain kernels behind the search that read slot_base's last entry: they stay on the count / fill passes)
+    MH_TRY(resident_enqueue(c, q, c->out_pairs, c->out_dist, sizes_pinned, L, /*allow_onepass=*/false));
     c->have_search = false;              // the sizes are not known to the host: not a cached search for the fill calls
     *total_dev = L->degenerate ? nullptr : c->slot_base.as<unsigned long long>() + c->nslots_bound;
     *pairs_dev = c->out_pairs.as<uint32_t>();
@@ -1618,13 +1750,7 @@ int molar_hip_search_resident(molar_hip_ctx *c, const molar_hip_search_desc *q, 
     if (!c) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: null argument");
     // Count, scan and fill are enqueued back to back against the capacities left by earlier frames; one
     // read-back tells whether the hit-bit buffer or the result buffers were too small.
-    MH_TRY(ensure_pinned(c, 64));
-    ResidentLaunch L;
-    MH_TRY(resident_enqueue(c, q, c->out_pairs, c->out_dist, c->h_pinned, &L));
-    if (!L.degenerate) {
-        MH_HIP(hipStreamSynchronize(c->stream));
-        MH_TRY(resident_settle(c, c->out_pairs, c->out_dist, c->h_pinned, L));
-    }
+    MH_TRY(resident_run(c, q, c->out_pairs, c->out_dist));
     if (out_count) *out_count = c->total;
     if (d_pairs) *d_pairs = c->out_pairs.as<uint32_t>();
     if (d_dist) *d_dist = c->out_dist.as<float>();
@@ -1638,7 +1764,7 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     if (T.pending)
         return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "both result sets are in flight: call molar_hip_search_resident_end first");
     MH_HIP(hipSetDevice(c->device));
-    if (!c->h_sizes) MH_HIP(hipHostMalloc(&c->h_sizes, 64, hipHostMallocDefault));
+    if (!c->h_sizes) MH_HIP(hipHostMalloc(&c->h_sizes, 64, hipHostMallocDefault));      // 32 bytes per ticket
     if (!T.done) MH_HIP(hipEventCreateWithFlags(&T.done, hipEventDisableTiming));
     T.desc = *q;
     ResidentLaunch L;
@@ -1655,7 +1781,7 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     c->side_wait2 = (c->count_done_set && c->env_grid_late) ? c->count_done : nullptr;
     if (c->env_grid_late && !c->count_done) MH_HIP(hipEventCreateWithFlags(&c->count_done, hipEventDisableTiming));
     c->record_count_done = c->env_grid_late;
-    const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 16 * slot, &L);
+    const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 32 * slot, &L);
     c->record_count_done = false;
     c->want_side = false;
     c->side_wait = nullptr;
@@ -1665,6 +1791,7 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     T.cap0 = L.cap0;
     T.maskcap0 = L.maskcap0;
     T.degenerate = L.degenerate;
+    T.onepass = L.onepass;
     T.serial = c->search_serial;
     T.pending = true;
     c->next_ticket ^= 1;
@@ -1684,12 +1811,25 @@ int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *ou
     uint64_t total = 0;
     if (!T.degenerate) {
         MH_HIP(hipEventSynchronize(T.done));
-        const void *sizes = (const char *)c->h_sizes + 16 * ticket;
-        unsigned long long res[2];
-        std::memcpy(res, sizes, 16);
+        const void *sizes = (const char *)c->h_sizes + 32 * ticket;
+        unsigned long long res[3];
+        std::memcpy(res, sizes, 24);
         const bool fast_kind = T.desc.kind == MOLAR_HIP_SEARCH_SINGLE || T.desc.kind == MOLAR_HIP_SEARCH_DOUBLE;
         total = res[0];
-        if (res[0] > T.cap0 || (fast_kind && res[1] > T.maskcap0)) {
+        if (T.onepass) {
+            if (res[2] != 0ull || res[0] > T.cap0) {
+                // the one-pass kernel gave up, or the result buffers were too small: let everything in flight finish (the other
+                // ticket's results sit in the other result set), then repeat the frame
+                MH_HIP(hipStreamSynchronize(c->stream));
+                ResidentLaunch L;
+                L.cap0 = T.cap0;
+                L.onepass = true;
+                bool ok = false;
+                MH_TRY(onepass_accept(c, outP, outD, sizes, L, &ok));      // grows the buffers / marks the context
+                MH_TRY(resident_run(c, &T.desc, outP, outD));
+                total = c->total;
+            }
+        } else if (res[0] > T.cap0 || (fast_kind && res[1] > T.maskcap0)) {
             // A buffer was too small (first frames of a trajectory).  Let everything in flight finish - a younger
             // search owns the context's intermediate buffers by now, its results sit in the other result set - then
             // grow and repeat: the affected passes if this is still the context's cached search, else the frame.
