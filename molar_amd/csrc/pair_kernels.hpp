@@ -332,7 +332,10 @@ __device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint3
         const uint32_t s = (F.head + lane) & (FIFO_CAP - 1);
         // F.pairs / F.dist / F.ids are per-lane pointers to entry (slot base + lane): the flush adds the FIFO head, and
         // the kernel's output pointers need not stay in (spilled) SGPRs
-        const uint32_t pos = F.head;
+        uint32_t pos = F.head;
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+        if (P.debug_skip & 32u) pos &= 63u;
+#endif
         if (KIND == MOLAR_HIP_SEARCH_WITHIN) {
             __builtin_nontemporal_store(F.fi[s], &F.ids[pos]);
         } else if (F.hist) {
@@ -348,9 +351,18 @@ __device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint3
             // (global_store ... nt) it does not take L2 lines from the second cell's records.  Fill pass 1.05 -> 0.98 ms,
             // 655-660 -> 680-695 frames/s on one box, alternating runs; "sc0 nt", "sc1 nt", "sc0 sc1 nt" the same, "sc1"
             // alone slower than plain stores (profiles/r03_store_policy_ab.txt).
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+            // knock-outs of the store path (timing only, wrong results; profiles/r04_store_knockout.txt): bit 4 no stores
+            // (everything else is computed), bit 5 every flush lands on the slot's first 64 entries
+            const float dist = __builtin_sqrtf(h.d2);
+            const bool wr = (P.debug_skip & 16u) ? dist == -1.0f : true;
+            if (F.has_pairs && wr) __builtin_nontemporal_store(((unsigned long long)h.j << 32) | h.i, reinterpret_cast<unsigned long long *>(&F.pairs[pos]));
+            if (F.has_dist && wr) __builtin_nontemporal_store(dist, &F.dist[pos]);
+#else
             if (F.has_pairs) __builtin_nontemporal_store(((unsigned long long)h.j << 32) | h.i, reinterpret_cast<unsigned long long *>(&F.pairs[pos]));
             // d2.sqrt() (:448): llvm.sqrt.f32 without fpmath metadata = IEEE correctly rounded
             if (F.has_dist) __builtin_nontemporal_store(__builtin_sqrtf(h.d2), &F.dist[pos]);
+#endif
         }
     }
     F.head += count;

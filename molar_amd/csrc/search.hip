@@ -1142,6 +1142,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     if (q->kind < 0 || q->kind > 3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: unknown kind %d", q->kind);
     MH_HIP(hipSetDevice(c->device));
     c->have_search = false;
+    c->slots_valid = false;
     c->kind = q->kind;
     const bool two = q->kind != MOLAR_HIP_SEARCH_SINGLE;
     const bool vdw = q->kind == MOLAR_HIP_SEARCH_DOUBLE_VDW;

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../molar_amd"
 mkdir -p _ab
 base="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize"
 objs=""
-for f in api search search_f64 measure measure_f64 membrane xtc pair_k0 pair_k1 pair_k2 pair_k3 pair_k4; do
+for f in api search search_f64 measure measure_f64 membrane xtc pair_k0 pair_k1 pair_k2 pair_k3 pair_k4 pair_k5; do
   if echo " $srcs " | grep -q " $f.hip "; then
     /opt/rocm/bin/hipcc $base $flags -c csrc/$f.hip -o _ab/${f}_$name.o
     objs="$objs _ab/${f}_$name.o"
