@@ -1137,6 +1137,31 @@ int enqueue_plan_slots(molar_hip_ctx *c) {
     return 0;
 }
 
+// Host-synchronous searches (count -> fill, histogram): what the plan came to, in one small read-back.
+//  * the hit-history units of the fast kinds: the buffer is sized exactly;
+//  * the number of slots: `nslots_bound` sizes every launch that walks slots (one workgroup per slot in the count and fill
+//    passes), and the bound counts 14 / 28 plan entries per cell whether or not both cells hold atoms.  Where one set is
+//    small (a solute in its solvent, the vdW overlap search of command_solvate.rs, `within` in its stream form) the plan is
+//    mostly empty - 3.2e6 workgroups launched for 1.6e5 slots cost 0.8 ms per pass in bare launches - so the launches of this
+//    search shrink to the slots that exist.  (Slot counters and records were prepared for the bound: a superset.)
+int size_plan(molar_hip_ctx *c) {
+    const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
+    if (!fast_kind && c->nslots_bound <= 65536ull) return 0;       // nothing to size, too few launches to save: no round trip
+    MH_TRY(ensure_pinned(c, 64));
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(c->h_pinned);
+    h[0] = h[1] = 0ull;
+    if (fast_kind) MH_HIP(hipMemcpyAsync(&h[0], c->task_moff.as<unsigned long long>() + c->ntasks, 8, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipMemcpyAsync(&h[1], c->task_nb.as<uint32_t>() + c->ntasks, 4, hipMemcpyDeviceToHost, c->stream));      // task_nb is scanned in place: the total
+    MH_HIP(hipStreamSynchronize(c->stream));
+    if (fast_kind) {
+        c->mask_units = h[0];
+        MH_TRY(c->maskbuf.reserve((size_t)h[0] * 256u + 256u));
+    }
+    const uint64_t real = (uint32_t)h[1];
+    if (real < c->nslots_bound) c->nslots_bound = real;
+    return 0;
+}
+
 int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_masks = true) {
     if (!c || !q) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: null argument");
     if (q->kind < 0 || q->kind > 3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: unknown kind %d", q->kind);
@@ -1313,12 +1338,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     // hit-history buffer of the count -> fill pair: sized exactly (one small read-back; the fused histogram
     // mode does not use it, but sizing it here keeps a later count/fill on the same cached search valid)
     c->mask_units = 0;
-    if (fast_kind && size_masks) {
-        unsigned long long units = 0;
-        MH_TRY(read_back(c, &units, c->task_moff.as<unsigned long long>() + c->ntasks, 8));
-        c->mask_units = units;
-        MH_TRY(c->maskbuf.reserve((size_t)units * 256u + 256u));
-    }
+    if (size_masks && !c->skip_plan) MH_TRY(size_plan(c));
     return 0;
 }
 
@@ -1482,12 +1502,7 @@ static int ensure_slots(molar_hip_ctx *c) {
     if (c->slots_valid || c->ntasks == 0) return 0;
     MH_TRY(enqueue_plan_slots(c));
     c->mask_units = 0;
-    if (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) {
-        unsigned long long units = 0;
-        MH_TRY(read_back(c, &units, c->task_moff.as<unsigned long long>() + c->ntasks, 8));
-        c->mask_units = units;
-        MH_TRY(c->maskbuf.reserve((size_t)units * 256u + 256u));
-    }
+    MH_TRY(size_plan(c));
     MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr));
     return finish_count(c);
 }
