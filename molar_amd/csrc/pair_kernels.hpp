@@ -23,6 +23,10 @@ enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2 };
 constexpr int waves_per_block(int mode) { return mode == MODE_HIST ? 4 : 1; }
 constexpr int KREG = 8;            // B-cell chunks (of 64 atoms) a lane keeps in registers
 constexpr int FIFO_CAP = 128;      // per-wave LDS FIFO entries (flush threshold 64, push <= 64)
+#ifndef MOLAR_HIP_NO_WIDE_FLUSH
+#define MOLAR_HIP_WIDE_FLUSH 1
+#endif
+constexpr int FIFO_WIDE = 256;     // ... of the plain entries' queue in the fill pass: flushed 128 at a time (fifo_flush_wide)
 constexpr uint32_t XCD_RUN = 128;  // consecutive slots an XCD takes at a time (pair_kernel)
 constexpr float F32_EPS = 1.1920929e-07f;
 constexpr bool MASKED_COUNT_SORTED = true;   // count pass of plain / same-cell entries walks the spatial order
@@ -326,10 +330,10 @@ __device__ __forceinline__ Hit fifo_hit(const SearchParams &P, const Fifo &F, ui
     return Hit{__float_as_uint(a.w), __float_as_uint(b.w), d2};
 }
 
-template <int KIND>
+template <int KIND, int CAP = FIFO_CAP>
 __device__ __forceinline__ void fifo_flush(const SearchParams &P, Fifo &F, uint32_t count, uint32_t lane) {
     if (lane < count && (F.hist || F.head + lane < F.room)) {
-        const uint32_t s = (F.head + lane) & (FIFO_CAP - 1);
+        const uint32_t s = (F.head + lane) & (CAP - 1);
         // F.pairs / F.dist / F.ids are per-lane pointers to entry (slot base + lane): the flush adds the FIFO head, and
         // the kernel's output pointers need not stay in (spilled) SGPRs
         uint32_t pos = F.head;
@@ -379,6 +383,52 @@ __device__ __forceinline__ void fifo_drain(const SearchParams &P, Fifo &F, uint3
         fifo_flush<KIND>(P, F, F.quota, lane);
         F.quota = 64u;
     } while (F.tail - F.head >= 64u);
+}
+
+// The plain (and same-cell) entries of the fill pass queue up to FIFO_WIDE hits and write 128 at a time: lane l takes entries
+// 2 l and 2 l + 1 - one 16-byte store of two (i, j) pairs and one 8-byte store of two distances per lane, 1 KB + 512 B
+// contiguous per wave instruction instead of 512 B + 256 B.  The slot's first flush goes, one entry per lane in rounds of 64
+// (fifo_flush), up to the next 128-entry boundary of the output; every later one is a naturally aligned block.
+template <int KIND>
+__device__ __forceinline__ void fifo_flush_wide(const SearchParams &P, Fifo &F, uint32_t lane) {
+    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const uint32_t e = F.head + 2u * lane;
+    if (e + 1u < F.room) {
+        const uint32_t s0 = e & (FIFO_WIDE - 1), s1 = (e + 1u) & (FIFO_WIDE - 1);
+        const u4_t pr = {F.fi[s0], F.fj[s0], F.fi[s1], F.fj[s1]};
+        const f2_t ds = {__builtin_sqrtf(__uint_as_float(F.fd[s0])), __builtin_sqrtf(__uint_as_float(F.fd[s1]))};   // d2.sqrt() (:448)
+        // F.pairs / F.dist point at entry (slot base + lane): + head + lane is entry head + 2 lane
+        if (F.has_pairs) __builtin_nontemporal_store(pr, reinterpret_cast<u4_t *>(&F.pairs[F.head + lane]));
+        if (F.has_dist) __builtin_nontemporal_store(ds, reinterpret_cast<f2_t *>(&F.dist[F.head + lane]));
+    } else if (e < F.room) {         // (the count pass gave this slot an odd number of entries and the fill pass more: never, but never past them)
+        const uint32_t s0 = e & (FIFO_WIDE - 1);
+        if (F.has_pairs) __builtin_nontemporal_store(((unsigned long long)F.fj[s0] << 32) | F.fi[s0], reinterpret_cast<unsigned long long *>(&F.pairs[F.head + lane]));
+        if (F.has_dist) __builtin_nontemporal_store(__builtin_sqrtf(__uint_as_float(F.fd[s0])), &F.dist[F.head + lane]);
+    }
+    F.head += 128u;
+}
+
+// >= 128 entries are queued (plain entries of the fill pass)
+template <int KIND>
+__device__ __forceinline__ void fifo_drain_wide(const SearchParams &P, Fifo &F, uint32_t lane) {
+    __builtin_amdgcn_wave_barrier();
+    do {
+        if (F.hist) {                    // consumer-fused mode on the generic kernel: the same queue, binned 64 at a time
+            fifo_flush<KIND, FIFO_WIDE>(P, F, 64u, lane);
+            fifo_flush<KIND, FIFO_WIDE>(P, F, 64u, lane);
+        } else if (F.quota != 128u) {    // the slot's first flush: up to the next 128-entry boundary of the output, one entry per lane
+            uint32_t left = F.quota;
+            while (left) {
+                const uint32_t c = left < 64u ? left : 64u;
+                fifo_flush<KIND, FIFO_WIDE>(P, F, c, lane);
+                left -= c;
+            }
+            F.quota = 128u;
+        } else {
+            fifo_flush_wide<KIND>(P, F, lane);
+        }
+    } while (F.tail - F.head >= 128u);
 }
 
 // One task = one ordered block of the reference's output:
@@ -1161,10 +1211,17 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
         return total;
     }
 
+    // plain and same-cell entries of the fill pass: queue of FIFO_WIDE, 128 entries per flush (fifo_flush_wide)
+#ifdef MOLAR_HIP_WIDE_FLUSH
+    constexpr bool WIDE = FILL && !WRAPPED && KIND != MOLAR_HIP_SEARCH_WITHIN;
+#else
+    constexpr bool WIDE = false;
+#endif
     if (FILL) {
         F.recompute = (WRAPPED && approx) ? 1u : 0u;
         F.la = la;
         F.wrap = T.wrap;
+        if (WIDE && !F.hist) F.quota = 128u - ((uint32_t)F.base & 127u);
     }
     uint32_t acc = 0;       // count pass.  !MASKED: per-lane hit counter (wrapped+approx: hits that are certain)
     uint32_t acc_hi = 0;    //              wrapped+approx: candidates at or below the upper edge of the band
@@ -1248,7 +1305,7 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
                         // FIFO slot = tail + rank among the hit lanes (mbcnt accumulates onto tail)
                         // (rank first, tail added with the shift: v_add_lshl_u32 takes the SGPR, no v_mov of the tail)
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                        const uint32_t off = ((rank + F.tail) << 2) & ((FIFO_CAP - 1u) << 2);
+                        const uint32_t off = ((rank + F.tail) << 2) & (((WIDE ? FIFO_WIDE : FIFO_CAP) - 1u) << 2);
                         typedef __attribute__((address_space(3))) uint32_t lds_u32;
                         *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fi + off) = id_i;
                         *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fj + off) = bid[k];
@@ -1256,7 +1313,9 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
                     }
                     F.tail += cnt;
                     total += cnt;
-                    if (F.tail - F.head >= 64u) fifo_drain<KIND>(P, F, lane);
+                    if (WIDE) {
+                        if (F.tail - F.head >= 128u) fifo_drain_wide<KIND>(P, F, lane);
+                    } else if (F.tail - F.head >= 64u) fifo_drain<KIND>(P, F, lane);
                 }
             }
         }
@@ -1294,7 +1353,14 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
         total = acc;
     } else if (F.tail != F.head) {
         __builtin_amdgcn_wave_barrier();
-        fifo_flush<KIND>(P, F, F.tail - F.head, lane);
+        if (WIDE) {                      // < 128 entries left (or a slot of fewer than 128 altogether): rounds of 64
+            while (F.tail != F.head) {
+                const uint32_t c = F.tail - F.head < 64u ? F.tail - F.head : 64u;
+                fifo_flush<KIND, FIFO_WIDE>(P, F, c, lane);
+            }
+        } else {
+            fifo_flush<KIND>(P, F, F.tail - F.head, lane);
+        }
     }
     if (FILL) F.recompute = 0u;
     return total;
@@ -1456,9 +1522,12 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
                                                      uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
                                                      uint32_t *__restrict__ out_ids) {
     constexpr int WAVES_PER_BLOCK = waves_per_block(MODE), BLOCK = 64 * WAVES_PER_BLOCK;
-    __shared__ uint32_t lds[WAVES_PER_BLOCK][3][FIFO_CAP];
+    // fill pass: three planes of FIFO_WIDE entries; the replay queue of the wrapped entries (FIFO_CAP x float4: the hits' second
+    // atoms, with the row numbers in plane 2) lies over planes 0 and 1, which a replaying slot does not use
+    constexpr int PLANE = MODE != MODE_COUNT ? FIFO_WIDE : FIFO_CAP;
+    static_assert(FIFO_CAP * 16 <= 2 * FIFO_WIDE * 4, "the replay queue fits in two planes");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[WAVES_PER_BLOCK][3][PLANE];
     __shared__ float4 lds_a[WAVES_PER_BLOCK][64];
-    __shared__ float4 lds_q[MODE == MODE_FILL ? WAVES_PER_BLOCK : 1][MODE == MODE_FILL ? FIFO_CAP : 1];   // replayed hits' second atoms
     __shared__ uint4 lds_h[MODE == MODE_COUNT ? WAVES_PER_BLOCK : 1][MODE == MODE_COUNT ? 128 : 1];       // matrix-core row records of the count pass
     constexpr bool FILL = MODE != MODE_COUNT;
     extern __shared__ uint32_t lds_hist[];     // histogram mode only (hist_nbins counters)
@@ -1529,7 +1598,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         F.recompute = 0u;
         F.la = lds_a[wave];
         F.fq = nullptr;
-        F.fq_store = MODE == MODE_FILL ? lds_q[wave] : nullptr;
+        F.fq_store = MODE == MODE_FILL ? reinterpret_cast<float4 *>(lds[wave][0]) : nullptr;
         F.lh = MODE == MODE_COUNT ? lds_h[wave] : nullptr;
         F.wrap = 0;
         F.hmin = P.hist_min;
