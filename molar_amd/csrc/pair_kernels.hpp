@@ -399,8 +399,14 @@ __device__ __forceinline__ void fifo_flush_wide(const SearchParams &P, Fifo &F, 
         const u4_t pr = {F.fi[s0], F.fj[s0], F.fi[s1], F.fj[s1]};
         const f2_t ds = {__builtin_sqrtf(__uint_as_float(F.fd[s0])), __builtin_sqrtf(__uint_as_float(F.fd[s1]))};   // d2.sqrt() (:448)
         // F.pairs / F.dist point at entry (slot base + lane): + head + lane is entry head + 2 lane
-        if (F.has_pairs) __builtin_nontemporal_store(pr, reinterpret_cast<u4_t *>(&F.pairs[F.head + lane]));
-        if (F.has_dist) __builtin_nontemporal_store(ds, reinterpret_cast<f2_t *>(&F.dist[F.head + lane]));
+        uint32_t at = F.head + lane;
+        bool wr = true;
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+        if (P.debug_skip & 16u) wr = ds.x == -1.0f;       // knock-outs, see fifo_flush
+        if (P.debug_skip & 32u) at = (F.head & 127u) + lane;
+#endif
+        if (F.has_pairs && wr) __builtin_nontemporal_store(pr, reinterpret_cast<u4_t *>(&F.pairs[at]));
+        if (F.has_dist && wr) __builtin_nontemporal_store(ds, reinterpret_cast<f2_t *>(&F.dist[at]));
     } else if (e < F.room) {         // (the count pass gave this slot an odd number of entries and the fill pass more: never, but never past them)
         const uint32_t s0 = e & (FIFO_WIDE - 1);
         if (F.has_pairs) __builtin_nontemporal_store(((unsigned long long)F.fj[s0] << 32) | F.fi[s0], reinterpret_cast<unsigned long long *>(&F.pairs[F.head + lane]));
