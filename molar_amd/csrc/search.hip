@@ -1137,7 +1137,7 @@ int enqueue_plan_slots(molar_hip_ctx *c) {
     return 0;
 }
 
-// Host-synchronous searches (count -> fill, histogram): what the plan came to, in one small read-back.
+// Host-synchronous searches (molar_hip_search_count -> fill calls): what the plan came to, in one small read-back.
 //  * the hit-history units of the fast kinds: the buffer is sized exactly;
 //  * the number of slots: `nslots_bound` sizes every launch that walks slots (one workgroup per slot in the count and fill
 //    passes), and the bound counts 14 / 28 plan entries per cell whether or not both cells hold atoms.  Where one set is
