@@ -175,6 +175,38 @@ def test_double_bit_exact_with_duplicates(eng, orc32, pbc):
     assert c.max() == 2
 
 
+@pytest.mark.parametrize("kind", ["double", "vdw"])
+def test_sparse_plan_small_set_in_a_large_one(eng, orc32, kind):
+    """A compact solute against its solvent (command_solvate.rs:94-101, `within`-like selections): most plan entries have
+    an empty cell on one side.  The host-synchronous search reads the plan's real slot count back and launches one workgroup
+    per slot that exists (size_plan); the result has to be what the full launch gave."""
+    a = api()
+    n = 120000
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, sigma=0.08)
+    centre = (box @ np.array([0.5, 0.5, 0.5], np.float32)).astype(np.float32)
+    order = np.argsort(((pos - centre) ** 2).sum(1))
+    solute = np.sort(order[:3000]).astype(np.uint64)
+    mask = np.ones(n, bool)
+    mask[solute.astype(int)] = False
+    solvent = np.nonzero(mask)[0].astype(np.uint64)
+    ob = orc32.box_from_matrix(box)
+    p1, p2 = pos[solvent.astype(int)], pos[solute.astype(int)]
+    if kind == "double":
+        ref = orc32.search_double_pbc(0.35, p1, p2, ob, 7, solvent, solute, nthreads=4)
+        cnt = eng.search_count(a.SEARCH_DOUBLE, 0.35, pos, solvent, pos, solute, box=box, pbc=7)
+    else:
+        rng = np.random.default_rng(3)
+        vdw = rng.choice(np.array([0.12, 0.152, 0.17, 0.21], np.float32), n)
+        v1, v2 = vdw[solvent.astype(int)], vdw[solute.astype(int)]
+        ref = orc32.search_double_vdw_pbc(p1, p2, v1, v2, ob, 7, nthreads=4)        # ids local to the two sets, as in the reference
+        cnt = eng.search_count(a.SEARCH_DOUBLE_VDW, None, pos, solvent, pos, solute, box=box, pbc=7, vdw1=v1, vdw2=v2)
+    assert cnt == len(ref["i"]) > 0
+    assert int(np.prod(eng.grid_dims())) * 28 > 65536      # a plan large enough for the slot count to be read back (size_plan)
+    pairs, d = eng.search_fill(cnt)
+    assert_same_pairs(pairs[:, 0], pairs[:, 1], d, ref)
+
+
 @pytest.mark.parametrize("pbc", [7, 0])
 def test_within_bit_exact(eng, orc32, pbc):
     a = api()
