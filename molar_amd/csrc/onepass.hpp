@@ -240,8 +240,7 @@ __device__ __forceinline__ void op_node(const SearchParams &P, const OnePassArgs
         for (int t = 0; t < MFMA_TILES; ++t) {
             const uint32_t col = (uint32_t)t * 32u + cl;
             bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                          // atom past the end: |b|^2 = 65504, never a hit
-            if (col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
-            if ((bq[t].w & 0x7C00u) == 0x7C00u) bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};      // non-finite atom: pairs with nothing
+            if (col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];  // (non-finite atoms carry that record since the grid build)
             if (kh == 0u) bq[t].w = 0x3C003C00u;                            // k = 6, 7 of the first half: (1, 1)
         }
     }

@@ -806,11 +806,14 @@ __device__ __forceinline__ uint32_t run_count_mfma(const SearchParams &P, const 
 #pragma unroll
     for (int t = 0; t < MFMA_TILES; ++t) {
         const uint32_t col = (uint32_t)t * 32u + cl;
-        bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                          // atom past the end: |b|^2 = 65504, never a hit
-        if (col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
-        // an atom with a NaN / infinite coordinate has a non-finite |b|^2: it pairs with nothing in the reference (its d2 is
-        // NaN or inf), but its accumulators would be NaNs of either sign
-        if ((bq[t].w & 0x7C00u) == 0x7C00u) bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};
+        // (a full block column - a wave-uniform test - is loaded as it is; only the cell's last, ragged one pays the per-lane
+        // selects.  Non-finite atoms carry the "never a hit" record since the grid build, place_order_kernel.)
+        if (32u * (uint32_t)(t + 1) <= T.n2) {
+            bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
+        } else {
+            bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                      // atom past the end: |b|^2 = 65504, never a hit
+            if (col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
+        }
     }
     if (TRI || need) la[rank] = a;                  // f32 rows (compacted), for the exact decision inside the band
     const float r0 = a.x - org.x, r1 = a.y - org.y, r2 = a.z - org.z;
@@ -989,11 +992,14 @@ __device__ __forceinline__ bool run_count_mfma_wrapped(const SearchParams &P, co
 #pragma unroll
     for (int t = 0; t < MFMA_TILES; ++t) {
         const uint32_t col = (uint32_t)t * 32u + cl;
-        bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                          // atom past the end: |b|^2 = 65504, never a hit
-        if (col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
-        // an atom with a NaN / infinite coordinate has a non-finite |b|^2: it pairs with nothing in the reference (its d2 is
-        // NaN or inf), but its accumulators would be NaNs of either sign
-        if ((bq[t].w & 0x7C00u) == 0x7C00u) bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};
+        // (a full block column - a wave-uniform test - is loaded as it is; only the cell's last, ragged one pays the per-lane
+        // selects.  Non-finite atoms carry the "never a hit" record since the grid build, place_order_kernel.)
+        if (32u * (uint32_t)(t + 1) <= T.n2) {
+            bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
+        } else {
+            bq[t] = u4_t{0u, 0u, 0u, 0x00007BFFu};                      // atom past the end: |b|^2 = 65504, never a hit
+            if (col < T.n2) bq[t] = ((const glb_u4 *)P.h16_b)[T.b0 + col];
+        }
     }
     {   // row records by RANK among the live rows; everything behind them is "a row past the end"
         ((lds_u4 *)lh)[2u * lane] = u4_t{0u, 0u, 0u, 0x00007BFFu};

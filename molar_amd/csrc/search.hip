@@ -322,7 +322,12 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
                 auto pk = [](_Float16 a, _Float16 b) -> uint32_t {
                     return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
                 };
-                h16[s + t] = make_uint4(pk(h[0], h[1]), pk(h[2], l[0]), pk(l[1], l[2]), pk(nh, nl));      // in the REFERENCE's cell order
+                // an atom with a NaN / infinite coordinate has a non-finite |b|^2: it pairs with nothing in the reference (its d2 is
+                // NaN or inf) but its accumulators would be NaNs of either sign - it gets the record of "an atom past the end"
+                // (|b|^2 = 65504, never a hit) here, once, instead of a test per tile in every slot of the count pass
+                const bool finite = (__builtin_bit_cast(unsigned short, nh) & 0x7C00u) != 0x7C00u;
+                h16[s + t] = finite ? make_uint4(pk(h[0], h[1]), pk(h[2], l[0]), pk(l[1], l[2]), pk(nh, nl))      // in the REFERENCE's cell order
+                                    : make_uint4(0u, 0u, 0u, 0x00007BFFu);
             }
             l3[0] = h3[0] = p.x; l3[1] = h3[1] = p.y; l3[2] = h3[2] = p.z;
         }
