@@ -181,6 +181,7 @@ struct molar_hip_ctx {
     mh::DevBuf tile_sum;       // u64 per tile of 256 slots: results of the tile (tile_sums_kernel -> slot_offsets_kernel)
     unsigned long long plan_out_cap = ~0ull;   // resident searches: the output capacity the plan kernel writes into the parameter block
     bool params_fresh = false;                 // the plan kernel of this search left a parameter block the count pass can use as it is
+    unsigned long long params_fresh_cap = 0;   // ... written with this output capacity
     unsigned long long *sizes_dev = nullptr;   // resident searches: device-side address of the pinned 16 bytes the kernels write the two sizes to
     mh::DevBuf scan_tmp;       // block sums for the scans
     mh::DevBuf scan_state;     // ticket + tile descriptors of the single-pass scans (zeroed by the plan kernel)

@@ -1007,7 +1007,9 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     // (a kernel argument, not a copy from pageable memory: the latter makes the host wait for the stream to drain,
     // which would serialise the begin/end pipelining of molar_hip_search_resident_begin)
     // (params_fresh: the plan kernel of this search has already written exactly this block - resident searches)
-    const bool plan_wrote = c->params_fresh && !FILL && !hist_nbins && out_cap == c->plan_out_cap;
+    // (compared with the capacity the plan kernel was given: resident_enqueue has reset plan_out_cap by now - comparing with
+    // that made every resident search upload the block again, 8.6 us on the critical stream of every frame, until round 4)
+    const bool plan_wrote = c->params_fresh && !FILL && !hist_nbins && out_cap == c->params_fresh_cap;
     c->params_fresh = false;
     if (!params_resident && !plan_wrote)
         hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, c->stream, P, c->params.as<SearchParams>());
@@ -1276,6 +1278,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
             P.out_cap = c->plan_out_cap;
             params_dst = c->params.as<SearchParams>();
             c->params_fresh = true;
+            c->params_fresh_cap = P.out_cap;
         }
         // ntasks + 1 threads (the last one writes the scan terminators); the same grid zeroes the slot counters and the
         // descriptors of the two look-back scans of this search
