@@ -159,6 +159,7 @@ molar_hip_ctx *molar_hip_create(int device) {
     c->env_no_tile_sum = std::getenv("MOLAR_HIP_NO_TILE_SUM") != nullptr;
     c->env_host_grid_wait = std::getenv("MOLAR_HIP_HOST_GRID_WAIT") != nullptr;
     c->env_grid_late = std::getenv("MOLAR_HIP_GRID_LATE") != nullptr;
+    c->env_no_bin_tile = std::getenv("MOLAR_HIP_NO_BIN_TILE") != nullptr;
     if (const char *op = std::getenv("MOLAR_HIP_ONEPASS")) c->env_onepass = std::atoi(op) != 0;
     if (const char *dbg = std::getenv("MOLAR_HIP_OP_DBG")) c->env_op_dbg = (uint32_t)std::atoi(dbg);
     if (const char *run = std::getenv("MOLAR_HIP_OP_RUN")) c->env_op_run = (uint32_t)std::max(1, std::atoi(run));

@@ -159,6 +159,7 @@ struct molar_hip_ctx {
     bool count_done_set = false;
     bool record_count_done = false;      // set around the enqueue of a pipelined search
     bool env_grid_late = false;          // MOLAR_HIP_GRID_LATE: the next frame's grid waits for the count pass of the frame in flight (A/B runs)
+    bool env_no_bin_tile = false;        // MOLAR_HIP_NO_BIN_TILE: the grid's binning with one global atomic per atom (A/B runs)
     bool env_onepass = false;            // MOLAR_HIP_ONEPASS=1: resident searches of the fixed-cutoff kinds run the one-pass kernel
                                          // (onepass.hpp; measured slower than count + fill, kept as an experiment)
     uint32_t env_op_run = 16;            // MOLAR_HIP_OP_RUN: consecutive plan entries an XCD takes at a time in the one-pass kernel

@@ -866,6 +866,40 @@ def test_resident_pipelined_begin_end_matches_the_plain_call():
     check(3, e2.search_resident_desc(descs[3][0]))
 
 
+def test_pipelined_large_frames_privatised_binning():
+    """Frames of >= 2^19 atoms whose grid is built on the side stream are binned with counters privatised in LDS
+    (bin_tile_kernel): three 600k-atom frames through begin / end, two in flight, against count + fill on another context
+    (which bins with one atomic per atom on its main stream); order-sensitive comparison on the device."""
+    import torch
+    a = api()
+    from molar_amd.api import Engine
+    e1, e2 = Engine(0), Engine(0)
+    n = 600_000
+    box = synth.box_a(n)
+    frames = [torch.from_numpy(synth.frame(n, box, k)).cuda() for k in range(3)]
+    descs = [e2.make_search_desc(a.SEARCH_SINGLE, 1.0, f, box=box, pbc=7) for f in frames]
+
+    def view(pp, dp, cnt):
+        return a.device_view(pp, (cnt, 2), torch.int32), a.device_view(dp, (cnt,), torch.float32)
+
+    def check(k, res):
+        cnt, pp, dp = res
+        wn = e1.search_count(a.SEARCH_SINGLE, 1.0, frames[k], box=box, pbc=7)
+        assert cnt == wn > 0
+        wp, wd = e1.search_fill_device()
+        e1.synchronize()              # the fill is only enqueued on e1's stream
+        gp, gd = view(pp, dp, cnt)
+        assert torch.equal(gp, a.device_view(wp, (cnt, 2), torch.int32)) and torch.equal(gd, a.device_view(wd, (cnt,), torch.float32)), f"frame {k}"
+
+    prev = None
+    for k in range(3):
+        t = e2.search_resident_begin(descs[k][0])
+        if prev is not None:
+            check(prev[0], e2.search_resident_end(prev[1]))
+        prev = (k, t)
+    check(prev[0], e2.search_resident_end(prev[1]))
+
+
 def test_randomised_differential(monkeypatch):
     """tools/fuzz_search.py: random boxes / cutoffs / densities / periodicity masks / selections / kinds, count+fill and
     resident entries, against the oracle - every case bit-identical (9000 cases were run this way in round 1)."""
