@@ -134,8 +134,8 @@ __global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restr
 // cell's share with ONE returning global atomic and adds the base to the ranks.  A tile of 8192 atoms touches ~3400 of the headline
 // frame's 3825 cells: 0.41 M global atomics instead of 1 M.  (Arrival order stays arbitrary - place_order_kernel ranks by input
 // index.)  For grids whose counters fit in LDS.
-constexpr uint32_t BIN_PER_THREAD = 32;
 constexpr uint32_t BIN_TILE_MAX_CELLS = 12288;      // 48 KB of LDS counters
+template <uint32_t BIN_PER_THREAD>
 __global__ void __launch_bounds__(256) bin_tile_kernel(BinParams P, uint32_t *__restrict__ key, uint32_t *__restrict__ arrival,
                                                        uint32_t *__restrict__ counters, uint32_t pad_shift, uint32_t ncells) {
     extern __shared__ uint32_t bin_cnt[];
@@ -850,8 +850,14 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         // (on the side stream, beside the pair kernels of the frame in flight: there the privatised form wins - 692-695 against
         // 699-706 frames/s in three alternations; alone it is 10 us SLOWER on the 1M-atom frame - 123 workgroups - so searches
         // that build their grid on the main stream keep one atomic per atom)
-        if (!c->env_no_bin_tile && c->on_side && ncells <= BIN_TILE_MAX_CELLS && (uint64_t)S.n >= 16ull * ncells && S.n >= (1u << 19))      // (250k atoms: 31 tiles are too few - the grid's span grows from 0.12 to 0.35 ms, frames/s equal)
-            hipLaunchKernelGGL(bin_tile_kernel, dim3((S.n + 256u * BIN_PER_THREAD - 1u) / (256u * BIN_PER_THREAD)), dim3(256), (size_t)ncells * 4, c->stream,
+        const bool tile_ok = !c->env_no_bin_tile && c->on_side && ncells <= BIN_TILE_MAX_CELLS && (uint64_t)S.n >= 16ull * ncells;
+        // (tiles of 8192 atoms for the 1M-atom frame; at 250k atoms 31 of those are too few - the grid's span grew from 0.12 to
+        // 0.35 ms - so smaller frames take tiles of 2048)
+        if (tile_ok && S.n >= (1u << 19))
+            hipLaunchKernelGGL(bin_tile_kernel<32>, dim3((S.n + 256u * 32u - 1u) / (256u * 32u)), dim3(256), (size_t)ncells * 4, c->stream,
+                               P, S.key.as<uint32_t>(), S.cursor.as<uint32_t>(), counters, pad_shift, ncells);
+        else if (tile_ok && S.n >= (1u << 17))
+            hipLaunchKernelGGL(bin_tile_kernel<8>, dim3((S.n + 256u * 8u - 1u) / (256u * 8u)), dim3(256), (size_t)ncells * 4, c->stream,
                                P, S.key.as<uint32_t>(), S.cursor.as<uint32_t>(), counters, pad_shift, ncells);
         else
         hipLaunchKernelGGL(bin_kernel, dim3(nb), dim3(bs), 0, c->stream, P, S.key.as<uint32_t>(),
