@@ -161,7 +161,10 @@ typedef struct {
 int molar_hip_search_count(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_count);
 /* Phase 2 (fill), results in exactly the reference's order (plan order, then i-major, j-minor;
  * distance_search.rs:949-953).  pairs: uint32 [count][2] (i,j); dist: float[count] = sqrt(d2)
- * (DistanceSearchOutput for (usize,usize,Float), :22-26).  Either may be NULL to skip it. */
+ * (DistanceSearchOutput for (usize,usize,Float), :22-26).  Either may be NULL to skip it.
+ * Outputs in DEVICE memory must be aligned to 16 bytes (pairs) and 8 bytes (dist) - the fill pass
+ * writes two results per lane and store instruction; anything else is MOLAR_HIP_ERR_INVALID_ARGUMENT
+ * (hipMalloc and framework allocators give 256 bytes; only offset views can violate it). */
 int molar_hip_search_fill(molar_hip_ctx *ctx, uint32_t *pairs, float *dist);
 /* Same, widened to MolAR's usize: separate i[], j[] arrays of uint64. */
 int molar_hip_search_fill_usize(molar_hip_ctx *ctx, uint64_t *i, uint64_t *j, float *dist);
@@ -563,6 +566,12 @@ int molar_hip_xtc_read(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t first,
  * this pays for windows of hundreds to thousands of frames - when the consumers of a multi-GPU node outrun the host's
  * decoder threads.  Frames whose packed triples exceed 64 bits fall back to the host decoder inside the call. */
 int molar_hip_xtc_read_device(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t first, size_t count, float *xyz_dev);
+/* Writer (xtc_handler.rs:117-168, write_state through molly::XTCWriter): ONE frame in GROMACS' compressed coordinate format
+ * (magic 1995; xdrfile's algorithm: integer grid at `precision`, mixed-radix triples, runs of small deltas with an adaptive
+ * delta size) into out[cap]; *out_len = bytes written, frames are simply concatenated in a file.  96 + 16 * natoms bytes
+ * always suffice.  box9 as in the header (9 floats, the order the file stores).  Host memory only. */
+int molar_hip_xtc_encode_frame(const float *xyz, size_t natoms, const float *box9, int32_t step, float time, float precision,
+                               uint8_t *out, size_t cap, size_t *out_len);
 
 /* ------------------------------------------------------------------ Modify (modify.rs) */
 

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <exception>
@@ -345,7 +346,9 @@ class SelBound {
     // them as selections of this selection)
     std::vector<std::vector<usize>> unwrap_connectivity_dim(Float cutoff, PbcDims dims) {
         const size_t n = index_.size();
-        std::vector<uint64_t> off(n + 1), ids(n ? n : 1);
+        // (an empty index vector may hand out data() == NULL, which the C ABI reads as "all atoms": MolAR has no empty selections)
+        if (n == 0) throw MolarError(MOLAR_HIP_ERR_INVALID_ARGUMENT, "unwrap_connectivity: empty selection");
+        std::vector<uint64_t> off(n + 1), ids(n);
         size_t ng = 0;
         check(molar_hip_unwrap_connectivity(ctx(), coords_ptr_mut(), natoms(), index_.data(), n, require_box().colmajor9(), cutoff,
                                             dims.raw(), off.data(), ids.data(), &ng));
@@ -825,6 +828,34 @@ class XtcReader {
         if (skip_to_frame) r->seek_frame(*skip_to_frame);
         if (skip_to_time) r->seek_time(*skip_to_time);
         return [r]() { return r->read_state(); };
+    }
+};
+
+// XTC writer: FileFormatHandler::create + write_state (xtc_handler.rs:54-62, 117-168); frames are appended to one file.
+class XtcWriter {
+    std::FILE *f_;
+    Float precision_;
+    size_t nframes_ = 0;
+    std::vector<uint8_t> buf_;
+
+   public:
+    explicit XtcWriter(const std::string &path, Float precision = 1000.0f) : f_(std::fopen(path.c_str(), "wb")), precision_(precision) {
+        if (!f_) throw MolarError(MOLAR_HIP_ERR_IO, "cannot create " + path);
+    }
+    XtcWriter(const XtcWriter &) = delete;
+    XtcWriter &operator=(const XtcWriter &) = delete;
+    ~XtcWriter() {
+        if (f_) std::fclose(f_);
+    }
+    size_t nframes() const { return nframes_; }
+    void write_state(const State &st) {
+        static const float zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        buf_.resize(96 + 16 * st.coords.size());
+        size_t len = 0;
+        check(molar_hip_xtc_encode_frame(st.coords.empty() ? nullptr : &st.coords[0].x, st.coords.size(), st.pbox ? st.pbox->colmajor9() : zero9,
+                                         (int32_t)nframes_, st.time, precision_, buf_.data(), buf_.size(), &len));
+        if (std::fwrite(buf_.data(), 1, len, f_) != len) throw MolarError(MOLAR_HIP_ERR_IO, "failed to write frame");      // XtcHandlerError::WriteFrame
+        ++nframes_;
     }
 };
 

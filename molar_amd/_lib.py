@@ -174,6 +174,7 @@ SYMBOLS = {
     "molar_hip_xtc_seek_time": (_I, [_P, C.c_float, _P]),
     "molar_hip_xtc_read": (_I, [_P, _P, _SZ, _SZ, _P, _I]),
     "molar_hip_xtc_read_device": (_I, [_P, _P, _SZ, _SZ, _P]),
+    "molar_hip_xtc_encode_frame": (_I, [_P, _SZ, _P, C.c_int32, C.c_float, C.c_float, _P, _SZ, _P]),
     "molar_hip_lipid_tail_order": (_I, [_P, _P, _SZ, _P, _P, _SZ, _I, _P, _P, _P, _P]),
     "molar_hip_apply_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
     "molar_hip_unwrap_simple": (_I, [_P, _P, _SZ, _P, _SZ, _P, _U8]),

@@ -544,6 +544,8 @@ class Engine:
         groups of LOCAL indices the reference returns as selections."""
         if not _is_torch(xyz):
             assert xyz.dtype == np.float32 and xyz.flags.c_contiguous, "unwrap_connectivity works in place"
+        if idx is not None and len(idx) == 0:      # (a NULL index means "all atoms" to the C ABI: never pass an empty one as NULL)
+            raise ValueError("unwrap_connectivity: empty selection")
         xa, na, ia, n, k = self._sel_args(xyz, idx)
         nsel = n if idx is not None else na
         ba, kb = self._box9(box)

@@ -152,7 +152,9 @@ molar_hip_ctx *molar_hip_create(int device) {
         return nullptr;
     }
     c->own_stream = true;
-    // environment knobs are read here, once: the per-search paths never call getenv
+    // The release library has ONE code path: no environment variable selects a kernel.  Builds with -DMOLAR_HIP_AB_KNOBS
+    // (tools/build_variant.sh, A/B runs on one box) read these switches here, once - the per-search paths never call getenv.
+#ifdef MOLAR_HIP_AB_KNOBS
     c->env_no_side = std::getenv("MOLAR_HIP_NO_SIDE_STREAM") != nullptr;
     c->env_no_mfma = std::getenv("MOLAR_HIP_NO_MFMA_COUNT") != nullptr;
     c->env_no_mfma_wrapped = std::getenv("MOLAR_HIP_NO_MFMA_WRAPPED") != nullptr;
@@ -160,11 +162,10 @@ molar_hip_ctx *molar_hip_create(int device) {
     c->env_host_grid_wait = std::getenv("MOLAR_HIP_HOST_GRID_WAIT") != nullptr;
     c->env_grid_late = std::getenv("MOLAR_HIP_GRID_LATE") != nullptr;
     c->env_no_bin_tile = std::getenv("MOLAR_HIP_NO_BIN_TILE") != nullptr;
-    if (const char *op = std::getenv("MOLAR_HIP_ONEPASS")) c->env_onepass = std::atoi(op) != 0;
-    if (const char *dbg = std::getenv("MOLAR_HIP_OP_DBG")) c->env_op_dbg = (uint32_t)std::atoi(dbg);
-    if (const char *run = std::getenv("MOLAR_HIP_OP_RUN")) c->env_op_run = (uint32_t)std::max(1, std::atoi(run));
+#endif
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     if (const char *dbg = std::getenv("MOLAR_HIP_DEBUG_SKIP")) c->env_debug_skip = (uint32_t)std::atoi(dbg);
+    if (const char *dbg = std::getenv("MOLAR_HIP_DEBUG_LAUNCH")) c->env_debug_launch = (uint32_t)std::atoi(dbg);
 #endif
     if (ensure_pinned(c, 1 << 16)) {
         (void)hipStreamDestroy(c->stream);
@@ -185,7 +186,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
             b->release();
     }
     for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->tile_sum, &c->scan_tmp, &c->scan_tmp_side, &c->scan_state, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
-                      &c->wide_i, &c->wide_j, &c->hist, &c->w_flags, &c->w_part_cnt, &c->w_part, &c->w_tile_cnt, &c->w_tile_off, &c->task_mu, &c->task_moff, &c->maskbuf, &c->m_xyz1, &c->m_xyz2, &c->m_idx1, &c->m_idx2,
+                      &c->wide_i, &c->wide_j, &c->hist, &c->hist_queue, &c->hist_edges, &c->dbg, &c->w_flags, &c->w_part_cnt, &c->w_part, &c->w_tile_cnt, &c->w_tile_off, &c->task_mu, &c->task_moff, &c->maskbuf, &c->m_xyz1, &c->m_xyz2, &c->m_idx1, &c->m_idx2,
                       &c->m_mass1, &c->m_mass2, &c->m_partials, &c->m_results, &c->m_out})
         b->release();
     for (auto &s : c->spans) {

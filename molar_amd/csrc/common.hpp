@@ -151,6 +151,7 @@ struct molar_hip_ctx {
     bool env_host_grid_wait = false;     // MOLAR_HIP_HOST_GRID_WAIT: the host, not the main stream, waits for the side stream's grid
     bool env_no_tile_sum = false;        // MOLAR_HIP_NO_TILE_SUM: slot offsets by the general three-kernel scan (A/B runs)
     uint32_t env_debug_skip = 0;         // MOLAR_HIP_DEBUG_SKIP (builds with -DMOLAR_HIP_DEBUG_KNOBS only), read once
+    uint32_t env_debug_launch = 0, dbg_launches = 0;   // MOLAR_HIP_DEBUG_LAUNCH (same builds): which histogram launch records its wave times
     hipEvent_t gen_free[2] = {nullptr, nullptr};   // recorded on the main stream behind the last asynchronous reader of
                                                    // a grid generation (histogram calls that do not wait)
     hipEvent_t side_wait = nullptr;      // what the side stream has to wait for before it rebuilds the generation
@@ -160,15 +161,6 @@ struct molar_hip_ctx {
     bool record_count_done = false;      // set around the enqueue of a pipelined search
     bool env_grid_late = false;          // MOLAR_HIP_GRID_LATE: the next frame's grid waits for the count pass of the frame in flight (A/B runs)
     bool env_no_bin_tile = false;        // MOLAR_HIP_NO_BIN_TILE: the grid's binning with one global atomic per atom (A/B runs)
-    bool env_onepass = false;            // MOLAR_HIP_ONEPASS=1: resident searches of the fixed-cutoff kinds run the one-pass kernel
-                                         // (onepass.hpp; measured slower than count + fill, kept as an experiment)
-    uint32_t env_op_run = 16;            // MOLAR_HIP_OP_RUN: consecutive plan entries an XCD takes at a time in the one-pass kernel
-    uint32_t env_op_dbg = 0;             // MOLAR_HIP_OP_DBG: profiling knobs of the one-pass kernel (wrong results)
-    bool onepass_broken = false;         // a one-pass search gave up (look-back timeout): this context stays on the two-pass kernels
-    bool onepass_now = false;            // set around prepare_search by a one-pass resident search: plan kernel only, no slots
-    bool slots_valid = false;            // the cached search has its slots, counts and offsets (count / fill state)
-    uint64_t op_nnodes = 0, op_nreg = 0, op_ntask_reg = 0;   // node layout of the one-pass kernel for the present plan
-    size_t op_state_word = 0;            // first word of the node descriptors inside scan_state (then: status, total)
     int hist_gen = 0;                    // generation of the last asynchronous histogram call
     bool on_side = false;                // launches currently go to side_stream (scans then use scan_tmp_side)
     mh::DevBuf scan_tmp_side;
@@ -192,7 +184,7 @@ struct molar_hip_ctx {
     mh::DevBuf &out_dist = out_dist_set[0];
     // pipelined resident searches (molar_hip_search_resident_begin/_end): two result sets, two tickets
     struct Ticket {
-        bool pending = false, degenerate = false, onepass = false;
+        bool pending = false, degenerate = false;
         unsigned long long cap0 = 0, maskcap0 = 0, serial = 0;
         hipEvent_t done = nullptr;
         molar_hip_search_desc desc{};
@@ -203,6 +195,8 @@ struct molar_hip_ctx {
     mh::DevBuf out_ids;
     mh::DevBuf wide_i, wide_j; // usize widening
     mh::DevBuf hist;           // u64 bins
+    mh::DevBuf dbg;            // builds with -DMOLAR_HIP_DEBUG_KNOBS: per-wave time accounting of hist_kernel
+    mh::DevBuf hist_queue;     // slot queues of hist_kernel (hist_kernels.hpp): zero between launches
     mh::DevBuf hist_edges;     // f32[nbins + 1]: smallest d2 that reaches each bin (hist_kernel), for the cached (min, max, nbins)
     float edges_min = 0.f, edges_max = 0.f;
     size_t edges_nbins = 0;    // 0: no table cached

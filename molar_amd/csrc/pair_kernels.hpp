@@ -101,6 +101,7 @@ struct SearchParams {
     uint32_t hist_lean;      // histogram mode: hist_kernel takes the slots hist_lean_slot() accepts, pair_kernel<MODE_HIST> the rest
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     uint32_t debug_skip;     // profiling aid (env MOLAR_HIP_DEBUG_SKIP): bit0 plain, bit1 wrapped, bit2 triangular slots do nothing
+    unsigned long long *dbg; // per-wave time accounting of hist_kernel (8 words per wave), molar_hip_debug_fetch
 #endif
     float cutoff2;
     uint64_t ntasks;
@@ -1670,371 +1671,6 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
 }
 
 
-// ================================================================= fused histogram, lean kernel
-// Consumer-fused histogram (molar_hip_search_histogram) for the slots that make up nearly all of the work: plain,
-// same-cell and band-classified wrapped entries whose second cell fits in registers.  Bins do not depend on the order
-// in which hits are found, so
-//  * plain and same-cell entries walk the second cell in the spatial order of the count pass (chunk bounding boxes:
-//    ~43 % of the candidate evaluations of the neighbour entries skipped) and queue only d2 (one LDS plane);
-//  * wrapped entries queue (row, unshifted second atom) in LDS and the exact PeriodicBox::distance_squared of the
-//    hits is evaluated densely at flush time (no global gather in the flush);
-//  * 64 queued hits at a time go through sqrt + Histogram1D::add_one (molar_membrane/src/stats.rs:29-35);
-//  * the queue of plain hits carries over from one slot to the next (no partial flush per slot).
-// Everything else (triclinic corner entries, cells > 512 atoms, vdW radii, boxes without the band classification)
-// stays with pair_kernel<KIND, MODE_HIST>, which skips the slots accepted here (SearchParams::hist_lean).
-// 64 VGPRs, 8 waves per SIMD; pair_kernel<MODE_HIST> carries every generic path and needs 108 (4 waves).
-struct HistFifo {
-    uint32_t *fd;        // LDS: d2 queue of the plain path (HIST_PLAIN_CAP words, the same memory as fq)
-    float4 *fq;          // LDS, FIFO_CAP: {unshifted second atom, row} of a wrapped hit
-    const float4 *la;    // the slot's first-cell atoms in LDS
-    uint32_t head, tail; // wave-uniform
-    uint32_t *hist;      // workgroup histogram in LDS
-    const float *edges;  // LDS copy of SearchParams::hist_edges, or NULL
-    float hmin, hmax, hn, scale;
-    // Wave-uniform values that live across hist_kernel's whole slot loop are kept in SGPRs (readfirstlane), never as
-    // "the same value in every lane" of a VGPR: under register pressure the allocator splits such a VGPR's live range
-    // with copies, and ROCm 7.2's compiler placed one of them in a join block ahead of the instruction that restores
-    // EXEC - lanes that were masked off at that point kept a stale copy for the rest of the kernel (found by the fuzzer:
-    // two-set search, 400-atom cells, bins of those lanes' hits wrong; tests/golden/hist_regression_case.npz).
-    float hn1;           // nbins - 1 as float
-    uint32_t nbins;
-};
-
-// Histogram1D::add_one (stats.rs:29-35) on d = sqrt(d2):  b = (n as Float * (val - min) / (max - min)).floor() as isize
-// The bin is a non-decreasing function of d2 (correctly rounded sqrt, subtraction of and multiplication / division by
-// constants, floor), so it is fully described by the smallest d2 that reaches each bin: edges[b], b = 0..n, computed
-// on the host with the formula itself (histogram_edges()).  A cheap estimate of the bin (v_sqrt_f32, one multiply) is at
-// most one bin off and is corrected with two comparisons against the exact edges.
-__device__ __forceinline__ void hist_add(const HistFifo &F, float d2) {
-    if (F.edges) {
-        typedef __attribute__((address_space(3))) float lds_f32;
-        float est = (__builtin_amdgcn_sqrtf(d2) - F.hmin) * F.scale;
-        est = __builtin_fminf(__builtin_fmaxf(est, 0.0f), F.hn1);            // also sends a NaN to 0
-        const int n = (int)F.nbins;
-        int b = (int)est;
-        const lds_f32 *e = (const lds_f32 *)F.edges;
-        const float e0 = e[b], e1 = e[b + 1];
-        // one step is exact: ensure_hist_edges() hands the table over only when a bin spans >= 8 ulp of the range's largest
-        // distance (the estimate is then within 0.3 bins); narrower bins take the formula below
-        const int b1 = b + (d2 >= e1 ? 1 : 0) - (d2 < e0 ? 1 : 0);
-        if ((uint32_t)b1 < (uint32_t)n) atomicAdd(&F.hist[b1], 1u);
-        return;
-    }
-    const float d = __builtin_sqrtf(d2);
-    float fb = __builtin_floorf(F.hn * (d - F.hmin) / (F.hmax - F.hmin));
-    if (fb != fb) fb = 0.0f;                                    // NaN as isize == 0
-    if (fb >= 0.0f && fb < F.hn) atomicAdd(&F.hist[(uint32_t)fb], 1u);
-}
-
-constexpr uint32_t HIST_PLAIN_CAP = 256;    // d2 queue of the plain path (flushed 128 at a time); the wrapped path's records use the same memory
-
-// plain queue: `count` <= 128 entries, two per lane (two independent sqrt / divide / atomic chains in flight)
-__device__ __forceinline__ void hist_flush_plain(HistFifo &F, uint32_t count, uint32_t lane) {
-    const uint32_t s0 = (F.head + lane) & (HIST_PLAIN_CAP - 1), s1 = (F.head + 64u + lane) & (HIST_PLAIN_CAP - 1);
-    const bool a0 = lane < count, a1 = lane + 64u < count;
-    float d0 = 0.f, d1 = 0.f;
-    if (a0) d0 = __uint_as_float(F.fd[s0]);
-    if (a1) d1 = __uint_as_float(F.fd[s1]);
-    if (a0) hist_add(F, d0);
-    if (a1) hist_add(F, d1);
-    F.head += count;
-}
-
-template <bool WRAPPED>
-__device__ __forceinline__ void hist_flush(const SearchParams &P, HistFifo &F, uint32_t count, uint32_t lane, uint32_t wrap) {
-    if (lane < count) {
-        const uint32_t s = (F.head + lane) & (FIFO_CAP - 1);
-        float d2;
-        if (WRAPPED) {
-            const float4 b = lload4(F.fq, s);                      // {x, y, z, row}
-            const float4 a = lload4(F.la, __float_as_uint(b.w));
-            d2 = wrapped_d2_exact(P, wrap, b.x - a.x, b.y - a.y, b.z - a.z);     // p2 - p1 (:485-486)
-        } else {
-            d2 = __uint_as_float(F.fd[s]);
-        }
-        hist_add(F, d2);
-    }
-    F.head += count;
-}
-
-template <int KIND, int NCH, bool TRI>
-__device__ __forceinline__ uint32_t run_hist_sorted(const SearchParams &P, const Task &T, uint32_t i0, HistFifo &F, float4 *la,
-                                                    uint32_t lane) {
-    const float cutoff2 = P.cutoff2;
-    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
-    la[lane] = a;
-    float bx[NCH], by[NCH], bz[NCH];
-    uint32_t bpos[TRI ? NCH : 1];      // position in the reference's cell order (same-cell entries: j > i, :443)
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const uint32_t jj = (uint32_t)k * 64u + lane;
-        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
-        if (jj < T.n2) q = gload4(P.perm_b, T.b0 + jj);
-        bx[k] = q.x; by[k] = q.y; bz[k] = q.z;
-        if (TRI) bpos[k] = __float_as_uint(q.w);
-    }
-    const uint32_t ubase = (T.b0 >> 6) + T.cb;
-    unsigned long long livek[NCH];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const float4 lo = gload4(P.chunk_aabb_b, 2u * (ubase + k)), hi = gload4(P.chunk_aabb_b, 2u * (ubase + k) + 1u);
-        const bool need = lane < rows && !(aabb_d2(a.x, a.y, a.z, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > cutoff2);
-        livek[k] = __builtin_amdgcn_ballot_w64(need);
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint32_t total = 0;
-    unsigned long long live = 0ull;
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) live |= livek[k];
-    while (live) {
-        const uint32_t r = (uint32_t)__builtin_ctzll(live);
-        live &= ~(1ull << r);
-        const float4 p = lload4(la, r);              // one broadcast ds_read per row
-        // wait for the row here, once: the chunk bodies sit behind branches, and at their merge points the compiler
-        // would otherwise place `s_waitcnt lgkmcnt(0)` in front of every chunk - which also waits for the LDS write of
-        // the previous chunk's queue push
-        asm volatile("" ::"v"(p.x), "v"(p.y), "v"(p.z));
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            if (!((livek[k] >> r) & 1ull)) continue;                              // wave-uniform: scalar branch
-            const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1
-            float d2 = (dx * dx + dy * dy) + dz * dz;                            // |p2-p1|^2 (:446, :460)
-            if (TRI) d2 = (bpos[k] > i0 + r) ? d2 : INFINITY;
-            const bool hit = d2 <= cutoff2;
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-            if (mask) {
-                const uint32_t cnt = (uint32_t)__popcll(mask);
-                if (hit) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    const uint32_t off = ((rank + F.tail) << 2) & ((HIST_PLAIN_CAP - 1u) << 2);
-                    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-                    *(lds_u32 *)((__attribute__((address_space(3))) char *)F.fd + off) = __float_as_uint(d2);
-                }
-                F.tail += cnt;
-                total += cnt;
-                if (F.tail - F.head >= HIST_PLAIN_CAP / 2u) {
-                    __builtin_amdgcn_wave_barrier();
-                    hist_flush_plain(F, HIST_PLAIN_CAP / 2u, lane);
-                }
-            }
-        }
-    }
-    return total;       // < 64 hits stay queued for the next slot
-}
-
-template <int KIND, int NCH>
-__device__ __forceinline__ uint32_t run_hist_wrapped(const SearchParams &P, const Task &T, uint32_t i0, HistFifo &F, float4 *la,
-                                                     uint32_t lane) {
-    // as run_fast<FILL, WRAPPED> with the band classification: candidates are classified with the plain distance to the
-    // image of the second cell (b + S); only those inside the band take the exact formula
-    float Sx = 0.f, Sy = 0.f, Sz = 0.f;
-    for (int d = 0; d < 3; ++d) {
-        if (!((T.wrap >> d) & 1u)) continue;
-        const float sgn = ((T.wrap_b >> d) & 1u) ? 1.0f : -1.0f;   // second cell wrapped: +col, first cell: -col
-        Sx += sgn * P.box.m[3 * d];
-        Sy += sgn * P.box.m[3 * d + 1];
-        Sz += sgn * P.box.m[3 * d + 2];
-    }
-    float bx[NCH], by[NCH], bz[NCH];         // unshifted: the shift is added per candidate, the hit queues the original
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const uint32_t jj = (uint32_t)k * 64u + lane;
-        float4 q = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
-        if (jj < T.n2) q = gload4(P.sb, T.b0 + jj);
-        bx[k] = q.x; by[k] = q.y; bz[k] = q.z;
-    }
-    const float cutoff2 = P.cutoff2;
-    const float band_lo = P.band_lo, band_hi = P.band_hi;
-    const uint32_t rows = __builtin_amdgcn_readfirstlane(T.n1 - i0 < T.rps ? T.n1 - i0 : T.rps);
-    unsigned long long live;
-    {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < rows) a = gload4(P.sa, T.a0 + i0 + lane);
-        la[lane] = a;
-        const float4 lo = gload4(P.aabb_b, 2 * T.cb), hi = gload4(P.aabb_b, 2 * T.cb + 1);
-        const bool need = !(aabb_d2(a.x - Sx, a.y - Sy, a.z - Sz, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) > P.prune_limit2);
-        live = __builtin_amdgcn_ballot_w64(lane < rows && need);
-    }
-    __builtin_amdgcn_wave_barrier();
-    F.la = la;
-    uint32_t total = 0;
-    while (live) {
-        const uint32_t r = (uint32_t)__builtin_ctzll(live);
-        live &= ~(1ull << r);
-        const float4 p = lload4(la, r);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const float qx = bx[k] + Sx, qy = by[k] + Sy, qz = bz[k] + Sz;       // image of p2 next to the first cell
-            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            const bool sure = d2 < band_lo, maybe = d2 <= band_hi;
-            bool hit = sure;
-            if (__builtin_amdgcn_ballot_w64(maybe && !sure))
-                hit = sure || (maybe && wrapped_d2_exact(P, T.wrap, bx[k] - p.x, by[k] - p.y, bz[k] - p.z) <= cutoff2);
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-            if (mask) {
-                const uint32_t cnt = (uint32_t)__popcll(mask);
-                if (hit) {
-                    const uint32_t s = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, F.tail)) &
-                                       (FIFO_CAP - 1);
-                    F.fq[s] = make_float4(bx[k], by[k], bz[k], __uint_as_float(r));
-                }
-                F.tail += cnt;
-                total += cnt;
-                if (F.tail - F.head >= 64u) {
-                    __builtin_amdgcn_wave_barrier();
-                    hist_flush<true>(P, F, 64u, lane, T.wrap);
-                }
-            }
-        }
-    }
-    if (F.tail != F.head) {            // these entries refer to this slot's rows
-        __builtin_amdgcn_wave_barrier();
-        hist_flush<true>(P, F, F.tail - F.head, lane, T.wrap);
-    }
-    return total;
-}
-
-constexpr int HIST_WAVES = 16;      // waves per workgroup of hist_kernel (one LDS histogram and one slot counter per workgroup; 4 / 8: +7 / +5 %)
-
-template <int KIND>
-__global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(8)))
-hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ slot_desc, uint32_t nslots) {
-    static_assert(HIST_PLAIN_CAP * 4 <= FIFO_CAP * 16, "the d2 queue of the plain path lives inside the wrapped path's queue");
-    __shared__ float4 lds_a[HIST_WAVES][64];
-    __shared__ float4 lds_q[HIST_WAVES][FIFO_CAP];      // wrapped path: {x, y, z, row} per hit; plain path: d2 words in the same memory
-    __shared__ uint32_t lds_next;
-    extern __shared__ uint32_t lds_hist[];
-    const SearchParams &P = *Pp;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += 64 * HIST_WAVES) lds_hist[b] = 0u;
-    float *lds_edges = reinterpret_cast<float *>(lds_hist + P.hist_nbins);       // nbins + 1 floats behind the counters
-    if (P.hist_edges)
-        for (uint32_t b = threadIdx.x; b <= P.hist_nbins; b += 64 * HIST_WAVES) lds_edges[b] = P.hist_edges[b];
-    if (threadIdx.x == 0) lds_next = 0u;
-    __syncthreads();
-    HistFifo F;
-    F.edges = P.hist_edges ? lds_edges : nullptr;
-    F.scale = P.hist_scale;
-    F.fd = reinterpret_cast<uint32_t *>(lds_q[wave]);
-    F.fq = lds_q[wave];
-    F.la = lds_a[wave];
-    F.head = F.tail = 0u;
-    F.hist = lds_hist;
-    F.hmin = P.hist_min;
-    F.hmax = P.hist_max;
-    F.hn = uniform_f32((float)P.hist_nbins);
-    F.hn1 = uniform_f32((float)P.hist_nbins - 1.0f);
-    F.nbins = P.hist_nbins;
-    unsigned long long wave_total = 0;
-    // A workgroup owns every gridDim.x-th slot and hands them to its waves one at a time through a counter in LDS
-    // (runs of 4 / 16 / 64 consecutive slots per workgroup, for the second cells in its CU's cache: 0 / -1 / -5 %):
-    // slots differ ~10x in work, and with a fixed share of ~9 slots per wave the slowest wave took 1.7x the mean.
-    // (One counter in memory for the whole grid serialises: 7*10^4 device-scope atomics on one address took 1.1 ms.)
-    for (;;) {
-        uint32_t tk = 0u;
-        if (lane == 0) tk = atomicAdd(&lds_next, 1u);
-        const unsigned long long w64 = blockIdx.x + (unsigned long long)__builtin_amdgcn_readfirstlane(tk) * gridDim.x;
-        if (w64 >= nslots) break;
-        uint32_t w = (uint32_t)w64;
-        {   // as pair_kernel: an XCD (workgroup index mod 8; the grid is a multiple of 8 wide) takes runs of consecutive slots
-            // (six alternations on one box: 2142 against 2056 frames/s on average, never behind by more than 1 %)
-            const uint32_t x = w & 7u, q = w >> 3;
-            const uint32_t full = (nslots / (8u * XCD_RUN)) * (8u * XCD_RUN);
-            if (w < full) w = ((q / XCD_RUN) * 8u + x) * XCD_RUN + (q % XCD_RUN);
-        }
-        const uint32_t slot = nslots - 1u - w;       // reverse plan order, as pair_kernel
-        Task T;
-        uint32_t i0, fl;
-        {
-            const uint4 lo = reinterpret_cast<const uint4 *>(slot_desc + slot)[0];
-            const uint4 hi = reinterpret_cast<const uint4 *>(slot_desc + slot)[1];
-            fl = __builtin_amdgcn_readfirstlane(hi.y);
-            if (!(fl & 0x200u)) continue;             // past the last slot
-            T.a0 = __builtin_amdgcn_readfirstlane(lo.x);
-            T.n1 = __builtin_amdgcn_readfirstlane(lo.y);
-            T.b0 = __builtin_amdgcn_readfirstlane(lo.z);
-            T.n2 = __builtin_amdgcn_readfirstlane(lo.w);
-            T.cb = __builtin_amdgcn_readfirstlane(hi.x);
-            i0 = __builtin_amdgcn_readfirstlane(hi.z);
-            T.wrap = fl & 7u;
-            T.tri = (fl & 0x100u) != 0u;
-            T.valid = true;
-            T.wrap_b = (fl >> 12) & 7u;
-            T.rps = fl >> 16;
-        }
-        if (!hist_lean_slot<KIND>(P, fl, T.n2)) continue;
-#ifdef MOLAR_HIP_DEBUG_KNOBS
-        if (P.debug_skip) {
-            const uint32_t kind_bit = T.tri ? 4u : ((P.use_box && T.wrap != 0u) ? 2u : 1u);
-            if (P.debug_skip & kind_bit) continue;
-        }
-#endif
-        const uint32_t nchunks = (T.n2 + 63u) >> 6;
-        uint32_t total = 0;
-        if (P.use_box && T.wrap != 0u) {
-            if (F.tail != F.head) {        // plain hits still queued: out before entries of another kind go in
-                __builtin_amdgcn_wave_barrier();
-                hist_flush_plain(F, F.tail - F.head, lane);       // < HIST_PLAIN_CAP / 2 <= 128 entries
-            }
-            switch (nchunks) {
-                case 1: total = run_hist_wrapped<KIND, 1>(P, T, i0, F, lds_a[wave], lane); break;
-                case 2: total = run_hist_wrapped<KIND, 2>(P, T, i0, F, lds_a[wave], lane); break;
-                case 3: total = run_hist_wrapped<KIND, 3>(P, T, i0, F, lds_a[wave], lane); break;
-                case 4: total = run_hist_wrapped<KIND, 4>(P, T, i0, F, lds_a[wave], lane); break;
-                case 5: total = run_hist_wrapped<KIND, 5>(P, T, i0, F, lds_a[wave], lane); break;
-                case 6: total = run_hist_wrapped<KIND, 6>(P, T, i0, F, lds_a[wave], lane); break;
-                case 7: total = run_hist_wrapped<KIND, 7>(P, T, i0, F, lds_a[wave], lane); break;
-                default: total = run_hist_wrapped<KIND, 8>(P, T, i0, F, lds_a[wave], lane); break;
-            }
-        } else if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) {
-            switch (nchunks) {
-                case 1: total = run_hist_sorted<KIND, 1, true>(P, T, i0, F, lds_a[wave], lane); break;
-                case 2: total = run_hist_sorted<KIND, 2, true>(P, T, i0, F, lds_a[wave], lane); break;
-                case 3: total = run_hist_sorted<KIND, 3, true>(P, T, i0, F, lds_a[wave], lane); break;
-                case 4: total = run_hist_sorted<KIND, 4, true>(P, T, i0, F, lds_a[wave], lane); break;
-                case 5: total = run_hist_sorted<KIND, 5, true>(P, T, i0, F, lds_a[wave], lane); break;
-                case 6: total = run_hist_sorted<KIND, 6, true>(P, T, i0, F, lds_a[wave], lane); break;
-                case 7: total = run_hist_sorted<KIND, 7, true>(P, T, i0, F, lds_a[wave], lane); break;
-                default: total = run_hist_sorted<KIND, 8, true>(P, T, i0, F, lds_a[wave], lane); break;
-            }
-        } else {
-            switch (nchunks) {
-                case 1: total = run_hist_sorted<KIND, 1, false>(P, T, i0, F, lds_a[wave], lane); break;
-                case 2: total = run_hist_sorted<KIND, 2, false>(P, T, i0, F, lds_a[wave], lane); break;
-                case 3: total = run_hist_sorted<KIND, 3, false>(P, T, i0, F, lds_a[wave], lane); break;
-                case 4: total = run_hist_sorted<KIND, 4, false>(P, T, i0, F, lds_a[wave], lane); break;
-                case 5: total = run_hist_sorted<KIND, 5, false>(P, T, i0, F, lds_a[wave], lane); break;
-                case 6: total = run_hist_sorted<KIND, 6, false>(P, T, i0, F, lds_a[wave], lane); break;
-                case 7: total = run_hist_sorted<KIND, 7, false>(P, T, i0, F, lds_a[wave], lane); break;
-                default: total = run_hist_sorted<KIND, 8, false>(P, T, i0, F, lds_a[wave], lane); break;
-            }
-        }
-        wave_total += total;
-    }
-    if (F.tail != F.head) {
-        __builtin_amdgcn_wave_barrier();
-        hist_flush_plain(F, F.tail - F.head, lane);
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += 64 * HIST_WAVES) {
-        const uint32_t v = lds_hist[b];
-        if (v) atomicAdd(&P.hist_bins[b], (unsigned long long)v);
-    }
-    if (lane == 0 && wave_total && P.hist_total) atomicAdd(P.hist_total, wave_total);
-}
-
-template <int KIND>
-inline void launch_hist_kernel(unsigned num_cus, size_t dyn_lds, hipStream_t stream, const SearchParams *dP,
-                               const SlotDesc *slot_desc, uint32_t nslots) {
-    // persistent workgroups: 32 waves per CU (8 per SIMD)
-    hipLaunchKernelGGL((hist_kernel<KIND>), dim3(num_cus * (32 / HIST_WAVES)), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots);   // counters, then the nbins + 1 bin edges
-}
-
-
 // HIP limits gridDim.x * blockDim.x to 2^32 threads: sparse giant grids (10^8 plan entries, one 64-lane workgroup per
 // slot) spill into grid.y; the kernels linearise (x fastest)
 inline dim3 pair_grid(unsigned nblocks) {
@@ -2056,8 +1692,10 @@ inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t str
 }  // namespace pairk
 
 // defined in pair_k0.hip .. pair_k3.hip (one search kind each)
+// (pair_k4.hip, hist_kernels.hpp) nslots_real: the plan's slot count in device memory; queue: hist_queue_words() zeroed words
 void launch_hist_lean(int kind, unsigned num_cus, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
-                      const pairk::SlotDesc *slot_desc, uint32_t nslots);
+                      const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, const uint32_t *nslots_real, uint32_t *queue);
+size_t hist_queue_words();
 void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
                         const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                         const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);

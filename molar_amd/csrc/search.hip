@@ -23,7 +23,6 @@
 #include "common.hpp"
 #include "hoststream.hpp"
 #include "pair_kernels.hpp"
-#include "onepass.hpp"
 #include "stages.hpp"
 
 using namespace mh;
@@ -1019,6 +1018,7 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.prune_limit2 = lim * lim;
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     P.debug_skip = c->env_debug_skip;
+    P.dbg = nullptr;
 #endif
     return P;
 }
@@ -1027,6 +1027,10 @@ template <bool FILL>
 int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uint32_t hist_nbins = 0, float hmin = 0.f,
                  float hmax = 0.f, unsigned long long *hist_bins = nullptr, unsigned long long out_cap = ~0ull,
                  bool params_resident = false, unsigned long long *hist_total = nullptr) {
+    // the fill pass writes two (i, j) pairs / two distances per lane and instruction (fifo_flush_wide): naturally aligned
+    // dwordx4 / dwordx2 stores relative to these bases (include/molar_hip.h states the requirement for caller-owned outputs)
+    if (FILL && (((uintptr_t)pairs & 15u) || ((uintptr_t)dist & 7u)))
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search fill: device outputs must be aligned to 16 bytes (pairs) and 8 bytes (distances)");
     Prof prof(c, FILL ? 3 : 1);
     SearchParams P = make_params(c);
     if (P.nblocks == 0) return 0;
@@ -1053,6 +1057,13 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
             P.hist_edges = c->hist_edges.as<float>();
             P.hist_scale = (float)hist_nbins / (hmax - hmin);
         }
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+        // 16 words per wave of hist_kernel; MOLAR_HIP_DEBUG_LAUNCH=n: only the n-th histogram launch of the context records
+        // (a launch in the middle of a queued sequence, with the next frame's grid being built beside it)
+        ++c->dbg_launches;
+        if (!c->dbg.reserve((size_t)c->num_cus * 32u * 128u) && (c->env_debug_launch == 0 || c->env_debug_launch == c->dbg_launches))
+            P.dbg = c->dbg.as<unsigned long long>();
+#endif
     }
     MH_TRY(c->params.reserve(sizeof(SearchParams)));
     // params_resident: the block uploaded for the previous pass of this search is still valid for this one
@@ -1071,7 +1082,13 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     uint32_t *sc = c->slot_cnt.as<uint32_t>();
     auto *sb = c->slot_base.as<unsigned long long>();
     const int mode = !FILL ? MODE_COUNT : (hist_nbins ? MODE_HIST : MODE_FILL);
-    if (P.hist_lean) launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st);
+    if (P.hist_lean) {
+        if (!c->hist_queue.p) {         // slot queues of hist_kernel: zeroed once, every launch leaves them zeroed
+            MH_TRY(c->hist_queue.reserve(hist_queue_words() * 4));
+            MH_HIP(hipMemsetAsync(c->hist_queue.p, 0, hist_queue_words() * 4, c->stream));
+        }
+        launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st, c->task_nb.as<uint32_t>() + c->ntasks, c->hist_queue.as<uint32_t>());
+    }
     switch (c->kind) {
         case MOLAR_HIP_SEARCH_SINGLE: launch_pair_single(mode, P.nblocks, dyn_lds, c->stream, dP, tf, st, sc, sb, pairs, dist, ids); break;
         case MOLAR_HIP_SEARCH_DOUBLE: launch_pair_double(mode, P.nblocks, dyn_lds, c->stream, dP, tf, st, sc, sb, pairs, dist, ids); break;
@@ -1178,8 +1195,7 @@ int device_fmax(molar_hip_ctx *c, const float *d_v, uint32_t n, float *out) {
 }
 
 // Second half of the plan, for the kernels that walk slots (count / fill / histogram): slot index of every plan entry and
-// (fast kinds) its first hit-history unit by one single-pass scan over both, then one record per slot.  The one-pass
-// resident search stops in front of this; a fill call on such a cached search catches up here (ensure_slots).
+// (fast kinds) its first hit-history unit by one single-pass scan over both, then one record per slot.
 int enqueue_plan_slots(molar_hip_ctx *c) {
     const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
     const unsigned pbs = c->on_side ? 64u : 256u;          // one-wave workgroups on the side stream (place_order_kernel)
@@ -1192,7 +1208,6 @@ int enqueue_plan_slots(molar_hip_ctx *c) {
                        c->task_desc.as<TaskDesc>(), fast_kind ? c->task_moff.as<unsigned long long>() : nullptr,
                        c->slot_desc.as<SlotDesc>(), c->nslots_bound, c->sizes_dev);
     MH_HIP(hipGetLastError());
-    c->slots_valid = true;
     return 0;
 }
 
@@ -1226,7 +1241,6 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     if (q->kind < 0 || q->kind > 3) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: unknown kind %d", q->kind);
     MH_HIP(hipSetDevice(c->device));
     c->have_search = false;
-    c->slots_valid = false;
     c->kind = q->kind;
     const bool two = q->kind != MOLAR_HIP_SEARCH_SINGLE;
     const bool vdw = q->kind == MOLAR_HIP_SEARCH_DOUBLE_VDW;
@@ -1301,21 +1315,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
     MH_TRY(c->params.reserve(sizeof(SearchParams)));
     const size_t st_tasks = lookback_state_words(c->ntasks + 1), st_slots = lookback_state_words(c->nslots_bound + 1);
-    // one-pass resident searches (onepass.hpp): OP_NW nodes per plan entry, OP_KC for the entries of the last home cell when
-    // those may run the triclinic candidate loop; their descriptors, the status word and the total follow the scans' state
-    {
-        const uint64_t mult = two ? 2ull : 1ull;
-        const uint64_t ncorner = (c->use_box && c->pbc == MOLAR_HIP_PBC_FULL && c->box.nshift != 0) ? 14ull * mult : 0ull;
-        c->op_ntask_reg = c->ntasks - ncorner;
-        c->op_nreg = c->op_ntask_reg * (uint64_t)pairk::OP_NW;
-        c->op_nnodes = c->op_nreg + ncorner * (uint64_t)pairk::OP_KC;
-        c->op_state_word = st_tasks + st_slots;
-    }
-    const bool op_layout = c->op_nnodes < 0xFFFFFF00ull;
-    if (c->onepass_now && !op_layout) c->onepass_now = false;
-    const size_t op_nblk = (size_t)((c->op_nnodes + 63) / 64);
-    const size_t st_nodes = op_layout ? (size_t)c->op_nnodes + 2 * op_nblk + 8 : 0;     // node words, 2 x block words, status, total
-    MH_TRY(c->scan_state.reserve((st_tasks + st_slots + st_nodes) * 8));
+    MH_TRY(c->scan_state.reserve((st_tasks + st_slots) * 8));
     MH_TRY(c->task_mu.reserve((c->ntasks + 1) * 4));
     MH_TRY(c->task_moff.reserve((c->ntasks + 1) * 8));
     const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
@@ -1334,24 +1334,22 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         }
         // ntasks + 1 threads (the last one writes the scan terminators); the same grid zeroes the slot counters and the
         // descriptors of the two look-back scans of this search
-        const uint64_t nplan = std::max<uint64_t>(std::max<uint64_t>(c->ntasks + 1, c->nslots_bound + 1), st_tasks + st_slots + st_nodes);
+        const uint64_t nplan = std::max<uint64_t>(std::max<uint64_t>(c->ntasks + 1, c->nslots_bound + 1), st_tasks + st_slots);
         const unsigned pbs = c->on_side ? 64u : 256u;          // one-wave workgroups on the side stream (place_order_kernel)
         const unsigned nb = (unsigned)((nplan + pbs - 1) / pbs);
         switch (c->kind) {
             case MOLAR_HIP_SEARCH_SINGLE:
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(nb), dim3(pbs), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
                                    c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
-                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots + st_nodes), params_dst);
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots), params_dst);
                 break;
             default:   // the three two-grid kinds decode tasks identically
                 hipLaunchKernelGGL((plan_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(nb), dim3(pbs), 0, c->stream, P, c->task_nb.as<uint32_t>(), c->task_desc.as<TaskDesc>(),
                                    c->task_mu.as<uint32_t>(), fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1,
-                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots + st_nodes), params_dst);
+                                   c->scan_state.as<unsigned long long>(), (uint64_t)(st_tasks + st_slots), params_dst);
                 break;
         }
         MH_HIP(hipGetLastError());
-        c->slots_valid = false;
-        if (c->onepass_now) return 0;       // the one-pass kernel reads the plan entries themselves: no slots
         return enqueue_plan_slots(c);
     };
     // Pipelined search on a context that owns its stream, inputs already in device memory: the grid build goes to the
@@ -1433,6 +1431,9 @@ int finish_count(molar_hip_ctx *c) {
 //  * ids are indices into a sorted selection (or 0..n), so the flagged positions in ascending order ARE the sorted,
 //    de-duplicated result: a count per 2048-flag tile, a scan of the tile counts and one compaction pass.
 constexpr uint32_t WITHIN_MAX_PART = 28;
+// every (mask, half) pair of the plan has exactly one first-set cell as its origin: a cell is the first cell of at most
+// 14 masks x 2 halves entries.  A plan with more masks or another stencil must grow the lists with it.
+static_assert(WITHIN_MAX_PART == 2u * sizeof(pairk::MASKS) / sizeof(pairk::MASKS[0]), "partner lists are sized for the plan's stencil");
 
 __global__ void __launch_bounds__(256) within_partners_kernel(const SearchParams *__restrict__ Pp, uint32_t *__restrict__ part_cnt,
                                                               uint32_t *__restrict__ part) {
@@ -1556,22 +1557,10 @@ int molar_hip_search_grid_dims(molar_hip_ctx *c, uint64_t dims[3]) {
     return MOLAR_HIP_OK;
 }
 
-// A cached search left by the one-pass resident kernel has its grid and plan entries but no slots, counts or offsets:
-// the fill calls of the count / fill ABI catch up (rest of the plan, count pass, offset scan).
-static int ensure_slots(molar_hip_ctx *c) {
-    if (c->slots_valid || c->ntasks == 0) return 0;
-    MH_TRY(enqueue_plan_slots(c));
-    c->mask_units = 0;
-    MH_TRY(size_plan(c));
-    MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr));
-    return finish_count(c);
-}
-
 static int fill_common(molar_hip_ctx *c, uint2 *d_pairs, float *d_dist, uint32_t *d_ids) {
     if (!c || !c->have_search) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached search: call molar_hip_search_count first");
     MH_HIP(hipSetDevice(c->device));
     if (c->total == 0 || c->ntasks == 0) return 0;
-    MH_TRY(ensure_slots(c));
     return launch_pairs<true>(c, d_pairs, d_dist, d_ids);
 }
 
@@ -1628,14 +1617,11 @@ int molar_hip_search_fill_device(molar_hip_ctx *c, const uint32_t **d_pairs, con
 // (struct ResidentLaunch: stages.hpp)
 
 static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::DevBuf &outP, mh::DevBuf &outD,
-                            void *sizes, ResidentLaunch *L, bool allow_onepass = true) {
+                            void *sizes, ResidentLaunch *L) {
     if (q && q->kind == MOLAR_HIP_SEARCH_WITHIN)
         return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within search yields ids: use molar_hip_search_count + fill_ids");
     const unsigned long long a = outP.cap / 8u, b = outD.cap / 4u;
     const unsigned long long cap0 = a < b ? a : b;
-    // fixed-cutoff kinds: one pass over the candidates (onepass.hpp) unless this context has had to give it up
-    c->onepass_now = allow_onepass && c->env_onepass && !c->onepass_broken && q &&
-                     (q->kind == MOLAR_HIP_SEARCH_SINGLE || q->kind == MOLAR_HIP_SEARCH_DOUBLE);
     // `sizes` is pinned host memory: the kernels write the two sizes there themselves (slotmap_kernel the hit-history
     // units, slot_offsets_kernel the grand total) - no copy commands behind the fill pass
     void *sizes_dev = nullptr;
@@ -1646,8 +1632,6 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     c->plan_out_cap = cap0;
     c->sizes_dev = (unsigned long long *)sizes_dev;
     const int prc = prepare_search(c, q, /*size_masks=*/false);
-    const bool onepass = c->onepass_now;       // (prepare_search declines it for plans with too many nodes)
-    c->onepass_now = false;
     c->plan_out_cap = ~0ull;
     c->sizes_dev = nullptr;
     MH_TRY(prc);
@@ -1655,43 +1639,6 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     *L = ResidentLaunch{};
     L->degenerate = c->have_search;
     if (L->degenerate) return 0;
-    if (onepass) {
-        // grid -> plan entries -> ONE kernel: classification on the matrix cores, offsets by look-back, results expanded from
-        // the classification.  The plan kernel has written the parameter block (output capacity included) and zeroed the
-        // node descriptors, the status word and the total.
-        c->params_fresh = false;
-        unsigned long long *st = c->scan_state.as<unsigned long long>() + c->op_state_word;
-        pairk::OnePassArgs A{};
-        A.state = st;
-        const size_t nblk = (size_t)((c->op_nnodes + 63) / 64);
-        A.blk = st + c->op_nnodes;
-        A.blkp = A.blk + nblk;
-        A.nnodes = (uint32_t)c->op_nnodes;
-        A.nreg = (uint32_t)c->op_nreg;
-        A.ntask_reg = (uint32_t)c->op_ntask_reg;
-        A.xcd_run = c->env_op_run;
-        A.dbg = c->env_op_dbg;
-        A.pairs = outP.as<uint2>();
-        A.dist = outD.as<float>();
-        A.sizes_host = (unsigned long long *)sizes_dev;
-        A.status = reinterpret_cast<uint32_t *>(A.blkp + nblk);
-        A.total_dev = A.blkp + nblk + 1;
-        std::memset((char *)sizes + 16, 0, 8);         // status: written by the kernel only when it gives up or finishes
-        {
-            Prof prof(c, 3);
-            launch_onepass(c->kind, c->stream, c->params.as<SearchParams>(), A);
-            MH_HIP(hipGetLastError());
-        }
-        if (!sizes_dev) {
-            std::memset((char *)sizes + 8, 0, 8);
-            MH_HIP(hipMemcpyAsync(sizes, A.total_dev, 8, hipMemcpyDeviceToHost, c->stream));
-            MH_HIP(hipMemcpyAsync((char *)sizes + 16, A.status, 8, hipMemcpyDeviceToHost, c->stream));
-        }
-        L->cap0 = cap0;
-        L->onepass = true;
-        L->total_dev = A.total_dev;
-        return 0;
-    }
     const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
     L->maskcap0 = c->maskbuf.cap / 256u;
     // one parameter block serves both passes: the count pass ignores the output capacity
@@ -1743,49 +1690,14 @@ static int resident_settle(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD,
     return 0;
 }
 
-// The sizes of a one-pass search have arrived: accept the result, or prepare the repeat (grow the result buffers; after a
-// look-back timeout keep this context on the two-pass kernels).
-static int onepass_accept(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD, const void *sizes, const ResidentLaunch &L, bool *ok) {
-    unsigned long long res[3] = {0, 0, 0};
-    std::memcpy(res, sizes, 24);
-    *ok = false;
-    if (res[2] != 0ull) {
-        c->onepass_broken = true;
-        return 0;
-    }
-    if (res[0] > L.cap0) {
-        MH_TRY(outP.reserve((size_t)(res[0] + res[0] / 16u) * 8));
-        MH_TRY(outD.reserve((size_t)(res[0] + res[0] / 16u) * 4));
-        return 0;
-    }
-    c->total = res[0];
-    c->mask_units = 0;
-    c->have_search = true;             // grid and plan entries are cached; the slots are built when a fill call asks (ensure_slots)
-    *ok = true;
-    return 0;
-}
-
 // One whole resident search, complete when the call returns (the stream has been waited for).
 static int resident_run(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::DevBuf &outP, mh::DevBuf &outD) {
     MH_TRY(ensure_pinned(c, 64));
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        ResidentLaunch L;
-        MH_TRY(resident_enqueue(c, q, outP, outD, c->h_pinned, &L));
-        if (L.degenerate) return 0;
-        MH_HIP(hipStreamSynchronize(c->stream));
-        if (!L.onepass) return resident_settle(c, outP, outD, c->h_pinned, L);
-        bool ok = false;
-        MH_TRY(onepass_accept(c, outP, outD, c->h_pinned, L, &ok));
-        if (c->env_op_dbg & 8u) {      // look-back statistics of this frame (onepass.hpp, op_lookback)
-            unsigned long long w[6] = {0, 0, 0, 0, 0, 0};
-            MH_TRY(read_back(c, w, L.total_dev + 1, sizeof w));
-            std::fprintf(stderr, "onepass look-back: block wait %.3f us/node, prefix wait %.3f us/node, polls %.2f + %.2f per node, %.2f windows, longest %.1f us (%llu nodes)\n",
-                         w[0] * 0.01 / (double)c->op_nnodes, w[1] * 0.01 / (double)c->op_nnodes, (double)w[2] / (double)c->op_nnodes,
-                         (double)w[3] / (double)c->op_nnodes, (double)w[4] / (double)c->op_nnodes, w[5] * 0.01, (unsigned long long)c->op_nnodes);
-        }
-        if (ok) return 0;
-    }
-    return fail(MOLAR_HIP_ERR_HIP, "resident search: the result did not settle");
+    ResidentLaunch L;
+    MH_TRY(resident_enqueue(c, q, outP, outD, c->h_pinned, &L));
+    if (L.degenerate) return 0;
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return resident_settle(c, outP, outD, c->h_pinned, L);
 }
 
 }  // extern "C"
@@ -1794,8 +1706,7 @@ static int resident_run(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::De
 int mh::search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, void *sizes_pinned, ResidentLaunch *L,
                                 const unsigned long long **total_dev, const uint32_t **pairs_dev) {
     std::memset(sizes_pinned, 0, 16);
-    // (callers chain kernels behind the search that read slot_base's last entry: they stay on the count / fill passes)
-    MH_TRY(resident_enqueue(c, q, c->out_pairs, c->out_dist, sizes_pinned, L, /*allow_onepass=*/false));
+    MH_TRY(resident_enqueue(c, q, c->out_pairs, c->out_dist, sizes_pinned, L));
     c->have_search = false;              // the sizes are not known to the host: not a cached search for the fill calls
     *total_dev = L->degenerate ? nullptr : c->slot_base.as<unsigned long long>() + c->nslots_bound;
     *pairs_dev = c->out_pairs.as<uint32_t>();
@@ -1867,7 +1778,6 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     T.cap0 = L.cap0;
     T.maskcap0 = L.maskcap0;
     T.degenerate = L.degenerate;
-    T.onepass = L.onepass;
     T.serial = c->search_serial;
     T.pending = true;
     c->next_ticket ^= 1;
@@ -1888,24 +1798,11 @@ int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *ou
     if (!T.degenerate) {
         MH_HIP(hipEventSynchronize(T.done));
         const void *sizes = (const char *)c->h_sizes + 32 * ticket;
-        unsigned long long res[3];
-        std::memcpy(res, sizes, 24);
+        unsigned long long res[2];
+        std::memcpy(res, sizes, 16);
         const bool fast_kind = T.desc.kind == MOLAR_HIP_SEARCH_SINGLE || T.desc.kind == MOLAR_HIP_SEARCH_DOUBLE;
         total = res[0];
-        if (T.onepass) {
-            if (res[2] != 0ull || res[0] > T.cap0) {
-                // the one-pass kernel gave up, or the result buffers were too small: let everything in flight finish (the other
-                // ticket's results sit in the other result set), then repeat the frame
-                MH_HIP(hipStreamSynchronize(c->stream));
-                ResidentLaunch L;
-                L.cap0 = T.cap0;
-                L.onepass = true;
-                bool ok = false;
-                MH_TRY(onepass_accept(c, outP, outD, sizes, L, &ok));      // grows the buffers / marks the context
-                MH_TRY(resident_run(c, &T.desc, outP, outD));
-                total = c->total;
-            }
-        } else if (res[0] > T.cap0 || (fast_kind && res[1] > T.maskcap0)) {
+        if (res[0] > T.cap0 || (fast_kind && res[1] > T.maskcap0)) {
             // A buffer was too small (first frames of a trajectory).  Let everything in flight finish - a younger
             // search owns the context's intermediate buffers by now, its results sit in the other result set - then
             // grow and repeat: the affected passes if this is still the context's cached search, else the frame.
@@ -2017,6 +1914,16 @@ int molar_hip_search_fill_ids(molar_hip_ctx *c, uint64_t *ids) {
     }
     return MOLAR_HIP_OK;
 }
+
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+// debug builds only (not part of include/molar_hip.h): the per-wave time accounting of the LAST hist_kernel launch
+int molar_hip_debug_fetch(molar_hip_ctx *c, void *dst, size_t bytes) {
+    if (!c || !dst || bytes > c->dbg.cap) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "debug_fetch: bad argument");
+    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(hipMemcpy(dst, c->dbg.p, bytes, hipMemcpyDeviceToHost));
+    return MOLAR_HIP_OK;
+}
+#endif
 
 int molar_hip_histogram_edges(float hmin, float hmax, size_t nbins, float *edges) {
     if (!edges) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "histogram_edges: null argument");

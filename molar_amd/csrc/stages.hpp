@@ -20,13 +20,11 @@ int enqueue_lipid_order(molar_hip_ctx *c, const float *xyz, const uint64_t *idx,
 // search.hip: the resident search (molar_hip_search_resident) without its wait.  Count, offset scan and fill go to the
 // context's result buffers against their present capacity; the number of results stays in device memory
 // (*total_dev, u64) for kernels enqueued behind it, and the two sizes the host needs to judge the capacities are
-// copied to `sizes_pinned` (24 bytes: results, hit-history units, status of the one-pass kernel).
+// copied to `sizes_pinned` (16 bytes: results, hit-history units).
 struct ResidentLaunch {
     unsigned long long cap0 = 0;      // result capacity the fill pass was launched with (0: the fill was skipped)
     unsigned long long maskcap0 = 0;  // hit-history units the count pass could record
     bool degenerate = false;          // empty vdw input: nothing was enqueued, the result is empty
-    bool onepass = false;             // the one-pass kernel ran (onepass.hpp): sizes = {results, 0, status}
-    const unsigned long long *total_dev = nullptr;   // one-pass: where the number of results sits in device memory
 };
 int search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, void *sizes_pinned, ResidentLaunch *L,
                             const unsigned long long **total_dev, const uint32_t **pairs_dev);

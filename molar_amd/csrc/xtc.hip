@@ -16,6 +16,9 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -34,7 +37,7 @@ constexpr int FIRSTIDX = 9;
     165140,  208063,  262144,  330280,  416127,  524287,  660561,  832255,  1048576, 1321122,  1664510,  2097152,  2642245,  \
     3329021, 4194304, 5284491, 6658042, 8388607, 10568983, 13316085, 16777216
 constexpr int MAGIC[] = {MOLAR_XTC_MAGIC_TABLE};
-__device__ const int MAGIC_DEV[] = {MOLAR_XTC_MAGIC_TABLE};       // the same table for the device decoder (xtc_decode_kernel)
+__device__ __attribute__((unused)) const int MAGIC_DEV[] = {MOLAR_XTC_MAGIC_TABLE};       // the same table for the device decoder (xtc_decode_kernel)
 constexpr int LASTIDX = (int)(sizeof(MAGIC) / sizeof(*MAGIC)) - 1;
 __host__ __device__ inline int magic_at(int k) {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -283,6 +286,184 @@ __global__ void __launch_bounds__(64) xtc_decode_kernel(const uint8_t *__restric
     status[k] = decode_frame(blob, fi[k], out + (size_t)k * natoms * 3);
 }
 
+
+// ------------------------------------------------------------------ writer (xtc_handler.rs:117-168: write_state)
+// One frame in GROMACS' compressed coordinate format, the algorithm of xdrfile's xdr3dfcoord: coordinates rounded to
+// integers at `precision`, every atom a mixed-radix triple over the frame's integer extent, atoms close to their predecessor
+// (water molecules) coded as runs of small deltas with an adaptive delta size.  The MolAR side of this is molly::XTCWriter;
+// here it writes the synthetic trajectories the XTC-fed benchmarks and tests read back (molar_hip_xtc_encode_frame).
+struct BitWriter {
+    uint8_t *p;
+    size_t cap, n = 0;
+    uint64_t acc = 0;
+    int have = 0;
+    bool overflow = false;
+    void put(int nbits, uint32_t v) {          // 0 <= nbits <= 32, MSB first
+        if (nbits == 0) return;
+        acc = (acc << nbits) | (uint64_t)(nbits == 32 ? v : (v & ((1u << nbits) - 1u)));
+        have += nbits;
+        while (have >= 8) {
+            if (n < cap) p[n++] = (uint8_t)(acc >> (have - 8));
+            else overflow = true;
+            have -= 8;
+        }
+    }
+    size_t finish() {
+        if (have > 0) {
+            if (n < cap) p[n++] = (uint8_t)(acc << (8 - have));
+            else overflow = true;
+            have = 0;
+        }
+        return n;
+    }
+};
+
+// the mixed-radix number ((u0 * s1) + u1) * s2 + u2, little-endian by bytes, in `nbits` bits (the inverse of unpack3)
+inline void pack3(BitWriter &w, int nbits, const uint32_t s[3], const uint32_t u[3]) {
+    unsigned __int128 v = ((unsigned __int128)u[0] * s[1] + u[1]) * s[2] + u[2];
+    int left = nbits;
+    while (left > 8) {
+        w.put(8, (uint32_t)(v & 0xff));
+        v >>= 8;
+        left -= 8;
+    }
+    if (left > 0) w.put(left, (uint32_t)(v & 0xff));
+}
+
+inline void put_be32(uint8_t *p, uint32_t v) {
+    p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v;
+}
+inline void put_bef(uint8_t *p, float f) { put_be32(p, __builtin_bit_cast(uint32_t, f)); }
+
+// returns the frame's length, 0 when `cap` is too small, (size_t)-1 when a coordinate does not fit the format
+size_t encode_frame(const float *xyz, size_t natoms, const float box9[9], int32_t step, float time, float precision, uint8_t *out, size_t cap) {
+    if (cap < 56) return 0;
+    put_be32(out, 1995u);
+    put_be32(out + 4, (uint32_t)natoms);
+    put_be32(out + 8, (uint32_t)step);
+    put_bef(out + 12, time);
+    for (int k = 0; k < 9; ++k) put_bef(out + 16 + 4 * k, box9[k]);
+    put_be32(out + 52, (uint32_t)natoms);
+    if (natoms <= 9) {                       // small systems are stored as plain floats
+        if (cap < 56 + natoms * 12) return 0;
+        for (size_t k = 0; k < 3 * natoms; ++k) put_bef(out + 56 + 4 * k, xyz[k]);
+        return 56 + natoms * 12;
+    }
+    if (cap < 92) return 0;
+    std::vector<int> ip(3 * natoms);
+    int minint[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, maxint[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    int mindiff = INT32_MAX, old[3] = {0, 0, 0};
+    for (size_t i = 0; i < natoms; ++i) {
+        int cur[3];
+        for (int c = 0; c < 3; ++c) {
+            const float lf = xyz[3 * i + c] * precision;
+            if (!(std::fabs(lf) < 2147483000.0f)) return (size_t)-1;        // scaling would overflow the integer grid
+            cur[c] = (int)(lf >= 0.0f ? lf + 0.5f : lf - 0.5f);
+            ip[3 * i + c] = cur[c];
+            if (cur[c] < minint[c]) minint[c] = cur[c];
+            if (cur[c] > maxint[c]) maxint[c] = cur[c];
+        }
+        const long long diff = std::llabs((long long)old[0] - cur[0]) + std::llabs((long long)old[1] - cur[1]) + std::llabs((long long)old[2] - cur[2]);
+        if (i > 0 && diff < mindiff) mindiff = (int)diff;
+        old[0] = cur[0]; old[1] = cur[1]; old[2] = cur[2];
+    }
+    uint32_t sizeint[3];
+    int bitsizeint[3] = {0, 0, 0}, bitsize;
+    for (int c = 0; c < 3; ++c) {
+        if ((long long)maxint[c] - (long long)minint[c] >= 0x7FFFFFFELL) return (size_t)-1;
+        sizeint[c] = (uint32_t)(maxint[c] - minint[c]) + 1u;
+    }
+    if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffffu) {
+        for (int c = 0; c < 3; ++c) bitsizeint[c] = bits_for(sizeint[c]);
+        bitsize = 0;
+    } else {
+        bitsize = bits_for_product(sizeint);
+    }
+    int smallidx = FIRSTIDX;
+    while (smallidx < LASTIDX && MAGIC[smallidx] < mindiff) ++smallidx;
+    const int maxidx = LASTIDX < smallidx + 8 ? LASTIDX : smallidx + 8, minidx = maxidx - 8;
+    int smaller = MAGIC[smallidx - 1 > FIRSTIDX ? smallidx - 1 : FIRSTIDX] / 2;
+    int smallnum = MAGIC[smallidx] / 2;
+    uint32_t sizesmall[3] = {(uint32_t)MAGIC[smallidx], (uint32_t)MAGIC[smallidx], (uint32_t)MAGIC[smallidx]};
+    const int larger = MAGIC[maxidx] / 2;
+    put_bef(out + 56, precision);
+    for (int c = 0; c < 3; ++c) {
+        put_be32(out + 60 + 4 * c, (uint32_t)minint[c]);
+        put_be32(out + 72 + 4 * c, (uint32_t)maxint[c]);
+    }
+    put_be32(out + 84, (uint32_t)smallidx);
+    const size_t hdr = 92;
+    BitWriter w{out + hdr, cap - hdr};
+    auto close = [](const int *a, const int *b, int lim) {
+        return std::abs(a[0] - b[0]) < lim && std::abs(a[1] - b[1]) < lim && std::abs(a[2] - b[2]) < lim;
+    };
+    size_t i = 0;
+    int prevrun = -1;
+    const int *prev = nullptr;
+    uint32_t tmp[30];
+    while (i < natoms) {
+        int *cur = &ip[3 * i];
+        int is_smaller;
+        if (smallidx < maxidx && i >= 1 && close(cur, prev, larger)) is_smaller = 1;
+        else if (smallidx > minidx) is_smaller = -1;
+        else is_smaller = 0;
+        bool is_small = false;
+        if (i + 1 < natoms && close(cur, cur + 3, smallnum)) {
+            // the first two atoms change places: the second is written in full, the first as a delta in front of it
+            for (int c = 0; c < 3; ++c) std::swap(cur[c], cur[3 + c]);
+            is_small = true;
+        }
+        uint32_t u[3];
+        for (int c = 0; c < 3; ++c) u[c] = (uint32_t)(cur[c] - minint[c]);
+        if (bitsize == 0) for (int c = 0; c < 3; ++c) w.put(bitsizeint[c], u[c]);
+        else pack3(w, bitsize, sizeint, u);
+        prev = cur;
+        cur += 3;
+        ++i;
+        int run = 0;
+        if (!is_small && is_smaller == -1) is_smaller = 0;
+        while (is_small && run < 8 * 3) {
+            if (is_smaller == -1) {
+                const long long dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
+                if (dx * dx + dy * dy + dz * dz >= (long long)smaller * smaller) is_smaller = 0;
+            }
+            for (int c = 0; c < 3; ++c) tmp[run++] = (uint32_t)(cur[c] - prev[c] + smallnum);
+            prev = cur;
+            cur += 3;
+            ++i;
+            is_small = i < natoms && close(cur, prev, smallnum);
+        }
+        if (run != prevrun || is_smaller != 0) {
+            prevrun = run;
+            w.put(1, 1u);
+            w.put(5, (uint32_t)(run + is_smaller + 1));
+        } else {
+            w.put(1, 0u);
+        }
+        for (int k = 0; k < run; k += 3) pack3(w, smallidx, sizesmall, &tmp[k]);
+        if (is_smaller != 0) {
+            smallidx += is_smaller;
+            if (is_smaller < 0) {
+                smallnum = smaller;
+                smaller = smallidx > FIRSTIDX ? MAGIC[smallidx - 1] / 2 : 0;
+            } else {
+                smaller = smallnum;
+                smallnum = MAGIC[smallidx] / 2;
+            }
+            sizesmall[0] = sizesmall[1] = sizesmall[2] = (uint32_t)MAGIC[smallidx];
+        }
+        if (w.overflow) return 0;
+    }
+    size_t nbytes = w.finish();
+    if (w.overflow || nbytes > 0xFFFFFFFFull) return 0;
+    put_be32(out + 88, (uint32_t)nbytes);
+    while (nbytes & 3u) {
+        if (hdr + nbytes >= cap) return 0;
+        out[hdr + nbytes++] = 0;
+    }
+    return hdr + nbytes;
+}
+
 }  // namespace
 
 struct molar_hip_xtc {
@@ -406,6 +587,18 @@ int molar_hip_xtc_seek_time(const molar_hip_xtc *x, float t, size_t *frame) {
     return fail(MOLAR_HIP_ERR_IO, "xtc_seek_time: no frame at or after t = %g", (double)t);
 }
 
+int molar_hip_xtc_encode_frame(const float *xyz, size_t natoms, const float *box9, int32_t step, float time, float precision,
+                               uint8_t *out, size_t cap, size_t *out_len) {
+    if ((!xyz && natoms) || !box9 || !out || !out_len) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "xtc_encode_frame: null argument");
+    if (natoms > 0x7FFFFFFFull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "xtc_encode_frame: too many atoms");
+    if (!(precision > 0.0f)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "xtc_encode_frame: precision must be positive (got %g)", (double)precision);
+    const size_t len = encode_frame(xyz, natoms, box9, step, time, precision, out, cap);
+    if (len == (size_t)-1) return fail(MOLAR_HIP_ERR_IO, "xtc_encode_frame: a coordinate times the precision does not fit the integer grid");
+    if (len == 0) return fail(MOLAR_HIP_ERR_TOO_LARGE, "xtc_encode_frame: the buffer of %zu bytes is too small (96 + 16 * natoms always suffices)", cap);
+    *out_len = len;
+    return MOLAR_HIP_OK;
+}
+
 int molar_hip_xtc_read(molar_hip_ctx *c, const molar_hip_xtc *x, size_t first, size_t count, float *xyz, int nthreads) {
     if (!x || !xyz) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "xtc_read: null argument");
     if (count == 0) return MOLAR_HIP_OK;
@@ -478,14 +671,21 @@ int molar_hip_xtc_read_device(molar_hip_ctx *c, const molar_hip_xtc *x, size_t f
     const size_t tab_bytes = count * sizeof(FrameInfo), st_bytes = count * sizeof(int);
     MH_TRY(c->m_xyz2.reserve((size_t)(end - off0) + 8));
     MH_TRY(c->m_idx2.reserve(tab_bytes + st_bytes));
-    MH_HIP(hipMemcpyAsync(c->m_xyz2.p, x->data + off0, (size_t)(end - off0), hipMemcpyHostToDevice, c->stream));
-    MH_HIP(hipMemcpyAsync(c->m_idx2.p, tab.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
-    int *d_status = reinterpret_cast<int *>(c->m_idx2.as<char>() + tab_bytes);
-    hipLaunchKernelGGL(xtc_decode_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream, c->m_xyz2.as<uint8_t>(),
-                       c->m_idx2.as<FrameInfo>(), (uint32_t)count, xyz_dev, natoms, d_status);
-    MH_HIP(hipGetLastError());
+    // From here on asynchronous copies read `tab` and write `status` (pageable, local): every way out waits for the stream first.
     std::vector<int> status(count);
-    MH_HIP(hipMemcpyAsync(status.data(), d_status, st_bytes, hipMemcpyDeviceToHost, c->stream));
+    int *d_status = reinterpret_cast<int *>(c->m_idx2.as<char>() + tab_bytes);
+    hipError_t e = hipMemcpyAsync(c->m_xyz2.p, x->data + off0, (size_t)(end - off0), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->m_idx2.p, tab.data(), tab_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(xtc_decode_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream, c->m_xyz2.as<uint8_t>(),
+                           c->m_idx2.as<FrameInfo>(), (uint32_t)count, xyz_dev, natoms, d_status);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(status.data(), d_status, st_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        return fail(MOLAR_HIP_ERR_HIP, "xtc_read_device: %s", hipGetErrorString(e));
+    }
     MH_HIP(hipStreamSynchronize(c->stream));
     std::vector<float> tmp;
     for (size_t k = 0; k < count; ++k) {

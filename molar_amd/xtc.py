@@ -8,6 +8,8 @@
 
 `read_frames(first, count, out=...)` is the batched entry the GPU path uses: frames are decoded in parallel on
 host threads straight into a torch/HIP device buffer (or a numpy array).
+
+    encode_frame / XtcWriter   write_state (xtc_handler.rs:117-168): GROMACS' compressed frames, written by the library
 """
 from __future__ import annotations
 
@@ -17,6 +19,48 @@ import numpy as np
 
 from . import _lib
 from .api import Engine, PeriodicBox, State, check, _addr
+
+
+def encode_frame(xyz, box9, step=0, time=0.0, precision=1000.0) -> bytes:
+    """One XTC frame (molar_hip_xtc_encode_frame): xyz float32 [natoms, 3] in nm, box9 = the 9 floats the file stores."""
+    lib = _lib.load()
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    box9 = np.ascontiguousarray(box9, np.float32).reshape(9)
+    n = xyz.shape[0] if xyz.ndim == 2 else xyz.size // 3
+    out = np.empty(96 + 16 * n, np.uint8)
+    ln = C.c_size_t(0)
+    check(lib.molar_hip_xtc_encode_frame(xyz.ctypes.data, n, box9.ctypes.data, int(step), float(time), float(precision),
+                                         out.ctypes.data, out.nbytes, C.byref(ln)))
+    return out[:ln.value].tobytes()
+
+
+class XtcWriter:
+    """FileFormatHandler::create + write_state for XTC (xtc_handler.rs:54-62, 117-168): frames appended to one file."""
+
+    def __init__(self, path, precision=1000.0):
+        self.f = open(path, "wb")
+        self.precision = precision
+        self.nframes = 0
+
+    def write_state(self, state: State, step=None):
+        # the file's 9 floats fill the matrix column by column (read_state below): the column-major form
+        box9 = np.zeros(9, np.float32) if state.pbox is None else np.asarray(state.pbox.colmajor9(), np.float32).reshape(9)
+        self.write(state.coords, box9, self.nframes if step is None else step, state.time)
+
+    def write(self, xyz, box9, step, time):
+        self.f.write(encode_frame(xyz, box9, step, time, self.precision))
+        self.nframes += 1
+
+    def close(self):
+        if self.f:
+            self.f.close()
+            self.f = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class XtcReader:
@@ -71,6 +115,15 @@ class XtcReader:
         thousands of frames; bit-identical to read_frames."""
         if self.engine is None:
             raise ValueError("read_frames_device needs an engine")
+        # the C entry point takes an address and no capacity: everything it relies on is checked here
+        import torch
+        need = count * (self.frame_info(first)["natoms"] if count else 0) * 3
+        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()):
+            raise ValueError("read_frames_device: `out` must be a contiguous float32 CUDA tensor")
+        if out.device.index != self.engine.device:
+            raise ValueError(f"read_frames_device: `out` lives on cuda:{out.device.index}, the engine on cuda:{self.engine.device}")
+        if out.numel() < need:
+            raise ValueError(f"read_frames_device: `out` holds {out.numel()} floats, {count} frames need {need}")
         addr, keep = _addr(out)
         check(self.lib.molar_hip_xtc_read_device(self.engine.ctx, self.h, first, count, addr))
         return out

@@ -538,28 +538,71 @@ static void cell_pair_two(const sctx *s, size_t cA, size_t cB, uint8_t wrap, pve
 }
 
 /* driver tail: plan.into_par_iter().with_min_len(3).map(..).flatten().collect()
- * (distance_search.rs:542-557, 949-953): ordered concatenation of per-entry results. */
+ * (distance_search.rs:542-557, 949-953): ordered concatenation of per-entry results.
+ *
+ * Schedule (what bench.py's cpu_baseline and the tools' CPU columns time):
+ *  - rayon never splits below 3 plan entries and adapts its splitting to the work it finds; the restatement uses
+ *    min(nthreads, entries / 3, candidate evaluations / 5e5) threads and stays serial for one - a plan of a few hundred
+ *    small entries (a 20-atom selection in a 100k-atom box) costs 8 ms serially, and forking a team of 256 threads over
+ *    it used to cost 250 ms whatever the problem (round 4's CPU columns);
+ *  - every thread appends the results of its entries to ONE growing arena of its own (the reference's Vec per task draws
+ *    on rayon's thread-local allocator caches; a malloc + realloc chain per plan entry made the 1M-atom baseline
+ *    page-fault-bound) and records (thread, start, length) per entry; the ordered concatenation is a prefix sum over the
+ *    entries and one parallel copy. */
+typedef struct { int th; size_t start, n; } part_ref;
+
+static size_t plan_work(const sctx *s, const plan_item *plan, size_t np) {
+    size_t w = 0;
+    for (size_t e = 0; e < np; ++e) {
+        if (s->kind == K_SINGLE) {
+            w += cell_len(s->g1, plan[e].c1) * cell_len(s->g1, plan[e].c2);
+        } else {
+            w += cell_len(s->g1, plan[e].c1) * cell_len(s->g2, plan[e].c2) + cell_len(s->g1, plan[e].c2) * cell_len(s->g2, plan[e].c1);
+        }
+    }
+    return w;
+}
+
 static orc_pairs *run_plan(const sctx *s, const plan_item *plan, size_t np, int nthreads) {
     int with_jd = s->kind != K_WITHIN;
-    pvec *parts = (pvec *)calloc(np ? np : 1, sizeof(pvec));
-    (void)nthreads;
+    int nt = nthreads > 0 ? nthreads : 1;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 3) num_threads(nthreads > 0 ? nthreads : 1)
+    {
+        size_t by_len = np / 3, by_work = plan_work(s, plan, np) / 500000u;
+        if ((size_t)nt > by_len) nt = (int)by_len;
+        if ((size_t)nt > by_work) nt = (int)by_work;
+        if (nt < 1) nt = 1;
+    }
+#else
+    nt = 1;
+#endif
+    pvec *arena = (pvec *)calloc((size_t)nt, sizeof(pvec));
+    part_ref *ref = (part_ref *)calloc(np ? np : 1, sizeof(part_ref));
+    for (int t = 0; t < nt; ++t) arena[t].with_jd = with_jd;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 3) num_threads(nt) if (nt > 1)
 #endif
     for (long e = 0; e < (long)np; ++e) {
-        pvec *f = &parts[e];
-        f->with_jd = with_jd;
+#ifdef _OPENMP
+        const int th = omp_get_thread_num();
+#else
+        const int th = 0;
+#endif
+        pvec *f = &arena[th];
+        ref[e].th = th;
+        ref[e].start = f->n;
         if (s->kind == K_SINGLE) {
             cell_pair_single(s, plan[e], f);
         } else {
             cell_pair_two(s, plan[e].c1, plan[e].c2, plan[e].wrap, f);
             cell_pair_two(s, plan[e].c2, plan[e].c1, plan[e].wrap, f);   /* (pair.1, pair.0, pair.2) */
         }
+        ref[e].n = f->n - ref[e].start;
     }
     orc_pairs *out = (orc_pairs *)calloc(1, sizeof(orc_pairs));
     size_t *off = (size_t *)malloc((np + 1) * sizeof(size_t));
     off[0] = 0;
-    for (size_t e = 0; e < np; ++e) off[e + 1] = off[e] + parts[e].n;
+    for (size_t e = 0; e < np; ++e) off[e + 1] = off[e] + ref[e].n;
     size_t tot = off[np];
     out->n = tot;
     out->i = (uint64_t *)malloc((tot ? tot : 1) * sizeof(uint64_t));
@@ -568,22 +611,25 @@ static orc_pairs *run_plan(const sctx *s, const plan_item *plan, size_t np, int 
         out->d = (REAL *)malloc((tot ? tot : 1) * sizeof(REAL));
     }
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel for schedule(static) num_threads(nt) if (nt > 1)
 #endif
     for (long e = 0; e < (long)np; ++e) {
-        pvec *f = &parts[e];
-        if (f->n) {
-            memcpy(out->i + off[e], f->i, f->n * sizeof(uint64_t));
+        const pvec *f = &arena[ref[e].th];
+        const size_t st = ref[e].start, n = ref[e].n;
+        if (n) {
+            memcpy(out->i + off[e], f->i + st, n * sizeof(uint64_t));
             if (with_jd) {
-                memcpy(out->j + off[e], f->j, f->n * sizeof(uint64_t));
-                memcpy(out->d + off[e], f->d, f->n * sizeof(REAL));
+                memcpy(out->j + off[e], f->j + st, n * sizeof(uint64_t));
+                memcpy(out->d + off[e], f->d + st, n * sizeof(REAL));
             }
         }
-        free(f->i); free(f->j); free(f->d);
     }
+    for (int t = 0; t < nt; ++t) { free(arena[t].i); free(arena[t].j); free(arena[t].d); }
+    free(arena);
+    free(ref);
     free(off);
-    free(parts);
     out->plan_len = np;
+    out->threads_used = nt;
     return out;
 }
 

@@ -87,6 +87,7 @@ typedef struct {
     REAL *d;       /* NULL for `within` results */
     uint64_t dims[3];   /* grid dims used (diagnostic) */
     size_t plan_len;    /* number of plan entries kept (diagnostic) */
+    int threads_used;   /* threads the plan was run on: min(nthreads, entries / 3, candidate evaluations / 5e5) (diagnostic) */
 } orc_pairs;
 
 void orc_pairs_free(orc_pairs *p);

@@ -35,6 +35,7 @@ class _Pairs(C.Structure):
         ("d", C.c_void_p),
         ("dims", C.c_uint64 * 3),
         ("plan_len", C.c_size_t),
+        ("threads_used", C.c_int),
     ]
 
 
@@ -113,7 +114,7 @@ class Oracle:
         pr = ptr.contents
         n = pr.n
         i = np.ctypeslib.as_array(pr.i, shape=(max(n, 1),))[:n].copy()
-        res = {"i": i, "dims": tuple(int(x) for x in pr.dims), "plan_len": int(pr.plan_len)}
+        res = {"i": i, "dims": tuple(int(x) for x in pr.dims), "plan_len": int(pr.plan_len), "threads_used": int(pr.threads_used)}
         if not within:
             j = np.ctypeslib.as_array(pr.j, shape=(max(n, 1),))[:n].copy()
             dptr = C.cast(pr.d, C.POINTER(self.creal))

@@ -671,7 +671,7 @@ def test_matrix_core_count_band_at_other_length_scales(eng, orc32, scale, monkey
     mfma_error_bound / mfma_bound_usable).  The band stress of the test above, scaled: tens of thousands of interior pairs at
     rc * (1 +- 1e-8 .. 1e-4); at scale 300 (cutoff^2 = 9e4) a blob whose cells are tight enough for the path to be tried.
     A wrong count shifts every later slot's output, so lists must equal the oracle's bit for bit - with the matrix-core
-    count and with the vector count (MOLAR_HIP_NO_MFMA_COUNT) alike."""
+    count and, in a build with the A/B knobs, with the vector count (MOLAR_HIP_NO_MFMA_COUNT) alike."""
     a = api()
     rng = np.random.default_rng(11)
     rc = np.float32(1.0 * scale)
@@ -692,7 +692,11 @@ def test_matrix_core_count_band_at_other_length_scales(eng, orc32, scale, monkey
         pos = (rng.normal(size=(300, 3)) * 8.0).astype(np.float32)
         ref = orc32.search_single(float(rc), pos, nthreads=4)
         kw = {}
-    for env in (None, "1"):
+    # the release library has one code path; a build with -DMOLAR_HIP_AB_KNOBS (tools/build_variant.sh) also runs the vector count
+    from molar_amd import _lib
+    lib_path = os.environ.get("MOLAR_HIP_PLUGIN") or _lib.DEFAULT_LIB
+    has_knobs = b"MOLAR_HIP_NO_MFMA_COUNT" in open(lib_path, "rb").read()
+    for env in ((None, "1") if has_knobs else (None,)):
         if env:
             monkeypatch.setenv("MOLAR_HIP_NO_MFMA_COUNT", env)
         e2 = a.Engine(0)          # the knob is read when a context is created

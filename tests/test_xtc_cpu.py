@@ -199,3 +199,101 @@ def test_xtc_randomised_differential():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_xtc
     assert fuzz_xtc.run(300, 3) == 0
+
+
+# ---------------------------------------------------------------- writer (molar_hip_xtc_encode_frame, xtc_handler.rs:117-168)
+
+def _water_like(rng, nmol, L):
+    """O, H, H per molecule, 0.1 nm bonds at 104.5 degrees in random orientations: the layout the format's runs of small
+    deltas are made for (a lower bound on the distance between consecutive atoms is what sets the first delta size)"""
+    o = rng.random((nmol, 3)) * L
+    a = rng.normal(size=(nmol, 3)); a /= np.linalg.norm(a, axis=1)[:, None]
+    b = rng.normal(size=(nmol, 3)); b -= (b * a).sum(1)[:, None] * a; b /= np.linalg.norm(b, axis=1)[:, None]
+    th = np.deg2rad(104.5)
+    return np.stack([o, o + 0.1 * a, o + 0.1 * (np.cos(th) * a + np.sin(th) * b)], 1).reshape(-1, 3).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["water", "random", "mixed", "ten_atoms", "nine_atoms", "one_atom", "huge_extent", "negative", "clustered"])
+def test_writer_round_trips_through_both_decoders(reader_cls, orc32, case):
+    """What the library writes, the library's decoder AND the oracle's xdrfile-style decoder read back as the same
+    integers: every coordinate equals round(x * precision) / precision computed as the format defines it, frame headers
+    survive, and water-like input takes fewer bits than scattered atoms (the small-delta runs are really used)."""
+    from molar_amd.xtc import encode_frame
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    prec = np.float32(1000.0)
+    if case == "water":
+        xyz = _water_like(rng, 4000, 6.0)
+    elif case == "random":
+        xyz = (rng.random((12000, 3)) * 6.0).astype(np.float32)
+    elif case == "mixed":
+        xyz = np.concatenate([_water_like(rng, 1500, 5.0), (rng.random((3001, 3)) * 5.0).astype(np.float32), _water_like(rng, 700, 5.0)])
+    elif case == "ten_atoms":
+        xyz = (rng.random((10, 3)) * 2.0).astype(np.float32)
+    elif case == "nine_atoms":
+        xyz = (rng.random((9, 3)) * 2.0).astype(np.float32)
+    elif case == "one_atom":
+        xyz = np.array([[0.5, -1.25, 3.0]], np.float32)
+    elif case == "huge_extent":          # sizes above 2^24 grid units: every coordinate in its own bit field
+        xyz = (rng.random((500, 3)) * 4.0e4 - 2.0e4).astype(np.float32)
+    elif case == "negative":
+        xyz = _water_like(rng, 900, 3.0) - np.float32(7.5)
+    else:                                # a tight cluster, then far jumps: the adaptive delta size moves both ways
+        xyz = np.concatenate([rng.normal(0, 0.004, (3000, 3)), rng.normal(0, 0.5, (3000, 3)), rng.normal(0, 0.02, (3000, 3))]).astype(np.float32) + np.float32(4.0)
+    box9 = np.array([6, 0, 0, 0.5, 6, 0, 0.25, 0.75, 6], np.float32)
+    blob = encode_frame(xyz, box9, step=42, time=17.5, precision=float(prec))
+    blob2 = encode_frame(xyz[::-1].copy(), box9, step=43, time=18.5, precision=float(prec))
+    data = blob + blob2
+    off = orc32.xtc_index(data)
+    assert list(off) == [0, len(blob)]
+    want_int = np.where(xyz * prec >= 0, xyz * prec + np.float32(0.5), xyz * prec - np.float32(0.5)).astype(np.int32)
+    want = want_int.astype(np.float32) * (np.float32(1.0) / prec) if len(xyz) > 9 else xyz
+    r = reader_cls(data)
+    assert len(r) == 2 and r.natoms == len(xyz)
+    got = r.read_frames(0, 2, nthreads=2)
+    ref0, h0 = orc32.xtc_decode(data, 0)
+    ref1, h1 = orc32.xtc_decode(data, int(off[1]))
+    assert np.array_equal(got[0], ref0) and np.array_equal(got[1], ref1)
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want[::-1])
+    assert h0["step"] == 42 and h0["time"] == 17.5 and h1["step"] == 43 and np.array_equal(h0["box9"], box9)
+    info = r.frame_info(1)
+    assert info["step"] == 43 and info["time"] == 18.5 and np.array_equal(info["box9"], box9)
+    r.close()
+
+
+def test_writer_uses_runs_for_water(reader_cls):
+    from molar_amd.xtc import encode_frame
+    rng = np.random.default_rng(5)
+    box9 = np.eye(3, dtype=np.float32).reshape(9) * 6
+    water = len(encode_frame(_water_like(rng, 5000, 6.0), box9))
+    scattered = len(encode_frame((rng.random((15000, 3)) * 6.0).astype(np.float32), box9))
+    assert water < 0.8 * scattered, (water, scattered)
+
+
+def test_writer_rejects_bad_input(reader_cls):
+    from molar_amd.xtc import encode_frame
+    from molar_amd._lib import MolarHipError
+    box9 = np.zeros(9, np.float32)
+    with pytest.raises(MolarHipError):
+        encode_frame(np.full((20, 3), 1.0e9, np.float32), box9)            # 1e12 grid units
+    with pytest.raises(MolarHipError):
+        encode_frame(np.zeros((20, 3), np.float32), box9, precision=0.0)
+    with pytest.raises(MolarHipError):
+        encode_frame(np.full((20, 3), np.nan, np.float32), box9)
+
+
+def test_xtc_writer_file_round_trip(reader_cls, tmp_path):
+    from molar_amd.xtc import XtcWriter
+    from molar_amd.api import PeriodicBox, State
+    rng = np.random.default_rng(9)
+    box = PeriodicBox.from_matrix(np.array([[5, 0.5, 0.25], [0, 5, 0.75], [0, 0, 5]], np.float32))
+    frames = [_water_like(rng, 300, 5.0) for _ in range(3)]
+    p = tmp_path / "w.xtc"
+    with XtcWriter(p) as w:
+        for k, f in enumerate(frames):
+            w.write_state(State(f, box, time=2.0 * k))
+    r = reader_cls(str(p))
+    states = list(r)
+    assert len(states) == 3 and [s.time for s in states] == [0.0, 2.0, 4.0]
+    for s, f in zip(states, frames):
+        assert np.abs(s.coords - f).max() <= 0.5001e-3
+        assert np.array_equal(s.pbox.get_matrix(), box.get_matrix())
