@@ -196,7 +196,10 @@ struct molar_hip_ctx {
     mh::DevBuf wide_i, wide_j; // usize widening
     mh::DevBuf hist;           // u64 bins
     mh::DevBuf dbg;            // builds with -DMOLAR_HIP_DEBUG_KNOBS: per-wave time accounting of hist_kernel
-    mh::DevBuf hist_queue;     // slot queues of hist_kernel (hist_kernels.hpp): zero between launches
+    mh::DevBuf hist_queue;     // slot queues and list counters of the fused histogram (hist_kernels.hpp)
+    mh::DevBuf slot_desc_rest; // fused histogram: records of the slots the generic kernel takes (hist_plan_kernel)
+    unsigned long long hist_frames = 0;   // fused-histogram launches of this context (parity selects the list counters)
+    bool hist_plan_now = false;           // set around prepare_search by the fused histogram of the fixed-cutoff kinds
     mh::DevBuf hist_edges;     // f32[nbins + 1]: smallest d2 that reaches each bin (hist_kernel), for the cached (min, max, nbins)
     float edges_min = 0.f, edges_max = 0.f;
     size_t edges_nbins = 0;    // 0: no table cached

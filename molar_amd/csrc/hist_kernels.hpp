@@ -51,11 +51,18 @@ constexpr int HIST_WAVES = MH_HIST_WAVES;      // waves per workgroup (one LDS h
 #ifndef MH_HIST_CU_WAVES
 #define MH_HIST_CU_WAVES 32
 #endif
-constexpr int HIST_CU_WAVES = MH_HIST_CU_WAVES;   // resident waves per CU the grid is sized for
+// Resident waves per CU the grid is sized for: all 32.  (24 - two 12-wave workgroups - costs the kernel 2 % alone, and was
+// tried so that the next frame's grid, plan and left-over slots could run beside it on the side stream: they do not.  A
+// second stream's workgroups get onto this chip beside a persistent kernel only when that kernel holds <= 16 waves per CU,
+// whatever registers and LDS it leaves free (profiles/microbench/coresidency.hip, profiles/r05_coresidency_mi355x.txt);
+// at 16 waves per CU this kernel is 26 % slower.  So the frames of a trajectory stay one after the other on one stream.)
+constexpr int HIST_CU_WAVES = MH_HIST_CU_WAVES;
 constexpr uint32_t HQ_WORDS = 512;             // per-wave stack, 32-bit words
 constexpr int HQ_ROW_CHUNKS = 6;               // chunks of a row between two looks at the stack: < 128 left over + 6 * 64 pushed fit
 static_assert(HQ_WORDS >= 127u + 64u * (uint32_t)HQ_ROW_CHUNKS && 2 * HQ_ROW_CHUNKS >= KREG, "a row is drained at most once in its middle");
 constexpr uint32_t HIST_NSUB = 4;              // slot queues per XCD
+constexpr uint32_t HIST_LIST_WORD = 32u * (8u * HIST_NSUB + 1u);      // queue words: [queue counters][done][lean, rest counts of parity 0][... of parity 1]
+constexpr uint32_t HIST_TRI_ROWS = 32;         // rows per slot of a same-cell entry: every row meets all chunks, a 64-row slot took 2.7x a plain one
 
 struct HistState {
     lds_u32 *q;            // this wave's stack
@@ -304,7 +311,7 @@ __device__ __forceinline__ uint32_t hist_run_wrapped(const SearchParams &P, cons
 template <int KIND>
 __global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(8)))
 hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ slot_desc, uint32_t nslots_bound,
-            const uint32_t *__restrict__ nslots_real, uint32_t *__restrict__ queue) {
+            uint32_t *__restrict__ queue, uint32_t parity) {
     __shared__ float4 lds_a[HIST_WAVES][64];
     __shared__ uint32_t lds_q[HIST_WAVES][HQ_WORDS];
     extern __shared__ uint32_t lds_hist[];
@@ -346,7 +353,8 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
     // free takes what is left, across workgroups.  (One counter for the whole grid serialises: 7*10^4 atomics on one address
     // took 1.1 ms in round 2; here a counter sees ~1800 of them over the kernel's 0.25 ms.)  The last workgroup to leave
     // zeroes the counters for the next launch.
-    const uint32_t nslots = sgpr(nslots_real[0] < nslots_bound ? nslots_real[0] : nslots_bound);
+    const uint32_t nlist = queue[HIST_LIST_WORD + 64u * parity];                    // records hist_plan_kernel wrote into this kernel's list
+    const uint32_t nslots = sgpr(nlist < nslots_bound ? nlist : nslots_bound);
     const uint32_t qx = blockIdx.x & 7u, qj = (blockIdx.x >> 3) & (HIST_NSUB - 1u);
     uint32_t *const qctr = queue + 32u * (qx * HIST_NSUB + qj);                      // one counter per 128-byte line
     const uint32_t nruns = (nslots + XCD_RUN - 1u) / XCD_RUN;                        // runs in all; queue (x, j) owns R = (8 k + x) with k mod NSUB == j
@@ -374,7 +382,6 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
             const uint4 lo = reinterpret_cast<const uint4 *>(slot_desc + slot)[0];
             const uint4 hi = reinterpret_cast<const uint4 *>(slot_desc + slot)[1];
             fl = sgpr(hi.y);
-            if (!(fl & 0x200u)) continue;             // past the last slot
             T.a0 = sgpr(lo.x);
             T.n1 = sgpr(lo.y);
             T.b0 = sgpr(lo.z);
@@ -387,7 +394,6 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
             T.wrap_b = (fl >> 12) & 7u;
             T.rps = fl >> 16;
         }
-        if (!hist_lean_slot<KIND>(P, fl, T.n2)) continue;
 #ifdef MOLAR_HIP_DEBUG_KNOBS
         if (P.debug_skip) {
             const uint32_t kind_bit = T.tri ? 4u : ((P.use_box && T.wrap != 0u) ? 2u : 1u);
@@ -482,26 +488,97 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         if (v) atomicAdd(&P.hist_bins[b], (unsigned long long)v);
     }
     if (lane == 0 && wave_total && P.hist_total) atomicAdd(P.hist_total, wave_total);
-    // every wave of this workgroup is past its last ticket (the barrier above): the last workgroup out resets the queues
+    // every wave of this workgroup is past its last ticket (the barrier above): the last workgroup out resets the queues, and
+    // the list counters of the OTHER parity for the next frame's plan (this frame's are still read by the generic kernel behind us)
     if (threadIdx.x == 0) {
         uint32_t *done = queue + 32u * (8u * HIST_NSUB);
         if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
             for (uint32_t i = 0; i <= 8u * HIST_NSUB; ++i) __hip_atomic_store(queue + 32u * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(queue + HIST_LIST_WORD + 64u * (parity ^ 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(queue + HIST_LIST_WORD + 64u * (parity ^ 1u) + 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-// words the slot queues need (zeroed once when the buffer is made; every launch leaves them zeroed)
-constexpr size_t HIST_QUEUE_WORDS = 32u * (8u * HIST_NSUB + 1u);
+// The plan of a fused-histogram frame in ONE kernel.  The reference's plan order matters to a pair LIST; a histogram only needs
+// every (entry, row block) once, so the three launches of the regular plan (entries, scan, slot records) and the parameter upload
+// collapse: a thread decodes its plan entry (decode_task: the reference's search_plan, distance_search.rs:217-269), the workgroup
+// scans its entries' row-block counts in LDS, reserves its share of the list with ONE atomic and writes the records - into the lean
+// kernel's list or, for the entries only the generic kernel can do, into that kernel's own (so neither walks the other's slots).
+template <int KIND>
+__global__ void __launch_bounds__(256) hist_plan_kernel(SearchParams P, SearchParams *__restrict__ params_dst, SlotDesc *__restrict__ lean,
+                                                        SlotDesc *__restrict__ rest, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t sh[2][256];
+    __shared__ uint32_t base[2];
+    if (blockIdx.x == 0) {      // the parameter block the two kernels read, from this kernel's own argument segment (P is its first argument)
+        const uint32_t *src = (const uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t *d = (uint32_t *)params_dst;
+        for (uint32_t w = threadIdx.x; w < (uint32_t)(sizeof(SearchParams) / 4u); w += blockDim.x) d[w] = src[w];
+    }
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    Task T;
+    uint32_t nb = 0u, fl = 0u, rps = 64u;
+    bool is_lean = true;
+    if (t < P.ntasks) {
+        T = decode_task<KIND, false>(P, t);
+        if (T.valid) {
+            rps = T.rps;
+            if (T.tri && rps > HIST_TRI_ROWS) rps = HIST_TRI_ROWS;
+            nb = (T.n1 + rps - 1u) / rps;
+            fl = T.wrap | (T.tri ? 0x100u : 0u) | 0x200u | (T.wrap_b << 12) | (rps << 16);
+            is_lean = P.hist_lean && hist_lean_slot<KIND>(P, fl, T.n2);
+        }
+    }
+    // inclusive scans of the two lists' counts over the workgroup (Hillis-Steele: 8 rounds over 256 entries)
+    sh[0][threadIdx.x] = is_lean ? nb : 0u;
+    sh[1][threadIdx.x] = is_lean ? 0u : nb;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
+        const uint32_t a0 = threadIdx.x >= d ? sh[0][threadIdx.x - d] : 0u, a1 = threadIdx.x >= d ? sh[1][threadIdx.x - d] : 0u;
+        __syncthreads();
+        sh[0][threadIdx.x] += a0;
+        sh[1][threadIdx.x] += a1;
+        __syncthreads();
+    }
+    if (threadIdx.x < 2u) {
+        const uint32_t tot = sh[threadIdx.x][255];
+        base[threadIdx.x] = tot ? __hip_atomic_fetch_add(counts + 32u * threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+    __syncthreads();
+    if (nb == 0u) return;
+    const uint32_t l = is_lean ? 0u : 1u;
+    SlotDesc *out = (is_lean ? lean : rest) + base[l] + (sh[l][threadIdx.x] - nb);
+    SlotDesc o;
+    o.a0 = T.a0; o.n1 = T.n1; o.b0 = T.b0; o.n2 = T.n2;
+    o.cb = T.cb; o.flags = fl; o.pad0 = 0u;
+    o.moff = ~0ull >> 1;          // no hit history in this mode
+    o.pad1 = 0ull;
+    for (uint32_t k = 0; k < nb; ++k) {
+        o.i0 = k * rps;
+        out[k] = o;
+    }
+}
+
+// words of the queue buffer: slot queues, the `done` word, two pairs of list counters (zeroed once when the buffer is made;
+// every launch leaves the queues and the next frame's list counters zeroed)
+constexpr size_t HIST_QUEUE_WORDS = HIST_LIST_WORD + 4u * 32u;
+
+template <int KIND>
+inline void launch_hist_plan_kernel(hipStream_t stream, const SearchParams &P, SearchParams *params_dst, SlotDesc *lean, SlotDesc *rest,
+                                    uint32_t *queue, int parity) {
+    const unsigned nb = (unsigned)((P.ntasks + 255ull) / 256ull);
+    hipLaunchKernelGGL((hist_plan_kernel<KIND>), dim3(nb ? nb : 1u), dim3(256), 0, stream, P, params_dst, lean, rest,
+                       queue + HIST_LIST_WORD + 64u * (unsigned)parity);
+}
 
 template <int KIND>
 inline void launch_hist_kernel(unsigned num_cus, size_t dyn_lds, hipStream_t stream, const SearchParams *dP,
-                               const SlotDesc *slot_desc, uint32_t nslots_bound, const uint32_t *nslots_real, uint32_t *queue) {
-    // persistent workgroups: 32 waves per CU (8 per SIMD); a multiple of 8 * HIST_NSUB wide so that every queue has the same number of takers
+                               const SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity) {
+    // persistent workgroups; a multiple of 8 * HIST_NSUB wide so that every queue has the same number of takers
     unsigned nb = num_cus * (HIST_CU_WAVES / HIST_WAVES);
     nb = (nb / (8u * HIST_NSUB)) * (8u * HIST_NSUB);
     if (nb == 0) nb = 8u * HIST_NSUB;
-    hipLaunchKernelGGL((hist_kernel<KIND>), dim3(nb), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots_bound, nslots_real, queue);   // counters, then the nbins + 1 bin edges
+    hipLaunchKernelGGL((hist_kernel<KIND>), dim3(nb), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots_bound, queue, (uint32_t)parity);   // counters, then the nbins + 1 bin edges
 }
 
 }  // namespace pairk

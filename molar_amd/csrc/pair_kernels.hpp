@@ -99,6 +99,8 @@ struct SearchParams {
     const float *hist_edges; // f32[nbins + 1], see histogram_edges() in search.hip; NULL: hist_kernel evaluates the formula per hit
     float hist_scale;        // nbins / (max - min), for the first guess of the bin
     uint32_t hist_lean;      // histogram mode: hist_kernel takes the slots hist_lean_slot() accepts, pair_kernel<MODE_HIST> the rest
+    const uint32_t *hist_nslots;   // histogram mode with the one-kernel plan (hist_plan_kernel): pair_kernel<MODE_HIST> walks a list of
+                                   // exactly this many records, all of them its own (NULL: the slot records of the regular plan)
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     uint32_t debug_skip;     // profiling aid (env MOLAR_HIP_DEBUG_SKIP): bit0 plain, bit1 wrapped, bit2 triangular slots do nothing
     unsigned long long *dbg; // per-wave time accounting of hist_kernel (8 words per wave), molar_hip_debug_fetch
@@ -1529,7 +1531,7 @@ template <int KIND, int MODE>
 __global__ void __launch_bounds__(64 * waves_per_block(MODE))
 __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 7 : 8)))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
-                                                     const uint32_t nslots,      // the host's bound: slots past the real count are empty
+                                                     const uint32_t nslots_arg,  // the host's bound: slots past the real count are empty
                                                      uint32_t *__restrict__ slot_cnt,
                                                      const unsigned long long *__restrict__ slot_base,
                                                      uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
@@ -1548,6 +1550,11 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
     // (box.shifts[k]), gets copied to scratch by the compiler and drags every field into VGPRs.
     const SearchParams &P = *Pp;
     const uint32_t lane = threadIdx.x & 63u;
+    uint32_t nslots = nslots_arg;
+    if (MODE == MODE_HIST && P.hist_nslots) {        // its own list, written by hist_plan_kernel: the count sits in memory
+        const uint32_t real = __builtin_amdgcn_readfirstlane(P.hist_nslots[0]);
+        nslots = real < nslots_arg ? real : nslots_arg;
+    }
     // one-wave workgroups (count / fill): the wave index is the constant 0, so every LDS address is an immediate
     const uint32_t wave = WAVES_PER_BLOCK == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr bool hist = MODE == MODE_HIST;
@@ -1629,7 +1636,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         }
         uint32_t total = 0;
         const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
-        if (hist && P.hist_lean && hist_lean_slot<KIND>(P, (T.tri ? 0x100u : 0u) | T.wrap, T.n2)) return;   // hist_kernel's
+        if (hist && P.hist_lean && !P.hist_nslots && hist_lean_slot<KIND>(P, (T.tri ? 0x100u : 0u) | T.wrap, T.n2)) return;   // hist_kernel's
 #ifdef MOLAR_HIP_DEBUG_KNOBS
         if (P.debug_skip) {     // not in release builds: tools/dbg_skip.sh builds with -DMOLAR_HIP_DEBUG_KNOBS
             const uint32_t kind_bit = T.tri ? 4u : (wk != WK_NONE ? (T.rps == 8u ? 8u : 2u) : 1u);   // 8: triclinic corner entries
@@ -1692,10 +1699,15 @@ inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t str
 }  // namespace pairk
 
 // defined in pair_k0.hip .. pair_k3.hip (one search kind each)
-// (pair_k4.hip, hist_kernels.hpp) nslots_real: the plan's slot count in device memory; queue: hist_queue_words() zeroed words
+// (pair_k4.hip, hist_kernels.hpp) the fused histogram of the fixed-cutoff kinds: the one-kernel plan (two slot lists: the lean
+// kernel's and the generic kernel's) and the lean kernel.  queue: hist_queue_words() words, zero before the first launch;
+// parity: alternates between consecutive frames of a context (which pair of list counters this frame uses)
+void launch_hist_plan(int kind, hipStream_t stream, const pairk::SearchParams &P, pairk::SearchParams *params_dst, pairk::SlotDesc *lean,
+                      pairk::SlotDesc *rest, uint32_t *queue, int parity);
 void launch_hist_lean(int kind, unsigned num_cus, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
-                      const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, const uint32_t *nslots_real, uint32_t *queue);
+                      const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity);
 size_t hist_queue_words();
+const uint32_t *hist_list_count(const uint32_t *queue, int parity, int which);      // which: 0 lean, 1 rest
 void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
                         const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                         const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);

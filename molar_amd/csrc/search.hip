@@ -938,6 +938,7 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.hist_min = P.hist_max = 0.f;
     P.hist_bins = nullptr;
     P.hist_total = nullptr;
+    P.hist_nslots = nullptr;
     // zero pattern shared by the matrix and its inverse -> which products a wrapped pair may skip
     P.wrap_kind = 3u;   // WK_GENERAL
     if (c->use_box) {
@@ -1043,6 +1044,7 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     size_t dyn_lds = 0;
     P.hist_lean = 0u;
     P.hist_edges = nullptr;
+    P.hist_nslots = nullptr;
     P.hist_scale = 0.f;
     if (hist_nbins) {
         dyn_lds = (size_t)hist_nbins * 4;
@@ -1074,7 +1076,7 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     // that made every resident search upload the block again, 8.6 us on the critical stream of every frame, until round 4)
     const bool plan_wrote = c->params_fresh && !FILL && !hist_nbins && out_cap == c->params_fresh_cap;
     c->params_fresh = false;
-    if (!params_resident && !plan_wrote)
+    if (!params_resident && !plan_wrote && !P.hist_lean)
         hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, c->stream, P, c->params.as<SearchParams>());
     const SearchParams *dP = c->params.as<SearchParams>();
     const SlotDesc *tf = c->slot_desc.as<SlotDesc>();
@@ -1083,11 +1085,18 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     auto *sb = c->slot_base.as<unsigned long long>();
     const int mode = !FILL ? MODE_COUNT : (hist_nbins ? MODE_HIST : MODE_FILL);
     if (P.hist_lean) {
-        if (!c->hist_queue.p) {         // slot queues of hist_kernel: zeroed once, every launch leaves them zeroed
+        // fused histogram of the fixed-cutoff kinds: one-kernel plan (which also writes the parameter block), the lean kernel on
+        // its list, the generic kernel on the list of what the lean one cannot do (triclinic corner entries, oversized cells)
+        if (!c->hist_queue.p) {         // slot queues and list counters: zeroed once, every launch leaves what the next one needs zeroed
             MH_TRY(c->hist_queue.reserve(hist_queue_words() * 4));
             MH_HIP(hipMemsetAsync(c->hist_queue.p, 0, hist_queue_words() * 4, c->stream));
         }
-        launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st, c->task_nb.as<uint32_t>() + c->ntasks, c->hist_queue.as<uint32_t>());
+        uint32_t *queue = c->hist_queue.as<uint32_t>();
+        const int parity = (int)(c->hist_frames++ & 1u);
+        P.hist_nslots = hist_list_count(queue, parity, 1);
+        launch_hist_plan(c->kind, c->stream, P, c->params.as<SearchParams>(), c->slot_desc.as<SlotDesc>(), c->slot_desc_rest.as<SlotDesc>(), queue, parity);
+        launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st, queue, parity);
+        tf = c->slot_desc_rest.as<SlotDesc>();
     }
     switch (c->kind) {
         case MOLAR_HIP_SEARCH_SINGLE: launch_pair_single(mode, P.nblocks, dyn_lds, c->stream, dP, tf, st, sc, sb, pairs, dist, ids); break;
@@ -1306,11 +1315,14 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     c->nslots_bound = (two ? 28ull : 14ull) * (((uint64_t)c->set[0].n + 63ull) / 64ull) + c->ntasks;
     // entries wrapping in all three dims of a triclinic box use 2-row (<= 1024 rows) or 8-row slots: <= 28 tasks of <= 512 slots
     c->nslots_bound += 28ull * 512ull;
+    // (the one-kernel plan of the fused histogram cuts same-cell entries into 32-row slots: one such entry per cell)
+    if (c->hist_plan_now) c->nslots_bound += ((uint64_t)c->set[0].n + 31ull) / 32ull + ncells;
     if (c->ntasks >= 0xFFFFFFF0ull || c->nslots_bound >= 0xFFFFFFF0ull || c->ntasks + c->nslots_bound >= 0xFFFFFF00ull)
         return fail(MOLAR_HIP_ERR_TOO_LARGE, "search plan too large (%llu entries)", (unsigned long long)c->ntasks);
     MH_TRY(c->task_nb.reserve((c->ntasks + 1) * 4));
     MH_TRY(c->task_desc.reserve((c->ntasks + 1) * sizeof(TaskDesc)));
     MH_TRY(c->slot_desc.reserve((c->nslots_bound + 1) * sizeof(SlotDesc)));
+    if (c->hist_plan_now) MH_TRY(c->slot_desc_rest.reserve((c->nslots_bound + 1) * sizeof(SlotDesc)));
     MH_TRY(c->slot_cnt.reserve((c->nslots_bound + 1) * 4));
     MH_TRY(c->slot_base.reserve((c->nslots_bound + 1) * 8));
     MH_TRY(c->params.reserve(sizeof(SearchParams)));
@@ -1950,7 +1962,13 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
         c->side_wait = c->gen_free[gen];
         c->want_side = !c->env_no_side;
     }
+    // the fixed-cutoff kinds plan inside launch_pairs (hist_plan_kernel): prepare_search builds the grid only
+    const bool hist_plan = q->kind == MOLAR_HIP_SEARCH_SINGLE || q->kind == MOLAR_HIP_SEARCH_DOUBLE;
+    c->skip_plan = hist_plan;
+    c->hist_plan_now = hist_plan;
     const int prc = prepare_search(c, q, /*size_masks=*/false);     // the fused pass records no hit bits
+    c->skip_plan = false;
+    c->hist_plan_now = false;
     c->want_side = false;
     c->side_wait = nullptr;
     MH_TRY(prc);
