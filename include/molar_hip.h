@@ -182,6 +182,12 @@ int molar_hip_search_fill_ids(molar_hip_ctx *ctx, uint64_t *ids);
  * (:627-629) is the caller's union with the inner selection.  ids: uint64[count], host or device. */
 int molar_hip_within_count(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_count);
 int molar_hip_within_fill(molar_hip_ctx *ctx, uint64_t *ids);
+/* Consecutive `within` requests against one frame (selection/ast.rs:589-631 evaluated for several inner selections or cutoffs;
+ * within_size_bench.rs:13-47) name the same first set: with the hold on, a molar_hip_within_count whose request has the same
+ * first-set pointers and sizes, the same box and periodicity and comes to the same grid reuses the staged coordinates and the
+ * grid of the request before it.  The caller promises that those coordinates do not change while the hold is on (for a Rust
+ * caller: while it holds the `&State`); any other search on the context, or on = 0, ends the reuse. */
+int molar_hip_within_hold(molar_hip_ctx *ctx, int on);
 /* Modify::unwrap_connectivity_dim (molar/src/modify.rs:72-131): neighbour search of the selection with local ids under
  * full PBC on the GPU, SearchConnectivity's adjacency in pair order (connectivity.rs:19-35) and the reference's stack
  * walk on the host - every atom is moved to the closest image (over `pbc_dims`) of the atom it was reached from.  xyz:

@@ -327,6 +327,12 @@ class Engine:
             check(self.lib.molar_hip_within_fill(self.ctx, ids.ctypes.data))
         return ids
 
+    def within_hold(self, on=True):
+        """molar_hip_within_hold: while on, within_set calls that name the same first set (same array / tensor, same index,
+        same box) and come to the same grid reuse its staged coordinates and its grid.  The caller promises not to change
+        those coordinates meanwhile."""
+        check(self.lib.molar_hip_within_hold(self.ctx, 1 if on else 0))
+
     def search_fill_ids(self, count):
         ids = np.empty(count, np.uint64)
         check(self.lib.molar_hip_search_fill_ids(self.ctx, ids.ctypes.data))

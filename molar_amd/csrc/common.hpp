@@ -203,7 +203,23 @@ struct molar_hip_ctx {
     mh::DevBuf hist_edges;     // f32[nbins + 1]: smallest d2 that reaches each bin (hist_kernel), for the cached (min, max, nbins)
     float edges_min = 0.f, edges_max = 0.f;
     size_t edges_nbins = 0;    // 0: no table cached
+    // molar_hip_within_hold: reuse of the first set's staged coordinates and grid across `within` requests
+    bool within_hold = false, hold_valid = false;
+    mh::GridSet *hold_set = nullptr;
+    const float *hold_xyz = nullptr;
+    const uint64_t *hold_idx = nullptr;
+    size_t hold_natoms = 0, hold_n = 0;
+    int hold_ids_local = 0;
+    bool hold_use_box = false;
+    uint8_t hold_pbc = 0;
+    molar_hip_box hold_box{};
+    uint32_t hold_dims[3]{0, 0, 0};
+    float hold_lower[3]{}, hold_upper[3]{};
     // `within` as a set (molar_hip_within_count / _fill)
+    mh::DevBuf w_list;         // small second sets: ids found, in the order they were found (within_small_kernel)
+    bool w_small = false;      // the cached within set was made by the small path (the list holds it)
+    uint64_t w_list_dirty = 0; // flags set through the list by the previous small-path call, to be cleared before the next
+    bool w_flags_all_dirty = false;   // the previous call went through the partner lists: any flag may be set
     mh::DevBuf w_flags, w_part_cnt, w_part, w_tile_cnt, w_tile_off;
     uint64_t within_nflags = 0, within_total = 0;
     bool have_within = false;

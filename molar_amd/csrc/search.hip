@@ -22,6 +22,8 @@
 #include "boxmath.hpp"
 #include "common.hpp"
 #include "hoststream.hpp"
+#include <algorithm>
+
 #include "pair_kernels.hpp"
 #include "stages.hpp"
 
@@ -1256,7 +1258,16 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     c->use_box = q->box9 != nullptr;
     c->pbc = q->pbc & 7u;
     if (c->use_box) MH_TRY(molar_hip_box_from_matrix(q->box9, &c->box));
-    MH_TRY(stage_set(c, c->set[0], q->xyz1, q->natoms1, q->idx1, q->n1, q->vdw1, vdw));
+    // molar_hip_within_hold: consecutive `within` requests against the SAME first set (same pointers and sizes, same box, same
+    // grid) reuse its staged coordinates and its grid; anything else that stages or bins set 0 ends the hold's validity
+    const bool may_hold = c->within_hold && q->kind == MOLAR_HIP_SEARCH_WITHIN && c->skip_plan;
+    bool reuse0 = may_hold && c->hold_valid && c->hold_set == c->set && c->hold_xyz == q->xyz1 && c->hold_natoms == q->natoms1 &&
+                  c->hold_idx == q->idx1 && c->hold_n == q->n1 && c->hold_ids_local == q->ids_local && c->hold_use_box == c->use_box &&
+                  c->hold_pbc == c->pbc && (!c->use_box || std::memcmp(&c->hold_box, &c->box, sizeof c->box) == 0);
+    if (!reuse0) {
+        c->hold_valid = false;
+        MH_TRY(stage_set(c, c->set[0], q->xyz1, q->natoms1, q->idx1, q->n1, q->vdw1, vdw));
+    }
     if (two) MH_TRY(stage_set(c, c->set[1], q->xyz2, q->natoms2, q->idx2, q->n2, q->vdw2, vdw));
     else c->set[1].n = 0;
 
@@ -1308,6 +1319,15 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         for (int d = 0; d < 3; ++d) ext[d] = c->upper[d] - c->lower[d];   // from_cutoff_and_min_max :112-114
     }
     MH_TRY(dims_from_extents(c, cutoff, ext));
+    if (reuse0) {          // the same cells? (the cutoff and, without a box, the caller's bounds decide the grid)
+        bool same = c->hold_dims[0] == c->dims[0] && c->hold_dims[1] == c->dims[1] && c->hold_dims[2] == c->dims[2];
+        for (int d = 0; d < 3 && !c->use_box; ++d) same = same && c->hold_lower[d] == c->lower[d] && c->hold_upper[d] == c->upper[d];
+        if (!same) {
+            reuse0 = false;
+            c->hold_valid = false;
+            MH_TRY(stage_set(c, c->set[0], q->xyz1, q->natoms1, q->idx1, q->n1, q->vdw1, vdw));
+        }
+    }
     const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
     c->ntasks = ncells * 14ull * (two ? 2ull : 1ull);
     // every set-1 cell is the first cell of at most 14 (two grids: 28) tasks, so
@@ -1382,7 +1402,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         hipStream_t main_stream = c->stream;
         c->stream = c->side_stream;
         c->on_side = true;
-        int rc = build_grid(c, c->set[0], q->ids_local || vdw);
+        int rc = reuse0 ? 0 : build_grid(c, c->set[0], q->ids_local || vdw);
         if (!rc && two) rc = build_grid(c, c->set[1], q->ids_local || vdw);
         hipError_t e = rc ? hipSuccess : hipEventRecord(c->grid_done, c->side_stream);
         c->stream = main_stream;
@@ -1396,8 +1416,15 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
         if (c->env_host_grid_wait) MH_HIP(hipEventSynchronize(c->grid_done));
         else MH_HIP(hipStreamWaitEvent(c->stream, c->grid_done, 0));
     } else {
-        MH_TRY(build_grid(c, c->set[0], q->ids_local || vdw));
+        if (!reuse0) MH_TRY(build_grid(c, c->set[0], q->ids_local || vdw));
         if (two) MH_TRY(build_grid(c, c->set[1], q->ids_local || vdw));
+    }
+    if (may_hold && !reuse0) {        // this grid of set 0 is the one later `within` requests may reuse
+        c->hold_valid = true;
+        c->hold_set = c->set;
+        c->hold_xyz = q->xyz1; c->hold_natoms = q->natoms1; c->hold_idx = q->idx1; c->hold_n = q->n1;
+        c->hold_ids_local = q->ids_local; c->hold_use_box = c->use_box; c->hold_pbc = c->pbc; c->hold_box = c->box;
+        for (int d = 0; d < 3; ++d) { c->hold_dims[d] = c->dims[d]; c->hold_lower[d] = c->lower[d]; c->hold_upper[d] = c->upper[d]; }
     }
 
     // (Round 4: the plan kernels - 32 us of small launches - on the side stream behind the grid, with a second generation
@@ -1456,6 +1483,94 @@ __global__ void __launch_bounds__(256) within_partners_kernel(const SearchParams
     if (!T.valid) return;
     const uint32_t s = atomicAdd(&part_cnt[T.ca], 1u);
     if (s < WITHIN_MAX_PART) part[(size_t)T.ca * WITHIN_MAX_PART + s] = T.cb | (T.wrap << 28);
+}
+
+// `within` against a SMALL second set (a ligand, a few residues: selection/ast.rs:589-631 on the shapes of
+// molar/benches/within_size_bench.rs): the plan is walked from the second set's side.  One wave per (second-set atom, one of
+// the 28 (mask, half) combinations); the wave of the FIRST atom of each occupied second-set cell finds the one plan entry
+// that has this cell as its second cell through that combination (decode_task on the candidate entry index: the
+// reference's own wrap / drop rules decide, nothing is re-derived), and tests the rows of the entry's first cell, 64 at a
+// time, lanes = rows, against the cell's few atoms with the reference's arithmetic (distance_squared over the entry's wrap
+// dims for wrapped entries).  A row that finds a partner sets its flag byte with an atomic OR on the containing word; the
+// lane that turned it on appends the id to a list - the result, unsorted, with its length in memory.  No partner lists over
+// all cells, no pass over the whole plan, no flag scan: two launches and one read-back for `within 0.8 of <20 atoms>`.
+__global__ void __launch_bounds__(64) within_small_kernel(const SearchParams *__restrict__ Pp, uint32_t n2, uint32_t ncells,
+                                                          uint32_t *__restrict__ flags32, uint32_t *__restrict__ list,
+                                                          uint32_t *__restrict__ list_n) {
+    const SearchParams &P = *Pp;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t j = blockIdx.x / 28u, combo = blockIdx.x % 28u;
+    if (j >= n2) return;
+    // the cell of sorted second-set atom j: the last cell whose start is <= j (binary search over cell_start)
+    uint32_t lo = 0u, hi = ncells;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (P.csb[mid] <= j) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t cell = lo;
+    if (P.csb[cell] != j) return;                                   // not the first atom of its cell
+    const uint32_t m = combo >> 1, half = combo & 1u;
+    const uint32_t cz = cell / (P.dx * P.dy), cy = (cell / P.dx) % P.dy, cx = cell % P.dx;
+    const uint32_t cc[3] = {cx, cy, cz}, dims[3] = {P.dx, P.dy, P.dz};
+    uint32_t home[3];
+    for (int d = 0; d < 3; ++d) {
+        const uint32_t off = half ? MASKS[m][d] : MASKS[m][3 + d];   // offset of the entry's SECOND cell from its home cell
+        if (cc[d] >= off) home[d] = cc[d] - off;
+        else if ((P.pbc >> d) & 1u) home[d] = dims[d] - 1u;          // reached across the periodic boundary
+        else return;
+    }
+    const uint64_t cidx = ((uint64_t)home[0] * P.dy + home[1]) * P.dz + home[2];          // x outer, z inner
+    const uint64_t t = (cidx * 14ull + m) * 2ull + half;
+    if (t >= P.ntasks) return;
+    const Task T = decode_task<MOLAR_HIP_SEARCH_WITHIN, false>(P, t);
+    if (!T.valid || T.cb != cell) return;
+    const float cutoff2 = P.cutoff2;
+    const bool wrapped = P.use_box && T.wrap != 0u;
+    float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), hi4 = lo4;
+    if (!wrapped) {
+        lo4 = gload4(P.aabb_b, 2 * T.cb);
+        hi4 = gload4(P.aabb_b, 2 * T.cb + 1);
+    }
+    // (blockIdx.y: a share of the first cell's 64-row blocks - large cutoffs mean cells of thousands of atoms)
+    for (uint32_t i0 = blockIdx.y * 64u; i0 < T.n1; i0 += gridDim.y * 64u) {
+        const bool have = i0 + lane < T.n1;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) a = gload4(P.sa, T.a0 + i0 + lane);
+        bool look = have;
+        if (!wrapped) look = look && !(aabb_d2(a.x, a.y, a.z, lo4.x, lo4.y, lo4.z, hi4.x, hi4.y, hi4.z) > cutoff2);
+        if (__builtin_amdgcn_ballot_w64(look) == 0ull) continue;
+        bool found = false;
+        for (uint32_t k0 = 0; k0 < T.n2; k0 += 64u) {
+            // 64 partner atoms at a time into the lanes, handed round with v_readlane (one load per 64 partners, not one each)
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + lane < T.n2) q = gload4(P.sb, T.b0 + k0 + lane);
+            const uint32_t cnt = T.n2 - k0 < 64u ? T.n2 - k0 : 64u;
+            for (uint32_t kk = 0; kk < cnt; ++kk) {
+                const float bx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.x), kk));
+                const float by = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.y), kk));
+                const float bz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.z), kk));
+                const float dx = bx - a.x, dy = by - a.y, dz = bz - a.z;                   // p2 - p1
+                const float d2 = wrapped ? wrapped_d2_exact(P, T.wrap, dx, dy, dz)          // :306-321
+                                         : (dx * dx + dy * dy) + dz * dz;                  // :281-292
+                found = found || (look && d2 <= cutoff2);
+                if ((kk & 7u) == 7u && __builtin_amdgcn_ballot_w64(look && !found) == 0ull) break;      // every row has its partner (:289, :318)
+            }
+            if (__builtin_amdgcn_ballot_w64(look && !found) == 0ull) break;
+        }
+        if (found) {
+            const uint32_t id = __float_as_uint(a.w);
+            const uint32_t bit = 1u << (8u * (id & 3u));
+            const uint32_t old = atomicOr(&flags32[id >> 2], bit);
+            if (!(old & bit)) list[atomicAdd(list_n, 1u)] = id;
+        }
+    }
+}
+
+// clears the flags a small-path call set (through its list) instead of a memset over every flag
+__global__ void __launch_bounds__(256) within_clear_kernel(const uint32_t *__restrict__ list, uint32_t n, uint8_t *__restrict__ flags) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) flags[list[i]] = 0u;
 }
 
 __global__ void __launch_bounds__(64) within_flags_kernel(const SearchParams *__restrict__ Pp, const uint32_t *__restrict__ part_cnt,
@@ -2026,15 +2141,42 @@ int molar_hip_within_count(molar_hip_ctx *c, const molar_hip_search_desc *q, uin
     }
     const uint32_t ncells = c->dims[0] * c->dims[1] * c->dims[2];
     const uint64_t ntiles = (nflags + 2047) / 2048;
-    MH_TRY(c->w_flags.reserve(nflags));
-    MH_TRY(c->w_part_cnt.reserve((size_t)ncells * 4));
-    MH_TRY(c->w_part.reserve((size_t)ncells * WITHIN_MAX_PART * 4));
+    const size_t flag_bytes = (nflags + 3) & ~(size_t)3;
+    const bool fresh_flags = c->w_flags.cap < flag_bytes;
+    MH_TRY(c->w_flags.reserve(flag_bytes));
     MH_TRY(c->w_tile_cnt.reserve((ntiles + 1) * 4));
     MH_TRY(c->w_tile_off.reserve((ntiles + 1) * 8));
     MH_TRY(c->params.reserve(sizeof(SearchParams)));
     const SearchParams P = make_params(c);
     hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, c->stream, P, c->params.as<SearchParams>());
-    MH_HIP(hipMemsetAsync(c->w_flags.p, 0, nflags, c->stream));
+    // flags: all zero between calls.  A small-path call leaves only the flags of its list set: those are cleared through the list.
+    if (fresh_flags || c->w_flags_all_dirty) MH_HIP(hipMemsetAsync(c->w_flags.p, 0, flag_bytes, c->stream));
+    else if (c->w_list_dirty)
+        hipLaunchKernelGGL(within_clear_kernel, dim3((unsigned)((c->w_list_dirty + 255) / 256)), dim3(256), 0, c->stream, c->w_list.as<uint32_t>() + 1,
+                           (uint32_t)c->w_list_dirty, c->w_flags.as<uint8_t>());
+    c->w_flags_all_dirty = false;
+    c->w_list_dirty = 0;
+    c->w_small = (uint64_t)c->set[1].n * 28ull <= (1ull << 17);           // <= 4681 second-set atoms: one wave per (atom, combination)
+    if (c->w_small) {
+        MH_TRY(c->w_list.reserve((nflags + 1) * 4));
+        MH_HIP(hipMemsetAsync(c->w_list.p, 0, 4, c->stream));               // word 0: the list's length, then the ids
+        // cells of many 64-row blocks (large cutoffs) get several waves per (cell, combination)
+        uint32_t wsplit = (uint32_t)(((uint64_t)c->set[0].n / 64u) / ncells) + 1u;
+        if (wsplit > 64u) wsplit = 64u;
+        hipLaunchKernelGGL(within_small_kernel, dim3(c->set[1].n * 28u, wsplit), dim3(64), 0, c->stream, c->params.as<SearchParams>(), c->set[1].n, ncells,
+                           c->w_flags.as<uint32_t>(), c->w_list.as<uint32_t>() + 1, c->w_list.as<uint32_t>());
+        MH_HIP(hipGetLastError());
+        uint32_t tot = 0;
+        MH_TRY(read_back(c, &tot, c->w_list.p, 4));
+        c->within_total = tot;
+        c->w_list_dirty = tot;
+        c->have_within = true;
+        if (out_count) *out_count = tot;
+        return MOLAR_HIP_OK;
+    }
+    c->w_flags_all_dirty = true;
+    MH_TRY(c->w_part_cnt.reserve((size_t)ncells * 4));
+    MH_TRY(c->w_part.reserve((size_t)ncells * WITHIN_MAX_PART * 4));
     MH_HIP(hipMemsetAsync(c->w_part_cnt.p, 0, (size_t)ncells * 4, c->stream));
     MH_HIP(hipMemsetAsync(c->w_tile_cnt.p, 0, (ntiles + 1) * 4, c->stream));
     hipLaunchKernelGGL(within_partners_kernel, dim3((unsigned)((c->ntasks + 255) / 256)), dim3(256), 0, c->stream, c->params.as<SearchParams>(),
@@ -2056,13 +2198,39 @@ int molar_hip_within_count(molar_hip_ctx *c, const molar_hip_search_desc *q, uin
     return MOLAR_HIP_OK;
 }
 
+// The first set of consecutive `within` requests stays the same while a selection expression is evaluated against one frame
+// (`within 0.3 of resid 1`, `within 0.8 of resid 1`, ...: within_size_bench.rs:13-47 asks 1600 times): with the hold on, a
+// request that names the same first set (same pointers and sizes, same box and periodicity) and comes to the same grid
+// reuses the staged coordinates and the grid of the one before.  The CALLER promises that the first set's coordinates do not
+// change while the hold is on (in Rust: for as long as it holds the `&State`); any other search on the context ends the reuse.
+int molar_hip_within_hold(molar_hip_ctx *c, int on) {
+    if (!c) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "null context");
+    c->within_hold = on != 0;
+    if (!on) c->hold_valid = false;
+    return MOLAR_HIP_OK;
+}
+
 int molar_hip_within_fill(molar_hip_ctx *c, uint64_t *ids) {
     if (!c || !c->have_within) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached within set: call molar_hip_within_count first");
     if (c->within_total == 0) return MOLAR_HIP_OK;
     if (!ids) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "within_fill: null output");
     MH_HIP(hipSetDevice(c->device));
     const bool dev = is_device_ptr(ids);
+    if (c->w_small && !dev) {           // the list IS the set: bring it over, sort it (SortedSet::from_unsorted, selection_expr.rs:112), widen it
+        std::vector<uint32_t> l((size_t)c->within_total);
+        MH_TRY(read_back(c, l.data(), c->w_list.as<uint32_t>() + 1, l.size() * 4));
+        std::sort(l.begin(), l.end());
+        for (size_t k = 0; k < l.size(); ++k) ids[k] = l[k];
+        return MOLAR_HIP_OK;
+    }
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(ids);
+    if (c->w_small) {                   // device output: compact the flags (they hold the same set)
+        const uint64_t ntiles = (c->within_nflags + 2047) / 2048;
+        MH_HIP(hipMemsetAsync(c->w_tile_cnt.p, 0, (ntiles + 1) * 4, c->stream));
+        hipLaunchKernelGGL(flag_tile_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, c->stream, c->w_flags.as<uint8_t>(), c->within_nflags,
+                           c->w_tile_cnt.as<uint32_t>());
+        MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->w_tile_cnt.as<uint32_t>(), c->w_tile_off.as<unsigned long long>(), ntiles + 1)));
+    }
     if (!dev) {
         MH_TRY(c->wide_i.reserve((size_t)c->within_total * 8));
         dst = c->wide_i.as<unsigned long long>();

@@ -45,3 +45,18 @@ def test_refuses_cleanly_without_enough_gpus():
 def test_world_size_mismatch_is_reported():
     r = run("--gpus", "2", "--launch-check", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_xtc_frame_supply_of_the_rdf_workload(gpus):
+    """`--workload rdf --source xtc` without the GPU: rank 0 writes the synthetic trajectory with the library's XTC writer,
+    every rank decodes its own contiguous block on host threads and gets exactly the frames (on the format's grid); the
+    ranks' counts are reduced over gloo."""
+    r = run("--gpus", str(gpus), "--steps", "5", "--launch-check", "--backend", "gloo", "--workload", "rdf", "--source", "xtc")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["source"] == "xtc" and d["n_gpus"] == gpus
+    assert d["frames_in_file"] == 5 * gpus and d["frames_decoded"] == 5 * gpus and d["ranks_with_exact_frames"] == gpus

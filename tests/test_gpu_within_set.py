@@ -115,3 +115,67 @@ def test_within_set_device_output_and_selection(eng, orc32):
                          device_out=lambda k: torch.empty(k, dtype=torch.int64, device="cuda"))
     eng.synchronize()
     assert np.array_equal(out.cpu().numpy().astype(np.uint64), np.unique(ref["i"]))
+
+
+@pytest.mark.parametrize("boxfn,n,cutoff,pbc,n2", [
+    (synth.box_a, 40000, 0.7, 7, 6000),        # second sets above the small-set path's limit: the partner-list path
+    (synth.box_b, 30000, 0.6, 7, 9000),
+    (synth.box_ortho, 30000, 0.8, 5, 5000),
+])
+def test_within_set_large_second_sets(eng, orc32, boxfn, n, cutoff, pbc, n2):
+    import molar_amd.api as a
+    box = boxfn(n)
+    pos = synth.frame(n, box)
+    rng = np.random.default_rng(n2)
+    ob = orc32.box_from_matrix(box)
+    idx1 = np.arange(n, dtype=np.uint64)
+    idx2 = np.sort(rng.choice(n, n2, replace=False)).astype(np.uint64)
+    want = np.unique(orc32.search_within_pbc(cutoff, pos, pos[idx2.astype(int)], ob, pbc, idx1, idx2, nthreads=8)["i"])
+    got = eng.within_set(cutoff, pos, idx1, pos, idx2, box=box, pbc=pbc)
+    assert np.array_equal(got, want)
+    # a small second set right after (flags left by the partner-list path are cleared), then the large one again
+    small = idx2[:40]
+    want_s = np.unique(orc32.search_within_pbc(cutoff, pos, pos[small.astype(int)], ob, pbc, idx1, small, nthreads=4)["i"])
+    assert np.array_equal(eng.within_set(cutoff, pos, idx1, pos, small, box=box, pbc=pbc), want_s)
+    assert np.array_equal(eng.within_set(cutoff, pos, idx1, pos, idx2, box=box, pbc=pbc), want)
+
+
+def test_within_hold_reuses_the_first_sets_grid(eng, orc32):
+    """molar_hip_within_hold: consecutive requests against one frame (within_size_bench.rs:13-47: groups of residues, a cutoff
+    sweep) - every answer equals the oracle's whether the grid was rebuilt or reused; a new cutoff (another grid), another
+    first set, a device tensor and a plain search in between all end the reuse without a wrong answer; after the hold is
+    switched off, changed coordinates are seen."""
+    import torch
+    import molar_amd.api as a
+    n = 50000
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 3)
+    ob = orc32.box_from_matrix(box)
+    idx1 = np.arange(n, dtype=np.uint64)
+    order = np.argsort(((pos - (box @ np.array([0.5, 0.5, 0.5], np.float32))) ** 2).sum(1))
+
+    def want(cutoff, p, i1, i2):
+        return np.unique(orc32.search_within_pbc(cutoff, p[i1.astype(int)], p[i2.astype(int)], ob, 7, i1, i2, nthreads=4)["i"])
+
+    e2 = a.Engine(0)
+    e2.within_hold(True)
+    dpos = torch.from_numpy(pos).cuda()
+    torch.cuda.synchronize()
+    for src in (pos, dpos):
+        for cutoff in (0.4, 0.4, 0.9, 0.4):
+            for nres in (1, 20, 1, 60):
+                grp = np.sort(order[:10 * (nres + 1)]).astype(np.uint64)
+                assert np.array_equal(e2.within_set(cutoff, src, idx1, src, grp, box=box, pbc=7), want(cutoff, pos, idx1, grp))
+        # another first set, then a plain search on the same context, then the first request again
+        half = idx1[::2].copy()
+        grp = np.sort(order[:50]).astype(np.uint64)
+        assert np.array_equal(e2.within_set(0.4, src, half, src, grp, box=box, pbc=7), want(0.4, pos, half, grp))
+        cnt = e2.search_count(a.SEARCH_SINGLE, 0.3, src, idx1[:5000], box=box, pbc=7)
+        assert cnt == len(orc32.search_single_pbc(0.3, pos[:5000], ob, 7, nthreads=4)["i"])
+        assert np.array_equal(e2.within_set(0.4, src, idx1, src, grp, box=box, pbc=7), want(0.4, pos, idx1, grp))
+    # hold off: the same array with other coordinates is staged again
+    e2.within_hold(False)
+    pos2 = pos.copy()
+    assert np.array_equal(e2.within_set(0.4, pos2, idx1, pos2, grp, box=box, pbc=7), want(0.4, pos2, idx1, grp))
+    pos2[:] = synth.frame(n, box, 4)
+    assert np.array_equal(e2.within_set(0.4, pos2, idx1, pos2, grp, box=box, pbc=7), want(0.4, pos2, idx1, grp))
