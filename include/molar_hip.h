@@ -188,6 +188,14 @@ int molar_hip_within_fill(molar_hip_ctx *ctx, uint64_t *ids);
  * grid of the request before it.  The caller promises that those coordinates do not change while the hold is on (for a Rust
  * caller: while it holds the `&State`); any other search on the context, or on = 0, ends the reuse. */
 int molar_hip_within_hold(molar_hip_ctx *ctx, int on);
+/* SearchConnectivity (molar/src/connectivity.rs:8-60: `for (i, j) in pairs { conn[i].push(j); conn[j].push(i) }`) of a
+ * single-selection search, built on the device from the resident pair list.  CSR over the request's id range - local ids
+ * (desc->ids_local): the selection's length; global ids: natoms - with every list in the reference's push order; an atom
+ * without a pair has an empty list (the reference's map has no key for it).  Count-then-fill like the searches: the first
+ * call runs the search (the request must be of kind MOLAR_HIP_SEARCH_SINGLE), builds the CSR in context-owned device memory
+ * and returns rows and entries (= 2 x pairs); the second copies offsets[rows + 1] and neigh[entries] to host or device memory. */
+int molar_hip_search_connectivity(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_rows, uint64_t *out_entries);
+int molar_hip_search_connectivity_fill(molar_hip_ctx *ctx, uint64_t *offsets, uint64_t *neigh);
 /* Modify::unwrap_connectivity_dim (molar/src/modify.rs:72-131): neighbour search of the selection with local ids under
  * full PBC on the GPU, SearchConnectivity's adjacency in pair order (connectivity.rs:19-35) and the reference's stack
  * walk on the host - every atom is moved to the closest image (over `pbc_dims`) of the atom it was reached from.  xyz:

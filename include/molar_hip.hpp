@@ -357,6 +357,29 @@ class SelBound {
         return out;
     }
     std::vector<std::vector<usize>> unwrap_connectivity(Float cutoff) { return unwrap_connectivity_dim(cutoff, PBC_FULL); }
+    // SearchConnectivity::from_iter(distance_search_single_pbc(cutoff, self, 0..len, box, dims)) (connectivity.rs:19-35, modify.rs:77-78)
+    // built on the device: conn[i] = neigh[offsets[i] .. offsets[i + 1]) in the reference's push order, local ids
+    struct Connectivity {
+        std::vector<uint64_t> offsets, neigh;
+        size_t len() const { size_t k = 0; for (size_t i = 0; i + 1 < offsets.size(); ++i) k += offsets[i + 1] > offsets[i]; return k; }   // keys of the reference's map
+        std::pair<const uint64_t *, const uint64_t *> get(usize i) const { return {neigh.data() + offsets[i], neigh.data() + offsets[i + 1]}; }
+    };
+    Connectivity search_connectivity(Float cutoff, PbcDims dims) const {
+        molar_hip_search_desc d{};
+        d.kind = MOLAR_HIP_SEARCH_SINGLE;
+        d.cutoff = cutoff;
+        d.xyz1 = coords_ptr(); d.natoms1 = natoms(); d.idx1 = index_.data(); d.n1 = index_.size();
+        d.ids_local = 1;
+        d.box9 = require_box().colmajor9();
+        d.pbc = dims.raw();
+        uint64_t rows = 0, ent = 0;
+        check(molar_hip_search_connectivity(ctx(), &d, &rows, &ent));
+        Connectivity c;
+        c.offsets.resize(rows + 1);
+        c.neigh.resize(ent);
+        check(molar_hip_search_connectivity_fill(ctx(), c.offsets.data(), ent ? c.neigh.data() : nullptr));
+        return c;
+    }
     void translate(const Vector3f &shift) {                       // modify.rs:16-23
         check(molar_hip_translate(ctx(), coords_ptr_mut(), natoms(), index_.data(), index_.size(), &shift.x));
     }

@@ -179,6 +179,8 @@ SYMBOLS = {
     "molar_hip_lipid_tail_order": (_I, [_P, _P, _SZ, _P, _P, _SZ, _I, _P, _P, _P, _P]),
     "molar_hip_apply_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
     "molar_hip_unwrap_simple": (_I, [_P, _P, _SZ, _P, _SZ, _P, _U8]),
+    "molar_hip_search_connectivity": (_I, [_P, _P, _P, _P]),
+    "molar_hip_search_connectivity_fill": (_I, [_P, _P, _P]),
     "molar_hip_unwrap_connectivity": (_I, [_P, _P, _SZ, _P, _SZ, _P, _F, _U8, _P, _P, _P]),
     "molar_hip_fit_rmsd_batch": (_I, [_P, _P, _SZ, _SZ, _P, _SZ, _P, _P, _SZ, _P, _I, _P, _P, _P, _P, _P]),
     "molar_hip_gyration_batch": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _P, _P]),

@@ -327,6 +327,19 @@ class Engine:
             check(self.lib.molar_hip_within_fill(self.ctx, ids.ctypes.data))
         return ids
 
+    def search_connectivity(self, cutoff, xyz, idx=None, box=None, pbc=0, ids_local=True):
+        """SearchConnectivity::from_iter over the single-selection search (connectivity.rs:19-35), built on the device from
+        the resident pair list (molar_hip_search_connectivity / _fill): CSR (offsets uint64[rows + 1], neigh uint64[2 * pairs])
+        with every list in the reference's push order; rows = len(selection) for local ids, natoms for global ones."""
+        d, keep = self._search_desc(SEARCH_SINGLE, cutoff, xyz, idx, None, None, box, pbc, None, None, ids_local, None, None)
+        rows, ent = C.c_uint64(0), C.c_uint64(0)
+        check(self.lib.molar_hip_search_connectivity(self.ctx, C.byref(d), C.byref(rows), C.byref(ent)))
+        self._keep = keep
+        off = np.zeros(rows.value + 1, np.uint64)
+        nb = np.zeros(max(ent.value, 1), np.uint64)
+        check(self.lib.molar_hip_search_connectivity_fill(self.ctx, off.ctypes.data, nb.ctypes.data))
+        return off, nb[:ent.value]
+
     def within_hold(self, on=True):
         """molar_hip_within_hold: while on, within_set calls that name the same first set (same array / tensor, same index,
         same box) and come to the same grid reuse its staged coordinates and its grid.  The caller promises not to change

@@ -203,6 +203,10 @@ struct molar_hip_ctx {
     mh::DevBuf hist_edges;     // f32[nbins + 1]: smallest d2 that reaches each bin (hist_kernel), for the cached (min, max, nbins)
     float edges_min = 0.f, edges_max = 0.f;
     size_t edges_nbins = 0;    // 0: no table cached
+    // SearchConnectivity on the device (molar_hip_search_connectivity / _fill)
+    mh::DevBuf conn_deg, conn_off, conn_ent, conn_neigh;
+    uint64_t conn_rows = 0, conn_entries = 0;
+    bool have_conn = false;
     // molar_hip_within_hold: reuse of the first set's staged coordinates and grid across `within` requests
     bool within_hold = false, hold_valid = false;
     mh::GridSet *hold_set = nullptr;

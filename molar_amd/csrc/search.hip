@@ -1452,6 +1452,49 @@ int finish_count(molar_hip_ctx *c) {
     return 0;
 }
 
+// ================================================================= SearchConnectivity on the device (connectivity.rs:19-35)
+// `for (i, j) in pairs { conn[i].push(j); conn[j].push(i) }` as CSR: degrees by atomics, an exclusive scan, every entry
+// dropped into its list in arrival order, then moved to its place - the number of entries of the same list that come from
+// earlier pairs (a pair feeds a list at most once per side; the entry of its i side precedes that of its j side when i == j
+// never happens: the single searches emit i != j).  Lists are a handful of bonded neighbours long, so the ranking reads its
+// own list; the result is the reference's push order exactly.
+__global__ void __launch_bounds__(256) conn_degree_kernel(const uint2 *__restrict__ pairs, unsigned long long npairs, uint32_t *__restrict__ deg) {
+    const unsigned long long p = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (p >= npairs) return;
+    const uint2 ij = pairs[p];
+    atomicAdd(&deg[ij.x], 1u);
+    atomicAdd(&deg[ij.y], 1u);
+}
+
+__global__ void __launch_bounds__(256) conn_bucket_kernel(const uint2 *__restrict__ pairs, unsigned long long npairs,
+                                                          const unsigned long long *__restrict__ off, uint32_t *__restrict__ cursor,
+                                                          unsigned long long *__restrict__ ent) {
+    const unsigned long long p = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (p >= npairs) return;
+    const uint2 ij = pairs[p];
+    // entry = (sequence number of the push << 32) | neighbour: pair p pushes j onto i's list (2p), then i onto j's (2p + 1)
+    ent[off[ij.x] + atomicAdd(&cursor[ij.x], 1u)] = ((2ull * p) << 32) | ij.y;
+    ent[off[ij.y] + atomicAdd(&cursor[ij.y], 1u)] = ((2ull * p + 1ull) << 32) | ij.x;
+}
+
+__global__ void __launch_bounds__(256) conn_rank_kernel(const unsigned long long *__restrict__ ent, const unsigned long long *__restrict__ off,
+                                                        uint32_t nrows, unsigned long long nent, unsigned long long *__restrict__ neigh) {
+    // one thread per entry; its list is found by bisection over the offsets
+    const unsigned long long e = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (e >= nent) return;
+    uint32_t lo = 0u, hi = nrows;                       // off[lo] <= e < off[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= e) lo = mid;
+        else hi = mid;
+    }
+    const unsigned long long a = off[lo], b = off[lo + 1];
+    const unsigned long long mine = ent[e];
+    unsigned long long rank = 0;
+    for (unsigned long long q = a; q < b; ++q) rank += (ent[q] >> 32) < (mine >> 32) ? 1ull : 0ull;
+    neigh[a + rank] = mine & 0xFFFFFFFFull;
+}
+
 // ================================================================= `within` as a set (selection/ast.rs:589-631)
 //
 // What a caller of distance_search_within(_pbc) keeps is the SET of first-set atoms with a second-set atom in range: the
@@ -2246,10 +2289,60 @@ int molar_hip_within_fill(molar_hip_ctx *c, uint64_t *ids) {
     return MOLAR_HIP_OK;
 }
 
+// SearchConnectivity (connectivity.rs:8-60) of a single-selection search, built on the device from the resident pair list:
+// CSR over the id range of the request (local ids: the selection's length; global ids: natoms), lists in the reference's push
+// order.  Count-then-fill: the first call runs the search and builds the CSR in context-owned device memory and returns the
+// number of entries (2 x pairs); the second copies offsets (rows + 1) and neighbours to host or device memory.
+int molar_hip_search_connectivity(molar_hip_ctx *c, const molar_hip_search_desc *q, uint64_t *out_rows, uint64_t *out_entries) {
+    if (!c || !q) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_connectivity: null argument");
+    if (q->kind != MOLAR_HIP_SEARCH_SINGLE)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_connectivity: ids of one selection index the lists - the request must be of kind MOLAR_HIP_SEARCH_SINGLE");
+    c->have_conn = false;
+    uint64_t npairs = 0;
+    const uint32_t *d_pairs = nullptr;
+    MH_TRY(molar_hip_search_resident(c, q, &npairs, &d_pairs, nullptr));
+    const size_t nsel = q->idx1 ? q->n1 : q->natoms1;
+    const uint64_t nrows = q->ids_local ? nsel : (q->idx1 ? q->natoms1 : nsel);
+    if (nrows >= 0xFFFFFFF0ull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "search_connectivity: too many rows");
+    const uint64_t nent = 2ull * npairs;
+    MH_TRY(c->conn_deg.reserve((nrows + 1) * 4 * 2));            // degrees, then the cursors
+    MH_TRY(c->conn_off.reserve((nrows + 1) * 8));
+    MH_TRY(c->conn_ent.reserve((nent ? nent : 1) * 8));
+    MH_TRY(c->conn_neigh.reserve((nent ? nent : 1) * 8));
+    uint32_t *deg = c->conn_deg.as<uint32_t>(), *cursor = deg + (nrows + 1);
+    MH_HIP(hipMemsetAsync(deg, 0, (nrows + 1) * 8, c->stream));
+    const unsigned nbP = (unsigned)((npairs + 255) / 256), nbE = (unsigned)((nent + 255) / 256);
+    const uint2 *pairs = reinterpret_cast<const uint2 *>(d_pairs);
+    if (nbP) hipLaunchKernelGGL(conn_degree_kernel, dim3(nbP), dim3(256), 0, c->stream, pairs, (unsigned long long)npairs, deg);
+    MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, deg, c->conn_off.as<unsigned long long>(), nrows + 1)));
+    if (nbP) {
+        hipLaunchKernelGGL(conn_bucket_kernel, dim3(nbP), dim3(256), 0, c->stream, pairs, (unsigned long long)npairs,
+                           c->conn_off.as<unsigned long long>(), cursor, c->conn_ent.as<unsigned long long>());
+        hipLaunchKernelGGL(conn_rank_kernel, dim3(nbE), dim3(256), 0, c->stream, c->conn_ent.as<unsigned long long>(), c->conn_off.as<unsigned long long>(),
+                           (uint32_t)nrows, (unsigned long long)nent, c->conn_neigh.as<unsigned long long>());
+    }
+    MH_HIP(hipGetLastError());
+    c->conn_rows = nrows;
+    c->conn_entries = nent;
+    c->have_conn = true;
+    if (out_rows) *out_rows = nrows;
+    if (out_entries) *out_entries = nent;
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_search_connectivity_fill(molar_hip_ctx *c, uint64_t *offsets, uint64_t *neigh) {
+    if (!c || !c->have_conn) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached connectivity: call molar_hip_search_connectivity first");
+    MH_HIP(hipSetDevice(c->device));
+    if (offsets) MH_HIP(hipMemcpyAsync(offsets, c->conn_off.p, (c->conn_rows + 1) * 8, hipMemcpyDefault, c->stream));
+    if (neigh && c->conn_entries) MH_HIP(hipMemcpyAsync(neigh, c->conn_neigh.p, c->conn_entries * 8, hipMemcpyDefault, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MOLAR_HIP_OK;
+}
+
 // Modify::unwrap_connectivity_dim (molar/src/modify.rs:72-131).  The neighbour search - the heavy part - runs on the GPU
 // (distance_search_single_pbc over the selection with LOCAL ids under full PBC, :77-78); the adjacency lists in push
 // order (SearchConnectivity::from_iter, connectivity.rs:19-35: for (i, j) in pair order conn[i].push(j), conn[j].push(i))
-// are a counting sort of the pair list on the host, and the reference's stack walk (:84-128) - serial by nature: every
+// are built on the device from the resident pair list (molar_hip_search_connectivity), and the reference's stack walk (:84-128) - serial by nature: every
 // atom is pulled to the closest image of the atom it was REACHED FROM, whose position the walk may just have changed -
 // runs on the host over that CSR with the same f32 arithmetic (boxmath.hpp's closest_image, the one the kernels use).
 // Quirks kept: the atom a component starts from (0, then the lowest unused index) is not a member of the selection
@@ -2273,24 +2366,11 @@ int molar_hip_unwrap_connectivity(molar_hip_ctx *c, float *xyz, size_t natoms, c
     q.ids_local = 1;
     q.box9 = box9;
     q.pbc = MOLAR_HIP_PBC_FULL;
-    uint64_t npairs = 0;
-    MH_TRY(molar_hip_search_count(c, &q, &npairs));
-    std::vector<uint32_t> pairs((size_t)npairs * 2);
-    if (npairs) MH_TRY(molar_hip_search_fill(c, pairs.data(), nullptr));
-    // ---- adjacency in push order (counting sort, stable)
-    std::vector<uint64_t> off(nsel + 1, 0);
-    for (size_t p = 0; p < 2 * (size_t)npairs; ++p) off[pairs[p] + 1]++;
-    for (size_t i = 0; i < nsel; ++i) off[i + 1] += off[i];
-    std::vector<uint32_t> adj(2 * (size_t)npairs);
-    {
-        std::vector<uint64_t> cur(off.begin(), off.end() - 1);
-        for (size_t p = 0; p < (size_t)npairs; ++p) {
-            const uint32_t i = pairs[2 * p], j = pairs[2 * p + 1];
-            adj[cur[i]++] = j;
-            adj[cur[j]++] = i;
-        }
-    }
-    std::vector<uint32_t>().swap(pairs);
+    // ---- adjacency in push order: SearchConnectivity on the device, only the CSR comes to the host
+    uint64_t nrows = 0, nent = 0;
+    MH_TRY(molar_hip_search_connectivity(c, &q, &nrows, &nent));
+    std::vector<uint64_t> off(nsel + 1, 0), adj((size_t)(nent ? nent : 1));
+    MH_TRY(molar_hip_search_connectivity_fill(c, off.data(), adj.data()));
     // ---- the coordinates of the frame on the host
     const bool dev = is_device_ptr(xyz);
     std::vector<float> hostcopy;
@@ -2333,7 +2413,7 @@ int molar_hip_unwrap_connectivity(molar_hip_ctx *c, float *xyz, size_t natoms, c
             const float *pc = pos(cc);
             const V3 p0 = v3(pc[0], pc[1], pc[2]);
             for (uint64_t e = off[cc]; e < off[cc + 1]; ++e) {
-                const uint32_t ind = adj[e];
+                const uint32_t ind = (uint32_t)adj[e];
                 if (used[ind]) continue;
                 float *pp = pos(ind);
                 const V3 r = closest_image(b, v3(pp[0], pp[1], pp[2]), p0, dims);

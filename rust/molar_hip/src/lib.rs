@@ -292,6 +292,33 @@ impl Engine {
         Ok(ids.into_iter().map(|v| v as usize).collect())
     }
 
+    /// While a caller holds `&State` the first set of its `within` requests cannot change: with the hold on, consecutive
+    /// `within_set_pbc` calls that name the same first set (same slices, same box) and come to the same grid reuse its staged
+    /// coordinates and its grid (molar_hip_within_hold; the reference's within_size_bench.rs asks 1600 times against one frame).
+    pub fn within_hold(&self, on: bool) -> Result<(), EngineError> {
+        self.plugin.check(unsafe { (self.plugin.fns.within_hold)(self.ctx, if on { 1 } else { 0 }) })
+    }
+
+    /// `SearchConnectivity::from_iter(distance_search_single_pbc(..))` (connectivity.rs:19-35, modify.rs:77-78) built on the
+    /// device: adjacency lists in the reference's push order as CSR over local ids (`offsets[len + 1]`, `neigh[2 * pairs]`).
+    pub fn search_connectivity_pbc(
+        &self, cutoff: f32, coords: &[[f32; 3]], index: Option<&[usize]>, box9: &[f32; 9], pbc: u8,
+    ) -> Result<(Vec<usize>, Vec<usize>), EngineError> {
+        check_index(index, coords.len(), "search_connectivity_pbc")?;
+        let (ip, n) = idx_ptr(index);
+        let d = MolarHipSearchDesc {
+            kind: SEARCH_SINGLE, cutoff, xyz1: coords.as_ptr() as *const f32, natoms1: coords.len(), idx1: ip, n1: n,
+            ids_local: 1, box9: box9.as_ptr(), pbc, ..Default::default()
+        };
+        let f = &self.plugin.fns;
+        let (mut rows, mut entries) = (0u64, 0u64);
+        self.plugin.check(unsafe { (f.search_connectivity)(self.ctx, &d, &mut rows, &mut entries) })?;
+        let mut off = vec![0u64; rows as usize + 1];
+        let mut nb = vec![0u64; entries as usize];
+        self.plugin.check(unsafe { (f.search_connectivity_fill)(self.ctx, off.as_mut_ptr(), if entries > 0 { nb.as_mut_ptr() } else { std::ptr::null_mut() }) })?;
+        Ok((off.into_iter().map(|v| v as usize).collect(), nb.into_iter().map(|v| v as usize).collect()))
+    }
+
     // ---------------------------------------------------------------- Measure (measure.rs:22-649)
 
     /// `Measure::center_of_mass` (:60-75)

@@ -1008,3 +1008,25 @@ def test_unwrap_connectivity_100k_atoms_against_the_oracle_entry(eng, orc32):
     # no box: the reference's require_box error
     with pytest.raises(a.MolarHipError):
         eng.unwrap_connectivity(wrapped.copy(), None, 0.17, 7)
+
+
+@pytest.mark.parametrize("boxfn,n,cutoff,local", [(synth.box_a, 30000, 0.25, True), (synth.box_b, 12000, 0.3, True),
+                                                 (synth.box_ortho, 20000, 0.2, False), (synth.box_a, 3000, 1.0, True)])
+def test_search_connectivity_csr_in_push_order(eng, orc32, boxfn, n, cutoff, local):
+    """SearchConnectivity::from_iter (connectivity.rs:19-35) on the device: conn[i].push(j); conn[j].push(i) in pair order.
+    The CSR must hold exactly those lists, element by element - including the dense case (cutoff 1.0: lists of hundreds)."""
+    box = boxfn(n)
+    pos = synth.frame(n, box)
+    idx = np.sort(np.random.default_rng(n).choice(n, n * 3 // 4, replace=False)).astype(np.uint64)
+    ob = orc32.box_from_matrix(box)
+    ref = orc32.search_single_pbc(cutoff, pos[idx.astype(int)], ob, 7, ids=None if local else idx, nthreads=8)
+    rows = len(idx) if local else n
+    lists = [[] for _ in range(rows)]
+    for i, j in zip(ref["i"].tolist(), ref["j"].tolist()):
+        lists[i].append(j)
+        lists[j].append(i)
+    off, nb = eng.search_connectivity(cutoff, pos, idx, box=box, pbc=7, ids_local=local)
+    assert len(off) == rows + 1 and off[0] == 0 and off[-1] == 2 * len(ref["i"]) == len(nb)
+    want_off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.uint64)
+    assert np.array_equal(off, want_off)
+    assert np.array_equal(nb, np.fromiter((v for l in lists for v in l), np.uint64, count=len(nb)))
