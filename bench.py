@@ -463,56 +463,84 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
     nres = min(K + W, 16)
     src = [torch.from_numpy(frame_of(rank, f)).to(device) for f in range(nres)]
 
-    def trajectory(eng, frames_dev, count, first_frame=0):
-        """count frames through one plan, two in flight; returns the accumulated sums (float64; integers exactly)."""
+    def trajectory(eng, frames_dev, count, first_frame=0, stride=1, offset=0):
+        """frames first_frame + offset, + offset + stride, ... (< first_frame + count) through one plan, two in flight; returns
+        (per-frame rows of sums in float64 - integers exactly -, seconds)."""
         m = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(cutoff=2.5, order_type=1))
         plan = m._plan()
         plan.set_valid(None)
         norder = plan.norder // nl
-        acc = np.zeros(4 + norder, np.float64)        # valid lipid-frames, vertices, area, |mean curvature|, order per carbon
+        ids = list(range(offset, count, stride))
+        rows = np.zeros((len(ids), 4 + norder), np.float64)   # valid lipid-frames, vertices, area, |mean curvature|, order per carbon
 
-        def take(t):
+        def take(t, k):
             r = plan.fetch(t, small)
             ok = r["valid"].astype(bool)
-            acc[0] += int(ok.sum())
-            acc[1] += int(r["nvert"][ok].sum())
-            acc[2] += float(r["area"][ok].sum(dtype=np.float64))
-            acc[3] += float(np.abs(r["mean_curv"][ok]).sum(dtype=np.float64))
-            acc[4:] += r["order"].reshape(nl, norder)[ok].sum(axis=0, dtype=np.float64)
+            rows[k, 0] = int(ok.sum())
+            rows[k, 1] = int(r["nvert"][ok].sum())
+            rows[k, 2] = float(r["area"][ok].sum(dtype=np.float64))
+            rows[k, 3] = float(np.abs(r["mean_curv"][ok]).sum(dtype=np.float64))
+            rows[k, 4:] = r["order"].reshape(nl, norder)[ok].sum(axis=0, dtype=np.float64)
 
-        bufs = [frames_dev[(first_frame + s) % len(frames_dev)].clone() for s in range(count)]     # unwrapped in place: fresh copies
+        bufs = [frames_dev[(first_frame + s) % len(frames_dev)].clone() for s in ids]     # unwrapped in place: fresh copies
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         prev = None
-        for s in range(count):
-            t = plan.begin(bufs[s], pbox)
+        for k in range(len(ids)):
+            t = plan.begin(bufs[k], pbox)
             if prev is not None:
-                plan.end(prev)
-                take(prev)
-            prev = t
+                plan.end(prev[0])
+                take(*prev)
+            prev = (t, k)
         if prev is not None:
-            plan.end(prev)
-            take(prev)
+            plan.end(prev[0])
+            take(*prev)
         eng.synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         plan.close()
-        return acc, dt
+        return rows, ids, dt
 
-    eng = api.Engine(local_rank)
+    S = max(1, args.streams)
+    engines = [api.Engine(local_rank) for _ in range(S)]
+    eng = engines[0]
+
+    def run_frames(count, first_frame=0):
+        """`count` frames over the S engine contexts (context s takes frames s, s + S, ...: one host thread, one stream and one
+        chained plan each - the frames of a trajectory are independent, and a frame is ~35 latency-bound launches that leave
+        most of the chip idle); sums accumulated in FRAME order, so the result does not depend on S."""
+        if S == 1:
+            rows, ids, dt = trajectory(eng, src, count, first_frame)
+            parts = [(rows, ids)]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(S) as pool:
+                res = list(pool.map(lambda s_: trajectory(engines[s_], src, count, first_frame, S, s_), range(S)))
+            dt = time.perf_counter() - t0
+            parts = [(r[0], r[1]) for r in res]
+        per_frame = [None] * count
+        for rows, ids in parts:
+            for k, f in enumerate(ids):
+                per_frame[f] = rows[k]
+        acc = np.zeros(per_frame[0].shape if count else 4, np.float64)
+        for row in per_frame:
+            acc += row
+        return acc, dt
 
     def barrier():
         if world > 1:
             dist.barrier()
-        eng.synchronize()
+        for e in engines:
+            e.synchronize()
         torch.cuda.synchronize()
 
     t_pre = time.perf_counter()
     while args.preheat > 0 and time.perf_counter() - t_pre < args.preheat:
-        trajectory(eng, src, 16)
-    trajectory(eng, src, max(W, 1))
+        run_frames(16)
+    run_frames(max(W, 1))
     barrier()
-    acc, elapsed = trajectory(eng, src, K, first_frame=W)
+    acc, elapsed = run_frames(K, first_frame=W)
     barrier()
     # sums over ranks: the integer entries exactly, the float sums in rank order on rank 0
     from molar_amd.distributed import gather_float64
@@ -547,9 +575,9 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C5 shape: 500k-atom synthetic bilayer frames resident in HBM, 2 x 2000 lipids of 52 atoms: unwrap, "
                                    "head / mid / tail markers, patches (rc 2.5 nm), initial normals, one smoothing pass (quadric fit, "
-                                   "Voronoi cell, curvatures, area), Scd of 8000 tails; one chained call per frame, two frames in flight, "
+                                   "Voronoi cell, curvatures, area), Scd of 8000 tails; one chained call per frame, two frames in flight per engine context, "
                                    "per-lipid results fetched and accumulated on the host every frame; frames sharded over ranks, one "
-                                   "gather of the accumulated sums", "natoms": len(xyz), "nlipids": nl, "frames_per_gpu": K},
+                                   "gather of the accumulated sums", "natoms": len(xyz), "nlipids": nl, "frames_per_gpu": K, "engine_contexts_per_gpu": S},
             "results": {"valid_lipid_frames": int(nvalid), "mean_vertices": total[1] / max(nvalid, 1), "mean_area_nm2": total[2] / max(nvalid, 1),
                         "mean_abs_mean_curvature": total[3] / max(nvalid, 1), "mean_abs_scd": float(np.abs(total[4:] / max(nvalid, 1)).mean())},
             "roofline": None,
@@ -572,7 +600,7 @@ def main():
     ap.add_argument("--serial-measure", action="store_true",
                     help="run the Kabsch fit/RMSD/COM/gyration of a frame after its search on the same stream instead of "
                          "concurrently on a second engine context (HIP stream) of the same GPU")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MOLAR_BENCH_STREAMS", "1")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MOLAR_BENCH_STREAMS", "0")),
                     help="engine contexts (HIP streams) per GPU working on different frames in the timed region.  1 (default): one "
                          "context, two frames in flight through molar_hip_search_resident_begin / _end, the next frame's grid built on "
                          "the side stream under the fill pass.  2: two contexts on alternate frames, one host thread each (until the "
@@ -604,6 +632,8 @@ def main():
                     help="functional check of the N>1 code path on a box with fewer GPUs: ranks share the visible GPUs "
                          "(rank r uses GPU r mod count) and reduce over gloo; the line it prints is NOT a scaling result")
     args = ap.parse_args()
+    if args.streams <= 0:         # default: one context for the search workloads; the membrane workload (a frame = ~35 latency-bound
+        args.streams = 4 if args.workload == "membrane" else 1      # launches on 4000 lipids) runs four contexts on alternate frames
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
