@@ -1662,6 +1662,8 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
     const uint32_t w0 = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES_PER_BLOCK + wave;
     if (!hist) {
         // COUNT / FILL: one wave per slot (nothing is live across slots -> fewer registers, more waves)
+        // (round 5: two / four consecutive slots per one-wave workgroup in the count pass - half / a quarter of the 2.9e5
+        // launches - took 1.21 / 0.93 ms against 0.41: the slot body in a loop loses its register allocation; not kept)
         if (w0 < nslots) process_slot(w0);
     } else {
         // histogram mode: capped grid, strided slots, so each workgroup flushes its LDS histogram once

@@ -1190,18 +1190,21 @@ int bbox_accumulate(molar_hip_ctx *c, uint32_t *d_mm, const GridSet &S) {
     return 0;
 }
 
-int device_fmax(molar_hip_ctx *c, const float *d_v, uint32_t n, float *out) {
+// max of each of two device arrays with ONE read-back (the vdW cutoff, distance_search.rs:781-783)
+int device_fmax2(molar_hip_ctx *c, const float *d_v1, uint32_t n1, const float *d_v2, uint32_t n2, float *out1, float *out2) {
     MH_TRY(c->hist.reserve(64));
     uint32_t *d = c->hist.as<uint32_t>();
-    const uint32_t seed = 0u;   // below every ordered float
-    MH_HIP(hipMemcpyAsync(d, &seed, 4, hipMemcpyHostToDevice, c->stream));
-    unsigned nb = (n + 255u) / 256u;
-    if (nb > 1024u) nb = 1024u;
-    hipLaunchKernelGGL(fmax_kernel, dim3(nb), dim3(256), 0, c->stream, d_v, n, d);
+    MH_HIP(hipMemsetAsync(d, 0, 8, c->stream));          // 0 is below every ordered float
+    unsigned nb1 = (n1 + 255u) / 256u, nb2 = (n2 + 255u) / 256u;
+    if (nb1 > 1024u) nb1 = 1024u;
+    if (nb2 > 1024u) nb2 = 1024u;
+    hipLaunchKernelGGL(fmax_kernel, dim3(nb1), dim3(256), 0, c->stream, d_v1, n1, d);
+    hipLaunchKernelGGL(fmax_kernel, dim3(nb2), dim3(256), 0, c->stream, d_v2, n2, d + 1);
     MH_HIP(hipGetLastError());
-    uint32_t o;
-    MH_TRY(read_back(c, &o, d, 4));
-    *out = ord2f(o);
+    uint32_t o[2];
+    MH_TRY(read_back(c, o, d, 8));
+    *out1 = ord2f(o[0]);
+    *out2 = ord2f(o[1]);
     return 0;
 }
 
@@ -1210,6 +1213,12 @@ int device_fmax(molar_hip_ctx *c, const float *d_v, uint32_t n, float *out) {
 int enqueue_plan_slots(molar_hip_ctx *c) {
     const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
     const unsigned pbs = c->on_side ? 64u : 256u;          // one-wave workgroups on the side stream (place_order_kernel)
+    if (c->ntasks + 1 > (1ull << 18)) {
+        // sparse giant plans (a vdW search of 1M atoms: 4e6 entries): the single-pass scan's chain of tiles - each waits for the
+        // one before it - took 0.3 ms there; three launches of the tile scan do not chain (in place: a thread reads its items first)
+        MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), c->ntasks + 1)));
+        if (fast_kind) MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, c->task_mu.as<uint32_t>(), c->task_moff.as<unsigned long long>(), c->ntasks + 1)));
+    } else
     MH_TRY((scan_lookback<uint32_t, uint32_t, uint32_t, unsigned long long>(
         c, c->task_nb.as<uint32_t>(), c->task_nb.as<uint32_t>(), fast_kind ? c->task_mu.as<uint32_t>() : nullptr,
         c->task_moff.as<unsigned long long>(), c->ntasks + 1, c->scan_state.as<unsigned long long>())));
@@ -1282,8 +1291,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
             return 0;
         }
         float m1, m2;
-        MH_TRY(device_fmax(c, c->set[0].d_vdw, c->set[0].n, &m1));
-        MH_TRY(device_fmax(c, c->set[1].d_vdw, c->set[1].n, &m2));
+        MH_TRY(device_fmax2(c, c->set[0].d_vdw, c->set[0].n, c->set[1].d_vdw, c->set[1].n, &m1, &m2));
         cutoff = (m1 + m2) + F32_EPS;
     }
     if (!(cutoff > 0.0f)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: cutoff must be positive (got %g)", (double)cutoff);
