@@ -421,6 +421,13 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
         ncell = max(int(gd[0]) * int(gd[1]) * int(gd[2]), 1)
         cand = 13.5 * n * (n / ncell)
         valu_peak = 157.3
+        # what the kernels really evaluate: the lean kernel skips the (row, 64-atom chunk) steps its bounding boxes rule out.
+        # Counted by a debug build in a separate run (tools/hist_wave_times.py -> profiles/hist_steps.json), like roofline.traffic.
+        executed = None
+        try:
+            executed = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hist_steps.json")))["executed_candidate_evaluations"]
+        except Exception:
+            pass
         print(json.dumps({
             "metric": "frames/sec, 250k-atom frames -> fused 1200-bin radial distance histogram, bins reduced over ranks",
             "value": K * world / t, "unit": "frames/s", "pairs_binned_per_sec": pairs / t,
@@ -437,6 +444,9 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
                                  "candidate evaluations x 9 flop against the fp32 vector peak",
                          "achieved": cand * 9 / (hist_ms / max(hist_n, 1) * 1e-3) / 1e12, "peak": valu_peak, "unit": "TFLOP/s",
                          "frac": cand * 9 / (hist_ms / max(hist_n, 1) * 1e-3) / 1e12 / valu_peak, "traffic": None,
+                         "frac_on_executed_evaluations": (executed * 9 / (hist_ms / max(hist_n, 1) * 1e-3) / 1e12 / valu_peak) if executed else None,
+                         "executed_candidate_evals_per_frame": executed,
+                         "executed_source": "profiles/hist_steps.json: steps counted by a -DMOLAR_HIP_DEBUG_KNOBS build on this workload's frame (separate run)",
                          "avg_launch_ms": hist_ms / max(hist_n, 1), "grid_dims": [int(x) for x in gd],
                          "candidate_evals_per_frame": cand, "candidate_evals_per_sec": cand * K * world / t},
             "reduced_bins_equal_single_rank": check,

@@ -72,6 +72,7 @@ struct HistState {
     uint32_t nbins;
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     mutable unsigned long long t_mark;     // s_memrealtime at the start of the slot's row loop (per-wave time accounting, tools/hist_wave_times.py)
+    mutable unsigned long long steps;      // (row, 64-atom chunk) steps evaluated by this wave
 #endif
 };
 
@@ -200,6 +201,9 @@ __device__ __forceinline__ uint32_t hist_run_plain(const SearchParams &P, const 
                 }
             }
             if (!((livek[k] >> r) & 1ull)) continue;                              // wave-uniform: scalar branch
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+            H.steps += 1ull;
+#endif
             const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1
             const float d2 = (dx * dx + dy * dy) + dz * dz;                      // |p2-p1|^2 (:446, :460)
             bool hit = d2 <= cutoff2;
@@ -283,6 +287,9 @@ __device__ __forceinline__ uint32_t hist_run_wrapped(const SearchParams &P, cons
                 }
             }
             if (!((livek[k] >> r) & 1ull)) continue;
+#ifdef MOLAR_HIP_DEBUG_KNOBS
+            H.steps += 1ull;
+#endif
             const float dx = bx[k] - px, dy = by[k] - py, dz = bz[k] - pz;
             const float d2 = (dx * dx + dy * dy) + dz * dz;
             // below the band a hit for sure, above it a miss for sure; candidates inside the band are queued like hits and the
@@ -342,6 +349,7 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
 #ifdef MOLAR_HIP_DEBUG_KNOBS
     // per-wave time accounting (100 MHz s_memrealtime): start, end, time in front of / inside the row loops, slots by class
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+    H.steps = 0ull;
     unsigned long long dbg_pre = 0, dbg_rows = 0, dbg_wr = 0, dbg_max = 0, dbg_last = 0, dbg_maxinfo = 0, dbg_maxpre = 0, dbg_maxtk = 0, dbg_maxstart = 0, dbg_first = 0, dbg_t5 = 0, dbg_t6 = 0, dbg_p5 = 0, dbg_p6 = 0;
     uint32_t dbg_n[3] = {0u, 0u, 0u};
 #endif
@@ -479,7 +487,7 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         o[2] = dbg_pre;
         o[3] = dbg_rows;
         o[4] = dbg_wr;
-        o[7] = __builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 31 << 11);      // HW_REG_XCC_ID
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 31 << 11) | (H.steps << 8);      // HW_REG_XCC_ID | steps
     }
 #endif
     __syncthreads();

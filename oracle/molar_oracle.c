@@ -537,6 +537,48 @@ static void cell_pair_two(const sctx *s, size_t cA, size_t cB, uint8_t wrap, pve
         }
 }
 
+/* Allocator caches.  The reference's per-task Vecs and its collected result come out of an allocator that keeps what it
+ * has handed out before (rayon workers' thread-local caches; a freed 4 GB block stays mapped): a second frame of a trajectory
+ * does not fault its 7 GB of pages in again.  Plain malloc / free of blocks this size returns them to the kernel every time,
+ * and with 256 threads faulting pages in at once the baseline measured the page-fault path, not the search.  So the arenas
+ * (one per thread) and ONE set of result buffers are kept between calls and grow only; orc_pairs_free hands the result
+ * buffers back to the cache.  Not thread-safe across concurrent searches (the tests and the benchmark run one at a time). */
+static pvec *g_arena = NULL;
+static int g_arena_n = 0;
+static pvec *arena_pool(int nt) {
+    if (nt > g_arena_n) {
+        g_arena = (pvec *)realloc(g_arena, (size_t)nt * sizeof(pvec));
+        memset(g_arena + g_arena_n, 0, (size_t)(nt - g_arena_n) * sizeof(pvec));
+        g_arena_n = nt;
+    }
+    return g_arena;
+}
+static void arena_want_jd(pvec *v) {          /* an arena last used by a `within` search has no j / d planes yet */
+    if (v->with_jd && v->cap && !v->j) {
+        v->j = (uint64_t *)malloc(v->cap * sizeof(uint64_t));
+        v->d = (REAL *)malloc(v->cap * sizeof(REAL));
+    }
+}
+static struct { uint64_t *i, *j; REAL *d; size_t cap_i, cap_jd; int busy; } g_res;
+static void result_buffers(orc_pairs *out, size_t tot, int with_jd) {
+    const size_t want = tot ? tot : 1;
+    if (g_res.busy) {                       /* a result is still out: plain allocation for this one */
+        out->i = (uint64_t *)malloc(want * sizeof(uint64_t));
+        if (with_jd) { out->j = (uint64_t *)malloc(want * sizeof(uint64_t)); out->d = (REAL *)malloc(want * sizeof(REAL)); }
+        return;
+    }
+    if (g_res.cap_i < want) { free(g_res.i); g_res.i = (uint64_t *)malloc(want * sizeof(uint64_t)); g_res.cap_i = want; }
+    if (with_jd && g_res.cap_jd < want) {
+        free(g_res.j); free(g_res.d);
+        g_res.j = (uint64_t *)malloc(want * sizeof(uint64_t));
+        g_res.d = (REAL *)malloc(want * sizeof(REAL));
+        g_res.cap_jd = want;
+    }
+    out->i = g_res.i;
+    if (with_jd) { out->j = g_res.j; out->d = g_res.d; }
+    g_res.busy = 1;
+}
+
 /* driver tail: plan.into_par_iter().with_min_len(3).map(..).flatten().collect()
  * (distance_search.rs:542-557, 949-953): ordered concatenation of per-entry results.
  *
@@ -576,9 +618,9 @@ static orc_pairs *run_plan(const sctx *s, const plan_item *plan, size_t np, int 
 #else
     nt = 1;
 #endif
-    pvec *arena = (pvec *)calloc((size_t)nt, sizeof(pvec));
+    pvec *arena = arena_pool(nt);
     part_ref *ref = (part_ref *)calloc(np ? np : 1, sizeof(part_ref));
-    for (int t = 0; t < nt; ++t) arena[t].with_jd = with_jd;
+    for (int t = 0; t < nt; ++t) { arena[t].with_jd = with_jd; arena[t].n = 0; arena_want_jd(&arena[t]); }
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 3) num_threads(nt) if (nt > 1)
 #endif
@@ -605,11 +647,7 @@ static orc_pairs *run_plan(const sctx *s, const plan_item *plan, size_t np, int 
     for (size_t e = 0; e < np; ++e) off[e + 1] = off[e] + ref[e].n;
     size_t tot = off[np];
     out->n = tot;
-    out->i = (uint64_t *)malloc((tot ? tot : 1) * sizeof(uint64_t));
-    if (with_jd) {
-        out->j = (uint64_t *)malloc((tot ? tot : 1) * sizeof(uint64_t));
-        out->d = (REAL *)malloc((tot ? tot : 1) * sizeof(REAL));
-    }
+    result_buffers(out, tot, with_jd);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(nt) if (nt > 1)
 #endif
@@ -624,8 +662,6 @@ static orc_pairs *run_plan(const sctx *s, const plan_item *plan, size_t np, int 
             }
         }
     }
-    for (int t = 0; t < nt; ++t) { free(arena[t].i); free(arena[t].j); free(arena[t].d); }
-    free(arena);
     free(ref);
     free(off);
     out->plan_len = np;
@@ -635,7 +671,11 @@ static orc_pairs *run_plan(const sctx *s, const plan_item *plan, size_t np, int 
 
 void orc_pairs_free(orc_pairs *p) {
     if (!p) return;
-    free(p->i); free(p->j); free(p->d);
+    if (p->i == g_res.i && p->i) {          /* the cached buffers go back to the cache */
+        g_res.busy = 0;
+    } else {
+        free(p->i); free(p->j); free(p->d);
+    }
     free(p);
 }
 

@@ -75,6 +75,8 @@ first = b[:, 14] * 0.01
 out["first_slot_us"] = {"p50": round(float(np.percentile(first, 50)), 1), "p90": round(float(np.percentile(first, 90)), 1), "max": round(float(first.max()), 1)}
 st = (b[:, 13].astype(np.int64) - start) * 0.01
 out["longest_slot_start_us"] = {"p10": round(float(np.percentile(st, 10)), 1), "p50": round(float(np.percentile(st, 50)), 1), "p90": round(float(np.percentile(st, 90)), 1)}
+out["executed_steps"] = int((b[:, 7] >> 8).sum())          # (row, 64-atom chunk) steps the lean kernel evaluated in this launch
+out["executed_candidate_evaluations"] = out["executed_steps"] * 64
 xcc = (b[:, 7] & 0xF).astype(np.int64)
 out["end_by_xcc_us"] = {int(x): round(float(((t1[xcc == x]).max() - start) * 0.01), 1) for x in np.unique(xcc)}
 # per workgroup (16 consecutive waves): the last wave's end
