@@ -639,6 +639,7 @@ def main():
     ap.add_argument("--decode-threads", type=int, default=0, help="--source xtc --decoder host: decoder threads per rank (0 = host cores / ranks)")
     ap.add_argument("--xtc-window", type=int, default=0, help="--source xtc: frames per decode window (0 = 16 for the host decoder, 1024 for the device decoder)")
     ap.add_argument("--xtc-path", default="", help="--source xtc: where rank 0 writes the synthetic trajectory (default: a file under $TMPDIR or /tmp)")
+    ap.add_argument("--no-pairs-only", action="store_true", help="search_fit: skip the extra leg that times the resident search with the (i, j) plane only")
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 recomputes all ranks' frames alone and compares (rdf: the reduced bins; search_fit: every "
                          "frame's pair count and RMSD); a mismatch exits with status 1")
@@ -798,9 +799,13 @@ def main():
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
         w = torch.arange(cnt, device=device, dtype=torch.int64) * 2 + 1
         pv = torch.as_tensor(_Dev(pp, cnt, "<i8"), device=device)
-        dv = torch.as_tensor(_Dev(dp, cnt, "<i4"), device=device).to(torch.int64)
-        a, b = int((pv * w).sum().item()), int((dv * w).sum().item())
-        del w, pv, dv
+        a = int((pv * w).sum().item())
+        b = 0
+        if dp:                 # (the pairs-only mode has no distance plane)
+            dv = torch.as_tensor(_Dev(dp, cnt, "<i4"), device=device).to(torch.int64)
+            b = int((dv * w).sum().item())
+            del dv
+        del w, pv
         return a, b
 
     def run_steps(first, count):
@@ -929,12 +934,50 @@ def main():
         e.profile_enable(False)
         prof = p1 if prof is None else {k: (prof[k][0] + p1[k][0], prof[k][1] + p1[k][1]) for k in prof}
 
+    # ---- a measured MODE, never `value`: the same steps with the resident searches filling the (i, j) plane only - the output
+    # form of the reference's (usize, usize) consumers (distance_search.rs:14-20; SearchConnectivity, the membrane's patches):
+    # 8 instead of 12 bytes per result and no square roots.  Checked: every frame's pair count against the timed run's, the
+    # pair plane of the last frame by checksum against the full mode's.
+    pairs_only = None
+    if overlap and pipelined and K >= 2 * S and not args.no_pairs_only:
+        for e in engines:
+            e.search_resident_planes(False)
+        K2 = min(K, 100)
+        run_steps(0, min(W, 5))
+        barrier()
+        t2 = time.perf_counter()
+        c2, _ = run_steps(W, K2)
+        barrier()
+        dt2 = time.perf_counter() - t2
+        ok_counts = c2 == counts[:K2]
+        ok_plane = None
+        if len(last_results) >= 1:
+            fno, cnt, pp, dp = last_results[-1]
+            mine = checksum_planes(cnt, pp, None)[0]
+            e4 = api.Engine(local_rank)
+            fr = frames[fno % nres].clone()
+            torch.cuda.synchronize()
+            c4, p4, d4 = e4.search_resident(api.SEARCH_SINGLE, CUTOFF, fr, box=box, pbc=7)
+            ok_plane = bool(cnt == c4 and mine == checksum_planes(c4, p4, None)[0] and dp is None)
+            del e4
+        for e in engines:
+            e.search_resident_planes(True)
+        pairs_only = (K2, dt2, bool(ok_counts), ok_plane)
+
     # end-of-run reductions (RCCL when world > 1): integer pair count, max-over-ranks wall time
     from molar_amd.distributed import max_over_ranks, reduce_counts
     from molar_amd.distributed import gather_float64
     total_pairs = float(reduce_counts([pairs], device=cdev)[0])
     t = max_over_ranks(elapsed, device=cdev)
     per_rank_s = [float(v[0]) for v in gather_float64([elapsed], device=cdev)]        # a straggling rank shows up here
+    pairs_only_line = None
+    if pairs_only is not None:
+        t_po = max_over_ranks(pairs_only[1], device=cdev)
+        ok_po = int(reduce_counts([0 if (pairs_only[2] and pairs_only[3] is not False) else 1], device=cdev)[0]) == 0
+        pairs_only_line = {"value": pairs_only[0] * world / t_po, "unit": "frames/s", "steps": pairs_only[0], "ms_per_step": t_po / pairs_only[0] * 1e3,
+                           "bytes_per_result": 8, "pair_counts_and_pair_plane_equal_full_mode": ok_po,
+                           "note": "measured mode, not the headline: molar_hip_search_resident_planes(ctx, 0) - the resident searches fill the (i, j) plane "
+                                   "only (the reference's (usize, usize) output form, distance_search.rs:14-20), same frames, same pipeline"}
     checks = reduce_counts([0 if self_check is None else 1, 1 if self_check is False else 0], device=cdev)
     self_check_all = None if int(checks[0]) == 0 else (int(checks[1]) == 0)
     verified = None
@@ -1006,6 +1049,7 @@ def main():
             },
             "preheat_ms": preheat_ms,
             "per_rank_fps": [K / v for v in per_rank_s],
+            "pairs_only": pairs_only_line,
             "verified_against_single_context": self_check_all if verified is None else (verified and self_check_all is not False),
             "verification": ("last two timed frames of every rank recomputed on a fresh single context after the timed region: "
                              "pair counts, order-sensitive 64-bit checksums of the pair and distance planes in HBM, RMSD (1e-6 rel)"

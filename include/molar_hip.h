@@ -219,6 +219,11 @@ int molar_hip_search_fill_device(molar_hip_ctx *ctx, const uint32_t **d_pairs, c
  * variants.  The result is complete in device memory when the call returns.  Not for WITHIN (ids, not pairs). */
 int molar_hip_search_resident(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_count,
                               const uint32_t **d_pairs, const float **d_dist);
+/* Which planes the resident searches (molar_hip_search_resident, _begin / _end) fill: want_dist = 0 selects the
+ * DistanceSearchOutput of (usize, usize) (distance_search.rs:14-20) - (i, j) only, 8 bytes per result, no square roots - for
+ * consumers that never read the distances (SearchConnectivity, patches); the d_dist pointers then come back NULL.  Not while
+ * pipelined searches are in flight.  Default: both planes. */
+int molar_hip_search_resident_planes(molar_hip_ctx *ctx, int want_dist);
 /* The same search split in two so that a per-frame loop never leaves the GPU idle: _begin enqueues everything for
  * one frame and returns at once with a ticket (0 or 1); _end waits for that frame only and returns its result.
  * Two searches may be in flight, each with its own result set, so the loop is

@@ -272,6 +272,11 @@ class Engine:
         check(self.lib.molar_hip_search_resident(self.ctx, C.byref(desc), C.byref(cnt), C.byref(p), C.byref(dd)))
         return int(cnt.value), p.value, dd.value
 
+    def search_resident_planes(self, want_dist=True):
+        """molar_hip_search_resident_planes: want_dist=False makes the resident searches fill the (i, j) plane only
+        (DistanceSearchOutput of (usize, usize)); the distance addresses they return are then None."""
+        check(self.lib.molar_hip_search_resident_planes(self.ctx, 1 if want_dist else 0))
+
     def search_resident_begin(self, desc):
         """Enqueue a whole resident search and return its ticket without waiting (molar_hip_search_resident_begin).
         `desc` (and what it points to) must stay alive and unchanged until search_resident_end(ticket)."""

@@ -190,6 +190,7 @@ struct molar_hip_ctx {
         molar_hip_search_desc desc{};
     } tickets[2];
     int next_ticket = 0;
+    bool resident_no_dist = false;          // molar_hip_search_resident_planes: the resident searches fill the (i, j) plane only
     unsigned long long search_serial = 0;   // counts resident searches enqueued on this context
     void *h_sizes = nullptr;                // pinned: 16 bytes of result sizes per ticket
     mh::DevBuf out_ids;

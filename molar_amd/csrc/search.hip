@@ -1545,22 +1545,28 @@ __global__ void __launch_bounds__(256) within_partners_kernel(const SearchParams
 // dims for wrapped entries).  A row that finds a partner sets its flag byte with an atomic OR on the containing word; the
 // lane that turned it on appends the id to a list - the result, unsorted, with its length in memory.  No partner lists over
 // all cells, no pass over the whole plan, no flag scan: two launches and one read-back for `within 0.8 of <20 atoms>`.
-__global__ void __launch_bounds__(64) within_small_kernel(const SearchParams *__restrict__ Pp, uint32_t n2, uint32_t ncells,
+__global__ void __launch_bounds__(64) within_small_kernel(const SearchParams *__restrict__ Pp, uint32_t n2, uint32_t ncells, uint32_t by_cell,
                                                           uint32_t *__restrict__ flags32, uint32_t *__restrict__ list,
                                                           uint32_t *__restrict__ list_n) {
     const SearchParams &P = *Pp;
     const uint32_t lane = threadIdx.x;
     const uint32_t j = blockIdx.x / 28u, combo = blockIdx.x % 28u;
-    if (j >= n2) return;
-    // the cell of sorted second-set atom j: the last cell whose start is <= j (binary search over cell_start)
-    uint32_t lo = 0u, hi = ncells;
-    while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (P.csb[mid] <= j) lo = mid;
-        else hi = mid;
+    uint32_t cell;
+    if (by_cell) {                  // fewer cells than second-set atoms (large cutoffs): one wave per (cell, combination)
+        cell = j;
+        if (cell >= ncells || P.csb[cell + 1] == P.csb[cell]) return;
+    } else {
+        if (j >= n2) return;
+        // the cell of sorted second-set atom j: the last cell whose start is <= j (binary search over cell_start)
+        uint32_t lo = 0u, hi = ncells;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (P.csb[mid] <= j) lo = mid;
+            else hi = mid;
+        }
+        cell = lo;
+        if (P.csb[cell] != j) return;                               // not the first atom of its cell
     }
-    const uint32_t cell = lo;
-    if (P.csb[cell] != j) return;                                   // not the first atom of its cell
     const uint32_t m = combo >> 1, half = combo & 1u;
     const uint32_t cz = cell / (P.dx * P.dy), cy = (cell / P.dx) % P.dy, cx = cell % P.dx;
     const uint32_t cc[3] = {cx, cy, cz}, dims[3] = {P.dx, P.dy, P.dz};
@@ -1829,7 +1835,7 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
         Prof prof(c, 2);
         MH_TRY(scan_slot_counts(c, (unsigned long long *)sizes_dev));
     }
-    if (cap0) MH_TRY(launch_pairs<true>(c, outP.as<uint2>(), outD.as<float>(), nullptr, 0, 0.f, 0.f, nullptr, cap0,
+    if (cap0) MH_TRY(launch_pairs<true>(c, outP.as<uint2>(), c->resident_no_dist ? nullptr : outD.as<float>(), nullptr, 0, 0.f, 0.f, nullptr, cap0,
                                         /*params_resident=*/true));
     if (!sizes_dev) {
         MH_HIP(hipMemcpyAsync(sizes, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1862,7 +1868,7 @@ static int resident_settle(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD,
         refill = true;
     }
     if (refill && c->total) {
-        MH_TRY(launch_pairs<true>(c, outP.as<uint2>(), outD.as<float>(), nullptr));
+        MH_TRY(launch_pairs<true>(c, outP.as<uint2>(), c->resident_no_dist ? nullptr : outD.as<float>(), nullptr));
         MH_HIP(hipStreamSynchronize(c->stream));   // like the common case, the result is complete when the call returns
     }
     return 0;
@@ -1918,7 +1924,18 @@ int molar_hip_search_resident(molar_hip_ctx *c, const molar_hip_search_desc *q, 
     MH_TRY(resident_run(c, q, c->out_pairs, c->out_dist));
     if (out_count) *out_count = c->total;
     if (d_pairs) *d_pairs = c->out_pairs.as<uint32_t>();
-    if (d_dist) *d_dist = c->out_dist.as<float>();
+    if (d_dist) *d_dist = c->resident_no_dist ? nullptr : c->out_dist.as<float>();
+    return MOLAR_HIP_OK;
+}
+
+// DistanceSearchOutput for (usize, usize) (distance_search.rs:14-20): consumers of the pair list that never look at the
+// distances - SearchConnectivity, the membrane's patches - ask for the (i, j) plane only.  The fill pass then takes no square
+// roots and writes 8 instead of 12 bytes per result; the distance pointers of the resident calls come back NULL.
+int molar_hip_search_resident_planes(molar_hip_ctx *c, int want_dist) {
+    if (!c) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "null context");
+    if (c->tickets[0].pending || c->tickets[1].pending)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "resident_planes: pipelined searches are in flight");
+    c->resident_no_dist = !want_dist;
     return MOLAR_HIP_OK;
 }
 
@@ -2007,7 +2024,7 @@ int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *ou
     }
     if (out_count) *out_count = total;
     if (d_pairs) *d_pairs = outP.as<uint32_t>();
-    if (d_dist) *d_dist = outD.as<float>();
+    if (d_dist) *d_dist = c->resident_no_dist ? nullptr : outD.as<float>();
     return MOLAR_HIP_OK;
 }
 
@@ -2214,7 +2231,8 @@ int molar_hip_within_count(molar_hip_ctx *c, const molar_hip_search_desc *q, uin
         // cells of many 64-row blocks (large cutoffs) get several waves per (cell, combination)
         uint32_t wsplit = (uint32_t)(((uint64_t)c->set[0].n / 64u) / ncells) + 1u;
         if (wsplit > 64u) wsplit = 64u;
-        hipLaunchKernelGGL(within_small_kernel, dim3(c->set[1].n * 28u, wsplit), dim3(64), 0, c->stream, c->params.as<SearchParams>(), c->set[1].n, ncells,
+        const uint32_t by_cell = ncells < c->set[1].n ? 1u : 0u;
+        hipLaunchKernelGGL(within_small_kernel, dim3((by_cell ? ncells : c->set[1].n) * 28u, wsplit), dim3(64), 0, c->stream, c->params.as<SearchParams>(), c->set[1].n, ncells, by_cell,
                            c->w_flags.as<uint32_t>(), c->w_list.as<uint32_t>() + 1, c->w_list.as<uint32_t>());
         MH_HIP(hipGetLastError());
         uint32_t tot = 0;

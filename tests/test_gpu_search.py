@@ -1030,3 +1030,50 @@ def test_search_connectivity_csr_in_push_order(eng, orc32, boxfn, n, cutoff, loc
     want_off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.uint64)
     assert np.array_equal(off, want_off)
     assert np.array_equal(nb, np.fromiter((v for l in lists for v in l), np.uint64, count=len(nb)))
+
+
+def test_resident_search_pairs_plane_only(eng, orc32):
+    """molar_hip_search_resident_planes(ctx, 0): the DistanceSearchOutput of (usize, usize) (distance_search.rs:14-20) - the
+    resident searches (plain and begin / end) fill the (i, j) plane only; it must be the full mode's pair plane bit for bit,
+    the distance address comes back NULL, and switching back restores the distances."""
+    import torch
+    a = api()
+    n = 40000
+    box = synth.box_a(n)
+    pos = torch.from_numpy(synth.frame(n, box)).cuda()
+    pos2 = torch.from_numpy(synth.frame(n, box, 1)).cuda()
+    torch.cuda.synchronize()
+    e2 = a.Engine(0)
+    ref = orc32.search_single_pbc(0.9, pos.cpu().numpy(), orc32.box_from_matrix(box), 7, nthreads=8)
+
+    def planes(cnt, pp, dp):
+        class _Dev:
+            def __init__(self, ptr, m, t):
+                self.__cuda_array_interface__ = {"shape": (m,), "typestr": t, "data": (ptr, False), "version": 2}
+        pr = torch.as_tensor(_Dev(pp, 2 * cnt, "<u4"), device="cuda").cpu().numpy().reshape(-1, 2)
+        d = torch.as_tensor(_Dev(dp, cnt, "<f4"), device="cuda").cpu().numpy() if dp else None
+        return pr, d
+
+    e2.search_resident_planes(False)
+    cnt, pp, dp = e2.search_resident(a.SEARCH_SINGLE, 0.9, pos, box=box, pbc=7)
+    assert cnt == len(ref["i"]) and dp is None
+    pr, _ = planes(cnt, pp, None)
+    assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"])
+    # two frames in flight
+    d1 = e2.make_search_desc(a.SEARCH_SINGLE, 0.9, pos, box=box, pbc=7)
+    d2 = e2.make_search_desc(a.SEARCH_SINGLE, 0.9, pos2, box=box, pbc=7)
+    t1 = e2.search_resident_begin(d1[0])
+    t2 = e2.search_resident_begin(d2[0])
+    with pytest.raises(Exception):
+        e2.search_resident_planes(True)            # not while searches are in flight
+    c1, p1, q1 = e2.search_resident_end(t1)
+    c2, p2, q2 = e2.search_resident_end(t2)
+    assert q1 is None and q2 is None and c1 == cnt
+    assert np.array_equal(planes(c1, p1, None)[0], pr)
+    ref2 = orc32.search_single_pbc(0.9, pos2.cpu().numpy(), orc32.box_from_matrix(box), 7, nthreads=8)
+    pr2, _ = planes(c2, p2, None)
+    assert c2 == len(ref2["i"]) and np.array_equal(pr2[:, 0], ref2["i"]) and np.array_equal(pr2[:, 1], ref2["j"])
+    e2.search_resident_planes(True)
+    cnt3, pp3, dp3 = e2.search_resident(a.SEARCH_SINGLE, 0.9, pos, box=box, pbc=7)
+    pr3, d3 = planes(cnt3, pp3, dp3)
+    assert np.array_equal(pr3, pr) and np.array_equal(d3, ref["d"])

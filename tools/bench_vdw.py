@@ -55,6 +55,17 @@ def main():
             pairs, d = eng.search_fill(k)
             return pairs, d
         t_gpu, (pairs, d) = timeit(gpu, 5)
+        # the same call with the selections and radii already in HBM (a plugin that keeps a topology's columns resident): what is
+        # left when 11 MB of index and radius arrays do not cross the link from pageable memory on every call
+        dsolv, dsolu = torch.from_numpy(solvent.astype(np.int64)).cuda(), torch.from_numpy(solute.astype(np.int64)).cuda()
+        dv1, dv2 = torch.from_numpy(v1).cuda(), torch.from_numpy(v2).cuda()
+        torch.cuda.synchronize()
+
+        def gpu_dev():
+            k = eng.search_count(api.SEARCH_DOUBLE_VDW, None, dpos, dsolv, dpos, dsolu, box=box, pbc=7, vdw1=dv1, vdw2=dv2)
+            return eng.search_fill(k)
+        t_gpu_dev, (pairs2, d2) = timeit(gpu_dev, 5)
+        assert np.array_equal(pairs, pairs2) and np.array_equal(d, d2)
         ob = orc.box_from_matrix(box)
         p1, p2 = pos[solvent.astype(np.int64)], pos[solute.astype(np.int64)]
         t_cpu, ref, info = cpu_best(lambda nt: orc.search_double_vdw_pbc(p1, p2, v1, v2, ob, 7, nthreads=nt), 2)
@@ -63,7 +74,7 @@ def main():
             np.array_equal(ref["j"], pairs[:, 1].astype(np.uint64)) and np.array_equal(ref["d"], d)
         print(json.dumps({"workload": f"vdW overlap search, {len(solvent)} solvent atoms against a compact {nsolute}-atom solute, full PBC",
                           "natoms": n, "cutoff_nm": float(v1.max() + v2.max()), "grid_dims": eng.grid_dims(), "overlaps": int(len(pairs)),
-                          "ms_gpu_count_fill_to_host": t_gpu * 1e3, "ms_cpu_restatement": t_cpu * 1e3, **info,
+                          "ms_gpu_count_fill_to_host": t_gpu * 1e3, "ms_gpu_selections_resident": t_gpu_dev * 1e3, "ms_cpu_restatement": t_cpu * 1e3, **info,
                           "speedup": t_cpu / t_gpu, "identical_to_cpu": bool(same)}), flush=True)
 
 
