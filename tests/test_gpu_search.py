@@ -1077,3 +1077,72 @@ def test_resident_search_pairs_plane_only(eng, orc32):
     cnt3, pp3, dp3 = e2.search_resident(a.SEARCH_SINGLE, 0.9, pos, box=box, pbc=7)
     pr3, d3 = planes(cnt3, pp3, dp3)
     assert np.array_equal(pr3, pr) and np.array_equal(d3, ref["d"])
+
+
+def test_fill_rejects_misaligned_device_outputs(eng):
+    """The fill pass writes two results per lane and store instruction (dwordx4 / dwordx2 relative to the output bases):
+    include/molar_hip.h asks for 16-byte (pairs) / 8-byte (distances) alignment of caller-owned DEVICE outputs, and a view
+    that breaks it is refused with MOLAR_HIP_ERR_INVALID_ARGUMENT instead of being written with misaligned stores."""
+    import ctypes as C
+    import torch
+    from molar_amd._lib import MolarHipError
+    a = api()
+    n = 20000
+    box = synth.box_a(n)
+    pos = synth.frame(n, box)
+    cnt = eng.search_count(a.SEARCH_SINGLE, 0.6, pos, box=box, pbc=7)
+    assert cnt > 0
+    pbuf = torch.zeros(2 * cnt + 8, dtype=torch.int32, device="cuda")
+    dbuf = torch.zeros(cnt + 8, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    with pytest.raises(MolarHipError):          # pairs 8 bytes past a 16-byte boundary
+        a.check(eng.lib.molar_hip_search_fill(eng.ctx, C.c_void_p(pbuf.data_ptr() + 8), C.c_void_p(dbuf.data_ptr())))
+    with pytest.raises(MolarHipError):          # distances 4 bytes past an 8-byte boundary
+        a.check(eng.lib.molar_hip_search_fill(eng.ctx, C.c_void_p(pbuf.data_ptr()), C.c_void_p(dbuf.data_ptr() + 4)))
+    a.check(eng.lib.molar_hip_search_fill(eng.ctx, C.c_void_p(pbuf.data_ptr()), C.c_void_p(dbuf.data_ptr())))
+    pr, d = eng.search_fill(cnt)
+    torch.cuda.synchronize()
+    assert np.array_equal(pbuf[:2 * cnt].cpu().numpy().view(np.uint32).reshape(-1, 2), pr) and np.array_equal(dbuf[:cnt].cpu().numpy(), d)
+
+
+def test_fused_histogram_call_forms_interleaved(eng, orc32):
+    """The one-kernel plan of the fused histogram alternates between two pairs of list counters from frame to frame (the
+    kernel of frame k zeroes the pair frame k + 1 will use).  Queued calls with device bins, waited calls with host bins, a
+    vdW histogram (regular plan, no lists) and systems of different size in between must all leave the counters right:
+    every call's bins equal the oracle's."""
+    import torch
+    a = api()
+    e2 = a.Engine(0)
+    rng = np.random.default_rng(77)
+    systems = []
+    for n, cutoff in ((3000, 0.7), (40000, 0.9), (200, 0.5), (12000, 1.1)):
+        box = synth.box_a(n)
+        pos = synth.frame(n, box, n % 5)
+        ref = orc32.search_single_pbc(cutoff, pos, orc32.box_from_matrix(box), 7, nthreads=8)
+        systems.append((n, cutoff, box, pos, torch.from_numpy(pos).cuda(), orc32.histogram_add(0.0, cutoff, 300, ref["d"]).astype(np.int64)))
+    torch.cuda.synchronize()
+    dev_bins = [torch.zeros(300, dtype=torch.int64, device="cuda") for _ in systems]
+    times = [0] * len(systems)
+    torch.cuda.synchronize()
+    order = [0, 1, 1, 2, 0, 3, 3, 3, 1, 2, 2, 0, 1, 3, 0]
+    for step, k in enumerate(order):
+        n, cutoff, box, pos, dpos, want = systems[k]
+        if step % 4 == 3:          # a waited call with host bins in between the queued ones
+            bins, cnt = e2.search_histogram(a.SEARCH_SINGLE, cutoff, 0.0, cutoff, 300, pos, box=box, pbc=7)
+            assert np.array_equal(bins.astype(np.int64), want) and cnt >= want.sum()
+        else:
+            e2.search_histogram(a.SEARCH_SINGLE, cutoff, 0.0, cutoff, 300, dpos, box=box, pbc=7, bins=dev_bins[k], want_count=False)
+            times[k] += 1
+        if step == 6:              # a histogram of another kind: the regular plan, no slot lists
+            m = 2000
+            bx = synth.box_ortho(m)
+            p = synth.frame(m, bx)
+            i1, i2 = np.arange(0, m // 2, dtype=np.uint64), np.arange(m // 2, m, dtype=np.uint64)
+            vd = rng.uniform(0.1, 0.2, m).astype(np.float32)
+            r = orc32.search_double_vdw_pbc(p[i1.astype(int)], p[i2.astype(int)], vd[i1.astype(int)], vd[i2.astype(int)], orc32.box_from_matrix(bx), 7, nthreads=4)
+            hb, hc = e2.search_histogram(a.SEARCH_DOUBLE_VDW, None, 0.0, 0.5, 64, p, i1, p, i2, box=bx, pbc=7, vdw1=vd[i1.astype(int)], vdw2=vd[i2.astype(int)])
+            assert hc == len(r["i"]) and np.array_equal(hb, orc32.histogram_add(0.0, 0.5, 64, r["d"]).astype(np.uint64))
+    e2.synchronize()
+    torch.cuda.synchronize()
+    for k, (n, cutoff, box, pos, dpos, want) in enumerate(systems):
+        assert np.array_equal(dev_bins[k].cpu().numpy(), want * times[k]), (k, times[k])
