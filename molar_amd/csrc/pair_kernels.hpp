@@ -108,6 +108,10 @@ struct SearchParams {
     float cutoff2;
     uint64_t ntasks;
     molar_hip_box box;
+    // box.shifts padded with zero vectors to 32 entries: the candidate loops of the triclinic corner entries read FOUR lattice
+    // shifts per trip (three 16-byte scalar loads, one wait) instead of one dependent scalar load per image; a zero shift gives
+    // the start vector itself, which never beats the running minimum (periodic_box.rs:304-317)
+    alignas(16) float shifts4[96];
 };
 
 // what plan_kernel stores per plan entry and the pair kernels read back with one 32-byte load
@@ -234,7 +238,7 @@ struct BoxRegs {
     int nshift;
 };
 
-template <int WK>
+template <int WK, bool WIDE4 = false>
 __device__ __forceinline__ v2f pair_d2x2(const SearchParams &P, const BoxRegs &B, uint32_t wrap, float px, float py,
                                          float pz, v2f qx, v2f qy, v2f qz) {
     const v2f vx = qx - px, vy = qy - py, vz = qz - pz;
@@ -273,13 +277,31 @@ __device__ __forceinline__ v2f pair_d2x2(const SearchParams &P, const BoxRegs &B
     }
     v2f best2 = (sx * sx + sy * sy) + sz * sz;
     if (WK != WK_DIAG && B.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {
-        for (int k = 0; k < B.nshift; ++k) {
-            const v2f cx = sx + P.box.shifts[3 * k], cy = sy + P.box.shifts[3 * k + 1], cz = sz + P.box.shifts[3 * k + 2];
-            const v2f n2 = (cx * cx + cy * cy) + cz * cz;
-            // `best` itself is only needed through its norm: cand = start + s is always formed from
-            // `start`, not from the running best (:310), so tracking best2 is enough
-            best2.x = n2.x < best2.x ? n2.x : best2.x;
-            best2.y = n2.y < best2.y ? n2.y : best2.y;
+        // (WIDE4: four lattice shifts per trip - three 16-byte scalar loads and one wait instead of a dependent scalar load per image.
+        // Halves the histogram's generic kernel, 27 -> 15 us on the C4 frame; in the count pass the twelve extra scalar registers
+        // cost more than the loads save (0.40 -> 0.43 ms on the headline frame), so count and fill keep one image per trip.)
+        if (WIDE4) {
+            for (int k = 0; k < B.nshift; k += 4) {
+                float sh[12];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) sh[q] = P.shifts4[3 * k + q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v2f cx = sx + sh[3 * q], cy = sy + sh[3 * q + 1], cz = sz + sh[3 * q + 2];
+                    const v2f n2 = (cx * cx + cy * cy) + cz * cz;
+                    best2.x = n2.x < best2.x ? n2.x : best2.x;
+                    best2.y = n2.y < best2.y ? n2.y : best2.y;
+                }
+            }
+        } else {
+            for (int k = 0; k < B.nshift; ++k) {
+                const v2f cx = sx + P.box.shifts[3 * k], cy = sy + P.box.shifts[3 * k + 1], cz = sz + P.box.shifts[3 * k + 2];
+                const v2f n2 = (cx * cx + cy * cy) + cz * cz;
+                // `best` itself is only needed through its norm: cand = start + s is always formed from
+                // `start`, not from the running best (:310), so tracking best2 is enough
+                best2.x = n2.x < best2.x ? n2.x : best2.x;
+                best2.y = n2.y < best2.y ? n2.y : best2.y;
+            }
         }
     }
     return best2;
@@ -310,6 +332,7 @@ struct Fifo {
     uint32_t wrap;
 };
 
+template <bool WIDE4 = false>
 __device__ __forceinline__ float wrapped_d2_exact(const SearchParams &P, uint32_t wrap, float vx, float vy, float vz);
 
 // One queued hit, resolved at flush time: ids and squared distance
@@ -449,7 +472,7 @@ __device__ __forceinline__ void fifo_drain_wide(const SearchParams &P, Fifo &F, 
 // with v_readlane into SGPRs, so the distance arithmetic takes scalar operands and no per-row
 // memory access sits on the critical path.
 // RUNTIME_NCH: the chunk count is checked at run time (triangular tasks, which skip chunks).
-template <int KIND, bool FILL, int WK, bool TRI, int NCH, bool RUNTIME_NCH>
+template <int KIND, bool FILL, int WK, bool TRI, int NCH, bool RUNTIME_NCH, bool WIDE4 = false>
 __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, uint32_t lane) {
     constexpr bool VDW = KIND == MOLAR_HIP_SEARCH_DOUBLE_VDW;
     constexpr bool WITHIN = KIND == MOLAR_HIP_SEARCH_WITHIN;
@@ -537,7 +560,7 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
             // two chunks (c0 = first chunk index) against row i; use0/use1: chunk is live
             auto pair_body = [&](uint32_t c0, bool use0, bool use1, bool rag0, bool rag1, v2f qx, v2f qy, v2f qz, v2f qv,
                                  uint32_t id0, uint32_t id1) {
-                const v2f d2 = pair_d2x2<WK>(P, B, T.wrap, px, py, pz, qx, qy, qz);
+                const v2f d2 = pair_d2x2<WK, WIDE4>(P, B, T.wrap, px, py, pz, qx, qy, qz);
                 bool h0, h1;
                 if (VDW) {
                     const v2f cut = (r1 + qv) + F32_EPS;                   // :392, :423
@@ -619,6 +642,7 @@ __device__ __forceinline__ uint32_t run_task(const SearchParams &P, const Task &
 // The grid stores every atom inside the primary cell along periodic dimensions (populate_pbc wraps
 // them, distance_search.rs:183-196), so |f[d]| < 1.5 for a wrapped dimension and f32::round reduces
 // to "copysign(1, f) if |f| >= 0.5 else 0" - the same value, three instructions instead of six.
+template <bool WIDE4>
 __device__ __forceinline__ float wrapped_d2_exact(const SearchParams &P, uint32_t wrap, float vx, float vy, float vz) {
     const float *I = P.box.inv, *M = P.box.m;
     float fx = (I[0] * vx + I[3] * vy) + I[6] * vz;
@@ -632,10 +656,24 @@ __device__ __forceinline__ float wrapped_d2_exact(const SearchParams &P, uint32_
     const float sz = (M[2] * fx + M[5] * fy) + M[8] * fz;
     float best2 = (sx * sx + sy * sy) + sz * sz;
     if (P.box.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {   // triclinic candidates (:304-317)
-        for (int k = 0; k < P.box.nshift; ++k) {
-            const float cx = sx + P.box.shifts[3 * k], cy = sy + P.box.shifts[3 * k + 1], cz = sz + P.box.shifts[3 * k + 2];
-            const float n2 = (cx * cx + cy * cy) + cz * cz;
-            best2 = n2 < best2 ? n2 : best2;
+        if (WIDE4) {
+            for (int k = 0; k < P.box.nshift; k += 4) {          // four images per trip (SearchParams::shifts4, see pair_d2x2)
+                float sh[12];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) sh[q] = P.shifts4[3 * k + q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float cx = sx + sh[3 * q], cy = sy + sh[3 * q + 1], cz = sz + sh[3 * q + 2];
+                    const float n2 = (cx * cx + cy * cy) + cz * cz;
+                    best2 = n2 < best2 ? n2 : best2;
+                }
+            }
+        } else {
+            for (int k = 0; k < P.box.nshift; ++k) {
+                const float cx = sx + P.box.shifts[3 * k], cy = sy + P.box.shifts[3 * k + 1], cz = sz + P.box.shifts[3 * k + 2];
+                const float n2 = (cx * cx + cy * cy) + cz * cz;
+                best2 = n2 < best2 ? n2 : best2;
+            }
         }
     }
     return best2;
@@ -1277,7 +1315,7 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
             const uint32_t jj = (uint32_t)k * 64u + lane;
             const float dx = bx[k] - p.x, dy = by[k] - p.y, dz = bz[k] - p.z;     // p2 - p1 (image of p2 if WRAPPED)
             float d2 = (dx * dx + dy * dy) + dz * dz;                            // |p2-p1|^2 (:446, :460)
-            if (WRAPPED && !approx) d2 = wrapped_d2_exact(P, T.wrap, dx, dy, dz); // S == 0: dx is the raw difference (:485-486)
+            if (WRAPPED && !approx) d2 = wrapped_d2_exact<FILL && !MASKED>(P, T.wrap, dx, dy, dz); // S == 0: dx is the raw difference (:485-486)
             if (TRI && (uint32_t)k * 64u <= i) d2 = (jj > i) ? d2 : INFINITY;    // diagonal chunk: j in i+1..n (:443)
             if (!FILL) {
                 if (MASKED) {
@@ -1433,11 +1471,11 @@ __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Ta
         }
     }
     if (nchunks > (uint32_t)KREG) {
-        if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) return run_task<KIND, FILL, WK, true, 0, false>(P, T, i0, F, lane);
-        return run_task<KIND, FILL, WK, false, 0, false>(P, T, i0, F, lane);
+        if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) return run_task<KIND, FILL, WK, true, 0, false, FILL && !MASKED>(P, T, i0, F, lane);
+        return run_task<KIND, FILL, WK, false, 0, false, FILL && !MASKED>(P, T, i0, F, lane);
     }
-    if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) return run_task<KIND, FILL, WK, true, KREG, true>(P, T, i0, F, lane);
-    return run_task<KIND, FILL, WK, false, KREG, true>(P, T, i0, F, lane);
+    if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) return run_task<KIND, FILL, WK, true, KREG, true, FILL && !MASKED>(P, T, i0, F, lane);
+    return run_task<KIND, FILL, WK, false, KREG, true, FILL && !MASKED>(P, T, i0, F, lane);
 }
 
 // Slots.  A plan entry ("task") is cut into blocks of 64 rows of its first cell; one wave processes

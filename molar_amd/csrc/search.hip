@@ -936,6 +936,7 @@ SearchParams make_params(molar_hip_ctx *c) {
     P.ntasks = c->ntasks;
     P.nblocks = (uint32_t)c->nslots_bound;      // count / fill: one wave per workgroup (launch_pairs adjusts the histogram mode)
     P.box = c->box;
+    for (int k = 0; k < 96; ++k) P.shifts4[k] = (c->use_box && k < 3 * c->box.nshift) ? c->box.shifts[k] : 0.0f;
     P.hist_nbins = 0u;
     P.hist_min = P.hist_max = 0.f;
     P.hist_bins = nullptr;
@@ -1608,7 +1609,7 @@ __global__ void __launch_bounds__(64) within_small_kernel(const SearchParams *__
                 const float by = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.y), kk));
                 const float bz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.z), kk));
                 const float dx = bx - a.x, dy = by - a.y, dz = bz - a.z;                   // p2 - p1
-                const float d2 = wrapped ? wrapped_d2_exact(P, T.wrap, dx, dy, dz)          // :306-321
+                const float d2 = wrapped ? wrapped_d2_exact<true>(P, T.wrap, dx, dy, dz)    // :306-321
                                          : (dx * dx + dy * dy) + dz * dz;                  // :281-292
                 found = found || (look && d2 <= cutoff2);
                 if ((kk & 7u) == 7u && __builtin_amdgcn_ballot_w64(look && !found) == 0ull) break;      // every row has its partner (:289, :318)
@@ -1669,7 +1670,7 @@ __global__ void __launch_bounds__(64) within_flags_kernel(const SearchParams *__
                     rm &= rm - 1ull;
                     const float4 p = lload4(la, r);                                  // one broadcast ds_read per row
                     const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;      // p2 - p1
-                    const float d2 = wrap ? wrapped_d2_exact(P, wrap, dx, dy, dz)    // :306-321 (distance_squared over the entry's dims)
+                    const float d2 = wrap ? wrapped_d2_exact<true>(P, wrap, dx, dy, dz)    // :306-321 (distance_squared over the entry's dims)
                                           : (dx * dx + dy * dy) + dz * dz;          // :281-292
                     if (__builtin_amdgcn_ballot_w64(inb && d2 <= cutoff2)) {         // `break` at the first hit (:289, :318)
                         live &= ~(1ull << r);
