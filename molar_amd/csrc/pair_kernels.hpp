@@ -278,7 +278,7 @@ __device__ __forceinline__ v2f pair_d2x2(const SearchParams &P, const BoxRegs &B
     v2f best2 = (sx * sx + sy * sy) + sz * sz;
     if (WK != WK_DIAG && B.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL) {
         // (WIDE4: four lattice shifts per trip - three 16-byte scalar loads and one wait instead of a dependent scalar load per image.
-        // Halves the histogram's generic kernel, 27 -> 15 us on the C4 frame; in the count pass the twelve extra scalar registers
+        // Takes the histogram's generic kernel from 27 to 17 us on the C4 frame (hist total 0.288 -> 0.280 ms); in the count pass the twelve extra scalar registers
         // cost more than the loads save (0.40 -> 0.43 ms on the headline frame), so count and fill keep one image per trip.)
         if (WIDE4) {
             for (int k = 0; k < B.nshift; k += 4) {
