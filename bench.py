@@ -808,13 +808,6 @@ def main():
         del w, pv
         return a, b
 
-    def sum_counts(e_, rs):
-        """results in result set `rs` of a context in the segmented layout"""
-        b_, n_, nseg_, _ = e_.search_segments(rs)
-        if not nseg_:
-            return 0
-        return int(api.device_view(n_, (nseg_,), torch.int32).to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
-
     def run_steps(first, count):
         """`count` steps starting at frame `first`, dealt round-robin to the S contexts.  Every context runs its frames
         through the begin / end form (two of ITS frames in flight: the next one is enqueued - grid, plan, count, offsets,
@@ -971,54 +964,6 @@ def main():
             e.search_resident_planes(True)
         pairs_only = (K2, dt2, bool(ok_counts), ok_plane)
 
-    # ---- a second measured MODE, never `value`: the segmented layout of the resident searches
-    # (molar_hip_search_resident_layout(ctx, 1)): every element of the search plan owns a segment of the result planes, the
-    # capacities come from the frame before, and no count pass runs in front of the fill - for consumers that walk the result
-    # cell pair by cell pair on the GPU.  Same frames, same pipeline.  Checked: every frame's pair count against the timed
-    # run's; the last frame's segments, compacted on the device, by checksum of both planes against the dense list of a
-    # fresh context.  With --no-pairs-only neither mode runs.
-    segmented = None
-    if overlap and pipelined and K >= 2 * S and not args.no_pairs_only:
-        seg_runs = {}
-        for label, want_dist in (("full", True), ("pairs_only", False)):
-            for e in engines:
-                e.search_resident_layout(True)
-                e.search_resident_planes(want_dist)
-            K3 = min(K, 100)
-            run_steps(0, min(max(W, 4), 6))      # the first searches of a plan size the planes and run the kernel twice
-            barrier()
-            t3 = time.perf_counter()
-            c3, _ = run_steps(W, K3)
-            barrier()
-            dt3 = time.perf_counter() - t3
-            ok3 = c3 == counts[:K3]
-            ok_planes = None
-            if len(last_results) >= 1:
-                fno, cnt, pp, dp = last_results[-1]
-                k_of = (fno - W) % S                 # the context that ran this frame; its result set: the ticket of its last _end
-                e_ = engines[k_of]
-                sets = [rs for rs in (0, 1) if e_.search_segments(rs)[2]]
-                e4 = api.Engine(local_rank)
-                fr = frames[fno % nres].clone()
-                torch.cuda.synchronize()
-                c4, p4, d4 = e4.search_resident(api.SEARCH_SINGLE, CUTOFF, fr, box=box, pbc=7)
-                theirs = checksum_planes(c4, p4, d4 if want_dist else None)
-                ok_planes = False
-                dense_p = torch.empty((max(cnt, 1), 2), dtype=torch.int32, device=device)
-                dense_d = torch.empty(max(cnt, 1), dtype=torch.float32, device=device) if want_dist else None
-                for rs in sets:                      # one of the context's two result sets holds the last frame
-                    if sum_counts(e_, rs) != cnt:
-                        continue
-                    e_.search_segments_compact(rs, dense_p.data_ptr(), dense_d.data_ptr() if want_dist else None)
-                    if cnt == c4 and checksum_planes(cnt, dense_p.data_ptr(), dense_d.data_ptr() if want_dist else None) == theirs:
-                        ok_planes = True
-                del e4, dense_p, dense_d
-            seg_runs[label] = (K3, dt3, bool(ok3), ok_planes)
-        for e in engines:
-            e.search_resident_layout(False)
-            e.search_resident_planes(True)
-        segmented = seg_runs
-
     # end-of-run reductions (RCCL when world > 1): integer pair count, max-over-ranks wall time
     from molar_amd.distributed import max_over_ranks, reduce_counts
     from molar_amd.distributed import gather_float64
@@ -1033,16 +978,6 @@ def main():
                            "bytes_per_result": 8, "pair_counts_and_pair_plane_equal_full_mode": ok_po,
                            "note": "measured mode, not the headline: molar_hip_search_resident_planes(ctx, 0) - the resident searches fill the (i, j) plane "
                                    "only (the reference's (usize, usize) output form, distance_search.rs:14-20), same frames, same pipeline"}
-    segmented_line = None
-    if segmented is not None:
-        segmented_line = {"note": "measured mode, not the headline: molar_hip_search_resident_layout(ctx, 1) - one segment of the result planes per "
-                                  "element of the search plan (a cell pair), capacities from the frame before, no count pass; same frames, same pipeline",
-                          "unit": "frames/s"}
-        for label, (k3, dt3, okc, okp) in segmented.items():
-            t_sg = max_over_ranks(dt3, device=cdev)
-            ok_sg = int(reduce_counts([0 if (okc and okp is not False) else 1], device=cdev)[0]) == 0
-            segmented_line[label] = {"value": k3 * world / t_sg, "steps": k3, "ms_per_step": t_sg / k3 * 1e3,
-                                     "pair_counts_and_compacted_planes_equal_dense_list": ok_sg}
     checks = reduce_counts([0 if self_check is None else 1, 1 if self_check is False else 0], device=cdev)
     self_check_all = None if int(checks[0]) == 0 else (int(checks[1]) == 0)
     verified = None
@@ -1115,7 +1050,6 @@ def main():
             "preheat_ms": preheat_ms,
             "per_rank_fps": [K / v for v in per_rank_s],
             "pairs_only": pairs_only_line,
-            "segmented": segmented_line,
             "verified_against_single_context": self_check_all if verified is None else (verified and self_check_all is not False),
             "verification": ("last two timed frames of every rank recomputed on a fresh single context after the timed region: "
                              "pair counts, order-sensitive 64-bit checksums of the pair and distance planes in HBM, RMSD (1e-6 rel)"

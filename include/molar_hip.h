@@ -224,27 +224,6 @@ int molar_hip_search_resident(molar_hip_ctx *ctx, const molar_hip_search_desc *d
  * consumers that never read the distances (SearchConnectivity, patches); the d_dist pointers then come back NULL.  Not while
  * pipelined searches are in flight.  Default: both planes. */
 int molar_hip_search_resident_planes(molar_hip_ctx *ctx, int want_dist);
-/* Layout of the resident searches' result (molar_hip_search_resident, _begin / _end): segmented = 0, the default, is the dense
- * list in the reference's order.  segmented = 1 gives every element of the reference's search plan (distance_search.rs:103-269:
- * one cell pair) its own SEGMENT of the result planes: the results of segment t are entries
- * seg_base[t] .. seg_base[t] + seg_count[t] of d_pairs / d_dist, in the reference's order inside the segment; segments follow
- * each other in plan order with unused entries between them, so the segments read one after the other ARE the dense list
- * (molar_hip_search_segments_compact produces it).  For consumers that stay on the GPU and walk the result cell pair by cell
- * pair (histograms, SearchConnectivity, the membrane's patches): without the dense list's offsets no count pass runs in front
- * of the fill - one pass evaluates, writes and counts.  Segment capacities come from the same entry's count in the search
- * before on this context (+ 1/8 + 64, rounded up to 64 entries: segment starts are 256-byte aligned); a search that outgrows a
- * segment or the planes is detected and repeated inside the call that returns the result (_resident, _end), and the first
- * search of a plan runs its kernel twice.  *out_count is the number of results (the sum of seg_count), the planes extend to
- * `span` entries.  SINGLE and DOUBLE searches only; not while pipelined searches are in flight. */
-int molar_hip_search_resident_layout(molar_hip_ctx *ctx, int segmented);
-/* The segments of result set `result_set` (the ticket of _begin / _end; 0 for molar_hip_search_resident): device arrays
- * seg_base[nseg + 1] (u64, first entry of each segment; seg_base[nseg] = span) and seg_count[nseg] (u32), valid as long as the
- * result set itself.  Errors: MOLAR_HIP_ERR_NO_SEARCH in the dense layout. */
-int molar_hip_search_segments(molar_hip_ctx *ctx, int32_t result_set, const uint64_t **d_seg_base, const uint32_t **d_seg_count,
-                              uint64_t *nseg, uint64_t *span);
-/* The dense list of a segmented result set, written to device memory of out_count entries (d_pairs: 8 bytes per result; either
- * may be NULL): identical to what the dense layout returns for the same search. */
-int molar_hip_search_segments_compact(molar_hip_ctx *ctx, int32_t result_set, uint32_t *d_pairs, float *d_dist);
 /* The same search split in two so that a per-frame loop never leaves the GPU idle: _begin enqueues everything for
  * one frame and returns at once with a ticket (0 or 1); _end waits for that frame only and returns its result.
  * Two searches may be in flight, each with its own result set, so the loop is

@@ -121,9 +121,6 @@ SYMBOLS = {
     "molar_hip_search_resident": (_I, [_P, _P, _P, _P, _P]),
     "molar_hip_search_fill_device": (_I, [_P, _P, _P]),
     "molar_hip_search_resident_planes": (_I, [_P, _I]),
-    "molar_hip_search_resident_layout": (_I, [_P, _I]),
-    "molar_hip_search_segments": (_I, [_P, C.c_int32, _P, _P, _P, _P]),
-    "molar_hip_search_segments_compact": (_I, [_P, C.c_int32, _P, _P]),
     "molar_hip_search_resident_begin": (_I, [_P, _P, _P]),
     "molar_hip_search_resident_end": (_I, [_P, C.c_int32, _P, _P, _P]),
     "molar_hip_search_histogram": (_I, [_P, _P, _F, _F, _SZ, _P, _P]),

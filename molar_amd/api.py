@@ -277,22 +277,6 @@ class Engine:
         (DistanceSearchOutput of (usize, usize)); the distance addresses they return are then None."""
         check(self.lib.molar_hip_search_resident_planes(self.ctx, 1 if want_dist else 0))
 
-    def search_resident_layout(self, segmented=False):
-        """molar_hip_search_resident_layout: segmented=True gives every element of the search plan (a cell pair) its own
-        segment of the result planes - no count pass in front of the fill; see search_segments."""
-        check(self.lib.molar_hip_search_resident_layout(self.ctx, 1 if segmented else 0))
-
-    def search_segments(self, result_set=0):
-        """Segments of a result set of the segmented layout: (seg_base_device_address (u64[nseg + 1]),
-        seg_count_device_address (u32[nseg]), nseg, span)."""
-        b = C.c_void_p(); n = C.c_void_p(); ns = C.c_uint64(0); sp = C.c_uint64(0)
-        check(self.lib.molar_hip_search_segments(self.ctx, C.c_int32(result_set), C.byref(b), C.byref(n), C.byref(ns), C.byref(sp)))
-        return b.value, n.value, int(ns.value), int(sp.value)
-
-    def search_segments_compact(self, result_set, pairs_ptr, dist_ptr):
-        """The dense list of a segmented result set into device memory (addresses; either may be None)."""
-        check(self.lib.molar_hip_search_segments_compact(self.ctx, C.c_int32(result_set), C.c_void_p(pairs_ptr or 0), C.c_void_p(dist_ptr or 0)))
-
     def search_resident_begin(self, desc):
         """Enqueue a whole resident search and return its ticket without waiting (molar_hip_search_resident_begin).
         `desc` (and what it points to) must stay alive and unchanged until search_resident_end(ticket)."""

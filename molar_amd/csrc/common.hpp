@@ -192,20 +192,7 @@ struct molar_hip_ctx {
     int next_ticket = 0;
     bool resident_no_dist = false;          // molar_hip_search_resident_planes: the resident searches fill the (i, j) plane only
     unsigned long long search_serial = 0;   // counts resident searches enqueued on this context
-    // segmented resident layout (molar_hip_search_resident_layout): one output segment per plan entry, capacities from the
-    // frame before, no count pass.  Per result set: results per segment, first entry per segment (+ terminator = span)
-    bool resident_segmented = false;
-    int seg_slot = 0;                       // the result set the resident search being enqueued writes
-    mh::DevBuf seg_cnt_set[2], seg_base_set[2];
-    mh::DevBuf seg_caps;                    // u32 per plan entry: capacity of its segment (scan input)
-    mh::DevBuf seg_dense_off;               // molar_hip_search_segments_compact: dense offset per plan entry
-    mh::DevBuf seg_tmp;                     // partial sums + arrival counter of seg_finish_kernel, staging of the four sizes
-    bool seg_valid = false;                 // seg_cnt_set[seg_last] holds the counts of the last segmented search ...
-    int seg_last = 0;
-    uint64_t seg_ntasks = 0;                // ... of a plan of this many entries
-    int seg_kind = -1;
-    uint64_t seg_n[2] = {0, 0}, seg_span[2] = {0, 0}, seg_total[2] = {0, 0};   // what molar_hip_search_segments reports per result set
-    void *h_sizes = nullptr;                // pinned: 32 bytes of result sizes per ticket
+    void *h_sizes = nullptr;                // pinned: 16 bytes of result sizes per ticket
     mh::DevBuf out_ids;
     mh::DevBuf wide_i, wide_j; // usize widening
     mh::DevBuf hist;           // u64 bins

@@ -9,10 +9,7 @@
 namespace mh {
 namespace pairk {
 
-enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2, MODE_SEG = 3 };
-// MODE_SEG: the segmented resident layout (molar_hip_search_resident_layout).  One wave per PLAN ENTRY walks the entry's slots
-// in row order and writes their results, distances evaluated here, behind one another into the entry's own segment of the
-// output - no count pass in front: the segment capacities come from the frame before (search.hip, seg_enqueue).
+enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2 };
 
 // (The fill kernel is compiled for 8 waves per SIMD - 64 VGPRs, the few spills fall outside the row loop: -5 % against
 // 7 waves; 32 one-wave workgroups hold 144 KB of the CU's 160 KB LDS.  The count kernel runs 7 waves per SIMD since its
@@ -31,10 +28,6 @@ constexpr int FIFO_CAP = 128;      // per-wave LDS FIFO entries (flush threshold
 #endif
 constexpr int FIFO_WIDE = 256;     // ... of the plain entries' queue in the fill pass: flushed 128 at a time (fifo_flush_wide)
 constexpr uint32_t XCD_RUN = 128;  // consecutive slots an XCD takes at a time (pair_kernel)
-#ifndef MH_SEG_WAVES_PER_EU
-#define MH_SEG_WAVES_PER_EU 8
-#endif
-constexpr int SEG_WAVES_PER_EU = MH_SEG_WAVES_PER_EU;
 constexpr float F32_EPS = 1.1920929e-07f;
 constexpr bool MASKED_COUNT_SORTED = true;   // count pass of plain / same-cell entries walks the spatial order
 
@@ -1574,14 +1567,13 @@ __device__ __forceinline__ bool hist_lean_slot(const SearchParams &P, uint32_t f
 
 template <int KIND, int MODE>
 __global__ void __launch_bounds__(64 * waves_per_block(MODE))
-__attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 7 : (MODE == MODE_SEG ? SEG_WAVES_PER_EU : 8))))) pair_kernel(const SearchParams *__restrict__ Pp,
+__attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 7 : 8)))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
-                                                     const uint32_t nslots_arg,  // the host's bound: slots past the real count are empty (MODE_SEG: plan entries)
-                                                     uint32_t *__restrict__ slot_cnt,                       // MODE_SEG: results per plan entry
-                                                     const unsigned long long *__restrict__ slot_base,      // MODE_SEG: first output entry per plan entry (+ 1 terminator), or NULL: count only
+                                                     const uint32_t nslots_arg,  // the host's bound: slots past the real count are empty
+                                                     uint32_t *__restrict__ slot_cnt,
+                                                     const unsigned long long *__restrict__ slot_base,
                                                      uint2 *__restrict__ out_pairs, float *__restrict__ out_dist,
-                                                     uint32_t *__restrict__ out_ids,
-                                                     const uint32_t *__restrict__ task_first = nullptr) {  // MODE_SEG: first slot per plan entry (+ 1 terminator)
+                                                     uint32_t *__restrict__ out_ids) {
     constexpr int WAVES_PER_BLOCK = waves_per_block(MODE), BLOCK = 64 * WAVES_PER_BLOCK;
     // fill pass: three planes of FIFO_WIDE entries; the replay queue of the wrapped entries (FIFO_CAP x float4: the hits' second
     // atoms, with the row numbers in plane 2) lies over planes 0 and 1, which a replaying slot does not use
@@ -1609,8 +1601,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         __syncthreads();
     }
     unsigned long long wave_total = 0;
-    // position w of the launch -> slot (MODE_SEG: plan entry)
-    auto launch_order = [&](uint32_t w) __attribute__((always_inline)) -> uint32_t {
+    auto process_slot = [&](uint32_t w) __attribute__((always_inline)) {
         // Blocks are handed out in launch order: walk the plan BACKWARDS so the cells at the far x edge,
         // whose entries wrap (several times the arithmetic per candidate), start first and the cheap
         // entries fill the tail; consecutive blocks land on different XCDs, which spreads that band
@@ -1625,10 +1616,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
             const uint32_t full = (nslots / (8u * XCD_RUN)) * (8u * XCD_RUN);      // the part that divides evenly; the tail keeps its order
             if (w < full) wr = ((q / XCD_RUN) * 8u + x) * XCD_RUN + (q % XCD_RUN);
         }
-        return nslots - 1u - wr;
-    };
-    // one slot; seg_base / seg_room (MODE_SEG): where this slot's results go and how many entries of the segment are left
-    auto run_slot = [&](uint32_t slot, unsigned long long seg_base, uint32_t seg_room) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t slot = nslots - 1u - wr;
         Task T;   // record prepared by slotmap_kernel: one dependent load between the kernel arguments and the atoms
         uint32_t i0;
         unsigned long long moff;
@@ -1637,7 +1625,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
             const uint4 hi = reinterpret_cast<const uint4 *>(slot_desc + slot)[1];
             const uint2 mo = reinterpret_cast<const uint2 *>(slot_desc + slot)[4];
             const uint32_t fl = __builtin_amdgcn_readfirstlane(hi.y);
-            if (!(fl & 0x200u)) return 0u;       // past the last slot
+            if (!(fl & 0x200u)) return;       // past the last slot
             T.a0 = __builtin_amdgcn_readfirstlane(lo.x);
             T.n1 = __builtin_amdgcn_readfirstlane(lo.y);
             T.b0 = __builtin_amdgcn_readfirstlane(lo.z);
@@ -1674,18 +1662,11 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         F.hmin = P.hist_min;
         F.hmax = P.hist_max;
         F.hn = (float)P.hist_nbins;
-        if (MODE == MODE_SEG) {
-            // behind the slots of this plan entry done so far; a flush never writes past the segment (F.room), the count goes on
-            F.base = seg_base;
-            F.quota = 64u - ((uint32_t)F.base & 63u);
-            F.room = seg_room;
-            if (out_pairs) F.pairs = out_pairs + F.base + lane;
-            if (out_dist) F.dist = out_dist + F.base + lane;
-        } else if (FILL && !hist) {
+        if (FILL && !hist) {
             F.base = slot_base[slot];
             F.quota = 64u - ((uint32_t)F.base & 63u);
             const unsigned long long end = slot_base[slot + 1];
-            if (end == F.base || end > P.out_cap) return 0u;  // nothing to emit / no room (the host grows and repeats)
+            if (end == F.base || end > P.out_cap) return;  // nothing to emit / no room (the host grows and repeats)
             F.room = end - F.base < 0xFFFFFFFFull ? (uint32_t)(end - F.base) : 0xFFFFFFFFu;
             if (out_pairs) F.pairs = out_pairs + F.base + lane;
             if (out_dist) F.dist = out_dist + F.base + lane;
@@ -1693,15 +1674,15 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         }
         uint32_t total = 0;
         const uint32_t wk = (P.use_box && T.wrap != 0) ? P.wrap_kind : (uint32_t)WK_NONE;
-        if (hist && P.hist_lean && !P.hist_nslots && hist_lean_slot<KIND>(P, (T.tri ? 0x100u : 0u) | T.wrap, T.n2)) return 0u;   // hist_kernel's
+        if (hist && P.hist_lean && !P.hist_nslots && hist_lean_slot<KIND>(P, (T.tri ? 0x100u : 0u) | T.wrap, T.n2)) return;   // hist_kernel's
 #ifdef MOLAR_HIP_DEBUG_KNOBS
         if (P.debug_skip) {     // not in release builds: tools/dbg_skip.sh builds with -DMOLAR_HIP_DEBUG_KNOBS
             const uint32_t kind_bit = T.tri ? 4u : (wk != WK_NONE ? (T.rps == 8u ? 8u : 2u) : 1u);   // 8: triclinic corner entries
-            if (P.debug_skip & kind_bit) return 0u;
+            if (P.debug_skip & kind_bit) return;
         }
 #endif
         // count/fill pair: the count pass records the hit bits of the fast-path slots, the fill pass replays them
-        constexpr bool MASKED = MODE != MODE_HIST && MODE != MODE_SEG;
+        constexpr bool MASKED = MODE != MODE_HIST;
         uint32_t *mwords = nullptr;
         if (MASKED) {
             const uint32_t nch = (T.n2 + 63u) >> 6;
@@ -1715,30 +1696,8 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
         }
         if (!FILL && lane == 0) slot_cnt[slot] = total;
         wave_total += total;
-        return total;
     };
-    auto process_slot = [&](uint32_t w) __attribute__((always_inline)) { (void)run_slot(launch_order(w), 0ull, 0u); };
     const uint32_t w0 = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES_PER_BLOCK + wave;
-    if (MODE == MODE_SEG) {
-        if (w0 >= nslots) return;
-        const uint32_t t = launch_order(w0);
-        const uint32_t s0 = __builtin_amdgcn_readfirstlane(task_first[t]), s1 = __builtin_amdgcn_readfirstlane(task_first[t + 1]);
-        unsigned long long base = 0ull;
-        uint32_t room = 0u;
-        if (slot_base && s0 != s1) {
-            base = slot_base[t];
-            const unsigned long long end = slot_base[t + 1];
-            // a segment past the end of the result buffers is counted, not written (the host grows the buffers and repeats)
-            if (end <= P.out_cap) room = end - base < 0xFFFFFFFFull ? (uint32_t)(end - base) : 0xFFFFFFFFu;
-        }
-        uint32_t done = 0u;
-        for (uint32_t slot = s0; slot < s1; ++slot) {
-            const uint32_t used = done < room ? done : room;
-            done += run_slot(slot, base + used, room - used);
-        }
-        if (lane == 0) slot_cnt[t] = done;
-        return;
-    }
     if (!hist) {
         // COUNT / FILL: one wave per slot (nothing is live across slots -> fewer registers, more waves)
         // (round 5: two / four consecutive slots per one-wave workgroup in the count pass - half / a quarter of the 2.9e5
@@ -1770,12 +1729,11 @@ inline dim3 pair_grid(unsigned nblocks) {
 template <int KIND, int MODE>
 inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t stream, const SearchParams *dP,
                                const SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
-                               const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids,
-                               const uint32_t *task_first = nullptr) {
+                               const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids) {
     // (count / fill: `nblocks` counts slots = waves; the histogram mode passes workgroups)
     if (MODE != MODE_HIST) nblocks = (nblocks + (unsigned)waves_per_block(MODE) - 1u) / (unsigned)waves_per_block(MODE);
     hipLaunchKernelGGL((pair_kernel<KIND, MODE>), pair_grid(nblocks), dim3(64 * waves_per_block(MODE)), dyn_lds, stream, dP, slot_desc, nslots,
-                       slot_cnt, slot_base, pairs, dist, ids, task_first);
+                       slot_cnt, slot_base, pairs, dist, ids);
 }
 
 }  // namespace pairk
@@ -1789,9 +1747,6 @@ void launch_hist_plan(int kind, hipStream_t stream, const pairk::SearchParams &P
 void launch_hist_lean(int kind, unsigned num_cus, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
                       const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity);
 size_t hist_queue_words();
-// (pair_k5.hip) the segmented resident layout of the fixed-cutoff kinds: pair_kernel<KIND, MODE_SEG>, one wave per plan entry
-void launch_pair_seg(int kind, unsigned ntasks, hipStream_t stream, const pairk::SearchParams *dP, const pairk::SlotDesc *slot_desc,
-                     const uint32_t *task_first, uint32_t *seg_cnt, const unsigned long long *seg_base, uint2 *pairs, float *dist);
 const uint32_t *hist_list_count(const uint32_t *queue, int parity, int which);      // which: 0 lean, 1 rest
 void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
                         const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,

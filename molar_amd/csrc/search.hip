@@ -1797,172 +1797,6 @@ int molar_hip_search_fill_device(molar_hip_ctx *c, const uint32_t **d_pairs, con
     return MOLAR_HIP_OK;
 }
 
-}  // extern "C"
-
-namespace {
-
-// ---- segmented resident layout (molar_hip_search_resident_layout) -------------------------------------------------------
-// The dense list needs every slot's offset before the first result is written: the count pass (0.37 ms of the 1.43 ms headline
-// frame) exists for nothing else.  Consumers that stay on the GPU and walk the list plan entry by plan entry - histograms,
-// SearchConnectivity (connectivity.rs:19-35), the membrane's patches - do not need the entries' results to touch.  Here every
-// plan entry (the reference's search_plan element, distance_search.rs:103-269) owns a SEGMENT of the result planes: its
-// results lie in it in the reference's order, segments follow each other in plan order, and the segments read one after the
-// other are the dense list.  A segment's capacity is the entry's count in the FRAME BEFORE plus an eighth plus 64, rounded up to
-// 64 entries (256-byte aligned segment starts): consecutive frames of a trajectory move a cell pair's count by a few per cent.
-// pair_kernel<MODE_SEG> evaluates, writes and counts in ONE pass; it never writes past a segment and goes on counting when one is
-// full, so a frame that outgrew a segment is detected (seg_finish_kernel), leaves exact counts, and is repeated with them
-// (molar_hip_search_resident_end / seg_settle).  The first frame of a plan runs the kernel twice (counts only, then with the
-// exact capacities).
-__global__ void __launch_bounds__(256) seg_caps_kernel(const uint32_t *__restrict__ prev_cnt, const uint32_t *__restrict__ task_first,
-                                                       uint64_t ntasks, uint32_t exact, uint32_t *__restrict__ caps) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (t > ntasks) return;
-    unsigned long long cap = 0ull;
-    if (t < ntasks && task_first[t] != task_first[t + 1]) {       // an entry without slots (an empty cell) owns nothing
-        const unsigned long long p = prev_cnt[t];
-        cap = exact ? p : p + (p >> 3) + 64ull;
-        cap = (cap + 63ull) & ~63ull;
-        if (cap > 0xFFFFFFC0ull) cap = 0xFFFFFFC0ull;
-    }
-    caps[t] = (uint32_t)cap;                                       // caps[ntasks] = 0: the terminator's offset is the span
-}
-
-// total results, span of the segments, segments that were not written in full -> `sizes` (4 words; pinned host memory or device)
-__global__ void __launch_bounds__(256) seg_finish_kernel(const uint32_t *__restrict__ cnt, const unsigned long long *__restrict__ base,
-                                                         uint64_t ntasks, unsigned long long out_cap, unsigned long long *__restrict__ tmp,
-                                                         unsigned long long *__restrict__ sizes) {
-    __shared__ unsigned long long part[2][4];
-    __shared__ bool last;
-    const uint64_t per = (ntasks + gridDim.x - 1) / gridDim.x;
-    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < ntasks ? lo + per : ntasks;
-    unsigned long long sum = 0ull, bad = 0ull;
-    for (uint64_t t = lo + threadIdx.x; t < hi; t += 256u) {
-        const unsigned long long n = cnt[t];
-        sum += n;
-        if (base && n && (n > base[t + 1] - base[t] || base[t + 1] > out_cap)) ++bad;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        sum += __shfl_xor(sum, off, 64);
-        bad += __shfl_xor(bad, off, 64);
-    }
-    if ((threadIdx.x & 63u) == 0u) { part[0][threadIdx.x >> 6] = sum; part[1][threadIdx.x >> 6] = bad; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        tmp[2 * blockIdx.x] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
-        tmp[2 * blockIdx.x + 1] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
-        __threadfence();
-        unsigned int *arrived = reinterpret_cast<unsigned int *>(tmp + 2 * gridDim.x);
-        last = atomicAdd(arrived, 1u) == gridDim.x - 1u;
-        if (last) *arrived = 0u;                  // ready for the next launch
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    sum = bad = 0ull;
-    for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256u) {
-        sum += __builtin_nontemporal_load(&tmp[2 * b]);
-        bad += __builtin_nontemporal_load(&tmp[2 * b + 1]);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        sum += __shfl_xor(sum, off, 64);
-        bad += __shfl_xor(bad, off, 64);
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63u) == 0u) { part[0][threadIdx.x >> 6] = sum; part[1][threadIdx.x >> 6] = bad; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        sizes[0] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
-        sizes[1] = 0ull;
-        sizes[2] = base ? base[ntasks] : 0ull;
-        sizes[3] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
-    }
-}
-
-// segments -> the dense list (molar_hip_search_segments_compact): one wave per plan entry copies its results to their dense offset
-__global__ void __launch_bounds__(64) seg_compact_kernel(const uint32_t *__restrict__ cnt, const unsigned long long *__restrict__ base,
-                                                         const unsigned long long *__restrict__ dense_off, uint64_t ntasks,
-                                                         const uint2 *__restrict__ pairs, const float *__restrict__ dist,
-                                                         uint2 *__restrict__ out_pairs, float *__restrict__ out_dist) {
-    const uint64_t t = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    if (t >= ntasks) return;
-    const uint32_t n = cnt[t];
-    const unsigned long long src = base[t], dst = dense_off[t];
-    for (uint32_t k = threadIdx.x; k < n; k += 64u) {
-        if (out_pairs) out_pairs[dst + k] = pairs[src + k];
-        if (out_dist) out_dist[dst + k] = dist[src + k];
-    }
-}
-
-constexpr unsigned SEG_FINISH_BLOCKS = 256;
-
-int seg_enqueue(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD, void *sizes, unsigned long long *sizes_dev,
-                       unsigned long long cap0) {
-    const int slot = c->seg_slot & 1;
-    const uint64_t nt = c->ntasks;
-    MH_TRY(c->seg_cnt_set[slot].reserve((nt + 1) * 4));
-    MH_TRY(c->seg_base_set[slot].reserve((nt + 1) * 8));
-    MH_TRY(c->seg_caps.reserve((nt + 1) * 4));
-    if (!c->seg_tmp.p) {
-        MH_TRY(c->seg_tmp.reserve((2 * SEG_FINISH_BLOCKS + 1 + 4) * 8));
-        MH_HIP(hipMemsetAsync(c->seg_tmp.p, 0, (2 * SEG_FINISH_BLOCKS + 1 + 4) * 8, c->stream));
-    }
-    uint32_t *cnt = c->seg_cnt_set[slot].as<uint32_t>();
-    unsigned long long *base = c->seg_base_set[slot].as<unsigned long long>();
-    uint32_t *caps = c->seg_caps.as<uint32_t>();
-    const uint32_t *task_first = c->task_nb.as<uint32_t>();        // scanned in place by the plan: first slot per entry
-    // the parameter block: the plan kernel of a resident search has written it (prepare_search, size_masks == false)
-    if (!(c->params_fresh && c->params_fresh_cap == cap0)) {
-        SearchParams P = make_params(c);
-        P.out_cap = cap0;
-        hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, c->stream, P, c->params.as<SearchParams>());
-    }
-    c->params_fresh = false;
-    const SearchParams *dP = c->params.as<SearchParams>();
-    const SlotDesc *sd = c->slot_desc.as<SlotDesc>();
-    uint2 *dp = outP.as<uint2>();
-    float *dd = c->resident_no_dist ? nullptr : outD.as<float>();
-    const bool exact = !(c->seg_valid && c->seg_ntasks == nt && c->seg_kind == c->kind);
-    const uint32_t *prev = exact ? cnt : c->seg_cnt_set[c->seg_last & 1].as<uint32_t>();
-    if (exact) {          // no frame before this one: counts only, then exact capacities
-        Prof prof(c, 1);
-        launch_pair_seg(c->kind, (unsigned)nt, c->stream, dP, sd, task_first, cnt, nullptr, nullptr, nullptr);
-    }
-    {
-        Prof prof(c, 2);
-        hipLaunchKernelGGL(seg_caps_kernel, dim3((unsigned)((nt + 1 + 255) / 256)), dim3(256), 0, c->stream, prev, task_first, nt,
-                           exact ? 1u : 0u, caps);
-        const uint64_t n = nt + 1, ntiles = (n + 255) / 256;
-        if (ntiles <= SLOT_SCAN_MAX_TILES) {
-            MH_TRY(c->tile_sum.reserve(ntiles * 8));
-            hipLaunchKernelGGL(tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, c->stream, caps, c->tile_sum.as<unsigned long long>(), n);
-            hipLaunchKernelGGL(slot_offsets_kernel, dim3((unsigned)ntiles), dim3(256), 0, c->stream, caps, c->tile_sum.as<unsigned long long>(),
-                               base, n, (unsigned long long *)nullptr);
-        } else {
-            MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, caps, base, n)));
-        }
-    }
-    {
-        Prof prof(c, 3);
-        if (cap0) launch_pair_seg(c->kind, (unsigned)nt, c->stream, dP, sd, task_first, cnt, base, dp, dd);
-        else if (!exact) launch_pair_seg(c->kind, (unsigned)nt, c->stream, dP, sd, task_first, cnt, nullptr, nullptr, nullptr);
-    }
-    unsigned long long *tmp = c->seg_tmp.as<unsigned long long>();
-    unsigned long long *dst = sizes_dev ? sizes_dev : tmp + 2 * SEG_FINISH_BLOCKS + 1;
-    hipLaunchKernelGGL(seg_finish_kernel, dim3(SEG_FINISH_BLOCKS), dim3(256), 0, c->stream, cnt, base, nt, cap0, tmp, dst);
-    MH_HIP(hipGetLastError());
-    if (!sizes_dev) MH_HIP(hipMemcpyAsync(sizes, dst, 32, hipMemcpyDeviceToHost, c->stream));
-    c->seg_valid = true;
-    c->seg_last = slot;
-    c->seg_n[slot] = nt;
-    c->seg_ntasks = nt;
-    c->seg_kind = c->kind;
-    return 0;
-}
-
-}  // namespace
-
-extern "C" {
-
 // Enqueue one whole resident search (grid, plan, count, offset scan, fill into outP/outD against their present
 // capacity) and the async read-back of its two sizes into `sizes` (pinned, 16 bytes).  No host wait.
 // (struct ResidentLaunch: stages.hpp)
@@ -1991,13 +1825,6 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     L->degenerate = c->have_search;
     if (L->degenerate) return 0;
     const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
-    if (c->resident_segmented) {
-        if (!fast_kind)
-            return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "segmented layout: single and double searches (the vdW search keeps the dense list)");
-        MH_TRY(seg_enqueue(c, outP, outD, sizes, (unsigned long long *)sizes_dev, cap0));
-        L->cap0 = cap0;
-        return 0;
-    }
     L->maskcap0 = c->maskbuf.cap / 256u;
     // one parameter block serves both passes: the count pass ignores the output capacity
     MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, cap0));
@@ -2048,51 +1875,13 @@ static int resident_settle(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD,
     return 0;
 }
 
-// Segmented layout, with `sizes` (4 words) delivered and the stream drained: a frame whose segments did not all fit - the result
-// planes were too short for the span (first frames) or an entry outgrew its segment - is repeated with the planes grown and
-// with ITS OWN counts as the capacities' source (they are exact: the kernel counts past a full segment).
-static int seg_settle(molar_hip_ctx *c, const molar_hip_search_desc *q, int slot, mh::DevBuf &outP, mh::DevBuf &outD, const void *sizes,
-                      unsigned long long cap0) {
-    unsigned long long res[4];
-    std::memcpy(res, sizes, 32);
-    for (int round = 0; res[2] > cap0 || res[3] != 0ull; ++round) {
-        if (round == 3) return fail(MOLAR_HIP_ERR_HIP, "segmented search: segments did not settle");
-        MH_HIP(hipStreamSynchronize(c->stream));
-        unsigned long long want = res[2] > res[0] + res[0] / 4u ? res[2] : res[0] + res[0] / 4u;   // span of the next try: counts * 9/8 + 64 per entry
-        want += 128ull * (c->ntasks + 1);
-        if (want > cap0) {
-            MH_TRY(outP.reserve((size_t)(want + want / 16u) * 8));
-            MH_TRY(outD.reserve((size_t)(want + want / 16u) * 4));
-        }
-        c->seg_slot = slot;
-        c->seg_last = slot;              // this frame's own counts
-        MH_TRY(ensure_pinned(c, 64));
-        ResidentLaunch L;
-        std::memset(c->h_pinned, 0, 32);
-        MH_TRY(resident_enqueue(c, q, outP, outD, c->h_pinned, &L));
-        MH_HIP(hipStreamSynchronize(c->stream));
-        std::memcpy(res, c->h_pinned, 32);
-        cap0 = L.cap0;
-    }
-    c->total = res[0];
-    c->have_search = false;              // no slot counts, no hit history: the other fill variants need their own count
-    c->seg_span[slot] = res[2];
-    c->seg_total[slot] = res[0];
-    return 0;
-}
-
 // One whole resident search, complete when the call returns (the stream has been waited for).
 static int resident_run(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::DevBuf &outP, mh::DevBuf &outD) {
     MH_TRY(ensure_pinned(c, 64));
     ResidentLaunch L;
-    c->seg_slot = 0;
     MH_TRY(resident_enqueue(c, q, outP, outD, c->h_pinned, &L));
-    if (L.degenerate) {
-        c->seg_n[0] = c->seg_span[0] = c->seg_total[0] = 0;
-        return 0;
-    }
+    if (L.degenerate) return 0;
     MH_HIP(hipStreamSynchronize(c->stream));
-    if (c->resident_segmented) return seg_settle(c, q, 0, outP, outD, c->h_pinned, L.cap0);
     return resident_settle(c, outP, outD, c->h_pinned, L);
 }
 
@@ -2102,11 +1891,7 @@ static int resident_run(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::De
 int mh::search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, void *sizes_pinned, ResidentLaunch *L,
                                 const unsigned long long **total_dev, const uint32_t **pairs_dev) {
     std::memset(sizes_pinned, 0, 16);
-    const bool seg = c->resident_segmented;        // the chained stages read the dense list
-    c->resident_segmented = false;
-    const int erc = resident_enqueue(c, q, c->out_pairs, c->out_dist, sizes_pinned, L);
-    c->resident_segmented = seg;
-    MH_TRY(erc);
+    MH_TRY(resident_enqueue(c, q, c->out_pairs, c->out_dist, sizes_pinned, L));
     c->have_search = false;              // the sizes are not known to the host: not a cached search for the fill calls
     *total_dev = L->degenerate ? nullptr : c->slot_base.as<unsigned long long>() + c->nslots_bound;
     *pairs_dev = c->out_pairs.as<uint32_t>();
@@ -2155,51 +1940,6 @@ int molar_hip_search_resident_planes(molar_hip_ctx *c, int want_dist) {
     return MOLAR_HIP_OK;
 }
 
-// The segmented layout of the resident searches (see seg_enqueue): on / off, not while pipelined searches are in flight.
-int molar_hip_search_resident_layout(molar_hip_ctx *c, int segmented) {
-    if (!c) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "null context");
-    if (c->tickets[0].pending || c->tickets[1].pending)
-        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "resident_layout: pipelined searches are in flight");
-    c->resident_segmented = segmented != 0;
-    c->seg_valid = false;
-    return MOLAR_HIP_OK;
-}
-
-int molar_hip_search_segments(molar_hip_ctx *c, int32_t result_set, const uint64_t **d_seg_base, const uint32_t **d_seg_count,
-                              uint64_t *nseg, uint64_t *span) {
-    if (!c || result_set < 0 || result_set > 1) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "segments: result set 0 or 1");
-    if (!c->resident_segmented) return fail(MOLAR_HIP_ERR_NO_SEARCH, "segments: the context's resident searches use the dense layout");
-    if (c->tickets[result_set].pending) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "segments: the search of this result set has not been ended");
-    const uint64_t n = c->seg_n[result_set];
-    if (d_seg_base) *d_seg_base = n ? reinterpret_cast<const uint64_t *>(c->seg_base_set[result_set].p) : nullptr;
-    if (d_seg_count) *d_seg_count = n ? c->seg_cnt_set[result_set].as<uint32_t>() : nullptr;
-    if (nseg) *nseg = n;
-    if (span) *span = c->seg_span[result_set];
-    return MOLAR_HIP_OK;
-}
-
-// The dense list from the segments of a result set: d_pairs (8 bytes per result) / d_dist, device memory, either may be NULL.
-int molar_hip_search_segments_compact(molar_hip_ctx *c, int32_t result_set, uint32_t *d_pairs, float *d_dist) {
-    if (!c || result_set < 0 || result_set > 1) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "segments: result set 0 or 1");
-    if (!c->resident_segmented) return fail(MOLAR_HIP_ERR_NO_SEARCH, "segments: the context's resident searches use the dense layout");
-    if (c->tickets[result_set].pending) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "segments: the search of this result set has not been ended");
-    if ((d_pairs && !is_device_ptr(d_pairs)) || (d_dist && !is_device_ptr(d_dist)))
-        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "segments_compact: outputs must be device memory");
-    if (d_dist && c->resident_no_dist) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "segments_compact: the resident searches fill the pair plane only");
-    const uint64_t n = c->seg_n[result_set];
-    if (!n || !c->seg_total[result_set]) return MOLAR_HIP_OK;
-    MH_HIP(hipSetDevice(c->device));
-    MH_TRY(c->seg_dense_off.reserve((n + 1) * 8));
-    const uint32_t *cnt = c->seg_cnt_set[result_set].as<uint32_t>();
-    MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, cnt, c->seg_dense_off.as<unsigned long long>(), n)));
-    hipLaunchKernelGGL(seg_compact_kernel, pairk::pair_grid((unsigned)n), dim3(64), 0, c->stream, cnt,
-                       c->seg_base_set[result_set].as<unsigned long long>(), c->seg_dense_off.as<unsigned long long>(), n,
-                       c->out_pairs_set[result_set].as<uint2>(), c->out_dist_set[result_set].as<float>(), reinterpret_cast<uint2 *>(d_pairs), d_dist);
-    MH_HIP(hipGetLastError());
-    MH_HIP(hipStreamSynchronize(c->stream));
-    return MOLAR_HIP_OK;
-}
-
 int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_desc *q, int32_t *ticket) {
     if (!c || !q || !ticket) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: null argument");
     const int slot = c->next_ticket & 1;
@@ -2224,8 +1964,6 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     c->side_wait2 = (c->count_done_set && c->env_grid_late) ? c->count_done : nullptr;
     if (c->env_grid_late && !c->count_done) MH_HIP(hipEventCreateWithFlags(&c->count_done, hipEventDisableTiming));
     c->record_count_done = c->env_grid_late;
-    c->seg_slot = slot;
-    std::memset((char *)c->h_sizes + 32 * slot, 0, 32);
     const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 32 * slot, &L);
     c->record_count_done = false;
     c->want_side = false;
@@ -2253,17 +1991,9 @@ int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *ou
     T.pending = false;
     MH_HIP(hipSetDevice(c->device));
     uint64_t total = 0;
-    if (T.degenerate) c->seg_n[ticket] = c->seg_span[ticket] = c->seg_total[ticket] = 0;
     if (!T.degenerate) {
         MH_HIP(hipEventSynchronize(T.done));
         const void *sizes = (const char *)c->h_sizes + 32 * ticket;
-        if (c->resident_segmented) {
-            MH_TRY(seg_settle(c, &T.desc, ticket, outP, outD, sizes, T.cap0));
-            if (out_count) *out_count = c->seg_total[ticket];
-            if (d_pairs) *d_pairs = outP.as<uint32_t>();
-            if (d_dist) *d_dist = c->resident_no_dist ? nullptr : outD.as<float>();
-            return MOLAR_HIP_OK;
-        }
         unsigned long long res[2];
         std::memcpy(res, sizes, 16);
         const bool fast_kind = T.desc.kind == MOLAR_HIP_SEARCH_SINGLE || T.desc.kind == MOLAR_HIP_SEARCH_DOUBLE;
