@@ -369,19 +369,31 @@ class Engine:
 
     # ------------------------------------------------------------ search, f64 build of MolAR (Float = f64)
     def search_f64(self, kind, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, vdw1=None, vdw2=None,
-                   ids_local=False, lower=None, upper=None):
+                   ids_local=False, lower=None, upper=None, device_out=False):
         """The distance_search drivers with every operation in double (molar_hip_search_count_f64 + fill): returns
-        (i, j, d) as uint64 / uint64 / float64 arrays in the reference's order, or the uint64 ids for SEARCH_WITHIN."""
+        (i, j, d) as uint64 / uint64 / float64 arrays in the reference's order, or the uint64 ids for SEARCH_WITHIN.
+        Coordinates, indices and radii may be torch tensors in HBM (used in place); device_out=True leaves the result
+        there too (int64 / int64 / float64 tensors)."""
         def f64(a):
-            return None if a is None else np.ascontiguousarray(a, np.float64)
+            if a is None:
+                return None
+            if hasattr(a, "data_ptr"):          # a torch tensor in HBM is used in place (float64, contiguous)
+                if str(a.dtype) != "torch.float64" or not a.is_contiguous():
+                    raise TypeError("search_f64: device tensors must be contiguous float64")
+                return a
+            return np.ascontiguousarray(a, np.float64)
+
+        def addr(a):
+            return None if a is None else (a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data)
         xyz1, xyz2, vdw1, vdw2 = f64(xyz1), f64(xyz2), f64(vdw1), f64(vdw2)
-        idx1, idx2 = _u64(idx1), _u64(idx2)
+        idx1 = idx1 if hasattr(idx1, "data_ptr") else _u64(idx1)       # (device index tensors: int64)
+        idx2 = idx2 if hasattr(idx2, "data_ptr") else _u64(idx2)
         d = SearchDescF64()
         d.kind = kind
         d.cutoff = float(cutoff) if cutoff is not None else 0.0
         keep = [xyz1, xyz2, vdw1, vdw2, idx1, idx2]
         for name, arr in (("xyz1", xyz1), ("idx1", idx1), ("xyz2", xyz2), ("idx2", idx2), ("vdw1", vdw1), ("vdw2", vdw2)):
-            setattr(d, name, None if arr is None else arr.ctypes.data)
+            setattr(d, name, addr(arr))
         d.natoms1 = 0 if xyz1 is None else xyz1.reshape(-1, 3).shape[0]
         d.natoms2 = 0 if xyz2 is None else xyz2.reshape(-1, 3).shape[0]
         d.n1 = 0 if idx1 is None else idx1.shape[0]
@@ -399,6 +411,19 @@ class Engine:
         n = C.c_uint64()
         check(self.lib.molar_hip_search_count_f64(self.ctx, C.byref(d), C.byref(n)))
         n = int(n.value)
+        if device_out:
+            import torch
+            dev = torch.device("cuda", self.device)
+            if kind == SEARCH_WITHIN:
+                ids = torch.empty(n, dtype=torch.int64, device=dev)
+                if n:
+                    check(self.lib.molar_hip_search_fill_ids_f64(self.ctx, ids.data_ptr()))
+                return ids
+            i = torch.empty(n, dtype=torch.int64, device=dev); j = torch.empty(n, dtype=torch.int64, device=dev)
+            dist = torch.empty(n, dtype=torch.float64, device=dev)
+            if n:
+                check(self.lib.molar_hip_search_fill_f64(self.ctx, i.data_ptr(), j.data_ptr(), dist.data_ptr()))
+            return i, j, dist
         if kind == SEARCH_WITHIN:
             ids = np.empty(n, np.uint64)
             check(self.lib.molar_hip_search_fill_ids_f64(self.ctx, ids.ctypes.data))

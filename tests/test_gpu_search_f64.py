@@ -92,6 +92,76 @@ def test_f64_decides_where_f32_cannot(eng, orc64):
     assert (near < 1e-9).sum() > 1000
 
 
+@pytest.mark.parametrize("name", ["ortho", "tric_a", "hex_b"])
+def test_f64_pairs_across_the_periodic_boundary_at_the_cutoff_edge(eng, orc64, name):
+    """Entries across the periodic boundary are classified by the distance to the second cell's adjacent image and decided by
+    PeriodicBox::distance_squared only inside a narrow band around the cutoff: pairs straddling every face of the cell at
+    rc * (1 +- 1e-15 .. 1e-8), in boxes with >= 4 cells per dimension, must come out exactly as the f64 reference has them -
+    single and double search, full and partial periodicity, coordinates resident in HBM."""
+    import torch
+    import molar_amd.api as a
+    rng = np.random.default_rng(23)
+    n = 30_000
+    box = boxes(n)[name]
+    rc = 0.7
+    ob = orc64.box_from_matrix(box)
+    npairs = 6000
+    # first atoms close to a face of the unit cell (fractional coordinate ~0 or ~1 in one dimension), partners at the cutoff edge
+    frac = rng.random((npairs, 3))
+    dim = rng.integers(0, 3, npairs)
+    frac[np.arange(npairs), dim] = rng.choice([0.0, 1.0], npairs) + rng.normal(0, 0.01, npairs)
+    pa = frac @ box.T
+    u = rng.normal(size=(npairs, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    e = 10.0 ** rng.uniform(-15.5, -8.0, npairs) * rng.choice([-1.0, 1.0], npairs)
+    pb = pa + rc * (1.0 + e)[:, None] * u
+    pos = np.concatenate([pa, pb, rng.random((n - 2 * npairs, 3)) @ box.T])
+    for pbc in (7, 5):
+        ref = orc64.search_single_pbc(rc, pos, ob, pbc)
+        assert min(ref["dims"]) >= 4
+        same(eng.search_f64(a.SEARCH_SINGLE, rc, pos, box=box, pbc=pbc), ref)
+        if pbc == 7:
+            assert (np.abs(ref["d"] / rc - 1.0) < 1e-9).sum() > 1000
+    dpos = torch.from_numpy(pos).cuda()
+    got = eng.search_f64(a.SEARCH_SINGLE, rc, dpos, box=box, pbc=7, device_out=True)
+    ref = orc64.search_single_pbc(rc, pos, ob, 7)
+    same((got[0].cpu().numpy().view(np.uint64), got[1].cpu().numpy().view(np.uint64), got[2].cpu().numpy()), ref)
+    i1 = np.arange(0, n, 2, dtype=np.uint64); i2 = np.arange(1, n, 2, dtype=np.uint64)
+    same(eng.search_f64(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=7),
+         orc64.search_double_pbc(rc, pos[0::2], pos[1::2], ob, 7, ids1=i1, ids2=i2))
+    ids = eng.search_f64(a.SEARCH_WITHIN, rc, pos, i1, pos, i2, box=box, pbc=7)
+    assert np.array_equal(ids, orc64.search_within_pbc(rc, pos[0::2], pos[1::2], ob, 7, ids1=i1, ids2=i2)["i"])
+
+
+def test_f64_large_cells_and_device_inputs(eng, orc64):
+    """Second cells of more than 256 atoms take the chunk-by-chunk loop; selections and radii resident in HBM; the non-periodic
+    bounding box reduced on the device; an out-of-range selection index is an error."""
+    import torch
+    import molar_amd.api as a
+    from molar_amd._lib import MolarHipError
+    rng = np.random.default_rng(29)
+    n = 20_000
+    box = np.diag([6.0, 6.0, 6.0])
+    pos = rng.random((n, 3)) * 6.0 + rng.normal(0, 0.05, (n, 3))
+    ob = orc64.box_from_matrix(box)
+    rc = 1.45                                     # 4 x 4 x 4 cells of ~310 atoms
+    ref = orc64.search_single_pbc(rc, pos, ob, 7)
+    assert tuple(ref["dims"]) == (4, 4, 4)
+    dpos = torch.from_numpy(pos).cuda()
+    same(eng.search_f64(a.SEARCH_SINGLE, rc, dpos, box=box, pbc=7), ref)
+    same(eng.search_f64(a.SEARCH_SINGLE, rc, dpos), orc64.search_single(rc, pos))
+    sel1 = np.sort(rng.choice(n, 8000, replace=False)).astype(np.uint64)
+    sel2 = np.sort(rng.choice(n, 5000, replace=False)).astype(np.uint64)
+    d1, d2 = torch.from_numpy(sel1.astype(np.int64)).cuda(), torch.from_numpy(sel2.astype(np.int64)).cuda()
+    want = orc64.search_double(0.6, pos[sel1.astype(int)], pos[sel2.astype(int)], ids1=sel1, ids2=sel2)
+    same(eng.search_f64(a.SEARCH_DOUBLE, 0.6, dpos, d1, dpos, d2), want)
+    v1, v2 = 0.1 + 0.1 * rng.random(len(sel1)), 0.1 + 0.1 * rng.random(len(sel2))
+    same(eng.search_f64(a.SEARCH_DOUBLE_VDW, None, dpos, d1, dpos, d2, box=box, pbc=7, vdw1=torch.from_numpy(v1).cuda(), vdw2=torch.from_numpy(v2).cuda()),
+         orc64.search_double_vdw_pbc(pos[sel1.astype(int)], pos[sel2.astype(int)], v1, v2, ob, 7))
+    bad = sel1.copy(); bad[17] = n + 5
+    with pytest.raises(MolarHipError):
+        eng.search_f64(a.SEARCH_SINGLE, 0.5, pos, bad, box=box, pbc=7)
+
+
 def test_errors_f64(eng):
     import molar_amd.api as a
     from molar_amd._lib import MolarHipError
