@@ -257,8 +257,9 @@ int molar_hip_histogram_edges(float hmin, float hmax, size_t nbins, float *edges
 
 /* ---- the drivers for MolAR built with its `f64` feature (Float = f64, aliases.rs:10-13): every operation in double -
  * cell assignment, the predicate d2 <= cutoff^2 and the distances - results as (usize, usize, f64) columns or usize ids.
- * Same request / count-then-fill convention as above; correct before fast (grid and plan on the host, one untuned
- * kernel pair): the tuned path is the f32 one. */
+ * Same request / count-then-fill convention as above.  Coordinates, index lists, radii and the result columns may be host or
+ * device memory (device memory is used in place); grid and plan are built on the device.  The matrix-core count and the
+ * pipelined resident forms exist for f32 only. */
 typedef struct {
     int32_t kind;
     double cutoff;
