@@ -468,6 +468,7 @@ __global__ void __launch_bounds__(256) scan_tile_kernel(const TIn *in, TOut *out
 // Scans TWO arrays of the same length at once when in2 != nullptr (task slot counts and task hit-history units).
 // `state` holds 1 ticket word + 2 descriptors per tile and must be zero on entry.
 constexpr unsigned long long LB_MASK = (1ull << 62) - 1ull;
+constexpr uint64_t FPLAN_MAX_TASKS = 1ull << 18;                          // plan_tiles_kernel / plan_slots_kernel: plans up to this many entries (+ terminator)
 __device__ __forceinline__ unsigned long long lb_resolve(unsigned long long *desc, uint32_t tile, unsigned long long tot) {
     if (tile == 0) {
         __hip_atomic_store(&desc[0], (2ull << 62) | tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -539,6 +540,150 @@ int scan_lookback(molar_hip_ctx *c, const TIn1 *in1, TOut1 *out1, const TIn2 *in
                        zeroed_state, ntiles);
     MH_HIP(hipGetLastError());
     return 0;
+}
+
+// The plan of a search in TWO launches without a chain between workgroups (round 5; it was plan_kernel -> scan_lookback_kernel ->
+// slotmap_kernel, 5 + 13 + 13 us on the critical stream of every frame): plan_tiles_kernel decodes 256 plan entries per workgroup,
+// scans their slot counts (and hit-history units) inside the tile and leaves the tile totals; in plan_slots_kernel workgroup b sums
+// the b totals in front of it (a few hundred words from L2, as slot_offsets_kernel does), finishes its entries' offsets and writes
+// the records of their slots.  (One launch with a decoupled look-back between the tiles was built first: correct, and 56 us - the
+// tiles' chain waits for whichever workgroup the dispatcher starts last, and the next frame's grid build on the high-priority
+// side stream starts at that very moment.)  plan_tiles_kernel also zeroes the slot counters and writes the parameter block, as
+// plan_kernel does; plan_slots_kernel also blanks the records between the real slot count and the host's bound (spread over all
+// workgroups: one workgroup alone took 45 us for 5e4 of them).
+template <int KIND>
+__global__ void __launch_bounds__(256) plan_tiles_kernel(SearchParams P, uint32_t *__restrict__ local_first, TaskDesc *__restrict__ task_desc,
+                                                         unsigned long long *__restrict__ local_moff, uint32_t fast_kind,
+                                                         uint32_t *__restrict__ slot_cnt, uint64_t nslot_cnt,
+                                                         unsigned long long *__restrict__ tile_tot, SearchParams *__restrict__ params_dst) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    for (uint64_t w = t; w < nslot_cnt; w += (uint64_t)gridDim.x * 256u) slot_cnt[w] = 0u;   // the count kernel writes the slots that exist
+    if (params_dst && blockIdx.x == 0) {
+        const uint32_t *src = (const uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();     // P is this kernel's first argument
+        uint32_t *d = (uint32_t *)params_dst;
+        for (uint32_t w = threadIdx.x; w < (uint32_t)(sizeof(SearchParams) / 4u); w += 256u) d[w] = src[w];
+    }
+    uint32_t nb = 0;
+    unsigned long long mu = 0;
+    if (t < P.ntasks) {
+        const Task T = decode_task<KIND, false>(P, t);
+        nb = T.valid ? (T.n1 + T.rps - 1u) / T.rps : 0u;
+        const uint32_t nch = (T.n2 + 63u) >> 6;
+        mu = (fast_kind && P.use_box && T.wrap != 0u && nch <= (uint32_t)KREG) ? (unsigned long long)nb * 2u * nch : 0ull;   // as plan_kernel
+        TaskDesc d;
+        d.a0 = T.a0; d.n1 = T.n1; d.b0 = T.b0; d.n2 = T.n2; d.cb = T.cb;
+        d.flags = T.wrap | (T.tri ? 0x100u : 0u) | (T.valid ? 0x200u : 0u) | (T.wrap_b << 12) | (T.rps << 16);
+        d.pad0 = nb;                              // slots of the entry (plan_slots_kernel)
+        d.pad1 = 0u;
+        task_desc[t] = d;
+    }
+    uint32_t tot_nb;
+    const uint32_t first = block_exclusive_scan<uint32_t>(nb, &tot_nb);
+    unsigned long long tot_mu = 0ull, m0 = 0ull;
+    if (fast_kind) m0 = block_exclusive_scan<unsigned long long>(mu, &tot_mu);
+    if (t <= P.ntasks) {                         // offsets inside the tile (t == ntasks: the terminator)
+        local_first[t] = first;
+        if (fast_kind) local_moff[t] = m0;
+    }
+    if (threadIdx.x == 0) {
+        tile_tot[2 * blockIdx.x] = tot_nb;
+        tile_tot[2 * blockIdx.x + 1] = tot_mu;
+    }
+}
+
+constexpr uint32_t PLAN_SUB = 64;          // plan entries per workgroup of plan_slots_kernel (a quarter of a tile)
+static __global__ void __launch_bounds__(256) plan_slots_kernel(uint64_t ntasks, uint32_t ntiles, const uint32_t *__restrict__ local_first,
+                                                                const unsigned long long *__restrict__ local_moff,
+                                                                uint32_t *__restrict__ task_first, const TaskDesc *__restrict__ task_desc,
+                                                                unsigned long long *__restrict__ task_moff,      // NULL: no hit history
+                                                                const unsigned long long *__restrict__ tile_tot,
+                                                                SlotDesc *__restrict__ slot_desc, uint64_t nslots_bound,
+                                                                unsigned long long *__restrict__ sizes_host) {  // pinned, or NULL
+    __shared__ unsigned long long part[3][4];
+    const uint32_t tile = blockIdx.x / (256u / PLAN_SUB), sub = blockIdx.x % (256u / PLAN_SUB);
+    unsigned long long pn = 0, pm = 0, all_n = 0;           // slots / hit-history units in front of this tile, slots of the whole plan
+    for (uint32_t b = threadIdx.x; b < ntiles; b += 256u) {
+        const unsigned long long n = tile_tot[2 * b];
+        all_n += n;
+        if (b < tile) {
+            pn += n;
+            pm += tile_tot[2 * b + 1];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        pn += __shfl_xor(pn, off, 64);
+        pm += __shfl_xor(pm, off, 64);
+        all_n += __shfl_xor(all_n, off, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u) { part[0][threadIdx.x >> 6] = pn; part[1][threadIdx.x >> 6] = pm; part[2][threadIdx.x >> 6] = all_n; }
+    __syncthreads();
+    const uint32_t base_n = (uint32_t)((part[0][0] + part[0][1]) + (part[0][2] + part[0][3]));
+    const unsigned long long base_m = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+    const unsigned long long total = (part[2][0] + part[2][1]) + (part[2][2] + part[2][3]);
+    // this workgroup's entries in LDS: offsets inside the tile, descriptors, first hit-history unit
+    __shared__ uint32_t lfirst[PLAN_SUB + 1];
+    __shared__ TaskDesc ldesc[PLAN_SUB];
+    __shared__ unsigned long long lm0[PLAN_SUB];
+    const uint32_t tile_n = (uint32_t)tile_tot[2 * tile];
+    if (threadIdx.x <= PLAN_SUB) {
+        const uint64_t t = (uint64_t)tile * 256u + sub * PLAN_SUB + threadIdx.x;        // (thread PLAN_SUB: the next workgroup's first entry)
+        const bool inside = threadIdx.x < PLAN_SUB || sub + 1u < 256u / PLAN_SUB;     // ... which lies in this tile
+        uint32_t local = tile_n;                 // past the terminator / past the tile: the tile's end
+        unsigned long long m0 = ~0ull >> 1;
+        TaskDesc d;
+        d.a0 = d.n1 = d.b0 = d.n2 = d.cb = d.flags = d.pad0 = d.pad1 = 0u;
+        if (inside && t <= ntasks) {
+            local = local_first[t];
+            if (threadIdx.x < PLAN_SUB) {
+                if (task_moff) m0 = base_m + local_moff[t];
+                if (t < ntasks) d = task_desc[t];
+            }
+        }
+        lfirst[threadIdx.x] = local;
+        if (threadIdx.x < PLAN_SUB) {
+            ldesc[threadIdx.x] = d;
+            lm0[threadIdx.x] = m0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < PLAN_SUB) {
+        const uint64_t t = (uint64_t)tile * 256u + sub * PLAN_SUB + threadIdx.x;
+        if (t <= ntasks) {
+            task_first[t] = base_n + lfirst[threadIdx.x];
+            if (task_moff) task_moff[t] = lm0[threadIdx.x];
+            if (t == ntasks && sizes_host) sizes_host[1] = task_moff ? lm0[threadIdx.x] : 0ull;      // hit-history units of this search
+        }
+    }
+    // One record per slot (as slotmap_kernel), written as the workgroup's contiguous run of 16-byte words: word i belongs to
+    // slot s0 + i / 3 of the tile, whose entry is the last one that starts at or before it.
+    const uint32_t s0 = lfirst[0], s1 = lfirst[PLAN_SUB];
+    uint4 *out = reinterpret_cast<uint4 *>(slot_desc) + 3 * ((size_t)base_n + s0);
+    for (uint32_t i = threadIdx.x; i < 3u * (s1 - s0); i += 256u) {
+        const uint32_t sl = s0 + i / 3u, part3 = i % 3u;
+        uint32_t lo = 0u, hi = PLAN_SUB;         // largest k with lfirst[k] <= sl
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (lfirst[mid] <= sl) lo = mid;
+            else hi = mid;
+        }
+        const TaskDesc d = ldesc[lo];
+        const uint32_t q = sl - lfirst[lo], rps = d.flags >> 16, nch = (d.n2 + 63u) >> 6;
+        uint4 w;
+        if (part3 == 0u) w = make_uint4(d.a0, d.n1, d.b0, d.n2);
+        else if (part3 == 1u) w = make_uint4(d.cb, d.flags, q * rps, 0u);
+        else {
+            const unsigned long long mo = task_moff ? lm0[lo] + (unsigned long long)q * 2u * nch : lm0[lo];
+            w = make_uint4((uint32_t)mo, (uint32_t)(mo >> 32), 0u, 0u);
+        }
+        out[i] = w;
+    }
+    // slots between the real count and the host's bound: waves launched for them leave at once (every workgroup blanks its share)
+    if (total <= nslots_bound) {
+        uint4 *blank = reinterpret_cast<uint4 *>(slot_desc) + 3 * (size_t)total;
+        const uint64_t nw = 3ull * (nslots_bound + 1ull - total);
+        for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nw; i += (uint64_t)gridDim.x * 256u)
+            blank[i] = (i % 3ull == 2ull) ? make_uint4(0xFFFFFFFFu, 0x7FFFFFFFu, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+    }
 }
 
 template <class T>
@@ -1372,6 +1517,25 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
             params_dst = c->params.as<SearchParams>();
             c->params_fresh = true;
             c->params_fresh_cap = P.out_cap;
+        }
+        if (!c->on_side && c->ntasks + 1 <= FPLAN_MAX_TASKS) {
+            // main stream, a plan of at most 2^18 entries: plan and tile scan, then offsets and slot records - two launches, no chain
+            const uint32_t ntiles = (uint32_t)((c->ntasks + 1 + 255) / 256);
+            MH_TRY(c->fplan_tiles.reserve((size_t)ntiles * 16 + (c->ntasks + 1) * 8));
+            unsigned long long *moff = fast_kind ? c->task_moff.as<unsigned long long>() : nullptr;
+            unsigned long long *tt = c->fplan_tiles.as<unsigned long long>();
+            unsigned long long *lmoff = tt + 2 * (size_t)ntiles;           // offsets inside the tiles: hit-history units ...
+            uint32_t *lfirst = c->task_mu.as<uint32_t>();                  // ... and slots
+            if (c->kind == MOLAR_HIP_SEARCH_SINGLE)
+                hipLaunchKernelGGL((plan_tiles_kernel<MOLAR_HIP_SEARCH_SINGLE>), dim3(ntiles), dim3(256), 0, c->stream, P, lfirst,
+                                   c->task_desc.as<TaskDesc>(), lmoff, fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1, tt, params_dst);
+            else          // the three two-grid kinds decode tasks identically
+                hipLaunchKernelGGL((plan_tiles_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(ntiles), dim3(256), 0, c->stream, P, lfirst,
+                                   c->task_desc.as<TaskDesc>(), lmoff, fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1, tt, params_dst);
+            hipLaunchKernelGGL(plan_slots_kernel, dim3(ntiles * (256u / PLAN_SUB)), dim3(256), 0, c->stream, c->ntasks, ntiles, lfirst, lmoff, c->task_nb.as<uint32_t>(),
+                               c->task_desc.as<TaskDesc>(), moff, tt, c->slot_desc.as<SlotDesc>(), c->nslots_bound, c->sizes_dev);
+            MH_HIP(hipGetLastError());
+            return 0;
         }
         // ntasks + 1 threads (the last one writes the scan terminators); the same grid zeroes the slot counters and the
         // descriptors of the two look-back scans of this search
