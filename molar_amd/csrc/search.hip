@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
                                                           float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
                                                           float4 *__restrict__ aabb, float4 *__restrict__ perm,
                                                           float4 *__restrict__ chunk_aabb, uint4 *__restrict__ h16,
-                                                          float4 *__restrict__ cell_org, int big_elsewhere) {
+                                                          float4 *__restrict__ cell_org, int big_elsewhere, int want_order) {
     // One wave per workgroup (5 KB of LDS): the grid of the NEXT frame is built on the side stream while the fill pass of
     // the frame in flight holds every wave slot of the chip with one-wave workgroups.  A freed slot takes a one-wave
     // workgroup of either queue; a four-wave workgroup needs four free slots on ONE compute unit at the same moment and
@@ -302,7 +302,9 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
                     ez = fmaxf(hi[2] - org[2], org[2] - lo[2]);
         cell_org[c] = make_float4(org[0], org[1], org[2], 1.0001f * sqrtf((ex * ex + ey * ey) + ez * ez));
     }
-    if (n == 0 || !small) return;
+    // (want_order: the spatial order, the chunk boxes and the f16 records serve the count pass and the fused histogram of the
+    // fixed-cutoff kinds only - the vdW and `within` searches, grids of 1e5 cells of a few atoms, stop here)
+    if (n == 0 || !small || !want_order) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the records placed above are re-read by other lanes of this wave (same CU: no L2 write-back needed)
     __builtin_amdgcn_wave_barrier();
     uint32_t *hist = keys;                          // the sort keys are no longer needed
@@ -890,8 +892,12 @@ __global__ void __launch_bounds__(256) minmax_kernel(const float *__restrict__ x
     }
 }
 
-// vdw.iter().cloned().reduce(Float::max) (distance_search.rs:781-782)
-__global__ void __launch_bounds__(256) fmax_kernel(const float *__restrict__ v, uint32_t n, uint32_t *__restrict__ out) {
+// vdw.iter().cloned().reduce(Float::max) (distance_search.rs:781-782) of both sets in one launch (blockIdx.y: the set), one
+// atomic per workgroup (it was one per wave of up to 1024 workgroups per set: 4096 atomics on one word, 18 us per set)
+__global__ void __launch_bounds__(256) fmax_kernel(const float *__restrict__ v1, uint32_t n1, const float *__restrict__ v2, uint32_t n2,
+                                                   uint32_t *__restrict__ out) {
+    const float *v = blockIdx.y ? v2 : v1;
+    const uint32_t n = blockIdx.y ? n2 : n1;
     float m = -INFINITY;
     bool any = false;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
@@ -902,8 +908,19 @@ __global__ void __launch_bounds__(256) fmax_kernel(const float *__restrict__ v, 
         }
     }
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    const bool wave_any = __ballot(any) != 0ull;
-    if ((threadIdx.x & 63) == 0 && wave_any) atomicMax(out, f2ord(m));
+    __shared__ float wm[4];
+    __shared__ uint32_t wa[4];
+    if ((threadIdx.x & 63) == 0) {
+        wm[threadIdx.x >> 6] = m;
+        wa[threadIdx.x >> 6] = __ballot(any) != 0ull ? 1u : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && (wa[0] | wa[1] | wa[2] | wa[3])) {
+        float r = -INFINITY;
+        for (int w = 0; w < 4; ++w)
+            if (wa[w]) r = fmaxf(r, wm[w]);
+        atomicMax(out + blockIdx.y, f2ord(r));
+    }
 }
 
 // u32 (i,j) pairs -> separate usize arrays (Vec<(usize,usize,Float)> split by field)
@@ -1022,7 +1039,8 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         hipLaunchKernelGGL(place_order_kernel, dim3(ncells), dim3(64), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
                            S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<float4>(),
-                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>(), big ? 1 : 0);
+                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>(), big ? 1 : 0,
+                           (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1 : 0);
         if (big) {
             unsigned by = (S.n + 63u) / 64u;
             if (by > 2048u) by = 2048u;
@@ -1341,11 +1359,10 @@ int device_fmax2(molar_hip_ctx *c, const float *d_v1, uint32_t n1, const float *
     MH_TRY(c->hist.reserve(64));
     uint32_t *d = c->hist.as<uint32_t>();
     MH_HIP(hipMemsetAsync(d, 0, 8, c->stream));          // 0 is below every ordered float
-    unsigned nb1 = (n1 + 255u) / 256u, nb2 = (n2 + 255u) / 256u;
-    if (nb1 > 1024u) nb1 = 1024u;
-    if (nb2 > 1024u) nb2 = 1024u;
-    hipLaunchKernelGGL(fmax_kernel, dim3(nb1), dim3(256), 0, c->stream, d_v1, n1, d);
-    hipLaunchKernelGGL(fmax_kernel, dim3(nb2), dim3(256), 0, c->stream, d_v2, n2, d + 1);
+    unsigned nb = ((n1 > n2 ? n1 : n2) + 2047u) / 2048u;
+    if (nb > 128u) nb = 128u;
+    if (nb == 0u) nb = 1u;
+    hipLaunchKernelGGL(fmax_kernel, dim3(nb, 2), dim3(256), 0, c->stream, d_v1, n1, d_v2, n2, d);
     MH_HIP(hipGetLastError());
     uint32_t o[2];
     MH_TRY(read_back(c, o, d, 8));

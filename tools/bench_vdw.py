@@ -36,7 +36,10 @@ def main():
     orc = Oracle("f32")
     ncores = os.cpu_count() or 1
     rng = np.random.default_rng(5)
+    only = int(os.environ.get("BENCH_VDW_ONLY", "0"))          # one size only (kernel traces)
     for n, nsolute in ((100_000, 5_000), (1_000_000, 50_000)):
+        if only and n != only:
+            continue
         box = synth.box_a(n)
         pos = synth.frame(n, box, 1)
         centre = (box @ np.array([0.5, 0.5, 0.5], np.float32)).astype(np.float32)
