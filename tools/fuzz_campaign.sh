@@ -16,5 +16,6 @@ for r in $(seq 1 $N); do
   timeout 300 python tools/fuzz_fit.py 400 $((s + 7)) 2>&1 | tail -1 | tee -a $O/fit.log
   timeout 300 python tools/fuzz_measure.py 300 $((s + 8)) 2>&1 | tail -1 | tee -a $O/measure.log
   timeout 300 python tools/fuzz_measure_f64.py 300 $((s + 9)) 2>&1 | tail -1 | tee -a $O/measure_f64.log
+  timeout 600 python tools/fuzz_search_f64.py 600 $((s + 11)) 2>&1 | tail -1 | tee -a $O/search_f64.log
 done
 timeout 600 python tools/fuzz_search_large.py 2>&1 | tail -1 | tee -a $O/large.log
