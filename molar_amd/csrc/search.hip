@@ -2072,7 +2072,13 @@ static int resident_run(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::De
 int mh::search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, void *sizes_pinned, ResidentLaunch *L,
                                 const unsigned long long **total_dev, const uint32_t **pairs_dev) {
     std::memset(sizes_pinned, 0, 16);
-    MH_TRY(resident_enqueue(c, q, c->out_pairs, c->out_dist, sizes_pinned, L));
+    {   // the chained stages (the membrane's patches) read the (i, j) plane only
+        const bool keep = c->resident_no_dist;
+        c->resident_no_dist = true;
+        const int rc = resident_enqueue(c, q, c->out_pairs, c->out_dist, sizes_pinned, L);
+        c->resident_no_dist = keep;
+        MH_TRY(rc);
+    }
     c->have_search = false;              // the sizes are not known to the host: not a cached search for the fill calls
     *total_dev = L->degenerate ? nullptr : c->slot_base.as<unsigned long long>() + c->nslots_bound;
     *pairs_dev = c->out_pairs.as<uint32_t>();
@@ -2508,7 +2514,13 @@ int molar_hip_search_connectivity(molar_hip_ctx *c, const molar_hip_search_desc 
     c->have_conn = false;
     uint64_t npairs = 0;
     const uint32_t *d_pairs = nullptr;
-    MH_TRY(molar_hip_search_resident(c, q, &npairs, &d_pairs, nullptr));
+    {   // the lists hold ids only: the (i, j) plane alone (DistanceSearchOutput of (usize, usize), distance_search.rs:14-20)
+        const bool keep = c->resident_no_dist;
+        c->resident_no_dist = true;
+        const int rc = molar_hip_search_resident(c, q, &npairs, &d_pairs, nullptr);
+        c->resident_no_dist = keep;
+        MH_TRY(rc);
+    }
     const size_t nsel = q->idx1 ? q->n1 : q->natoms1;
     const uint64_t nrows = q->ids_local ? nsel : (q->idx1 ? q->natoms1 : nsel);
     if (nrows >= 0xFFFFFFF0ull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "search_connectivity: too many rows");
