@@ -186,13 +186,21 @@ struct molar_hip_ctx {
     // pipelined resident searches (molar_hip_search_resident_begin/_end): two result sets, two tickets
     struct Ticket {
         bool pending = false, degenerate = false;
-        unsigned long long cap0 = 0, maskcap0 = 0, serial = 0;
+        unsigned long long cap0 = 0, maskcap0 = 0, serial = 0, launched = 0, ntasks = 0;
+        int kind = -1;
         hipEvent_t done = nullptr;
         molar_hip_search_desc desc{};
     } tickets[2];
     int next_ticket = 0;
     bool resident_no_dist = false;          // molar_hip_search_resident_planes: the resident searches fill the (i, j) plane only
     unsigned long long search_serial = 0;   // counts resident searches enqueued on this context
+    // Resident searches launch their count and fill passes over the slots the plan of the SEARCH BEFORE came to (+ 3 % + 512)
+    // instead of the host's bound (14 N / 64 + entries: 13 % above the real count on the headline frame - 3.7e4 workgroups per
+    // pass that only find out they have nothing to do); the plan writes its real slot count beside the other sizes, and a
+    // search that needed more slots than were launched is repeated with the bound where its sizes are read.
+    unsigned long long trim_real = 0, trim_ntasks = 0;   // slots of the last resident search whose sizes were read, and its plan
+    int trim_kind = -1;
+    uint32_t slot_launch = 0;               // slots the passes of the resident search being enqueued launch (0: the bound)
     void *h_sizes = nullptr;                // pinned: 16 bytes of result sizes per ticket
     mh::DevBuf out_ids;
     mh::DevBuf wide_i, wide_j; // usize widening

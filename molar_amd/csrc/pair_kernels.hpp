@@ -1526,7 +1526,10 @@ static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, co
                                                       SlotDesc *__restrict__ slot_desc, uint64_t nslots_bound,
                                                       unsigned long long *__restrict__ sizes_host) {   // pinned, or NULL
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0 && sizes_host) sizes_host[1] = task_moff ? task_moff[ntasks] : 0ull;   // hit-history units of this search
+    if (t == 0 && sizes_host) {
+        sizes_host[1] = task_moff ? task_moff[ntasks] : 0ull;   // hit-history units of this search
+        sizes_host[2] = task_first[ntasks];                     // its slots
+    }
     if (t >= ntasks) {
         // slots between the real count and the host's bound: waves launched for them leave at once
         const uint64_t s = (uint64_t)task_first[ntasks] + (t - ntasks);

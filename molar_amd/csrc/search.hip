@@ -653,7 +653,10 @@ static __global__ void __launch_bounds__(256) plan_slots_kernel(uint64_t ntasks,
         if (t <= ntasks) {
             task_first[t] = base_n + lfirst[threadIdx.x];
             if (task_moff) task_moff[t] = lm0[threadIdx.x];
-            if (t == ntasks && sizes_host) sizes_host[1] = task_moff ? lm0[threadIdx.x] : 0ull;      // hit-history units of this search
+            if (t == ntasks && sizes_host) {
+                sizes_host[1] = task_moff ? lm0[threadIdx.x] : 0ull;      // hit-history units of this search
+                sizes_host[2] = base_n + lfirst[threadIdx.x];             // its slots
+            }
         }
     }
     // One record per slot (as slotmap_kernel), written as the workgroup's contiguous run of 16-byte words: word i belongs to
@@ -1246,7 +1249,8 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
         hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, c->stream, P, c->params.as<SearchParams>());
     const SearchParams *dP = c->params.as<SearchParams>();
     const SlotDesc *tf = c->slot_desc.as<SlotDesc>();
-    const uint32_t st = (uint32_t)c->nslots_bound;
+    uint32_t st = (uint32_t)c->nslots_bound;
+    if (c->slot_launch && !hist_nbins && c->slot_launch < st) P.nblocks = st = c->slot_launch;      // resident searches, see common.hpp
     uint32_t *sc = c->slot_cnt.as<uint32_t>();
     auto *sb = c->slot_base.as<unsigned long long>();
     const int mode = !FILL ? MODE_COUNT : (hist_nbins ? MODE_HIST : MODE_FILL);
@@ -2007,6 +2011,18 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     if (L->degenerate) return 0;
     const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
     L->maskcap0 = c->maskbuf.cap / 256u;
+    // slots the two passes are launched over: what the plan of the search before came to, with a margin (common.hpp, trim_real)
+    L->launched = c->nslots_bound;
+    L->ntasks = c->ntasks;
+    if (c->trim_real && c->trim_ntasks == c->ntasks && c->trim_kind == c->kind) {
+        const unsigned long long want = c->trim_real + c->trim_real / 32u + 512ull;
+        if (want < L->launched) L->launched = want;
+    }
+    c->slot_launch = (uint32_t)L->launched;
+    struct SlotLaunchReset {
+        molar_hip_ctx *c;
+        ~SlotLaunchReset() { c->slot_launch = 0u; }
+    } slot_launch_reset{c};
     // one parameter block serves both passes: the count pass ignores the output capacity
     MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, cap0));
     if (c->record_count_done) {
@@ -2023,9 +2039,26 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
         MH_HIP(hipMemcpyAsync(sizes, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8, hipMemcpyDeviceToHost, c->stream));
         if (fast_kind)
             MH_HIP(hipMemcpyAsync((char *)sizes + 8, c->task_moff.as<unsigned long long>() + c->ntasks, 8, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipMemcpyAsync((char *)sizes + 16, c->task_nb.as<uint32_t>() + c->ntasks, 4, hipMemcpyDeviceToHost, c->stream));   // (little-endian: the upper half was zeroed)
     }
     L->cap0 = cap0;
     return 0;
+}
+
+// The sizes of a resident search have been read: what its plan came to is the next search's launch size - and was this search
+// itself launched over enough slots?  If not (the frame before had fewer slots than this one less the margin), the next
+// enqueue of this plan launches the bound again.
+static bool resident_covered(molar_hip_ctx *c, const void *sizes, unsigned long long launched, unsigned long long ntasks, int kind) {
+    unsigned long long res[3] = {0, 0, 0};
+    std::memcpy(res, sizes, 24);
+    if (res[2] > launched) {
+        c->trim_real = 0;
+        return false;
+    }
+    c->trim_real = res[2];
+    c->trim_ntasks = ntasks;
+    c->trim_kind = kind;
+    return true;
 }
 
 // With `sizes` delivered and the search still the context's cached one: grow what was too small and repeat the
@@ -2060,9 +2093,16 @@ static int resident_settle(molar_hip_ctx *c, mh::DevBuf &outP, mh::DevBuf &outD,
 static int resident_run(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::DevBuf &outP, mh::DevBuf &outD) {
     MH_TRY(ensure_pinned(c, 64));
     ResidentLaunch L;
+    std::memset(c->h_pinned, 0, 32);
     MH_TRY(resident_enqueue(c, q, outP, outD, c->h_pinned, &L));
     if (L.degenerate) return 0;
     MH_HIP(hipStreamSynchronize(c->stream));
+    if (!resident_covered(c, c->h_pinned, L.launched, L.ntasks, c->kind)) {       // too few slots launched: once more, over the bound
+        std::memset(c->h_pinned, 0, 32);
+        MH_TRY(resident_enqueue(c, q, outP, outD, c->h_pinned, &L));
+        MH_HIP(hipStreamSynchronize(c->stream));
+        (void)resident_covered(c, c->h_pinned, L.launched, L.ntasks, c->kind);
+    }
     return resident_settle(c, outP, outD, c->h_pinned, L);
 }
 
@@ -2071,12 +2111,16 @@ static int resident_run(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::De
 // stages.hpp: the resident search for callers that chain device work behind it
 int mh::search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, void *sizes_pinned, ResidentLaunch *L,
                                 const unsigned long long **total_dev, const uint32_t **pairs_dev) {
-    std::memset(sizes_pinned, 0, 16);
-    {   // the chained stages (the membrane's patches) read the (i, j) plane only
+    std::memset(sizes_pinned, 0, 24);
+    {   // the chained stages (the membrane's patches) read the (i, j) plane only; their passes launch the bound (searches of 1e4
+        // markers: nothing to trim, and nobody reads the plan's size back in between)
         const bool keep = c->resident_no_dist;
+        const unsigned long long keep_trim = c->trim_real;
         c->resident_no_dist = true;
+        c->trim_real = 0;
         const int rc = resident_enqueue(c, q, c->out_pairs, c->out_dist, sizes_pinned, L);
         c->resident_no_dist = keep;
+        c->trim_real = keep_trim;
         MH_TRY(rc);
     }
     c->have_search = false;              // the sizes are not known to the host: not a cached search for the fill calls
@@ -2134,7 +2178,10 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     if (T.pending)
         return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "both result sets are in flight: call molar_hip_search_resident_end first");
     MH_HIP(hipSetDevice(c->device));
-    if (!c->h_sizes) MH_HIP(hipHostMalloc(&c->h_sizes, 64, hipHostMallocDefault));      // 32 bytes per ticket
+    if (!c->h_sizes) {
+        MH_HIP(hipHostMalloc(&c->h_sizes, 64, hipHostMallocDefault));      // 32 bytes per ticket
+        std::memset(c->h_sizes, 0, 64);
+    }
     if (!T.done) MH_HIP(hipEventCreateWithFlags(&T.done, hipEventDisableTiming));
     T.desc = *q;
     ResidentLaunch L;
@@ -2160,6 +2207,9 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     MH_HIP(hipEventRecord(T.done, c->stream));
     T.cap0 = L.cap0;
     T.maskcap0 = L.maskcap0;
+    T.launched = L.launched;
+    T.ntasks = L.ntasks;
+    T.kind = q->kind;
     T.degenerate = L.degenerate;
     T.serial = c->search_serial;
     T.pending = true;
@@ -2185,7 +2235,8 @@ int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *ou
         std::memcpy(res, sizes, 16);
         const bool fast_kind = T.desc.kind == MOLAR_HIP_SEARCH_SINGLE || T.desc.kind == MOLAR_HIP_SEARCH_DOUBLE;
         total = res[0];
-        if (res[0] > T.cap0 || (fast_kind && res[1] > T.maskcap0)) {
+        const bool covered = resident_covered(c, sizes, T.launched, T.ntasks, T.kind);
+        if (!covered || res[0] > T.cap0 || (fast_kind && res[1] > T.maskcap0)) {
             // A buffer was too small (first frames of a trajectory).  Let everything in flight finish - a younger
             // search owns the context's intermediate buffers by now, its results sit in the other result set - then
             // grow and repeat: the affected passes if this is still the context's cached search, else the frame.
@@ -2193,7 +2244,7 @@ int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *ou
             ResidentLaunch L;
             L.cap0 = T.cap0;
             L.maskcap0 = T.maskcap0;
-            if (T.serial != c->search_serial) {
+            if (T.serial != c->search_serial || !covered) {      // (not covered: the counts themselves are short - the whole frame again)
                 if (fast_kind && res[1] > c->maskbuf.cap / 256u)
                     MH_TRY(c->maskbuf.reserve((size_t)(res[1] + res[1] / 4u) * 256u + 256u));
                 if (res[0] > T.cap0) {
@@ -2201,9 +2252,11 @@ int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *ou
                     MH_TRY(outD.reserve((size_t)(res[0] + res[0] / 16u) * 4));
                 }
                 MH_TRY(ensure_pinned(c, 64));
+                std::memset(c->h_pinned, 0, 32);
                 MH_TRY(resident_enqueue(c, &T.desc, outP, outD, c->h_pinned, &L));
                 MH_HIP(hipStreamSynchronize(c->stream));
                 sizes = c->h_pinned;
+                (void)resident_covered(c, sizes, L.launched, L.ntasks, T.kind);      // (launched over the bound: covered)
             }
             MH_TRY(resident_settle(c, outP, outD, sizes, L));
             MH_HIP(hipStreamSynchronize(c->stream));

@@ -20,10 +20,12 @@ int enqueue_lipid_order(molar_hip_ctx *c, const float *xyz, const uint64_t *idx,
 // search.hip: the resident search (molar_hip_search_resident) without its wait.  Count, offset scan and fill go to the
 // context's result buffers against their present capacity; the number of results stays in device memory
 // (*total_dev, u64) for kernels enqueued behind it, and the two sizes the host needs to judge the capacities are
-// copied to `sizes_pinned` (16 bytes: results, hit-history units).
+// copied to `sizes_pinned` (24 bytes: results, hit-history units, slots of the plan).
 struct ResidentLaunch {
     unsigned long long cap0 = 0;      // result capacity the fill pass was launched with (0: the fill was skipped)
     unsigned long long maskcap0 = 0;  // hit-history units the count pass could record
+    unsigned long long launched = 0;  // slots the count and fill passes were launched over (the plan's real count must not exceed it)
+    unsigned long long ntasks = 0;    // entries of the search's plan
     bool degenerate = false;          // empty vdw input: nothing was enqueued, the result is empty
 };
 int search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, void *sizes_pinned, ResidentLaunch *L,

@@ -904,6 +904,44 @@ def test_pipelined_large_frames_privatised_binning():
     check(prev[0], e2.search_resident_end(prev[1]))
 
 
+def test_resident_launch_follows_the_previous_plan_and_repeats_when_short():
+    """Resident searches launch their passes over the slots the plan of the search before came to (+ 3 % + 512) instead of the
+    host's bound; a frame that needs more slots than that - same box, same grid, twice the atoms - is repeated over the bound
+    where its sizes are read (molar_hip_search_resident, and _end with a younger search in flight).  Every result against
+    count + fill on another context, order-sensitive."""
+    import torch
+    a = api()
+    from molar_amd.api import Engine
+    e1, e2 = Engine(0), Engine(0)
+    nA, nB = 120_000, 260_000
+    box = synth.box_a(nB)
+    rng = np.random.default_rng(41)
+    fa = torch.from_numpy((rng.random((nA, 3)) @ box.astype(np.float64).T).astype(np.float32)).cuda()
+    fb = torch.from_numpy((rng.random((nB, 3)) @ box.astype(np.float64).T).astype(np.float32)).cuda()
+    frames = {"A": fa, "B": fb}
+    descs = {k: e2.make_search_desc(a.SEARCH_SINGLE, 1.0, f, box=box, pbc=7) for k, f in frames.items()}
+
+    def check(k, res):
+        cnt, pp, dp = res
+        wn = e1.search_count(a.SEARCH_SINGLE, 1.0, frames[k], box=box, pbc=7)
+        assert cnt == wn > 0, k
+        wp, wd = e1.search_fill_device()
+        e1.synchronize()
+        assert torch.equal(a.device_view(pp, (cnt, 2), torch.int32), a.device_view(wp, (cnt, 2), torch.int32)), k
+        assert torch.equal(a.device_view(dp, (cnt,), torch.float32), a.device_view(wd, (cnt,), torch.float32)), k
+
+    for k in "ABABBA":                       # B after A needs 2.2 x the slots A's plan came to
+        check(k, e2.search_resident_desc(descs[k][0]))
+    order = "AABBABAAB"
+    prev = None
+    for k in order:
+        t = e2.search_resident_begin(descs[k][0])
+        if prev is not None:
+            check(prev[0], e2.search_resident_end(prev[1]))
+        prev = (k, t)
+    check(prev[0], e2.search_resident_end(prev[1]))
+
+
 def test_randomised_differential(monkeypatch):
     """tools/fuzz_search.py: random boxes / cutoffs / densities / periodicity masks / selections / kinds, count+fill and
     resident entries, against the oracle - every case bit-identical (9000 cases were run this way in round 1)."""
