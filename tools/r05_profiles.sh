@@ -13,4 +13,7 @@ python bench.py --workload membrane --steps 200 --warmup 10 --streams 1 2>/dev/n
 python tools/bench_configs.py 2>/dev/null > $O/bench_configs.jsonl
 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2>/dev/null
 bash tools/r04_timeline.sh r05 > $O/timeline.txt 2>&1
+# what comes back through gpurun_out/ is capped at 64 MiB: the per-dispatch traces are not needed once the summaries exist
+find $R/gpurun_out -name "*kernel_trace.csv" -delete; find $R/gpurun_out -name "*.db" -delete; find $R/gpurun_out -name "*_agent_info.csv" -delete
+du -sh $R/gpurun_out | tail -1
 tail -n 3 $O/profile_bench.log; cut -c1-300 $O/membrane_bench.json; cut -c1-200 $O/bench_steps20.json
