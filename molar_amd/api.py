@@ -340,8 +340,8 @@ class Engine:
         rows, ent = C.c_uint64(0), C.c_uint64(0)
         check(self.lib.molar_hip_search_connectivity(self.ctx, C.byref(d), C.byref(rows), C.byref(ent)))
         self._keep = keep
-        off = np.zeros(rows.value + 1, np.uint64)
-        nb = np.zeros(max(ent.value, 1), np.uint64)
+        off = np.empty(rows.value + 1, np.uint64)
+        nb = np.empty(max(ent.value, 1), np.uint64)
         check(self.lib.molar_hip_search_connectivity_fill(self.ctx, off.ctypes.data, nb.ctypes.data))
         return off, nb[:ent.value]
 

@@ -1652,41 +1652,36 @@ int finish_count(molar_hip_ctx *c) {
 // earlier pairs (a pair feeds a list at most once per side; the entry of its i side precedes that of its j side when i == j
 // never happens: the single searches emit i != j).  Lists are a handful of bonded neighbours long, so the ranking reads its
 // own list; the result is the reference's push order exactly.
-__global__ void __launch_bounds__(256) conn_degree_kernel(const uint2 *__restrict__ pairs, unsigned long long npairs, uint32_t *__restrict__ deg) {
+// SearchConnectivity::from_iter (connectivity.rs:19-35): pair p pushes j onto i's list (entry 2p), then i onto j's (entry 2p + 1).
+// A list in push order is the entries of its row in entry order: a STABLE sort of the entries by row (devsort.hip).  (Until the end
+// of round 5: atomics into buckets, then every entry ranked against its whole list - quadratic in the list length, 10 ms of an
+// 11 ms call for 25k atoms at rc 1.0 nm, 420 entries per list.)
+__global__ void __launch_bounds__(256) conn_entries_kernel(const uint2 *__restrict__ pairs, unsigned long long npairs, uint32_t *__restrict__ row,
+                                                           uint32_t *__restrict__ nb) {
     const unsigned long long p = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
     if (p >= npairs) return;
     const uint2 ij = pairs[p];
-    atomicAdd(&deg[ij.x], 1u);
-    atomicAdd(&deg[ij.y], 1u);
+    reinterpret_cast<uint2 *>(row)[p] = make_uint2(ij.x, ij.y);
+    reinterpret_cast<uint2 *>(nb)[p] = make_uint2(ij.y, ij.x);
 }
 
-__global__ void __launch_bounds__(256) conn_bucket_kernel(const uint2 *__restrict__ pairs, unsigned long long npairs,
-                                                          const unsigned long long *__restrict__ off, uint32_t *__restrict__ cursor,
-                                                          unsigned long long *__restrict__ ent) {
-    const unsigned long long p = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
-    if (p >= npairs) return;
-    const uint2 ij = pairs[p];
-    // entry = (sequence number of the push << 32) | neighbour: pair p pushes j onto i's list (2p), then i onto j's (2p + 1)
-    ent[off[ij.x] + atomicAdd(&cursor[ij.x], 1u)] = ((2ull * p) << 32) | ij.y;
-    ent[off[ij.y] + atomicAdd(&cursor[ij.y], 1u)] = ((2ull * p + 1ull) << 32) | ij.x;
-}
-
-__global__ void __launch_bounds__(256) conn_rank_kernel(const unsigned long long *__restrict__ ent, const unsigned long long *__restrict__ off,
-                                                        uint32_t nrows, unsigned long long nent, unsigned long long *__restrict__ neigh) {
-    // one thread per entry; its list is found by bisection over the offsets
-    const unsigned long long e = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
-    if (e >= nent) return;
-    uint32_t lo = 0u, hi = nrows;                       // off[lo] <= e < off[hi]
-    while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (off[mid] <= e) lo = mid;
+// off[r] = first sorted entry with row >= r, r = 0 .. nrows (off[nrows] = number of entries)
+__global__ void __launch_bounds__(256) conn_offsets_kernel(const uint32_t *__restrict__ row_sorted, unsigned long long nent, uint32_t nrows,
+                                                           unsigned long long *__restrict__ off) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r > nrows) return;
+    unsigned long long lo = 0, hi = nent;
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        if (row_sorted[mid] < r) lo = mid + 1;
         else hi = mid;
     }
-    const unsigned long long a = off[lo], b = off[lo + 1];
-    const unsigned long long mine = ent[e];
-    unsigned long long rank = 0;
-    for (unsigned long long q = a; q < b; ++q) rank += (ent[q] >> 32) < (mine >> 32) ? 1ull : 0ull;
-    neigh[a + rank] = mine & 0xFFFFFFFFull;
+    off[r] = lo;
+}
+
+__global__ void __launch_bounds__(256) conn_widen_kernel(const uint32_t *__restrict__ nb_sorted, unsigned long long nent, unsigned long long *__restrict__ neigh) {
+    const unsigned long long e = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (e < nent) neigh[e] = nb_sorted[e];
 }
 
 // ================================================================= `within` as a set (selection/ast.rs:589-631)
@@ -2580,22 +2575,22 @@ int molar_hip_search_connectivity(molar_hip_ctx *c, const molar_hip_search_desc 
     const uint64_t nrows = q->ids_local ? nsel : (q->idx1 ? q->natoms1 : nsel);
     if (nrows >= 0xFFFFFFF0ull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "search_connectivity: too many rows");
     const uint64_t nent = 2ull * npairs;
-    MH_TRY(c->conn_deg.reserve((nrows + 1) * 4 * 2));            // degrees, then the cursors
+    if (nent >= 0x7FFFFFFFull) return fail(MOLAR_HIP_ERR_TOO_LARGE, "search_connectivity: %llu list entries", (unsigned long long)nent);
     MH_TRY(c->conn_off.reserve((nrows + 1) * 8));
-    MH_TRY(c->conn_ent.reserve((nent ? nent : 1) * 8));
+    MH_TRY(c->conn_ent.reserve((nent ? nent : 1) * 16));           // four u32 arrays: rows and neighbours, unsorted and sorted
     MH_TRY(c->conn_neigh.reserve((nent ? nent : 1) * 8));
-    uint32_t *deg = c->conn_deg.as<uint32_t>(), *cursor = deg + (nrows + 1);
-    MH_HIP(hipMemsetAsync(deg, 0, (nrows + 1) * 8, c->stream));
+    uint32_t *row_in = c->conn_ent.as<uint32_t>(), *nb_in = row_in + nent, *row_out = nb_in + nent, *nb_out = row_out + nent;
     const unsigned nbP = (unsigned)((npairs + 255) / 256), nbE = (unsigned)((nent + 255) / 256);
     const uint2 *pairs = reinterpret_cast<const uint2 *>(d_pairs);
-    if (nbP) hipLaunchKernelGGL(conn_degree_kernel, dim3(nbP), dim3(256), 0, c->stream, pairs, (unsigned long long)npairs, deg);
-    MH_TRY((exclusive_scan<uint32_t, unsigned long long>(c, deg, c->conn_off.as<unsigned long long>(), nrows + 1)));
     if (nbP) {
-        hipLaunchKernelGGL(conn_bucket_kernel, dim3(nbP), dim3(256), 0, c->stream, pairs, (unsigned long long)npairs,
-                           c->conn_off.as<unsigned long long>(), cursor, c->conn_ent.as<unsigned long long>());
-        hipLaunchKernelGGL(conn_rank_kernel, dim3(nbE), dim3(256), 0, c->stream, c->conn_ent.as<unsigned long long>(), c->conn_off.as<unsigned long long>(),
-                           (uint32_t)nrows, (unsigned long long)nent, c->conn_neigh.as<unsigned long long>());
+        hipLaunchKernelGGL(conn_entries_kernel, dim3(nbP), dim3(256), 0, c->stream, pairs, (unsigned long long)npairs, row_in, nb_in);
+        int end_bit = 1;
+        while (end_bit < 32 && (nrows >> end_bit)) ++end_bit;
+        MH_TRY(device_sort_pairs_u32(c, c->conn_deg, row_in, row_out, nb_in, nb_out, (size_t)nent, end_bit));
+        hipLaunchKernelGGL(conn_widen_kernel, dim3(nbE), dim3(256), 0, c->stream, nb_out, (unsigned long long)nent, c->conn_neigh.as<unsigned long long>());
     }
+    hipLaunchKernelGGL(conn_offsets_kernel, dim3((unsigned)((nrows + 1 + 255) / 256)), dim3(256), 0, c->stream, row_out, (unsigned long long)nent,
+                       (uint32_t)nrows, c->conn_off.as<unsigned long long>());
     MH_HIP(hipGetLastError());
     c->conn_rows = nrows;
     c->conn_entries = nent;
@@ -2609,7 +2604,17 @@ int molar_hip_search_connectivity_fill(molar_hip_ctx *c, uint64_t *offsets, uint
     if (!c || !c->have_conn) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached connectivity: call molar_hip_search_connectivity first");
     MH_HIP(hipSetDevice(c->device));
     if (offsets) MH_HIP(hipMemcpyAsync(offsets, c->conn_off.p, (c->conn_rows + 1) * 8, hipMemcpyDefault, c->stream));
-    if (neigh && c->conn_entries) MH_HIP(hipMemcpyAsync(neigh, c->conn_neigh.p, c->conn_entries * 8, hipMemcpyDefault, c->stream));
+    if (neigh && c->conn_entries) {
+        // large lists into ordinary host memory: the pinned ring and its host threads (hoststream.hpp), as the pair lists travel
+        // (25k atoms at rc 1.0 nm: 83 MB of neighbours, 11 ms through the runtime's pageable copy)
+        if (!is_device_ptr(neigh) && ring_pays(c->conn_entries * 8, neigh)) {
+            MH_HIP(hipStreamSynchronize(c->stream));
+            std::vector<RingJob> jobs;
+            jobs.push_back(RingJob{c->conn_neigh.p, (size_t)c->conn_entries * 8, RING_COPY, neigh, nullptr});
+            return ring_to_host(c, jobs);
+        }
+        MH_HIP(hipMemcpyAsync(neigh, c->conn_neigh.p, c->conn_entries * 8, hipMemcpyDefault, c->stream));
+    }
     MH_HIP(hipStreamSynchronize(c->stream));
     return MOLAR_HIP_OK;
 }

@@ -28,8 +28,7 @@
 #include "boxmath64.hpp"
 #include "common.hpp"
 #include "hoststream.hpp"
-
-#include <hipcub/hipcub.hpp>
+#include "stages.hpp"
 
 using namespace mh;
 
@@ -320,10 +319,6 @@ __global__ void __launch_bounds__(256) slots64_kernel(GridP G, uint64_t ntasks, 
         slots[first + q] = s;
     }
 }
-
-struct U32ToU64 {
-    __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; }
-};
 
 struct Params64 {
     const double *posA, *posB, *vdwA, *vdwB;
@@ -679,12 +674,8 @@ static int build_grid64(molar_hip_ctx *c, molar_hip_search64_state &Z, const Set
                        Z.pos3.as<double>(), err_dev);
     int end_bit = 1;
     while (end_bit < 32 && (2ull * G.ncells) >> end_bit) ++end_bit;            // keys 0 .. 2 * ncells
-    size_t tmp_bytes = 0;
-    MH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, Z.key_in.as<uint32_t>(), Z.key_out.as<uint32_t>(), Z.val_in.as<uint32_t>(),
-                                              Z.val_out.as<uint32_t>(), (int)n, 0, end_bit, c->stream));
-    MH_TRY(Z.cub_tmp.reserve(tmp_bytes ? tmp_bytes : 8));
-    MH_HIP(hipcub::DeviceRadixSort::SortPairs(Z.cub_tmp.p, tmp_bytes, Z.key_in.as<uint32_t>(), Z.key_out.as<uint32_t>(), Z.val_in.as<uint32_t>(),
-                                              Z.val_out.as<uint32_t>(), (int)n, 0, end_bit, c->stream));
+    MH_TRY(device_sort_pairs_u32(c, Z.cub_tmp, Z.key_in.as<uint32_t>(), Z.key_out.as<uint32_t>(), Z.val_in.as<uint32_t>(), Z.val_out.as<uint32_t>(),
+                                 n, end_bit));
     hipLaunchKernelGGL(gather64_kernel, dim3(nb), dim3(256), 0, c->stream, S, n, G.ncells, Z.key_out.as<uint32_t>(), Z.val_out.as<uint32_t>(),
                        Z.pos3.as<double>(), pos.as<double>(), id.as<unsigned long long>(), S.vdw ? vdw.as<double>() : nullptr);
     hipLaunchKernelGGL(cellstart64_kernel, dim3((G.ncells + 1u + 255u) / 256u), dim3(256), 0, c->stream, Z.key_out.as<uint32_t>(), n, G.ncells,
@@ -836,12 +827,7 @@ int molar_hip_search_count_f64(molar_hip_ctx *c, const molar_hip_search_desc_f64
     MH_TRY(Z.task_first.reserve((ntasks + 1) * 4));
     hipLaunchKernelGGL(plan64_kernel, dim3((unsigned)((ntasks + 1 + 255) / 256)), dim3(256), 0, c->stream, G, ntasks, mult, startA, startB,
                        Z.task_ns.as<uint32_t>());
-    {
-        size_t tmp_bytes = 0;
-        MH_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, Z.task_ns.as<uint32_t>(), Z.task_first.as<uint32_t>(), (int)(ntasks + 1), c->stream));
-        MH_TRY(Z.cub_tmp.reserve(tmp_bytes ? tmp_bytes : 8));
-        MH_HIP(hipcub::DeviceScan::ExclusiveSum(Z.cub_tmp.p, tmp_bytes, Z.task_ns.as<uint32_t>(), Z.task_first.as<uint32_t>(), (int)(ntasks + 1), c->stream));
-    }
+    MH_TRY(device_exclusive_sum_u32(c, Z.cub_tmp, Z.task_ns.as<uint32_t>(), Z.task_first.as<uint32_t>(), ntasks + 1));
     struct { uint32_t nslots; int err; } hs = {0, 0};
     MH_HIP(hipMemcpyAsync(&hs.nslots, Z.task_first.as<uint32_t>() + ntasks, 4, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipMemcpyAsync(&hs.err, err_dev, 4, hipMemcpyDeviceToHost, c->stream));
@@ -909,13 +895,7 @@ int molar_hip_search_count_f64(molar_hip_ctx *c, const molar_hip_search_desc_f64
                kind, use_box ? 1 : 0, cutoff * cutoff, Z.approx ? 1 : 0, Z.band_lo, Z.band_hi, (two ? Z.aabbB : Z.aabbA).as<double>(), Z.prune_limit2};
     launch_pair64<false>(kind, grid_of(Z.nslots), c->stream, P, Z.slot_cnt.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
     MH_HIP(hipGetLastError());
-    {
-        hipcub::TransformInputIterator<unsigned long long, U32ToU64, const uint32_t *> in(Z.slot_cnt.as<uint32_t>(), U32ToU64());
-        size_t tmp_bytes = 0;
-        MH_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, Z.slot_base.as<unsigned long long>(), (int)(Z.nslots + 1), c->stream));
-        MH_TRY(Z.cub_tmp.reserve(tmp_bytes ? tmp_bytes : 8));
-        MH_HIP(hipcub::DeviceScan::ExclusiveSum(Z.cub_tmp.p, tmp_bytes, in, Z.slot_base.as<unsigned long long>(), (int)(Z.nslots + 1), c->stream));
-    }
+    MH_TRY(device_exclusive_sum_u32_u64(c, Z.cub_tmp, Z.slot_cnt.as<uint32_t>(), Z.slot_base.as<unsigned long long>(), (size_t)Z.nslots + 1));
     unsigned long long run = 0;
     MH_HIP(hipMemcpyAsync(&run, Z.slot_base.as<unsigned long long>() + Z.nslots, 8, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));

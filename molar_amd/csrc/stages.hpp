@@ -34,4 +34,10 @@ int search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, vo
 // enqueued again
 int search_resident_fits(molar_hip_ctx *c, const void *sizes_pinned, const ResidentLaunch &L, bool *fits);
 
+// devsort.hip: stable radix sort of (u32, u32) pairs by the keys' low `end_bit` bits, exclusive prefix sums (rocPRIM)
+int device_sort_pairs_u32(molar_hip_ctx *c, DevBuf &tmp, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
+                          uint32_t *vals_out, size_t n, int end_bit);
+int device_exclusive_sum_u32(molar_hip_ctx *c, DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n);
+int device_exclusive_sum_u32_u64(molar_hip_ctx *c, DevBuf &tmp, const uint32_t *in, unsigned long long *out, size_t n);
+
 }  // namespace mh
