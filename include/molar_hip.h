@@ -193,7 +193,8 @@ int molar_hip_within_hold(molar_hip_ctx *ctx, int on);
  * (desc->ids_local): the selection's length; global ids: natoms - with every list in the reference's push order; an atom
  * without a pair has an empty list (the reference's map has no key for it).  Count-then-fill like the searches: the first
  * call runs the search (the request must be of kind MOLAR_HIP_SEARCH_SINGLE), builds the CSR in context-owned device memory
- * and returns rows and entries (= 2 x pairs); the second copies offsets[rows + 1] and neigh[entries] to host or device memory. */
+ * and returns rows and entries (= 2 x pairs, < 2^31: MOLAR_HIP_ERR_TOO_LARGE beyond); the second copies offsets[rows + 1] and
+ * neigh[entries] to host or device memory. */
 int molar_hip_search_connectivity(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, uint64_t *out_rows, uint64_t *out_entries);
 int molar_hip_search_connectivity_fill(molar_hip_ctx *ctx, uint64_t *offsets, uint64_t *neigh);
 /* Modify::unwrap_connectivity_dim (molar/src/modify.rs:72-131): neighbour search of the selection with local ids under
