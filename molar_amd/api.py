@@ -369,11 +369,12 @@ class Engine:
 
     # ------------------------------------------------------------ search, f64 build of MolAR (Float = f64)
     def search_f64(self, kind, cutoff, xyz1, idx1=None, xyz2=None, idx2=None, box=None, pbc=0, vdw1=None, vdw2=None,
-                   ids_local=False, lower=None, upper=None, device_out=False):
+                   ids_local=False, lower=None, upper=None, device_out=False, out=None):
         """The distance_search drivers with every operation in double (molar_hip_search_count_f64 + fill): returns
         (i, j, d) as uint64 / uint64 / float64 arrays in the reference's order, or the uint64 ids for SEARCH_WITHIN.
         Coordinates, indices and radii may be torch tensors in HBM (used in place); device_out=True leaves the result
-        there too (int64 / int64 / float64 tensors)."""
+        there too (int64 / int64 / float64 tensors); `out` = (i, j, d) device tensors of at least the result's length to fill
+        instead of fresh ones (views of the result's length are returned)."""
         def f64(a):
             if a is None:
                 return None
@@ -419,8 +420,13 @@ class Engine:
                 if n:
                     check(self.lib.molar_hip_search_fill_ids_f64(self.ctx, ids.data_ptr()))
                 return ids
-            i = torch.empty(n, dtype=torch.int64, device=dev); j = torch.empty(n, dtype=torch.int64, device=dev)
-            dist = torch.empty(n, dtype=torch.float64, device=dev)
+            if out is not None:
+                if min(len(out[0]), len(out[1]), len(out[2])) < n:
+                    raise ValueError("search_f64: `out` tensors are shorter than the result")
+                i, j, dist = out[0][:n], out[1][:n], out[2][:n]
+            else:
+                i = torch.empty(n, dtype=torch.int64, device=dev); j = torch.empty(n, dtype=torch.int64, device=dev)
+                dist = torch.empty(n, dtype=torch.float64, device=dev)
             if n:
                 check(self.lib.molar_hip_search_fill_f64(self.ctx, i.data_ptr(), j.data_ptr(), dist.data_ptr()))
             return i, j, dist

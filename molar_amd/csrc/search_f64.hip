@@ -197,19 +197,25 @@ __global__ void __launch_bounds__(256) cellstart64_kernel(const uint32_t *__rest
     start[c] = lo;
 }
 
-// bounding box of every cell's items (row pruning of the pair kernels)
+// bounding box of every cell's items (row pruning of the pair kernels): one wave per cell
 __global__ void __launch_bounds__(256) aabb64_kernel(const uint32_t *__restrict__ start, uint32_t ncells, const double *__restrict__ pos,
                                                      double *__restrict__ aabb) {
-    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (c >= ncells) return;
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t k = start[c]; k < start[c + 1]; ++k)
+    for (uint32_t k = start[c] + lane; k < start[c + 1]; k += 64u)
         for (int d = 0; d < 3; ++d) {
             const double v = pos[3 * (size_t)k + d];
             lo[d] = fmin(lo[d], v);
             hi[d] = fmax(hi[d], v);
         }
-    for (int d = 0; d < 3; ++d) { aabb[6 * (size_t)c + d] = lo[d]; aabb[6 * (size_t)c + 3 + d] = hi[d]; }
+    for (int d = 0; d < 3; ++d)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fmin(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = fmax(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+    if (lane == 0)
+        for (int d = 0; d < 3; ++d) { aabb[6 * (size_t)c + d] = lo[d]; aabb[6 * (size_t)c + 3 + d] = hi[d]; }
 }
 
 // compute_min_max (:602-616, seeded with zeros) over the selected atoms: per-workgroup partials {lo[3], hi[3]}
@@ -819,7 +825,7 @@ int molar_hip_search_count_f64(molar_hip_ctx *c, const molar_hip_search_desc_f64
     {   // bounding boxes of the second grid's cells
         DevBuf &bb = two ? Z.aabbB : Z.aabbA;
         MH_TRY(bb.reserve((size_t)G.ncells * 48));
-        hipLaunchKernelGGL(aabb64_kernel, dim3((G.ncells + 255u) / 256u), dim3(256), 0, c->stream, startB, G.ncells,
+        hipLaunchKernelGGL(aabb64_kernel, dim3((G.ncells + 3u) / 4u), dim3(256), 0, c->stream, startB, G.ncells,
                            (two ? Z.posB : Z.posA).as<double>(), bb.as<double>());
     }
     const uint64_t ntasks = (uint64_t)G.ncells * 14ull * mult;
