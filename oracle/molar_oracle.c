@@ -457,6 +457,7 @@ static plan_item *search_plan(const grid_t *g1, const grid_t *g2, uint8_t pbc, s
 
 typedef struct {
     size_t n, cap;
+    size_t cap_jd;         /* entries the j / d planes hold: a `within` search grows the i plane alone */
     uint64_t *i, *j;
     REAL *d;
     int with_jd;
@@ -469,6 +470,7 @@ static inline void pv_push(pvec *v, uint64_t i, uint64_t j, REAL d) {
         if (v->with_jd) {
             v->j = (uint64_t *)realloc(v->j, nc * sizeof(uint64_t));
             v->d = (REAL *)realloc(v->d, nc * sizeof(REAL));
+            v->cap_jd = nc;
         }
         v->cap = nc;
     }
@@ -553,10 +555,11 @@ static pvec *arena_pool(int nt) {
     }
     return g_arena;
 }
-static void arena_want_jd(pvec *v) {          /* an arena last used by a `within` search has no j / d planes yet */
-    if (v->with_jd && v->cap && !v->j) {
-        v->j = (uint64_t *)malloc(v->cap * sizeof(uint64_t));
-        v->d = (REAL *)malloc(v->cap * sizeof(REAL));
+static void arena_want_jd(pvec *v) {          /* an arena a `within` search has used (and grown) has no, or too short, j / d planes */
+    if (v->with_jd && v->cap_jd < v->cap) {
+        v->j = (uint64_t *)realloc(v->j, v->cap * sizeof(uint64_t));
+        v->d = (REAL *)realloc(v->d, v->cap * sizeof(REAL));
+        v->cap_jd = v->cap;
     }
 }
 static struct { uint64_t *i, *j; REAL *d; size_t cap_i, cap_jd; int busy; } g_res;

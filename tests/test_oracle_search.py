@@ -185,3 +185,43 @@ def test_small_grid_duplicates(orc32):
     assert got["dims"] == (2, 2, 2)
     gp, _ = norm_pairs(got)
     assert len(np.unique(gp, axis=0)) < len(gp)
+
+
+def test_arenas_survive_a_within_search_between_two_pair_searches():
+    """The restatement keeps one result arena per thread between calls.  A `within` search grows an arena's id plane alone; the
+    pair search after it must find (or make) j / d planes of the same length - until round 5 it wrote past planes a smaller
+    pair search had left (heap corruption: `double free or corruption` in tools/fuzz_search.py on a 256-core box).  Run in a
+    process of its own with glibc's heap checks on: small pair search, `within` with 2.6e5 ids, pair search with 2e6 results,
+    the last one twice and against brute force on a sample."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from oracle.oracle import Oracle
+        o = Oracle("f32")
+        rng = np.random.default_rng(3)
+        box = np.diag([6.0, 6.0, 6.0]).astype(np.float32)
+        ob = o.box_from_matrix(box)
+        small = (rng.random((300, 3)) * 6).astype(np.float32)
+        big = (rng.random((20000, 3)) * 6).astype(np.float32)
+        for nt in (1, 4):
+            r1 = o.search_single_pbc(0.5, small, ob, 7, nthreads=nt)
+            i1 = np.arange(len(big), dtype=np.uint64); i2 = np.arange(0, len(big), 7, dtype=np.uint64)
+            r2 = o.search_within_pbc(1.0, big, big[::7], ob, 7, i1, i2, nthreads=nt)
+            r3 = o.search_single_pbc(0.8, big, ob, 7, nthreads=nt)
+            r4 = o.search_single_pbc(0.8, big, ob, 7, nthreads=nt)
+            assert len(r2["i"]) > 100000 and len(r3["i"]) > 1000000
+            assert np.array_equal(r3["i"], r4["i"]) and np.array_equal(r3["j"], r4["j"]) and np.array_equal(r3["d"], r4["d"])
+            sel = rng.choice(len(r3["i"]), 2000, replace=False)
+            d = big[r3["j"][sel].astype(int)].astype(np.float64) - big[r3["i"][sel].astype(int)]
+            d -= 6.0 * np.round(d / 6.0)
+            assert np.allclose(np.sqrt((d * d).sum(1)), r3["d"][sel], atol=1e-5) and (r3["d"][sel] <= 0.8).all()
+        print("ok")
+    """ % root)
+    env = dict(os.environ, MALLOC_CHECK_="3")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
