@@ -172,3 +172,27 @@ def test_errors_f64(eng):
         eng.search_f64(a.SEARCH_WITHIN, 0.5, pos, None, pos, None)          # needs lower / upper without a box
     i, j, d = eng.search_f64(a.SEARCH_SINGLE, 0.01, pos[:1])                # one atom: nothing to pair
     assert len(i) == 0
+
+
+@pytest.mark.timeout(900)
+def test_f64_half_a_million_atoms_against_the_f64_oracle(eng, orc64):
+    """The f64 single-selection search at 500k atoms (triclinic box A, rc 1.0 nm, ~1e8 results): grid by the stable device sort,
+    plan and scans on the device, bounding-box row pruning, adjacent-image classification, LDS output queue - ids, order and
+    distances bit for bit against the f64 oracle on the box's host cores, frame and result resident in HBM."""
+    import os
+    import torch
+    import molar_amd.api as a
+    n, rc = 500_000, 1.0
+    box = synth.box_a(n).astype(np.float64)
+    pos = synth.frame(n, synth.box_a(n), 3).astype(np.float64)
+    pos += np.random.default_rng(2).normal(0, 1e-9, pos.shape)                  # digits an f32 frame does not have
+    ob = orc64.box_from_matrix(box)
+    ref = orc64.search_single_pbc(rc, pos, ob, 7, nthreads=min(os.cpu_count() or 4, 64))
+    dpos = torch.from_numpy(pos).cuda()
+    i, j, d = eng.search_f64(a.SEARCH_SINGLE, rc, dpos, box=box, pbc=7, device_out=True)
+    assert len(i) == len(ref["i"]) > 5e7 and eng.grid_dims_f64() == tuple(int(x) for x in ref["dims"])
+    step = 1 << 24
+    for k in range(0, len(i), step):
+        assert np.array_equal(i[k:k + step].cpu().numpy().view(np.uint64), ref["i"][k:k + step]), k
+        assert np.array_equal(j[k:k + step].cpu().numpy().view(np.uint64), ref["j"][k:k + step]), k
+        assert np.array_equal(d[k:k + step].cpu().numpy(), ref["d"][k:k + step]), k
