@@ -99,6 +99,7 @@ struct GridSet {
     DevBuf cnt_pad;            // cell counters at one per 128-byte line while binning (crowded grids)
     DevBuf cursor;             // u32 per atom: arrival order inside its cell
     DevBuf tmp_key;            // u32 per kept atom (unsorted inside the cell)
+    DevBuf sort_buf;           // grids of large cells: keys and atom numbers, unsorted and sorted (4 x u32 per atom; devsort.hip)
     DevBuf sorted;             // float4 {x,y,z,id-bits} in reference cell order
     DevBuf sorted_vdw;         // float per sorted atom (vdw searches)
     DevBuf aabb;               // float4 lo/hi per cell
@@ -177,6 +178,7 @@ struct molar_hip_ctx {
     unsigned long long params_fresh_cap = 0;   // ... written with this output capacity
     unsigned long long *sizes_dev = nullptr;   // resident searches: device-side address of the pinned 16 bytes the kernels write the two sizes to
     mh::DevBuf scan_tmp;       // block sums for the scans
+    mh::DevBuf sort_tmp;       // scratch of the device sort (devsort.hip)
     mh::DevBuf scan_state;     // ticket + tile descriptors of the single-pass scans (zeroed by the plan kernel)
     mh::DevBuf fplan_tiles;    // plan_tiles_kernel -> plan_slots_kernel: slot / hit-history totals per tile of 256 plan entries
     mh::DevBuf out_pairs_set[2];   // ctx-owned result buffers (device-resident results / host staging); the second

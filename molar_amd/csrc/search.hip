@@ -202,6 +202,27 @@ __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t
     tmp_key[pos] = ((ky & 1u) << 31) | k;     // sort key inside the cell: in-box first, then input order
 }
 
+// Grids of large cells (more than 384 atoms per cell on average: cutoffs that are large against the box) order their atoms by a
+// stable device sort of (cell << 1 | wrapped, atom number) instead of ranking every atom against its whole cell (place_big_kernel:
+// quadratic in the cell population - 100 us for 64 cells of 1560 atoms, 1 ms for 660 of them): sort_prep_kernel makes the keys
+// (dropped atoms behind everything), sort_tmpkey_kernel turns the sorted order into the tmp_key entries place_order_kernel reads,
+// which then takes an entry's position as its rank.
+__global__ void __launch_bounds__(256) sort_prep_kernel(uint32_t n, uint32_t ncells, const uint32_t *__restrict__ key, uint32_t *__restrict__ k2,
+                                                        uint32_t *__restrict__ v) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t ky = key[k];
+    k2[k] = ky == DROPPED ? 2u * ncells : ky;
+    v[k] = k;
+}
+__global__ void __launch_bounds__(256) sort_tmpkey_kernel(uint32_t n, uint32_t ncells, const uint32_t *__restrict__ k_sorted,
+                                                          const uint32_t *__restrict__ v_sorted, uint32_t *__restrict__ tmp_key) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t ky = k_sorted[t];
+    if (ky < 2u * ncells) tmp_key[t] = ((ky & 1u) << 31) | v_sorted[t];      // kept atoms come first, cell by cell: t is the final position
+}
+
 // One wave per cell does everything that depends on the cell's content:
 //  * PLACE: rank of every atom inside the cell segment by (wrapped, input index) - the reference's push order:
 //    in-box atoms in input order, then wrapped atoms (distance_search.rs:180,203-209) - and its record
@@ -224,7 +245,7 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
                                                           float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
                                                           float4 *__restrict__ aabb, float4 *__restrict__ perm,
                                                           float4 *__restrict__ chunk_aabb, uint4 *__restrict__ h16,
-                                                          float4 *__restrict__ cell_org, int big_elsewhere, int want_order) {
+                                                          float4 *__restrict__ cell_org, int big_elsewhere, int want_order, int presorted) {
     // One wave per workgroup (5 KB of LDS): the grid of the NEXT frame is built on the side stream while the fill pass of
     // the frame in flight holds every wave slot of the chip with one-wave workgroups.  A freed slot takes a one-wave
     // workgroup of either queue; a four-wave workgroup needs four free slots on ONE compute unit at the same moment and
@@ -261,7 +282,9 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
             lo[2] = fminf(lo[2], ca.pos.z); hi[2] = fmaxf(hi[2], ca.pos.z);
             continue;
         }
-        if (small) {
+        if (presorted) {
+            rank = t;                                           // tmp_key is already in the reference's order (sort_tmpkey_kernel)
+        } else if (small) {
             const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
             uint32_t q = 0;
             for (; q + 4u <= n; q += 4u) {                      // wave-uniform address: one broadcast ds_read_b128
@@ -1033,17 +1056,28 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
                                S.cell_count.as<uint32_t>());
         MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, S.cell_count.as<uint32_t>(), S.cell_count.as<uint32_t>(),
                                                    (uint64_t)ncells + 1)));
+        // cells of more than 384 atoms on average: the order comes from a stable sort (sort_prep_kernel)
+        const bool by_sort = (uint64_t)S.n > 384ull * ncells && !c->on_side;
+        if (by_sort) {
+            MH_TRY(S.sort_buf.reserve((size_t)S.n * 16));
+            uint32_t *k_in = S.sort_buf.as<uint32_t>(), *v_in = k_in + S.n, *k_out = v_in + S.n, *v_out = k_out + S.n;
+            hipLaunchKernelGGL(sort_prep_kernel, dim3((S.n + 255u) / 256u), dim3(256), 0, c->stream, S.n, ncells, S.key.as<uint32_t>(), k_in, v_in);
+            int end_bit = 1;
+            while (end_bit < 32 && (2ull * ncells) >> end_bit) ++end_bit;
+            MH_TRY(device_sort_pairs_u32(c, c->sort_tmp, k_in, k_out, v_in, v_out, S.n, end_bit));
+            hipLaunchKernelGGL(sort_tmpkey_kernel, dim3((S.n + 255u) / 256u), dim3(256), 0, c->stream, S.n, ncells, k_out, v_out, S.tmp_key.as<uint32_t>());
+        } else
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(bs), 0, c->stream, S.n, S.key.as<uint32_t>(),
                            S.cell_count.as<uint32_t>(), S.cursor.as<uint32_t>(), S.tmp_key.as<uint32_t>());
         // cells of more than 512 atoms are the rule (mean population above 384; the headline frame has 261) and the grid
         // is small enough for a (cell, 64-atom block) launch: such cells are ranked by place_big_kernel.  (Crowded cells
         // in a grid that is sparse on average keep the single wave: correct, slow.)
-        const bool big = (uint64_t)S.n > 384ull * ncells && ncells <= 4096u;
+        const bool big = (uint64_t)S.n > 384ull * ncells && ncells <= 4096u && !by_sort;
         hipLaunchKernelGGL(place_order_kernel, dim3(ncells), dim3(64), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
                            S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<float4>(),
                            S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>(), big ? 1 : 0,
-                           (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1 : 0);
+                           (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1 : 0, by_sort ? 1 : 0);
         if (big) {
             unsigned by = (S.n + 63u) / 64u;
             if (by > 2048u) by = 2048u;
