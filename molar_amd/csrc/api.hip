@@ -185,7 +185,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
                           &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb, &s.h16, &s.cell_org})
             b->release();
     }
-    for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->tile_sum, &c->scan_tmp, &c->sort_tmp, &c->scan_tmp_side, &c->scan_state, &c->fplan_tiles, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
+    for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->tile_sum, &c->scan_tmp, &c->sort_tmp, &c->sort_tmp_side, &c->scan_tmp_side, &c->scan_state, &c->fplan_tiles, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
                       &c->wide_i, &c->wide_j, &c->hist, &c->hist_queue, &c->slot_desc_rest, &c->hist_edges, &c->dbg, &c->conn_deg, &c->conn_off, &c->conn_ent, &c->conn_neigh, &c->w_flags, &c->w_list, &c->w_part_cnt, &c->w_part, &c->w_tile_cnt, &c->w_tile_off, &c->task_mu, &c->task_moff, &c->maskbuf, &c->m_xyz1, &c->m_xyz2, &c->m_idx1, &c->m_idx2,
                       &c->m_mass1, &c->m_mass2, &c->m_partials, &c->m_results, &c->m_out})
         b->release();

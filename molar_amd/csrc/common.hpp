@@ -178,7 +178,7 @@ struct molar_hip_ctx {
     unsigned long long params_fresh_cap = 0;   // ... written with this output capacity
     unsigned long long *sizes_dev = nullptr;   // resident searches: device-side address of the pinned 16 bytes the kernels write the two sizes to
     mh::DevBuf scan_tmp;       // block sums for the scans
-    mh::DevBuf sort_tmp;       // scratch of the device sort (devsort.hip)
+    mh::DevBuf sort_tmp, sort_tmp_side;   // scratch of the device sort (devsort.hip), per stream
     mh::DevBuf scan_state;     // ticket + tile descriptors of the single-pass scans (zeroed by the plan kernel)
     mh::DevBuf fplan_tiles;    // plan_tiles_kernel -> plan_slots_kernel: slot / hit-history totals per tile of 256 plan entries
     mh::DevBuf out_pairs_set[2];   // ctx-owned result buffers (device-resident results / host staging); the second

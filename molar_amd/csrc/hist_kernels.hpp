@@ -315,7 +315,11 @@ __device__ __forceinline__ uint32_t hist_run_wrapped(const SearchParams &P, cons
     return total;
 }
 
-template <int KIND>
+// BIG: frames whose cells hold more than KREG * 64 atoms as a rule (SearchParams::hist_big, set by the host from the mean
+// population): a slot's second cell is walked in blocks of that many atoms - bins do not care in which order the pairs of a slot
+// are found.  The other instance is the kernel as it was (wrapping its slot body in that loop cost the C4 frame 3-5 %) and
+// leaves the odd oversized cell of an ordinary frame to the generic kernel.
+template <int KIND, bool BIG>
 __global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(8)))
 hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ slot_desc, uint32_t nslots_bound,
             uint32_t *__restrict__ queue, uint32_t parity) {
@@ -421,24 +425,64 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         case 7: total = CALL(7); break;      \
         default: total = CALL(8); break;     \
     }
-        if (P.use_box && T.wrap != 0u) {
-            if (tail) {                    // plain hits still on the stack: out before entries of the other layout go in
-                hist_pop_plain(H, 0u, tail, lane);
-                tail = 0u;
-            }
+        if (!BIG) {
+            if (P.use_box && T.wrap != 0u) {
+                if (tail) {                    // plain hits still on the stack: out before entries of the other layout go in
+                    hist_pop_plain(H, 0u, tail, lane);
+                    tail = 0u;
+                }
 #define MH_HIST_WRAPPED(N) hist_run_wrapped<KIND, N>(P, T, i0, H, lds_a[wave], lane)
-            MH_HIST_CASES(MH_HIST_WRAPPED)
+                MH_HIST_CASES(MH_HIST_WRAPPED)
 #undef MH_HIST_WRAPPED
-        } else if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) {
+            } else if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) {
 #define MH_HIST_TRI(N) hist_run_plain<KIND, N, true>(P, T, i0, H, tail, lds_a[wave], lane)
-            MH_HIST_CASES(MH_HIST_TRI)
+                MH_HIST_CASES(MH_HIST_TRI)
 #undef MH_HIST_TRI
-        } else {
+            } else {
 #define MH_HIST_PLAIN(N) hist_run_plain<KIND, N, false>(P, T, i0, H, tail, lds_a[wave], lane)
-            MH_HIST_CASES(MH_HIST_PLAIN)
+                MH_HIST_CASES(MH_HIST_PLAIN)
 #undef MH_HIST_PLAIN
-        }
+            }
 #undef MH_HIST_CASES
+        } else {
+            const uint32_t n2_all = T.n2, b0_all = T.b0;
+            for (uint32_t cb0 = 0u; cb0 < n2_all; cb0 += 64u * (uint32_t)KREG) {
+                T.b0 = b0_all + cb0;
+                T.n2 = n2_all - cb0 < 64u * (uint32_t)KREG ? n2_all - cb0 : 64u * (uint32_t)KREG;
+                const uint32_t nchunks_b = (T.n2 + 63u) >> 6;
+                uint32_t part = 0;
+#define MH_HIST_CASES_B(CALL)                  \
+    switch (nchunks_b) {                       \
+        case 1: part = CALL(1); break;         \
+        case 2: part = CALL(2); break;         \
+        case 3: part = CALL(3); break;         \
+        case 4: part = CALL(4); break;         \
+        case 5: part = CALL(5); break;         \
+        case 6: part = CALL(6); break;         \
+        case 7: part = CALL(7); break;         \
+        default: part = CALL(8); break;        \
+    }
+                if (P.use_box && T.wrap != 0u) {
+                    if (tail) {                    // plain hits still on the stack: out before entries of the other layout go in
+                        hist_pop_plain(H, 0u, tail, lane);
+                        tail = 0u;
+                    }
+#define MH_HIST_WRAPPED_B(N) hist_run_wrapped<KIND, N>(P, T, i0, H, lds_a[wave], lane)
+                    MH_HIST_CASES_B(MH_HIST_WRAPPED_B)
+#undef MH_HIST_WRAPPED_B
+                } else if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) {
+#define MH_HIST_TRI_B(N) hist_run_plain<KIND, N, true>(P, T, i0, H, tail, lds_a[wave], lane)
+                    MH_HIST_CASES_B(MH_HIST_TRI_B)
+#undef MH_HIST_TRI_B
+                } else {
+#define MH_HIST_PLAIN_B(N) hist_run_plain<KIND, N, false>(P, T, i0, H, tail, lds_a[wave], lane)
+                    MH_HIST_CASES_B(MH_HIST_PLAIN_B)
+#undef MH_HIST_PLAIN_B
+                }
+#undef MH_HIST_CASES_B
+                total += part;
+            }
+        }
         wave_total += total;
 #ifdef MOLAR_HIP_DEBUG_KNOBS
         {
@@ -581,12 +625,15 @@ inline void launch_hist_plan_kernel(hipStream_t stream, const SearchParams &P, S
 
 template <int KIND>
 inline void launch_hist_kernel(unsigned num_cus, size_t dyn_lds, hipStream_t stream, const SearchParams *dP,
-                               const SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity) {
+                               const SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity, bool big) {
     // persistent workgroups; a multiple of 8 * HIST_NSUB wide so that every queue has the same number of takers
     unsigned nb = num_cus * (HIST_CU_WAVES / HIST_WAVES);
     nb = (nb / (8u * HIST_NSUB)) * (8u * HIST_NSUB);
     if (nb == 0) nb = 8u * HIST_NSUB;
-    hipLaunchKernelGGL((hist_kernel<KIND>), dim3(nb), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots_bound, queue, (uint32_t)parity);   // counters, then the nbins + 1 bin edges
+    if (big)
+        hipLaunchKernelGGL((hist_kernel<KIND, true>), dim3(nb), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots_bound, queue, (uint32_t)parity);
+    else
+        hipLaunchKernelGGL((hist_kernel<KIND, false>), dim3(nb), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots_bound, queue, (uint32_t)parity);   // counters, then the nbins + 1 bin edges
 }
 
 }  // namespace pairk

@@ -11,12 +11,12 @@ void launch_hist_plan(int kind, hipStream_t stream, const pairk::SearchParams &P
 }
 
 void launch_hist_lean(int kind, unsigned num_cus, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
-                      const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity) {
+                      const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity, bool big) {
     using namespace pairk;
     if (kind == MOLAR_HIP_SEARCH_SINGLE)
-        launch_hist_kernel<MOLAR_HIP_SEARCH_SINGLE>(num_cus, dyn_lds, stream, dP, slot_desc, nslots_bound, queue, parity);
+        launch_hist_kernel<MOLAR_HIP_SEARCH_SINGLE>(num_cus, dyn_lds, stream, dP, slot_desc, nslots_bound, queue, parity, big);
     else if (kind == MOLAR_HIP_SEARCH_DOUBLE)
-        launch_hist_kernel<MOLAR_HIP_SEARCH_DOUBLE>(num_cus, dyn_lds, stream, dP, slot_desc, nslots_bound, queue, parity);
+        launch_hist_kernel<MOLAR_HIP_SEARCH_DOUBLE>(num_cus, dyn_lds, stream, dP, slot_desc, nslots_bound, queue, parity, big);
 }
 
 size_t hist_queue_words() { return pairk::HIST_QUEUE_WORDS; }

@@ -112,6 +112,8 @@ struct SearchParams {
     // shifts per trip (three 16-byte scalar loads, one wait) instead of one dependent scalar load per image; a zero shift gives
     // the start vector itself, which never beats the running minimum (periodic_box.rs:304-317)
     alignas(16) float shifts4[96];
+    uint32_t hist_big;       // histogram mode: cells of more than KREG * 64 atoms are the rule (mean population above 384): the lean kernel's BIG
+                             // instance (at the end: the fields in front of it keep their places)
 };
 
 // what plan_kernel stores per plan entry and the pair kernels read back with one 32-byte load
@@ -1561,7 +1563,9 @@ static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, co
 template <int KIND>
 __device__ __forceinline__ bool hist_lean_slot(const SearchParams &P, uint32_t flags, uint32_t n2) {
     if (KIND != MOLAR_HIP_SEARCH_SINGLE && KIND != MOLAR_HIP_SEARCH_DOUBLE) return false;
-    if (((n2 + 63u) >> 6) > (uint32_t)KREG) return false;
+    // second cells of more than KREG * 64 atoms: hist_kernel<KIND, BIG> walks them in blocks of that size where such cells are the
+    // rule (hist_big); the odd oversized cell of an ordinary frame stays with the generic kernel
+    if (((n2 + 63u) >> 6) > (uint32_t)KREG && !P.hist_big) return false;
     const uint32_t wrap = flags & 7u;
     if (!(P.use_box && wrap != 0u)) return true;                    // plain or same-cell entry
     if (flags & 0x100u) return false;                               // a cell paired with its own periodic image
@@ -1748,7 +1752,7 @@ inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t str
 void launch_hist_plan(int kind, hipStream_t stream, const pairk::SearchParams &P, pairk::SearchParams *params_dst, pairk::SlotDesc *lean,
                       pairk::SlotDesc *rest, uint32_t *queue, int parity);
 void launch_hist_lean(int kind, unsigned num_cus, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
-                      const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity);
+                      const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity, bool big);
 size_t hist_queue_words();
 const uint32_t *hist_list_count(const uint32_t *queue, int parity, int which);      // which: 0 lean, 1 rest
 void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,

@@ -203,8 +203,8 @@ __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t
 }
 
 // Grids of large cells (more than 384 atoms per cell on average: cutoffs that are large against the box) order their atoms by a
-// stable device sort of (cell << 1 | wrapped, atom number) instead of ranking every atom against its whole cell (place_big_kernel:
-// quadratic in the cell population - 100 us for 64 cells of 1560 atoms, 1 ms for 660 of them): sort_prep_kernel makes the keys
+// stable device sort of (cell << 1 | wrapped, atom number) instead of ranking every atom against its whole cell (quadratic in the
+// cell population: with one wave per 64 atoms of a cell, 100 us for 64 cells of 1560 atoms, 1 ms for 660 of them): sort_prep_kernel makes the keys
 // (dropped atoms behind everything), sort_tmpkey_kernel turns the sorted order into the tmp_key entries place_order_kernel reads,
 // which then takes an entry's position as its rank.
 __global__ void __launch_bounds__(256) sort_prep_kernel(uint32_t n, uint32_t ncells, const uint32_t *__restrict__ key, uint32_t *__restrict__ k2,
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
                                                           float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
                                                           float4 *__restrict__ aabb, float4 *__restrict__ perm,
                                                           float4 *__restrict__ chunk_aabb, uint4 *__restrict__ h16,
-                                                          float4 *__restrict__ cell_org, int big_elsewhere, int want_order, int presorted) {
+                                                          float4 *__restrict__ cell_org, int want_order, int presorted) {
     // One wave per workgroup (5 KB of LDS): the grid of the NEXT frame is built on the side stream while the fill pass of
     // the frame in flight holds every wave slot of the chip with one-wave workgroups.  A freed slot takes a one-wave
     // workgroup of either queue; a four-wave workgroup needs four free slots on ONE compute unit at the same moment and
@@ -271,17 +271,6 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
     for (uint32_t t = lane; t < n; t += 64u) {
         const uint32_t mine = small ? keys[t] : tmp_key[s + t];
         uint32_t rank = 0;
-        if (!small && big_elsewhere) {
-            // a cell of more than 512 atoms: place_big_kernel ranks it with one wave per 64 atoms (this wave alone would
-            // walk n^2 / 64 keys per lane); here only the bounding box
-            const uint32_t k = mine & 0x7FFFFFFFu;
-            const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
-            const CellOfAtom ca = classify(P, load_pos(P.xyz, a));
-            lo[0] = fminf(lo[0], ca.pos.x); hi[0] = fmaxf(hi[0], ca.pos.x);
-            lo[1] = fminf(lo[1], ca.pos.y); hi[1] = fmaxf(hi[1], ca.pos.y);
-            lo[2] = fminf(lo[2], ca.pos.z); hi[2] = fmaxf(hi[2], ca.pos.z);
-            continue;
-        }
         if (presorted) {
             rank = t;                                           // tmp_key is already in the reference's order (sort_tmpkey_kernel)
         } else if (small) {
@@ -303,6 +292,9 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
         const float4 rec = make_float4(ca.pos.x, ca.pos.y, ca.pos.z, __uint_as_float(id));
         sorted[s + rank] = rec;
         if (vdw) sorted_vdw[s + rank] = vdw[k];
+        // cells of more than ORDER_MAX atoms get no Morton order: their "spatial" copy is the reference's order itself (the fused
+        // histogram walks it in blocks of ORDER_MAX atoms, hist_kernel), their chunk boxes below the box of the whole cell
+        if (!small && want_order) perm[s + rank] = make_float4(rec.x, rec.y, rec.z, __uint_as_float(rank));
         lo[0] = fminf(lo[0], rec.x); hi[0] = fmaxf(hi[0], rec.x);
         lo[1] = fminf(lo[1], rec.y); hi[1] = fmaxf(hi[1], rec.y);
         lo[2] = fminf(lo[2], rec.z); hi[2] = fmaxf(hi[2], rec.z);
@@ -327,6 +319,13 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
     }
     // (want_order: the spatial order, the chunk boxes and the f16 records serve the count pass and the fused histogram of the
     // fixed-cutoff kinds only - the vdW and `within` searches, grids of 1e5 cells of a few atoms, stop here)
+    if (!small && want_order) {
+        const uint32_t ub = (s >> 6) + c;
+        for (uint32_t k = lane; k * 64u < n; k += 64u) {
+            chunk_aabb[2 * (ub + k)] = make_float4(lo[0], lo[1], lo[2], 0.f);
+            chunk_aabb[2 * (ub + k) + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        }
+    }
     if (n == 0 || !small || !want_order) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the records placed above are re-read by other lanes of this wave (same CU: no L2 write-back needed)
     __builtin_amdgcn_wave_barrier();
@@ -408,40 +407,6 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
     }
 }
 
-// Cells of more than ORDER_MAX atoms (a cutoff that is large against the box: a few cells of thousands of atoms): the
-// placement of place_order_kernel - rank by (wrapped, input index) among the cell's keys - with one wave per 64 ATOMS
-// instead of one per cell.  Wave (c, b) ranks atoms b*64 .. b*64+63 of cell c against all of its keys (wave-uniform
-// reads, L2-resident); cells within ORDER_MAX are left to place_order_kernel.  With eight cells of 12 500 atoms the
-// single wave per cell took 59 ms.
-__global__ void __launch_bounds__(64) place_big_kernel(BinParams P, uint32_t ncells, int ids_local, const uint32_t *__restrict__ cell_start,
-                                                       const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
-                                                       float4 *__restrict__ sorted, float *__restrict__ sorted_vdw) {
-    const uint32_t c = blockIdx.x, lane = threadIdx.x;
-    const uint32_t s = cell_start[c], e = cell_start[c + 1], n = e - s;
-    if (n <= ORDER_MAX) return;
-    for (uint32_t t0 = blockIdx.y * 64u; t0 < n; t0 += gridDim.y * 64u) {
-        const uint32_t t = t0 + lane;
-        const uint32_t mine = t < n ? tmp_key[s + t] : 0xFFFFFFFFu;
-        uint32_t rank = 0;
-        const uint4 *k4 = reinterpret_cast<const uint4 *>(tmp_key + ((s + 3u) & ~3u));       // aligned middle part
-        const uint32_t head = ((s + 3u) & ~3u) - s < n ? ((s + 3u) & ~3u) - s : n;
-        for (uint32_t q = 0; q < head; ++q) rank += tmp_key[s + q] < mine ? 1u : 0u;
-        const uint32_t nq = (n - head) >> 2;
-        for (uint32_t q = 0; q < nq; ++q) {
-            const uint4 v = k4[q];
-            rank += (v.x < mine ? 1u : 0u) + (v.y < mine ? 1u : 0u) + (v.z < mine ? 1u : 0u) + (v.w < mine ? 1u : 0u);
-        }
-        for (uint32_t q = head + 4u * nq; q < n; ++q) rank += tmp_key[s + q] < mine ? 1u : 0u;
-        if (t < n) {
-            const uint32_t k = mine & 0x7FFFFFFFu;
-            const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
-            const CellOfAtom ca = classify(P, load_pos(P.xyz, a));
-            const uint32_t id = ids_local ? k : (uint32_t)a;
-            sorted[s + rank] = make_float4(ca.pos.x, ca.pos.y, ca.pos.z, __uint_as_float(id));
-            if (vdw) sorted_vdw[s + rank] = vdw[k];
-        }
-    }
-}
 
 // ================================================================= scans (exclusive, n elements)
 
@@ -1057,34 +1022,23 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         MH_TRY((exclusive_scan<uint32_t, uint32_t>(c, S.cell_count.as<uint32_t>(), S.cell_count.as<uint32_t>(),
                                                    (uint64_t)ncells + 1)));
         // cells of more than 384 atoms on average: the order comes from a stable sort (sort_prep_kernel)
-        const bool by_sort = (uint64_t)S.n > 384ull * ncells && !c->on_side;
+        const bool by_sort = (uint64_t)S.n > 384ull * ncells;
         if (by_sort) {
             MH_TRY(S.sort_buf.reserve((size_t)S.n * 16));
             uint32_t *k_in = S.sort_buf.as<uint32_t>(), *v_in = k_in + S.n, *k_out = v_in + S.n, *v_out = k_out + S.n;
             hipLaunchKernelGGL(sort_prep_kernel, dim3((S.n + 255u) / 256u), dim3(256), 0, c->stream, S.n, ncells, S.key.as<uint32_t>(), k_in, v_in);
             int end_bit = 1;
             while (end_bit < 32 && (2ull * ncells) >> end_bit) ++end_bit;
-            MH_TRY(device_sort_pairs_u32(c, c->sort_tmp, k_in, k_out, v_in, v_out, S.n, end_bit));
+            MH_TRY(device_sort_pairs_u32(c, c->on_side ? c->sort_tmp_side : c->sort_tmp, k_in, k_out, v_in, v_out, S.n, end_bit));
             hipLaunchKernelGGL(sort_tmpkey_kernel, dim3((S.n + 255u) / 256u), dim3(256), 0, c->stream, S.n, ncells, k_out, v_out, S.tmp_key.as<uint32_t>());
         } else
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(bs), 0, c->stream, S.n, S.key.as<uint32_t>(),
                            S.cell_count.as<uint32_t>(), S.cursor.as<uint32_t>(), S.tmp_key.as<uint32_t>());
-        // cells of more than 512 atoms are the rule (mean population above 384; the headline frame has 261) and the grid
-        // is small enough for a (cell, 64-atom block) launch: such cells are ranked by place_big_kernel.  (Crowded cells
-        // in a grid that is sparse on average keep the single wave: correct, slow.)
-        const bool big = (uint64_t)S.n > 384ull * ncells && ncells <= 4096u && !by_sort;
         hipLaunchKernelGGL(place_order_kernel, dim3(ncells), dim3(64), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
                            S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<float4>(),
-                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>(), big ? 1 : 0,
+                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>(),
                            (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1 : 0, by_sort ? 1 : 0);
-        if (big) {
-            unsigned by = (S.n + 63u) / 64u;
-            if (by > 2048u) by = 2048u;
-            while (by > 1u && (uint64_t)by * ncells > (1ull << 20)) by >>= 1;
-            hipLaunchKernelGGL(place_big_kernel, dim3(ncells, by), dim3(64), 0, c->stream, P, ncells, ids_local, S.cell_count.as<uint32_t>(),
-                               S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(), S.d_vdw ? S.sorted_vdw.as<float>() : nullptr);
-        }
         MH_HIP(hipGetLastError());
     }
     return 0;
@@ -1246,6 +1200,7 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     P.hist_total = hist_total;
     size_t dyn_lds = 0;
     P.hist_lean = 0u;
+    P.hist_big = 0u;
     P.hist_edges = nullptr;
     P.hist_nslots = nullptr;
     P.hist_scale = 0.f;
@@ -1258,6 +1213,11 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
         // plain, same-cell and band-classified wrapped slots go to the lean kernel (8 waves per SIMD), the rest to
         // pair_kernel<MODE_HIST>; both add into the same bins
         P.hist_lean = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
+        {   // cells of more than KREG * 64 atoms are the rule (the grids' own criterion for ordering them by a sort, build_grid)
+            const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
+            const uint64_t nb_set = c->kind == MOLAR_HIP_SEARCH_SINGLE ? c->set[0].n : c->set[1].n;
+            P.hist_big = (P.hist_lean && nb_set > 384ull * ncells) ? 1u : 0u;
+        }
         if (P.hist_lean && c->edges_nbins == hist_nbins && c->edges_min == hmin && c->edges_max == hmax) {
             P.hist_edges = c->hist_edges.as<float>();
             P.hist_scale = (float)hist_nbins / (hmax - hmin);
@@ -1299,7 +1259,7 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
         const int parity = (int)(c->hist_frames++ & 1u);
         P.hist_nslots = hist_list_count(queue, parity, 1);
         launch_hist_plan(c->kind, c->stream, P, c->params.as<SearchParams>(), c->slot_desc.as<SlotDesc>(), c->slot_desc_rest.as<SlotDesc>(), queue, parity);
-        launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st, queue, parity);
+        launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st, queue, parity, P.hist_big != 0u);
         tf = c->slot_desc_rest.as<SlotDesc>();
     }
     switch (c->kind) {

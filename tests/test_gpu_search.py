@@ -366,7 +366,7 @@ def test_fused_histogram_bit_identical(eng, orc32, n, cutoff, nbins):
     assert np.array_equal(half, want_half)
 
 
-@pytest.mark.parametrize("case", ["rhombic", "ortho", "big_cells", "pbc_xy", "no_box", "few_cells", "hmin", "vdw", "two_sets_rhombic"])
+@pytest.mark.parametrize("case", ["rhombic", "ortho", "big_cells", "big_cells_band", "big_cells_two_sets", "big_cells_no_box", "pbc_xy", "no_box", "few_cells", "hmin", "vdw", "two_sets_rhombic"])
 def test_fused_histogram_equals_the_distance_stream(eng, orc32, case):
     """Every class of plan entry of the fused histogram (plain / same-cell / band-classified wrapped entries in the lean
     kernel; triclinic corner entries, cells > 512 atoms, boxes without the band classification, vdW radii in the generic
@@ -380,7 +380,16 @@ def test_fused_histogram_equals_the_distance_stream(eng, orc32, case):
     elif case == "ortho":
         box = synth.box_ortho(n)
     elif case == "big_cells":
-        cutoff, nbins = 2.1, 700            # ~900 atoms per cell: streaming path
+        cutoff, nbins = 2.1, 700            # ~900 atoms per cell, 3 cells per dimension: plain entries in blocks of 512 second-cell atoms, wrapped ones exact
+        box = synth.box_a(n)
+    elif case == "big_cells_band":
+        n, cutoff, nbins = 100_000, 1.9, 950     # ~800 atoms per cell, 5 cells per dimension: band-classified wrapped entries in blocks too
+        box = synth.box_a(n)
+    elif case == "big_cells_two_sets":
+        kind, n, cutoff, nbins = a.SEARCH_DOUBLE, 100_000, 2.0, 800
+        box = synth.box_a(n)
+    elif case == "big_cells_no_box":
+        cutoff, nbins, pbc = 2.1, 700, 0
         box = synth.box_a(n)
     elif case == "pbc_xy":
         box, pbc = synth.box_a(n), 3
@@ -407,7 +416,7 @@ def test_fused_histogram_equals_the_distance_stream(eng, orc32, case):
             cutoff, hmax, nbins = None, 0.5, 250
             kw = dict(vdw1=rng.uniform(0.1, 0.22, len(idx1)).astype(np.float32),
                       vdw2=rng.uniform(0.1, 0.22, len(idx2)).astype(np.float32))
-    use_box = box if case != "no_box" else None
+    use_box = box if case not in ("no_box", "big_cells_no_box") else None
     cnt = eng.search_count(kind, cutoff, box=use_box, pbc=pbc, **args, **kw)
     _, dist = eng.search_fill(cnt)
     assert cnt > 1000
