@@ -1423,10 +1423,41 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
 
 // chunk-count dispatch: for the single-set search the non-triangular tasks get a fully unrolled,
 // branch-free row body per chunk count; everything else checks the chunk count at run time
-template <int KIND, bool FILL, int WK, bool MASKED>
+// KMAX: chunks of the second cell a slot may keep in registers.  KREG for the regular instances (64 VGPRs at 8 waves per SIMD);
+// the instances for frames of large cells (pair_kernel<KIND, MODE, WPE = 4>: 128 VGPRs) take cells of up to KMAX_WIDE * 64 atoms
+// through the same row loops - plain, same-cell and, evaluated in both passes (no hit history: the plan records none beyond
+// KREG chunks), band-classified wrapped entries - instead of streaming the second cell from memory for every row.
+constexpr int KMAX_WIDE = 16;
+template <int KIND, bool FILL, int WK, bool MASKED, int KMAX = KREG>
 __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                                  uint32_t lane, uint32_t *mwords) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
+    if constexpr (KMAX > KREG) {
+        if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && nchunks > (uint32_t)KREG && nchunks <= (uint32_t)KMAX) {
+            constexpr bool WR = WK != WK_NONE;
+            const bool tri = KIND == MOLAR_HIP_SEARCH_SINGLE && WK == WK_NONE && T.tri;
+            if (!T.tri || tri) {
+#define MH_WIDE_CASE(N)                                                                                              \
+    case N:                                                                                                          \
+        if (tri) {                                                                                                   \
+            if constexpr (KIND == MOLAR_HIP_SEARCH_SINGLE && WK == WK_NONE)                                          \
+                return run_fast<KIND, FILL, false, N, true, false>(P, T, i0, F, la, lane, nullptr);                  \
+        }                                                                                                            \
+        return run_fast<KIND, FILL, WR, N, false, false>(P, T, i0, F, la, lane, nullptr);
+                switch (nchunks) {
+                    MH_WIDE_CASE(9) MH_WIDE_CASE(10) MH_WIDE_CASE(11) MH_WIDE_CASE(12)
+                    MH_WIDE_CASE(13) MH_WIDE_CASE(14) MH_WIDE_CASE(15)
+                    default: break;
+                }
+                if (tri) {
+                    if constexpr (KIND == MOLAR_HIP_SEARCH_SINGLE && WK == WK_NONE)
+                        return run_fast<KIND, FILL, false, 16, true, false>(P, T, i0, F, la, lane, nullptr);
+                }
+                return run_fast<KIND, FILL, WR, 16, false, false>(P, T, i0, F, la, lane, nullptr);
+#undef MH_WIDE_CASE
+            }
+        }
+    }
     if constexpr (!FILL && WK == WK_NONE && (KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE)) {
         // plain and same-cell entries with a second cell of <= 320 atoms: the count goes to the matrix cores unless the
         // slot's error bound is too wide
@@ -1572,9 +1603,13 @@ __device__ __forceinline__ bool hist_lean_slot(const SearchParams &P, uint32_t f
     return P.approx_wrapped != 0u && !(P.box.nshift != 0 && wrap == MOLAR_HIP_PBC_FULL);
 }
 
-template <int KIND, int MODE>
+// WPE: waves per SIMD of a second instance of the count / fill kernels for frames whose cells hold more than 448 atoms on
+// average (launch_pair_wide, pair_k5.hip): with 128 registers per lane a slot keeps up to 16 chunks (1024 atoms) of the second
+// cell resident (run_task_nch, KMAX) - the regular instances stream cells above 512 atoms from memory for every row (1M atoms
+// in the sheared box at rc 1.6 nm, 636 atoms per cell: 65 M pairs per ms against 220-240 up to 1.4 nm).  0: the usual budget.
+template <int KIND, int MODE, int WPE = 0>
 __global__ void __launch_bounds__(64 * waves_per_block(MODE))
-__attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 7 : 8)))) pair_kernel(const SearchParams *__restrict__ Pp,
+__attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 7 : 8))))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
                                                      const uint32_t nslots_arg,  // the host's bound: slots past the real count are empty
                                                      uint32_t *__restrict__ slot_cnt,
@@ -1695,11 +1730,12 @@ __attribute__((amdgpu_waves_per_eu(MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ?
             const uint32_t nch = (T.n2 + 63u) >> 6;
             if (moff + 2u * nch <= P.mask_cap_units) mwords = P.maskbuf + moff * 64u;
         }
+        constexpr int KMAX = WPE ? KMAX_WIDE : KREG;
         switch (wk) {
-            case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
-            case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
-            case WK_UPPER: total = run_task_nch<KIND, FILL, WK_UPPER, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
-            default: total = run_task_nch<KIND, FILL, WK_GENERAL, MASKED>(P, T, i0, F, lds_a[wave], lane, mwords); break;
+            case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE, MASKED, KMAX>(P, T, i0, F, lds_a[wave], lane, mwords); break;
+            case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG, MASKED, KMAX>(P, T, i0, F, lds_a[wave], lane, mwords); break;
+            case WK_UPPER: total = run_task_nch<KIND, FILL, WK_UPPER, MASKED, KMAX>(P, T, i0, F, lds_a[wave], lane, mwords); break;
+            default: total = run_task_nch<KIND, FILL, WK_GENERAL, MASKED, KMAX>(P, T, i0, F, lds_a[wave], lane, mwords); break;
         }
         if (!FILL && lane == 0) slot_cnt[slot] = total;
         wave_total += total;
@@ -1733,13 +1769,13 @@ inline dim3 pair_grid(unsigned nblocks) {
 }
 
 // one launch of the pair kernel for a search kind / mode
-template <int KIND, int MODE>
+template <int KIND, int MODE, int WPE = 0>
 inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t stream, const SearchParams *dP,
                                const SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                                const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids) {
     // (count / fill: `nblocks` counts slots = waves; the histogram mode passes workgroups)
     if (MODE != MODE_HIST) nblocks = (nblocks + (unsigned)waves_per_block(MODE) - 1u) / (unsigned)waves_per_block(MODE);
-    hipLaunchKernelGGL((pair_kernel<KIND, MODE>), pair_grid(nblocks), dim3(64 * waves_per_block(MODE)), dyn_lds, stream, dP, slot_desc, nslots,
+    hipLaunchKernelGGL((pair_kernel<KIND, MODE, WPE>), pair_grid(nblocks), dim3(64 * waves_per_block(MODE)), dyn_lds, stream, dP, slot_desc, nslots,
                        slot_cnt, slot_base, pairs, dist, ids);
 }
 
@@ -1755,6 +1791,10 @@ void launch_hist_lean(int kind, unsigned num_cus, size_t dyn_lds, hipStream_t st
                       const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity, bool big);
 size_t hist_queue_words();
 const uint32_t *hist_list_count(const uint32_t *queue, int parity, int which);      // which: 0 lean, 1 rest
+// (pair_k5.hip) count / fill of the fixed-cutoff kinds with 4 waves per SIMD (128 VGPRs): frames of large cells, see pair_kernel
+void launch_pair_wide(int kind, int mode, unsigned nblocks, hipStream_t stream, const pairk::SearchParams *dP,
+                      const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
+                      const unsigned long long *slot_base, uint2 *pairs, float *dist);
 void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
                         const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                         const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids);

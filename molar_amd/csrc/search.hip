@@ -1262,6 +1262,17 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
         launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st, queue, parity, P.hist_big != 0u);
         tf = c->slot_desc_rest.as<SlotDesc>();
     }
+    // frames of large cells (more than 448 atoms per cell of the second set on average, i.e. cells above 512 are common): the
+    // instances with 128 registers per lane and up to 16 chunks of the second cell resident
+    if (!hist_nbins && !ids && (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE)) {
+        const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
+        const uint64_t nb_set = c->kind == MOLAR_HIP_SEARCH_SINGLE ? c->set[0].n : c->set[1].n;
+        if (nb_set > 448ull * ncells) {
+            launch_pair_wide(c->kind, mode, P.nblocks, c->stream, dP, tf, st, sc, sb, pairs, dist);
+            MH_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     switch (c->kind) {
         case MOLAR_HIP_SEARCH_SINGLE: launch_pair_single(mode, P.nblocks, dyn_lds, c->stream, dP, tf, st, sc, sb, pairs, dist, ids); break;
         case MOLAR_HIP_SEARCH_DOUBLE: launch_pair_double(mode, P.nblocks, dyn_lds, c->stream, dP, tf, st, sc, sb, pairs, dist, ids); break;

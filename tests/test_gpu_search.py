@@ -121,6 +121,44 @@ def test_large_cells_streaming_path(eng, orc32):
     assert_same_pairs(gi, gj, gd, ref)
 
 
+@pytest.mark.parametrize("case", ["single_tric", "single_pbc_xy", "single_no_box", "double_tric"])
+def test_cells_of_513_to_1024_atoms_stay_in_registers(eng, orc32, case):
+    """Frames whose cells hold more than 448 atoms on average run the count / fill instances with 128 registers per lane, which keep
+    up to 16 chunks (1024 atoms) of the second cell resident: plain, same-cell and band-classified wrapped entries (evaluated in
+    both passes, no hit history), resident and count + fill entries, against the oracle - ids, order, distances."""
+    a = api()
+    n, rc = 120_000, 1.6
+    box = synth.box_a(n)                                    # 5 x 5 x 6 cells of ~800 atoms
+    pos = synth.frame(n, box, 4)
+    ob = orc32.box_from_matrix(box)
+    if case.startswith("single"):
+        pbc = {"single_tric": 7, "single_pbc_xy": 3, "single_no_box": 0}[case]
+        if pbc:
+            ref = orc32.search_single_pbc(rc, pos, ob, pbc, nthreads=16)
+            kw = dict(box=box, pbc=pbc)
+            if pbc == 7:
+                assert tuple(ref["dims"]) == (5, 5, 6)
+        else:
+            ref = orc32.search_single(rc, pos, nthreads=16)
+            kw = {}
+        cnt = eng.search_count(a.SEARCH_SINGLE, rc, pos, **kw)
+        pr, d = eng.search_fill(cnt)
+        cnt2, _, _ = eng.search_resident(a.SEARCH_SINGLE, rc, pos, **kw)
+        pr2, d2 = eng.search_fill(cnt2)
+    else:
+        rng = np.random.default_rng(9)
+        i1 = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.uint64)
+        i2 = np.sort(rng.choice(n, (3 * n) // 4, replace=False)).astype(np.uint64)        # overlaps i1: same-cell duplicates
+        ref = orc32.search_double_pbc(rc, pos[i1.astype(int)], pos[i2.astype(int)], ob, 7, ids1=i1, ids2=i2, nthreads=16)
+        cnt = eng.search_count(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=7)
+        pr, d = eng.search_fill(cnt)
+        cnt2, _, _ = eng.search_resident(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=7)
+        pr2, d2 = eng.search_fill(cnt2)
+    assert cnt == cnt2 == len(ref["i"]) > 1e7
+    assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"])
+    assert np.array_equal(pr, pr2) and np.array_equal(d, d2)
+
+
 def test_tiny_inputs(eng, orc32):
     box = np.diag([5.0, 5.0, 5.0]).astype(np.float32)
     ob = orc32.box_from_matrix(box)
