@@ -14,7 +14,7 @@ for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
     if "hist_kernel" in k: key = "hist_lean"
     elif "hist_plan" in k: key = "hist_plan"
-    elif "pair_kernel" in k: key = "fill" if "<0, 1>" in k else ("hist_rest" if "<0, 2>" in k else "count")
+    elif "pair_kernel" in k: key = "fill" if "<0, 1," in k else ("hist_rest" if "<0, 2," in k else "count")
     else: continue
     acc[key][r["Counter_Name"]] += float(r["Counter_Value"]); n[(key, r["Counter_Name"])] += 1
 for key in acc:

@@ -12,7 +12,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for r in csv.DictReader(open(fs[0])):
     k = r["Kernel_Name"]
     if "pair_kernel" not in k: continue
-    key = "fill" if "<0, 1>" in k else "count"
+    key = "fill" if "<0, 1," in k else "count"
     acc[key][r["Counter_Name"]] += float(r["Counter_Value"]); n[(key, r["Counter_Name"])] += 1
 for key in acc:
     print(key, {c: round(v / n[(key, c)] / 1e6, 3) for c, v in acc[key].items()}, "(millions)")

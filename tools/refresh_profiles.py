@@ -16,7 +16,7 @@ for name in ("fetch", "write"):
         rows.append((k, c, sum(v) / len(v), len(v))); vals[(k, c)] = sum(v) / len(v)
 with open(f"{P}/{TAG}_pmc_hbm_bytes.csv", "w") as f:
     w = csv.writer(f); w.writerow(["k", "Counter_Name", "mean", "count"]); w.writerows(rows)
-fk = "pair_kernel<0, 1>"
+fk = "pair_kernel<0, 1, 0>"
 fetch, write = vals[(fk, "FETCH_SIZE")], vals[(fk, "WRITE_SIZE")]
 traffic = (2 * fetch + write) * 1024
 json.dump({"pair_fill_hbm_bytes_per_launch": traffic,
