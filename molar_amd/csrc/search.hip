@@ -239,6 +239,48 @@ __global__ void __launch_bounds__(256) sort_tmpkey_kernel(uint32_t n, uint32_t n
 //    Counting does not depend on the order in which candidates are visited, so the count pass walks compact
 //    chunks and skips (row, chunk) pairs by bounding box; the fill pass keeps the reference's order.
 constexpr uint32_t ORDER_MAX = 512;   // = KREG * 64 of the pair kernels
+
+// The PLACE step and the bounding box alone, 16 lanes per cell: grids of ~1e5 cells of a few atoms (vdW cutoffs, `within` with a
+// short range) that want no spatial order.  A wave per cell spends its time starting up: 98 736 waves took 68 us for a set of
+// 950k atoms and 40 us for one of 50k.  Keys are ranked straight from global memory (a cell's segment is one or two lines).
+__global__ void __launch_bounds__(256) place_small_kernel(BinParams P, uint32_t ncells, int ids_local,
+                                                          const uint32_t *__restrict__ cell_start,
+                                                          const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
+                                                          float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
+                                                          float4 *__restrict__ aabb, float4 *__restrict__ cell_org) {
+    const uint32_t sub = threadIdx.x & 15u;
+    const uint32_t c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = c < ncells;                               // (whole 16-lane groups: the shuffles below stay inside a group)
+    const uint32_t s = live ? cell_start[c] : 0u, e = live ? cell_start[c + 1] : 0u, n = e - s;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t t = sub; t < n; t += 16u) {
+        const uint32_t mine = tmp_key[s + t];
+        uint32_t rank = 0;
+        for (uint32_t q = s; q < e; ++q) rank += tmp_key[q] < mine ? 1u : 0u;
+        const uint32_t k = mine & 0x7FFFFFFFu;
+        const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
+        const CellOfAtom ca = classify(P, load_pos(P.xyz, a));   // same arithmetic as bin_kernel
+        const uint32_t id = ids_local ? k : (uint32_t)a;
+        sorted[s + rank] = make_float4(ca.pos.x, ca.pos.y, ca.pos.z, __uint_as_float(id));
+        if (vdw) sorted_vdw[s + rank] = vdw[k];
+        lo[0] = fminf(lo[0], ca.pos.x); hi[0] = fmaxf(hi[0], ca.pos.x);
+        lo[1] = fminf(lo[1], ca.pos.y); hi[1] = fmaxf(hi[1], ca.pos.y);
+        lo[2] = fminf(lo[2], ca.pos.z); hi[2] = fmaxf(hi[2], ca.pos.z);
+    }
+    for (int d = 0; d < 3; ++d)
+        for (int off = 8; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+    if (live && sub == 0) {
+        aabb[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        aabb[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        const float org[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+        const float ex = fmaxf(hi[0] - org[0], org[0] - lo[0]), ey = fmaxf(hi[1] - org[1], org[1] - lo[1]),
+                    ez = fmaxf(hi[2] - org[2], org[2] - lo[2]);
+        cell_org[c] = make_float4(org[0], org[1], org[2], 1.0001f * sqrtf((ex * ex + ey * ey) + ez * ez));
+    }
+}
 __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t ncells, int ids_local,
                                                           const uint32_t *__restrict__ cell_start,
                                                           const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
@@ -1034,11 +1076,16 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         } else
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(bs), 0, c->stream, S.n, S.key.as<uint32_t>(),
                            S.cell_count.as<uint32_t>(), S.cursor.as<uint32_t>(), S.tmp_key.as<uint32_t>());
+        const int want_order = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1 : 0;
+        if (!want_order && !by_sort && (uint64_t)S.n < 16ull * ncells)
+            hipLaunchKernelGGL(place_small_kernel, dim3((unsigned)(((uint64_t)ncells * 16u + bs - 1u) / bs)), dim3(bs), 0, c->stream, P, ncells,
+                               ids_local, S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
+                               S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.cell_org.as<float4>());
+        else
         hipLaunchKernelGGL(place_order_kernel, dim3(ncells), dim3(64), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
                            S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<float4>(),
-                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>(),
-                           (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1 : 0, by_sort ? 1 : 0);
+                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>(), want_order, by_sort ? 1 : 0);
         MH_HIP(hipGetLastError());
     }
     return 0;

@@ -293,6 +293,40 @@ def test_vdw_bit_exact(eng, orc32, pbc):
     assert_same_pairs(pairs[:, 0], pairs[:, 1], d, ref)     # LOCAL ids (:791-792)
 
 
+@pytest.mark.parametrize("pbc", [0, 7])
+def test_vdw_sparse_grid_with_crowded_cells(eng, orc32, pbc):
+    """Grids of many cells of a few atoms are placed by 16 lanes per cell (place_small_kernel); a few crowded cells in such a grid
+    (blobs of 20-150 atoms inside one cell) take the same path in several trips and keep the push order
+    (distance_search.rs:180,203-209)."""
+    a = api()
+    n = 9000
+    box = synth.box_ortho(n, density=25.0)
+    pos = synth.frame(n, box)
+    rng = np.random.default_rng(11)
+    L = np.diag(box)
+    for blob, size in enumerate((20, 33, 64, 150)):
+        centre = rng.uniform(0.2, 0.8, 3) * L
+        at = rng.choice(n, size, replace=False)
+        pos[at] = (centre + rng.normal(0, 0.03, (size, 3))).astype(np.float32)
+    idx1 = np.sort(rng.choice(n, 6000, replace=False)).astype(np.uint64)
+    idx2 = np.setdiff1d(np.arange(n, dtype=np.uint64), idx1)
+    v1 = rng.uniform(0.1, 0.2, len(idx1)).astype(np.float32)
+    v2 = rng.uniform(0.1, 0.2, len(idx2)).astype(np.float32)
+    ob = orc32.box_from_matrix(box)
+    p1, p2 = pos[idx1.astype(int)], pos[idx2.astype(int)]
+    if pbc:
+        ref = orc32.search_double_vdw_pbc(p1, p2, v1, v2, ob, pbc, nthreads=4)
+        cnt = eng.search_count(a.SEARCH_DOUBLE_VDW, None, pos, idx1, pos, idx2, box=box, pbc=pbc, vdw1=v1, vdw2=v2)
+    else:
+        ref = orc32.search_double_vdw(p1, p2, v1, v2, nthreads=4)
+        cnt = eng.search_count(a.SEARCH_DOUBLE_VDW, None, pos, idx1, pos, idx2, vdw1=v1, vdw2=v2)
+    dims = eng.grid_dims()
+    assert len(idx1) < 16 * dims[0] * dims[1] * dims[2]          # the sparse-grid placement is the one that ran
+    pairs, d = eng.search_fill(cnt)
+    assert cnt > 500
+    assert_same_pairs(pairs[:, 0], pairs[:, 1], d, ref)
+
+
 def test_pymolar_style_dispatch(eng, orc32):
     """distance_search(cutoff, sel1, sel2=None, dims=None) dispatch table (molar_python/src/lib.rs:271-362)."""
     a = api()
