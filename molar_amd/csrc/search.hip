@@ -27,6 +27,11 @@
 #include "pair_kernels.hpp"
 #include "stages.hpp"
 
+namespace mh {
+// pair_small.hip: count / fill kernels for frames of small cells, 64 / lanes_per_slot slots per wave
+void launch_pair_small(int mode, int lanes_per_slot, hipStream_t stream, const pairk::SearchParams *dP, const pairk::SlotDesc *slot_desc,
+                       uint32_t nslots, uint32_t *slot_cnt, const unsigned long long *slot_base, uint2 *pairs, float *dist);
+}
 using namespace mh;
 using namespace mh::pairk;
 
@@ -999,6 +1004,17 @@ int dims_from_extents(molar_hip_ctx *c, float cutoff, const float ext[3]) {
     return 0;
 }
 
+// Frames of small cells (contact / hydrogen-bond cutoffs) of the fixed-cutoff kinds go to pair_small.hip: 16 lanes per slot up to 13
+// atoms per cell on average, 32 up to 19, 0 = the regular kernels (1M atoms: 0.30 / 0.35 / 0.40 / 0.45 / 0.50 nm take 1.30 / 1.00 /
+// 0.89 / 1.01 / 0.99 ms per frame against 2.91 / 2.14 / 1.66 / 1.30 / 1.07; at 0.55 nm - 23 atoms per cell - the regular kernels win).
+// Decided from the sets' sizes and the grid alone: the grid build (no spatial order for these) and both passes agree on it.
+int small_cell_lanes(const molar_hip_ctx *c) {
+    if (c->kind != MOLAR_HIP_SEARCH_SINGLE && c->kind != MOLAR_HIP_SEARCH_DOUBLE) return 0;
+    const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
+    const uint64_t n_max = c->kind == MOLAR_HIP_SEARCH_SINGLE ? c->set[0].n : std::max(c->set[0].n, c->set[1].n);
+    return n_max <= 13ull * ncells ? 16 : (n_max <= 19ull * ncells ? 32 : 0);
+}
+
 int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     Prof prof(c, 0);
     const uint32_t ncells = c->dims[0] * c->dims[1] * c->dims[2];
@@ -1076,7 +1092,9 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         } else
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(bs), 0, c->stream, S.n, S.key.as<uint32_t>(),
                            S.cell_count.as<uint32_t>(), S.cursor.as<uint32_t>(), S.tmp_key.as<uint32_t>());
-        const int want_order = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1 : 0;
+        // (the spatial order serves the regular count pass and the fused histogram; pair_small.hip reads the placed records only)
+        const int want_order = ((c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) &&
+                                (c->hist_plan_now || small_cell_lanes(c) == 0)) ? 1 : 0;
         if (!want_order && !by_sort && (uint64_t)S.n < 16ull * ncells)
             hipLaunchKernelGGL(place_small_kernel, dim3((unsigned)(((uint64_t)ncells * 16u + bs - 1u) / bs)), dim3(bs), 0, c->stream, P, ncells,
                                ids_local, S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
@@ -1316,6 +1334,15 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
         const uint64_t nb_set = c->kind == MOLAR_HIP_SEARCH_SINGLE ? c->set[0].n : c->set[1].n;
         if (nb_set > 448ull * ncells) {
             launch_pair_wide(c->kind, mode, P.nblocks, c->stream, dP, tf, st, sc, sb, pairs, dist);
+            MH_HIP(hipGetLastError());
+            return 0;
+        }
+    }
+    // frames of small cells (contact / hydrogen-bond cutoffs): several slots per wave, pair_small.hip
+    if (!hist_nbins && !ids) {
+        const int lanes = small_cell_lanes(c);
+        if (lanes) {
+            launch_pair_small(mode, lanes, c->stream, dP, tf, st, sc, sb, pairs, dist);
             MH_HIP(hipGetLastError());
             return 0;
         }

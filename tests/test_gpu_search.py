@@ -159,6 +159,54 @@ def test_cells_of_513_to_1024_atoms_stay_in_registers(eng, orc32, case):
     assert np.array_equal(pr, pr2) and np.array_equal(d, d2)
 
 
+@pytest.mark.parametrize("rc", [0.35, 0.47])
+@pytest.mark.parametrize("case", ["single_tric", "single_pbc_xy", "single_no_box", "double_tric"])
+def test_small_cells_several_slots_per_wave(eng, orc32, case, rc):
+    """Frames of cells of a few atoms (up to 13 per cell on average: 16 lanes per slot, up to 19: 32) run the kernels of
+    pair_small.hip - 2 or 4 slots per wave, every distance by the exact formula in both passes.  Plain, same-cell, wrapped and
+    triclinic corner entries, crowded cells inside the sparse grid (second cells longer than a slot's lanes, first cells of more
+    than 64 rows: several slots per entry), resident and count + fill entries, against the oracle - ids, order, distances
+    (distance_search.rs:324-373,432-517)."""
+    a = api()
+    n = 60_000
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 6)
+    rng = np.random.default_rng(21)
+    for size in (40, 100, 150):                              # crowded cells
+        centre = box @ rng.uniform(0.2, 0.8, 3).astype(np.float32)
+        at = rng.choice(n, size, replace=False)
+        pos[at] = (centre + rng.normal(0, 0.05, (size, 3))).astype(np.float32)
+    ob = orc32.box_from_matrix(box)
+    if case.startswith("single"):
+        pbc = {"single_tric": 7, "single_pbc_xy": 3, "single_no_box": 0}[case]
+        if pbc:
+            ref = orc32.search_single_pbc(rc, pos, ob, pbc, nthreads=8)
+            kw = dict(box=box, pbc=pbc)
+        else:
+            ref = orc32.search_single(rc, pos, nthreads=8)
+            kw = {}
+        cnt = eng.search_count(a.SEARCH_SINGLE, rc, pos, **kw)
+        dims = eng.grid_dims()
+        pr, d = eng.search_fill(cnt)
+        cnt2, _, _ = eng.search_resident(a.SEARCH_SINGLE, rc, pos, **kw)
+        pr2, d2 = eng.search_fill(cnt2)
+        n_max = n
+    else:
+        i1 = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.uint64)
+        i2 = np.sort(rng.choice(n, (3 * n) // 4, replace=False)).astype(np.uint64)        # overlaps i1: same-cell duplicates
+        ref = orc32.search_double_pbc(rc, pos[i1.astype(int)], pos[i2.astype(int)], ob, 7, ids1=i1, ids2=i2, nthreads=8)
+        cnt = eng.search_count(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=7)
+        dims = eng.grid_dims()
+        pr, d = eng.search_fill(cnt)
+        cnt2, _, _ = eng.search_resident(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=7)
+        pr2, d2 = eng.search_fill(cnt2)
+        n_max = len(i2)
+    assert n_max <= 19 * dims[0] * dims[1] * dims[2]        # the frame is one of those the small-cell kernels take
+    assert cnt == cnt2 == len(ref["i"]) > 1e5
+    assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"])
+    assert np.array_equal(pr, pr2) and np.array_equal(d, d2)
+
+
 def test_tiny_inputs(eng, orc32):
     box = np.diag([5.0, 5.0, 5.0]).astype(np.float32)
     ob = orc32.box_from_matrix(box)

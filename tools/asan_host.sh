@@ -19,7 +19,7 @@ done
 for p in $pids; do wait $p; done
 objs="$O/api.o $O/xtc.o $O/measure.o $O/membrane.o $O/search.o $O/search_f64.o $O/measure_f64.o"
 for k in 0 1 2 3 4 5 6; do objs="$objs $R/molar_amd/csrc/pair_k$k.o"; done
-objs="$objs $R/molar_amd/csrc/devsort.o"
+objs="$objs $R/molar_amd/csrc/pair_small.o $R/molar_amd/csrc/devsort.o"
 $HIPCC --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libsan -o $O/libmolar_hip.so $objs
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 cd $R
