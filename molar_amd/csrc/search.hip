@@ -505,7 +505,8 @@ __global__ void __launch_bounds__(256) scan_tile_kernel(const TIn *in, TOut *out
 // Scans TWO arrays of the same length at once when in2 != nullptr (task slot counts and task hit-history units).
 // `state` holds 1 ticket word + 2 descriptors per tile and must be zero on entry.
 constexpr unsigned long long LB_MASK = (1ull << 62) - 1ull;
-constexpr uint64_t FPLAN_MAX_TASKS = 1ull << 18;                          // plan_tiles_kernel / plan_slots_kernel: plans up to this many entries (+ terminator)
+constexpr uint64_t FPLAN_MAX_TASKS = 1ull << 22;                          // plan_tiles_kernel / plan_slots_kernel: plans up to this many entries (+ terminator)
+constexpr uint32_t PLAN_GROUP = 128;                                       // plans of more than 1024 tiles: tile totals are summed in groups of this many first (plan_groups_kernel)
 __device__ __forceinline__ unsigned long long lb_resolve(unsigned long long *desc, uint32_t tile, unsigned long long tot) {
     if (tile == 0) {
         __hip_atomic_store(&desc[0], (2ull << 62) | tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -628,6 +629,24 @@ __global__ void __launch_bounds__(256) plan_tiles_kernel(SearchParams P, uint32_
     }
 }
 
+// Plans of more than 1024 tiles (2^18 entries: a 1M-atom frame below 0.72 nm): every workgroup of plan_slots_kernel summing every
+// tile total in front of it would read ntiles^2 / 2 words (2.3e6 entries: 36 000 workgroups x 9 000 tiles), so the totals of
+// groups of PLAN_GROUP tiles are formed first - one more launch of ntiles / 128 single-wave workgroups - and a workgroup adds the
+// groups in front of its own and the tiles of its own group in front of its tile.
+static __global__ void __launch_bounds__(64) plan_groups_kernel(uint32_t ntiles, const unsigned long long *__restrict__ tile_tot,
+                                                                unsigned long long *__restrict__ group_tot) {
+    unsigned long long n = 0, m = 0;
+    for (uint32_t k = threadIdx.x; k < PLAN_GROUP; k += 64u) {
+        const uint32_t b = blockIdx.x * PLAN_GROUP + k;
+        if (b < ntiles) { n += tile_tot[2 * b]; m += tile_tot[2 * b + 1]; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_xor(n, off, 64);
+        m += __shfl_xor(m, off, 64);
+    }
+    if (threadIdx.x == 0) { group_tot[2 * blockIdx.x] = n; group_tot[2 * blockIdx.x + 1] = m; }
+}
+
 constexpr uint32_t PLAN_SUB = 64;          // plan entries per workgroup of plan_slots_kernel (a quarter of a tile)
 static __global__ void __launch_bounds__(256) plan_slots_kernel(uint64_t ntasks, uint32_t ntiles, const uint32_t *__restrict__ local_first,
                                                                 const unsigned long long *__restrict__ local_moff,
@@ -635,15 +654,32 @@ static __global__ void __launch_bounds__(256) plan_slots_kernel(uint64_t ntasks,
                                                                 unsigned long long *__restrict__ task_moff,      // NULL: no hit history
                                                                 const unsigned long long *__restrict__ tile_tot,
                                                                 SlotDesc *__restrict__ slot_desc, uint64_t nslots_bound,
-                                                                unsigned long long *__restrict__ sizes_host) {  // pinned, or NULL
+                                                                unsigned long long *__restrict__ sizes_host,    // pinned, or NULL
+                                                                const unsigned long long *__restrict__ group_tot) {  // NULL: at most 1024 tiles
     __shared__ unsigned long long part[3][4];
     const uint32_t tile = blockIdx.x / (256u / PLAN_SUB), sub = blockIdx.x % (256u / PLAN_SUB);
     unsigned long long pn = 0, pm = 0, all_n = 0;           // slots / hit-history units in front of this tile, slots of the whole plan
-    for (uint32_t b = threadIdx.x; b < ntiles; b += 256u) {
-        const unsigned long long n = tile_tot[2 * b];
-        all_n += n;
-        if (b < tile) {
-            pn += n;
+    if (!group_tot) {
+        for (uint32_t b = threadIdx.x; b < ntiles; b += 256u) {
+            const unsigned long long n = tile_tot[2 * b];
+            all_n += n;
+            if (b < tile) {
+                pn += n;
+                pm += tile_tot[2 * b + 1];
+            }
+        }
+    } else {
+        const uint32_t ngroups = (ntiles + PLAN_GROUP - 1u) / PLAN_GROUP, g = tile / PLAN_GROUP;
+        for (uint32_t b = threadIdx.x; b < ngroups; b += 256u) {
+            const unsigned long long n = group_tot[2 * b];
+            all_n += n;
+            if (b < g) {
+                pn += n;
+                pm += group_tot[2 * b + 1];
+            }
+        }
+        for (uint32_t b = g * PLAN_GROUP + threadIdx.x; b < tile; b += 256u) {
+            pn += tile_tot[2 * b];
             pm += tile_tot[2 * b + 1];
         }
     }
@@ -1619,9 +1655,11 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
             c->params_fresh_cap = P.out_cap;
         }
         if (!c->on_side && c->ntasks + 1 <= FPLAN_MAX_TASKS) {
-            // main stream, a plan of at most 2^18 entries: plan and tile scan, then offsets and slot records - two launches, no chain
+            // main stream, a plan of at most 2^22 entries: plan and tile scan, then offsets and slot records - two launches (three
+            // above 2^18 entries, plan_groups_kernel), no chain
             const uint32_t ntiles = (uint32_t)((c->ntasks + 1 + 255) / 256);
-            MH_TRY(c->fplan_tiles.reserve((size_t)ntiles * 16 + (c->ntasks + 1) * 8));
+            const uint32_t ngroups = ntiles > 1024u ? (ntiles + PLAN_GROUP - 1u) / PLAN_GROUP : 0u;
+            MH_TRY(c->fplan_tiles.reserve((size_t)ntiles * 16 + (c->ntasks + 1) * 8 + (size_t)ngroups * 16));
             unsigned long long *moff = fast_kind ? c->task_moff.as<unsigned long long>() : nullptr;
             unsigned long long *tt = c->fplan_tiles.as<unsigned long long>();
             unsigned long long *lmoff = tt + 2 * (size_t)ntiles;           // offsets inside the tiles: hit-history units ...
@@ -1632,8 +1670,10 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
             else          // the three two-grid kinds decode tasks identically
                 hipLaunchKernelGGL((plan_tiles_kernel<MOLAR_HIP_SEARCH_DOUBLE>), dim3(ntiles), dim3(256), 0, c->stream, P, lfirst,
                                    c->task_desc.as<TaskDesc>(), lmoff, fast_kind, c->slot_cnt.as<uint32_t>(), c->nslots_bound + 1, tt, params_dst);
+            unsigned long long *gt = ngroups ? lmoff + (c->ntasks + 1) : nullptr;
+            if (ngroups) hipLaunchKernelGGL(plan_groups_kernel, dim3(ngroups), dim3(64), 0, c->stream, ntiles, tt, gt);
             hipLaunchKernelGGL(plan_slots_kernel, dim3(ntiles * (256u / PLAN_SUB)), dim3(256), 0, c->stream, c->ntasks, ntiles, lfirst, lmoff, c->task_nb.as<uint32_t>(),
-                               c->task_desc.as<TaskDesc>(), moff, tt, c->slot_desc.as<SlotDesc>(), c->nslots_bound, c->sizes_dev);
+                               c->task_desc.as<TaskDesc>(), moff, tt, c->slot_desc.as<SlotDesc>(), c->nslots_bound, c->sizes_dev, gt);
             MH_HIP(hipGetLastError());
             return 0;
         }

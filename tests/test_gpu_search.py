@@ -207,6 +207,28 @@ def test_small_cells_several_slots_per_wave(eng, orc32, case, rc):
     assert np.array_equal(pr, pr2) and np.array_equal(d, d2)
 
 
+@pytest.mark.parametrize("n,rc", [(500_000, 0.55), (200_000, 0.3)])
+def test_plans_of_more_than_2_18_entries(eng, orc32, n, rc):
+    """Plans of 2^18 ... 2^22 entries (a large frame at a contact cutoff) take the plan in three launches: tile totals, totals of
+    groups of 128 tiles, offsets and slot records (plan_groups_kernel).  500k atoms at 0.55 nm: 2.9e5 entries through the regular
+    count / fill kernels; 200k atoms at 0.3 nm: 6.5e5 entries through the small-cell kernels.  Resident and count + fill entries
+    against the oracle - ids, order, distances (search_plan, distance_search.rs:217-269)."""
+    a = api()
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 8)
+    ob = orc32.box_from_matrix(box)
+    ref = orc32.search_single_pbc(rc, pos, ob, 7, nthreads=16)
+    cnt = eng.search_count(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+    dims = eng.grid_dims()
+    assert (1 << 18) < 14 * dims[0] * dims[1] * dims[2] < (1 << 22)
+    pr, d = eng.search_fill(cnt)
+    cnt2, _, _ = eng.search_resident(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+    pr2, d2 = eng.search_fill(cnt2)
+    assert cnt == cnt2 == len(ref["i"]) > 1e6
+    assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"])
+    assert np.array_equal(pr, pr2) and np.array_equal(d, d2)
+
+
 def test_tiny_inputs(eng, orc32):
     box = np.diag([5.0, 5.0, 5.0]).astype(np.float32)
     ob = orc32.box_from_matrix(box)
