@@ -55,7 +55,7 @@ def make_frames(nframes, rank, box, device):
     return frames, ref
 
 
-def cpu_baseline(frame0, ref, box, mass, idx, warmup=2, reps=5):
+def cpu_baseline(frame0, ref, box, mass, idx, warmup=5, reps=10):
     """The oracle (a C restatement of MolAR's algorithm, NOT the Rust binary) in the reference's schedule — serial
     grid + plan, thread pool over plan entries (never fewer than 3 per task, one result arena per thread), ordered
     concatenation, serial Measure passes — on one frame of the same workload.  BASELINE.md §3 protocol, bounded:
@@ -318,7 +318,7 @@ def run_rdf_xtc(args, rank, local_rank, world, device, cdev):
             check = bool(np.array_equal(want, total_bins))
         pairs = float(total_bins.sum())
         dec_fps, con_fps = [float(s_[0]) for s_ in sides], [float(s_[1]) for s_ in sides]
-        print(json.dumps({
+        line = ({
             "metric": "frames/sec, 250k-atom XTC frames -> decode -> HBM -> fused 1200-bin radial distance histogram, bins reduced over ranks",
             "value": K * world / t, "unit": "frames/s", "pairs_binned_per_sec": pairs / t,
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": t / K * 1e3, "higher_is_better": True,
@@ -334,13 +334,14 @@ def run_rdf_xtc(args, rank, local_rank, world, device, cdev):
             "binding_side": ["decode" if d < c_ else "histogram" for d, c_ in zip(dec_fps, con_fps)],
             "roofline": None,
             "reduced_bins_equal_resident_frames": check,
-        }))
+        })
         try:
             os.remove(path)
         except OSError:
             pass
-        if check is False:
-            raise SystemExit(1)
+        line["_failed"] = check is False
+        return line
+    return None
 
 
 def run_rdf(args, rank, local_rank, world, device, cdev):
@@ -428,7 +429,7 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
             executed = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hist_steps.json")))["executed_candidate_evaluations"]
         except Exception:
             pass
-        print(json.dumps({
+        line = ({
             "metric": "frames/sec, 250k-atom frames -> fused 1200-bin radial distance histogram, bins reduced over ranks",
             "value": K * world / t, "unit": "frames/s", "pairs_binned_per_sec": pairs / t,
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": t / K * 1e3, "higher_is_better": True,
@@ -450,9 +451,10 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
                          "avg_launch_ms": hist_ms / max(hist_n, 1), "grid_dims": [int(x) for x in gd],
                          "candidate_evals_per_frame": cand, "candidate_evals_per_sec": cand * K * world / t},
             "reduced_bins_equal_single_rank": check,
-        }))
-        if check is False:
-            raise SystemExit(1)
+        })
+        line["_failed"] = check is False
+        return line
+    return None
 
 
 def run_membrane(args, rank, local_rank, world, device, cdev):
@@ -585,7 +587,7 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
                 chk.append(a2)
             check = bool(np.array_equal(np.sum(np.stack(chk), axis=0), total))
         nvalid = total[0]
-        print(json.dumps({
+        line = ({
             "metric": "frames/sec, 500k-atom bilayer (4000 lipids): per-lipid order parameters + neighbour analysis per frame, sums reduced over ranks",
             "value": K * world / t, "unit": "frames/s", "lipid_frames_per_sec": nl * K * world / t,
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": t / K * 1e3, "higher_is_better": True,
@@ -601,9 +603,39 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
             "roofline_note": "no roofline claim: ~35 latency-bound launches per frame over 4000 lipids (the largest, the per-lipid fit, runs "
                              "63 waves for 0.11 ms) and a serial host pass of 0.2 ms hidden behind them; profiles/r03_membrane_frame_kernel_stats.csv",
             "sums_equal_stage_by_stage_single_rank": check,
-        }))
-        if check is False:
-            raise SystemExit(1)
+        })
+        line["_failed"] = check is False
+        return line
+    return None
+
+
+def secondary_legs(args, rank, local_rank, world, device, cdev):
+    """BASELINE.json configs[3] and [4] beside the headline, on the same clock: `--workload rdf` (resident 250k-atom frames,
+    fused 1200-bin histogram) and `--workload membrane` (500k-atom bilayer, 4000 lipids) as short legs with --verify on
+    (rdf: the reduced bins against every frame recomputed alone; membrane: the accumulated sums against the stage-by-stage
+    calls).  Returns {"rdf": line, "membrane": line, "seconds": ...}; an exception inside a leg is reported as {"error": ...}."""
+    import copy
+    import traceback
+    out = {}
+    t0 = time.perf_counter()
+    for name, fn, over in (("rdf", run_rdf, dict(workload="rdf", steps=args.secondary_rdf_steps, warmup=10, verify=True, profile_steps=50)),
+                           ("membrane", run_membrane, dict(workload="membrane", steps=args.secondary_membrane_steps, warmup=8, verify=True,
+                                                           preheat=min(args.preheat, 1.0), streams=4))):
+        a2 = copy.copy(args)
+        for k, v in over.items():
+            setattr(a2, k, v)
+        t1 = time.perf_counter()
+        try:
+            ln = fn(a2, rank, local_rank, world, device, cdev)
+        except Exception as exc:       # the headline line is still printed; the run exits with status 1
+            ln = {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-800:], "_failed": True}
+        if ln is not None:
+            ln["leg_seconds"] = time.perf_counter() - t1
+            out[name] = ln
+    out["seconds"] = time.perf_counter() - t0
+    out["note"] = ("secondary legs, never `value`: the C4 and C5 shapes of BASELINE.json run after the headline in the same process, "
+                   "fewer steps than `python bench.py --workload rdf|membrane` runs by default")
+    return out
 
 
 def main():
@@ -639,6 +671,10 @@ def main():
     ap.add_argument("--decode-threads", type=int, default=0, help="--source xtc --decoder host: decoder threads per rank (0 = host cores / ranks)")
     ap.add_argument("--xtc-window", type=int, default=0, help="--source xtc: frames per decode window (0 = 16 for the host decoder, 1024 for the device decoder)")
     ap.add_argument("--xtc-path", default="", help="--source xtc: where rank 0 writes the synthetic trajectory (default: a file under $TMPDIR or /tmp)")
+    ap.add_argument("--no-secondary", action="store_true", help="search_fit: skip the short C4 (rdf) and C5 (membrane) legs attached to the line as `secondary`")
+    ap.add_argument("--secondary", action="store_true", help="search_fit: run the secondary legs at N > 1 as well (default: N = 1 only)")
+    ap.add_argument("--secondary-rdf-steps", type=int, default=200)
+    ap.add_argument("--secondary-membrane-steps", type=int, default=256)
     ap.add_argument("--no-pairs-only", action="store_true", help="search_fit: skip the extra leg that times the resident search with the (i, j) plane only")
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 recomputes all ranks' frames alone and compares (rdf: the reduced bins; search_fit: every "
@@ -690,9 +726,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if args.workload in ("rdf", "membrane"):
         fn = run_membrane if args.workload == "membrane" else (run_rdf_xtc if args.source == "xtc" else run_rdf)
-        fn(args, rank, local_rank, world, device, cdev)
+        line = fn(args, rank, local_rank, world, device, cdev)
+        failed = bool(line.pop("_failed", False)) if line else False
+        if line:
+            print(json.dumps(line))
         if world > 1:
             dist.destroy_process_group()
+        if failed:
+            raise SystemExit(1)
         return
 
     from molar_amd import api, build, synth
@@ -927,12 +968,26 @@ def main():
     S_timed, S = S, 1
     run_steps(W, KP)
     barrier()
-    S = S_timed
     prof = None
     for e in prof_engines:
         p1 = e.profile_read()
         e.profile_enable(False)
         prof = p1 if prof is None else {k: (prof[k][0] + p1[k][0], prof[k][1] + p1[k][1]) for k in prof}
+    # ---- a third untimed pass: ONE event pair per frame around count + offsets + fill (molar_hip_profile_enable(ctx, 2)).  The
+    # pass above brackets every kernel group with its own pair, and an event record is a barrier packet of 5-10 us on the
+    # stream: its three entries read longer than the kernels run and used to add up to MORE than ms_per_step.
+    for e in engines:
+        e.profile_enable(2)
+        e.profile_read()
+    run_steps(W, KP)
+    barrier()
+    frame_span_ms, frame_span_n = 0.0, 0
+    for e in engines:
+        p2 = e.profile_read()["search_frame"]
+        e.profile_enable(False)
+        frame_span_ms += p2[0]
+        frame_span_n += p2[1]
+    S = S_timed
 
     # ---- a measured MODE, never `value`: the same steps with the resident searches filling the (i, j) plane only - the output
     # form of the reference's (usize, usize) consumers (distance_search.rs:14-20; SearchConnectivity, the membrane's patches):
@@ -1057,7 +1112,7 @@ def main():
                              if self_check_all is not None else
                              ("--verify: every frame's pair count and RMSD" if verified is not None else None)),
             "self_check_s": self_check_s,
-            "kernel_ms_per_frame": {k: v[0] / KP for k, v in prof.items()},
+            "kernel_ms_per_frame": {k: v[0] / KP for k, v in prof.items() if k != "search_frame"},
             "kernel_ms_note": f"HIP-event times from a separate untimed pass of {KP} of the same steps on one context (events are "
                               "not recorded inside the timed region); grid_build (side stream) and measure (second context) "
                               "OVERLAP the search kernels, so the entries do not add up to ms_per_step",
@@ -1065,7 +1120,12 @@ def main():
             # ~0.05 ms of plan kernels and launch gaps); the second runs beside it and is stretched by the contention
             "critical_stream_ms_per_frame": {k: v[0] / KP for k, v in prof.items() if k in ("pair_count", "offset_scan", "pair_fill")},
             "overlapped_ms_per_frame": {k: v[0] / KP for k, v in prof.items() if k in ("grid_build", "measure")},
-            "critical_path_ms_per_frame": sum(v[0] for k, v in prof.items() if k in ("pair_count", "offset_scan", "pair_fill")) / KP,   # + ~0.05 ms of plan kernels (timed inside grid_build)
+            # count + offsets + fill of a frame between ONE pair of events (third pass): what the critical stream spends per frame
+            # besides the plan kernels (~0.02 ms) and the gaps between frames; <= ms_per_step
+            "critical_path_ms_per_frame": frame_span_ms / max(frame_span_n, 1),
+            "critical_path_source": f"one HIP-event pair per frame around count + offsets + fill, separate untimed pass of {KP} steps "
+                                    "(the per-class entries above carry one event pair EACH and read 5-10 us longer per class than the kernels run)",
+            "critical_path_sum_of_bracketed_classes_ms": sum(v[0] for k, v in prof.items() if k in ("pair_count", "offset_scan", "pair_fill")) / KP,
             "roofline": {
                 "kernel": "pair_kernel<SINGLE,FILL>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -1081,6 +1141,19 @@ def main():
             line["cpu_baseline"] = cpu_baseline(f0, ref.cpu().numpy(), box, mass.cpu().numpy(),
                                                 idx_np.astype(np.uint64))
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+    # ---- the two other BASELINE configs on the same clock (never `value`): short legs of --workload rdf (C4) and --workload
+    # membrane (C5) with their own self-checks, attached to the line as `secondary`.  N = 1 only unless --secondary is given
+    # (a failure inside a leg's collectives must not cost a multi-GPU run its headline line).
+    if (world == 1 and not args.no_secondary) or args.secondary:
+        sec = secondary_legs(args, rank, local_rank, world, device, cdev)
+        if rank == 0:
+            line["secondary"] = sec
+            if any(v.get("_failed") for v in sec.values() if isinstance(v, dict)):
+                exit_code = 1
+            for v in sec.values():
+                if isinstance(v, dict):
+                    v.pop("_failed", None)
+    if rank == 0:
         print(json.dumps(line))
         if verified is False or self_check_all is False:
             exit_code = 1

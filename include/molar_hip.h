@@ -78,7 +78,10 @@ int molar_hip_synchronize(molar_hip_ctx *ctx);
 /* Per-kernel-class timing with HIP events recorded on the context's stream (what bench.py's
  * roofline line is computed from).  Classes: 0 grid build (bin/scan/scatter/place), 1 pair count
  * kernel, 2 offset scan, 3 pair fill kernel, 4 measure/fit kernels.  read() synchronises the
- * stream, returns the accumulated milliseconds and launch counts since the last read, and resets. */
+ * stream, returns the accumulated milliseconds and launch counts since the last read, and resets.
+ * enable(ctx, 2): the resident searches record ONE span per search instead - class 5: count pass +
+ * offset scan + fill pass between a single pair of events (an event record is a barrier packet of
+ * 5-10 us on the stream, so the three bracketed passes of mode 1 read longer than they run). */
 #define MOLAR_HIP_PROFILE_CLASSES 8
 int molar_hip_profile_enable(molar_hip_ctx *ctx, int on);
 int molar_hip_profile_read(molar_hip_ctx *ctx, float ms[MOLAR_HIP_PROFILE_CLASSES],
@@ -162,9 +165,10 @@ int molar_hip_search_count(molar_hip_ctx *ctx, const molar_hip_search_desc *desc
 /* Phase 2 (fill), results in exactly the reference's order (plan order, then i-major, j-minor;
  * distance_search.rs:949-953).  pairs: uint32 [count][2] (i,j); dist: float[count] = sqrt(d2)
  * (DistanceSearchOutput for (usize,usize,Float), :22-26).  Either may be NULL to skip it.
- * Outputs in DEVICE memory must be aligned to 16 bytes (pairs) and 8 bytes (dist) - the fill pass
- * writes two results per lane and store instruction; anything else is MOLAR_HIP_ERR_INVALID_ARGUMENT
- * (hipMalloc and framework allocators give 256 bytes; only offset views can violate it). */
+ * Outputs in DEVICE memory should be aligned to 16 bytes (pairs) and 8 bytes (dist) - the fill pass
+ * writes two results per lane and store instruction (hipMalloc and framework allocators give 256
+ * bytes).  An offset view that is not aligned like that is filled through the context's own buffers
+ * and copied device to device: the same result, one more pass over it. */
 int molar_hip_search_fill(molar_hip_ctx *ctx, uint32_t *pairs, float *dist);
 /* Same, widened to MolAR's usize: separate i[], j[] arrays of uint64. */
 int molar_hip_search_fill_usize(molar_hip_ctx *ctx, uint64_t *i, uint64_t *j, float *dist);
@@ -186,7 +190,10 @@ int molar_hip_within_fill(molar_hip_ctx *ctx, uint64_t *ids);
  * within_size_bench.rs:13-47) name the same first set: with the hold on, a molar_hip_within_count whose request has the same
  * first-set pointers and sizes, the same box and periodicity and comes to the same grid reuses the staged coordinates and the
  * grid of the request before it.  The caller promises that those coordinates do not change while the hold is on (for a Rust
- * caller: while it holds the `&State`); any other search on the context, or on = 0, ends the reuse. */
+ * caller: while it holds the `&State`); any other search on the context, or on = 0, ends the reuse.  A first set in host
+ * memory is additionally checked by a fingerprint of the array (both ends and 512 atoms spread over it), so a frame updated
+ * in place - or a new array at the old address - is staged again; a set in device memory is read in place, and there the
+ * promise is all there is: toggle the hold per frame. */
 int molar_hip_within_hold(molar_hip_ctx *ctx, int on);
 /* SearchConnectivity (molar/src/connectivity.rs:8-60: `for (i, j) in pairs { conn[i].push(j); conn[j].push(i) }`) of a
  * single-selection search, built on the device from the resident pair list.  CSR over the request's id range - local ids

@@ -210,10 +210,11 @@ class Engine:
     def synchronize(self):
         check(self.lib.molar_hip_synchronize(self.ctx))
 
-    PROFILE_CLASSES = ("grid_build", "pair_count", "offset_scan", "pair_fill", "measure")
+    PROFILE_CLASSES = ("grid_build", "pair_count", "offset_scan", "pair_fill", "measure", "search_frame")
 
     def profile_enable(self, on=True):
-        check(self.lib.molar_hip_profile_enable(self.ctx, 1 if on else 0))
+        """True / 1: a span per kernel class; 2: one span per resident search (class search_frame); False: off."""
+        check(self.lib.molar_hip_profile_enable(self.ctx, int(on)))
 
     def profile_read(self):
         """{class: (milliseconds, launches)} accumulated since the last read (HIP events)."""

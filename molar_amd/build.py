@@ -54,7 +54,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         try:
             if not force and not needs_build():
                 return LIB
-            return _build_locked(verbose)
+            return _build_locked(verbose, force)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
@@ -104,7 +104,32 @@ def exec_restore_hazards(asm_path: str) -> list[str]:
     return found
 
 
-def _build_locked(verbose: bool) -> str:
+def _deps(name: str, seen: set | None = None) -> set:
+    """The file and every header it includes with quotes, transitively (paths relative to csrc/)."""
+    import re
+    seen = set() if seen is None else seen
+    path = os.path.normpath(os.path.join(CSRC, name))
+    if path in seen:
+        return seen
+    seen.add(path)
+    with open(path, "r", errors="replace") as f:
+        for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', f.read(), re.M):
+            _deps(os.path.join(os.path.dirname(name), m.group(1)), seen)
+    return seen
+
+
+def _unit_hash(source: str) -> str:
+    """What one translation unit is built from: flags, the source, the headers it reaches."""
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for path in sorted(_deps(source)):
+        with open(path, "rb") as f:
+            h.update(os.path.relpath(path, CSRC).encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _build_locked(verbose: bool, force: bool = False) -> str:
     import glob
     import shutil
     import tempfile
@@ -118,25 +143,42 @@ def _build_locked(verbose: bool) -> str:
     for s in SOURCES:
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
+        # an object whose unit hash (flags + source + reached headers) is unchanged was compiled AND audited before
+        uh = _unit_hash(s)
+        try:
+            fresh = not force and os.path.exists(obj) and open(obj + ".hash").read().strip() == uh
+        except OSError:
+            fresh = False
+        if fresh:
+            continue
+        if os.path.exists(obj + ".hash"):
+            os.remove(obj + ".hash")
         cmd = [hipcc, *FLAGS, "-save-temps", "-c", os.path.join(CSRC, s), "-o", obj]      # temporaries go to the cwd
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=tmp)))
-    for cmd, p in procs:
+        procs.append((cmd, obj, uh, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=tmp)))
+    failed = []
+    for cmd, obj, uh, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{out}")
-        if verbose and out.strip():
+            failed.append(f"hipcc failed: {' '.join(cmd)}\n{out}")
+        elif verbose and out.strip():
             print(out)
+    if failed:
+        shutil.rmtree(tmp, ignore_errors=True)
+        raise RuntimeError("\n".join(failed))
     hazards = []
     asms = sorted(glob.glob(os.path.join(tmp, "*-hip-amdgcn-amd-amdhsa-gfx950.s")))
-    if len(asms) != len(SOURCES):
-        raise RuntimeError(f"ISA audit: expected {len(SOURCES)} device assembly files in {tmp}, found {len(asms)}")
+    if len(asms) != len(procs):
+        raise RuntimeError(f"ISA audit: expected {len(procs)} device assembly files in {tmp}, found {len(asms)}")
     for asm in asms:
         hazards += exec_restore_hazards(asm)
     shutil.rmtree(tmp, ignore_errors=True)
     if hazards and not os.environ.get("MOLAR_HIP_ALLOW_EXEC_HAZARD"):
         raise RuntimeError("the compiler placed VGPR copies ahead of an EXEC restore (see exec_restore_hazards):\n" + "\n".join(hazards))
+    for cmd, obj, uh, p in procs:
+        with open(obj + ".hash", "w") as f:
+            f.write(uh)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -147,4 +189,6 @@ def _build_locked(verbose: bool) -> str:
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    # `python -m molar_amd.build` rebuilds the units whose sources changed; `--all` recompiles every unit
+    print(build_library(force="--all" in sys.argv, verbose=True))

@@ -228,6 +228,7 @@ int molar_hip_synchronize(molar_hip_ctx *c) {
 int molar_hip_profile_enable(molar_hip_ctx *c, int on) {
     if (!c) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "null context");
     c->profiling = on != 0;
+    c->profile_frames = on == 2;
     return MOLAR_HIP_OK;
 }
 

@@ -222,6 +222,7 @@ struct molar_hip_ctx {
     // molar_hip_within_hold: reuse of the first set's staged coordinates and grid across `within` requests
     bool within_hold = false, hold_valid = false;
     mh::GridSet *hold_set = nullptr;
+    uint64_t hold_fp = 0;      // fingerprint of a host-memory first set as it was staged (0: device memory, read in place)
     const float *hold_xyz = nullptr;
     const uint64_t *hold_idx = nullptr;
     size_t hold_natoms = 0, hold_n = 0;
@@ -247,6 +248,7 @@ struct molar_hip_ctx {
 
     // ---- profiling (HIP events on `stream`)
     bool profiling = false;
+    bool profile_frames = false;   // molar_hip_profile_enable(ctx, 2): ONE span (class 5) around count + offsets + fill of a resident search, none inside
     struct Span { int cls; hipEvent_t a, b; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
@@ -274,6 +276,7 @@ struct Prof {
     }
     Prof(molar_hip_ctx *ctx, int k) : c(ctx), cls(k) {
         if (!c->profiling) return;
+        if (c->profile_frames ? (k >= 1 && k <= 3) : k == 5) return;      // frame mode: the three passes share the frame's span
         a = get(c);
         b = get(c);
         (void)hipEventRecord(a, c->stream);

@@ -126,7 +126,8 @@ struct TaskDesc {
 // slot count -> slot's task -> task descriptor -> atoms).  Slots in [number of slots, host-side bound] have flags == 0.
 struct SlotDesc {
     uint32_t a0, n1, b0, n2;          // as TaskDesc
-    uint32_t cb, flags, i0, pad0;     // i0: first row of the slot inside the first cell
+    uint32_t cb, flags, i0, frame;    // i0: first row of the slot inside the first cell; frame: which parameter block of the launch the slot
+                                      // belongs to (fused histogram over several frames, molar_hip_search_histogram_frames; 0 everywhere else)
     unsigned long long moff, pad1;    // first 64-word unit of the slot in maskbuf
 };
 static_assert(sizeof(SlotDesc) == 48, "SlotDesc is read with three 16-byte loads");
@@ -1568,7 +1569,7 @@ static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, co
         const uint64_t s = (uint64_t)task_first[ntasks] + (t - ntasks);
         if (s <= nslots_bound) {
             SlotDesc z;
-            z.a0 = z.n1 = z.b0 = z.n2 = z.cb = z.flags = z.i0 = z.pad0 = 0u;
+            z.a0 = z.n1 = z.b0 = z.n2 = z.cb = z.flags = z.i0 = z.frame = 0u;
             z.moff = ~0ull >> 1;
             z.pad1 = 0ull;
             slot_desc[s] = z;
@@ -1583,7 +1584,7 @@ static __global__ void __launch_bounds__(256) slotmap_kernel(uint64_t ntasks, co
     for (uint32_t s = s0; s < s1; ++s) {
         SlotDesc o;
         o.a0 = d.a0; o.n1 = d.n1; o.b0 = d.b0; o.n2 = d.n2;
-        o.cb = d.cb; o.flags = d.flags; o.i0 = (s - s0) * rps; o.pad0 = 0u;
+        o.cb = d.cb; o.flags = d.flags; o.i0 = (s - s0) * rps; o.frame = 0u;
         o.moff = task_moff ? m0 + (unsigned long long)(s - s0) * 2u * nch : m0;
         o.pad1 = 0ull;
         slot_desc[s] = o;
@@ -1628,18 +1629,20 @@ __attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE ==
     extern __shared__ uint32_t lds_hist[];     // histogram mode only (hist_nbins counters)
     // The parameter block lives in device memory: a by-value struct this large, indexed dynamically
     // (box.shifts[k]), gets copied to scratch by the compiler and drags every field into VGPRs.
-    const SearchParams &P = *Pp;
+    // (histogram mode over several frames: Pp is an array, one block per frame; the slot record says which.  The histogram's own
+    // fields - bins, range, list counter - are the same in all of them and are read from the first.)
+    const SearchParams &P0 = *Pp;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t nslots = nslots_arg;
-    if (MODE == MODE_HIST && P.hist_nslots) {        // its own list, written by hist_plan_kernel: the count sits in memory
-        const uint32_t real = __builtin_amdgcn_readfirstlane(P.hist_nslots[0]);
+    if (MODE == MODE_HIST && P0.hist_nslots) {        // its own list, written by hist_plan_kernel: the count sits in memory
+        const uint32_t real = __builtin_amdgcn_readfirstlane(P0.hist_nslots[0]);
         nslots = real < nslots_arg ? real : nslots_arg;
     }
     // one-wave workgroups (count / fill): the wave index is the constant 0, so every LDS address is an immediate
     const uint32_t wave = WAVES_PER_BLOCK == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr bool hist = MODE == MODE_HIST;
     if (hist) {
-        for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += BLOCK) lds_hist[b] = 0u;
+        for (uint32_t b = threadIdx.x; b < P0.hist_nbins; b += BLOCK) lds_hist[b] = 0u;
         __syncthreads();
     }
     unsigned long long wave_total = 0;
@@ -1662,12 +1665,14 @@ __attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE ==
         Task T;   // record prepared by slotmap_kernel: one dependent load between the kernel arguments and the atoms
         uint32_t i0;
         unsigned long long moff;
+        uint32_t frame = 0u;
         {
             const uint4 lo = reinterpret_cast<const uint4 *>(slot_desc + slot)[0];
             const uint4 hi = reinterpret_cast<const uint4 *>(slot_desc + slot)[1];
             const uint2 mo = reinterpret_cast<const uint2 *>(slot_desc + slot)[4];
             const uint32_t fl = __builtin_amdgcn_readfirstlane(hi.y);
             if (!(fl & 0x200u)) return;       // past the last slot
+            if (MODE == MODE_HIST) frame = __builtin_amdgcn_readfirstlane(hi.w);
             T.a0 = __builtin_amdgcn_readfirstlane(lo.x);
             T.n1 = __builtin_amdgcn_readfirstlane(lo.y);
             T.b0 = __builtin_amdgcn_readfirstlane(lo.z);
@@ -1681,6 +1686,7 @@ __attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE ==
             T.wrap_b = (fl >> 12) & 7u;
             T.rps = fl >> 16;
         }
+        const SearchParams &P = MODE == MODE_HIST ? Pp[frame] : P0;
         Fifo F;
         F.fi = lds[wave][0];
         F.fj = lds[wave][1];
@@ -1752,11 +1758,11 @@ __attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE ==
     }
     if (hist) {
         __syncthreads();
-        for (uint32_t b = threadIdx.x; b < P.hist_nbins; b += BLOCK) {
+        for (uint32_t b = threadIdx.x; b < P0.hist_nbins; b += BLOCK) {
             const uint32_t v = lds_hist[b];
-            if (v) atomicAdd(&P.hist_bins[b], (unsigned long long)v);
+            if (v) atomicAdd(&P0.hist_bins[b], (unsigned long long)v);
         }
-        if (lane == 0 && wave_total && P.hist_total) atomicAdd(P.hist_total, wave_total);
+        if (lane == 0 && wave_total && P0.hist_total) atomicAdd(P0.hist_total, wave_total);
     }
 }
 
@@ -1785,12 +1791,17 @@ inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t str
 // (pair_k4.hip, hist_kernels.hpp) the fused histogram of the fixed-cutoff kinds: the one-kernel plan (two slot lists: the lean
 // kernel's and the generic kernel's) and the lean kernel.  queue: hist_queue_words() words, zero before the first launch;
 // parity: alternates between consecutive frames of a context (which pair of list counters this frame uses)
+// lslot: which of the four pairs of list counters this launch uses - consecutive launches of a context take consecutive ones, and
+// a launch leaves pair (lslot + 2) & 3 zeroed for the launch after the next
 void launch_hist_plan(int kind, hipStream_t stream, const pairk::SearchParams &P, pairk::SearchParams *params_dst, pairk::SlotDesc *lean,
-                      pairk::SlotDesc *rest, uint32_t *queue, int parity);
+                      pairk::SlotDesc *rest, uint32_t *queue, int lslot);
+// the plans of `nframes` frames in one launch: parameter blocks params[0 .. nframes) already in device memory
+void launch_hist_plan_frames(int kind, hipStream_t stream, const pairk::SearchParams *params, unsigned nframes, uint64_t ntasks_max,
+                             pairk::SlotDesc *lean, pairk::SlotDesc *rest, uint32_t *queue, int lslot);
 void launch_hist_lean(int kind, unsigned num_cus, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,
-                      const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity, bool big);
+                      const pairk::SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int lslot, bool big);
 size_t hist_queue_words();
-const uint32_t *hist_list_count(const uint32_t *queue, int parity, int which);      // which: 0 lean, 1 rest
+const uint32_t *hist_list_count(const uint32_t *queue, int lslot, int which);      // which: 0 lean, 1 rest
 // (pair_k5.hip) count / fill of the fixed-cutoff kinds with 4 waves per SIMD (128 VGPRs): frames of large cells, see pair_kernel
 void launch_pair_wide(int kind, int mode, unsigned nblocks, hipStream_t stream, const pairk::SearchParams *dP,
                       const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,

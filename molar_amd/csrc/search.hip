@@ -982,11 +982,12 @@ __global__ void __launch_bounds__(256) fmax_kernel(const float *__restrict__ v1,
         }
     }
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const bool wave_any = __ballot(any) != 0ull;   // by the whole wave: inside the branch below only lane 0 would vote
     __shared__ float wm[4];
     __shared__ uint32_t wa[4];
     if ((threadIdx.x & 63) == 0) {
         wm[threadIdx.x >> 6] = m;
-        wa[threadIdx.x >> 6] = __ballot(any) != 0ull ? 1u : 0u;
+        wa[threadIdx.x >> 6] = wave_any ? 1u : 0u;
     }
     __syncthreads();
     if (threadIdx.x == 0 && (wa[0] | wa[1] | wa[2] | wa[3])) {
@@ -1049,6 +1050,13 @@ int small_cell_lanes(const molar_hip_ctx *c) {
     const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
     const uint64_t n_max = c->kind == MOLAR_HIP_SEARCH_SINGLE ? c->set[0].n : std::max(c->set[0].n, c->set[1].n);
     return n_max <= 13ull * ncells ? 16 : (n_max <= 19ull * ncells ? 32 : 0);
+}
+
+// Does the count pass of this search record hit history for the fill pass to replay?  The fixed-cutoff kinds do - except on
+// frames of small cells: pair_small.hip evaluates in both passes and never touches the buffer, so its plan accounts for none
+// (a plan that did made the first resident frame of such a trajectory grow the buffer and run count and fill again for nothing).
+static bool records_hit_history(const molar_hip_ctx *c) {
+    return (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) && small_cell_lanes(c) == 0;
 }
 
 int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
@@ -1493,7 +1501,7 @@ int device_fmax2(molar_hip_ctx *c, const float *d_v1, uint32_t n1, const float *
 // Second half of the plan, for the kernels that walk slots (count / fill / histogram): slot index of every plan entry and
 // (fast kinds) its first hit-history unit by one single-pass scan over both, then one record per slot.
 int enqueue_plan_slots(molar_hip_ctx *c) {
-    const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
+    const uint32_t fast_kind = records_hit_history(c) ? 1u : 0u;
     const unsigned pbs = c->on_side ? 64u : 256u;          // one-wave workgroups on the side stream (place_order_kernel)
     if (c->ntasks + 1 > (1ull << 18)) {
         // sparse giant plans (a vdW search of 1M atoms: 4e6 entries): the single-pass scan's chain of tiles - each waits for the
@@ -1521,7 +1529,7 @@ int enqueue_plan_slots(molar_hip_ctx *c) {
 //    mostly empty - 3.2e6 workgroups launched for 1.6e5 slots cost 0.8 ms per pass in bare launches - so the launches of this
 //    search shrink to the slots that exist.  (Slot counters and records were prepared for the bound: a superset.)
 int size_plan(molar_hip_ctx *c) {
-    const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
+    const bool fast_kind = records_hit_history(c);
     if (!fast_kind && c->nslots_bound <= 65536ull) return 0;       // nothing to size, too few launches to save: no round trip
     MH_TRY(ensure_pinned(c, 64));
     unsigned long long *h = reinterpret_cast<unsigned long long *>(c->h_pinned);
@@ -1552,7 +1560,24 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     // molar_hip_within_hold: consecutive `within` requests against the SAME first set (same pointers and sizes, same box, same
     // grid) reuse its staged coordinates and its grid; anything else that stages or bins set 0 ends the hold's validity
     const bool may_hold = c->within_hold && q->kind == MOLAR_HIP_SEARCH_WITHIN && c->skip_plan;
-    bool reuse0 = may_hold && c->hold_valid && c->hold_set == c->set && c->hold_xyz == q->xyz1 && c->hold_natoms == q->natoms1 &&
+    // A first set in HOST memory is staged, so the hold would serve a copy: a fingerprint of the caller's array (its two ends and
+    // 512 atoms spread over it) tells an array updated in place, or a new one that the allocator put at the old address, from the
+    // one that was staged.  Device memory is read in place by the grid build; there the caller's promise is all there is.
+    uint64_t fp = 0;
+    if (may_hold && q->xyz1 && q->natoms1 && !is_device_ptr(q->xyz1)) {
+        fp = 0xcbf29ce484222325ull;
+        auto mix = [&](size_t atom) {
+            uint32_t w[3];
+            std::memcpy(w, q->xyz1 + 3 * atom, 12);
+            for (int k = 0; k < 3; ++k) fp = (fp ^ w[k]) * 0x100000001b3ull;
+        };
+        const size_t n = q->natoms1, step = n > 512 ? n / 512 : 1;
+        for (size_t a = 0; a < n && a < 64; ++a) mix(a);
+        for (size_t a = 0; a < n; a += step) mix(a);
+        for (size_t a = n > 64 ? n - 64 : 0; a < n; ++a) mix(a);
+        fp |= 1ull;
+    }
+    bool reuse0 = may_hold && c->hold_valid && c->hold_fp == fp && c->hold_set == c->set && c->hold_xyz == q->xyz1 && c->hold_natoms == q->natoms1 &&
                   c->hold_idx == q->idx1 && c->hold_n == q->n1 && c->hold_ids_local == q->ids_local && c->hold_use_box == c->use_box &&
                   c->hold_pbc == c->pbc && (!c->use_box || std::memcmp(&c->hold_box, &c->box, sizeof c->box) == 0);
     if (!reuse0) {
@@ -1640,7 +1665,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     MH_TRY(c->scan_state.reserve((st_tasks + st_slots) * 8));
     MH_TRY(c->task_mu.reserve((c->ntasks + 1) * 4));
     MH_TRY(c->task_moff.reserve((c->ntasks + 1) * 8));
-    const uint32_t fast_kind = (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) ? 1u : 0u;
+    const uint32_t fast_kind = records_hit_history(c) ? 1u : 0u;
     auto enqueue_plan = [&]() -> int {
         Prof prof(c, 0);
         SearchParams P = make_params(c);
@@ -1734,6 +1759,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
     }
     if (may_hold && !reuse0) {        // this grid of set 0 is the one later `within` requests may reuse
         c->hold_valid = true;
+        c->hold_fp = fp;
         c->hold_set = c->set;
         c->hold_xyz = q->xyz1; c->hold_natoms = q->natoms1; c->hold_idx = q->idx1; c->hold_n = q->n1;
         c->hold_ids_local = q->ids_local; c->hold_use_box = c->use_box; c->hold_pbc = c->pbc; c->hold_box = c->box;
@@ -2045,7 +2071,24 @@ static int fill_common(molar_hip_ctx *c, uint2 *d_pairs, float *d_dist, uint32_t
     if (!c || !c->have_search) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached search: call molar_hip_search_count first");
     MH_HIP(hipSetDevice(c->device));
     if (c->total == 0 || c->ntasks == 0) return 0;
-    return launch_pairs<true>(c, d_pairs, d_dist, d_ids);
+    // The fill pass stores two results per lane (16-byte / 8-byte stores relative to the output bases).  A caller's device view
+    // that is not aligned like that (an offset slice of a larger tensor) is filled through the context's own buffers and copied
+    // device to device - correct at the cost of one more pass over the result, instead of an error.
+    uint2 *p = d_pairs;
+    float *d = d_dist;
+    const bool via_p = p && ((uintptr_t)p & 15u) != 0, via_d = d && ((uintptr_t)d & 7u) != 0;
+    if (via_p) {
+        MH_TRY(c->out_pairs.reserve((size_t)c->total * 8));
+        p = c->out_pairs.as<uint2>();
+    }
+    if (via_d) {
+        MH_TRY(c->out_dist.reserve((size_t)c->total * 4));
+        d = c->out_dist.as<float>();
+    }
+    MH_TRY(launch_pairs<true>(c, p, d, d_ids));
+    if (via_p) MH_HIP(hipMemcpyAsync(d_pairs, p, (size_t)c->total * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (via_d) MH_HIP(hipMemcpyAsync(d_dist, d, (size_t)c->total * 4, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
 }
 
 int molar_hip_search_fill(molar_hip_ctx *c, uint32_t *pairs, float *dist) {
@@ -2123,7 +2166,7 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     *L = ResidentLaunch{};
     L->degenerate = c->have_search;
     if (L->degenerate) return 0;
-    const bool fast_kind = c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE;
+    const bool fast_kind = records_hit_history(c);
     L->maskcap0 = c->maskbuf.cap / 256u;
     // slots the two passes are launched over: what the plan of the search before came to, with a margin (common.hpp, trim_real)
     L->launched = c->nslots_bound;
@@ -2137,6 +2180,7 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
         molar_hip_ctx *c;
         ~SlotLaunchReset() { c->slot_launch = 0u; }
     } slot_launch_reset{c};
+    Prof frame_span(c, 5);       // (profile mode 2 only: count + offsets + fill between ONE pair of events)
     // one parameter block serves both passes: the count pass ignores the output capacity
     MH_TRY(launch_pairs<false>(c, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, cap0));
     if (c->record_count_done) {

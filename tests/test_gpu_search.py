@@ -363,6 +363,29 @@ def test_vdw_bit_exact(eng, orc32, pbc):
     assert_same_pairs(pairs[:, 0], pairs[:, 1], d, ref)     # LOCAL ids (:791-792)
 
 
+def test_vdw_nan_radii_are_ignored_by_the_cutoff_maximum(eng, orc32):
+    """vdw.iter().cloned().reduce(Float::max) ignores NaN (distance_search.rs:781-783). Every radius a wave's lane 0 reads
+    is NaN here (every 64th entry): the maximum has to come from the other lanes, and a pair with a NaN radius never hits."""
+    a = api()
+    n = 6000
+    box = synth.box_ortho(n, density=60.0)
+    pos = synth.frame(n, box)
+    idx1 = np.arange(0, n // 2, dtype=np.uint64)
+    idx2 = np.arange(n // 2, n, dtype=np.uint64)
+    rng = np.random.default_rng(5)
+    v1 = rng.uniform(0.1, 0.2, len(idx1)).astype(np.float32)
+    v2 = rng.uniform(0.1, 0.2, len(idx2)).astype(np.float32)
+    v1[::64] = np.nan
+    v2[::64] = np.nan
+    ob = orc32.box_from_matrix(box)
+    p1, p2 = pos[idx1.astype(int)], pos[idx2.astype(int)]
+    ref = orc32.search_double_vdw_pbc(p1, p2, v1, v2, ob, 7, nthreads=4)
+    cnt = eng.search_count(a.SEARCH_DOUBLE_VDW, None, pos, idx1, pos, idx2, box=box, pbc=7, vdw1=v1, vdw2=v2)
+    pairs, d = eng.search_fill(cnt)
+    assert cnt > 0
+    assert_same_pairs(pairs[:, 0], pairs[:, 1], d, ref)
+
+
 @pytest.mark.parametrize("pbc", [0, 7])
 def test_vdw_sparse_grid_with_crowded_cells(eng, orc32, pbc):
     """Grids of many cells of a few atoms are placed by 16 lanes per cell (place_small_kernel); a few crowded cells in such a grid
@@ -1268,30 +1291,35 @@ def test_resident_search_pairs_plane_only(eng, orc32):
     assert np.array_equal(pr3, pr) and np.array_equal(d3, ref["d"])
 
 
-def test_fill_rejects_misaligned_device_outputs(eng):
-    """The fill pass writes two results per lane and store instruction (dwordx4 / dwordx2 relative to the output bases):
-    include/molar_hip.h asks for 16-byte (pairs) / 8-byte (distances) alignment of caller-owned DEVICE outputs, and a view
-    that breaks it is refused with MOLAR_HIP_ERR_INVALID_ARGUMENT instead of being written with misaligned stores."""
+def test_fill_into_misaligned_device_views(eng):
+    """The fill pass writes two results per lane and store instruction (dwordx4 / dwordx2 relative to the output bases), so it
+    wants 16-byte (pairs) / 8-byte (distances) alignment.  A caller's DEVICE view that is not aligned like that - an offset
+    slice of a larger tensor - is filled through the context's own buffers and copied device to device: the same result
+    (it used to be refused with MOLAR_HIP_ERR_INVALID_ARGUMENT)."""
     import ctypes as C
     import torch
-    from molar_amd._lib import MolarHipError
     a = api()
     n = 20000
     box = synth.box_a(n)
     pos = synth.frame(n, box)
     cnt = eng.search_count(a.SEARCH_SINGLE, 0.6, pos, box=box, pbc=7)
     assert cnt > 0
-    pbuf = torch.zeros(2 * cnt + 8, dtype=torch.int32, device="cuda")
-    dbuf = torch.zeros(cnt + 8, dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
-    with pytest.raises(MolarHipError):          # pairs 8 bytes past a 16-byte boundary
-        a.check(eng.lib.molar_hip_search_fill(eng.ctx, C.c_void_p(pbuf.data_ptr() + 8), C.c_void_p(dbuf.data_ptr())))
-    with pytest.raises(MolarHipError):          # distances 4 bytes past an 8-byte boundary
-        a.check(eng.lib.molar_hip_search_fill(eng.ctx, C.c_void_p(pbuf.data_ptr()), C.c_void_p(dbuf.data_ptr() + 4)))
-    a.check(eng.lib.molar_hip_search_fill(eng.ctx, C.c_void_p(pbuf.data_ptr()), C.c_void_p(dbuf.data_ptr())))
     pr, d = eng.search_fill(cnt)
-    torch.cuda.synchronize()
-    assert np.array_equal(pbuf[:2 * cnt].cpu().numpy().view(np.uint32).reshape(-1, 2), pr) and np.array_equal(dbuf[:cnt].cpu().numpy(), d)
+    for poff, doff in ((8, 0), (0, 4), (8, 4), (0, 0)):      # bytes past an aligned base
+        pbuf = torch.full((2 * cnt + 8,), -1, dtype=torch.int32, device="cuda")
+        dbuf = torch.full((cnt + 8,), -1.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        a.check(eng.lib.molar_hip_search_fill(eng.ctx, C.c_void_p(pbuf.data_ptr() + poff), C.c_void_p(dbuf.data_ptr() + doff)))
+        eng.synchronize()
+        got_p = pbuf[poff // 4: poff // 4 + 2 * cnt].cpu().numpy().view(np.uint32).reshape(-1, 2)
+        got_d = dbuf[doff // 4: doff // 4 + cnt].cpu().numpy()
+        assert np.array_equal(got_p, pr) and np.array_equal(got_d, d), (poff, doff)
+        # nothing outside the view was touched
+        assert int(pbuf[poff // 4 + 2 * cnt:].max()) == -1 and float(dbuf[doff // 4 + cnt:].max()) == -1.0
+        if poff:
+            assert int(pbuf[:poff // 4].max()) == -1
+        if doff:
+            assert float(dbuf[:doff // 4].max()) == -1.0
 
 
 def test_fused_histogram_call_forms_interleaved(eng, orc32):

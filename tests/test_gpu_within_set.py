@@ -179,3 +179,22 @@ def test_within_hold_reuses_the_first_sets_grid(eng, orc32):
     assert np.array_equal(e2.within_set(0.4, pos2, idx1, pos2, grp, box=box, pbc=7), want(0.4, pos2, idx1, grp))
     pos2[:] = synth.frame(n, box, 4)
     assert np.array_equal(e2.within_set(0.4, pos2, idx1, pos2, grp, box=box, pbc=7), want(0.4, pos2, idx1, grp))
+
+
+def test_within_hold_sees_a_host_frame_updated_in_place(eng, orc32):
+    """With the hold left on across a trajectory loop, a host array that is overwritten with the next frame (same address,
+    same sizes) must not be answered from the staged copy of the frame before: the hold keeps a fingerprint of a host-memory
+    first set and stages it again when it differs."""
+    import molar_amd.api as a
+    n = 30000
+    box = synth.box_a(n)
+    ob = orc32.box_from_matrix(box)
+    idx1 = np.arange(n, dtype=np.uint64)
+    grp = np.arange(200, 260, dtype=np.uint64)
+    e2 = a.Engine(0)
+    e2.within_hold(True)
+    buf = np.empty((n, 3), np.float32)
+    for f in (3, 4, 4, 5):
+        buf[:] = synth.frame(n, box, f)
+        want = np.unique(orc32.search_within_pbc(0.5, buf, buf[grp.astype(int)], ob, 7, idx1, grp, nthreads=4)["i"])
+        assert np.array_equal(e2.within_set(0.5, buf, idx1, buf, grp, box=box, pbc=7), want)
