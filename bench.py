@@ -261,8 +261,11 @@ def run_rdf_xtc(args, rank, local_rank, world, device, cdev):
 
     def consume(buf, count):
         t0 = time.perf_counter()
-        for q in range(count):
-            eng.search_histogram(api.SEARCH_SINGLE, CUTOFF, 0.0, CUTOFF, nbins, buf[q], box=box, pbc=7, bins=bins, want_count=False)
+        if args.rdf_single_calls:
+            for q in range(count):
+                eng.search_histogram(api.SEARCH_SINGLE, CUTOFF, 0.0, CUTOFF, nbins, buf[q], box=box, pbc=7, bins=bins, want_count=False)
+        else:
+            eng.search_histogram_frames(api.SEARCH_SINGLE, CUTOFF, 0.0, CUTOFF, nbins, buf[:count], box=box, pbc=7, bins=bins)
         eng.synchronize()                                           # this window's buffer is free again
         return time.perf_counter() - t0
 
@@ -368,9 +371,19 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
     torch.cuda.synchronize()      # frames and bins were made on torch's stream; the engine works on its own
 
     def run(first, count):
-        for s in range(count):
-            eng.search_histogram(api.SEARCH_SINGLE, CUTOFF, 0.0, CUTOFF, nbins, frames[(first + s) % nres], box=box, pbc=7,
-                                 bins=bins, want_count=False)
+        if args.rdf_single_calls:
+            for s in range(count):
+                eng.search_histogram(api.SEARCH_SINGLE, CUTOFF, 0.0, CUTOFF, nbins, frames[(first + s) % nres], box=box, pbc=7,
+                                     bins=bins, want_count=False)
+            return
+        # the resident frames as blocks of the trajectory (molar_hip_search_histogram_frames: groups of up to 8 frames share
+        # their launches); the ring of nres resident frames is walked in contiguous pieces
+        s = 0
+        while s < count:
+            f0 = (first + s) % nres
+            k = min(count - s, nres - f0)
+            eng.search_histogram_frames(api.SEARCH_SINGLE, CUTOFF, 0.0, CUTOFF, nbins, frames[f0:f0 + k], box=box, pbc=7, bins=bins)
+            s += k
 
     def barrier():
         if world > 1:
@@ -414,6 +427,8 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
             check = bool(np.array_equal(chk.cpu().numpy(), total_bins))
         pairs = float(total_bins.sum())
         hist_ms, hist_n = prof["pair_fill"]
+        hist_launches = hist_n
+        hist_n = KP          # per FRAME: a launch of the frames form carries up to 8 frames
         # algorithmic work of one frame: the plan's candidate evaluations, 13.5 * N * mean cell
         # population (13 neighbour cells in full, the own cell as a triangle), 9 flop each; the kernels skip part of
         # them by bounding boxes, the reference evaluates all
@@ -437,6 +452,7 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
             "config": {"workload": "C4 shape: 250k-atom synthetic triclinic box A frames resident in HBM, rc=1.2 nm, fused "
                                    "Histogram1D binning (1200 bins of 0.001 nm), frames sharded over ranks, one all_reduce "
                                    "of 1200 x int64", "natoms": n, "nbins": nbins, "frames_per_gpu": K,
+                       "call_form": "one call per frame" if args.rdf_single_calls else "molar_hip_search_histogram_frames over blocks of the resident frames (groups of <= 8 frames per launch)",
                        "pairs_per_frame": pairs / (K * world)},
             "kernel_ms_per_frame": {k: v[0] / KP for k, v in prof.items()},
             "kernel_ms_source": f"HIP events on the engine's stream in a separate untimed pass over {KP} of the same frames",
@@ -448,7 +464,8 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
                          "frac_on_executed_evaluations": (executed * 9 / (hist_ms / max(hist_n, 1) * 1e-3) / 1e12 / valu_peak) if executed else None,
                          "executed_candidate_evals_per_frame": executed,
                          "executed_source": "profiles/hist_steps.json: steps counted by a -DMOLAR_HIP_DEBUG_KNOBS build on this workload's frame (separate run)",
-                         "avg_launch_ms": hist_ms / max(hist_n, 1), "grid_dims": [int(x) for x in gd],
+                         "avg_launch_ms": hist_ms / max(hist_n, 1), "avg_launch_ms_is": "histogram kernels' time per FRAME",
+                         "launches_in_profile_pass": hist_launches, "frames_in_profile_pass": KP, "grid_dims": [int(x) for x in gd],
                          "candidate_evals_per_frame": cand, "candidate_evals_per_sec": cand * K * world / t},
             "reduced_bins_equal_single_rank": check,
         })
@@ -671,6 +688,9 @@ def main():
     ap.add_argument("--decode-threads", type=int, default=0, help="--source xtc --decoder host: decoder threads per rank (0 = host cores / ranks)")
     ap.add_argument("--xtc-window", type=int, default=0, help="--source xtc: frames per decode window (0 = 16 for the host decoder, 1024 for the device decoder)")
     ap.add_argument("--xtc-path", default="", help="--source xtc: where rank 0 writes the synthetic trajectory (default: a file under $TMPDIR or /tmp)")
+    ap.add_argument("--rdf-single-calls", action="store_true",
+                    help="rdf workload: one molar_hip_search_histogram call per frame (the form of rounds 2-5) instead of "
+                         "molar_hip_search_histogram_frames over blocks of frames")
     ap.add_argument("--no-secondary", action="store_true", help="search_fit: skip the short C4 (rdf) and C5 (membrane) legs attached to the line as `secondary`")
     ap.add_argument("--secondary", action="store_true", help="search_fit: run the secondary legs at N > 1 as well (default: N = 1 only)")
     ap.add_argument("--secondary-rdf-steps", type=int, default=200)

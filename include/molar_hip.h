@@ -257,6 +257,18 @@ int molar_hip_search_resident_end(molar_hip_ctx *ctx, int32_t ticket, uint64_t *
  * histogram kernel of the frame before: as for _begin, the inputs must be complete in memory at the call. */
 int molar_hip_search_histogram(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, float hmin,
                                float hmax, size_t nbins, uint64_t *bins, uint64_t *out_count);
+/* The same for a block of a trajectory: `nframes` frames of the request's first set, frame k at desc->xyz1 + k * xyz1_stride
+ * floats (second set: xyz2 + k * xyz2_stride), box of frame k at boxes9 + 9 k (NULL: desc->box9 for every frame) - the state
+ * iterator of analysis_task.rs:245-252 / io.rs:198-271 handed over a window at a time.  The sums in `bins` are those of
+ * nframes calls of molar_hip_search_histogram (integer bins do not care how their pairs are grouped).  Single-set periodic
+ * requests whose coordinates, index and bins are all in device memory, on a context that owns its stream, run in groups of up
+ * to eight frames that share their launches - the grids of a group are built together on the side stream while the group before
+ * is still in its histogram kernel, one plan launch and one persistent kernel walk the slots of all of them - and the call
+ * does not wait (molar_hip_synchronize before reading the bins; the frames must be complete in memory at the call).  Anything
+ * else is walked frame by frame through molar_hip_search_histogram. */
+int molar_hip_search_histogram_frames(molar_hip_ctx *ctx, const molar_hip_search_desc *desc, size_t nframes, size_t xyz1_stride,
+                                      size_t xyz2_stride, const float *boxes9, float hmin, float hmax, size_t nbins,
+                                      uint64_t *bins);
 /* Host arithmetic, no GPU: the table the fused histogram bins with.  Histogram1D::add_one's bin (stats.rs:29-35) is a
  * non-decreasing function of the squared distance; edges[b], b = 0..nbins (nbins + 1 floats), is the smallest
  * non-negative float d2 whose bin floor(n*(sqrt(d2)-min)/(max-min)) is >= b, found by bisection with the formula

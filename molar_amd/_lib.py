@@ -124,6 +124,7 @@ SYMBOLS = {
     "molar_hip_search_resident_begin": (_I, [_P, _P, _P]),
     "molar_hip_search_resident_end": (_I, [_P, C.c_int32, _P, _P, _P]),
     "molar_hip_search_histogram": (_I, [_P, _P, _F, _F, _SZ, _P, _P]),
+    "molar_hip_search_histogram_frames": (_I, [_P, _P, _SZ, _SZ, _SZ, _P, _F, _F, _SZ, _P]),
     "molar_hip_histogram_edges": (_I, [_F, _F, _SZ, _P]),
     "molar_hip_min_max": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
     "molar_hip_center_of_geometry": (_I, [_P, _P, _SZ, _P, _SZ, _P]),

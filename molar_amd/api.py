@@ -485,6 +485,54 @@ class Engine:
         self._keep = keep
         return bins, (int(cnt.value) if want_count else None)
 
+    def search_histogram_frames(self, kind, cutoff, hmin, hmax, nbins, frames, idx1=None, box=None, pbc=0, bins=None):
+        """molar_hip_search_histogram_frames: the frames of a trajectory block, `frames` = [nframes, natoms, 3] float32 (one
+        contiguous array or CUDA tensor), through the fused histogram; the same sums as nframes calls of search_histogram.
+        `box`: one 3x3 matrix for all frames or [nframes, 3, 3].  With frames, index and bins in device memory the frames go
+        through the GPU in groups that share their launches, and the call does not wait (synchronize() before reading)."""
+        stride = None
+        if _is_torch(frames) and frames.ndim == 3 and frames.stride(2) == 1 and frames.stride(1) == 3:
+            import torch
+            assert frames.dtype == torch.float32
+            stride = int(frames.stride(0))          # frames with a gap between them (a window of a larger buffer): no copy
+            fa, k1 = frames.data_ptr(), frames
+        else:
+            frames = _f32(frames)
+            fa, k1 = _addr(frames)
+        assert frames.ndim == 3 and frames.shape[2] == 3
+        idx1 = _u64(idx1)
+        nframes, natoms = int(frames.shape[0]), int(frames.shape[1])
+        if stride is None:
+            stride = natoms * 3
+        d = SearchDesc()
+        d.kind = kind
+        d.cutoff = float(cutoff)
+        ia, k2 = _addr(idx1)
+        d.xyz1 = fa
+        d.idx1 = ia
+        d.natoms1 = natoms
+        d.n1 = 0 if idx1 is None else idx1.shape[0]
+        keep = [k1, k2]
+        boxes_ptr = None
+        if box is not None:
+            b = np.asarray(box.get_matrix() if isinstance(box, PeriodicBox) else box, np.float32)
+            if b.ndim == 3:
+                b9 = np.ascontiguousarray(np.transpose(b, (0, 2, 1))).reshape(nframes, 9)      # column-major per frame
+                boxes_ptr = b9.ctypes.data
+                d.box9 = boxes_ptr
+            else:
+                b9 = np.ascontiguousarray(b.reshape(3, 3).T).reshape(9)
+                d.box9 = b9.ctypes.data
+            keep.append(b9)
+        d.pbc = pbc_mask(pbc)
+        if bins is None:
+            bins = np.zeros(nbins, np.uint64)
+        ba_, kb_ = _addr(bins)
+        check(self.lib.molar_hip_search_histogram_frames(self.ctx, C.byref(d), nframes, stride, 0, boxes_ptr, float(hmin), float(hmax),
+                                                         nbins, ba_))
+        self._keep = keep
+        return bins
+
     # ------------------------------------------------------------ measure
     def _sel_args(self, xyz, idx):
         xyz = _f32(xyz); idx = _u64(idx)

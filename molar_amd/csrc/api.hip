@@ -185,6 +185,15 @@ void molar_hip_destroy(molar_hip_ctx *c) {
                           &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb, &s.h16, &s.cell_org})
             b->release();
     }
+    for (auto &gen : c->hb_sets) for (auto &s : gen) {
+        for (DevBuf *b : {&s.xyz_stage, &s.idx_stage, &s.vdw_stage, &s.key, &s.cell_count, &s.cnt_pad, &s.cursor, &s.tmp_key, &s.sort_buf,
+                          &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb, &s.h16, &s.cell_org})
+            b->release();
+    }
+    for (DevBuf *b : {&c->hb_lean[0], &c->hb_lean[1], &c->hb_rest[0], &c->hb_rest[1], &c->hb_blocks[0], &c->hb_blocks[1]}) b->release();
+    if (c->hb_pin) (void)hipHostFree(c->hb_pin);
+    for (auto e : c->hb_pin_ev)
+        if (e) (void)hipEventDestroy(e);
     for (DevBuf *b : {&c->params, &c->task_desc, &c->task_nb, &c->slot_desc, &c->slot_cnt, &c->slot_base, &c->tile_sum, &c->scan_tmp, &c->sort_tmp, &c->sort_tmp_side, &c->scan_tmp_side, &c->scan_state, &c->fplan_tiles, &c->out_pairs_set[0], &c->out_dist_set[0], &c->out_pairs_set[1], &c->out_dist_set[1], &c->out_ids,
                       &c->wide_i, &c->wide_j, &c->hist, &c->hist_queue, &c->slot_desc_rest, &c->hist_edges, &c->dbg, &c->conn_deg, &c->conn_off, &c->conn_ent, &c->conn_neigh, &c->w_flags, &c->w_list, &c->w_part_cnt, &c->w_part, &c->w_tile_cnt, &c->w_tile_off, &c->task_mu, &c->task_moff, &c->maskbuf, &c->m_xyz1, &c->m_xyz2, &c->m_idx1, &c->m_idx2,
                       &c->m_mass1, &c->m_mass2, &c->m_partials, &c->m_results, &c->m_out})

@@ -210,7 +210,15 @@ struct molar_hip_ctx {
     mh::DevBuf dbg;            // builds with -DMOLAR_HIP_DEBUG_KNOBS: per-wave time accounting of hist_kernel
     mh::DevBuf hist_queue;     // slot queues and list counters of the fused histogram (hist_kernels.hpp)
     mh::DevBuf slot_desc_rest; // fused histogram: records of the slots the generic kernel takes (hist_plan_kernel)
-    unsigned long long hist_frames = 0;   // fused-histogram launches of this context (parity selects the list counters)
+    unsigned long long hist_frames = 0;   // fused-histogram launches of this context (mod 4: which pair of list counters a launch uses)
+    // molar_hip_search_histogram_frames: groups of frames through one set of launches (search.hip, hist_frames_group)
+    mh::GridSet hb_sets[2][8];            // grids of a group's frames, two generations
+    mh::DevBuf hb_lean[2], hb_rest[2];    // the group's two slot lists
+    mh::DevBuf hb_blocks[2];              // [8 parameter blocks | 8 grid records] of the group
+    void *hb_pin = nullptr;               // pinned staging of those records: four slots
+    hipEvent_t hb_pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool hb_pin_used[4] = {false, false, false, false};
+    unsigned hb_pin_next = 0;
     bool hist_plan_now = false;           // set around prepare_search by the fused histogram of the fixed-cutoff kinds
     mh::DevBuf hist_edges;     // f32[nbins + 1]: smallest d2 that reaches each bin (hist_kernel), for the cached (min, max, nbins)
     float edges_min = 0.f, edges_max = 0.f;

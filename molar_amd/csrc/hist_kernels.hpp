@@ -61,7 +61,7 @@ constexpr uint32_t HQ_WORDS = 512;             // per-wave stack, 32-bit words
 constexpr int HQ_ROW_CHUNKS = 6;               // chunks of a row between two looks at the stack: < 128 left over + 6 * 64 pushed fit
 static_assert(HQ_WORDS >= 127u + 64u * (uint32_t)HQ_ROW_CHUNKS && 2 * HQ_ROW_CHUNKS >= KREG, "a row is drained at most once in its middle");
 constexpr uint32_t HIST_NSUB = 4;              // slot queues per XCD
-constexpr uint32_t HIST_LIST_WORD = 32u * (8u * HIST_NSUB + 1u);      // queue words: [queue counters][done][lean, rest counts of parity 0][... of parity 1]
+constexpr uint32_t HIST_LIST_WORD = 32u * (8u * HIST_NSUB + 1u);      // queue words: [queue counters][done][lean, rest counts of list slot 0] ... [of list slot 3]
 constexpr uint32_t HIST_TRI_ROWS = 32;         // rows per slot of a same-cell entry: every row meets all chunks, a 64-row slot took 2.7x a plain one
 
 struct HistState {
@@ -322,10 +322,13 @@ __device__ __forceinline__ uint32_t hist_run_wrapped(const SearchParams &P, cons
 template <int KIND, bool BIG>
 __global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(8)))
 hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ slot_desc, uint32_t nslots_bound,
-            uint32_t *__restrict__ queue, uint32_t parity) {
+            uint32_t *__restrict__ queue, uint32_t lslot) {
     __shared__ float4 lds_a[HIST_WAVES][64];
     __shared__ uint32_t lds_q[HIST_WAVES][HQ_WORDS];
     extern __shared__ uint32_t lds_hist[];
+    // One launch may carry the slots of SEVERAL frames (molar_hip_search_histogram_frames): Pp is then an array with one block per
+    // frame and a slot's record says which one is its own (coordinates, box, band).  What belongs to the histogram - bins, range,
+    // edges - is the same in all of them and is read from the first.
     const SearchParams &P = *Pp;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = sgpr(threadIdx.x >> 6);
@@ -365,7 +368,7 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
     // free takes what is left, across workgroups.  (One counter for the whole grid serialises: 7*10^4 atomics on one address
     // took 1.1 ms in round 2; here a counter sees ~1800 of them over the kernel's 0.25 ms.)  The last workgroup to leave
     // zeroes the counters for the next launch.
-    const uint32_t nlist = queue[HIST_LIST_WORD + 64u * parity];                    // records hist_plan_kernel wrote into this kernel's list
+    const uint32_t nlist = queue[HIST_LIST_WORD + 64u * lslot];                     // records hist_plan_kernel wrote into this kernel's list
     const uint32_t nslots = sgpr(nlist < nslots_bound ? nlist : nslots_bound);
     const uint32_t qx = blockIdx.x & 7u, qj = (blockIdx.x >> 3) & (HIST_NSUB - 1u);
     uint32_t *const qctr = queue + 32u * (qx * HIST_NSUB + qj);                      // one counter per 128-byte line
@@ -389,11 +392,12 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         if (w >= nslots) continue;
         const uint32_t slot = nslots - 1u - w;
         Task T;
-        uint32_t i0, fl;
+        uint32_t i0, fl, frame;
         {
             const uint4 lo = reinterpret_cast<const uint4 *>(slot_desc + slot)[0];
             const uint4 hi = reinterpret_cast<const uint4 *>(slot_desc + slot)[1];
             fl = sgpr(hi.y);
+            frame = sgpr(hi.w);
             T.a0 = sgpr(lo.x);
             T.n1 = sgpr(lo.y);
             T.b0 = sgpr(lo.z);
@@ -406,9 +410,10 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
             T.wrap_b = (fl >> 12) & 7u;
             T.rps = fl >> 16;
         }
+        const SearchParams &PF = Pp[frame];          // this slot's frame
 #ifdef MOLAR_HIP_DEBUG_KNOBS
         if (P.debug_skip) {
-            const uint32_t kind_bit = T.tri ? 4u : ((P.use_box && T.wrap != 0u) ? 2u : 1u);
+            const uint32_t kind_bit = T.tri ? 4u : ((PF.use_box && T.wrap != 0u) ? 2u : 1u);
             if (P.debug_skip & kind_bit) continue;
         }
 #endif
@@ -426,20 +431,20 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         default: total = CALL(8); break;     \
     }
         if (!BIG) {
-            if (P.use_box && T.wrap != 0u) {
+            if (PF.use_box && T.wrap != 0u) {
                 if (tail) {                    // plain hits still on the stack: out before entries of the other layout go in
                     hist_pop_plain(H, 0u, tail, lane);
                     tail = 0u;
                 }
-#define MH_HIST_WRAPPED(N) hist_run_wrapped<KIND, N>(P, T, i0, H, lds_a[wave], lane)
+#define MH_HIST_WRAPPED(N) hist_run_wrapped<KIND, N>(PF, T, i0, H, lds_a[wave], lane)
                 MH_HIST_CASES(MH_HIST_WRAPPED)
 #undef MH_HIST_WRAPPED
             } else if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) {
-#define MH_HIST_TRI(N) hist_run_plain<KIND, N, true>(P, T, i0, H, tail, lds_a[wave], lane)
+#define MH_HIST_TRI(N) hist_run_plain<KIND, N, true>(PF, T, i0, H, tail, lds_a[wave], lane)
                 MH_HIST_CASES(MH_HIST_TRI)
 #undef MH_HIST_TRI
             } else {
-#define MH_HIST_PLAIN(N) hist_run_plain<KIND, N, false>(P, T, i0, H, tail, lds_a[wave], lane)
+#define MH_HIST_PLAIN(N) hist_run_plain<KIND, N, false>(PF, T, i0, H, tail, lds_a[wave], lane)
                 MH_HIST_CASES(MH_HIST_PLAIN)
 #undef MH_HIST_PLAIN
             }
@@ -462,20 +467,20 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         case 7: part = CALL(7); break;         \
         default: part = CALL(8); break;        \
     }
-                if (P.use_box && T.wrap != 0u) {
+                if (PF.use_box && T.wrap != 0u) {
                     if (tail) {                    // plain hits still on the stack: out before entries of the other layout go in
                         hist_pop_plain(H, 0u, tail, lane);
                         tail = 0u;
                     }
-#define MH_HIST_WRAPPED_B(N) hist_run_wrapped<KIND, N>(P, T, i0, H, lds_a[wave], lane)
+#define MH_HIST_WRAPPED_B(N) hist_run_wrapped<KIND, N>(PF, T, i0, H, lds_a[wave], lane)
                     MH_HIST_CASES_B(MH_HIST_WRAPPED_B)
 #undef MH_HIST_WRAPPED_B
                 } else if (KIND == MOLAR_HIP_SEARCH_SINGLE && T.tri) {
-#define MH_HIST_TRI_B(N) hist_run_plain<KIND, N, true>(P, T, i0, H, tail, lds_a[wave], lane)
+#define MH_HIST_TRI_B(N) hist_run_plain<KIND, N, true>(PF, T, i0, H, tail, lds_a[wave], lane)
                     MH_HIST_CASES_B(MH_HIST_TRI_B)
 #undef MH_HIST_TRI_B
                 } else {
-#define MH_HIST_PLAIN_B(N) hist_run_plain<KIND, N, false>(P, T, i0, H, tail, lds_a[wave], lane)
+#define MH_HIST_PLAIN_B(N) hist_run_plain<KIND, N, false>(PF, T, i0, H, tail, lds_a[wave], lane)
                     MH_HIST_CASES_B(MH_HIST_PLAIN_B)
 #undef MH_HIST_PLAIN_B
                 }
@@ -487,7 +492,7 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
 #ifdef MOLAR_HIP_DEBUG_KNOBS
         {
             const unsigned long long tc = __builtin_amdgcn_s_memrealtime();
-            const bool wrapped = P.use_box && T.wrap != 0u;
+            const bool wrapped = PF.use_box && T.wrap != 0u;
             dbg_pre += H.t_mark - dbg_ta;
             dbg_rows += tc - H.t_mark;
             dbg_last = dbg_ta;
@@ -540,14 +545,17 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         if (v) atomicAdd(&P.hist_bins[b], (unsigned long long)v);
     }
     if (lane == 0 && wave_total && P.hist_total) atomicAdd(P.hist_total, wave_total);
-    // every wave of this workgroup is past its last ticket (the barrier above): the last workgroup out resets the queues, and
-    // the list counters of the OTHER parity for the next frame's plan (this frame's are still read by the generic kernel behind us)
+    // every wave of this workgroup is past its last ticket (the barrier above): the last workgroup out resets the queues, and the
+    // list counters the launch AFTER THE NEXT will use.  (This launch's own are still read by the generic kernel behind it; the
+    // next launch's may be being written already: the plans of a multi-frame launch run on the side stream while the launch
+    // before it is still at work.  A plan starts only after the launch two before it has ended - the generation's event.)
     if (threadIdx.x == 0) {
         uint32_t *done = queue + 32u * (8u * HIST_NSUB);
         if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
             for (uint32_t i = 0; i <= 8u * HIST_NSUB; ++i) __hip_atomic_store(queue + 32u * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(queue + HIST_LIST_WORD + 64u * (parity ^ 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(queue + HIST_LIST_WORD + 64u * (parity ^ 1u) + 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t z = (lslot + 2u) & 3u;
+            __hip_atomic_store(queue + HIST_LIST_WORD + 64u * z, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(queue + HIST_LIST_WORD + 64u * z + 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -558,15 +566,10 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
 // scans its entries' row-block counts in LDS, reserves its share of the list with ONE atomic and writes the records - into the lean
 // kernel's list or, for the entries only the generic kernel can do, into that kernel's own (so neither walks the other's slots).
 template <int KIND>
-__global__ void __launch_bounds__(256) hist_plan_kernel(SearchParams P, SearchParams *__restrict__ params_dst, SlotDesc *__restrict__ lean,
-                                                        SlotDesc *__restrict__ rest, uint32_t *__restrict__ counts) {
+__device__ __forceinline__ void hist_plan_body(const SearchParams &P, uint32_t frame, SlotDesc *__restrict__ lean, SlotDesc *__restrict__ rest,
+                                               uint32_t *__restrict__ counts) {
     __shared__ uint32_t sh[2][256];
     __shared__ uint32_t base[2];
-    if (blockIdx.x == 0) {      // the parameter block the two kernels read, from this kernel's own argument segment (P is its first argument)
-        const uint32_t *src = (const uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
-        uint32_t *d = (uint32_t *)params_dst;
-        for (uint32_t w = threadIdx.x; w < (uint32_t)(sizeof(SearchParams) / 4u); w += blockDim.x) d[w] = src[w];
-    }
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     Task T;
     uint32_t nb = 0u, fl = 0u, rps = 64u;
@@ -602,7 +605,7 @@ __global__ void __launch_bounds__(256) hist_plan_kernel(SearchParams P, SearchPa
     SlotDesc *out = (is_lean ? lean : rest) + base[l] + (sh[l][threadIdx.x] - nb);
     SlotDesc o;
     o.a0 = T.a0; o.n1 = T.n1; o.b0 = T.b0; o.n2 = T.n2;
-    o.cb = T.cb; o.flags = fl; o.pad0 = 0u;
+    o.cb = T.cb; o.flags = fl; o.frame = frame;
     o.moff = ~0ull >> 1;          // no hit history in this mode
     o.pad1 = 0ull;
     for (uint32_t k = 0; k < nb; ++k) {
@@ -611,29 +614,56 @@ __global__ void __launch_bounds__(256) hist_plan_kernel(SearchParams P, SearchPa
     }
 }
 
+template <int KIND>
+__global__ void __launch_bounds__(256) hist_plan_kernel(SearchParams P, SearchParams *__restrict__ params_dst, SlotDesc *__restrict__ lean,
+                                                        SlotDesc *__restrict__ rest, uint32_t *__restrict__ counts) {
+    if (blockIdx.x == 0) {      // the parameter block the two kernels read, from this kernel's own argument segment (P is its first argument)
+        const uint32_t *src = (const uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t *d = (uint32_t *)params_dst;
+        for (uint32_t w = threadIdx.x; w < (uint32_t)(sizeof(SearchParams) / 4u); w += blockDim.x) d[w] = src[w];
+    }
+    hist_plan_body<KIND>(P, 0u, lean, rest, counts);
+}
+
+// The plans of several frames in one launch (blockIdx.y: the frame): the parameter blocks are in device memory already (the grid
+// build of the batch put them there), every frame's records go into the same two lists with the frame's number in them.
+template <int KIND>
+__global__ void __launch_bounds__(256) hist_plan_frames_kernel(const SearchParams *__restrict__ params, SlotDesc *__restrict__ lean,
+                                                               SlotDesc *__restrict__ rest, uint32_t *__restrict__ counts) {
+    hist_plan_body<KIND>(params[blockIdx.y], blockIdx.y, lean, rest, counts);
+}
+
 // words of the queue buffer: slot queues, the `done` word, two pairs of list counters (zeroed once when the buffer is made;
 // every launch leaves the queues and the next frame's list counters zeroed)
-constexpr size_t HIST_QUEUE_WORDS = HIST_LIST_WORD + 4u * 32u;
+constexpr size_t HIST_QUEUE_WORDS = HIST_LIST_WORD + 8u * 32u;
 
 template <int KIND>
 inline void launch_hist_plan_kernel(hipStream_t stream, const SearchParams &P, SearchParams *params_dst, SlotDesc *lean, SlotDesc *rest,
-                                    uint32_t *queue, int parity) {
+                                    uint32_t *queue, int lslot) {
     const unsigned nb = (unsigned)((P.ntasks + 255ull) / 256ull);
     hipLaunchKernelGGL((hist_plan_kernel<KIND>), dim3(nb ? nb : 1u), dim3(256), 0, stream, P, params_dst, lean, rest,
-                       queue + HIST_LIST_WORD + 64u * (unsigned)parity);
+                       queue + HIST_LIST_WORD + 64u * (unsigned)lslot);
+}
+
+template <int KIND>
+inline void launch_hist_plan_frames_kernel(hipStream_t stream, const SearchParams *params, unsigned nframes, uint64_t ntasks_max, SlotDesc *lean,
+                                           SlotDesc *rest, uint32_t *queue, int lslot) {
+    const unsigned nb = (unsigned)((ntasks_max + 255ull) / 256ull);
+    hipLaunchKernelGGL((hist_plan_frames_kernel<KIND>), dim3(nb ? nb : 1u, nframes), dim3(256), 0, stream, params, lean, rest,
+                       queue + HIST_LIST_WORD + 64u * (unsigned)lslot);
 }
 
 template <int KIND>
 inline void launch_hist_kernel(unsigned num_cus, size_t dyn_lds, hipStream_t stream, const SearchParams *dP,
-                               const SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int parity, bool big) {
+                               const SlotDesc *slot_desc, uint32_t nslots_bound, uint32_t *queue, int lslot, bool big) {
     // persistent workgroups; a multiple of 8 * HIST_NSUB wide so that every queue has the same number of takers
     unsigned nb = num_cus * (HIST_CU_WAVES / HIST_WAVES);
     nb = (nb / (8u * HIST_NSUB)) * (8u * HIST_NSUB);
     if (nb == 0) nb = 8u * HIST_NSUB;
     if (big)
-        hipLaunchKernelGGL((hist_kernel<KIND, true>), dim3(nb), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots_bound, queue, (uint32_t)parity);
+        hipLaunchKernelGGL((hist_kernel<KIND, true>), dim3(nb), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots_bound, queue, (uint32_t)lslot);
     else
-        hipLaunchKernelGGL((hist_kernel<KIND, false>), dim3(nb), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots_bound, queue, (uint32_t)parity);   // counters, then the nbins + 1 bin edges
+        hipLaunchKernelGGL((hist_kernel<KIND, false>), dim3(nb), dim3(64 * HIST_WAVES), 2 * dyn_lds + 4, stream, dP, slot_desc, nslots_bound, queue, (uint32_t)lslot);   // counters, then the nbins + 1 bin edges
 }
 
 }  // namespace pairk

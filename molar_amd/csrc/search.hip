@@ -123,9 +123,8 @@ __device__ __forceinline__ V3 load_pos(const float *xyz, uint64_t a) {
 // chip's rate of returning atomics, ~28 G/s, not by queues on single addresses: one set of counters per XCD, chosen by
 // HW_REG_XCC_ID and incremented at workgroup scope, left it at 41 us.  The compiler emits the same instruction -
 // global_atomic_add ... sc0 - for workgroup and agent scope on gfx950.)
-__global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restrict__ key,
-                                                  uint32_t *__restrict__ arrival, uint32_t *__restrict__ counters,
-                                                  uint32_t pad_shift) {
+__device__ __forceinline__ void bin_body(const BinParams &P, uint32_t *__restrict__ key, uint32_t *__restrict__ arrival,
+                                         uint32_t *__restrict__ counters, uint32_t pad_shift) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P.n) return;
     const uint64_t a = P.idx ? P.idx[k] : (uint64_t)k;
@@ -133,6 +132,25 @@ __global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restr
     key[k] = c.key;
     // arrival order inside the cell (arbitrary): lets scatter place the atom without a second atomic
     if (c.key != DROPPED) arrival[k] = atomicAdd(&counters[(size_t)(c.key >> 1) << pad_shift], 1u);
+}
+__global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restrict__ key,
+                                                  uint32_t *__restrict__ arrival, uint32_t *__restrict__ counters,
+                                                  uint32_t pad_shift) {
+    bin_body(P, key, arrival, counters, pad_shift);
+}
+
+// The grids of several frames in one set of launches (molar_hip_search_histogram_frames): what the kernels of ONE frame take, as a
+// record in device memory; blockIdx.y picks the frame.  The frames of a batch have the same number of atoms and cells, so the
+// launch shapes and the scalar arguments are shared.
+struct GridFrame {
+    BinParams P;
+    uint32_t *key, *cursor, *counters, *cell_count, *cnt_pad, *tmp_key;
+    float4 *sorted, *aabb, *perm, *chunk_aabb, *cell_org;
+    uint4 *h16;
+};
+__global__ void __launch_bounds__(256) bin_frames_kernel(const GridFrame *__restrict__ G, uint32_t pad_shift) {
+    const GridFrame &g = G[blockIdx.y];
+    bin_body(g.P, g.key, g.cursor, g.counters, pad_shift);
 }
 
 // The same with the counters privatised (round 4): a workgroup of 256 threads takes a tile of 256 * BIN_PER_THREAD consecutive atoms,
@@ -142,8 +160,8 @@ __global__ void __launch_bounds__(256) bin_kernel(BinParams P, uint32_t *__restr
 // index.)  For grids whose counters fit in LDS.
 constexpr uint32_t BIN_TILE_MAX_CELLS = 12288;      // 48 KB of LDS counters
 template <uint32_t BIN_PER_THREAD>
-__global__ void __launch_bounds__(256) bin_tile_kernel(BinParams P, uint32_t *__restrict__ key, uint32_t *__restrict__ arrival,
-                                                       uint32_t *__restrict__ counters, uint32_t pad_shift, uint32_t ncells) {
+__device__ __forceinline__ void bin_tile_body(const BinParams &P, uint32_t *__restrict__ key, uint32_t *__restrict__ arrival,
+                                              uint32_t *__restrict__ counters, uint32_t pad_shift, uint32_t ncells) {
     extern __shared__ uint32_t bin_cnt[];
     for (uint32_t c = threadIdx.x; c < ncells; c += 256u) bin_cnt[c] = 0u;
     __syncthreads();
@@ -173,6 +191,16 @@ __global__ void __launch_bounds__(256) bin_tile_kernel(BinParams P, uint32_t *__
         if (k < P.n && ky[u] != DROPPED) arrival[k] = bin_cnt[ky[u] >> 1] + lr[u];
     }
 }
+template <uint32_t BIN_PER_THREAD>
+__global__ void __launch_bounds__(256) bin_tile_kernel(BinParams P, uint32_t *__restrict__ key, uint32_t *__restrict__ arrival,
+                                                       uint32_t *__restrict__ counters, uint32_t pad_shift, uint32_t ncells) {
+    bin_tile_body<BIN_PER_THREAD>(P, key, arrival, counters, pad_shift, ncells);
+}
+template <uint32_t BIN_PER_THREAD>
+__global__ void __launch_bounds__(256) bin_tile_frames_kernel(const GridFrame *__restrict__ G, uint32_t pad_shift, uint32_t ncells) {
+    const GridFrame &g = G[blockIdx.y];
+    bin_tile_body<BIN_PER_THREAD>(g.P, g.key, g.cursor, g.counters, pad_shift, ncells);
+}
 
 // one launch instead of hipMemsetAsync, which splits an unaligned range into up to three fill kernels (~5 us each)
 __global__ void __launch_bounds__(256) zero2_kernel(uint32_t *__restrict__ a, size_t na, uint32_t *__restrict__ b, size_t nb) {
@@ -193,6 +221,19 @@ __global__ void __launch_bounds__(256) unpad_kernel(uint32_t ncells, const uint3
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < ncells) cell_count[c] = padded[(size_t)c << pad_shift];
 }
+// (frames: zero the counters of every frame / copy the padded counters out)
+__global__ void __launch_bounds__(256) zero_frames_kernel(const GridFrame *__restrict__ G, size_t na, size_t nb) {
+    const GridFrame &g = G[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < na) g.cell_count[i] = 0u;
+        else g.cnt_pad[i - na] = 0u;
+    }
+}
+__global__ void __launch_bounds__(256) unpad_frames_kernel(const GridFrame *__restrict__ G, uint32_t ncells, uint32_t pad_shift) {
+    const GridFrame &g = G[blockIdx.y];
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncells) g.cell_count[c] = g.cnt_pad[(size_t)c << pad_shift];
+}
 
 __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t *__restrict__ key,
                                                       const uint32_t *__restrict__ cell_start,
@@ -205,6 +246,14 @@ __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t
     const uint32_t cell = ky >> 1;
     const uint32_t pos = cell_start[cell] + arrival[k];
     tmp_key[pos] = ((ky & 1u) << 31) | k;     // sort key inside the cell: in-box first, then input order
+}
+__global__ void __launch_bounds__(256) scatter_frames_kernel(const GridFrame *__restrict__ G, uint32_t n) {
+    const GridFrame &g = G[blockIdx.y];
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t ky = g.key[k];
+    if (ky == DROPPED) return;
+    g.tmp_key[g.cell_count[ky >> 1] + g.cursor[k]] = ((ky & 1u) << 31) | k;
 }
 
 // Grids of large cells (more than 384 atoms per cell on average: cutoffs that are large against the box) order their atoms by a
@@ -286,7 +335,7 @@ __global__ void __launch_bounds__(256) place_small_kernel(BinParams P, uint32_t 
         cell_org[c] = make_float4(org[0], org[1], org[2], 1.0001f * sqrtf((ex * ex + ey * ey) + ez * ez));
     }
 }
-__global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t ncells, int ids_local,
+__device__ __forceinline__ void place_order_body(const BinParams &P, uint32_t ncells, int ids_local,
                                                           const uint32_t *__restrict__ cell_start,
                                                           const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
                                                           float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
@@ -452,6 +501,20 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
             chunk_aabb[2 * (ubase + k) + 1] = make_float4(h3[0], h3[1], h3[2], 0.f);
         }
     }
+}
+__global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t ncells, int ids_local,
+                                                          const uint32_t *__restrict__ cell_start,
+                                                          const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
+                                                          float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
+                                                          float4 *__restrict__ aabb, float4 *__restrict__ perm,
+                                                          float4 *__restrict__ chunk_aabb, uint4 *__restrict__ h16,
+                                                          float4 *__restrict__ cell_org, int want_order, int presorted) {
+    place_order_body(P, ncells, ids_local, cell_start, tmp_key, vdw, sorted, sorted_vdw, aabb, perm, chunk_aabb, h16, cell_org, want_order, presorted);
+}
+__global__ void __launch_bounds__(64) place_order_frames_kernel(const GridFrame *__restrict__ G, uint32_t ncells, int ids_local) {
+    const GridFrame &g = G[blockIdx.y];
+    place_order_body(g.P, ncells, ids_local, g.cell_count, g.tmp_key, nullptr, g.sorted, nullptr, g.aabb, g.perm, g.chunk_aabb, g.h16, g.cell_org,
+                     /*want_order=*/1, /*presorted=*/0);
 }
 
 
@@ -838,6 +901,30 @@ __global__ void __launch_bounds__(64) scan_small_wave_kernel(const TIn *in, TOut
         carry += __shfl(inc, 63, 64);
     }
 }
+// cell counts -> cell starts of every frame of a batch, in place: one wave per frame (blockIdx.x)
+__global__ void __launch_bounds__(64) scan_frames_kernel(const GridFrame *__restrict__ G, uint32_t n) {
+    uint32_t *a = G[blockIdx.x].cell_count;
+    uint32_t carry = 0;
+    for (uint32_t start = 0; start < n; start += 512u) {
+        const uint32_t base = start + threadIdx.x * 8u;
+        uint32_t item[8], sum = 0;
+        for (int q = 0; q < 8; ++q) {
+            item[q] = base + q < n ? a[base + q] : 0u;
+            sum += item[q];
+        }
+        uint32_t inc = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if ((int)threadIdx.x >= off) inc += o;
+        }
+        uint32_t run = carry + inc - sum;
+        for (int q = 0; q < 8; ++q) {
+            if (base + q < n) a[base + q] = run;
+            run += item[q];
+        }
+        carry += __shfl(inc, 63, 64);
+    }
+}
 
 template <class TIn, class TOut>
 int exclusive_scan(molar_hip_ctx *c, const TIn *in, TOut *out, uint64_t n) {
@@ -1059,9 +1146,8 @@ static bool records_hit_history(const molar_hip_ctx *c) {
     return (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE) && small_cell_lanes(c) == 0;
 }
 
-int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
-    Prof prof(c, 0);
-    const uint32_t ncells = c->dims[0] * c->dims[1] * c->dims[2];
+// what the grid kernels take of the request (the context's cached search) and of a set
+static BinParams grid_bin_params(const molar_hip_ctx *c, const GridSet &S) {
     BinParams P{};
     P.xyz = S.d_xyz;
     P.idx = S.d_idx;
@@ -1076,6 +1162,33 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         P.upper[d] = c->upper[d];
     }
     P.box = c->box;
+    return P;
+}
+
+// one counter per 128-byte line while binning, as long as that stays small (<= 64 MB) and cells are crowded
+static uint32_t grid_pad_shift(uint32_t n, uint32_t ncells) { return (n && ncells <= (1u << 19) && (uint64_t)n >= 8ull * ncells) ? 5u : 0u; }
+
+static int grid_reserve(GridSet &S, uint32_t ncells) {
+    MH_TRY(S.key.reserve((size_t)(S.n ? S.n : 1) * 4));
+    MH_TRY(S.cell_count.reserve((size_t)(ncells + 1) * 4));
+    MH_TRY(S.cursor.reserve((size_t)(S.n ? S.n : 1) * 4));   // arrival order of each atom in its cell
+    MH_TRY(S.tmp_key.reserve((size_t)(S.n ? S.n : 1) * 4));
+    MH_TRY(S.sorted.reserve((size_t)(S.n ? S.n : 1) * sizeof(float4)));
+    if (S.d_vdw) MH_TRY(S.sorted_vdw.reserve((size_t)(S.n ? S.n : 1) * 4));
+    MH_TRY(S.aabb.reserve((size_t)ncells * 2 * sizeof(float4)));
+    MH_TRY(S.perm.reserve((size_t)(S.n ? S.n : 1) * 16));
+    MH_TRY(S.chunk_aabb.reserve(((size_t)S.n / 64 + ncells + 1) * 2 * sizeof(float4)));
+    MH_TRY(S.h16.reserve((size_t)(S.n ? S.n : 1) * 16));
+    MH_TRY(S.cell_org.reserve((size_t)(ncells + 1) * 16));
+    const uint32_t pad_shift = grid_pad_shift(S.n, ncells);
+    if (pad_shift) MH_TRY(S.cnt_pad.reserve(((size_t)ncells << pad_shift) * 4));
+    return 0;
+}
+
+int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
+    Prof prof(c, 0);
+    const uint32_t ncells = c->dims[0] * c->dims[1] * c->dims[2];
+    const BinParams P = grid_bin_params(c, S);
     MH_TRY(S.key.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.cell_count.reserve((size_t)(ncells + 1) * 4));
     MH_TRY(S.cursor.reserve((size_t)(S.n ? S.n : 1) * 4));   // arrival order of each atom in its cell
@@ -1088,7 +1201,7 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     MH_TRY(S.h16.reserve((size_t)(S.n ? S.n : 1) * 16));
     MH_TRY(S.cell_org.reserve((size_t)(ncells + 1) * 16));
     // one counter per 128-byte line while that stays small (<= 64 MB) and cells are crowded
-    const uint32_t pad_shift = (S.n && ncells <= (1u << 19) && (uint64_t)S.n >= 8ull * ncells) ? 5u : 0u;
+    const uint32_t pad_shift = grid_pad_shift(S.n, ncells);
     const size_t npad = pad_shift ? ((size_t)ncells << pad_shift) : 0;
     if (pad_shift) MH_TRY(S.cnt_pad.reserve(npad * 4));
     {
@@ -1365,10 +1478,10 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
             MH_HIP(hipMemsetAsync(c->hist_queue.p, 0, hist_queue_words() * 4, c->stream));
         }
         uint32_t *queue = c->hist_queue.as<uint32_t>();
-        const int parity = (int)(c->hist_frames++ & 1u);
-        P.hist_nslots = hist_list_count(queue, parity, 1);
-        launch_hist_plan(c->kind, c->stream, P, c->params.as<SearchParams>(), c->slot_desc.as<SlotDesc>(), c->slot_desc_rest.as<SlotDesc>(), queue, parity);
-        launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st, queue, parity, P.hist_big != 0u);
+        const int lslot = (int)(c->hist_frames++ & 3u);
+        P.hist_nslots = hist_list_count(queue, lslot, 1);
+        launch_hist_plan(c->kind, c->stream, P, c->params.as<SearchParams>(), c->slot_desc.as<SlotDesc>(), c->slot_desc_rest.as<SlotDesc>(), queue, lslot);
+        launch_hist_lean(c->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, tf, st, queue, lslot, P.hist_big != 0u);
         tf = c->slot_desc_rest.as<SlotDesc>();
     }
     // frames of large cells (more than 448 atoms per cell of the second set on average, i.e. cells above 512 are common): the
@@ -2586,6 +2699,212 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
     MH_TRY(read_back(c, h.data(), c->hist.p, (nbins + 1) * 8));
     for (size_t b = 0; b < nbins; ++b) bins[b] += h[b];
     if (out_count) *out_count = h[nbins];
+    return MOLAR_HIP_OK;
+}
+
+// Several frames of one trajectory through the fused histogram in ONE set of launches (BASELINE config 4: the frames of a
+// trajectory are independent, and bins do not care in which order - or of which frame - pairs are found).  What a frame costs
+// beside its arithmetic is all per LAUNCH: the persistent kernel's idle tail (a fifth of its span), the plan, the generic kernel
+// for the triclinic corner entries, and the grid of the next frame, which the persistent kernel keeps off the chip until that
+// tail.  A group of up to HIST_BATCH frames shares them:
+//   side stream : parameter blocks + grid records of the group (one copy from pinned memory), then the grids of ALL its frames by
+//                 the frame-indexed kernels (zero, bin, unpad, scan, scatter, place + order), then all plans in one launch - slot
+//                 records of every frame in the same two lists, the frame's number in the record;
+//   main stream : one hist_kernel over the joint list, one generic kernel over the joint rest list.
+// Two generations of everything the side stream writes; the side stream starts on a generation when the launch two before has
+// ended (gen_free, the event the asynchronous single-frame calls use as well: the two forms may be mixed on a context).
+// Returns 1 when the group does not qualify (the caller then walks it frame by frame), 0 when enqueued.
+constexpr int HIST_BATCH = 8;
+static_assert(HIST_BATCH <= (int)(sizeof(((molar_hip_ctx *)nullptr)->hb_sets[0]) / sizeof(mh::GridSet)), "hb_sets holds a group");
+
+static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, size_t first, int W, size_t stride1, const float *boxes9, float hmin,
+                             float hmax, size_t nbins, unsigned long long *bins) {
+    // ---- what every frame of the group comes to on the host: box, grid dims.  One shape for all of them, or no batch.
+    const float cutoff = q->cutoff;
+    if (!(cutoff > 0.0f)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: cutoff must be positive (got %g)", (double)cutoff);
+    const size_t nsel = q->idx1 ? q->n1 : q->natoms1;
+    if (nsel == 0 || nsel >= 0x7FFFFFFFull || q->natoms1 >= 0xFFFFFFFFull) return 1;
+    molar_hip_box boxes[HIST_BATCH];
+    uint32_t dims[3] = {0, 0, 0};
+    for (int f = 0; f < W; ++f) {
+        const float *b9 = boxes9 ? boxes9 + 9 * (first + f) : q->box9;
+        MH_TRY(molar_hip_box_from_matrix(b9, &boxes[f]));
+        float ext[3];
+        molar_hip_box_lab_extents(&boxes[f], ext);
+        c->box = boxes[f];
+        MH_TRY(dims_from_extents(c, cutoff, ext));
+        if (f == 0) for (int d = 0; d < 3; ++d) dims[d] = c->dims[d];
+        else if (dims[0] != c->dims[0] || dims[1] != c->dims[1] || dims[2] != c->dims[2]) return 1;
+    }
+    const uint64_t ncells64 = (uint64_t)dims[0] * dims[1] * dims[2];
+    if (ncells64 + 1 > 32768ull || (uint64_t)nsel > 384ull * ncells64) return 1;      // one-wave scan per frame; big cells are ordered by a device sort
+    const uint32_t ncells = (uint32_t)ncells64, n = (uint32_t)nsel;
+    c->kind = MOLAR_HIP_SEARCH_SINGLE;
+    c->use_box = true;
+    c->pbc = q->pbc & 7u;
+    c->cutoff = cutoff;
+    c->have_search = false;
+    c->hold_valid = false;
+    c->ntasks = ncells64 * 14ull;
+    // slots of one frame (prepare_search) incl. the 32-row slots of the same-cell entries
+    const uint64_t bound1 = 14ull * (((uint64_t)n + 63ull) / 64ull) + c->ntasks + 28ull * 512ull + ((uint64_t)n + 31ull) / 32ull + ncells64;
+    const uint64_t bound = bound1 * (uint64_t)W;
+    if (bound >= 0xFFFFFFF0ull) return 1;
+    const int gen = (c->hist_gen ^= 1);
+    MH_TRY(c->hb_lean[gen].reserve((bound1 * HIST_BATCH + 1) * sizeof(SlotDesc)));
+    MH_TRY(c->hb_rest[gen].reserve((bound1 * HIST_BATCH + 1) * sizeof(SlotDesc)));
+    const size_t blk_bytes = HIST_BATCH * (sizeof(SearchParams) + sizeof(GridFrame));
+    MH_TRY(c->hb_blocks[gen].reserve(blk_bytes));
+    if (!c->hb_pin) {
+        MH_HIP(hipHostMalloc(&c->hb_pin, 4 * blk_bytes, hipHostMallocDefault));
+        for (auto &e : c->hb_pin_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (!c->side_stream) {
+        int lo = 0, hi = 0;
+        MH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        MH_HIP(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi));
+        MH_HIP(hipEventCreateWithFlags(&c->grid_done, hipEventDisableTiming));
+    }
+    MH_TRY(ensure_hist_edges(c, hmin, hmax, nbins));
+    if (!c->hist_queue.p) {
+        MH_TRY(c->hist_queue.reserve(hist_queue_words() * 4));
+        MH_HIP(hipMemsetAsync(c->hist_queue.p, 0, hist_queue_words() * 4, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));          // the side stream's plan is the first to touch the counters
+    }
+    uint32_t *queue = c->hist_queue.as<uint32_t>();
+    const int lslot = (int)(c->hist_frames++ & 3u);
+    // ---- the group's records in the pinned slot: parameter blocks, then grid records
+    const int pslot = c->hb_pin_next++ & 3;
+    if (c->hb_pin_used[pslot]) MH_HIP(hipEventSynchronize(c->hb_pin_ev[pslot]));      // its copy of four groups ago has long run
+    char *pin = (char *)c->hb_pin + (size_t)pslot * blk_bytes;
+    SearchParams *hP = reinterpret_cast<SearchParams *>(pin);
+    GridFrame *hG = reinterpret_cast<GridFrame *>(pin + HIST_BATCH * sizeof(SearchParams));
+    SearchParams *dP = c->hb_blocks[gen].as<SearchParams>();
+    GridFrame *dG = reinterpret_cast<GridFrame *>((char *)c->hb_blocks[gen].p + HIST_BATCH * sizeof(SearchParams));
+    mh::GridSet *keep_set = c->set;
+    const uint32_t pad_shift = grid_pad_shift(n, ncells);
+    size_t dyn_lds = (size_t)nbins * 4;
+    bool big = false;
+    for (int f = 0; f < W; ++f) {
+        mh::GridSet &S = c->hb_sets[gen][f];
+        S.n = n;
+        S.d_xyz = q->xyz1 + (first + f) * stride1;
+        S.d_idx = q->idx1;
+        S.d_vdw = nullptr;
+        const int rrc = grid_reserve(S, ncells);
+        if (rrc) { c->set = keep_set; return rrc; }
+        c->box = boxes[f];
+        c->set = &S;                              // (SINGLE: set[1] is never read)
+        c->nslots_bound = bound;
+        SearchParams P = make_params(c);
+        P.nblocks = 0;
+        P.out_cap = ~0ull;
+        P.hist_nbins = (uint32_t)nbins;
+        P.hist_min = hmin;
+        P.hist_max = hmax;
+        P.hist_bins = bins;
+        P.hist_total = nullptr;
+        P.hist_lean = 1u;
+        P.hist_big = 0u;                          // (mean population <= 384: checked above)
+        P.hist_edges = nullptr;
+        P.hist_scale = 0.f;
+        if (c->edges_nbins == nbins && c->edges_min == hmin && c->edges_max == hmax) {
+            P.hist_edges = c->hist_edges.as<float>();
+            P.hist_scale = (float)nbins / (hmax - hmin);
+        }
+        P.hist_nslots = hist_list_count(queue, lslot, 1);
+        hP[f] = P;
+        GridFrame g{};
+        g.P = grid_bin_params(c, S);
+        g.key = S.key.as<uint32_t>();
+        g.cursor = S.cursor.as<uint32_t>();
+        g.cell_count = S.cell_count.as<uint32_t>();
+        g.cnt_pad = S.cnt_pad.as<uint32_t>();
+        g.counters = pad_shift ? g.cnt_pad : g.cell_count;
+        g.tmp_key = S.tmp_key.as<uint32_t>();
+        g.sorted = S.sorted.as<float4>();
+        g.aabb = S.aabb.as<float4>();
+        g.perm = S.perm.as<float4>();
+        g.chunk_aabb = S.chunk_aabb.as<float4>();
+        g.cell_org = S.cell_org.as<float4>();
+        g.h16 = S.h16.as<uint4>();
+        hG[f] = g;
+    }
+    c->set = keep_set;
+    // ---- side stream: records, grids, plans
+    hipStream_t ss = c->side_stream;
+    if (c->gen_free[gen]) MH_HIP(hipStreamWaitEvent(ss, c->gen_free[gen], 0));
+    MH_HIP(hipMemcpyAsync(c->hb_blocks[gen].p, pin, blk_bytes, hipMemcpyHostToDevice, ss));
+    MH_HIP(hipEventRecord(c->hb_pin_ev[pslot], ss));
+    c->hb_pin_used[pslot] = true;
+    {
+        const unsigned fw = (unsigned)W;
+        const size_t na = (size_t)ncells + 1, npad = pad_shift ? ((size_t)ncells << pad_shift) : 0;
+        const unsigned zb = (unsigned)std::min<size_t>((na + npad + 255) / 256, 512u);
+        hipLaunchKernelGGL(zero_frames_kernel, dim3(zb, fw), dim3(256), 0, ss, dG, na, npad);
+        const bool tile_ok = ncells <= BIN_TILE_MAX_CELLS && (uint64_t)n >= 16ull * ncells;
+        if (tile_ok && n >= (1u << 19))
+            hipLaunchKernelGGL(bin_tile_frames_kernel<32>, dim3((n + 256u * 32u - 1u) / (256u * 32u), fw), dim3(256), (size_t)ncells * 4, ss, dG, pad_shift, ncells);
+        else if (tile_ok && n >= (1u << 17))
+            hipLaunchKernelGGL(bin_tile_frames_kernel<8>, dim3((n + 256u * 8u - 1u) / (256u * 8u), fw), dim3(256), (size_t)ncells * 4, ss, dG, pad_shift, ncells);
+        else
+            hipLaunchKernelGGL(bin_frames_kernel, dim3((n + 255u) / 256u, fw), dim3(256), 0, ss, dG, pad_shift);
+        if (pad_shift) hipLaunchKernelGGL(unpad_frames_kernel, dim3((ncells + 255u) / 256u, fw), dim3(256), 0, ss, dG, ncells, pad_shift);
+        hipLaunchKernelGGL(scan_frames_kernel, dim3(fw), dim3(64), 0, ss, dG, ncells + 1u);
+        hipLaunchKernelGGL(scatter_frames_kernel, dim3((n + 255u) / 256u, fw), dim3(256), 0, ss, dG, n);
+        hipLaunchKernelGGL(place_order_frames_kernel, dim3(ncells, fw), dim3(64), 0, ss, dG, ncells, q->ids_local);
+        launch_hist_plan_frames(MOLAR_HIP_SEARCH_SINGLE, ss, dP, fw, c->ntasks, c->hb_lean[gen].as<SlotDesc>(), c->hb_rest[gen].as<SlotDesc>(), queue, lslot);
+        MH_HIP(hipGetLastError());
+    }
+    MH_HIP(hipEventRecord(c->grid_done, ss));
+    // ---- main stream: the two kernels over the joint lists
+    MH_HIP(hipStreamWaitEvent(c->stream, c->grid_done, 0));
+    {
+        Prof prof(c, 3);
+        launch_hist_lean(MOLAR_HIP_SEARCH_SINGLE, (unsigned)c->num_cus, dyn_lds, c->stream, dP, c->hb_lean[gen].as<SlotDesc>(), (uint32_t)bound, queue, lslot, big);
+        uint32_t nblk = ((uint32_t)bound + (uint32_t)waves_per_block(MODE_HIST) - 1u) / (uint32_t)waves_per_block(MODE_HIST);
+        const uint32_t cap = (uint32_t)c->num_cus * 8u;
+        if (nblk > cap) nblk = cap;
+        launch_pair_single(MODE_HIST, nblk, dyn_lds, c->stream, dP, c->hb_rest[gen].as<SlotDesc>(), (uint32_t)bound, c->slot_cnt.as<uint32_t>(),
+                           c->slot_base.as<unsigned long long>(), nullptr, nullptr, nullptr);
+        MH_HIP(hipGetLastError());
+    }
+    if (!c->gen_free[gen]) MH_HIP(hipEventCreateWithFlags(&c->gen_free[gen], hipEventDisableTiming));
+    MH_HIP(hipEventRecord(c->gen_free[gen], c->stream));
+    return 0;
+}
+
+int molar_hip_search_histogram_frames(molar_hip_ctx *c, const molar_hip_search_desc *q, size_t nframes, size_t xyz1_stride, size_t xyz2_stride,
+                                      const float *boxes9, float hmin, float hmax, size_t nbins, uint64_t *bins) {
+    if (!c || !q || !bins) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_histogram_frames: null argument");
+    if (q->kind == MOLAR_HIP_SEARCH_WITHIN)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_histogram: a within search has no distances");
+    if (nbins == 0 || nbins > 8192) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_histogram: nbins must be in 1..8192");
+    if (nframes == 0) return MOLAR_HIP_OK;
+    if (!q->xyz1) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: xyz pointer is null");
+    MH_HIP(hipSetDevice(c->device));
+    // the batched form: one set, periodic, everything the kernels read already in device memory, a context with its own streams
+    const bool batch = q->kind == MOLAR_HIP_SEARCH_SINGLE && (q->box9 || boxes9) && c->own_stream && !c->env_no_side && is_device_ptr(bins) &&
+                       is_device_ptr(q->xyz1) && (!q->idx1 || is_device_ptr(q->idx1)) && !c->tickets[0].pending && !c->tickets[1].pending;
+    size_t f = 0;
+    while (f < nframes) {
+        const int W = (int)std::min<size_t>(HIST_BATCH, nframes - f);
+        int rc = 1;
+        if (batch && W >= 2) {
+            rc = hist_frames_group(c, q, f, W, xyz1_stride, boxes9, hmin, hmax, nbins, reinterpret_cast<unsigned long long *>(bins));
+            if (rc < 0 || rc > 1) return rc;
+        }
+        if (rc == 1) {               // frame by frame (the form molar_hip_search_histogram documents), same sums
+            for (int k = 0; k < W; ++k) {
+                molar_hip_search_desc qf = *q;
+                qf.xyz1 = q->xyz1 + (f + k) * xyz1_stride;
+                if (q->xyz2) qf.xyz2 = q->xyz2 + (f + k) * xyz2_stride;
+                if (boxes9) qf.box9 = boxes9 + 9 * (f + k);
+                MH_TRY(molar_hip_search_histogram(c, &qf, hmin, hmax, nbins, bins, nullptr));
+            }
+        }
+        f += (size_t)W;
+    }
     return MOLAR_HIP_OK;
 }
 

@@ -1363,3 +1363,75 @@ def test_fused_histogram_call_forms_interleaved(eng, orc32):
     torch.cuda.synchronize()
     for k, (n, cutoff, box, pos, dpos, want) in enumerate(systems):
         assert np.array_equal(dev_bins[k].cpu().numpy(), want * times[k]), (k, times[k])
+
+
+@pytest.mark.parametrize("boxkind,n,cutoff,nframes,pbc,strided", [
+    ("a", 30000, 0.9, 11, 7, False),        # triclinic box A: corner entries through the generic kernel's joint list; 8 + 3 frames
+    ("ortho", 20000, 0.8, 8, 7, False),
+    ("a", 140000, 1.0, 5, 7, False),        # >= 2^17 atoms: the tiled binning kernel
+    ("b", 9000, 0.7, 17, 7, True),          # sheared box, an index, frames with a gap between them; 8 + 8 + 1 (a group of one: single call)
+    ("ortho", 12000, 0.9, 6, 5, False),     # y not periodic: drop rule, fewer wrapped entries
+    ("npt", 25000, 0.85, 9, 7, False),      # a box per frame (same grid), one frame whose box gives ANOTHER grid: that group goes frame by frame
+])
+def test_fused_histogram_frames_equals_single_calls(eng, orc32, boxkind, n, cutoff, nframes, pbc, strided):
+    """molar_hip_search_histogram_frames: a block of a trajectory through the fused histogram in groups of up to eight frames
+    that share their launches (grids of a group built by frame-indexed kernels, one plan launch, one persistent kernel over
+    the joint slot list with the frame's number in every record).  The bins are integers: they must equal those of one
+    molar_hip_search_histogram call per frame exactly, and the oracle's distance stream binned by Histogram1D::add_one
+    (molar_membrane/src/stats.rs:29-35).  Mixed with single-frame calls on the same context (the list counters rotate)."""
+    import torch
+    a = api()
+    e2 = a.Engine(0)
+    nbins = 400
+    base_box = {"a": synth.box_a, "b": synth.box_b, "ortho": synth.box_ortho, "npt": synth.box_a}[boxkind](n)
+    boxes = np.repeat(base_box[None], nframes, axis=0).astype(np.float32)
+    if boxkind == "npt":
+        for f in range(nframes):
+            boxes[f] *= np.float32(1.0 + 0.002 * np.sin(f))
+        boxes[4] *= np.float32(1.15)        # another grid in the middle of the first group
+    frames_np = np.stack([synth.frame(n, boxes[f], f) for f in range(nframes)])
+    idx = np.sort(np.random.default_rng(5).choice(n, n - n // 7, replace=False)).astype(np.uint64) if strided else None
+    if strided:
+        store = torch.zeros((nframes, n + 37, 3), dtype=torch.float32, device="cuda")
+        store[:, :n] = torch.from_numpy(frames_np).cuda()
+        dframes = store[:, :n]              # stride (n + 37) * 3 floats between frames
+    else:
+        dframes = torch.from_numpy(frames_np).cuda()
+    didx = None if idx is None else torch.from_numpy(idx.astype(np.int64)).cuda()
+    bins_f = torch.zeros(nbins, dtype=torch.int64, device="cuda")
+    bins_s = torch.zeros(nbins, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    want = np.zeros(nbins, np.int64)
+    for f in range(nframes):
+        p = frames_np[f] if idx is None else frames_np[f][idx.astype(int)]
+        ref = orc32.search_single_pbc(cutoff, p, orc32.box_from_matrix(boxes[f]), pbc, nthreads=8)
+        want += orc32.histogram_add(0.0, cutoff, nbins, ref["d"]).astype(np.int64)
+    box_arg = boxes if boxkind == "npt" else base_box
+    for rep in range(3):                    # three blocks back to back: both generations of the group buffers, all four list slots
+        e2.search_histogram_frames(a.SEARCH_SINGLE, cutoff, 0.0, cutoff, nbins, dframes, idx1=didx, box=box_arg, pbc=pbc, bins=bins_f)
+        if rep == 1:                        # a queued single-frame call in between
+            e2.search_histogram(a.SEARCH_SINGLE, cutoff, 0.0, cutoff, nbins, dframes[0], idx1=didx, box=boxes[0], pbc=pbc, bins=bins_s, want_count=False)
+    e2.synchronize()
+    got = bins_f.cpu().numpy()
+    assert want.sum() > 0
+    assert np.array_equal(got, 3 * want), (int(got.sum()), int(3 * want.sum()))
+    one = bins_s.cpu().numpy().copy()
+    for f in range(1, nframes):
+        e2.search_histogram(a.SEARCH_SINGLE, cutoff, 0.0, cutoff, nbins, dframes[f], idx1=didx, box=boxes[f], pbc=pbc, bins=bins_s, want_count=False)
+    e2.synchronize()
+    assert np.array_equal(bins_s.cpu().numpy(), want)
+    assert one.sum() > 0
+
+
+def test_fused_histogram_frames_host_inputs(eng, orc32):
+    """Frames in host memory (or host bins) are walked frame by frame: the same sums."""
+    a = api()
+    n, cutoff, nbins, nframes = 6000, 0.8, 200, 3
+    box = synth.box_a(n)
+    frames_np = np.stack([synth.frame(n, box, f) for f in range(nframes)])
+    want = np.zeros(nbins, np.int64)
+    for f in range(nframes):
+        ref = orc32.search_single_pbc(cutoff, frames_np[f], orc32.box_from_matrix(box), 7, nthreads=4)
+        want += orc32.histogram_add(0.0, cutoff, nbins, ref["d"]).astype(np.int64)
+    bins = eng.search_histogram_frames(a.SEARCH_SINGLE, cutoff, 0.0, cutoff, nbins, frames_np, box=box, pbc=7)
+    assert np.array_equal(bins.astype(np.int64), want)
