@@ -635,7 +635,7 @@ def secondary_legs(args, rank, local_rank, world, device, cdev):
     import traceback
     out = {}
     t0 = time.perf_counter()
-    for name, fn, over in (("rdf", run_rdf, dict(workload="rdf", steps=args.secondary_rdf_steps, warmup=10, verify=True, profile_steps=50)),
+    for name, fn, over in (("rdf", run_rdf, dict(workload="rdf", steps=args.secondary_rdf_steps, warmup=32, verify=True, profile_steps=64)),
                            ("membrane", run_membrane, dict(workload="membrane", steps=args.secondary_membrane_steps, warmup=8, verify=True,
                                                            preheat=min(args.preheat, 1.0), streams=4))):
         a2 = copy.copy(args)
@@ -693,7 +693,7 @@ def main():
                          "molar_hip_search_histogram_frames over blocks of frames")
     ap.add_argument("--no-secondary", action="store_true", help="search_fit: skip the short C4 (rdf) and C5 (membrane) legs attached to the line as `secondary`")
     ap.add_argument("--secondary", action="store_true", help="search_fit: run the secondary legs at N > 1 as well (default: N = 1 only)")
-    ap.add_argument("--secondary-rdf-steps", type=int, default=200)
+    ap.add_argument("--secondary-rdf-steps", type=int, default=512)
     ap.add_argument("--secondary-membrane-steps", type=int, default=256)
     ap.add_argument("--no-pairs-only", action="store_true", help="search_fit: skip the extra leg that times the resident search with the (i, j) plane only")
     ap.add_argument("--verify", action="store_true",

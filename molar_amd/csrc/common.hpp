@@ -212,9 +212,11 @@ struct molar_hip_ctx {
     mh::DevBuf slot_desc_rest; // fused histogram: records of the slots the generic kernel takes (hist_plan_kernel)
     unsigned long long hist_frames = 0;   // fused-histogram launches of this context (mod 4: which pair of list counters a launch uses)
     // molar_hip_search_histogram_frames: groups of frames through one set of launches (search.hip, hist_frames_group)
-    mh::GridSet hb_sets[2][8];            // grids of a group's frames, two generations
+    mh::GridSet hb_sets[2][16];           // grids of a group's frames, two generations
+    bool hb_zeroed[2][16] = {};           // a set's padded cell counters are zero (the frames' unpad kernel leaves them so)
+    uint32_t hb_zeroed_cells[2][16] = {}; // ... for a grid of this many cells
     mh::DevBuf hb_lean[2], hb_rest[2];    // the group's two slot lists
-    mh::DevBuf hb_blocks[2];              // [8 parameter blocks | 8 grid records] of the group
+    mh::DevBuf hb_blocks[2];              // [parameter blocks | grid records] of the group
     void *hb_pin = nullptr;               // pinned staging of those records: four slots
     hipEvent_t hb_pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool hb_pin_used[4] = {false, false, false, false};

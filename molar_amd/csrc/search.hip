@@ -229,10 +229,46 @@ __global__ void __launch_bounds__(256) zero_frames_kernel(const GridFrame *__res
         else g.cnt_pad[i - na] = 0u;
     }
 }
-__global__ void __launch_bounds__(256) unpad_frames_kernel(const GridFrame *__restrict__ G, uint32_t ncells, uint32_t pad_shift) {
-    const GridFrame &g = G[blockIdx.y];
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < ncells) g.cell_count[c] = g.cnt_pad[(size_t)c << pad_shift];
+// Padded counters -> cell starts of every frame (one workgroup per frame): reads a frame's ncells counters, leaves them ZERO for the
+// next group that bins into this generation (so nothing has to be zeroed in front of the binning kernel again), and writes the
+// exclusive scan - cell_count[0 .. ncells], the last entry the number of kept atoms.  unpad + scan + zero of the single-frame
+// path in one launch.
+__global__ void __launch_bounds__(256) unpad_scan_frames_kernel(const GridFrame *__restrict__ G, uint32_t ncells, uint32_t pad_shift) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    const GridFrame &g = G[blockIdx.x];
+    if (threadIdx.x == 0) carry_s = 0u;
+    __syncthreads();
+    for (uint32_t start = 0; start <= ncells; start += 1024u) {
+        const uint32_t base = start + threadIdx.x * 4u;
+        uint32_t item[4], sum = 0;
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t cidx = base + q;
+            item[q] = 0u;
+            if (cidx < ncells) {
+                item[q] = g.cnt_pad[(size_t)cidx << pad_shift];
+                g.cnt_pad[(size_t)cidx << pad_shift] = 0u;
+            }
+            sum += item[q];
+        }
+        uint32_t inc = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if ((int)(threadIdx.x & 63u) >= off) inc += o;
+        }
+        if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t pre = carry_s;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) pre += wsum[w];
+        uint32_t run = pre + inc - sum;
+        for (int q = 0; q < 4; ++q) {
+            if (base + q <= ncells) g.cell_count[base + q] = run;
+            run += item[q];
+        }
+        __syncthreads();
+        if (threadIdx.x == 255u) carry_s = pre + inc;
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(256) scatter_kernel(uint32_t n, const uint32_t *__restrict__ key,
@@ -2708,13 +2744,14 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
 // for the triclinic corner entries, and the grid of the next frame, which the persistent kernel keeps off the chip until that
 // tail.  A group of up to HIST_BATCH frames shares them:
 //   side stream : parameter blocks + grid records of the group (one copy from pinned memory), then the grids of ALL its frames by
-//                 the frame-indexed kernels (zero, bin, unpad, scan, scatter, place + order), then all plans in one launch - slot
-//                 records of every frame in the same two lists, the frame's number in the record;
-//   main stream : one hist_kernel over the joint list, one generic kernel over the joint rest list.
+//                 the frame-indexed kernels (bin, unpad + scan, scatter, place + order), then all plans in one launch - slot
+//                 records of every frame in the same two lists, the frame's number in the record - and the generic kernel
+//                 over the joint rest list;
+//   main stream : one hist_kernel over the joint list.
 // Two generations of everything the side stream writes; the side stream starts on a generation when the launch two before has
 // ended (gen_free, the event the asynchronous single-frame calls use as well: the two forms may be mixed on a context).
 // Returns 1 when the group does not qualify (the caller then walks it frame by frame), 0 when enqueued.
-constexpr int HIST_BATCH = 8;
+constexpr int HIST_BATCH = 16;
 static_assert(HIST_BATCH <= (int)(sizeof(((molar_hip_ctx *)nullptr)->hb_sets[0]) / sizeof(mh::GridSet)), "hb_sets holds a group");
 
 static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, size_t first, int W, size_t stride1, const float *boxes9, float hmin,
@@ -2841,7 +2878,14 @@ static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, s
         const unsigned fw = (unsigned)W;
         const size_t na = (size_t)ncells + 1, npad = pad_shift ? ((size_t)ncells << pad_shift) : 0;
         const unsigned zb = (unsigned)std::min<size_t>((na + npad + 255) / 256, 512u);
-        hipLaunchKernelGGL(zero_frames_kernel, dim3(zb, fw), dim3(256), 0, ss, dG, na, npad);
+        // (padded counters: unpad_scan_frames_kernel leaves them zero; a generation's sets are zeroed when they are new)
+        bool need_zero = !pad_shift;
+        for (int f = 0; f < W; ++f) {
+            if (!c->hb_zeroed[gen][f] || c->hb_zeroed_cells[gen][f] != ncells) need_zero = true;
+            c->hb_zeroed[gen][f] = pad_shift != 0;
+            c->hb_zeroed_cells[gen][f] = ncells;
+        }
+        if (need_zero) hipLaunchKernelGGL(zero_frames_kernel, dim3(zb, fw), dim3(256), 0, ss, dG, na, npad);
         const bool tile_ok = ncells <= BIN_TILE_MAX_CELLS && (uint64_t)n >= 16ull * ncells;
         if (tile_ok && n >= (1u << 19))
             hipLaunchKernelGGL(bin_tile_frames_kernel<32>, dim3((n + 256u * 32u - 1u) / (256u * 32u), fw), dim3(256), (size_t)ncells * 4, ss, dG, pad_shift, ncells);
@@ -2849,24 +2893,28 @@ static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, s
             hipLaunchKernelGGL(bin_tile_frames_kernel<8>, dim3((n + 256u * 8u - 1u) / (256u * 8u), fw), dim3(256), (size_t)ncells * 4, ss, dG, pad_shift, ncells);
         else
             hipLaunchKernelGGL(bin_frames_kernel, dim3((n + 255u) / 256u, fw), dim3(256), 0, ss, dG, pad_shift);
-        if (pad_shift) hipLaunchKernelGGL(unpad_frames_kernel, dim3((ncells + 255u) / 256u, fw), dim3(256), 0, ss, dG, ncells, pad_shift);
-        hipLaunchKernelGGL(scan_frames_kernel, dim3(fw), dim3(64), 0, ss, dG, ncells + 1u);
+        if (pad_shift) hipLaunchKernelGGL(unpad_scan_frames_kernel, dim3(fw), dim3(256), 0, ss, dG, ncells, pad_shift);
+        else hipLaunchKernelGGL(scan_frames_kernel, dim3(fw), dim3(64), 0, ss, dG, ncells + 1u);
         hipLaunchKernelGGL(scatter_frames_kernel, dim3((n + 255u) / 256u, fw), dim3(256), 0, ss, dG, n);
         hipLaunchKernelGGL(place_order_frames_kernel, dim3(ncells, fw), dim3(64), 0, ss, dG, ncells, q->ids_local);
         launch_hist_plan_frames(MOLAR_HIP_SEARCH_SINGLE, ss, dP, fw, c->ntasks, c->hb_lean[gen].as<SlotDesc>(), c->hb_rest[gen].as<SlotDesc>(), queue, lslot);
+        // The generic kernel (the triclinic corner entries of every frame of the group: short latency-bound slots) runs HERE, behind
+        // its plan on the side stream, not behind the persistent kernel on the main stream: there it met the next group's placement
+        // kernel - 10^4 one-wave workgroups of 5 KB of LDS each, from the stream of higher priority - and waited for it to drain
+        // (30 us alone, 450 us in every second group).  It adds into the same bins with the same integer atomics.
+        uint32_t nblk = ((uint32_t)bound + (uint32_t)waves_per_block(MODE_HIST) - 1u) / (uint32_t)waves_per_block(MODE_HIST);
+        const uint32_t cap = (uint32_t)c->num_cus * 8u;
+        if (nblk > cap) nblk = cap;
+        launch_pair_single(MODE_HIST, nblk, dyn_lds, ss, dP, c->hb_rest[gen].as<SlotDesc>(), (uint32_t)bound, c->slot_cnt.as<uint32_t>(),
+                           c->slot_base.as<unsigned long long>(), nullptr, nullptr, nullptr);
         MH_HIP(hipGetLastError());
     }
     MH_HIP(hipEventRecord(c->grid_done, ss));
-    // ---- main stream: the two kernels over the joint lists
+    // ---- main stream: the persistent kernel over the joint list
     MH_HIP(hipStreamWaitEvent(c->stream, c->grid_done, 0));
     {
         Prof prof(c, 3);
         launch_hist_lean(MOLAR_HIP_SEARCH_SINGLE, (unsigned)c->num_cus, dyn_lds, c->stream, dP, c->hb_lean[gen].as<SlotDesc>(), (uint32_t)bound, queue, lslot, big);
-        uint32_t nblk = ((uint32_t)bound + (uint32_t)waves_per_block(MODE_HIST) - 1u) / (uint32_t)waves_per_block(MODE_HIST);
-        const uint32_t cap = (uint32_t)c->num_cus * 8u;
-        if (nblk > cap) nblk = cap;
-        launch_pair_single(MODE_HIST, nblk, dyn_lds, c->stream, dP, c->hb_rest[gen].as<SlotDesc>(), (uint32_t)bound, c->slot_cnt.as<uint32_t>(),
-                           c->slot_base.as<unsigned long long>(), nullptr, nullptr, nullptr);
         MH_HIP(hipGetLastError());
     }
     if (!c->gen_free[gen]) MH_HIP(hipEventCreateWithFlags(&c->gen_free[gen], hipEventDisableTiming));
