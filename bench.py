@@ -301,6 +301,8 @@ def run_rdf_xtc(args, rank, local_rank, world, device, cdev):
     total_bins = reduce_counts(bins.cpu().numpy(), device=cdev)       # the only collective
     t = max_over_ranks(elapsed, device=cdev)
     sides = gather_float64(np.array([K / max(t_dec, 1e-9), K / max(t_con, 1e-9), K / elapsed]), device=cdev)
+    from molar_amd.distributed import collective_view
+    comm = collective_view(local_rank) if world > 1 else None
     if rank == 0:
         check = None
         if args.verify:       # the same frames held resident (decoded to the format's grid), on one fresh context
@@ -335,6 +337,7 @@ def run_rdf_xtc(args, rank, local_rank, world, device, cdev):
             # each rank's two sides over the time that side was busy (they overlap: the slower one sets the rank's frames/s)
             "decode_fps": dec_fps, "consumer_fps": con_fps, "per_rank_fps": [float(s_[2]) for s_ in sides],
             "binding_side": ["decode" if d < c_ else "histogram" for d, c_ in zip(dec_fps, con_fps)],
+            "collective": comm,
             "roofline": None,
             "reduced_bins_equal_resident_frames": check,
         })
@@ -411,6 +414,9 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
     eng.profile_enable(False)
     total_bins = reduce_counts(timed_bins, device=cdev)       # the only collective
     t = max_over_ranks(elapsed, device=cdev)
+    from molar_amd.distributed import collective_view, gather_float64 as _gf
+    comm = collective_view(local_rank) if world > 1 else None
+    per_rank = [float(v[0]) for v in _gf([K / elapsed], device=cdev)]
     if rank == 0:
         check = None
         if args.verify:       # rank 0 recomputes every rank's frames alone: the reduced bins must be identical
@@ -454,6 +460,7 @@ def run_rdf(args, rank, local_rank, world, device, cdev):
                                    "of 1200 x int64", "natoms": n, "nbins": nbins, "frames_per_gpu": K,
                        "call_form": "one call per frame" if args.rdf_single_calls else "molar_hip_search_histogram_frames over blocks of the resident frames (groups of <= 8 frames per launch)",
                        "pairs_per_frame": pairs / (K * world)},
+            "per_rank_fps": per_rank, "collective": comm,
             "kernel_ms_per_frame": {k: v[0] / KP for k, v in prof.items()},
             "kernel_ms_source": f"HIP events on the engine's stream in a separate untimed pass over {KP} of the same frames",
             "roofline": {"kernel": "hist_plan_kernel + hist_kernel<SINGLE> + pair_kernel<SINGLE,HIST>", "bound": "valu",
@@ -582,6 +589,9 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
     from molar_amd.distributed import gather_float64
     parts = gather_float64(acc, device=cdev)
     t = max_over_ranks(elapsed, device=cdev)
+    from molar_amd.distributed import collective_view
+    comm = collective_view(local_rank) if world > 1 else None
+    per_rank = [float(v[0]) for v in gather_float64([K / elapsed], device=cdev)]
     if rank == 0:
         total = np.sum(np.stack(parts), axis=0)
         check = None
@@ -616,6 +626,7 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
                                    "gather of the accumulated sums", "natoms": len(xyz), "nlipids": nl, "frames_per_gpu": K, "engine_contexts_per_gpu": S},
             "results": {"valid_lipid_frames": int(nvalid), "mean_vertices": total[1] / max(nvalid, 1), "mean_area_nm2": total[2] / max(nvalid, 1),
                         "mean_abs_mean_curvature": total[3] / max(nvalid, 1), "mean_abs_scd": float(np.abs(total[4:] / max(nvalid, 1)).mean())},
+            "per_rank_fps": per_rank, "collective": comm,
             "roofline": None,
             "roofline_note": "no roofline claim: ~35 latency-bound launches per frame over 4000 lipids (the largest, the per-lipid fit, runs "
                              "63 waves for 0.11 ms) and a serial host pass of 0.2 ms hidden behind them; profiles/r03_membrane_frame_kernel_stats.csv",
@@ -1053,6 +1064,8 @@ def main():
                            "bytes_per_result": 8, "pair_counts_and_pair_plane_equal_full_mode": ok_po,
                            "note": "measured mode, not the headline: molar_hip_search_resident_planes(ctx, 0) - the resident searches fill the (i, j) plane "
                                    "only (the reference's (usize, usize) output form, distance_search.rs:14-20), same frames, same pipeline"}
+    from molar_amd.distributed import collective_view
+    comm = collective_view(local_rank) if world > 1 else None
     checks = reduce_counts([0 if self_check is None else 1, 1 if self_check is False else 0], device=cdev)
     self_check_all = None if int(checks[0]) == 0 else (int(checks[1]) == 0)
     verified = None
@@ -1124,6 +1137,8 @@ def main():
             },
             "preheat_ms": preheat_ms,
             "per_rank_fps": [K / v for v in per_rank_s],
+            # N > 1: the collective library's own view of the job (RCCL version, world size, every rank's device)
+            "collective": comm,
             "pairs_only": pairs_only_line,
             "verified_against_single_context": self_check_all if verified is None else (verified and self_check_all is not False),
             "verification": ("last two timed frames of every rank recomputed on a fresh single context after the timed region: "

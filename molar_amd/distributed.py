@@ -87,3 +87,37 @@ def max_over_ranks(value: float, device=None) -> float:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def collective_view(local_device_index=None):
+    """What the collective library itself reports about the job, gathered over ranks: backend, its version (RCCL's on the
+    GPU box), the world size torch.distributed sees and every rank's device (index, name, PCI bus id).  bench.py prints it
+    into the N > 1 line, so that a scaling run proves N ranks on N distinct devices were seen.  Collective: call on every rank."""
+    import os
+    import torch
+    dist = _dist()
+    view = {"backend": None, "world_size": 1, "nccl_version": None, "ranks": []}
+    mine = {"rank": 0, "pid": os.getpid(), "device_index": local_device_index, "device_name": None, "pci_bus_id": None}
+    if local_device_index is not None and torch.cuda.is_available():
+        try:
+            pr = torch.cuda.get_device_properties(local_device_index)
+            mine["device_name"] = pr.name
+            mine["pci_bus_id"] = f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+        except Exception:
+            pass
+    if dist.is_available() and dist.is_initialized():
+        view["backend"] = dist.get_backend()
+        view["world_size"] = dist.get_world_size()
+        mine["rank"] = dist.get_rank()
+        if view["backend"] == "nccl":
+            try:
+                view["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                pass
+        parts = [None] * view["world_size"]
+        dist.all_gather_object(parts, mine)
+        view["ranks"] = parts
+    else:
+        view["ranks"] = [mine]
+    view["distinct_devices"] = len({(r["pci_bus_id"], r["device_index"]) for r in view["ranks"]})
+    return view

@@ -14,7 +14,7 @@ def _compile(src, exe, extra=()):
     os.makedirs(OUT, exist_ok=True)
     libdir = os.path.join(ROOT, "molar_amd")
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", src),
-           "-o", os.path.join(OUT, exe), "-L", libdir, "-lmolar_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", *extra]
+           "-o", os.path.join(OUT, exe), "-L", libdir, "-lmolar_hip", "-lpthread", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", *extra]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     return os.path.join(OUT, exe)
@@ -22,9 +22,13 @@ def _compile(src, exe, extra=()):
 
 def test_analysis_task_and_suffix_cpu():
     exe = _compile("test_analysis_task.cpp", "test_analysis_task")
-    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "benzene.xtc")], capture_output=True, text=True, timeout=120)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:      # (the sharded-reader test writes a 40-frame, 250k-atom trajectory there: ~40 MB)
+        r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "benzene.xtc"), tmp], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all host-mirror CPU tests passed" in r.stdout
+    assert "own readers" in r.stdout
+    print(r.stdout)
 
 
 def test_rotation_solver_cpu():

@@ -63,8 +63,12 @@ def _worker(rank, world, port, nframes, q):
     full = gather_series(series, nframes)
     tmax = max_over_ranks(float(rank + 1))
     parts = gather_float64(np.array([rank + 0.25, 1.0 / (rank + 3)]))       # the membrane workload's accumulators travel like this
+    from molar_amd.distributed import collective_view
+    view = collective_view(None)          # what bench.py prints into the N > 1 line
     dist.barrier()
     if rank == 0:
+        assert view["backend"] == "gloo" and view["world_size"] == world and view["nccl_version"] is None
+        assert [r["rank"] for r in view["ranks"]] == list(range(world)) and len({r["pid"] for r in view["ranks"]}) == world
         q.put((hist, pairs, full, tmax, parts))
     dist.destroy_process_group()
 
