@@ -637,6 +637,25 @@ int molar_hip_fit_rmsd_batch(molar_hip_ctx *ctx, float *frames, size_t nframes, 
                              float *R_out /*[nframes][9]*/, float *t_out /*[nframes][3]*/,
                              float *com_out /*[nframes][3]*/, float *gyr_out /*[nframes]*/);
 
+/* The same loop for a trajectory whose frames live in HOST memory, at the rate the SELECTION crosses the link (a Rust
+ * AnalysisTask hands its State's coords over frame by frame, analysis_task.rs:245-252; molar_hip_fit_rmsd_batch on a host frame
+ * stages all natoms x 12 bytes from pageable memory per call).  _create packs the frame-invariant columns once (reference
+ * selection, the masses of the selected atoms; all topology-side arrays in host memory) and starts `host_threads` threads
+ * (0: min(8, cores / 2)) that take the selected atoms out of a frame into pinned staging.  _begin(frame) gathers, sends the packed
+ * selection behind the frame before it, enqueues the batch entry's kernels on it and returns a ticket (0..2; up to three frames
+ * in flight: `begin(k + 1); end(k)`); _end(ticket) waits for that frame and returns what the batch entry returns per frame
+ * (each output optional) - bit-identical to it: same terms, same order.  apply != 0: the fitted selection is written into the
+ * frame handed to _begin (which must stay valid, and untouched, until _end) - apply_transform (modify.rs:32-36).  Errors as for
+ * the batch entry (ERR_SIZES, ERR_ZERO_MASS, ERR_SVD_FAILED from _end). */
+typedef struct molar_hip_fit_stream molar_hip_fit_stream;
+int molar_hip_fit_stream_create(molar_hip_ctx *ctx, size_t natoms, const uint64_t *idx, size_t n, const float *mass,
+                                const float *ref_xyz, size_t ref_natoms, const uint64_t *ref_idx, int host_threads,
+                                molar_hip_fit_stream **out);
+int molar_hip_fit_stream_begin(molar_hip_fit_stream *stream, float *xyz, int apply, int32_t *ticket);
+int molar_hip_fit_stream_end(molar_hip_fit_stream *stream, int32_t ticket, float *rmsd, float R9[9], float t3[3], float com3[3],
+                             float *gyration);
+void molar_hip_fit_stream_destroy(molar_hip_fit_stream *stream);
+
 /* ------------------------------------------------------------------ batched over K selections (CSR)
  * What MolAR runs from rayon over a ParSplit (selection/system.rs:193-213, README.md:656-691): the same Measure method
  * on thousands of small sub-selections (residues, lipids, molecules).  Selection k is idx[offsets[k] .. offsets[k+1]);

@@ -136,6 +136,10 @@ SYMBOLS = {
     "molar_hip_rmsd": (_I, [_P, _P, _SZ, _P, _SZ, _P, _SZ, _P, _SZ, _P]),
     "molar_hip_rmsd_mw": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P]),
     "molar_hip_fit_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P, _I, _P, _P]),
+    "molar_hip_fit_stream_create": (_I, [_P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _I, _P]),
+    "molar_hip_fit_stream_begin": (_I, [_P, _P, _I, _P]),
+    "molar_hip_fit_stream_end": (_I, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "molar_hip_fit_stream_destroy": (None, [_P]),
     "molar_hip_center_of_geometry_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
     "molar_hip_center_of_mass_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),
     "molar_hip_gyration_f64": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P]),

@@ -848,6 +848,53 @@ class Engine:
         return dict(rmsd=rm, R=R.reshape(F, 3, 3).transpose(0, 2, 1).copy(), t=t, com=com, gyration=gy)
 
 
+class FitStream:
+    """molar_hip_fit_stream_*: the per-frame fit loop of benches/comparison_small.rs:14-25 for frames in HOST memory (numpy),
+    three in flight - `t = fs.begin(frame_k1); out = fs.end(t_k)`.  The selected atoms are packed by host threads and only
+    they cross the link; every record equals fit_rmsd_batch's for the same frame.  apply=True moves the selection inside the
+    numpy frame handed to begin() (keep it alive and untouched until end())."""
+
+    def __init__(self, engine: "Engine", natoms, mass, ref_xyz, idx=None, ref_idx=None, host_threads=0):
+        self.eng, self.lib = engine, engine.lib
+        idx = None if idx is None else np.ascontiguousarray(idx, np.uint64)
+        ref_idx = idx if ref_idx is None else np.ascontiguousarray(ref_idx, np.uint64)
+        mass = np.ascontiguousarray(mass, np.float32)
+        ref_xyz = np.ascontiguousarray(ref_xyz, np.float32)
+        self.natoms = int(natoms)
+        h = C.c_void_p()
+        check(self.lib.molar_hip_fit_stream_create(engine.ctx, self.natoms, None if idx is None else idx.ctypes.data,
+                                                   0 if idx is None else len(idx), mass.ctypes.data, ref_xyz.ctypes.data,
+                                                   ref_xyz.shape[0] if ref_xyz.ndim == 2 else ref_xyz.shape[0] // 3,
+                                                   None if ref_idx is None else ref_idx.ctypes.data, int(host_threads), C.byref(h)))
+        self.h = h
+        self._frames = {}
+
+    def begin(self, frame, apply=False) -> int:
+        assert isinstance(frame, np.ndarray) and frame.dtype == np.float32 and frame.flags.c_contiguous and frame.size == self.natoms * 3
+        t = C.c_int32(-1)
+        check(self.lib.molar_hip_fit_stream_begin(self.h, frame.ctypes.data, 1 if apply else 0, C.byref(t)))
+        self._frames[t.value] = frame
+        return t.value
+
+    def end(self, ticket):
+        rm = C.c_float(); gy = C.c_float()
+        R = np.zeros(9, np.float32); t = np.zeros(3, np.float32); com = np.zeros(3, np.float32)
+        check(self.lib.molar_hip_fit_stream_end(self.h, ticket, C.byref(rm), R.ctypes.data, t.ctypes.data, com.ctypes.data, C.byref(gy)))
+        self._frames.pop(ticket, None)
+        return dict(rmsd=np.float32(rm.value), R=R.reshape(3, 3).T.copy(), t=t, com=com, gyration=np.float32(gy.value))
+
+    def close(self):
+        if self.h:
+            self.lib.molar_hip_fit_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _f64(x):
     if x is None:
         return None

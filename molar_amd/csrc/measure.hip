@@ -6,6 +6,13 @@
 // summed in a fixed order by the finalize step, so results are deterministic and agree with the
 // reference's serial f32 sums to better than the f32 roundoff those sums carry themselves.
 // These passes move 12-44 bytes per atom and a handful of flops: HBM-bound, no MFMA.
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
 #include "boxmath.hpp"
 #include "common.hpp"
 #include "stages.hpp"
@@ -1652,6 +1659,230 @@ int molar_hip_principal_transform(molar_hip_ctx *c, const float *xyz, size_t nat
     t3[0] = cm[0] + rv.x;
     t3[1] = cm[1] + rv.y;
     t3[2] = cm[2] + rv.z;
+    return MOLAR_HIP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The per-frame fit of a trajectory whose frames live in HOST memory (a State's coords, state.rs:22-28, handed to the task by
+// analysis_task.rs:245-252) at the rate the selection - not the frame - crosses the link.  molar_hip_fit_rmsd_batch on a host
+// frame stages all natoms x 12 bytes from pageable memory per call (1.5 k frames/s for the 1M-atom frame of BASELINE config 3,
+// whose selection is 100k atoms).  Here the SELECTED atoms are taken out of the frame by a small pool of host threads into pinned
+// staging, sent (1.2 MB instead of 12), fitted by the kernels of the batch entry on the packed selection - same terms, same
+// order, same block layout: the record is bit-identical to the batch entry's - and, with `apply`, the moved selection comes back
+// the same way and is scattered into the caller's frame at _end.  Three frames may be in flight: gather k+1 on the host, copy
+// and fit k on the stream, scatter k-1.
+struct molar_hip_fit_stream {
+    molar_hip_ctx *c = nullptr;
+    size_t natoms = 0;
+    uint32_t n = 0;
+    std::vector<uint64_t> idx;           // the selection (host copy; empty = identity)
+    mh::DevBuf ref_pk, mass_pk, mass_ref_pk;   // packed reference selection [n][3], masses of the frame's / the reference's selected atoms [n]
+    static constexpr int NSLOT = 3;
+    struct Slot {
+        float *h_in = nullptr, *h_out = nullptr;   // pinned: packed selection in / moved selection out
+        float *h_rec = nullptr;                    // pinned: the 18-float record of k_fit_final
+        mh::DevBuf cur, part, out;
+        hipEvent_t done = nullptr;
+        float *frame = nullptr;                    // the caller's frame (apply: scattered into at _end)
+        bool pending = false, apply = false;
+    } slot[NSLOT];
+    int next = 0;
+    // host threads for the gather / scatter of the selection
+    std::vector<std::thread> pool;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    std::function<void(size_t, size_t)> job;       // [lo, hi) of the selection
+    size_t job_serial = 0, job_left = 0;
+    bool quit = false;
+    void parallel(const std::function<void(size_t, size_t)> &f) {
+        if (pool.empty() || n < 4096u) { f(0, n); return; }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = f;
+            job_left = pool.size();
+            ++job_serial;
+        }
+        cv.notify_all();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return job_left == 0; });
+    }
+};
+
+extern "C" {
+
+void molar_hip_fit_stream_destroy(molar_hip_fit_stream *s) {
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        s->quit = true;
+    }
+    s->cv.notify_all();
+    for (auto &t : s->pool) t.join();
+    if (s->c) {
+        (void)hipSetDevice(s->c->device);
+        (void)hipStreamSynchronize(s->c->stream);
+    }
+    for (auto &sl : s->slot) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.h_rec) (void)hipHostFree(sl.h_rec);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        sl.cur.release(); sl.part.release(); sl.out.release();
+    }
+    s->ref_pk.release();
+    s->mass_pk.release();
+    s->mass_ref_pk.release();
+    delete s;
+}
+
+int molar_hip_fit_stream_create(molar_hip_ctx *c, size_t natoms, const uint64_t *idx, size_t n, const float *mass, const float *ref_xyz,
+                                size_t ref_natoms, const uint64_t *ref_idx, int host_threads, molar_hip_fit_stream **out) {
+    MH_CTX(c);
+    if (!out || !mass || !ref_xyz) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_stream_create: null argument");
+    *out = nullptr;
+    const size_t nsel = idx ? n : natoms, nref = ref_idx ? n : ref_natoms;
+    if (nsel != nref) return fail(MOLAR_HIP_ERR_SIZES, "incompatible sizes: %zu and %zu", nsel, nref);
+    if (nsel == 0 || nsel >= 0xFFFFFFFFull) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_stream_create: %zu selected atoms", nsel);
+    if (is_device_ptr(idx) || is_device_ptr(ref_idx) || is_device_ptr(mass) || is_device_ptr(ref_xyz))
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_stream_create: the topology-side arrays are taken from host memory (frames already "
+                                                      "in device memory go through molar_hip_fit_rmsd_batch)");
+    for (size_t k = 0; idx && k < n; ++k)
+        if (idx[k] >= natoms) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_stream_create: index %llu out of range", (unsigned long long)idx[k]);
+    for (size_t k = 0; ref_idx && k < n; ++k)
+        if (ref_idx[k] >= ref_natoms) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_stream_create: reference index %llu out of range", (unsigned long long)ref_idx[k]);
+    auto *s = new molar_hip_fit_stream;
+    s->c = c;
+    s->natoms = natoms;
+    s->n = (uint32_t)nsel;
+    if (idx) s->idx.assign(idx, idx + n);
+    // the frame-invariant columns, packed once: reference selection and the masses of the frame's selected atoms (the batch
+    // entry's convention: the reference centre uses the same column)
+    // (the reference centre takes the SAME column through the reference's own index: fit_transform uses sel2's masses, :512)
+    if (ref_idx && ref_natoms > natoms) { delete s; return fail(MOLAR_HIP_ERR_SIZES, "fit_stream_create: the mass column has %zu entries, the reference %zu atoms", natoms, ref_natoms); }
+    std::vector<float> rp(nsel * 3), mp(nsel), mr(nsel);
+    for (size_t k = 0; k < nsel; ++k) {
+        const size_t a = idx ? (size_t)idx[k] : k, r = ref_idx ? (size_t)ref_idx[k] : k;
+        rp[3 * k] = ref_xyz[3 * r]; rp[3 * k + 1] = ref_xyz[3 * r + 1]; rp[3 * k + 2] = ref_xyz[3 * r + 2];
+        mp[k] = mass[a];
+        mr[k] = mass[r];
+    }
+    int rc = s->ref_pk.reserve(nsel * 12);
+    if (!rc) rc = s->mass_pk.reserve(nsel * 4);
+    if (!rc) rc = s->mass_ref_pk.reserve(nsel * 4);
+    hipError_t e = rc ? hipSuccess : hipMemcpy(s->ref_pk.p, rp.data(), nsel * 12, hipMemcpyHostToDevice);
+    if (!rc && e == hipSuccess) e = hipMemcpy(s->mass_pk.p, mp.data(), nsel * 4, hipMemcpyHostToDevice);
+    if (!rc && e == hipSuccess) e = hipMemcpy(s->mass_ref_pk.p, mr.data(), nsel * 4, hipMemcpyHostToDevice);
+    const uint32_t nb = blocks_for(c, s->n, 1);
+    for (auto &sl : s->slot) {
+        if (rc || e != hipSuccess) break;
+        e = hipHostMalloc((void **)&sl.h_in, nsel * 12, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_out, nsel * 12, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_rec, 18 * 4, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+        if (e == hipSuccess) rc = sl.cur.reserve(nsel * 12);
+        if (!rc) rc = sl.part.reserve((size_t)nb * FS_ALL * 8);
+        if (!rc) rc = sl.out.reserve(18 * 4);
+    }
+    if (rc || e != hipSuccess) {
+        molar_hip_fit_stream_destroy(s);
+        return rc ? rc : fail(MOLAR_HIP_ERR_HIP, "fit_stream_create: %s", hipGetErrorString(e));
+    }
+    unsigned nt = host_threads > 0 ? (unsigned)host_threads : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2u));
+    if (nsel < 4096) nt = 0;
+    for (unsigned t = 0; t < nt; ++t) {
+        s->pool.emplace_back([s, t, nt]() {
+            size_t seen = 0;
+            for (;;) {
+                std::function<void(size_t, size_t)> f;
+                {
+                    std::unique_lock<std::mutex> lk(s->m);
+                    s->cv.wait(lk, [&] { return s->quit || s->job_serial != seen; });
+                    if (s->quit) return;
+                    seen = s->job_serial;
+                    f = s->job;
+                }
+                const size_t per = ((size_t)s->n + nt - 1) / nt, lo = std::min((size_t)s->n, t * per), hi = std::min((size_t)s->n, lo + per);
+                if (lo < hi) f(lo, hi);
+                {
+                    std::lock_guard<std::mutex> lk(s->m);
+                    if (--s->job_left == 0) s->cv_done.notify_all();
+                }
+            }
+        });
+    }
+    *out = s;
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_fit_stream_begin(molar_hip_fit_stream *s, float *xyz, int apply, int32_t *ticket) {
+    if (!s || !xyz || !ticket) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_stream_begin: null argument");
+    if (is_device_ptr(xyz)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_stream_begin: the frame is in device memory (use molar_hip_fit_rmsd_batch)");
+    molar_hip_ctx *c = s->c;
+    MH_CTX(c);
+    const int k = s->next;
+    auto &sl = s->slot[k];
+    if (sl.pending) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_stream_begin: %d frames are in flight: call molar_hip_fit_stream_end first", molar_hip_fit_stream::NSLOT);
+    const uint64_t *idx = s->idx.empty() ? nullptr : s->idx.data();
+    float *dst = sl.h_in;
+    s->parallel([=](size_t lo, size_t hi) {
+        if (!idx) { std::memcpy(dst + 3 * lo, xyz + 3 * lo, (hi - lo) * 12); return; }
+        for (size_t q = lo; q < hi; ++q) {
+            const float *p = xyz + 3 * idx[q];
+            dst[3 * q] = p[0]; dst[3 * q + 1] = p[1]; dst[3 * q + 2] = p[2];
+        }
+    });
+    const uint32_t n = s->n, nb = blocks_for(c, n, 1);
+    MH_HIP(hipMemcpyAsync(sl.cur.p, sl.h_in, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    Sel cur{sl.cur.as<float>(), nullptr, s->mass_pk.as<float>(), n, 0};
+    Sel ref{s->ref_pk.as<float>(), nullptr, s->mass_ref_pk.as<float>(), n, 0};
+    {
+        Prof prof(c, 4);
+        hipLaunchKernelGGL(k_fit_sums<true>, dim3(nb, 1), dim3(RB), 0, c->stream, cur, ref, sl.part.as<double>());
+        hipLaunchKernelGGL(k_fit_final<FS_ALL>, dim3(1), dim3(64), 0, c->stream, sl.part.as<double>(), nb, n, 0, sl.out.as<float>(), sl.h_rec);
+        if (apply) hipLaunchKernelGGL(k_apply_batch, dim3(nb, 1), dim3(RB), 0, c->stream, cur, sl.cur.as<float>(), sl.out.as<float>());
+    }
+    MH_HIP(hipGetLastError());
+    if (apply) MH_HIP(hipMemcpyAsync(sl.h_out, sl.cur.p, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipEventRecord(sl.done, c->stream));
+    sl.pending = true;
+    sl.apply = apply != 0;
+    sl.frame = xyz;
+    s->next = (k + 1) % molar_hip_fit_stream::NSLOT;
+    *ticket = k;
+    return MOLAR_HIP_OK;
+}
+
+int molar_hip_fit_stream_end(molar_hip_fit_stream *s, int32_t ticket, float *rmsd, float R9[9], float t3[3], float com3[3], float *gyr) {
+    if (!s || ticket < 0 || ticket >= molar_hip_fit_stream::NSLOT || !s->slot[ticket].pending)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "fit_stream_end: no frame in flight with ticket %d", (int)ticket);
+    auto &sl = s->slot[ticket];
+    MH_CTX(s->c);
+    MH_HIP(hipEventSynchronize(sl.done));
+    sl.pending = false;
+    float h[18];
+    std::memcpy(h, sl.h_rec, sizeof h);
+    int st;
+    std::memcpy(&st, &h[17], 4);
+    if (st) return fail(st, st == MOLAR_HIP_ERR_ZERO_MASS ? "zero mass" : "SVD failed");
+    if (sl.apply) {          // apply_transform (modify.rs:32-36) on the caller's frame: the moved selection back into its atoms
+        const uint64_t *idx = s->idx.empty() ? nullptr : s->idx.data();
+        const float *src = sl.h_out;
+        float *frame = sl.frame;
+        s->parallel([=](size_t lo, size_t hi) {
+            if (!idx) { std::memcpy(frame + 3 * lo, src + 3 * lo, (hi - lo) * 12); return; }
+            for (size_t q = lo; q < hi; ++q) {
+                float *p = frame + 3 * idx[q];
+                p[0] = src[3 * q]; p[1] = src[3 * q + 1]; p[2] = src[3 * q + 2];
+            }
+        });
+    }
+    if (rmsd) *rmsd = h[12];
+    if (gyr) *gyr = h[16];
+    if (R9) std::memcpy(R9, h, 36);
+    if (t3) std::memcpy(t3, h + 9, 12);
+    if (com3) std::memcpy(com3, h + 13, 12);
     return MOLAR_HIP_OK;
 }
 

@@ -14,6 +14,12 @@ pub struct MolarHipXtc {
     _opaque: [u8; 0],
 }
 
+/// Opaque streamed fit (`molar_hip_fit_stream`): per-frame Kabsch fit of host-memory frames, selection packed by host threads.
+#[repr(C)]
+pub struct MolarHipFitStream {
+    _opaque: [u8; 0],
+}
+
 /// `molar_hip_box` (header :96-101): MolAR's `PeriodicBox` (periodic_box.rs:15-23) - matrix with columns a, b, c,
 /// its inverse and the triclinic correction shifts.
 #[repr(C)]

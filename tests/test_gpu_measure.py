@@ -462,3 +462,54 @@ def test_csr_batches_with_device_resident_inputs(eng):
     assert np.array_equal(dv.cpu().numpy(), h)
     rest = np.ones(n, bool); rest[idx2.astype(np.int64)] = False
     assert np.array_equal(h[rest], x1[rest]) and not np.array_equal(h[~rest], x1[~rest])
+
+
+def test_fit_stream_equals_the_batch_entry(eng):
+    """molar_hip_fit_stream_*: frames in host memory, the selection packed by host threads, three frames in flight.  Every
+    record - and, with apply, every moved frame - must equal molar_hip_fit_rmsd_batch's on the same frame bit for bit (same
+    kernels on the packed selection, same terms in the same order); also with a reference selection of its own index set,
+    with the identity selection, and with a selection too small for the thread pool."""
+    from molar_amd import api
+    rng = np.random.default_rng(23)
+    n, F = 120011, 9
+    ref = rng.uniform(0, 12, (n, 3)).astype(np.float32)
+    mass = rng.uniform(1, 40, n).astype(np.float32)
+    for m, same_ref, threads in ((12007, True, 0), (12007, False, 3), (n, True, 4), (900, True, 0)):
+        idx = None if m == n else np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+        ref_idx = idx if same_ref else np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+        sel = np.arange(n) if idx is None else idx.astype(np.int64)
+        rsel = np.arange(n) if ref_idx is None else ref_idx.astype(np.int64)
+        frames = np.empty((F, n, 3), np.float32)
+        for f in range(F):
+            R = api.rotation_from_axis_angle(rng.normal(size=3), float(rng.uniform(-3, 3))).astype(np.float64)
+            frames[f] = rng.uniform(0, 12, (n, 3))
+            frames[f][sel] = (ref[rsel].astype(np.float64) @ R.T + rng.uniform(-3, 3, 3) + rng.normal(0, 0.05, (len(sel), 3))).astype(np.float32)
+        for apply in (False, True):
+            want_frames = frames.copy()
+            want = eng.fit_rmsd_batch(want_frames, mass, ref, idx=idx, ref_idx=ref_idx, apply=apply)
+            got_frames = frames.copy()
+            fs = api.FitStream(eng, n, mass, ref, idx=idx, ref_idx=ref_idx, host_threads=threads)
+            got, pending = [None] * F, []
+            for f in range(F):
+                pending.append((f, fs.begin(got_frames[f], apply=apply)))
+                if len(pending) == 3:
+                    g, t = pending.pop(0)
+                    got[g] = fs.end(t)
+            for g, t in pending:
+                got[g] = fs.end(t)
+            fs.close()
+            for f in range(F):
+                for k in ("rmsd", "R", "t", "com", "gyration"):
+                    assert np.array_equal(got[f][k], want[k][f]), (m, same_ref, apply, k, f)
+            assert np.array_equal(got_frames, want_frames)
+            assert max(float(g["rmsd"]) for g in got) < 0.2
+    # a fourth begin without an end is refused
+    fs = api.FitStream(eng, n, mass, ref, idx=None)
+    work = frames[:4].copy()
+    ts = [fs.begin(work[f]) for f in range(3)]
+    from molar_amd._lib import MolarHipError
+    with pytest.raises(MolarHipError):
+        fs.begin(work[3])
+    for t in ts:
+        fs.end(t)
+    fs.close()

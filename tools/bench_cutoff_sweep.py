@@ -61,10 +61,20 @@ def main():
         c, _, _ = eng.search_resident_end(state["t"]); state["t"] = None
         torch.cuda.synchronize()
         t_pipe = (time.perf_counter() - t0) / (3 * reps)
+        # per-class event times of the same pipelined loop in a separate pass (every class carries its own event pair: 5-10 us each)
+        eng.profile_enable(True); eng.profile_read()
+        for _ in range(reps):
+            step()
+        c, _, _ = eng.search_resident_end(state["t"]); state["t"] = None
+        pr = eng.profile_read(); eng.profile_enable(False)
+        kern = {k: round(v[0] / max(reps, 1), 4) for k, v in pr.items() if k in ("grid_build", "pair_count", "offset_scan", "pair_fill")}
+        alg = 12.0 * n + 12.0 * cnt              # coordinates read once, every pair written once as (u32, u32, f32)
         print(json.dumps({"natoms": n, "cutoff_nm": rc, "grid_dims": dims, "atoms_per_cell": round(n / (dims[0] * dims[1] * dims[2]), 1),
                           "pairs": cnt, "ms_count": round(t_count * 1e3, 3), "ms_resident_serial": round(t_serial * 1e3, 3),
                           "ms_resident_pipelined": round(t_pipe * 1e3, 3), "mpairs_per_ms_serial": round(cnt / t_serial / 1e9, 1),
-                          "mpairs_per_ms_pipelined": round(cnt / t_pipe / 1e9, 1), "frames_per_s_pipelined": round(1.0 / t_pipe, 1)}),
+                          "mpairs_per_ms_pipelined": round(cnt / t_pipe / 1e9, 1), "frames_per_s_pipelined": round(1.0 / t_pipe, 1),
+                          "kernel_ms_per_frame": kern, "algorithmic_bytes": alg,
+                          "hbm_roofline_frac_pipelined": round(alg / t_pipe / 8.0e12, 3)}),
               flush=True)
 
 
