@@ -431,6 +431,45 @@ inline IsometryMatrix3 fit_transform_at_origin(const SelBound &s1, const SelBoun
     return tr;
 }
 
+// The per-frame fit of an AnalysisTask whose States live in host memory (analysis_task.rs:245-252 hands them over frame by frame),
+// at the rate the SELECTION crosses the link: molar_hip_fit_stream_*.  Built on the selection and the reference once;
+//     auto t1 = fs.begin(state_k1.coords);  FitRecord r = fs.end(t0);      // up to three frames in flight
+// every record is the one fit_transform + apply_transform + rmsd + center_of_mass + gyration give for that frame.
+struct FitRecord {
+    IsometryMatrix3 tr;          // fit_transform (measure.rs:507-522)
+    Float rmsd = 0;              // of the fitted selection against the reference (:485-504)
+    Vector3f com;                // center_of_mass of the fitted selection (:60-75)
+    Float gyration = 0;          // (:78-87)
+};
+class FitStream {
+    molar_hip_fit_stream *h_ = nullptr;
+
+   public:
+    // `sel`: the selection (its index and the topology's masses are taken now; its System supplies natoms); `reference`: the
+    // selection fitted onto (coordinates taken now)
+    FitStream(const SelBound &sel, const SelBound &reference, int host_threads = 0) {
+        const auto i1 = sel.get_index_slice(), i2 = reference.get_index_slice();
+        if (i1.size() != i2.size()) throw MolarError(MOLAR_HIP_ERR_SIZES, "incompatible sizes");      // MeasureError::Sizes (measure.rs:489)
+        check(molar_hip_fit_stream_create(sel.ctx(), sel.natoms(), i1.data(), i1.size(), sel.masses(), reference.coords_ptr(),
+                                          reference.natoms(), i2.data(), host_threads, &h_));
+    }
+    FitStream(const FitStream &) = delete;
+    FitStream &operator=(const FitStream &) = delete;
+    ~FitStream() { molar_hip_fit_stream_destroy(h_); }
+    // apply: the fitted selection is written into `coords` at end() (Modify::apply_transform, modify.rs:32-36); the vector must stay
+    // alive and untouched until then
+    int32_t begin(std::vector<Pos> &coords, bool apply = false) {
+        int32_t t = -1;
+        check(molar_hip_fit_stream_begin(h_, &coords[0].x, apply ? 1 : 0, &t));
+        return t;
+    }
+    FitRecord end(int32_t ticket) {
+        FitRecord r;
+        check(molar_hip_fit_stream_end(h_, ticket, &r.rmsd, r.tr.R.m.data(), &r.tr.t.x, &r.com.x, &r.gyration));
+        return r;
+    }
+};
+
 // ---------------------------------------------------------------- distance search (distance_search.rs)
 
 // DistanceSearchOutput (:6-26): usize | (usize,usize) | (usize,usize,Float)

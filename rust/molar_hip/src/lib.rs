@@ -499,6 +499,79 @@ impl Engine {
     }
 }
 
+/// What one frame of a streamed fit returns: `fit_transform` (measure.rs:507-522) as (R column-major, t), and RMSD / centre of
+/// mass / gyration of the fitted selection.
+#[derive(Clone, Copy, Debug)]
+pub struct FitRecord {
+    pub r: [f32; 9],
+    pub t: [f32; 3],
+    pub rmsd: f32,
+    pub com: [f32; 3],
+    pub gyration: f32,
+}
+
+/// The per-frame fit loop of `benches/comparison_small.rs:14-25` for States in host memory (`analysis_task.rs:245-252` hands
+/// them to the task one by one), at the rate the SELECTION crosses the link: `molar_hip_fit_stream_*`.  Up to three frames in
+/// flight: `let t1 = fs.begin(&mut next, false)?; let rec = fs.end(t0)?;`.
+pub struct FitStream<'e> {
+    engine: &'e Engine,
+    handle: *mut types::MolarHipFitStream,
+    natoms: usize,
+}
+
+impl<'e> FitStream<'e> {
+    /// `index` / `ref_index`: the selection in the frames and in the reference (None = all atoms); `masses`: the topology's
+    /// column; `reference`: the frame fitted onto.
+    pub fn new(
+        engine: &'e Engine, natoms: usize, index: Option<&[usize]>, masses: &[f32], reference: &[[f32; 3]], ref_index: Option<&[usize]>,
+        host_threads: i32,
+    ) -> Result<Self, EngineError> {
+        check_index(index, natoms, "FitStream::new (selection)")?;
+        check_index(ref_index, reference.len(), "FitStream::new (reference)")?;
+        check_column(masses.len(), natoms, "FitStream::new: masses")?;
+        let (ip, n) = idx_ptr(index);
+        let (rp, rn) = idx_ptr(ref_index);
+        if index.is_some() != ref_index.is_some() || n != rn {
+            return Err(EngineError::Sizes("FitStream::new: the two selections differ in size".into()));
+        }
+        let mut handle = std::ptr::null_mut();
+        engine.plugin.check(unsafe {
+            (engine.plugin.fns.fit_stream_create)(engine.ctx, natoms, ip, n, masses.as_ptr(), reference.as_ptr() as *const f32, reference.len(), rp,
+                                                  host_threads, &mut handle)
+        })?;
+        Ok(FitStream { engine, handle, natoms })
+    }
+
+    /// Enqueues one frame.  With `apply` the fitted selection is written into `coords` by `end` (`Modify::apply_transform`,
+    /// modify.rs:32-36): the borrow the ticket stands for must stay alive and untouched until then - hence `unsafe`.
+    ///
+    /// # Safety
+    /// `coords` must outlive the matching `end` call and must not be read or written in between.
+    pub unsafe fn begin(&mut self, coords: &mut [[f32; 3]], apply: bool) -> Result<i32, EngineError> {
+        if coords.len() != self.natoms {
+            return Err(EngineError::Sizes(format!("FitStream::begin: frame of {} atoms, stream built for {}", coords.len(), self.natoms)));
+        }
+        let mut ticket = -1i32;
+        self.engine.plugin.check(unsafe { (self.engine.plugin.fns.fit_stream_begin)(self.handle, coords.as_mut_ptr() as *mut f32, apply as i32, &mut ticket) })?;
+        Ok(ticket)
+    }
+
+    pub fn end(&mut self, ticket: i32) -> Result<FitRecord, EngineError> {
+        let mut rec = FitRecord { r: [0.0; 9], t: [0.0; 3], rmsd: 0.0, com: [0.0; 3], gyration: 0.0 };
+        self.engine.plugin.check(unsafe {
+            (self.engine.plugin.fns.fit_stream_end)(self.handle, ticket, &mut rec.rmsd, rec.r.as_mut_ptr(), rec.t.as_mut_ptr(), rec.com.as_mut_ptr(),
+                                                   &mut rec.gyration)
+        })?;
+        Ok(rec)
+    }
+}
+
+impl Drop for FitStream<'_> {
+    fn drop(&mut self) {
+        unsafe { (self.engine.plugin.fns.fit_stream_destroy)(self.handle) }
+    }
+}
+
 /// The remaining entry points (histogram-fused search, resident/pipelined search, batched fits, membrane smoothing,
 /// lipid order, XTC reader, PeriodicBox helpers) are reachable through `Engine::raw()`; they take the same pointer/size
 /// pairs and follow the count-then-fill convention documented in `include/molar_hip.h`.

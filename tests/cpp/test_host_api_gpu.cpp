@@ -323,6 +323,40 @@ static void task_tests() {
     }
 }
 
+// FitStream (molar_hip_fit_stream_*): host-memory frames, three in flight - every record equals what the selection methods give
+// for that frame (same kernels on the packed selection), and apply moves the frame like apply_transform does
+static void fit_stream_tests() {
+    Frames src;
+    System ref_sys(src.top, src.traj[0]);
+    std::vector<usize> idx;
+    for (usize k = 0; k < src.n; k += 3) idx.push_back(k);
+    SelBound ref(ref_sys, idx);
+    FitStream fs(ref, ref, 2);
+    std::vector<State> work(src.traj.begin(), src.traj.end());
+    std::vector<int32_t> tickets;
+    std::vector<FitRecord> got;
+    for (size_t f = 0; f < work.size(); ++f) {
+        tickets.push_back(fs.begin(work[f].coords, /*apply=*/true));
+        if (tickets.size() == 3) { got.push_back(fs.end(tickets.front())); tickets.erase(tickets.begin()); }
+    }
+    for (int32_t t : tickets) got.push_back(fs.end(t));
+    EXPECT(got.size() == work.size());
+    for (size_t f = 0; f < work.size() && f < got.size(); ++f) {
+        System cur_sys(src.top, src.traj[f]);
+        SelBound cur(cur_sys, idx);
+        const IsometryMatrix3 tr = fit_transform(cur, ref);
+        for (int q = 0; q < 9; ++q) EXPECT(std::fabs(tr.R.m[q] - got[f].tr.R.m[q]) < 2e-6f);
+        EXPECT(std::fabs(tr.t.x - got[f].tr.t.x) < 2e-5f && std::fabs(tr.t.y - got[f].tr.t.y) < 2e-5f && std::fabs(tr.t.z - got[f].tr.t.z) < 2e-5f);
+        cur.apply_transform(got[f].tr);
+        EXPECT(std::fabs(rmsd(cur, ref) - got[f].rmsd) < 1e-5f + 1e-5f * got[f].rmsd);
+        for (usize k : idx) {     // the stream moved the same atoms to the same places; the others are untouched
+            EXPECT(cur_sys.state.coords[k].x == work[f].coords[k].x && cur_sys.state.coords[k].y == work[f].coords[k].y &&
+                   cur_sys.state.coords[k].z == work[f].coords[k].z);
+        }
+        EXPECT(work[f].coords[1].x == src.traj[f].coords[1].x);
+    }
+}
+
 // ---- the frame-parallel form: two engine contexts (both on device 0 here; one per GPU on a node) over 8 frames must give
 // the integer bins bit for bit and the per-frame series value for value of the serial run (analysis_task.rs:202-267 per
 // frame; DESIGN.md section 7: contiguous frame blocks, integer reduction at the end, series in frame order)
@@ -533,6 +567,7 @@ int main() {
         search_tests();
         measure_tests();
         task_tests();
+        fit_stream_tests();
         sharded_task_tests();
         membrane_frames_tests();
     } catch (const std::exception &e) {
