@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmolar_hip.so")
-SOURCES = ["api.hip", "search.hip", "search_f64.hip", "measure.hip", "measure_f64.hip", "membrane.hip", "xtc.hip", "pair_k0.hip", "pair_k1.hip", "pair_k2.hip", "pair_k3.hip", "pair_k4.hip", "pair_k5.hip", "pair_k6.hip", "pair_small.hip", "devsort.hip"]
+SOURCES = ["api.hip", "search.hip", "search_f64.hip", "measure.hip", "measure_f64.hip", "membrane.hip", "xtc.hip", "pair_k0.hip", "pair_k1.hip", "pair_k2.hip", "pair_k3.hip", "pair_k4.hip", "pair_k5.hip", "pair_k6.hip", "pair_k7.hip", "pair_k8.hip", "pair_small.hip", "devsort.hip"]
 HEADERS = ["common.hpp", "boxmath.hpp", "linalg3.hpp", "pair_kernels.hpp", "hist_kernels.hpp", "hoststream.hpp", "boxmath64.hpp", "stages.hpp", os.path.join("..", "..", "include", "molar_hip.h")]
 # -ffp-contract=off: MolAR (Rust) never contracts a*b+c; bit-identical neighbour lists need the same
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -1429,11 +1429,33 @@ __device__ __forceinline__ uint32_t run_fast(const SearchParams &P, const Task &
 // through the same row loops - plain, same-cell and, evaluated in both passes (no hit history: the plan records none beyond
 // KREG chunks), band-classified wrapped entries - instead of streaming the second cell from memory for every row.
 constexpr int KMAX_WIDE = 16;
+constexpr int KMAX_HUGE = 32;      // ... of the instances with 3 (or 2) waves per SIMD: 168 (256) registers per lane
 template <int KIND, bool FILL, int WK, bool MASKED, int KMAX = KREG>
 __device__ __forceinline__ uint32_t run_task_nch(const SearchParams &P, const Task &T, uint32_t i0, Fifo &F, float4 *la,
                                                  uint32_t lane, uint32_t *mwords) {
     const uint32_t nchunks = (T.n2 + 63u) >> 6;
-    if constexpr (KMAX > KREG) {
+    if constexpr (KMAX > KMAX_WIDE) {
+        // the 168-register instances (pair_kernel<KIND, MODE, WPE = 3>: frames whose cells hold more than 1024 atoms as a rule): up to
+        // KMAX_HUGE chunks (2048 atoms) of the second cell resident, the chunk count rounded up to 16 / 20 / 24 / 28 / 32 (a chunk past
+        // the end of the cell holds "never a hit" coordinates: wasted lanes, no wrong results) - five sizes instead of 24 keep the
+        // build within minutes
+        if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && nchunks > (uint32_t)KREG && nchunks <= (uint32_t)KMAX) {
+            constexpr bool WR = WK != WK_NONE;
+            const bool tri = KIND == MOLAR_HIP_SEARCH_SINGLE && WK == WK_NONE && T.tri;
+            if (!T.tri || tri) {
+#define MH_HUGE_CASE(N)                                                                                              \
+    if (nchunks <= (uint32_t)(N)) {                                                                                  \
+        if (tri) {                                                                                                   \
+            if constexpr (KIND == MOLAR_HIP_SEARCH_SINGLE && WK == WK_NONE)                                          \
+                return run_fast<KIND, FILL, false, N, true, false>(P, T, i0, F, la, lane, nullptr);                  \
+        }                                                                                                            \
+        return run_fast<KIND, FILL, WR, N, false, false>(P, T, i0, F, la, lane, nullptr);                            \
+    }
+                MH_HUGE_CASE(16) MH_HUGE_CASE(20) MH_HUGE_CASE(24) MH_HUGE_CASE(28) MH_HUGE_CASE(32)
+#undef MH_HUGE_CASE
+            }
+        }
+    } else if constexpr (KMAX > KREG) {
         if ((KIND == MOLAR_HIP_SEARCH_SINGLE || KIND == MOLAR_HIP_SEARCH_DOUBLE) && nchunks > (uint32_t)KREG && nchunks <= (uint32_t)KMAX) {
             constexpr bool WR = WK != WK_NONE;
             const bool tri = KIND == MOLAR_HIP_SEARCH_SINGLE && WK == WK_NONE && T.tri;
@@ -1736,7 +1758,7 @@ __attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE ==
             const uint32_t nch = (T.n2 + 63u) >> 6;
             if (moff + 2u * nch <= P.mask_cap_units) mwords = P.maskbuf + moff * 64u;
         }
-        constexpr int KMAX = WPE ? KMAX_WIDE : KREG;
+        constexpr int KMAX = (WPE == 2 || WPE == 3) ? KMAX_HUGE : (WPE ? KMAX_WIDE : KREG);
         switch (wk) {
             case WK_NONE: total = run_task_nch<KIND, FILL, WK_NONE, MASKED, KMAX>(P, T, i0, F, lds_a[wave], lane, mwords); break;
             case WK_DIAG: total = run_task_nch<KIND, FILL, WK_DIAG, MASKED, KMAX>(P, T, i0, F, lds_a[wave], lane, mwords); break;
@@ -1804,6 +1826,11 @@ size_t hist_queue_words();
 const uint32_t *hist_list_count(const uint32_t *queue, int lslot, int which);      // which: 0 lean, 1 rest
 // (pair_k5.hip) count / fill of the fixed-cutoff kinds with 4 waves per SIMD (128 VGPRs): frames of large cells, see pair_kernel
 void launch_pair_wide(int kind, int mode, unsigned nblocks, hipStream_t stream, const pairk::SearchParams *dP,
+                      const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
+                      const unsigned long long *slot_base, uint2 *pairs, float *dist);
+// (pair_k7.hip) the same with 3 waves per SIMD (168 VGPRs), up to 32 chunks of the second cell resident: frames of cells of more
+// than 1024 atoms (single-selection and two-selection kinds)
+void launch_pair_huge(int kind, int mode, unsigned nblocks, hipStream_t stream, const pairk::SearchParams *dP,
                       const pairk::SlotDesc *slot_desc, uint32_t nslots, uint32_t *slot_cnt,
                       const unsigned long long *slot_base, uint2 *pairs, float *dist);
 void launch_pair_single(int mode, unsigned nblocks, size_t dyn_lds, hipStream_t stream, const pairk::SearchParams *dP,

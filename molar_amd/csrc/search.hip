@@ -1525,6 +1525,11 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     if (!hist_nbins && !ids && (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE)) {
         const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
         const uint64_t nb_set = c->kind == MOLAR_HIP_SEARCH_SINGLE ? c->set[0].n : c->set[1].n;
+        if (nb_set > 1000ull * ncells) {       // cells above 1024 atoms are the rule: 256 registers per lane, up to 2048 atoms resident (pair_k7.hip)
+            launch_pair_huge(c->kind, mode, P.nblocks, c->stream, dP, tf, st, sc, sb, pairs, dist);
+            MH_HIP(hipGetLastError());
+            return 0;
+        }
         if (nb_set > 448ull * ncells) {
             launch_pair_wide(c->kind, mode, P.nblocks, c->stream, dP, tf, st, sc, sb, pairs, dist);
             MH_HIP(hipGetLastError());

@@ -159,6 +159,55 @@ def test_cells_of_513_to_1024_atoms_stay_in_registers(eng, orc32, case):
     assert np.array_equal(pr, pr2) and np.array_equal(d, d2)
 
 
+@pytest.mark.parametrize("case", ["single_tric_4x4x5", "single_tric_3x3x4", "single_pbc_xy", "single_no_box", "double_tric", "single_above_2048"])
+def test_cells_of_1025_to_2048_atoms_stay_in_registers(eng, orc32, case):
+    """Frames whose cells hold more than 1000 atoms on average (rc >= 1.9 nm at water density; the reference's sweep goes to 4.2 nm,
+    benches/within_size_bench.rs:13-47) run the count / fill instances with 168 registers per lane: up to 32 chunks (2048 atoms) of the
+    second cell resident, chunk count rounded up to 16 / 20 / 24 / 28 / 32.  Plain, same-cell and wrapped entries (band-classified
+    with >= 4 cells per periodic dimension, exact below), both entry forms, against the oracle - ids, order, distances; and a frame
+    of cells ABOVE 2048 atoms, which the same instances still stream (distance_search.rs:432-517)."""
+    a = api()
+    n, rc = {"single_tric_4x4x5": (120_000, 2.0), "single_tric_3x3x4": (60_000, 2.0), "single_pbc_xy": (60_000, 2.0), "single_no_box": (60_000, 2.0),
+             "double_tric": (100_000, 2.0), "single_above_2048": (40_000, 2.4)}[case]
+    box = synth.box_a(n)
+    pos = synth.frame(n, box, 5)
+    ob = orc32.box_from_matrix(box)
+    if case.startswith("single"):
+        pbc = {"single_pbc_xy": 3, "single_no_box": 0}.get(case, 7)
+        if pbc:
+            ref = orc32.search_single_pbc(rc, pos, ob, pbc, nthreads=16)
+            kw = dict(box=box, pbc=pbc)
+        else:
+            ref = orc32.search_single(rc, pos, nthreads=16)
+            kw = {}
+        cnt = eng.search_count(a.SEARCH_SINGLE, rc, pos, **kw)
+        dims = eng.grid_dims()
+        pr, d = eng.search_fill(cnt)
+        cnt2, _, _ = eng.search_resident(a.SEARCH_SINGLE, rc, pos, **kw)
+        pr2, d2 = eng.search_fill(cnt2)
+        per_cell = n / (dims[0] * dims[1] * dims[2])
+    else:
+        rng = np.random.default_rng(9)
+        i1 = np.sort(rng.choice(n, (2 * n) // 3, replace=False)).astype(np.uint64)
+        i2 = np.sort(rng.choice(n, (5 * n) // 6, replace=False)).astype(np.uint64)        # overlaps i1: same-cell duplicates
+        ref = orc32.search_double_pbc(rc, pos[i1.astype(int)], pos[i2.astype(int)], ob, 7, ids1=i1, ids2=i2, nthreads=16)
+        cnt = eng.search_count(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=7)
+        dims = eng.grid_dims()
+        pr, d = eng.search_fill(cnt)
+        cnt2, _, _ = eng.search_resident(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=7)
+        pr2, d2 = eng.search_fill(cnt2)
+        per_cell = len(i2) / (dims[0] * dims[1] * dims[2])
+    if case == "single_tric_4x4x5":
+        assert tuple(dims) == (4, 4, 5)
+    if case != "single_no_box":          # (without a box the grid comes from the bounding box padded by the cutoff: other cells)
+        assert per_cell > (2048 if case == "single_above_2048" else 1000)
+        if case != "single_above_2048":
+            assert per_cell < 2048
+    assert cnt == cnt2 == len(ref["i"]) > 3e7
+    assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"])
+    assert np.array_equal(pr, pr2) and np.array_equal(d, d2)
+
+
 @pytest.mark.parametrize("rc", [0.35, 0.47])
 @pytest.mark.parametrize("case", ["single_tric", "single_pbc_xy", "single_no_box", "double_tric"])
 def test_small_cells_several_slots_per_wave(eng, orc32, case, rc):
