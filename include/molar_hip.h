@@ -606,6 +606,15 @@ int molar_hip_xtc_read(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t first,
  * this pays for windows of hundreds to thousands of frames - when the consumers of a multi-GPU node outrun the host's
  * decoder threads.  Frames whose packed triples exceed 64 bits fall back to the host decoder inside the call. */
 int molar_hip_xtc_read_device(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t first, size_t count, float *xyz_dev);
+/* A radial distance histogram over a block of the trajectory in one call (BASELINE config 4 for a caller without device memory
+ * of its own - the process_frame loop of an RDF task, analysis_task.rs:245-252, with Histogram1D::add_one over every distance of
+ * distance_search_single_pbc, molar_membrane/src/stats.rs:29-35): frames [first, first + count) are decoded on `decode_threads`
+ * host threads (0 = all) into windows of 16 frames in HBM while the window before is in the fused histogram
+ * (molar_hip_search_histogram_frames: selection idx - NULL = all atoms - of every frame against itself, cutoff, the frame's own
+ * box from its header, periodic dimensions `pbc`); integer bins, ADDED into bins[nbins] (host) at the end.  The same sums as
+ * molar_hip_xtc_read + molar_hip_search_histogram frame by frame. */
+int molar_hip_xtc_histogram(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t first, size_t count, const uint64_t *idx, size_t n,
+                            float cutoff, uint8_t pbc, float hmin, float hmax, size_t nbins, uint64_t *bins, int decode_threads);
 /* Writer (xtc_handler.rs:117-168, write_state through molly::XTCWriter): ONE frame in GROMACS' compressed coordinate format
  * (magic 1995; xdrfile's algorithm: integer grid at `precision`, mixed-radix triples, runs of small deltas with an adaptive
  * delta size) into out[cap]; *out_len = bytes written, frames are simply concatenated in a file.  96 + 16 * natoms bytes

@@ -611,6 +611,10 @@ class Histogram1D {
         const molar_hip_search_desc d = detail::desc(MOLAR_HIP_SEARCH_DOUBLE, cutoff, d1, &d2, false, &pbox, pbc_dims);
         return feed(d1.ctx(), d);
     }
+    // the same stream over frames [first, first + count) of an XTC trajectory in one call (molar_hip_xtc_histogram): decode on host
+    // threads and the fused histogram of 16-frame windows overlap inside it; every frame's own box; `index` empty = all atoms
+    void add_distances_trajectory_single_pbc(Engine &eng, const class XtcReader &traj, size_t first, size_t count, Float cutoff,
+                                             const std::vector<usize> &index, PbcDims pbc_dims, int decode_threads = 0);
     const std::vector<uint64_t> &counts() const { return counts_; }
     // adds another histogram of the same shape bin by bin (the integer reduction at the end of a frame-parallel run:
     // AnalysisTask::run_sharded, or one all_reduce of these counters across ranks)
@@ -866,6 +870,7 @@ class XtcReader {
     ~XtcReader() { molar_hip_xtc_close(h_); }
     size_t nframes() const { return molar_hip_xtc_nframes(h_); }
     size_t natoms() const { return molar_hip_xtc_natoms(h_); }
+    const molar_hip_xtc *handle() const { return h_; }
     size_t current_frame() const { return cur_fr_; }
     void seek_frame(size_t fr) {
         if (fr > nframes()) throw MolarError(MOLAR_HIP_ERR_IO, "seek to frame failed");
@@ -899,6 +904,12 @@ class XtcReader {
         return [r]() { return r->read_state(); };
     }
 };
+
+inline void Histogram1D::add_distances_trajectory_single_pbc(Engine &eng, const XtcReader &traj, size_t first, size_t count, Float cutoff,
+                                                             const std::vector<usize> &index, PbcDims pbc_dims, int decode_threads) {
+    check(molar_hip_xtc_histogram(eng.ctx(), traj.handle(), first, count, index.empty() ? nullptr : index.data(), index.size(), cutoff,
+                                  pbc_dims.raw(), min_, max_, counts_.size(), counts_.data(), decode_threads));
+}
 
 // XTC writer: FileFormatHandler::create + write_state (xtc_handler.rs:54-62, 117-168); frames are appended to one file.
 class XtcWriter {

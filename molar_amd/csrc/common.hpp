@@ -256,6 +256,10 @@ struct molar_hip_ctx {
     mh::DevBuf maskbuf;        // hit bits recorded by the count pass, replayed by the fill pass
     uint64_t mask_units = 0;
 
+    // molar_hip_xtc_histogram: a second context for the decoder thread (its own stream and pinned staging), two windows of frames, bins + index
+    molar_hip_ctx *aux = nullptr;
+    mh::DevBuf xh_win[2], xh_bins;
+
     // ---- profiling (HIP events on `stream`)
     bool profiling = false;
     bool profile_frames = false;   // molar_hip_profile_enable(ctx, 2): ONE span (class 5) around count + offsets + fill of a resident search, none inside

@@ -128,6 +128,22 @@ class XtcReader:
         check(self.lib.molar_hip_xtc_read_device(self.engine.ctx, self.h, first, count, addr))
         return out
 
+    def histogram(self, first, count, cutoff, hmin, hmax, nbins, idx=None, pbc=7, bins=None, nthreads=None):
+        """molar_hip_xtc_histogram: the distances of distance_search_single_pbc of frames [first, first + count) - selection idx
+        (None = all atoms) of every frame against itself, every frame's own box - through Histogram1D::add_one, decode and the
+        fused histogram overlapped inside the call.  Adds into `bins` (numpy uint64[nbins], made if None) and returns it."""
+        if self.engine is None:
+            raise ValueError("histogram needs an engine")
+        from .api import pbc_mask
+        if bins is None:
+            bins = np.zeros(nbins, np.uint64)
+        assert bins.dtype == np.uint64 and bins.flags.c_contiguous and len(bins) == nbins
+        idx = None if idx is None else np.ascontiguousarray(idx, np.uint64)
+        check(self.lib.molar_hip_xtc_histogram(self.engine.ctx, self.h, first, count, None if idx is None else idx.ctypes.data,
+                                               0 if idx is None else len(idx), float(cutoff), pbc_mask(pbc), float(hmin), float(hmax), nbins,
+                                               bins.ctypes.data, self.nthreads if nthreads is None else nthreads))
+        return bins
+
     # ---- FileFormatHandler mirror
     def seek_frame(self, fr):
         if fr > len(self):

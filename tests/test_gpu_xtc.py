@@ -177,3 +177,46 @@ def test_device_decoder_reports_corrupt_streams(eng, orc32):
     with pytest.raises(MolarHipError):
         r.read_frames_device(0, 3, dev)
     r.read_frames_device(0, 1, dev[:1])               # the intact frame in front still decodes
+
+
+def test_xtc_histogram_one_call(eng, orc32):
+    """molar_hip_xtc_histogram: BASELINE config 4's whole path as one call for a caller without device memory - frames of an XTC
+    block decoded on host threads into 16-frame windows in HBM (helper thread, auxiliary context) while the window before is in
+    the frames form of the fused histogram, every frame's own box.  Integer bins: they must equal Histogram1D::add_one
+    (stats.rs:29-35) over the oracle's distance stream of the oracle-decoded frames - all atoms and a selection, a block that is
+    not a multiple of the window, frames whose boxes differ, a sub-range of the file; repeated calls add up."""
+    from molar_amd import synth
+    from molar_amd.xtc import XtcReader
+    n, nframes, rc, nbins = 30_000, 37, 0.9, 500
+    box = synth.box_a(n)
+    blobs, boxes = [], []
+    for f in range(nframes):
+        b = (box * np.float32(1.0 + 0.002 * np.sin(f))).astype(np.float32)
+        boxes.append(b)
+        blobs.append(orc32.xtc_encode(synth.frame(n, b, f), np.ascontiguousarray(b.T).reshape(9), step=f, time=float(f)))
+    blob = b"".join(blobs)
+    r = XtcReader(blob, engine=eng, nthreads=4)
+    assert len(r) == nframes
+    idx = np.sort(np.random.default_rng(3).choice(n, n // 3, replace=False)).astype(np.uint64)
+    offs = orc32.xtc_index(blob)
+
+    def want(first, count, sel):
+        w = np.zeros(nbins, np.uint64)
+        for f in range(first, first + count):
+            xyz = orc32.xtc_decode(blob, offs[f])[0]
+            p = xyz if sel is None else xyz[sel.astype(int)]
+            # the box the FILE holds (f32 through the encoder's header), as the engine reads it from the frame's header
+            fb = r.frame_info(f)["box9"].reshape(3, 3).T
+            ref = orc32.search_single_pbc(rc, p, orc32.box_from_matrix(fb), 7, nthreads=8)
+            w += orc32.histogram_add(0.0, rc, nbins, ref["d"]).astype(np.uint64)
+        return w
+    w_all = want(0, nframes, None)
+    got = r.histogram(0, nframes, rc, 0.0, rc, nbins)
+    assert w_all.sum() > 1e8 and np.array_equal(got, w_all)
+    r.histogram(0, nframes, rc, 0.0, rc, nbins, bins=got)              # added into
+    assert np.array_equal(got, 2 * w_all)
+    assert np.array_equal(r.histogram(5, 18, rc, 0.0, rc, nbins, idx=idx), want(5, 18, idx))
+    assert np.array_equal(r.histogram(36, 1, rc, 0.0, rc, nbins), want(36, 1, None))
+    from molar_amd._lib import MolarHipError
+    with pytest.raises(MolarHipError):
+        r.histogram(30, 10, rc, 0.0, rc, nbins)
