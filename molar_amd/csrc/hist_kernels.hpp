@@ -378,16 +378,27 @@ hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ sl
         if (lane == 0) t = __hip_atomic_fetch_add(qctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return t;
     };
+    // -DMH_HIST_TICKET_AHEAD=1: the ticket of the NEXT slot is taken while the slot in hand is worked on (one returning atomic in
+    // flight per wave), so that its round trip - the first of the four dependent ones in front of a slot's first distance - hides
+    // behind the work.  Round 5 measured it 10 % slower on single-frame launches (at the end of a queue every busy wave sits on a
+    // slot an idle one could have had); round 6 again on launches over 16 frames, where a queue ends once per group: 0.1993 against
+    // 0.1977 ms of kernel per frame in three alternations on one box (tools/ab_rdf.sh) - the ticket costs the kernel its 65th
+    // vector register (one spill), and with 8 waves per SIMD its latency was hidden already.  Off.
+#ifndef MH_HIST_TICKET_AHEAD
+#define MH_HIST_TICKET_AHEAD 0
+#endif
+    uint32_t ticket_next = MH_HIST_TICKET_AHEAD ? take() : 0u;
     for (;;) {
 #ifdef MOLAR_HIP_DEBUG_KNOBS
         const unsigned long long dbg_ta = __builtin_amdgcn_s_memrealtime();
 #endif
-        const uint32_t s = sgpr(take());
+        const uint32_t s = sgpr(MH_HIST_TICKET_AHEAD ? ticket_next : take());
 #ifdef MOLAR_HIP_DEBUG_KNOBS
         const unsigned long long dbg_tb = __builtin_amdgcn_s_memrealtime();      // the ticket has arrived
 #endif
         const uint32_t k = (s / XCD_RUN) * HIST_NSUB + qj, run = k * 8u + qx;         // this queue's (s / XCD_RUN)-th run
         if (run >= nruns) break;
+        if (MH_HIST_TICKET_AHEAD) ticket_next = take();
         const uint32_t w = run * XCD_RUN + (s % XCD_RUN);
         if (w >= nslots) continue;
         const uint32_t slot = nslots - 1u - w;

@@ -7,7 +7,7 @@ name=$1; flags=$2; shift 2
 srcs=${@:-pair_k0.hip}
 cd "$(dirname "$0")/../molar_amd"
 mkdir -p _ab
-all="api search search_f64 measure measure_f64 membrane xtc pair_k0 pair_k1 pair_k2 pair_k3 pair_k4 pair_k5 pair_k6 pair_small devsort"
+all="api search search_f64 measure measure_f64 membrane xtc pair_k0 pair_k1 pair_k2 pair_k3 pair_k4 pair_k5 pair_k6 pair_k7 pair_k8 pair_small devsort"
 if [ "$srcs" = all ]; then srcs=$(for f in $all; do printf "%s.hip " $f; done); fi
 base="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize"
 objs=""
