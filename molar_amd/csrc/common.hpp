@@ -267,6 +267,7 @@ struct molar_hip_ctx {
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
 
+    mh::DevBuf fit_redo;       // membrane fit: lipids k_membrane_fit_lanes hands to the one-lane kernel
     // ---- measure scratch
     mh::DevBuf m_xyz1, m_xyz2, m_idx1, m_idx2, m_mass1, m_mass2, m_partials, m_results, m_out;
 };

@@ -44,6 +44,8 @@ struct SmoothDev {
     const uint32_t *rev_off;   // [K+1]   transpose of the patch CSR
     const uint32_t *rev_entry; // [E]     flat patch entry
     const uint32_t *rev_owner; // [E]     lipid owning that entry
+    uint8_t *redo = nullptr;   // [K] or NULL: k_membrane_fit_lanes leaves 1 for the lipids it hands to k_membrane_fit (which then
+                               //             takes only those), 0 for the ones it has done
 };
 
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(64) void k_membrane_fit(SmoothDev A) {
     const uint32_t lanes = blockDim.x;               // lipids per workgroup (16, 32 or 64: launch_fit)
     const uint32_t i = blockIdx.x * lanes + threadIdx.x;
     if (i >= A.K || !A.valid[i]) return;
+    if (A.redo && !A.redo[i]) return;                // done by k_membrane_fit_lanes
     const uint64_t p0 = A.poff[i];
     const uint32_t np = (uint32_t)(A.poff[i + 1] - p0);
     const uint64_t slot = p0 + 4ull * i;
@@ -359,8 +362,283 @@ __global__ __launch_bounds__(64) void k_membrane_fit(SmoothDev A) {
     A.head[3 * i] += t.x; A.head[3 * i + 1] += t.y; A.head[3 * i + 2] += t.z;
 }
 
+// The same fit with SIXTEEN lanes per lipid (round 6).  One lane per lipid is a serial chain of ~100 us - 40 patch members x
+// (gather, 42 multiply-adds into the normal equations), a Cholesky solve, 40 half-plane clips each walking a linked list with
+// dependent LDS loads - and a bilayer of 4000 lipids cannot hide it behind other lipids.  Here a lipid's lanes share the work
+// WITHOUT changing a single rounding, so every output equals the one-lane kernel's bit for bit:
+//   * local points: one patch member per lane (gathers in parallel), kept in LDS;
+//   * normal equations: the 36 + 6 accumulators are dealt over the lanes (three each); every accumulator still runs over the
+//     members in patch order - the reference's order of additions (lib.rs:851-860) - only 3 instead of 42 per lane and member;
+//   * Cholesky (get_quad_coefs, lib.rs:862): every lane gathers the sums and solves, redundantly;
+//   * Voronoi cell: the ring of vertices lives one vertex per lane, in ring order from the cell's `init` vertex.  A half-plane
+//     (VoronoiCell::add_point, voronoi_cell.rs:107-205) is classified by all lanes at once (one ballot); the reference's walk -
+//     first inner vertex from init, first outer one after it (cut #1), next inner one (cut #2) - becomes three bit scans, the
+//     two new vertices are the reference's expressions on values fetched by shuffles, and the ring closes up by one shift.
+//     Cells of more than 16 vertices at any moment, patches of more than FIT_PTS members and non-finite distances are handed
+//     to k_membrane_fit (redo flag): nothing has been written for them by then;
+//   * outputs (neighbour ids, cell vertices on the fitted surface, fan area - summed in ring order -, fitted patch points) by
+//     the lanes that hold the values.
+constexpr uint32_t FIT_G = 16;           // lanes per lipid
+constexpr uint32_t FIT_PTS = 96;         // patch members per lipid in LDS
+
+__global__ __launch_bounds__(64) void k_membrane_fit_lanes(SmoothDev A) {
+    // a patch member in the lipid's local frame, as the seven factors of its normal-equation terms and its id:
+    // {x x, y y, x y, x, y, 1, z, id} - the accumulators pick their two factors by index (an LDS read each, no selects)
+    __shared__ float pts_s[64 / FIT_G][FIT_PTS][8];
+    const uint32_t lane = threadIdx.x & 63u, g = lane / FIT_G, sub = lane % FIT_G, gl = g * FIT_G;      // gl: first lane of the group
+    const uint32_t i = blockIdx.x * (64u / FIT_G) + g;
+    if (i >= A.K) return;
+    if (!A.valid[i]) {
+        if (sub == 0u) A.redo[i] = 0;
+        return;
+    }
+    const uint64_t p0 = A.poff[i];
+    const uint32_t np = (uint32_t)(A.poff[i + 1] - p0);
+    const uint64_t slot = p0 + 4ull * i;
+    if (np > FIT_PTS) {                              // a patch too long for the LDS slice: the one-lane kernel
+        if (sub == 0u) A.redo[i] = 1;
+        return;
+    }
+    float (*pts)[8] = pts_s[g];
+    const V3 nrm = v3(A.normals[3 * i], A.normals[3 * i + 1], A.normals[3 * i + 2]);
+    float to_lab[9], to_local[9];
+    {   // get_to_lab_transform (lipid_molecule.rs:190-196)
+        const V3 c0 = cross(nrm, v3(1.0f, 0.0f, 0.0f));
+        const V3 c1 = cross(nrm, c0);
+        to_lab[0] = c0.x; to_lab[1] = c0.y; to_lab[2] = c0.z;
+        to_lab[3] = c1.x; to_lab[4] = c1.y; to_lab[5] = c1.z;
+        to_lab[6] = -nrm.x; to_lab[7] = -nrm.y; to_lab[8] = -nrm.z;
+    }
+    if (!inverse3(to_lab, to_local)) {
+        if (sub == 0u) { A.valid[i] = 0; A.redo[i] = 0; }
+        return;
+    }
+    const V3 c = v3(A.saved[3 * i], A.saved[3 * i + 1], A.saved[3 * i + 2]);
+    const molar_hip_box &box = A.box;
+    // Everything from here to the end of the Voronoi loop runs with WAVE-UNIFORM control flow: the four lipids of a wave differ in
+    // patch length and in what a half-plane cuts, and a divergent region in the middle of this code would have the compiler
+    // split live ranges across its join (ROCm 7.2 places such copies ahead of the EXEC restore: molar_amd/build.py audits the
+    // ISA for it and refused the first version of this kernel).  Loops run to the wave's longest patch, a lipid's own length
+    // and state select what is kept.
+    uint32_t np_w = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 64u; k += FIT_G) {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)np, (int)k);      // (lanes that left above read as whatever they held: bounded below)
+        np_w = v > np_w && v <= FIT_PTS ? v : np_w;
+    }
+    // ---- local points (lib.rs:685-689): one member per lane
+    for (uint32_t q0 = 0; q0 < np_w; q0 += FIT_G) {
+        const uint32_t q = q0 + sub;
+        if (q < np) {
+            const uint32_t j = (uint32_t)A.pids[p0 + q];
+            const V3 ss = v3(A.saved[3 * j], A.saved[3 * j + 1], A.saved[3 * j + 2]);
+            const V3 l = mat_vec(to_local, shortest_vector(box, ss - c, MOLAR_HIP_PBC_FULL));
+            float *rec = pts[q];
+            rec[0] = l.x * l.x; rec[1] = l.y * l.y; rec[2] = l.x * l.y; rec[3] = l.x; rec[4] = l.y; rec[5] = 1.0f; rec[6] = l.z;
+            rec[7] = __uint_as_float(j);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- normal equations (lib.rs:851-860): accumulator a = sub + 16 k; a < 36: m[a] (column a / 6, row a % 6), else cf[a - 36]
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t ar_[3], ac_[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t a = sub + FIT_G * (uint32_t)k;
+        ar_[k] = a < 36u ? a % 6u : a - 36u;
+        ac_[k] = a < 36u ? a / 6u : 6u;
+    }
+    for (uint32_t q = 0; q < np_w; ++q) {
+        const float *rec = pts[q];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float prod = rec[ar_[k]] * rec[ac_[k]];       // pw[r] * pw[c], pw[r] * z
+            acc[k] += q < np ? prod : 0.0f;              // (x + 0 == x: members past this lipid's patch change nothing)
+        }
+    }
+    float m[36], cf[6];
+#pragma unroll
+    for (int a = 0; a < 36; ++a) m[a] = __shfl(acc[a / (int)FIT_G], (int)(gl + (uint32_t)(a % (int)FIT_G)), 64);
+#pragma unroll
+    for (int a = 36; a < 42; ++a) cf[a - 36] = __shfl(acc[a / (int)FIT_G], (int)(gl + (uint32_t)(a % (int)FIT_G)), 64);
+    // state of this lipid: 0 running, 1 handed to the one-lane kernel, 2 dropped (valid = 0)
+    uint32_t state = 0u;
+    {   // cholesky6_solve without its early exits (same operations in the same order; a failed factorisation runs on into NaNs nobody reads)
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                const float factor = -m[k * 6 + j];
+#pragma unroll
+                for (int r = j; r < 6; ++r) m[j * 6 + r] = factor * m[k * 6 + r] + m[j * 6 + r];
+            }
+            const float diag = m[j * 6 + j];
+            ok = ok && diag > 0.0f;
+            const float denom = __builtin_sqrtf(diag);
+            m[j * 6 + j] = denom;
+#pragma unroll
+            for (int r = j + 1; r < 6; ++r) m[j * 6 + r] /= denom;
+        }
+#pragma unroll
+        for (int r0 = 0; r0 < 6; ++r0) {
+            const float coeff = cf[r0] / m[r0 * 6 + r0];
+            cf[r0] = coeff;
+#pragma unroll
+            for (int r = r0 + 1; r < 6; ++r) cf[r] = (-coeff) * m[r0 * 6 + r] + cf[r];
+        }
+#pragma unroll
+        for (int r0 = 5; r0 >= 0; --r0) {
+            float dot = 0.0f;
+#pragma unroll
+            for (int r = r0 + 1; r < 6; ++r) dot += m[r0 * 6 + r] * cf[r];
+            cf[r0] = (cf[r0] - dot) / m[r0 * 6 + r0];
+        }
+        if (!ok) state = 2u;
+    }
+    // ---- Voronoi cell: vertex `sub` of the ring, counted from the cell's init vertex
+    float vx = (sub == 0u || sub == 3u) ? -10.0f : 10.0f;          // VoronoiCell::new(-10, 10, -10, 10)  (voronoi_cell.rs:62-80)
+    float vy = sub < 2u ? -10.0f : 10.0f;
+    int32_t vid = -(int32_t)sub - 1;
+    uint32_t nv = 4u;
+    const float TOL = 1e-10f;
+    for (uint32_t q = 0; q < np_w; ++q) {
+        const bool run = state == 0u && q < np;
+        const float px = pts[q][3], py = pts[q][4], pidf = pts[q][7];
+        const float lx = 0.5f * px, ly = 0.5f * py;
+        const float r2 = lx * lx + ly * ly;
+        float d = (lx * vx + ly * vy) - r2;                          // line.pos.dot(pos) - r2  (voronoi_cell.rs:83-85)
+        const uint32_t vmask = (1u << nv) - 1u;
+        const bool here = sub < nv;
+        uint32_t in_mask = (uint32_t)(__builtin_amdgcn_ballot_w64(here && d < TOL) >> gl) & vmask;
+        const uint32_t out_any = (uint32_t)(__builtin_amdgcn_ballot_w64(here && d >= TOL) >> gl) & vmask;
+        // a distance that is neither (not a number): the one-lane kernel walks it like the reference;  no vertex on the inner
+        // side: the reference's walk never ends (its guard): the lipid is dropped
+        const bool nan_d = (in_mask | out_any) != vmask, none_in = in_mask == 0u;
+        const uint32_t s0 = none_in ? 0u : (uint32_t)__builtin_ctz(in_mask);          // the walk from init stops at the first inner vertex: the new init
+        const bool step = run && !nan_d && !none_in;
+        {   // the ring turns so that the new init is vertex 0 (s0 == 0: every lane reads itself)
+            const uint32_t src = gl + (sub + s0 < nv ? sub + s0 : (sub + s0 - nv) & (FIT_G - 1u));
+            const float rx = __shfl(vx, (int)src, 64), ry = __shfl(vy, (int)src, 64), rd = __shfl(d, (int)src, 64);
+            const int32_t rid = __shfl(vid, (int)src, 64);
+            if (step) { vx = rx; vy = ry; vid = rid; }
+            d = rd;
+            in_mask = s0 ? ((in_mask >> s0) | (in_mask << (nv - s0))) & vmask : in_mask;
+        }
+        const uint32_t out_mask = ~in_mask & vmask;
+        const bool cut = step && out_mask != 0u;                                         // else: every vertex is inside, nothing to cut
+        const uint32_t t1 = out_mask ? (uint32_t)__builtin_ctz(out_mask) : 1u;          // c1_out; c1_in = t1 - 1  (t1 >= 1: vertex 0 is inside)
+        const uint32_t t1s = t1 ? t1 : 1u;
+        const uint32_t rest = in_mask >> t1s;
+        const uint32_t t2 = rest ? t1s + (uint32_t)__builtin_ctz(rest) : nv;            // c2_in (nv: the ring closes on vertex 0); c2_out = t2 - 1
+        const uint32_t c2in = t2 >= nv ? 0u : t2;
+        const uint32_t l1i = gl + ((t1s - 1u) & (FIT_G - 1u)), l1o = gl + (t1s & (FIT_G - 1u)), l2o = gl + ((t2 - 1u) & (FIT_G - 1u)), l2i = gl + c2in;
+        const float x1i = __shfl(vx, (int)l1i, 64), y1i = __shfl(vy, (int)l1i, 64), d1i = __shfl(d, (int)l1i, 64);
+        const float x1o = __shfl(vx, (int)l1o, 64), y1o = __shfl(vy, (int)l1o, 64), d1o = __shfl(d, (int)l1o, 64);
+        const float x2o = __shfl(vx, (int)l2o, 64), y2o = __shfl(vy, (int)l2o, 64), d2o = __shfl(d, (int)l2o, 64);
+        const float x2i = __shfl(vx, (int)l2i, 64), y2i = __shfl(vy, (int)l2i, 64), d2i = __shfl(d, (int)l2i, 64);
+        const int32_t id2 = __shfl(vid, (int)l2o, 64);
+        const float f2 = d2o / (fabsf(d2i) + d2o);                                      // cut #2 (:173-195)
+        const float p2x = (1.0f - f2) * x2o + f2 * x2i, p2y = (1.0f - f2) * y2o + f2 * y2i;
+        const float f1 = d1o / (fabsf(d1i) + d1o);                                      // cut #1 (:197-202)
+        const float p1x = (1.0f - f1) * x1o + f1 * x1i, p1y = (1.0f - f1) * y1o + f1 * y1i;
+        const uint32_t nv_new = t1s + 2u + (nv - (t2 > nv ? nv : t2));
+        const bool grow = cut && nv_new > FIT_G;                                         // the cell outgrows the lanes: the one-lane kernel
+        // the ring closes up: [0, t1) stay, t1 <- P1 (edge made by this point), t1 + 1 <- P2 (keeps the outer vertex's edge id), then old [t2, nv)
+        const uint32_t from = sub >= t1s + 2u ? sub - (t1s + 2u) + t2 : sub;
+        const uint32_t srcl = gl + (from & (FIT_G - 1u));
+        const float sx = __shfl(vx, (int)srcl, 64), sy = __shfl(vy, (int)srcl, 64);
+        const int32_t sid = __shfl(vid, (int)srcl, 64);
+        const bool apply = cut && !grow;
+        const bool is1 = sub == t1s, is2 = sub == t1s + 1u, tail = sub >= t1s + 2u;
+        vx = apply ? (is1 ? p1x : is2 ? p2x : tail ? sx : vx) : vx;
+        vy = apply ? (is1 ? p1y : is2 ? p2y : tail ? sy : vy) : vy;
+        vid = apply ? (is1 ? (int32_t)__float_as_uint(pidf) : is2 ? id2 : tail ? sid : vid) : vid;
+        nv = apply ? nv_new : nv;
+        state = run ? (nan_d ? 1u : none_in ? 2u : grow ? 1u : state) : state;
+    }
+    if (state != 0u) {                               // leaves for good: nothing of this lipid has been written yet
+        if (sub == 0u) {
+            A.redo[i] = state == 1u ? 1 : 0;
+            if (state == 2u) A.valid[i] = 0;
+        }
+        return;
+    }
+    if (sub == 0u) A.redo[i] = 0;
+    // ---- direct neighbours (lib.rs:706-726): ring order, wall vertices (negative ids) left out
+    {
+        const bool is_nb = sub < nv && vid >= 0;
+        const uint32_t nb_mask = (uint32_t)(__builtin_amdgcn_ballot_w64(is_nb) >> gl) & 0xFFFFu;
+        if (is_nb) A.neib[slot + (uint32_t)__popc(nb_mask & ((1u << sub) - 1u))] = (uint64_t)vid;
+        if ((uint32_t)__popc(nb_mask) < nv) {        // a wall vertex survived: open cell
+            if (sub == 0u) A.valid[i] = 0;
+            return;
+        }
+    }
+    if (sub == 0u) {
+        A.nvert[i] = nv;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) A.coefs[6 * i + k] = cf[k];
+        // compute_curvature_and_normal (lipid_molecule.rs:134-187)
+        const float a = cf[0], b = cf[1], cq = cf[2], dd = cf[3], e = cf[4];
+        const float E = 1.0f + dd * dd, F = dd * e, G = 1.0f + e * e;
+        const float L = 2.0f * a, M = cq, N = 2.0f * b;
+        const float Z = E * G - F * F;
+        A.gauss[i] = (L * N - M * M) / Z;
+        A.mean[i] = 0.5f * ((E * N - 2.0f * F * M) + G * L) / Z;
+        const float glen = __builtin_sqrtf((dd * dd + e * e) + 1.0f);
+        const V3 fn = mat_vec(to_lab, v3(dd / glen, e / glen, -1.0f / glen));
+        A.normals[3 * i] = fn.x; A.normals[3 * i + 1] = fn.y; A.normals[3 * i + 2] = fn.z;
+        float ev[2], evec[4];
+        eig2_sym((E * L - F * M) / Z, (G * M - F * L) / Z, (G * N - F * M) / Z, ev, evec);
+        A.pcurv[2 * i] = ev[0]; A.pcurv[2 * i + 1] = ev[1];
+        for (int k = 0; k < 2; ++k) {
+            const V3 pd = mat_vec(to_lab, v3(evec[2 * k], evec[2 * k + 1], 0.0f));
+            A.pdirs[6 * i + 3 * k] = pd.x; A.pdirs[6 * i + 3 * k + 1] = pd.y; A.pdirs[6 * i + 3 * k + 2] = pd.z;
+        }
+    }
+    {   // cell vertices on the fitted surface, lab frame, relative to the marker; fan area summed in ring order (lib.rs:731-752)
+        V3 p = v3(0.f, 0.f, 0.f);
+        if (sub < nv) {
+            p = mat_vec(to_lab, v3(vx, vy, z_surf(vx, vy, cf)));
+            float *dst = A.voro + 3 * (slot + sub);
+            dst[0] = p.x; dst[1] = p.y; dst[2] = p.z;
+        }
+        const uint32_t prev = gl + (sub == 0u ? nv - 1u : sub - 1u);
+        const V3 pp = v3(__shfl(p.x, (int)prev, 64), __shfl(p.y, (int)prev, 64), __shfl(p.z, (int)prev, 64));
+        const float term = 0.5f * __builtin_sqrtf(norm2(cross(pp, p)));      // lane 0: the closing triangle (last vertex, first vertex)
+        float ar = 0.0f;
+        for (uint32_t k = 1; k < nv; ++k) ar += __shfl(term, (int)(gl + k), 64);
+        ar += __shfl(term, (int)gl, 64);
+        if (sub == 0u) A.area[i] = ar;
+    }
+    float *fp = A.fitted + 3 * p0;
+    for (uint32_t q = sub; q < np; q += FIT_G) {     // fitted patch points (lib.rs:760-768)
+        const float rx = pts[q][3], ry = pts[q][4], rz = pts[q][6];
+        const uint32_t j = __float_as_uint(pts[q][7]);
+        const V3 ss = v3(A.saved[3 * j], A.saved[3 * j + 1], A.saved[3 * j + 2]);
+        const V3 t = mat_vec(to_lab, v3(0.0f, 0.0f, z_surf(rx, ry, cf) - rz));
+        fp[3 * q] = ss.x + t.x;
+        fp[3 * q + 1] = ss.y + t.y;
+        fp[3 * q + 2] = ss.z + t.z;
+    }
+    if (sub != 0u) return;
+    if (fabsf(cf[5]) > 0.5f) { A.valid[i] = 0; return; }   // fitted surface too far from the marker (lib.rs:774-777)
+    const V3 t = mat_vec(to_lab, v3(0.0f, 0.0f, cf[5]));
+    A.head[3 * i] += t.x; A.head[3 * i + 1] += t.y; A.head[3 * i + 2] += t.z;
+}
+
 // the fit kernel needs more LDS than a kernel gets by default
-int launch_fit(molar_hip_ctx *c, const SmoothDev &A) {
+int launch_fit(molar_hip_ctx *c, const SmoothDev &A0) {
+    SmoothDev A = A0;
+    // sixteen lanes per lipid first; what it hands back (cells of more than 16 vertices, patches of more than 96 members) goes
+    // through the one-lane kernel below
+    A.redo = nullptr;
+#ifndef MH_FIT_ONE_LANE          // (-DMH_FIT_ONE_LANE: the one-lane kernel alone, for A/B runs and bit-for-bit comparisons)
+    MH_TRY(c->fit_redo.reserve(A.K));
+    A.redo = c->fit_redo.as<uint8_t>();
+    hipLaunchKernelGGL(k_membrane_fit_lanes, dim3((A.K + 64u / FIT_G - 1u) / (64u / FIT_G)), dim3(64), 0, c->stream, A);
+#endif
     static bool ready[64] = {};          // per device: the attribute belongs to the device's copy of the kernel
     const int dev = c->device & 63;
     if (!ready[dev]) {
@@ -652,10 +930,13 @@ __global__ __launch_bounds__(256) void k_split_markers(uint32_t K, const float *
     }
 }
 
+// (mask_units / mask_cap: a search whose hit history did not fit has left the results of its wrapped entries unwritten - stale
+// pairs of whatever search used the buffer before, possibly of a larger system: ids beyond this one's arrays.  The list then
+// counts as not there, like one that outgrew its buffer; the host grows the history and repeats the stage.)
 __global__ void k_patch_begin(const unsigned long long *__restrict__ total, unsigned long long cap_pairs, unsigned long long cap_entries,
-                              FrameInfo *__restrict__ info) {
+                              const unsigned long long *__restrict__ mask_units, unsigned long long mask_cap, FrameInfo *__restrict__ info) {
     const unsigned long long t = total ? *total : 0ull;
-    const bool over = t > cap_pairs || 2ull * t > cap_entries;
+    const bool over = t > cap_pairs || 2ull * t > cap_entries || (mask_units && *mask_units > mask_cap);
     info->npairs = over ? 0ull : t;
     info->E = over ? 0ull : 2ull * t;
     info->overflow = over ? 1 : 0;
@@ -1124,7 +1405,8 @@ int enqueue_b(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
     const size_t Ecap = S.Ecap;
     uint32_t *deg = P->work.as<uint32_t>(), *cursor = deg + (K + 1), *t_ord = cursor + K, *t_oth = t_ord + Ecap, *t_grp = t_oth + Ecap;
     MH_HIP(hipMemsetAsync(deg, 0, ((K + 1) + K) * 4, st));
-    hipLaunchKernelGGL(k_patch_begin, dim3(1), dim3(1), 0, st, total_dev, S.cap_pairs, (unsigned long long)Ecap, info);
+    hipLaunchKernelGGL(k_patch_begin, dim3(1), dim3(1), 0, st, total_dev, S.cap_pairs, (unsigned long long)Ecap, S.L.mask_units_dev,
+                       S.L.maskcap0, info);
     uint64_t *poff = (uint64_t *)(d + L.poff), *pids = (uint64_t *)(d + L.pids);
     uint32_t *roff = (uint32_t *)(d + L.roff), *pids32 = (uint32_t *)(d + L.pids32), *owner = (uint32_t *)(d + L.owner),
              *rev_entry = (uint32_t *)(d + L.rev_entry), *rev_owner = (uint32_t *)(d + L.rev_owner);

@@ -2322,6 +2322,7 @@ static int resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, mh
     if (L->degenerate) return 0;
     const bool fast_kind = records_hit_history(c);
     L->maskcap0 = c->maskbuf.cap / 256u;
+    L->mask_units_dev = fast_kind ? c->task_moff.as<unsigned long long>() + c->ntasks : nullptr;
     // slots the two passes are launched over: what the plan of the search before came to, with a margin (common.hpp, trim_real)
     L->launched = c->nslots_bound;
     L->ntasks = c->ntasks;

@@ -27,6 +27,10 @@ struct ResidentLaunch {
     unsigned long long launched = 0;  // slots the count and fill passes were launched over (the plan's real count must not exceed it)
     unsigned long long ntasks = 0;    // entries of the search's plan
     bool degenerate = false;          // empty vdw input: nothing was enqueued, the result is empty
+    // Device address of the hit-history units this search's plan asked for (NULL: the search records none).  When they exceed
+    // maskcap0 the fill pass has left the wrapped slots' results UNWRITTEN - whatever the buffer held before: a kernel chained
+    // behind the search must look (the host only finds out at its next wait) and treat the list as not there.
+    const unsigned long long *mask_units_dev = nullptr;
 };
 int search_resident_enqueue(molar_hip_ctx *c, const molar_hip_search_desc *q, void *sizes_pinned, ResidentLaunch *L,
                             const unsigned long long **total_dev, const uint32_t **pairs_dev);

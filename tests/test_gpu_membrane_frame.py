@@ -244,3 +244,27 @@ def test_plan_argument_errors(eng):
     with pytest.raises(api.MolarHipError):
         api.MembranePlan(eng, 10, m.lipid_idx, m.lipid_off, m.marker_idx, m.marker_off, masses[:10], m.tail_idx, m.tail_off,
                          np.repeat(np.arange(m.K, dtype=np.uint32), m.ntails), m.tail_bonds, 1.5, 1)     # indices beyond natoms
+
+
+def test_regular_marker_search_after_a_small_cell_one_on_the_same_context():
+    """A bilayer whose marker search runs the small-cell kernels (no hit history: none is allocated) followed, on the SAME engine
+    context, by a smaller bilayer with a larger cutoff whose marker search runs the regular kernels: the first attempt of that
+    search finds no room for its hit history, its fill pass leaves the wrapped entries' results unwritten - stale pairs of the
+    larger system - and the patch kernels chained behind it must not touch them (k_patch_begin: the list counts as not there;
+    round 6 met a memory fault here).  The frame is repeated with the history grown and must equal a fresh context's."""
+    from molar_amd import api, build
+    from molar_amd import membrane as mb
+    build.build_library()
+    e_shared, e_fresh = api.Engine(0), api.Engine(0)
+    big = mb.build_bilayer(800, 120_000, seed=101)
+    small = mb.build_bilayer(450, 60_000, seed=103)
+    m_big = mb.Membrane(e_shared, len(big[0]), big[2], big[3], big[4], mb.MembraneOptions(cutoff=2.5, order_type=1))
+    r0 = m_big.compute(big[0].copy(), big[1])
+    assert int(r0["valid"].sum()) > 1000
+    opt = mb.MembraneOptions(cutoff=3.5, order_type=1, max_smooth_iter=2)
+    got = mb.Membrane(e_shared, len(small[0]), small[2], small[3], small[4], opt).compute(small[0].copy(), small[1])
+    want = mb.Membrane(e_fresh, len(small[0]), small[2], small[3], small[4], opt).compute(small[0].copy(), small[1])
+    assert int(want["valid"].sum()) > 500
+    for k, v in want.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(got[k], v), k
