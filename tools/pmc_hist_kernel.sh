@@ -1,9 +1,10 @@
-# SQ counters of the fused-histogram kernels (bench.py --workload rdf), one rocprofv3 pass per counter group
+# SQ counters of the fused-histogram kernels (bench.py --workload rdf, frames form: every hist_kernel launch carries 16 frames -
+# the figures are per LAUNCH, divide by 16 for a frame), one rocprofv3 pass per counter group
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_ATOMIC_RETURN"; do
   D=$R/gpurun_out/pmch_$(echo $C | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -- python $R/bench.py --workload rdf --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -- python $R/bench.py --workload rdf --steps 32 --warmup 16 --profile-steps 16 --no-cpu-baseline > /dev/null 2>&1
   F=$(find $D -name "*counter_collection.csv" | head -1)
   python - "$F" <<'PY'
 import sys, csv, collections

@@ -1,7 +1,7 @@
 # kernel trace of the pipelined headline bench -> tools/timeline.py summary (gpurun_out/r04/<tag>_timeline.txt)
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; T=${1:-tl}; O=$R/gpurun_out/r04; mkdir -p $O; rm -rf $O/trace_$T
-rocprofv3 --kernel-trace --output-format csv -d $O/trace_$T -- python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_$T -- python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 F=$(find $O/trace_$T -name "*kernel_trace.csv" | head -1)
 python $R/tools/timeline.py $F > $O/${T}_timeline.txt 2>&1
 cat $O/${T}_timeline.txt
