@@ -705,7 +705,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="search_fit: skip the short C4 (rdf) and C5 (membrane) legs attached to the line as `secondary`")
     ap.add_argument("--secondary", action="store_true", help="search_fit: run the secondary legs at N > 1 as well (default: N = 1 only)")
     ap.add_argument("--secondary-rdf-steps", type=int, default=512)
-    ap.add_argument("--secondary-membrane-steps", type=int, default=256)
+    ap.add_argument("--secondary-membrane-steps", type=int, default=512)
     ap.add_argument("--no-pairs-only", action="store_true", help="search_fit: skip the extra leg that times the resident search with the (i, j) plane only")
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 recomputes all ranks' frames alone and compares (rdf: the reduced bins; search_fit: every "

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Randomised differential test of the fused fit path (molar_hip_fit_rmsd_batch, molar_hip_fit_batch, fit_transform)
+"""Randomised differential test of the fused fit path (molar_hip_fit_rmsd_batch, molar_hip_fit_batch, fit_transform, molar_hip_fit_stream_*)
 against the f64 oracle: selection sizes 3..20000, far-from-origin clouds, near-identical frames (RMSD ~ 1e-4), planar and
 nearly collinear selections (for the collinear ones the rotation is not unique: only the RMSD after the fit, the
 centre and the gyration radius are compared), large rigid motions.  Usage: python tools/fuzz_fit.py [ncases] [seed]"""
@@ -59,6 +59,25 @@ def run(ncases=300, seed=1, eng=None):
             for f in range(nf):
                 o1 = eng.fit_rmsd_batch(fr[f:f + 1].copy(), mass, ref, idx=idx, apply=False)
                 ok = ok and all(np.array_equal(ob[k][f], o1[k][0]) for k in ("rmsd", "R", "t", "com", "gyration"))
+        if case % 3 == 0:              # the streamed form (host frames, selection packed by host threads): the batch entry's record and frame
+            nf = int(rng.integers(1, 6))
+            fr = np.stack([cur] + [(cur + rng.normal(0, 0.02, cur.shape)).astype(np.float32) for _ in range(nf - 1)])
+            apply = bool(rng.integers(0, 2))
+            wb = fr.copy()
+            per = [eng.fit_rmsd_batch(wb[f:f + 1], mass, ref, idx=idx, apply=apply) for f in range(nf)]
+            ws = fr.copy()
+            fs = api.FitStream(eng, natoms, mass, ref, idx=idx, host_threads=int(rng.integers(0, 4)))
+            got, pend = [], []
+            for f in range(nf):
+                pend.append(fs.begin(ws[f], apply=apply))
+                if len(pend) == 3:
+                    got.append(fs.end(pend.pop(0)))
+            while pend:
+                got.append(fs.end(pend.pop(0)))
+            fs.close()
+            for f in range(nf):
+                ok = ok and all(np.array_equal(got[f][k], per[f][k][0]) for k in ("rmsd", "R", "t", "com", "gyration"))
+            ok = ok and np.array_equal(ws, wb)
         if not ok:
             fails += 1
             print("MISMATCH", case, kind, natoms, m, out["rmsd"][0], w_rmsd, out["gyration"][0], w_gyr, np.abs(out["R"][0] - R).max())
