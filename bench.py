@@ -639,7 +639,8 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
 
 def secondary_legs(args, rank, local_rank, world, device, cdev):
     """BASELINE.json configs[3] and [4] beside the headline, on the same clock: `--workload rdf` (resident 250k-atom frames,
-    fused 1200-bin histogram) and `--workload membrane` (500k-atom bilayer, 4000 lipids) as short legs with --verify on
+    fused 1200-bin histogram), the same fed from a synthetic XTC file (`--source xtc`: configs[3] as stated) and `--workload
+    membrane` (500k-atom bilayer, 4000 lipids) as short legs with --verify on
     (rdf: the reduced bins against every frame recomputed alone; membrane: the accumulated sums against the stage-by-stage
     calls).  Returns {"rdf": line, "membrane": line, "seconds": ...}; an exception inside a leg is reported as {"error": ...}."""
     import copy
@@ -647,6 +648,9 @@ def secondary_legs(args, rank, local_rank, world, device, cdev):
     out = {}
     t0 = time.perf_counter()
     for name, fn, over in (("rdf", run_rdf, dict(workload="rdf", steps=args.secondary_rdf_steps, warmup=32, verify=True, profile_steps=64)),
+                           # C4 as BASELINE.json states it: XTC file -> decoder threads -> HBM windows -> fused histogram (frames form)
+                           ("rdf_xtc", run_rdf_xtc, dict(workload="rdf", source="xtc", steps=args.secondary_xtc_steps, warmup=32, verify=True,
+                                                         xtc_window=16, decoder="host", decode_threads=0, xtc_path="")),
                            ("membrane", run_membrane, dict(workload="membrane", steps=args.secondary_membrane_steps, warmup=8, verify=True,
                                                            preheat=min(args.preheat, 1.0), streams=4))):
         a2 = copy.copy(args)
@@ -706,6 +710,7 @@ def main():
     ap.add_argument("--secondary", action="store_true", help="search_fit: run the secondary legs at N > 1 as well (default: N = 1 only)")
     ap.add_argument("--secondary-rdf-steps", type=int, default=512)
     ap.add_argument("--secondary-membrane-steps", type=int, default=512)
+    ap.add_argument("--secondary-xtc-steps", type=int, default=256, help="frames of the XTC-fed C4 leg (a synthetic 250k-atom trajectory of that many + 32 frames is written to $TMPDIR: ~1 MB per frame)")
     ap.add_argument("--no-pairs-only", action="store_true", help="search_fit: skip the extra leg that times the resident search with the (i, j) plane only")
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 recomputes all ranks' frames alone and compares (rdf: the reduced bins; search_fit: every "

@@ -2757,7 +2757,7 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
 // Two generations of everything the side stream writes; the side stream starts on a generation when the launch two before has
 // ended (gen_free, the event the asynchronous single-frame calls use as well: the two forms may be mixed on a context).
 // Returns 1 when the group does not qualify (the caller then walks it frame by frame), 0 when enqueued.
-constexpr int HIST_BATCH = 16;
+constexpr int HIST_BATCH = MH_HIST_BATCH;
 static_assert(HIST_BATCH <= (int)(sizeof(((molar_hip_ctx *)nullptr)->hb_sets[0]) / sizeof(mh::GridSet)), "hb_sets holds a group");
 
 static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, size_t first, int W, size_t stride1, const float *boxes9, float hmin,
