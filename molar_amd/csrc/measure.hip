@@ -674,24 +674,28 @@ __device__ __forceinline__ float f3angle(F3 a, F3 b) {
     return acosf(c);
 }
 
-// One thread per tail: the reference's loop writes order[i-1] and order[i] from a double bond at i, so
-// bonds are walked sequentially to keep its last-writer-wins behaviour for any bond pattern.
-__global__ void __launch_bounds__(64) k_lipid_order(const float *__restrict__ xyz, const uint64_t *__restrict__ idx,
-                                                    const uint64_t *__restrict__ toff, uint32_t ntails, int order_type,
-                                                    const float *__restrict__ normals, const uint64_t *__restrict__ noff,
-                                                    const uint8_t *__restrict__ bonds, float *__restrict__ out,
-                                                    int *__restrict__ status) {
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+// Sixteen lanes per tail, one output per lane and round.  The reference's loop (measure.rs:330-420) walks the bonds in
+// order and a double bond at i writes order[i-1] and order[i], so for any bond pattern output k ends up with the value of
+// its LAST writer: the double bond at k+1 (its first half) if there is one, else the single-single pair at k or the second
+// half of a double bond at k, else 0.  Each lane evaluates only that writer, with the reference's f32 expressions; every
+// bond 0..n-3 is checked for a legal position by the lane of the same number.
+constexpr uint32_t ORDER_G = 16;
+__global__ void __launch_bounds__(256) k_lipid_order(const float *__restrict__ xyz, const uint64_t *__restrict__ idx,
+                                                     const uint64_t *__restrict__ toff, uint32_t ntails, int order_type,
+                                                     const float *__restrict__ normals, const uint64_t *__restrict__ noff,
+                                                     const uint8_t *__restrict__ bonds, float *__restrict__ out,
+                                                     int *__restrict__ status) {
+    const uint32_t t = blockIdx.x * (256u / ORDER_G) + threadIdx.x / ORDER_G, sub = threadIdx.x % ORDER_G;
     if (t >= ntails) return;
-    const uint64_t a0 = toff[t];
+    const uint64_t a0 = toff[t], n0 = noff[t];
     const uint32_t n = (uint32_t)(toff[t + 1] - a0);
-    const uint32_t nn = (uint32_t)(noff[t + 1] - noff[t]);
+    const uint32_t nn = (uint32_t)(noff[t + 1] - n0);
     if (n < 3) {
-        atomicMax(status, MOLAR_HIP_ERR_LIPID_TAIL_TOO_SHORT);
+        if (sub == 0) atomicMax(status, MOLAR_HIP_ERR_LIPID_TAIL_TOO_SHORT);
         return;
     }
     if (nn != 1 && nn != n - 2) {
-        atomicMax(status, MOLAR_HIP_ERR_LIPID_NORMALS_COUNT);
+        if (sub == 0) atomicMax(status, MOLAR_HIP_ERR_LIPID_NORMALS_COUNT);
         return;
     }
     const uint8_t *bo = bonds + (a0 - t);
@@ -701,60 +705,57 @@ __global__ void __launch_bounds__(64) k_lipid_order(const float *__restrict__ xy
         return F3{q[0], q[1], q[2]};
     };
     auto N = [&](uint32_t k) {
-        const float *q = normals + 3 * (noff[t] + (nn == 1 ? 0 : k));
+        const float *q = normals + 3 * (n0 + (nn == 1 ? 0 : k));
         return F3{q[0], q[1], q[2]};
     };
-    for (uint32_t k = 0; k < n - 2; ++k) order[k] = 0.0f;
-    if (order_type == 0) {
-        for (uint32_t at = 1; at + 1 < n; ++at) {
-            const float c = cosf(f3angle(f3sub(P(at + 1), P(at - 1)), N(at - 1)));
-            order[at - 1] = 1.5f * (c * c) - 0.5f;
-        }
-        return;
-    }
     const float sqrt3 = __builtin_sqrtf(3.0f), pi = 3.14159265358979323846f;
-    for (uint32_t i = 0; i + 2 < n; ++i) {
-        if (bo[i] == 1) {
-            if (bo[i + 1] == 1) {
-                const F3 p1 = P(i), p2 = P(i + 1), p3 = P(i + 2);
+    for (uint32_t k = sub; k < n - 2; k += ORDER_G) {
+        if (order_type == 0) {
+            const float c = cosf(f3angle(f3sub(P(k + 2), P(k)), N(k)));
+            order[k] = 1.5f * (c * c) - 0.5f;
+            continue;
+        }
+        const bool dbl_here = bo[k] != 1, dbl_next = bo[k + 1] != 1;
+        // a double bond at bond 0 has no C(i-1); at the last bond it has no normal for atom i+1 when normals are per
+        // bond.  The reference indexes out of range there (usize underflow panic / unchecked read,
+        // measure.rs:361-364,385): refuse the tail instead of touching memory outside it.
+        const bool bad_here = dbl_here && (k == 0 || (nn != 1 && k + 1 >= nn));
+        if (bad_here) atomicMax(status, MOLAR_HIP_ERR_INVALID_ARGUMENT);
+        const bool from_next = dbl_next && k + 1 < n - 2;                 // bond n-2 is never visited by the reference's loop
+        float v = 0.0f;
+        if (!from_next && !dbl_here) {
+            if (!dbl_next) {
+                const F3 p1 = P(k), p2 = P(k + 1), p3 = P(k + 2);
                 const F3 lz = f3unit(f3sub(p3, p1));
                 const F3 lx = f3unit(f3cross(f3sub(p1, p2), f3sub(p3, p2)));
                 const F3 ly = f3cross(lx, lz);
-                const F3 nv = N(i);
+                const F3 nv = N(k);
                 const float cx = cosf(f3angle(lx, nv)), cy = cosf(f3angle(ly, nv));
                 const float sxx = 0.5f * (3.0f * (cx * cx) - 1.0f), syy = 0.5f * (3.0f * (cy * cy) - 1.0f);
-                order[i] = -(2.0f * sxx + syy) / 3.0f;
+                v = -(2.0f * sxx + syy) / 3.0f;
             }
-        } else {
-            // a double bond at bond 0 has no C(i-1); at the last bond it has no normal for atom i+1 when normals are
-            // per bond.  The reference indexes out of range there (usize underflow panic / unchecked read,
-            // measure.rs:361-364,385): refuse the tail instead of touching memory outside it.
-            if (i == 0 || (nn != 1 && i + 1 >= nn)) {
-                atomicMax(status, MOLAR_HIP_ERR_INVALID_ARGUMENT);
-                return;
-            }
+        } else if (from_next || !bad_here) {
+            const int side = from_next ? 0 : 1;                            // which half of the double bond at i lands on k
+            const uint32_t i = from_next ? k + 1 : k;
             const F3 p1 = P(i - 1), p2 = P(i), p3 = P(i + 1), p4 = P(i + 2);
-            const float a1 = 0.5f * (pi - f3angle(f3sub(p1, p2), f3sub(p3, p2)));
-            const float a2 = 0.5f * (pi - f3angle(f3sub(p2, p3), f3sub(p4, p3)));
+            const float a = side == 0 ? 0.5f * (pi - f3angle(f3sub(p1, p2), f3sub(p3, p2)))
+                                      : 0.5f * (pi - f3angle(f3sub(p2, p3), f3sub(p4, p3)));
             const F3 lz = f3unit(f3sub(p3, p2));
-            for (int side = 0; side < 2; ++side) {
-                const F3 lx = f3unit(f3cross(side == 0 ? f3sub(p1, p2) : f3sub(p3, p4), lz));
-                const F3 ly = f3cross(lx, lz);
-                const F3 nv = N(side == 0 ? i : i + 1);
-                const float cy = cosf(f3angle(ly, nv)), cz = cosf(f3angle(lz, nv));
-                const float szz = 0.5f * (3.0f * (cz * cz) - 1.0f), syy = 0.5f * (3.0f * (cy * cy) - 1.0f);
-                const float syz = 1.5f * cy * cz;
-                const float a = side == 0 ? a1 : a2, sgn = side == 0 ? -1.0f : 1.0f;
-                float v;
-                if (order_type == 2) {
-                    const float ca = cosf(a), sa = sinf(a);
-                    v = -(((ca * ca) * syy + (sa * sa) * szz) + sgn * (2.0f * ca * sa * syz));
-                } else {
-                    v = -((szz / 4.0f + 3.0f * syy / 4.0f) + sgn * (sqrt3 * syz / 2.0f));
-                }
-                order[side == 0 ? i - 1 : i] = v;
+            const F3 lx = f3unit(f3cross(side == 0 ? f3sub(p1, p2) : f3sub(p3, p4), lz));
+            const F3 ly = f3cross(lx, lz);
+            const F3 nv = N(side == 0 ? i : i + 1);
+            const float cy = cosf(f3angle(ly, nv)), cz = cosf(f3angle(lz, nv));
+            const float szz = 0.5f * (3.0f * (cz * cz) - 1.0f), syy = 0.5f * (3.0f * (cy * cy) - 1.0f);
+            const float syz = 1.5f * cy * cz;
+            const float sgn = side == 0 ? -1.0f : 1.0f;
+            if (order_type == 2) {
+                const float ca = cosf(a), sa = sinf(a);
+                v = -(((ca * ca) * syy + (sa * sa) * szz) + sgn * (2.0f * ca * sa * syz));
+            } else {
+                v = -((szz / 4.0f + 3.0f * syy / 4.0f) + sgn * (sqrt3 * syz / 2.0f));
             }
         }
+        order[k] = v;
     }
 }
 
@@ -941,7 +942,7 @@ int enqueue_lipid_order(molar_hip_ctx *c, const float *xyz, const uint64_t *idx,
                         int order_type, const float *normals, const uint64_t *noff, const uint8_t *bonds, float *out,
                         int *status) {
     if (ntails == 0) return 0;
-    hipLaunchKernelGGL(k_lipid_order, dim3((ntails + 63u) / 64u), dim3(64), 0, c->stream, xyz, idx, toff, ntails, order_type,
+    hipLaunchKernelGGL(k_lipid_order, dim3((ntails + 15u) / 16u), dim3(256), 0, c->stream, xyz, idx, toff, ntails, order_type,
                        normals, noff, bonds, out, status);
     MH_HIP(hipGetLastError());
     return 0;

@@ -655,21 +655,43 @@ int launch_fit(molar_hip_ctx *c, const SmoothDev &A0) {
 }
 
 // lib.rs:781-809.  `fitted_head` holds the markers after k_membrane_fit; the average is written to `head`.
+// Sixteen lanes per lipid: a round gathers sixteen images of the marker at once (owner's flag, entry, point - three dependent
+// loads that one lane would walk one after the other), then the group adds them in the order of the reference's scatter
+// loop from shuffles, every lane holding the same sum.  Rounds are counted per wave, so the shuffles run with all lanes on.
+constexpr uint32_t AVG_G = 16;
 __global__ __launch_bounds__(64) void k_membrane_average(SmoothDev A, const float *fitted_head) {
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= A.K || !A.valid[i]) return;
+    const uint32_t i = blockIdx.x * (64u / AVG_G) + threadIdx.x / AVG_G, sub = threadIdx.x % AVG_G;
+    const bool live = i < A.K && A.valid[i];
+    const uint32_t r0 = live ? A.rev_off[i] : 0u, r1 = live ? A.rev_off[i + 1] : 0u;
+    uint32_t rounds = (r1 - r0 + AVG_G - 1u) / AVG_G;
+    rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, 16));
+    rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, 32));
     float n = 1.0f;
-    V3 s = v3(fitted_head[3 * i], fitted_head[3 * i + 1], fitted_head[3 * i + 2]);
-    for (uint32_t r = A.rev_off[i]; r < A.rev_off[i + 1]; ++r) {
-        if (!A.valid[A.rev_owner[r]]) continue;
-        const float *p = A.fitted + 3ull * A.rev_entry[r];
-        n += 1.0f;
-        s = s + v3(p[0], p[1], p[2]);
+    V3 s = live ? v3(fitted_head[3 * i], fitted_head[3 * i + 1], fitted_head[3 * i + 2]) : v3(0.0f, 0.0f, 0.0f);
+    for (uint32_t q = 0; q < rounds; ++q) {
+        const uint32_t r = r0 + q * AVG_G + sub;
+        bool ok = false;
+        float px = 0.0f, py = 0.0f, pz = 0.0f;
+        if (r < r1 && A.valid[A.rev_owner[r]]) {
+            const float *p = A.fitted + 3ull * A.rev_entry[r];
+            ok = true; px = p[0]; py = p[1]; pz = p[2];
+        }
+        const uint32_t okmask = (uint32_t)(__ballot(ok) >> (threadIdx.x / AVG_G * AVG_G)) & 0xffffu;
+#pragma unroll
+        for (uint32_t j = 0; j < AVG_G; ++j) {
+            const float x = __shfl(px, (int)j, (int)AVG_G), y = __shfl(py, (int)j, (int)AVG_G), z = __shfl(pz, (int)j, (int)AVG_G);
+            const bool take = (okmask >> j) & 1u;
+            const V3 t = s + v3(x, y, z);
+            n = take ? n + 1.0f : n;
+            s.x = take ? t.x : s.x; s.y = take ? t.y : s.y; s.z = take ? t.z : s.z;
+        }
     }
+    if (!live) return;
     const V3 h = v3(s.x / n, s.y / n, s.z / n);
-    A.head[3 * i] = h.x; A.head[3 * i + 1] = h.y; A.head[3 * i + 2] = h.z;
+    if (sub == 0) { A.head[3 * i] = h.x; A.head[3 * i + 1] = h.y; A.head[3 * i + 2] = h.z; }
     const uint64_t slot = A.poff[i] + 4ull * i;
-    for (uint32_t k = 0; k < A.nvert[i]; ++k) {
+    const uint32_t nv = A.nvert[i];
+    for (uint32_t k = sub; k < nv; k += AVG_G) {
         float *v = A.voro + 3 * (slot + k);
         v[0] += h.x; v[1] += h.y; v[2] += h.z;
     }
@@ -766,10 +788,9 @@ extern "C" int molar_hip_membrane_smooth(molar_hip_ctx *c, const molar_hip_membr
         A.fitted = (float *)(d + o_fitted); A.vwork = (float4 *)(d + o_vwork); A.pwork = (float4 *)(d + o_pwork);
         A.rev_off = (const uint32_t *)(d + o_roff); A.rev_entry = (const uint32_t *)(d + o_rent);
         A.rev_owner = (const uint32_t *)(d + o_rown);
-        const uint32_t nb = (uint32_t)((K + 63) / 64);
         MH_TRY(launch_fit(c, A));
         MH_HIP(hipMemcpyAsync(d + o_fh, d + o_head, K * 12, hipMemcpyDeviceToDevice, c->stream));
-        hipLaunchKernelGGL(k_membrane_average, dim3(nb), dim3(64), 0, c->stream, A, (const float *)(d + o_fh));
+        hipLaunchKernelGGL(k_membrane_average, dim3((uint32_t)((K + 3) / 4)), dim3(64), 0, c->stream, A, (const float *)(d + o_fh));
         MH_HIP(hipGetLastError());
         MH_HIP(hipMemcpyAsync(h, d, io_bytes, hipMemcpyDeviceToHost, c->stream));
     }
@@ -933,8 +954,13 @@ __global__ __launch_bounds__(256) void k_split_markers(uint32_t K, const float *
 // (mask_units / mask_cap: a search whose hit history did not fit has left the results of its wrapped entries unwritten - stale
 // pairs of whatever search used the buffer before, possibly of a larger system: ids beyond this one's arrays.  The list then
 // counts as not there, like one that outgrew its buffer; the host grows the history and repeats the stage.)
-__global__ void k_patch_begin(const unsigned long long *__restrict__ total, unsigned long long cap_pairs, unsigned long long cap_entries,
-                              const unsigned long long *__restrict__ mask_units, unsigned long long mask_cap, FrameInfo *__restrict__ info) {
+__global__ __launch_bounds__(256) void k_patch_begin(const unsigned long long *__restrict__ total, unsigned long long cap_pairs,
+                                                     unsigned long long cap_entries, const unsigned long long *__restrict__ mask_units,
+                                                     unsigned long long mask_cap, FrameInfo *__restrict__ info,
+                                                     uint32_t *__restrict__ deg, uint32_t ndeg) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < ndeg) deg[i] = 0u;                       // degrees and cursors of the patch build start from zero
+    if (i != 0) return;
     const unsigned long long t = total ? *total : 0ull;
     const bool over = t > cap_pairs || 2ull * t > cap_entries || (mask_units && *mask_units > mask_cap);
     info->npairs = over ? 0ull : t;
@@ -1148,8 +1174,8 @@ void normals_pass2_host(size_t K, const uint32_t *poff, const uint32_t *pids, co
 // fresh per-lipid state of a frame: the LipidMolecule defaults of Membrane::new (lib.rs:152-177; the rest is zeroed by a
 // memset), the working copy of the head markers and the initial normals
 __global__ __launch_bounds__(256) void k_state_defaults(uint32_t K, float *__restrict__ mean, float *__restrict__ gauss,
-                                                        const float *__restrict__ head, const float *__restrict__ n0,
-                                                        float *__restrict__ s_head, float *__restrict__ s_normals) {
+                                                        const float *__restrict__ head, const float *__restrict__ n0_host,
+                                                        float *__restrict__ n0, float *__restrict__ s_head, float *__restrict__ s_normals) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= K) return;
     mean[i] = -100.0f;
@@ -1157,7 +1183,9 @@ __global__ __launch_bounds__(256) void k_state_defaults(uint32_t K, float *__res
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         s_head[3 * i + d] = head[3 * i + d];
-        s_normals[3 * i + d] = n0[3 * i + d];
+        const float v = n0_host[3 * i + d];          // the host pass's normals, read from its pinned block (no copy ahead)
+        n0[3 * i + d] = v;
+        s_normals[3 * i + d] = v;
     }
 }
 
@@ -1404,9 +1432,9 @@ int enqueue_b(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
     S.cap_pairs = S.L.cap0;
     const size_t Ecap = S.Ecap;
     uint32_t *deg = P->work.as<uint32_t>(), *cursor = deg + (K + 1), *t_ord = cursor + K, *t_oth = t_ord + Ecap, *t_grp = t_oth + Ecap;
-    MH_HIP(hipMemsetAsync(deg, 0, ((K + 1) + K) * 4, st));
-    hipLaunchKernelGGL(k_patch_begin, dim3(1), dim3(1), 0, st, total_dev, S.cap_pairs, (unsigned long long)Ecap, S.L.mask_units_dev,
-                       S.L.maskcap0, info);
+    const uint32_t ndeg = (uint32_t)((K + 1) + K);
+    hipLaunchKernelGGL(k_patch_begin, dim3((ndeg + 255u) / 256u), dim3(256), 0, st, total_dev, S.cap_pairs, (unsigned long long)Ecap,
+                       S.L.mask_units_dev, S.L.maskcap0, info, deg, ndeg);
     uint64_t *poff = (uint64_t *)(d + L.poff), *pids = (uint64_t *)(d + L.pids);
     uint32_t *roff = (uint32_t *)(d + L.roff), *pids32 = (uint32_t *)(d + L.pids32), *owner = (uint32_t *)(d + L.owner),
              *rev_entry = (uint32_t *)(d + L.rev_entry), *rev_owner = (uint32_t *)(d + L.rev_owner);
@@ -1428,6 +1456,8 @@ int enqueue_b(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
     // ---- to the host, in one copy: status, offsets, first-pass normals, flags, ids
     MH_HIP(hipMemcpyAsync((char *)S.h_mid + L.info, d + L.info, L.pids32 - L.info + std::min(Ecap, 2 * pair_room) * 4, hipMemcpyDeviceToHost, st));
     MH_HIP(hipEventRecord(S.mid, st));
+    // the smoothing's per-lipid state starts from zero: cleared here, while the host makes its pass over the normals
+    MH_HIP(hipMemsetAsync(d + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
     S.b_enqueued = true;
     S.passed = false;
     return 0;
@@ -1474,12 +1504,11 @@ int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
     uint8_t *valid = P->valid.as<uint8_t>();
     FrameInfo *info = reinterpret_cast<FrameInfo *>(d + L.info);
     float *n0 = (float *)(d + L.normals0);
-    MH_HIP(hipMemcpyAsync(n0, (char *)S.h_mid + mid_n2(L, S.Ecap), K * 12, hipMemcpyHostToDevice, st));
     const uint32_t nbK = (K32 + 255u) / 256u;
-    // ---- smooth (lib.rs:661-812)
-    MH_HIP(hipMemsetAsync(d + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
+    // ---- smooth (lib.rs:661-812); the per-lipid state was zeroed at the end of B
     hipLaunchKernelGGL(k_state_defaults, dim3(nbK), dim3(256), 0, st, K32, (float *)(d + L.mean), (float *)(d + L.gauss),
-                       (const float *)(d + L.head), (const float *)n0, (float *)(d + L.s_head), (float *)(d + L.s_normals));
+                       (const float *)(d + L.head), (const float *)((char *)S.h_mid + mid_n2(L, S.Ecap)), n0, (float *)(d + L.s_head),
+                       (float *)(d + L.s_normals));
     SmoothDev A;
     A.K = K32;
     MH_TRY(molar_hip_box_from_matrix(S.box9, &A.box));
@@ -1491,7 +1520,6 @@ int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
     A.fitted = (float *)(d + L.fitted); A.vwork = (float4 *)(d + L.vwork); A.pwork = (float4 *)(d + L.pwork);
     A.rev_off = (const uint32_t *)(d + L.roff); A.rev_entry = (const uint32_t *)(d + L.rev_entry);
     A.rev_owner = (const uint32_t *)(d + L.rev_owner);
-    const uint32_t nbF = (K32 + 63u) / 64u;
     for (int it = 0; it < P->max_iter; ++it) {
         // the markers before the iteration: the frame's own for the first one (the working copy starts as their image)
         if (it == 0) A.saved = (const float *)(d + L.head);
@@ -1501,7 +1529,7 @@ int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
         }
         MH_TRY(launch_fit(c, A));
         // (a lane of the averaging kernel reads the fitted marker of its own lipid only, before it overwrites it)
-        hipLaunchKernelGGL(k_membrane_average, dim3(nbF), dim3(64), 0, st, A, (const float *)A.head);
+        hipLaunchKernelGGL(k_membrane_average, dim3((uint32_t)((K + 3) / 4)), dim3(64), 0, st, A, (const float *)A.head);
     }
     hipLaunchKernelGGL(k_valid_out, dim3(nbK), dim3(256), 0, st, K32, (const uint8_t *)(d + L.valid_prev), valid, (uint8_t *)(d + L.valid_out),
                        &info->changed);
@@ -1736,6 +1764,31 @@ extern "C" int molar_hip_membrane_frame_end(molar_hip_membrane_plan *P, int32_t 
     return MOLAR_HIP_OK;
 }
 
+namespace {
+// Arrays of a finished frame stored into the pinned block of the fetch, all in one launch.  Sources and places in the block
+// are 16-byte aligned (Blob2 / the 64-byte steps of `want`); a tail of fewer than 16 bytes goes by bytes.
+constexpr uint32_t FETCH_PACK_MAX = 20;
+struct FetchPack {
+    const char *src[FETCH_PACK_MAX];
+    size_t at[FETCH_PACK_MAX], bytes[FETCH_PACK_MAX];
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void k_fetch_pack(FetchPack Q, char *__restrict__ dst) {
+    const size_t tid = (size_t)blockIdx.x * 256u + threadIdx.x, nth = (size_t)gridDim.x * 256u;
+    for (uint32_t k = 0; k < Q.n; ++k) {
+        const char *s = Q.src[k];
+        char *d = dst + Q.at[k];
+        const size_t words = Q.bytes[k] / 16u;
+        if (((uintptr_t)s & 15u) == 0) {
+            for (size_t w = tid; w < words; w += nth) reinterpret_cast<uint4 *>(d)[w] = reinterpret_cast<const uint4 *>(s)[w];
+            for (size_t b = words * 16u + tid; b < Q.bytes[k]; b += nth) d[b] = s[b];
+        } else {
+            for (size_t b = tid; b < Q.bytes[k]; b += nth) d[b] = s[b];
+        }
+    }
+}
+}  // namespace
+
 extern "C" int molar_hip_membrane_frame_fetch(molar_hip_membrane_plan *P, int32_t ticket, const molar_hip_membrane_out *O) {
     MH_TRY(check_ticket(P, ticket, /*want_ended=*/true));
     if (!O) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_fetch: null argument");
@@ -1771,7 +1824,21 @@ extern "C" int molar_hip_membrane_frame_fetch(molar_hip_membrane_plan *P, int32_
         MH_HIP(hipHostMalloc(&P->h_fetch, total + total / 4, hipHostMallocDefault));
         P->h_fetch_cap = total + total / 4;
     }
-    for (const Item &it : items) MH_HIP(hipMemcpyAsync((char *)P->h_fetch + it.at, it.src, it.bytes, hipMemcpyDeviceToHost, cs));
+    // one kernel stores the arrays into the pinned block (a device-to-host copy is a launch of its own here, twenty of them
+    // cost more than the bytes); an array too large for that share goes by a copy
+    FetchPack pack{};
+    for (const Item &it : items) {
+        if (it.bytes <= (4u << 20) && pack.n < FETCH_PACK_MAX) {
+            pack.src[pack.n] = (const char *)it.src; pack.at[pack.n] = it.at; pack.bytes[pack.n] = it.bytes;
+            ++pack.n;
+        } else {
+            MH_HIP(hipMemcpyAsync((char *)P->h_fetch + it.at, it.src, it.bytes, hipMemcpyDeviceToHost, cs));
+        }
+    }
+    if (pack.n) {
+        hipLaunchKernelGGL(k_fetch_pack, dim3(64), dim3(256), 0, cs, pack, (char *)P->h_fetch);
+        MH_HIP(hipGetLastError());
+    }
     MH_HIP(hipStreamSynchronize(cs));
     for (const Item &it : items) std::memcpy(it.dst, (const char *)P->h_fetch + it.at, it.bytes);
     return MOLAR_HIP_OK;
