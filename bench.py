@@ -485,8 +485,8 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
     """BASELINE.json configs[4] shape: each rank owns K frames of the 500k-atom bilayer (4000 lipids, resident in HBM).  A
     frame is one chained call (molar_hip_membrane_frame_*: unwrap, markers, patches with rc 2.5 nm, initial normals, one
     smoothing pass, Scd of the 8000 tails), two frames in flight; the per-lipid results (flags, normals, curvatures, areas,
-    vertex counts, order parameters) come to the host every frame and are accumulated there like LipidGroup::frame_update
-    does; ONE all_reduce of the accumulated sums combines the ranks at the end."""
+    vertex counts, order parameters) come to the host with the end of every frame (molar_hip_membrane_frame_end_fetch) and are
+    accumulated there like LipidGroup::frame_update does, while the GPU runs the next frame; ONE all_reduce of the accumulated sums combines the ranks at the end."""
     import torch
     import torch.distributed as dist
     from molar_amd import api, build
@@ -516,8 +516,7 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
         ids = list(range(offset, count, stride))
         rows = np.zeros((len(ids), 4 + norder), np.float64)   # valid lipid-frames, vertices, area, |mean curvature|, order per carbon
 
-        def take(t, k):
-            r = plan.fetch(t, small)
+        def sums(r, k):
             ok = r["valid"].astype(bool)
             rows[k, 0] = int(ok.sum())
             rows[k, 1] = int(r["nvert"][ok].sum())
@@ -528,16 +527,37 @@ def run_membrane(args, rank, local_rank, world, device, cdev):
         bufs = [frames_dev[(first_frame + s) % len(frames_dev)].clone() for s in ids]     # unwrapped in place: fresh copies
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        prev = None
-        for k in range(len(ids)):
-            t = plan.begin(bufs[k], pbox)
+        prev = None          # (ticket, row) of the frame in flight
+        if os.environ.get("BENCH_C5_SUMS", "thread" if S == 1 else "defer") == "thread":
+            # one context: the host sums of a frame run on a thread of their own (numpy releases the interpreter lock inside them),
+            # beside the calls that feed the GPU.  Several contexts (a feeding thread each already): the sums wait until the next
+            # frame has been begun - more threads only fight for the interpreter (measured: 3.7 k against 5.3 k frames/s on four)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=1) as acc:
+                jobs = []
+                for k in range(len(ids)):
+                    t = plan.begin(bufs[k], pbox)
+                    if prev is not None:
+                        jobs.append(acc.submit(sums, plan.end(prev[0], small)[1], prev[1]))   # the arrays come with the end: one wait
+                    prev = (t, k)
+                if prev is not None:
+                    jobs.append(acc.submit(sums, plan.end(prev[0], small)[1], prev[1]))
+                for j in jobs:
+                    j.result()
+        else:
+            got = None           # (arrays, row) of the frame that ended last: summed while the GPU runs the next frame
+            for k in range(len(ids)):
+                t = plan.begin(bufs[k], pbox)
+                if got is not None:
+                    sums(*got)
+                    got = None
+                if prev is not None:
+                    got = (plan.end(prev[0], small)[1], prev[1])
+                prev = (t, k)
+            if got is not None:
+                sums(*got)
             if prev is not None:
-                plan.end(prev[0])
-                take(*prev)
-            prev = (t, k)
-        if prev is not None:
-            plan.end(prev[0])
-            take(*prev)
+                sums(plan.end(prev[0], small)[1], prev[1])
         eng.synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0

@@ -565,6 +565,12 @@ int molar_hip_membrane_frame_begin(molar_hip_membrane_plan *plan, float *xyz, co
 int molar_hip_membrane_frame_end(molar_hip_membrane_plan *plan, int32_t ticket, molar_hip_membrane_view *view);
 /* Copies the chosen arrays of an ended frame to host memory. */
 int molar_hip_membrane_frame_fetch(molar_hip_membrane_plan *plan, int32_t ticket, const molar_hip_membrane_out *out);
+/* _frame_end and the fetch of per-lipid results in one wait: the chosen arrays leave on the frame's stream right behind its last
+ * kernel (what LipidGroup::frame_update reads every frame, molar_membrane/src/lipid_group.rs: flags, normals, curvatures, areas,
+ * vertex counts, order).  The arrays sized by the frame's patch entries (patch_ids, neib_ids, voro_vertexes,
+ * fitted_patch_points) must be NULL here - their length is only known from the view; _frame_fetch brings them afterwards. */
+int molar_hip_membrane_frame_end_fetch(molar_hip_membrane_plan *plan, int32_t ticket, molar_hip_membrane_view *view,
+                                       const molar_hip_membrane_out *out);
 
 /* Measure::lipid_tail_order (measure.rs:270-422), batched over `ntails` tails given as CSR:
  * tail t holds the carbons idx[tail_offsets[t] .. tail_offsets[t+1]) (n_t atoms), its normals are

@@ -741,6 +741,25 @@ class MembraneFrames {
         check(molar_hip_membrane_frame_end(plan_, ticket_, &v));
         return v;
     }
+    // finish() with the per-lipid arrays of that frame brought to the host in the same wait (molar_hip_membrane_frame_end_fetch:
+    // no patch-sized arrays here)
+    std::optional<molar_hip_membrane_view> finish(const molar_hip_membrane_out &out) {
+        if (!pending_) return std::nullopt;
+        pending_ = false;
+        molar_hip_membrane_view v{};
+        last_ = ticket_;
+        check(molar_hip_membrane_frame_end_fetch(plan_, ticket_, &v, &out));
+        return v;
+    }
+    // push() whose handed-back frame comes with its per-lipid arrays, like finish(out)
+    std::optional<molar_hip_membrane_view> push(float *xyz, const PeriodicBox &pbox, const molar_hip_membrane_out &out) {
+        int32_t t = -1;
+        check(molar_hip_membrane_frame_begin(plan_, xyz, pbox.colmajor9(), &t));
+        std::optional<molar_hip_membrane_view> v = finish(out);
+        ticket_ = t;
+        pending_ = true;
+        return v;
+    }
     // arrays of the frame handed back last (null members of `out` are skipped)
     void fetch(const molar_hip_membrane_out &out) { check(molar_hip_membrane_frame_fetch(plan_, last_, &out)); }
 

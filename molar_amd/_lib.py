@@ -173,6 +173,7 @@ SYMBOLS = {
     "molar_hip_membrane_frame_begin": (_I, [_P, _P, _P, _P]),
     "molar_hip_membrane_frame_end": (_I, [_P, _I, _P]),
     "molar_hip_membrane_frame_fetch": (_I, [_P, _I, _P]),
+    "molar_hip_membrane_frame_end_fetch": (_I, [_P, _I, _P, _P]),
     "molar_hip_xtc_open": (_P, [C.c_char_p]),
     "molar_hip_xtc_open_memory": (_P, [_P, _SZ]),
     "molar_hip_xtc_close": (None, [_P]),

@@ -1193,26 +1193,40 @@ class MembranePlan:
         self._keep[t.value] = kx
         return t.value
 
-    def end(self, ticket):
-        """Wait for the frame; returns its MembraneView (device addresses, sizes)."""
+    _PATCH_SIZED = ("patch_ids", "neib_ids", "voro_vertexes", "fitted_patch_points")
+
+    def end(self, ticket, names=None):
+        """Wait for the frame; returns its MembraneView (device addresses, sizes) - or, with `names` (per-lipid arrays and
+        "order"), the pair (view, dict of numpy arrays): the arrays leave behind the frame's last kernel, one wait for both
+        (molar_hip_membrane_frame_end_fetch)."""
         v = MembraneView()
-        rc = self.lib.molar_hip_membrane_frame_end(self.handle, int(ticket), C.byref(v))
+        out = None
+        if names is None:
+            rc = self.lib.molar_hip_membrane_frame_end(self.handle, int(ticket), C.byref(v))
+        else:
+            if any(k in self._PATCH_SIZED for k in names):
+                raise ValueError("end(names=...): per-lipid arrays and order only; fetch() brings the patch-sized arrays")
+            out, o = self._arrays(names, self.K, 0)
+            rc = self.lib.molar_hip_membrane_frame_end_fetch(self.handle, int(ticket), C.byref(v), C.byref(o))
         if rc == 0 or int(ticket) not in (0, 1) or v.nlipids:      # the frame is over (even if one of its stages failed)
             self._keep.pop(int(ticket), None)
         check(rc)
         self._views[int(ticket)] = v
-        return v
+        return v if names is None else (v, out)
+
+    def _arrays(self, names, K, E):
+        out, o = {}, MembraneOut()
+        for k in names:
+            dt, shp = self._SHAPES[k]
+            a = np.empty(shp(K, E, E + 4 * K, self.norder), dt)         # (every element is written by the fetch)
+            out[k] = a
+            setattr(o, k, a.ctypes.data if a.size else None)
+        return out, o
 
     def fetch(self, ticket, names=MEMBRANE_ARRAYS):
         """The named arrays of an ended frame as numpy arrays."""
         v = self._views[int(ticket)]
-        K, E = self.K, int(v.patch_entries)
-        out, o = {}, MembraneOut()
-        for k in names:
-            dt, shp = self._SHAPES[k]
-            a = np.zeros(shp(K, E, E + 4 * K, self.norder), dt)
-            out[k] = a
-            setattr(o, k, a.ctypes.data if a.size else None)
+        out, o = self._arrays(names, self.K, int(v.patch_entries))
         check(self.lib.molar_hip_membrane_frame_fetch(self.handle, int(ticket), C.byref(o)))
         return out
 

@@ -1739,34 +1739,9 @@ static void fill_view(molar_hip_membrane_plan *P, const molar_hip_membrane_plan:
     V->order = (const float *)(d + L.order); V->norder = P->norder;
 }
 
-extern "C" int molar_hip_membrane_frame_end(molar_hip_membrane_plan *P, int32_t ticket, molar_hip_membrane_view *view) {
-    MH_TRY(check_ticket(P, ticket, /*want_ended=*/false));
-    MH_HIP(hipSetDevice(P->c->device));
-    auto &S = P->slot[ticket];
-    // frames end in begin order: the older one first
-    auto &O = P->slot[ticket ^ 1];
-    if (O.pending && O.serial < S.serial) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_end: end the older frame (ticket %d) first", ticket ^ 1);
-    if (!S.b_enqueued) MH_TRY(enqueue_b(P, S, /*restore=*/false));     // (only after an error left the chain short)
-    if (!S.passed) MH_TRY(host_pass(P, S, /*may_repeat=*/true));
-    MH_TRY(enqueue_c(P, S));
-    // while the GPU smooths this frame: the host pass of the younger one, whose B is already through (it sits ahead of
-    // this C on the stream)
-    if (O.pending && O.b_enqueued && !O.passed) MH_TRY(host_pass(P, O, /*may_repeat=*/false));
-    MH_HIP(hipEventSynchronize(S.done));
-    std::memcpy(&S.info, (char *)S.h + H_INFO, sizeof(FrameInfo));
-    if (O.pending && (!O.b_enqueued || (O.speculative && S.info.changed))) MH_TRY(enqueue_b(P, O, /*restore=*/false));
-    O.speculative = false;
-    S.pending = false;
-    S.ended = true;
-    if (view) fill_view(P, S, view);
-    if (S.info.st_center) return fail(S.info.st_center, "membrane frame: a marker selection has zero mass");
-    if (S.info.st_order) return fail(S.info.st_order, "membrane frame: lipid order error (status %d)", S.info.st_order);
-    return MOLAR_HIP_OK;
-}
-
 namespace {
 // Arrays of a finished frame stored into the pinned block of the fetch, all in one launch.  Sources and places in the block
-// are 16-byte aligned (Blob2 / the 64-byte steps of `want`); a tail of fewer than 16 bytes goes by bytes.
+// are 16-byte aligned (Blob2 / the 64-byte steps of the items); a tail of fewer than 16 bytes goes by bytes.
 constexpr uint32_t FETCH_PACK_MAX = 20;
 struct FetchPack {
     const char *src[FETCH_PACK_MAX];
@@ -1787,26 +1762,23 @@ __global__ __launch_bounds__(256) void k_fetch_pack(FetchPack Q, char *__restric
         }
     }
 }
-}  // namespace
 
-extern "C" int molar_hip_membrane_frame_fetch(molar_hip_membrane_plan *P, int32_t ticket, const molar_hip_membrane_out *O) {
-    MH_TRY(check_ticket(P, ticket, /*want_ended=*/true));
-    if (!O) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_fetch: null argument");
-    MH_HIP(hipSetDevice(P->c->device));
-    const auto &S = P->slot[ticket];
+// A fetch in three steps: the list of arrays the caller asked for (and room for them in the pinned block), their way into the
+// block on a stream, and - once that stream has been waited for - plain memcpy into the caller's arrays.
+struct FetchItem { void *dst; const void *src; size_t bytes, at; };
+struct FetchJob {
+    std::vector<FetchItem> items;
+    size_t total = 0;
+};
+
+int fetch_prepare(molar_hip_membrane_plan *P, const molar_hip_membrane_plan::Slot &S, const molar_hip_membrane_out *O, FetchJob &J) {
     molar_hip_membrane_view V;
     fill_view(P, S, &V);
     const size_t K = P->K, E = V.patch_entries, slots = E + 4 * K;
-    hipStream_t cs = P->copy_stream;
-    // everything through one pinned block: the copies run back to back on the copy stream (beside the kernels of the
-    // frame in flight), one wait, then plain memcpy into the caller's arrays
-    struct Item { void *dst; const void *src; size_t bytes, at; };
-    std::vector<Item> items;
-    size_t total = 0;
     auto want = [&](void *dst, const void *src, size_t bytes) {
         if (!dst || !bytes) return;
-        items.push_back(Item{dst, src, bytes, total});
-        total += (bytes + 63) & ~size_t(63);
+        J.items.push_back(FetchItem{dst, src, bytes, J.total});
+        J.total += (bytes + 63) & ~size_t(63);
     };
     want(O->head, V.head, K * 12); want(O->mid, V.mid, K * 12); want(O->tail, V.tail, K * 12);
     want(O->patch_offsets, V.patch_offsets, (K + 1) * 8); want(O->patch_ids, V.patch_ids, E * 8);
@@ -1816,31 +1788,98 @@ extern "C" int molar_hip_membrane_frame_fetch(molar_hip_membrane_plan *P, int32_
     want(O->princ_curvs, V.princ_curvs, K * 8); want(O->princ_dirs, V.princ_dirs, K * 24); want(O->area, V.area, K * 4);
     want(O->nvert, V.nvert, K * 4); want(O->neib_ids, V.neib_ids, slots * 8); want(O->voro_vertexes, V.voro_vertexes, slots * 12);
     want(O->fitted_patch_points, V.fitted_patch_points, E * 12); want(O->order, V.order, P->norder * 4);
-    if (items.empty()) return MOLAR_HIP_OK;
-    if (total > P->h_fetch_cap) {
+    if (J.total > P->h_fetch_cap) {
         if (P->h_fetch) (void)hipHostFree(P->h_fetch);
         P->h_fetch = nullptr;
         P->h_fetch_cap = 0;
-        MH_HIP(hipHostMalloc(&P->h_fetch, total + total / 4, hipHostMallocDefault));
-        P->h_fetch_cap = total + total / 4;
+        MH_HIP(hipHostMalloc(&P->h_fetch, J.total + J.total / 4, hipHostMallocDefault));
+        P->h_fetch_cap = J.total + J.total / 4;
     }
-    // one kernel stores the arrays into the pinned block (a device-to-host copy is a launch of its own here, twenty of them
-    // cost more than the bytes); an array too large for that share goes by a copy
+    return 0;
+}
+
+// one kernel stores the arrays into the pinned block (a device-to-host copy is a launch of its own here, twenty of them cost
+// more than the bytes); an array too large for that share goes by a copy
+int fetch_enqueue(molar_hip_membrane_plan *P, const FetchJob &J, hipStream_t st) {
     FetchPack pack{};
-    for (const Item &it : items) {
+    for (const FetchItem &it : J.items) {
         if (it.bytes <= (4u << 20) && pack.n < FETCH_PACK_MAX) {
             pack.src[pack.n] = (const char *)it.src; pack.at[pack.n] = it.at; pack.bytes[pack.n] = it.bytes;
             ++pack.n;
         } else {
-            MH_HIP(hipMemcpyAsync((char *)P->h_fetch + it.at, it.src, it.bytes, hipMemcpyDeviceToHost, cs));
+            MH_HIP(hipMemcpyAsync((char *)P->h_fetch + it.at, it.src, it.bytes, hipMemcpyDeviceToHost, st));
         }
     }
     if (pack.n) {
-        hipLaunchKernelGGL(k_fetch_pack, dim3(64), dim3(256), 0, cs, pack, (char *)P->h_fetch);
+        hipLaunchKernelGGL(k_fetch_pack, dim3(64), dim3(256), 0, st, pack, (char *)P->h_fetch);
         MH_HIP(hipGetLastError());
     }
-    MH_HIP(hipStreamSynchronize(cs));
-    for (const Item &it : items) std::memcpy(it.dst, (const char *)P->h_fetch + it.at, it.bytes);
+    return 0;
+}
+
+void fetch_finish(molar_hip_membrane_plan *P, const FetchJob &J) {
+    for (const FetchItem &it : J.items) std::memcpy(it.dst, (const char *)P->h_fetch + it.at, it.bytes);
+}
+
+int frame_end(molar_hip_membrane_plan *P, int32_t ticket, molar_hip_membrane_view *view, const molar_hip_membrane_out *out) {
+    MH_TRY(check_ticket(P, ticket, /*want_ended=*/false));
+    MH_HIP(hipSetDevice(P->c->device));
+    auto &S = P->slot[ticket];
+    // frames end in begin order: the older one first
+    auto &O = P->slot[ticket ^ 1];
+    if (O.pending && O.serial < S.serial) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_end: end the older frame (ticket %d) first", ticket ^ 1);
+    if (!S.b_enqueued) MH_TRY(enqueue_b(P, S, /*restore=*/false));     // (only after an error left the chain short)
+    if (!S.passed) MH_TRY(host_pass(P, S, /*may_repeat=*/true));
+    MH_TRY(enqueue_c(P, S));
+    FetchJob J;
+    if (out) {     // the caller's arrays leave on the frame's own stream, right behind C: no second round trip for them
+        MH_TRY(fetch_prepare(P, S, out, J));
+        if (!J.items.empty()) {
+            MH_TRY(fetch_enqueue(P, J, P->c->stream));
+            MH_HIP(hipEventRecord(S.done, P->c->stream));
+        }
+    }
+    // while the GPU smooths this frame: the host pass of the younger one, whose B is already through (it sits ahead of
+    // this C on the stream)
+    if (O.pending && O.b_enqueued && !O.passed) MH_TRY(host_pass(P, O, /*may_repeat=*/false));
+    MH_HIP(hipEventSynchronize(S.done));
+    std::memcpy(&S.info, (char *)S.h + H_INFO, sizeof(FrameInfo));
+    if (O.pending && (!O.b_enqueued || (O.speculative && S.info.changed))) MH_TRY(enqueue_b(P, O, /*restore=*/false));
+    O.speculative = false;
+    S.pending = false;
+    S.ended = true;
+    if (view) fill_view(P, S, view);
+    if (out) fetch_finish(P, J);
+    if (S.info.st_center) return fail(S.info.st_center, "membrane frame: a marker selection has zero mass");
+    if (S.info.st_order) return fail(S.info.st_order, "membrane frame: lipid order error (status %d)", S.info.st_order);
+    return MOLAR_HIP_OK;
+}
+}  // namespace
+
+extern "C" int molar_hip_membrane_frame_end(molar_hip_membrane_plan *P, int32_t ticket, molar_hip_membrane_view *view) {
+    return frame_end(P, ticket, view, nullptr);
+}
+
+extern "C" int molar_hip_membrane_frame_end_fetch(molar_hip_membrane_plan *P, int32_t ticket, molar_hip_membrane_view *view,
+                                                  const molar_hip_membrane_out *out) {
+    if (!out) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_end_fetch: null argument");
+    // the caller cannot size the arrays that follow the frame's patch entries before the frame has ended
+    if (out->patch_ids || out->neib_ids || out->voro_vertexes || out->fitted_patch_points)
+        return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_end_fetch: per-lipid arrays and order only (patch-sized arrays: _frame_fetch after the view)");
+    return frame_end(P, ticket, view, out);
+}
+
+extern "C" int molar_hip_membrane_frame_fetch(molar_hip_membrane_plan *P, int32_t ticket, const molar_hip_membrane_out *O) {
+    MH_TRY(check_ticket(P, ticket, /*want_ended=*/true));
+    if (!O) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_fetch: null argument");
+    MH_HIP(hipSetDevice(P->c->device));
+    FetchJob J;
+    MH_TRY(fetch_prepare(P, P->slot[ticket], O, J));
+    if (J.items.empty()) return MOLAR_HIP_OK;
+    // on the copy stream, beside the kernels of the frame in flight
+    MH_TRY(fetch_enqueue(P, J, P->copy_stream));
+    MH_HIP(hipStreamSynchronize(P->copy_stream));
+    fetch_finish(P, J);
     return MOLAR_HIP_OK;
 }
 

@@ -124,6 +124,54 @@ def test_two_frames_in_flight(eng):
     assert np.array_equal(fused.valid, staged.valid) and np.count_nonzero(fused.valid == 0) > 0
 
 
+def test_end_with_its_arrays_equals_end_then_fetch(eng):
+    """molar_hip_membrane_frame_end_fetch: the per-lipid arrays that come with the end of a frame (stored behind its last
+    kernel, one wait) are the arrays a fetch brings afterwards, with two frames in flight and flags that change on the way;
+    arrays sized by the patch entries are refused there."""
+    from molar_amd import api, membrane as mb
+    xyz, box, first, tpl, masses = mb.build_bilayer(150, 30000)
+    fr = frames_of(xyz, 5, seed=9)
+    fr[1][31 * 52: 31 * 52 + 12, 2] += 1.5
+    names = ["head", "mid", "tail", "patch_offsets", "initial_normals", "valid", "smoothed_head", "normals", "quad_coefs", "mean_curv",
+             "gauss_curv", "princ_curvs", "princ_dirs", "area", "nvert", "order"]
+    res = []
+    for with_end in (False, True):
+        m = mb.Membrane(eng, len(xyz), first, tpl, masses, mb.MembraneOptions(cutoff=1.5, order_type=2))
+        plan = m._plan()
+        plan.set_valid(None)
+        bufs = [f.copy() for f in fr]
+        out, prev = [], None
+        for k in range(len(fr) + 1):
+            t = plan.begin(bufs[k], box) if k < len(fr) else None
+            if prev is not None:
+                if with_end:
+                    v, r = plan.end(prev, names)
+                    assert v.nlipids == m.K
+                    r["neib_ids"] = plan.fetch(prev, ["neib_ids"])["neib_ids"]       # a later fetch of the same frame still works
+                else:
+                    plan.end(prev)
+                    r = plan.fetch(prev, names + ["neib_ids"])
+                out.append(r)
+            prev = t
+        if with_end:
+            t = plan.begin(bufs[0].copy(), box)
+            with pytest.raises(ValueError):
+                plan.end(t, ["valid", "patch_ids"])
+            o = api.MembraneOut()
+            ids = np.zeros(8, np.uint64)
+            o.patch_ids = ids.ctypes.data
+            assert plan.lib.molar_hip_membrane_frame_end_fetch(plan.handle, t, None, __import__("ctypes").byref(o)) == 50        # MOLAR_HIP_ERR_INVALID_ARGUMENT
+            plan.end(t)
+        plan.close()
+        res.append(out)
+    assert len(res[0]) == len(fr)
+    for k, (a, b) in enumerate(zip(*res)):
+        assert a["valid"].sum() > 0
+        for n in names + ["neib_ids"]:
+            same_bits(b[n], a[n], f"frame {k} {n}")
+    assert any((r["valid"] == 0).any() for r in res[1])
+
+
 def test_a_frame_that_outgrows_its_buffers_is_repeated(eng):
     """Pair and patch capacities come from earlier frames.  A frame with several times as many neighbours (the box and the
     bilayer squeezed laterally) overflows them with a younger frame already enqueued behind it: both are repeated
