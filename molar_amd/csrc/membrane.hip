@@ -930,25 +930,37 @@ struct FrameInfo {                 // device block of a frame, read back with it
 
 // first kernel of a frame's B part: the valid flags as this frame finds them are remembered (or, on a repeat of B after
 // its buffers were grown, put back), markers split into their arrays, the search input made
+__device__ __forceinline__ float nrm3(float x, float y, float z) { return __builtin_sqrtf((x * x + y * y) + z * z); }
+
 __global__ __launch_bounds__(256) void k_split_markers(uint32_t K, const float *__restrict__ mk, uint8_t *__restrict__ valid,
                                                        uint8_t *__restrict__ valid_prev, int restore, float *__restrict__ head,
-                                                       float *__restrict__ mid, float *__restrict__ tail, float *__restrict__ head_search) {
+                                                       float *__restrict__ mid, float *__restrict__ tail, float *__restrict__ head_search,
+                                                       float *__restrict__ thv, float *__restrict__ nrm) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= K) return;
     uint8_t v;
     if (restore) { v = valid_prev[i]; valid[i] = v; }
     else { v = valid[i]; valid_prev[i] = v; }
     const bool ok = v != 0;
+    float hd[3], tl[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float h = mk[9 * i + d];
+        hd[d] = h;
+        tl[d] = mk[9 * i + 6 + d];
         head[3 * i + d] = h;
         mid[3 * i + d] = mk[9 * i + 3 + d];
-        tail[3 * i + d] = mk[9 * i + 6 + d];
+        tail[3 * i + d] = tl[d];
         // compute_patches searches among the valid lipids only (lib.rs:540-546).  A NaN position pairs with nothing and
         // leaves the order of every other pair alone, so the search keeps its fixed size and the ids stay lipid ids.
         head_search[3 * i + d] = ok ? h : __builtin_nanf("");
     }
+    // compute_initial_normals starts from the unit tail-to-head vectors of the valid lipids (lib.rs:456-466); the first-pass
+    // normals start from zero
+    const float x = hd[0] - tl[0], y = hd[1] - tl[1], z = hd[2] - tl[2];
+    const float n = nrm3(x, y, z);
+    thv[3 * i] = ok ? x / n : 0.f; thv[3 * i + 1] = ok ? y / n : 0.f; thv[3 * i + 2] = ok ? z / n : 0.f;
+    nrm[3 * i] = 0.f; nrm[3 * i + 1] = 0.f; nrm[3 * i + 2] = 0.f;
 }
 
 // (mask_units / mask_cap: a search whose hit history did not fit has left the results of its wrapped entries unwritten - stale
@@ -1058,20 +1070,6 @@ __global__ __launch_bounds__(256) void k_patch_reverse(const FrameInfo *__restri
         for (uint64_t e = poff[i]; e < q; ++e) less += pids[e] == t ? 1u : 0u;
     rev_entry[ta + less] = (uint32_t)q;
     rev_owner[ta + less] = i;
-}
-
-__device__ __forceinline__ float nrm3(float x, float y, float z) { return __builtin_sqrtf((x * x + y * y) + z * z); }
-
-// tail -> head unit vectors of the valid lipids (lib.rs:459-461); zero for the others
-__global__ __launch_bounds__(256) void k_tail_head(uint32_t K, const float *__restrict__ head, const float *__restrict__ tail,
-                                                   const uint8_t *__restrict__ valid, float *__restrict__ thv, float *__restrict__ nrm) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= K) return;
-    const bool ok = valid[i] != 0;
-    const float x = head[3 * i] - tail[3 * i], y = head[3 * i + 1] - tail[3 * i + 1], z = head[3 * i + 2] - tail[3 * i + 2];
-    const float n = nrm3(x, y, z);
-    thv[3 * i] = ok ? x / n : 0.f; thv[3 * i + 1] = ok ? y / n : 0.f; thv[3 * i + 2] = ok ? z / n : 0.f;
-    nrm[3 * i] = 0.f; nrm[3 * i + 1] = 0.f; nrm[3 * i + 2] = 0.f;
 }
 
 // "angle <= FRAC_PI_2" of nalgebra's Vector::angle (lib.rs:472-473, 494) as a threshold on the cosine: `cos_min` is the
@@ -1189,24 +1187,23 @@ __global__ __launch_bounds__(256) void k_state_defaults(uint32_t K, float *__res
     }
 }
 
-// the flags a frame leaves, for its results; and whether its smoothing changed any
-__global__ __launch_bounds__(256) void k_valid_out(uint32_t K, const uint8_t *__restrict__ before, const uint8_t *__restrict__ after,
-                                                   uint8_t *__restrict__ out, int *__restrict__ changed) {
+// the flags a frame leaves, for its results, and whether its smoothing changed any; and the normal each tail is measured
+// against (its lipid's, or the global one) - one launch over max(lipids, tails)
+__global__ __launch_bounds__(256) void k_flags_tail_normals(uint32_t K, const uint8_t *__restrict__ before, const uint8_t *__restrict__ after,
+                                                            uint8_t *__restrict__ out, int *__restrict__ changed, uint32_t ntails,
+                                                            const uint32_t *__restrict__ tail_lipid, const float *__restrict__ normals,
+                                                            int use_global, float gx, float gy, float gz, float *__restrict__ tnorm) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= K) return;
-    out[i] = after[i];
-    if (before[i] != after[i]) *changed = 1;
-}
-
-__global__ __launch_bounds__(256) void k_tail_normals(uint32_t ntails, const uint32_t *__restrict__ tail_lipid,
-                                                      const float *__restrict__ normals, int use_global, float gx, float gy, float gz,
-                                                      float *__restrict__ out) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= ntails) return;
-    const uint32_t l = tail_lipid[t];
-    out[3 * t] = use_global ? gx : normals[3 * l];
-    out[3 * t + 1] = use_global ? gy : normals[3 * l + 1];
-    out[3 * t + 2] = use_global ? gz : normals[3 * l + 2];
+    if (i < K) {
+        out[i] = after[i];
+        if (before[i] != after[i]) *changed = 1;
+    }
+    if (i < ntails) {
+        const uint32_t l = tail_lipid[i];
+        tnorm[3 * i] = use_global ? gx : normals[3 * l];
+        tnorm[3 * i + 1] = use_global ? gy : normals[3 * l + 1];
+        tnorm[3 * i + 2] = use_global ? gz : normals[3 * l + 2];
+    }
 }
 
 // smallest f32 c with acosf(c) <= pi/2 (f32): the comparison compute_initial_normals makes, decided by the host's libm
@@ -1414,7 +1411,8 @@ int enqueue_b(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
     float *head = (float *)(d + L.head), *tail = (float *)(d + L.tail);
     const uint32_t nbK = (K32 + 255u) / 256u;
     hipLaunchKernelGGL(k_split_markers, dim3(nbK), dim3(256), 0, st, K32, (const float *)(d + L.mk), valid, (uint8_t *)(d + L.valid_prev),
-                       restore ? 1 : 0, head, (float *)(d + L.mid), tail, (float *)(d + L.head_search));
+                       restore ? 1 : 0, head, (float *)(d + L.mid), tail, (float *)(d + L.head_search), (float *)(d + L.thv),
+                       (float *)(d + L.normals0));
     // ---- compute_patches (lib.rs:539-558)
     molar_hip_search_desc q{};
     q.kind = MOLAR_HIP_SEARCH_SINGLE;
@@ -1450,7 +1448,6 @@ int enqueue_b(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
     }
     // ---- compute_initial_normals, first pass (lib.rs:456-484)
     float *thv = (float *)(d + L.thv), *n0 = (float *)(d + L.normals0);
-    hipLaunchKernelGGL(k_tail_head, dim3(nbK), dim3(256), 0, st, K32, head, tail, valid, thv, n0);
     hipLaunchKernelGGL(k_normals_pass1, dim3((K32 + 15u) / 16u), dim3(256), 0, st, K32, valid, poff, pids, thv, n0, P->cos_min);
     MH_HIP(hipGetLastError());
     // ---- to the host, in one copy: status, offsets, first-pass normals, flags, ids
@@ -1494,7 +1491,7 @@ int host_pass(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool
 }
 
 // C: smoothing on a fresh per-lipid state, order
-int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
+int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S, bool info_to_host = true) {
     molar_hip_ctx *c = P->c;
     const size_t K = P->K;
     const uint32_t K32 = (uint32_t)K;
@@ -1531,18 +1528,22 @@ int enqueue_c(molar_hip_membrane_plan *P, molar_hip_membrane_plan::Slot &S) {
         // (a lane of the averaging kernel reads the fitted marker of its own lipid only, before it overwrites it)
         hipLaunchKernelGGL(k_membrane_average, dim3((uint32_t)((K + 3) / 4)), dim3(64), 0, st, A, (const float *)A.head);
     }
-    hipLaunchKernelGGL(k_valid_out, dim3(nbK), dim3(256), 0, st, K32, (const uint8_t *)(d + L.valid_prev), valid, (uint8_t *)(d + L.valid_out),
-                       &info->changed);
+    {
+        const uint32_t nt = (uint32_t)P->ntails, nmax = std::max(K32, nt);
+        hipLaunchKernelGGL(k_flags_tail_normals, dim3((nmax + 255u) / 256u), dim3(256), 0, st, K32, (const uint8_t *)(d + L.valid_prev), valid,
+                           (uint8_t *)(d + L.valid_out), &info->changed, nt, P->tail_lipid, (const float *)(d + L.s_normals), P->use_global,
+                           P->gn[0], P->gn[1], P->gn[2], (float *)(d + L.tnorm));
+    }
     // ---- compute_order (lib.rs:435-443)
     if (P->ntails) {
-        hipLaunchKernelGGL(k_tail_normals, dim3((uint32_t)((P->ntails + 255) / 256)), dim3(256), 0, st, (uint32_t)P->ntails, P->tail_lipid,
-                           (const float *)(d + L.s_normals), P->use_global, P->gn[0], P->gn[1], P->gn[2], (float *)(d + L.tnorm));
         MH_TRY(enqueue_lipid_order(c, S.xyz_dev, P->tail_idx, P->tail_off, (uint32_t)P->ntails, P->order_type, (const float *)(d + L.tnorm),
                                    P->noff, P->tail_bonds, (float *)(d + L.order), &info->st_order));
     }
     MH_HIP(hipGetLastError());
-    MH_HIP(hipMemcpyAsync((char *)S.h + H_INFO, info, sizeof(FrameInfo), hipMemcpyDeviceToHost, st));
-    MH_HIP(hipEventRecord(S.done, st));
+    if (info_to_host) {
+        MH_HIP(hipMemcpyAsync((char *)S.h + H_INFO, info, sizeof(FrameInfo), hipMemcpyDeviceToHost, st));
+        MH_HIP(hipEventRecord(S.done, st));
+    }
     return 0;
 }
 
@@ -1744,17 +1745,18 @@ namespace {
 // are 16-byte aligned (Blob2 / the 64-byte steps of the items); a tail of fewer than 16 bytes goes by bytes.
 constexpr uint32_t FETCH_PACK_MAX = 20;
 struct FetchPack {
-    const char *src[FETCH_PACK_MAX];
-    size_t at[FETCH_PACK_MAX], bytes[FETCH_PACK_MAX];
+    const char *src[FETCH_PACK_MAX + 1];
+    char *dst[FETCH_PACK_MAX + 1];
+    size_t bytes[FETCH_PACK_MAX + 1];
     uint32_t n;
 };
-__global__ __launch_bounds__(256) void k_fetch_pack(FetchPack Q, char *__restrict__ dst) {
+__global__ __launch_bounds__(256) void k_fetch_pack(FetchPack Q) {
     const size_t tid = (size_t)blockIdx.x * 256u + threadIdx.x, nth = (size_t)gridDim.x * 256u;
     for (uint32_t k = 0; k < Q.n; ++k) {
         const char *s = Q.src[k];
-        char *d = dst + Q.at[k];
+        char *d = Q.dst[k];
         const size_t words = Q.bytes[k] / 16u;
-        if (((uintptr_t)s & 15u) == 0) {
+        if ((((uintptr_t)s | (uintptr_t)d) & 15u) == 0) {
             for (size_t w = tid; w < words; w += nth) reinterpret_cast<uint4 *>(d)[w] = reinterpret_cast<const uint4 *>(s)[w];
             for (size_t b = words * 16u + tid; b < Q.bytes[k]; b += nth) d[b] = s[b];
         } else {
@@ -1800,18 +1802,24 @@ int fetch_prepare(molar_hip_membrane_plan *P, const molar_hip_membrane_plan::Slo
 
 // one kernel stores the arrays into the pinned block (a device-to-host copy is a launch of its own here, twenty of them cost
 // more than the bytes); an array too large for that share goes by a copy
-int fetch_enqueue(molar_hip_membrane_plan *P, const FetchJob &J, hipStream_t st) {
+// (`also_src` .. `also_bytes`: one more block for the same launch - the frame's status words on their way to the host)
+int fetch_enqueue(molar_hip_membrane_plan *P, const FetchJob &J, hipStream_t st, const void *also_src = nullptr, void *also_dst = nullptr,
+                  size_t also_bytes = 0) {
     FetchPack pack{};
     for (const FetchItem &it : J.items) {
         if (it.bytes <= (4u << 20) && pack.n < FETCH_PACK_MAX) {
-            pack.src[pack.n] = (const char *)it.src; pack.at[pack.n] = it.at; pack.bytes[pack.n] = it.bytes;
+            pack.src[pack.n] = (const char *)it.src; pack.dst[pack.n] = (char *)P->h_fetch + it.at; pack.bytes[pack.n] = it.bytes;
             ++pack.n;
         } else {
             MH_HIP(hipMemcpyAsync((char *)P->h_fetch + it.at, it.src, it.bytes, hipMemcpyDeviceToHost, st));
         }
     }
+    if (also_bytes) {
+        pack.src[pack.n] = (const char *)also_src; pack.dst[pack.n] = (char *)also_dst; pack.bytes[pack.n] = also_bytes;
+        ++pack.n;
+    }
     if (pack.n) {
-        hipLaunchKernelGGL(k_fetch_pack, dim3(64), dim3(256), 0, st, pack, (char *)P->h_fetch);
+        hipLaunchKernelGGL(k_fetch_pack, dim3(64), dim3(256), 0, st, pack);
         MH_HIP(hipGetLastError());
     }
     return 0;
@@ -1830,14 +1838,15 @@ int frame_end(molar_hip_membrane_plan *P, int32_t ticket, molar_hip_membrane_vie
     if (O.pending && O.serial < S.serial) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "membrane_frame_end: end the older frame (ticket %d) first", ticket ^ 1);
     if (!S.b_enqueued) MH_TRY(enqueue_b(P, S, /*restore=*/false));     // (only after an error left the chain short)
     if (!S.passed) MH_TRY(host_pass(P, S, /*may_repeat=*/true));
-    MH_TRY(enqueue_c(P, S));
     FetchJob J;
-    if (out) {     // the caller's arrays leave on the frame's own stream, right behind C: no second round trip for them
-        MH_TRY(fetch_prepare(P, S, out, J));
-        if (!J.items.empty()) {
-            MH_TRY(fetch_enqueue(P, J, P->c->stream));
-            MH_HIP(hipEventRecord(S.done, P->c->stream));
-        }
+    if (out) MH_TRY(fetch_prepare(P, S, out, J));
+    const bool packed = !J.items.empty();
+    MH_TRY(enqueue_c(P, S, /*info_to_host=*/!packed));
+    if (packed) {  // the caller's arrays leave on the frame's own stream, right behind C - no second round trip for them -, and
+                   // the frame's status words ride in the same launch
+        char *d = S.blob.as<char>();
+        MH_TRY(fetch_enqueue(P, J, P->c->stream, d + S.lay.info, (char *)S.h + H_INFO, sizeof(FrameInfo)));
+        MH_HIP(hipEventRecord(S.done, P->c->stream));
     }
     // while the GPU smooths this frame: the host pass of the younger one, whose B is already through (it sits ahead of
     // this C on the stream)
