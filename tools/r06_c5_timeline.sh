@@ -32,7 +32,8 @@ for s, e, n, q in seg:
         busy += max(0, e - max(s, end))
     if e > end: end = e; prev = n
 print(f"frames {nfr}  period {span / nfr / 1e3:.1f} us  busy {busy / nfr / 1e3:.1f} us  idle {(span - busy) / nfr / 1e3:.1f} us")
-print("-- operations per frame (us)")
+print(f"operations per frame {sum(c for c, t in per.values()) / nfr:.1f} (kernels, fills and copies on all queues), their time {sum(t for c, t in per.values()) / nfr / 1e3:.1f} us")
+print("-- operations per frame: count x average us = us per frame")
 for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{n:46s} {c / nfr:6.2f} x {t / c / 1e3:7.2f} = {t / nfr / 1e3:7.2f}")
 print("-- idle gaps per frame (us) by (before -> after)")

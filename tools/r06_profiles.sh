@@ -17,6 +17,7 @@ python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2>/dev/null
 bash tools/r04_timeline.sh r06 > $O/timeline.txt 2>&1; cp $R/gpurun_out/r04/r06_timeline.txt $O/frame_timeline.txt 2>/dev/null
 bash tools/r06_rdf_trace.sh final > /dev/null 2>&1
 bash tools/r06_membrane_trace.sh final > /dev/null 2>&1
+bash tools/r06_c5_timeline.sh final > /dev/null 2>&1
 timeout 900 python tools/bench_cutoff_sweep.py 0.3 0.35 0.4 0.5 0.6 0.8 1.0 1.2 1.3 1.4 1.5 1.6 1.8 2.0 2.2 2.4 > $O/cutoff_sweep.jsonl 2>/dev/null
 # what comes back through gpurun_out/ is capped at 64 MiB: keep the summaries (kernel statistics, the FETCH / WRITE counter tables of the
 # three-step passes, text and JSON), drop the per-dispatch traces and every other raw file of rocprofv3
