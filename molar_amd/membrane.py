@@ -208,9 +208,13 @@ class Membrane:
     def compute_end(self, ticket, names=None):
         """Wait for a frame begun with compute_begin; returns the same dict as compute (all arrays, or only `names`)."""
         plan = self._plan()
-        plan.end(ticket)
         want = list(api.MEMBRANE_ARRAYS) if names is None else list(dict.fromkeys(list(names) + ["valid"]))
-        r = plan.fetch(ticket, want)
+        # the per-lipid arrays come with the frame's end (one wait); the arrays sized by its patch entries need the view first
+        late = [k for k in want if k in api.MembranePlan._PATCH_SIZED]
+        _, r = plan.end(ticket, [k for k in want if k not in late])
+        if late:
+            r.update(plan.fetch(ticket, late))
+        r = {k: r[k] for k in want}
         self.valid[:] = r["valid"]
         self._inflight -= 1
         self._valid_dev = self.valid.copy() if self._inflight == 0 else None     # a younger frame is ahead of self.valid
