@@ -260,9 +260,9 @@ int molar_hip_search_histogram(molar_hip_ctx *ctx, const molar_hip_search_desc *
 /* The same for a block of a trajectory: `nframes` frames of the request's first set, frame k at desc->xyz1 + k * xyz1_stride
  * floats (second set: xyz2 + k * xyz2_stride), box of frame k at boxes9 + 9 k (NULL: desc->box9 for every frame) - the state
  * iterator of analysis_task.rs:245-252 / io.rs:198-271 handed over a window at a time.  The sums in `bins` are those of
- * nframes calls of molar_hip_search_histogram (integer bins do not care how their pairs are grouped).  Single-set periodic
- * requests whose coordinates, index and bins are all in device memory, on a context that owns its stream, run in groups of up
- * to eight frames that share their launches - the grids of a group are built together on the side stream while the group before
+ * nframes calls of molar_hip_search_histogram (integer bins do not care how their pairs are grouped).  Periodic requests of
+ * kind SINGLE or DOUBLE whose coordinates, indices and bins are all in device memory, on a context that owns its stream, run in
+ * groups of up to sixteen frames that share their launches - the grids of a group are built together on the side stream while the group before
  * is still in its histogram kernel, one plan launch and one persistent kernel walk the slots of all of them - and the call
  * does not wait (molar_hip_synchronize before reading the bins; the frames must be complete in memory at the call).  Anything
  * else is walked frame by frame through molar_hip_search_histogram. */

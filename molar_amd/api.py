@@ -485,25 +485,27 @@ class Engine:
         self._keep = keep
         return bins, (int(cnt.value) if want_count else None)
 
-    def search_histogram_frames(self, kind, cutoff, hmin, hmax, nbins, frames, idx1=None, box=None, pbc=0, bins=None):
+    def search_histogram_frames(self, kind, cutoff, hmin, hmax, nbins, frames, idx1=None, box=None, pbc=0, bins=None, frames2=None, idx2=None):
         """molar_hip_search_histogram_frames: the frames of a trajectory block, `frames` = [nframes, natoms, 3] float32 (one
         contiguous array or CUDA tensor), through the fused histogram; the same sums as nframes calls of search_histogram.
-        `box`: one 3x3 matrix for all frames or [nframes, 3, 3].  With frames, index and bins in device memory the frames go
+        `box`: one 3x3 matrix for all frames or [nframes, 3, 3].  SEARCH_DOUBLE: the second set is `idx2` of `frames2` (None:
+        of the same frames - two selections of one trajectory).  With frames, indices and bins in device memory the frames go
         through the GPU in groups that share their launches, and the call does not wait (synchronize() before reading)."""
-        stride = None
-        if _is_torch(frames) and frames.ndim == 3 and frames.stride(2) == 1 and frames.stride(1) == 3:
-            import torch
-            assert frames.dtype == torch.float32
-            stride = int(frames.stride(0))          # frames with a gap between them (a window of a larger buffer): no copy
-            fa, k1 = frames.data_ptr(), frames
-        else:
-            frames = _f32(frames)
-            fa, k1 = _addr(frames)
-        assert frames.ndim == 3 and frames.shape[2] == 3
+        def block(fr):
+            stride = None
+            if _is_torch(fr) and fr.ndim == 3 and fr.stride(2) == 1 and fr.stride(1) == 3:
+                import torch
+                assert fr.dtype == torch.float32
+                stride = int(fr.stride(0))          # frames with a gap between them (a window of a larger buffer): no copy
+                fa, k = fr.data_ptr(), fr
+            else:
+                fr = _f32(fr)
+                fa, k = _addr(fr)
+            assert fr.ndim == 3 and fr.shape[2] == 3
+            return fr, fa, k, (int(fr.shape[1]) * 3 if stride is None else stride)
+        frames, fa, k1, stride = block(frames)
         idx1 = _u64(idx1)
         nframes, natoms = int(frames.shape[0]), int(frames.shape[1])
-        if stride is None:
-            stride = natoms * 3
         d = SearchDesc()
         d.kind = kind
         d.cutoff = float(cutoff)
@@ -513,6 +515,17 @@ class Engine:
         d.natoms1 = natoms
         d.n1 = 0 if idx1 is None else idx1.shape[0]
         keep = [k1, k2]
+        stride2 = 0
+        if kind in (SEARCH_DOUBLE, SEARCH_DOUBLE_VDW):
+            f2, fa2, k3, stride2 = block(frames if frames2 is None else frames2)
+            assert int(f2.shape[0]) == nframes
+            idx2 = _u64(idx2)
+            ia2, k4 = _addr(idx2)
+            d.xyz2 = fa2
+            d.idx2 = ia2
+            d.natoms2 = int(f2.shape[1])
+            d.n2 = 0 if idx2 is None else idx2.shape[0]
+            keep += [k3, k4]
         boxes_ptr = None
         if box is not None:
             b = np.asarray(box.get_matrix() if isinstance(box, PeriodicBox) else box, np.float32)
@@ -528,7 +541,7 @@ class Engine:
         if bins is None:
             bins = np.zeros(nbins, np.uint64)
         ba_, kb_ = _addr(bins)
-        check(self.lib.molar_hip_search_histogram_frames(self.ctx, C.byref(d), nframes, stride, 0, boxes_ptr, float(hmin), float(hmax),
+        check(self.lib.molar_hip_search_histogram_frames(self.ctx, C.byref(d), nframes, stride, stride2, boxes_ptr, float(hmin), float(hmax),
                                                          nbins, ba_))
         self._keep = keep
         return bins

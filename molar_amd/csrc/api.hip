@@ -187,7 +187,7 @@ void molar_hip_destroy(molar_hip_ctx *c) {
     }
     if (c->aux) molar_hip_destroy(c->aux);
     for (DevBuf *b : {&c->xh_win[0], &c->xh_win[1], &c->xh_bins, &c->fit_redo}) b->release();
-    for (auto &gen : c->hb_sets) for (auto &s : gen) {
+    for (auto &gen : c->hb_sets) for (auto &fr : gen) for (auto &s : fr) {
         for (DevBuf *b : {&s.xyz_stage, &s.idx_stage, &s.vdw_stage, &s.key, &s.cell_count, &s.cnt_pad, &s.cursor, &s.tmp_key, &s.sort_buf,
                           &s.sorted, &s.sorted_vdw, &s.aabb, &s.perm, &s.chunk_aabb, &s.h16, &s.cell_org})
             b->release();

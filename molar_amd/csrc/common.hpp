@@ -217,9 +217,9 @@ struct molar_hip_ctx {
     mh::DevBuf slot_desc_rest; // fused histogram: records of the slots the generic kernel takes (hist_plan_kernel)
     unsigned long long hist_frames = 0;   // fused-histogram launches of this context (mod 4: which pair of list counters a launch uses)
     // molar_hip_search_histogram_frames: groups of frames through one set of launches (search.hip, hist_frames_group)
-    mh::GridSet hb_sets[2][MH_HIST_BATCH];           // grids of a group's frames, two generations
-    bool hb_zeroed[2][MH_HIST_BATCH] = {};           // a set's padded cell counters are zero (the frames' unpad kernel leaves them so)
-    uint32_t hb_zeroed_cells[2][MH_HIST_BATCH] = {}; // ... for a grid of this many cells
+    mh::GridSet hb_sets[2][MH_HIST_BATCH][2];           // grids of a group's frames (first / second set), two generations
+    bool hb_zeroed[2][MH_HIST_BATCH][2] = {};           // a set's padded cell counters are zero (the frames' unpad kernel leaves them so)
+    uint32_t hb_zeroed_cells[2][MH_HIST_BATCH][2] = {}; // ... for a grid of this many cells
     mh::DevBuf hb_lean[2], hb_rest[2];    // the group's two slot lists
     mh::DevBuf hb_blocks[2];              // [parameter blocks | grid records] of the group
     void *hb_pin = nullptr;               // pinned staging of those records: four slots

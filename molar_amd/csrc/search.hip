@@ -2758,15 +2758,18 @@ int molar_hip_search_histogram(molar_hip_ctx *c, const molar_hip_search_desc *q,
 // ended (gen_free, the event the asynchronous single-frame calls use as well: the two forms may be mixed on a context).
 // Returns 1 when the group does not qualify (the caller then walks it frame by frame), 0 when enqueued.
 constexpr int HIST_BATCH = MH_HIST_BATCH;
-static_assert(HIST_BATCH <= (int)(sizeof(((molar_hip_ctx *)nullptr)->hb_sets[0]) / sizeof(mh::GridSet)), "hb_sets holds a group");
+static_assert(HIST_BATCH <= (int)(sizeof(((molar_hip_ctx *)nullptr)->hb_sets[0]) / sizeof(((molar_hip_ctx *)nullptr)->hb_sets[0][0])), "hb_sets holds a group");
 
-static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, size_t first, int W, size_t stride1, const float *boxes9, float hmin,
-                             float hmax, size_t nbins, unsigned long long *bins) {
+static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, size_t first, int W, size_t stride1, size_t stride2,
+                             const float *boxes9, float hmin, float hmax, size_t nbins, unsigned long long *bins) {
     // ---- what every frame of the group comes to on the host: box, grid dims.  One shape for all of them, or no batch.
     const float cutoff = q->cutoff;
     if (!(cutoff > 0.0f)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: cutoff must be positive (got %g)", (double)cutoff);
-    const size_t nsel = q->idx1 ? q->n1 : q->natoms1;
-    if (nsel == 0 || nsel >= 0x7FFFFFFFull || q->natoms1 >= 0xFFFFFFFFull) return 1;
+    const bool two = q->kind == MOLAR_HIP_SEARCH_DOUBLE;
+    const int nsets = two ? 2 : 1;
+    const size_t nsel[2] = {q->idx1 ? q->n1 : q->natoms1, two ? (q->idx2 ? q->n2 : q->natoms2) : 0};
+    for (int s = 0; s < nsets; ++s)
+        if (nsel[s] == 0 || nsel[s] >= 0x7FFFFFFFull || (s ? q->natoms2 : q->natoms1) >= 0xFFFFFFFFull) return 1;
     molar_hip_box boxes[HIST_BATCH];
     uint32_t dims[3] = {0, 0, 0};
     for (int f = 0; f < W; ++f) {
@@ -2780,23 +2783,26 @@ static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, s
         else if (dims[0] != c->dims[0] || dims[1] != c->dims[1] || dims[2] != c->dims[2]) return 1;
     }
     const uint64_t ncells64 = (uint64_t)dims[0] * dims[1] * dims[2];
-    if (ncells64 + 1 > 32768ull || (uint64_t)nsel > 384ull * ncells64) return 1;      // one-wave scan per frame; big cells are ordered by a device sort
-    const uint32_t ncells = (uint32_t)ncells64, n = (uint32_t)nsel;
-    c->kind = MOLAR_HIP_SEARCH_SINGLE;
+    if (ncells64 + 1 > 32768ull) return 1;                                   // one-wave scan per frame
+    for (int s = 0; s < nsets; ++s)
+        if ((uint64_t)nsel[s] > 384ull * ncells64) return 1;               // big cells are ordered by a device sort
+    const uint32_t ncells = (uint32_t)ncells64;
+    const uint32_t n[2] = {(uint32_t)nsel[0], (uint32_t)nsel[1]};
+    c->kind = q->kind;
     c->use_box = true;
     c->pbc = q->pbc & 7u;
     c->cutoff = cutoff;
     c->have_search = false;
     c->hold_valid = false;
-    c->ntasks = ncells64 * 14ull;
+    c->ntasks = ncells64 * 14ull * (two ? 2ull : 1ull);
     // slots of one frame (prepare_search) incl. the 32-row slots of the same-cell entries
-    const uint64_t bound1 = 14ull * (((uint64_t)n + 63ull) / 64ull) + c->ntasks + 28ull * 512ull + ((uint64_t)n + 31ull) / 32ull + ncells64;
+    const uint64_t bound1 = (two ? 28ull : 14ull) * (((uint64_t)n[0] + 63ull) / 64ull) + c->ntasks + 28ull * 512ull + ((uint64_t)n[0] + 31ull) / 32ull + ncells64;
     const uint64_t bound = bound1 * (uint64_t)W;
     if (bound >= 0xFFFFFFF0ull) return 1;
     const int gen = (c->hist_gen ^= 1);
     MH_TRY(c->hb_lean[gen].reserve((bound1 * HIST_BATCH + 1) * sizeof(SlotDesc)));
     MH_TRY(c->hb_rest[gen].reserve((bound1 * HIST_BATCH + 1) * sizeof(SlotDesc)));
-    const size_t blk_bytes = HIST_BATCH * (sizeof(SearchParams) + sizeof(GridFrame));
+    const size_t blk_bytes = HIST_BATCH * (sizeof(SearchParams) + 2 * sizeof(GridFrame));
     MH_TRY(c->hb_blocks[gen].reserve(blk_bytes));
     if (!c->hb_pin) {
         MH_HIP(hipHostMalloc(&c->hb_pin, 4 * blk_bytes, hipHostMallocDefault));
@@ -2816,7 +2822,7 @@ static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, s
     }
     uint32_t *queue = c->hist_queue.as<uint32_t>();
     const int lslot = (int)(c->hist_frames++ & 3u);
-    // ---- the group's records in the pinned slot: parameter blocks, then grid records
+    // ---- the group's records in the pinned slot: parameter blocks, then grid records (first sets, second sets)
     const int pslot = c->hb_pin_next++ & 3;
     if (c->hb_pin_used[pslot]) MH_HIP(hipEventSynchronize(c->hb_pin_ev[pslot]));      // its copy of four groups ago has long run
     char *pin = (char *)c->hb_pin + (size_t)pslot * blk_bytes;
@@ -2825,19 +2831,22 @@ static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, s
     SearchParams *dP = c->hb_blocks[gen].as<SearchParams>();
     GridFrame *dG = reinterpret_cast<GridFrame *>((char *)c->hb_blocks[gen].p + HIST_BATCH * sizeof(SearchParams));
     mh::GridSet *keep_set = c->set;
-    const uint32_t pad_shift = grid_pad_shift(n, ncells);
+    const uint32_t pad_shift[2] = {grid_pad_shift(n[0], ncells), two ? grid_pad_shift(n[1], ncells) : 0u};
     size_t dyn_lds = (size_t)nbins * 4;
     bool big = false;
     for (int f = 0; f < W; ++f) {
-        mh::GridSet &S = c->hb_sets[gen][f];
-        S.n = n;
-        S.d_xyz = q->xyz1 + (first + f) * stride1;
-        S.d_idx = q->idx1;
-        S.d_vdw = nullptr;
-        const int rrc = grid_reserve(S, ncells);
-        if (rrc) { c->set = keep_set; return rrc; }
+        mh::GridSet *SS = c->hb_sets[gen][f];
+        for (int s = 0; s < nsets; ++s) {
+            mh::GridSet &S = SS[s];
+            S.n = n[s];
+            S.d_xyz = s ? q->xyz2 + (first + f) * stride2 : q->xyz1 + (first + f) * stride1;
+            S.d_idx = s ? q->idx2 : q->idx1;
+            S.d_vdw = nullptr;
+            const int rrc = grid_reserve(S, ncells);
+            if (rrc) { c->set = keep_set; return rrc; }
+        }
         c->box = boxes[f];
-        c->set = &S;                              // (SINGLE: set[1] is never read)
+        c->set = SS;                              // (SINGLE: set[1] is never read)
         c->nslots_bound = bound;
         SearchParams P = make_params(c);
         P.nblocks = 0;
@@ -2857,21 +2866,24 @@ static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, s
         }
         P.hist_nslots = hist_list_count(queue, lslot, 1);
         hP[f] = P;
-        GridFrame g{};
-        g.P = grid_bin_params(c, S);
-        g.key = S.key.as<uint32_t>();
-        g.cursor = S.cursor.as<uint32_t>();
-        g.cell_count = S.cell_count.as<uint32_t>();
-        g.cnt_pad = S.cnt_pad.as<uint32_t>();
-        g.counters = pad_shift ? g.cnt_pad : g.cell_count;
-        g.tmp_key = S.tmp_key.as<uint32_t>();
-        g.sorted = S.sorted.as<float4>();
-        g.aabb = S.aabb.as<float4>();
-        g.perm = S.perm.as<float4>();
-        g.chunk_aabb = S.chunk_aabb.as<float4>();
-        g.cell_org = S.cell_org.as<float4>();
-        g.h16 = S.h16.as<uint4>();
-        hG[f] = g;
+        for (int s = 0; s < nsets; ++s) {
+            mh::GridSet &S = SS[s];
+            GridFrame g{};
+            g.P = grid_bin_params(c, S);
+            g.key = S.key.as<uint32_t>();
+            g.cursor = S.cursor.as<uint32_t>();
+            g.cell_count = S.cell_count.as<uint32_t>();
+            g.cnt_pad = S.cnt_pad.as<uint32_t>();
+            g.counters = pad_shift[s] ? g.cnt_pad : g.cell_count;
+            g.tmp_key = S.tmp_key.as<uint32_t>();
+            g.sorted = S.sorted.as<float4>();
+            g.aabb = S.aabb.as<float4>();
+            g.perm = S.perm.as<float4>();
+            g.chunk_aabb = S.chunk_aabb.as<float4>();
+            g.cell_org = S.cell_org.as<float4>();
+            g.h16 = S.h16.as<uint4>();
+            hG[s * HIST_BATCH + f] = g;
+        }
     }
     c->set = keep_set;
     // ---- side stream: records, grids, plans
@@ -2882,28 +2894,32 @@ static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, s
     c->hb_pin_used[pslot] = true;
     {
         const unsigned fw = (unsigned)W;
-        const size_t na = (size_t)ncells + 1, npad = pad_shift ? ((size_t)ncells << pad_shift) : 0;
-        const unsigned zb = (unsigned)std::min<size_t>((na + npad + 255) / 256, 512u);
-        // (padded counters: unpad_scan_frames_kernel leaves them zero; a generation's sets are zeroed when they are new)
-        bool need_zero = !pad_shift;
-        for (int f = 0; f < W; ++f) {
-            if (!c->hb_zeroed[gen][f] || c->hb_zeroed_cells[gen][f] != ncells) need_zero = true;
-            c->hb_zeroed[gen][f] = pad_shift != 0;
-            c->hb_zeroed_cells[gen][f] = ncells;
+        for (int s = 0; s < nsets; ++s) {        // the grids of the group's first sets, then of its second sets
+            const GridFrame *G = dG + s * HIST_BATCH;
+            const uint32_t ns = n[s], ps = pad_shift[s];
+            const size_t na = (size_t)ncells + 1, npad = ps ? ((size_t)ncells << ps) : 0;
+            const unsigned zb = (unsigned)std::min<size_t>((na + npad + 255) / 256, 512u);
+            // (padded counters: unpad_scan_frames_kernel leaves them zero; a generation's sets are zeroed when they are new)
+            bool need_zero = !ps;
+            for (int f = 0; f < W; ++f) {
+                if (!c->hb_zeroed[gen][f][s] || c->hb_zeroed_cells[gen][f][s] != ncells) need_zero = true;
+                c->hb_zeroed[gen][f][s] = ps != 0;
+                c->hb_zeroed_cells[gen][f][s] = ncells;
+            }
+            if (need_zero) hipLaunchKernelGGL(zero_frames_kernel, dim3(zb, fw), dim3(256), 0, ss, G, na, npad);
+            const bool tile_ok = ncells <= BIN_TILE_MAX_CELLS && (uint64_t)ns >= 16ull * ncells;
+            if (tile_ok && ns >= (1u << 19))
+                hipLaunchKernelGGL(bin_tile_frames_kernel<32>, dim3((ns + 256u * 32u - 1u) / (256u * 32u), fw), dim3(256), (size_t)ncells * 4, ss, G, ps, ncells);
+            else if (tile_ok && ns >= (1u << 17))
+                hipLaunchKernelGGL(bin_tile_frames_kernel<8>, dim3((ns + 256u * 8u - 1u) / (256u * 8u), fw), dim3(256), (size_t)ncells * 4, ss, G, ps, ncells);
+            else
+                hipLaunchKernelGGL(bin_frames_kernel, dim3((ns + 255u) / 256u, fw), dim3(256), 0, ss, G, ps);
+            if (ps) hipLaunchKernelGGL(unpad_scan_frames_kernel, dim3(fw), dim3(256), 0, ss, G, ncells, ps);
+            else hipLaunchKernelGGL(scan_frames_kernel, dim3(fw), dim3(64), 0, ss, G, ncells + 1u);
+            hipLaunchKernelGGL(scatter_frames_kernel, dim3((ns + 255u) / 256u, fw), dim3(256), 0, ss, G, ns);
+            hipLaunchKernelGGL(place_order_frames_kernel, dim3(ncells, fw), dim3(64), 0, ss, G, ncells, q->ids_local);
         }
-        if (need_zero) hipLaunchKernelGGL(zero_frames_kernel, dim3(zb, fw), dim3(256), 0, ss, dG, na, npad);
-        const bool tile_ok = ncells <= BIN_TILE_MAX_CELLS && (uint64_t)n >= 16ull * ncells;
-        if (tile_ok && n >= (1u << 19))
-            hipLaunchKernelGGL(bin_tile_frames_kernel<32>, dim3((n + 256u * 32u - 1u) / (256u * 32u), fw), dim3(256), (size_t)ncells * 4, ss, dG, pad_shift, ncells);
-        else if (tile_ok && n >= (1u << 17))
-            hipLaunchKernelGGL(bin_tile_frames_kernel<8>, dim3((n + 256u * 8u - 1u) / (256u * 8u), fw), dim3(256), (size_t)ncells * 4, ss, dG, pad_shift, ncells);
-        else
-            hipLaunchKernelGGL(bin_frames_kernel, dim3((n + 255u) / 256u, fw), dim3(256), 0, ss, dG, pad_shift);
-        if (pad_shift) hipLaunchKernelGGL(unpad_scan_frames_kernel, dim3(fw), dim3(256), 0, ss, dG, ncells, pad_shift);
-        else hipLaunchKernelGGL(scan_frames_kernel, dim3(fw), dim3(64), 0, ss, dG, ncells + 1u);
-        hipLaunchKernelGGL(scatter_frames_kernel, dim3((n + 255u) / 256u, fw), dim3(256), 0, ss, dG, n);
-        hipLaunchKernelGGL(place_order_frames_kernel, dim3(ncells, fw), dim3(64), 0, ss, dG, ncells, q->ids_local);
-        launch_hist_plan_frames(MOLAR_HIP_SEARCH_SINGLE, ss, dP, fw, c->ntasks, c->hb_lean[gen].as<SlotDesc>(), c->hb_rest[gen].as<SlotDesc>(), queue, lslot);
+        launch_hist_plan_frames(q->kind, ss, dP, fw, c->ntasks, c->hb_lean[gen].as<SlotDesc>(), c->hb_rest[gen].as<SlotDesc>(), queue, lslot);
         // The generic kernel (the triclinic corner entries of every frame of the group: short latency-bound slots) runs HERE, behind
         // its plan on the side stream, not behind the persistent kernel on the main stream: there it met the next group's placement
         // kernel - 10^4 one-wave workgroups of 5 KB of LDS each, from the stream of higher priority - and waited for it to drain
@@ -2911,8 +2927,12 @@ static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, s
         uint32_t nblk = ((uint32_t)bound + (uint32_t)waves_per_block(MODE_HIST) - 1u) / (uint32_t)waves_per_block(MODE_HIST);
         const uint32_t cap = (uint32_t)c->num_cus * 8u;
         if (nblk > cap) nblk = cap;
-        launch_pair_single(MODE_HIST, nblk, dyn_lds, ss, dP, c->hb_rest[gen].as<SlotDesc>(), (uint32_t)bound, c->slot_cnt.as<uint32_t>(),
-                           c->slot_base.as<unsigned long long>(), nullptr, nullptr, nullptr);
+        if (two)
+            launch_pair_double(MODE_HIST, nblk, dyn_lds, ss, dP, c->hb_rest[gen].as<SlotDesc>(), (uint32_t)bound, c->slot_cnt.as<uint32_t>(),
+                               c->slot_base.as<unsigned long long>(), nullptr, nullptr, nullptr);
+        else
+            launch_pair_single(MODE_HIST, nblk, dyn_lds, ss, dP, c->hb_rest[gen].as<SlotDesc>(), (uint32_t)bound, c->slot_cnt.as<uint32_t>(),
+                               c->slot_base.as<unsigned long long>(), nullptr, nullptr, nullptr);
         MH_HIP(hipGetLastError());
     }
     MH_HIP(hipEventRecord(c->grid_done, ss));
@@ -2920,7 +2940,7 @@ static int hist_frames_group(molar_hip_ctx *c, const molar_hip_search_desc *q, s
     MH_HIP(hipStreamWaitEvent(c->stream, c->grid_done, 0));
     {
         Prof prof(c, 3);
-        launch_hist_lean(MOLAR_HIP_SEARCH_SINGLE, (unsigned)c->num_cus, dyn_lds, c->stream, dP, c->hb_lean[gen].as<SlotDesc>(), (uint32_t)bound, queue, lslot, big);
+        launch_hist_lean(q->kind, (unsigned)c->num_cus, dyn_lds, c->stream, dP, c->hb_lean[gen].as<SlotDesc>(), (uint32_t)bound, queue, lslot, big);
         MH_HIP(hipGetLastError());
     }
     if (!c->gen_free[gen]) MH_HIP(hipEventCreateWithFlags(&c->gen_free[gen], hipEventDisableTiming));
@@ -2937,15 +2957,18 @@ int molar_hip_search_histogram_frames(molar_hip_ctx *c, const molar_hip_search_d
     if (nframes == 0) return MOLAR_HIP_OK;
     if (!q->xyz1) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: xyz pointer is null");
     MH_HIP(hipSetDevice(c->device));
-    // the batched form: one set, periodic, everything the kernels read already in device memory, a context with its own streams
-    const bool batch = q->kind == MOLAR_HIP_SEARCH_SINGLE && (q->box9 || boxes9) && c->own_stream && !c->env_no_side && is_device_ptr(bins) &&
-                       is_device_ptr(q->xyz1) && (!q->idx1 || is_device_ptr(q->idx1)) && !c->tickets[0].pending && !c->tickets[1].pending;
+    // the batched form: fixed-cutoff kinds, periodic, everything the kernels read already in device memory, a context with its own streams
+    const bool two = q->kind == MOLAR_HIP_SEARCH_DOUBLE;
+    if (two && !q->xyz2) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search: xyz pointer is null");
+    const bool batch = (q->kind == MOLAR_HIP_SEARCH_SINGLE || two) && (q->box9 || boxes9) && c->own_stream && !c->env_no_side && is_device_ptr(bins) &&
+                       is_device_ptr(q->xyz1) && (!q->idx1 || is_device_ptr(q->idx1)) &&
+                       (!two || (is_device_ptr(q->xyz2) && (!q->idx2 || is_device_ptr(q->idx2)))) && !c->tickets[0].pending && !c->tickets[1].pending;
     size_t f = 0;
     while (f < nframes) {
         const int W = (int)std::min<size_t>(HIST_BATCH, nframes - f);
         int rc = 1;
         if (batch && W >= 2) {
-            rc = hist_frames_group(c, q, f, W, xyz1_stride, boxes9, hmin, hmax, nbins, reinterpret_cast<unsigned long long *>(bins));
+            rc = hist_frames_group(c, q, f, W, xyz1_stride, xyz2_stride, boxes9, hmin, hmax, nbins, reinterpret_cast<unsigned long long *>(bins));
             if (rc < 0 || rc > 1) return rc;
         }
         if (rc == 1) {               // frame by frame (the form molar_hip_search_histogram documents), same sums

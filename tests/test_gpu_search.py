@@ -1472,6 +1472,65 @@ def test_fused_histogram_frames_equals_single_calls(eng, orc32, boxkind, n, cuto
     assert one.sum() > 0
 
 
+@pytest.mark.parametrize("boxkind,n,cutoff,nframes,pbc,own_frames", [
+    ("a", 24000, 0.9, 9, 7, False),         # two selections of one trajectory (ions / water): same frames, two indices
+    ("ortho", 16000, 0.8, 5, 7, True),      # the second set has frames of its own (another stride), no index on it
+    ("b", 150000, 0.9, 4, 7, False),        # a first set of >= 2^17 atoms (tiled binning) against a small second one
+    ("ortho", 10000, 0.9, 6, 3, False),     # z not periodic
+])
+def test_fused_histogram_frames_two_sets(eng, orc32, boxkind, n, cutoff, nframes, pbc, own_frames):
+    """The frames form for distance_search_double_pbc (a radial distribution between two selections): groups of frames share
+    their launches, both sets' grids built by the frame-indexed kernels; integer bins equal to one call per frame and to the
+    oracle's distance stream, same-cell duplicates included (overlapping selections)."""
+    import torch
+    a = api()
+    e2 = a.Engine(0)
+    nbins = 300
+    box = {"a": synth.box_a, "b": synth.box_b, "ortho": synth.box_ortho}[boxkind](n)
+    frames_np = np.stack([synth.frame(n, box, 40 + f) for f in range(nframes)])
+    rng = np.random.default_rng(11)
+    n1 = n - n // 5 if boxkind == "b" else n // 3
+    idx1 = np.sort(rng.choice(n, n1, replace=False)).astype(np.uint64)
+    dframes = torch.from_numpy(frames_np).cuda()
+    if own_frames:
+        m = n // 2
+        f2_np = np.stack([synth.frame(m, box, 90 + f) for f in range(nframes)])
+        store = torch.zeros((nframes, m + 11, 3), dtype=torch.float32, device="cuda")
+        store[:, :m] = torch.from_numpy(f2_np).cuda()
+        d2, idx2 = store[:, :m], None
+    else:
+        f2_np = frames_np
+        n2 = n // 40 if boxkind == "b" else n // 4
+        idx2 = np.sort(rng.choice(n, n2, replace=False)).astype(np.uint64)      # overlaps idx1: pairs of an atom with itself at d = 0
+        d2 = None
+    didx1 = torch.from_numpy(idx1.astype(np.int64)).cuda()
+    didx2 = None if idx2 is None else torch.from_numpy(idx2.astype(np.int64)).cuda()
+    want = np.zeros(nbins, np.int64)
+    ob = orc32.box_from_matrix(box)
+    for f in range(nframes):
+        p1 = frames_np[f][idx1.astype(int)]
+        p2 = f2_np[f] if idx2 is None else f2_np[f][idx2.astype(int)]
+        ref = orc32.search_double_pbc(cutoff, p1, p2, ob, pbc, nthreads=8)
+        want += orc32.histogram_add(0.0, cutoff, nbins, ref["d"]).astype(np.int64)
+    bins_f = torch.zeros(nbins, dtype=torch.int64, device="cuda")
+    bins_s = torch.zeros(nbins, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(2):
+        e2.search_histogram_frames(a.SEARCH_DOUBLE, cutoff, 0.0, cutoff, nbins, dframes, idx1=didx1, box=box, pbc=pbc, bins=bins_f, frames2=d2, idx2=didx2)
+    e2.search_histogram_frames(a.SEARCH_SINGLE, cutoff, 0.0, cutoff, nbins, dframes[:3], idx1=didx1, box=box, pbc=pbc, bins=bins_s)   # the other kind in between
+    e2.search_histogram_frames(a.SEARCH_DOUBLE, cutoff, 0.0, cutoff, nbins, dframes, idx1=didx1, box=box, pbc=pbc, bins=bins_f, frames2=d2, idx2=didx2)
+    e2.synchronize()
+    assert want.sum() > 0
+    got = bins_f.cpu().numpy()
+    assert np.array_equal(got, 3 * want), (int(got.sum()), int(3 * want.sum()))
+    bins_1 = torch.zeros(nbins, dtype=torch.int64, device="cuda")
+    for f in range(nframes):
+        e2.search_histogram(a.SEARCH_DOUBLE, cutoff, 0.0, cutoff, nbins, dframes[f], didx1, dframes[f] if d2 is None else d2[f], didx2, box=box, pbc=pbc,
+                            bins=bins_1, want_count=False)
+    e2.synchronize()
+    assert np.array_equal(bins_1.cpu().numpy(), want)
+
+
 def test_fused_histogram_frames_host_inputs(eng, orc32):
     """Frames in host memory (or host bins) are walked frame by frame: the same sums."""
     a = api()

@@ -5,7 +5,8 @@ grid), cutoff, periodicity, index, bin count and range go through the frames for
 calls and host-bins calls in between - and must leave exactly the bins that one waited molar_hip_search_histogram call per frame
 leaves on a second context (the form tools/fuzz_search.py checks against the oracle); every 8th block is checked against the
 oracle directly.  Exercises the groups of <= 16 frames, both generations of the group buffers, the four pairs of list counters
-and the fall-back to single calls.
+and the fall-back to single calls.  A third of the blocks are of kind DOUBLE (two selections of the same frames, overlapping
+now and then): both sets' grids per frame.
 Usage: python tools/fuzz_hist_frames.py [nblocks] [seed]"""
 import os
 import sys
@@ -48,32 +49,45 @@ def main():
         for f in range(F):
             frames[f] = (rng.random((n, 3)) @ boxes[f].astype(np.float64).T + rng.normal(0, rng.choice([0.0, 0.05, 0.4]), (n, 3))).astype(np.float32)
         idx = None if rng.random() < 0.6 else np.sort(rng.choice(n, max(n // 2, 2), replace=False)).astype(np.uint64)
+        two = rng.random() < 0.34
+        kind = api.SEARCH_DOUBLE if two else api.SEARCH_SINGLE
+        idx2 = None
+        if two:       # the second selection: a few atoms up to most of them; None = all atoms (every atom of set 1 is in it too)
+            idx2 = None if rng.random() < 0.2 else np.sort(rng.choice(n, max(int(n * rng.choice([0.02, 0.3, 0.8])), 1), replace=False)).astype(np.uint64)
         dframes = torch.from_numpy(frames).cuda()
         didx = None if idx is None else torch.from_numpy(idx.astype(np.int64)).cuda()
+        didx2 = None if idx2 is None else torch.from_numpy(idx2.astype(np.int64)).cuda()
+        second = dict(frames2=None, idx2=didx2) if two else {}
         got = torch.zeros(nbins, dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         box_arg = box0 if mode == "one" else boxes
-        tag = f"block {blk}: n {n} F {F} rc {rc:.3f} pbc {pbc} nbins {nbins} boxes {mode} idx {idx is not None}"
+        tag = f"block {blk}: n {n} F {F} rc {rc:.3f} pbc {pbc} nbins {nbins} boxes {mode} idx {idx is not None} two {two} idx2 {idx2 is not None}"
+
+        def one_call(e, xyz, i1, i2, bx, **kw):
+            return e.search_histogram(kind, rc, hmin, hmax, nbins, xyz, i1, xyz if two else None, i2 if two else None, box=bx, pbc=pbc, **kw)
         try:
             reps = int(rng.choice([1, 1, 2]))
             extra = np.zeros(nbins, np.int64)
             for r in range(reps):
-                eng.search_histogram_frames(api.SEARCH_SINGLE, rc, hmin, hmax, nbins, dframes, idx1=didx, box=box_arg, pbc=pbc, bins=got)
+                eng.search_histogram_frames(kind, rc, hmin, hmax, nbins, dframes, idx1=didx, box=box_arg, pbc=pbc, bins=got, **second)
                 if rng.random() < 0.4:        # a queued single-frame call on the same bins in between
                     k = int(rng.integers(0, F))
-                    eng.search_histogram(api.SEARCH_SINGLE, rc, hmin, hmax, nbins, dframes[k], idx1=didx, box=boxes[k], pbc=pbc, bins=got, want_count=False)
-                    hb, _ = ref_eng.search_histogram(api.SEARCH_SINGLE, rc, hmin, hmax, nbins, frames[k], idx, box=boxes[k], pbc=pbc)
+                    one_call(eng, dframes[k], didx, didx2, boxes[k], bins=got, want_count=False)
+                    hb, _ = one_call(ref_eng, frames[k], idx, idx2, boxes[k])
                     extra += hb.astype(np.int64)
             eng.synchronize()
             want = np.zeros(nbins, np.int64)
             for f in range(F):
-                hb, _ = ref_eng.search_histogram(api.SEARCH_SINGLE, rc, hmin, hmax, nbins, frames[f], idx, box=boxes[f], pbc=pbc)
+                hb, _ = one_call(ref_eng, frames[f], idx, idx2, boxes[f])
                 want += hb.astype(np.int64)
             if blk % 8 == 0:
                 wo = np.zeros(nbins, np.int64)
                 for f in range(F):
                     p = frames[f] if idx is None else frames[f][idx.astype(int)]
-                    ref = o.search_single_pbc(rc, p, o.box_from_matrix(boxes[f]), pbc, nthreads=8)
+                    if two:
+                        ref = o.search_double_pbc(rc, p, frames[f] if idx2 is None else frames[f][idx2.astype(int)], o.box_from_matrix(boxes[f]), pbc, nthreads=8)
+                    else:
+                        ref = o.search_single_pbc(rc, p, o.box_from_matrix(boxes[f]), pbc, nthreads=8)
                     wo += o.histogram_add(hmin, hmax, nbins, ref["d"]).astype(np.int64)
                 if not np.array_equal(wo, want):
                     fails += 1
