@@ -621,6 +621,12 @@ int molar_hip_xtc_read_device(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t
  * molar_hip_xtc_read + molar_hip_search_histogram frame by frame. */
 int molar_hip_xtc_histogram(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t first, size_t count, const uint64_t *idx, size_t n,
                             float cutoff, uint8_t pbc, float hmin, float hmax, size_t nbins, uint64_t *bins, int decode_threads);
+/* The same between TWO selections of every frame (distance_search_double_pbc: the radial distribution of one species around
+ * another); idx1 / idx2 NULL = all atoms.  Selections may overlap (an atom against itself counts at distance 0, as in the
+ * reference). */
+int molar_hip_xtc_histogram_double(molar_hip_ctx *ctx, const molar_hip_xtc *x, size_t first, size_t count, const uint64_t *idx1,
+                                   size_t n1, const uint64_t *idx2, size_t n2, float cutoff, uint8_t pbc, float hmin, float hmax,
+                                   size_t nbins, uint64_t *bins, int decode_threads);
 /* Writer (xtc_handler.rs:117-168, write_state through molly::XTCWriter): ONE frame in GROMACS' compressed coordinate format
  * (magic 1995; xdrfile's algorithm: integer grid at `precision`, mixed-radix triples, runs of small deltas with an adaptive
  * delta size) into out[cap]; *out_len = bytes written, frames are simply concatenated in a file.  96 + 16 * natoms bytes

@@ -615,6 +615,10 @@ class Histogram1D {
     // threads and the fused histogram of 16-frame windows overlap inside it; every frame's own box; `index` empty = all atoms
     void add_distances_trajectory_single_pbc(Engine &eng, const class XtcReader &traj, size_t first, size_t count, Float cutoff,
                                              const std::vector<usize> &index, PbcDims pbc_dims, int decode_threads = 0);
+    // ... and between two selections of every frame (distance_search_double_pbc; molar_hip_xtc_histogram_double)
+    void add_distances_trajectory_double_pbc(Engine &eng, const class XtcReader &traj, size_t first, size_t count, Float cutoff,
+                                             const std::vector<usize> &index1, const std::vector<usize> &index2, PbcDims pbc_dims,
+                                             int decode_threads = 0);
     const std::vector<uint64_t> &counts() const { return counts_; }
     // adds another histogram of the same shape bin by bin (the integer reduction at the end of a frame-parallel run:
     // AnalysisTask::run_sharded, or one all_reduce of these counters across ranks)
@@ -928,6 +932,14 @@ inline void Histogram1D::add_distances_trajectory_single_pbc(Engine &eng, const 
                                                              const std::vector<usize> &index, PbcDims pbc_dims, int decode_threads) {
     check(molar_hip_xtc_histogram(eng.ctx(), traj.handle(), first, count, index.empty() ? nullptr : index.data(), index.size(), cutoff,
                                   pbc_dims.raw(), min_, max_, counts_.size(), counts_.data(), decode_threads));
+}
+
+inline void Histogram1D::add_distances_trajectory_double_pbc(Engine &eng, const XtcReader &traj, size_t first, size_t count, Float cutoff,
+                                                             const std::vector<usize> &index1, const std::vector<usize> &index2,
+                                                             PbcDims pbc_dims, int decode_threads) {
+    check(molar_hip_xtc_histogram_double(eng.ctx(), traj.handle(), first, count, index1.empty() ? nullptr : index1.data(), index1.size(),
+                                         index2.empty() ? nullptr : index2.data(), index2.size(), cutoff, pbc_dims.raw(), min_, max_,
+                                         counts_.size(), counts_.data(), decode_threads));
 }
 
 // XTC writer: FileFormatHandler::create + write_state (xtc_handler.rs:54-62, 117-168); frames are appended to one file.

@@ -137,6 +137,7 @@ SYMBOLS = {
     "molar_hip_rmsd_mw": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P]),
     "molar_hip_fit_transform": (_I, [_P, _P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _SZ, _P, _I, _P, _P]),
     "molar_hip_xtc_histogram": (_I, [_P, _P, _SZ, _SZ, _P, _SZ, _F, _U8, _F, _F, _SZ, _P, _I]),
+    "molar_hip_xtc_histogram_double": (_I, [_P, _P, _SZ, _SZ, _P, _SZ, _P, _SZ, _F, _U8, _F, _F, _SZ, _P, _I]),
     "molar_hip_fit_stream_create": (_I, [_P, _SZ, _P, _SZ, _P, _P, _SZ, _P, _I, _P]),
     "molar_hip_fit_stream_begin": (_I, [_P, _P, _I, _P]),
     "molar_hip_fit_stream_end": (_I, [_P, C.c_int32, _P, _P, _P, _P, _P]),

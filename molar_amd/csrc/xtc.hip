@@ -657,18 +657,22 @@ int molar_hip_xtc_read(molar_hip_ctx *c, const molar_hip_xtc *x, size_t first, s
 // the context's auxiliary context, while the window before is in its histogram kernels - and every window goes through
 // molar_hip_search_histogram_frames (one selection, every frame's own box from its header) into device-resident bins; at the end
 // the bins are ADDED into the caller's host array (Histogram1D::add_one over the whole block, molar_membrane/src/stats.rs:29-35).
-int molar_hip_xtc_histogram(molar_hip_ctx *c, const molar_hip_xtc *x, size_t first, size_t count, const uint64_t *idx, size_t n, float cutoff,
-                            uint8_t pbc, float hmin, float hmax, size_t nbins, uint64_t *bins, int decode_threads) {
+// (`two`: distance_search_double_pbc between the selections idx / idx2 of every frame; a NULL index = all atoms)
+static int xtc_histogram_impl(molar_hip_ctx *c, const molar_hip_xtc *x, size_t first, size_t count, const uint64_t *idx, size_t n, bool two,
+                              const uint64_t *idx2, size_t n2, float cutoff, uint8_t pbc, float hmin, float hmax, size_t nbins, uint64_t *bins,
+                              int decode_threads) {
     if (!c || !x || !bins) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "xtc_histogram: null argument");
     if (nbins == 0 || nbins > 8192) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_histogram: nbins must be in 1..8192");
     if (count == 0) return MOLAR_HIP_OK;
     if (first + count > x->frames.size()) return fail(MOLAR_HIP_ERR_IO, "xtc_histogram: frames %zu..%zu past the end (%zu frames)", first, first + count, x->frames.size());
-    if (is_device_ptr(bins) || is_device_ptr(idx)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "xtc_histogram: index and bins are host arrays");
+    if (is_device_ptr(bins) || is_device_ptr(idx) || is_device_ptr(idx2)) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "xtc_histogram: index and bins are host arrays");
     const size_t natoms = (size_t)x->frames[first].natoms;
     for (size_t k = first; k < first + count; ++k)
         if ((size_t)x->frames[k].natoms != natoms) return fail(MOLAR_HIP_ERR_SIZES, "xtc_histogram: frame %zu has %d atoms, frame %zu has %zu", k, x->frames[k].natoms, first, natoms);
     for (size_t k = 0; idx && k < n; ++k)
         if (idx[k] >= natoms) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "xtc_histogram: index %llu out of range", (unsigned long long)idx[k]);
+    for (size_t k = 0; idx2 && k < n2; ++k)
+        if (idx2[k] >= natoms) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "xtc_histogram: index %llu out of range", (unsigned long long)idx2[k]);
     MH_HIP(hipSetDevice(c->device));
     if (!c->aux) {
         c->aux = molar_hip_create(c->device);
@@ -678,13 +682,17 @@ int molar_hip_xtc_histogram(molar_hip_ctx *c, const molar_hip_xtc *x, size_t fir
     const size_t fbytes = natoms * 12;
     MH_TRY(c->xh_win[0].reserve(WIN * fbytes));
     MH_TRY(c->xh_win[1].reserve(WIN * fbytes));
-    MH_TRY(c->xh_bins.reserve(nbins * 8 + (idx ? n * 8 : 0)));
+    MH_TRY(c->xh_bins.reserve(nbins * 8 + (idx ? n * 8 : 0) + (idx2 ? n2 * 8 : 0)));
     unsigned long long *dbins = c->xh_bins.as<unsigned long long>();
-    const uint64_t *didx = nullptr;
+    const uint64_t *didx = nullptr, *didx2 = nullptr;
     MH_HIP(hipMemsetAsync(dbins, 0, nbins * 8, c->stream));
     if (idx) {
         didx = reinterpret_cast<const uint64_t *>(dbins + nbins);
         MH_HIP(hipMemcpyAsync(const_cast<uint64_t *>(didx), idx, n * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (idx2) {
+        didx2 = reinterpret_cast<const uint64_t *>(dbins + nbins) + (idx ? n : 0);
+        MH_HIP(hipMemcpyAsync(const_cast<uint64_t *>(didx2), idx2, n2 * 8, hipMemcpyHostToDevice, c->stream));
     }
     MH_HIP(hipStreamSynchronize(c->stream));
     const size_t nwin = (count + WIN - 1) / WIN;
@@ -708,15 +716,21 @@ int molar_hip_xtc_histogram(molar_hip_ctx *c, const molar_hip_xtc *x, size_t fir
         const size_t f0 = first + w * WIN, k = std::min(WIN, first + count - f0);
         for (size_t f = 0; f < k; ++f) std::memcpy(&boxes[9 * f], x->frames[f0 + f].box, 36);
         molar_hip_search_desc q{};
-        q.kind = MOLAR_HIP_SEARCH_SINGLE;
+        q.kind = two ? MOLAR_HIP_SEARCH_DOUBLE : MOLAR_HIP_SEARCH_SINGLE;
         q.cutoff = cutoff;
         q.xyz1 = c->xh_win[w & 1].as<float>();
         q.natoms1 = natoms;
         q.idx1 = didx;
         q.n1 = idx ? n : 0;
+        if (two) {
+            q.xyz2 = q.xyz1;
+            q.natoms2 = natoms;
+            q.idx2 = didx2;
+            q.n2 = idx2 ? n2 : 0;
+        }
         q.box9 = boxes.data();
         q.pbc = pbc;
-        rc = molar_hip_search_histogram_frames(c, &q, k, natoms * 3, 0, boxes.data(), hmin, hmax, nbins, reinterpret_cast<uint64_t *>(dbins));
+        rc = molar_hip_search_histogram_frames(c, &q, k, natoms * 3, natoms * 3, boxes.data(), hmin, hmax, nbins, reinterpret_cast<uint64_t *>(dbins));
     }
     if (helper.joinable()) helper.join();
     if (rc) {
@@ -728,6 +742,17 @@ int molar_hip_xtc_histogram(molar_hip_ctx *c, const molar_hip_xtc *x, size_t fir
     MH_HIP(hipStreamSynchronize(c->stream));
     for (size_t b = 0; b < nbins; ++b) bins[b] += h[b];
     return MOLAR_HIP_OK;
+}
+
+int molar_hip_xtc_histogram(molar_hip_ctx *c, const molar_hip_xtc *x, size_t first, size_t count, const uint64_t *idx, size_t n, float cutoff,
+                            uint8_t pbc, float hmin, float hmax, size_t nbins, uint64_t *bins, int decode_threads) {
+    return xtc_histogram_impl(c, x, first, count, idx, n, false, nullptr, 0, cutoff, pbc, hmin, hmax, nbins, bins, decode_threads);
+}
+
+int molar_hip_xtc_histogram_double(molar_hip_ctx *c, const molar_hip_xtc *x, size_t first, size_t count, const uint64_t *idx1, size_t n1,
+                                   const uint64_t *idx2, size_t n2, float cutoff, uint8_t pbc, float hmin, float hmax, size_t nbins, uint64_t *bins,
+                                   int decode_threads) {
+    return xtc_histogram_impl(c, x, first, count, idx1, n1, true, idx2, n2, cutoff, pbc, hmin, hmax, nbins, bins, decode_threads);
 }
 
 int molar_hip_xtc_read_device(molar_hip_ctx *c, const molar_hip_xtc *x, size_t first, size_t count, float *xyz_dev) {

@@ -128,10 +128,12 @@ class XtcReader:
         check(self.lib.molar_hip_xtc_read_device(self.engine.ctx, self.h, first, count, addr))
         return out
 
-    def histogram(self, first, count, cutoff, hmin, hmax, nbins, idx=None, pbc=7, bins=None, nthreads=None):
+    def histogram(self, first, count, cutoff, hmin, hmax, nbins, idx=None, pbc=7, bins=None, nthreads=None, idx2=None, two_sets=False):
         """molar_hip_xtc_histogram: the distances of distance_search_single_pbc of frames [first, first + count) - selection idx
         (None = all atoms) of every frame against itself, every frame's own box - through Histogram1D::add_one, decode and the
-        fused histogram overlapped inside the call.  Adds into `bins` (numpy uint64[nbins], made if None) and returns it."""
+        fused histogram overlapped inside the call.  With `idx2` (or two_sets=True: idx against all atoms) the distances are those
+        of distance_search_double_pbc between the two selections (molar_hip_xtc_histogram_double).  Adds into `bins` (numpy
+        uint64[nbins], made if None) and returns it."""
         if self.engine is None:
             raise ValueError("histogram needs an engine")
         from .api import pbc_mask
@@ -139,9 +141,16 @@ class XtcReader:
             bins = np.zeros(nbins, np.uint64)
         assert bins.dtype == np.uint64 and bins.flags.c_contiguous and len(bins) == nbins
         idx = None if idx is None else np.ascontiguousarray(idx, np.uint64)
-        check(self.lib.molar_hip_xtc_histogram(self.engine.ctx, self.h, first, count, None if idx is None else idx.ctypes.data,
-                                               0 if idx is None else len(idx), float(cutoff), pbc_mask(pbc), float(hmin), float(hmax), nbins,
-                                               bins.ctypes.data, self.nthreads if nthreads is None else nthreads))
+        idx2 = None if idx2 is None else np.ascontiguousarray(idx2, np.uint64)
+        nt = self.nthreads if nthreads is None else nthreads
+        a1, n1 = (None, 0) if idx is None else (idx.ctypes.data, len(idx))
+        if idx2 is not None or two_sets:
+            a2, n2 = (None, 0) if idx2 is None else (idx2.ctypes.data, len(idx2))
+            check(self.lib.molar_hip_xtc_histogram_double(self.engine.ctx, self.h, first, count, a1, n1, a2, n2, float(cutoff), pbc_mask(pbc),
+                                                          float(hmin), float(hmax), nbins, bins.ctypes.data, nt))
+        else:
+            check(self.lib.molar_hip_xtc_histogram(self.engine.ctx, self.h, first, count, a1, n1, float(cutoff), pbc_mask(pbc), float(hmin),
+                                                   float(hmax), nbins, bins.ctypes.data, nt))
         return bins
 
     # ---- FileFormatHandler mirror

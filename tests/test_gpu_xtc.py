@@ -217,6 +217,20 @@ def test_xtc_histogram_one_call(eng, orc32):
     assert np.array_equal(got, 2 * w_all)
     assert np.array_equal(r.histogram(5, 18, rc, 0.0, rc, nbins, idx=idx), want(5, 18, idx))
     assert np.array_equal(r.histogram(36, 1, rc, 0.0, rc, nbins), want(36, 1, None))
+    # between two selections of every frame (molar_hip_xtc_histogram_double): overlapping ones, and one against all atoms
+    idx2 = np.sort(np.random.default_rng(4).choice(n, n // 10, replace=False)).astype(np.uint64)
+
+    def want2(first, count, s1, s2):
+        w = np.zeros(nbins, np.uint64)
+        for f in range(first, first + count):
+            xyz = orc32.xtc_decode(blob, offs[f])[0]
+            fb = r.frame_info(f)["box9"].reshape(3, 3).T
+            ref = orc32.search_double_pbc(rc, xyz[s1.astype(int)], xyz if s2 is None else xyz[s2.astype(int)], orc32.box_from_matrix(fb), 7, nthreads=8)
+            w += orc32.histogram_add(0.0, rc, nbins, ref["d"]).astype(np.uint64)
+        return w
+    assert np.intersect1d(idx, idx2).size > 0
+    assert np.array_equal(r.histogram(2, 21, rc, 0.0, rc, nbins, idx=idx, idx2=idx2), want2(2, 21, idx, idx2))
+    assert np.array_equal(r.histogram(30, 7, rc, 0.0, rc, nbins, idx=idx2, two_sets=True), want2(30, 7, idx2, None))
     from molar_amd._lib import MolarHipError
     with pytest.raises(MolarHipError):
         r.histogram(30, 10, rc, 0.0, rc, nbins)
