@@ -20,7 +20,13 @@ enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2 };
 // histogram keeps 4: every workgroup owns an LDS histogram that it flushes with atomics at the end.
 // (round 4, count pass with 2 / 4 waves per workgroup - half / a quarter of the 2.9e5 workgroups, whose bare launch takes
 // 69 us: 0.42 / 0.45 ms against 0.40, three alternations on one box)
-constexpr int waves_per_block(int mode) { return mode == MODE_HIST ? 4 : 1; }
+#ifndef MH_COUNT_WPE
+#define MH_COUNT_WPE 7
+#endif
+#ifndef MH_WPB
+#define MH_WPB 1
+#endif
+constexpr int waves_per_block(int mode) { return mode == MODE_HIST ? 4 : MH_WPB; }
 constexpr int KREG = 8;            // B-cell chunks (of 64 atoms) a lane keeps in registers
 constexpr int FIFO_CAP = 128;      // per-wave LDS FIFO entries (flush threshold 64, push <= 64)
 #ifndef MOLAR_HIP_NO_WIDE_FLUSH
@@ -1632,7 +1638,7 @@ __device__ __forceinline__ bool hist_lean_slot(const SearchParams &P, uint32_t f
 // in the sheared box at rc 1.6 nm, 636 atoms per cell: 65 M pairs per ms against 220-240 up to 1.4 nm).  0: the usual budget.
 template <int KIND, int MODE, int WPE = 0>
 __global__ void __launch_bounds__(64 * waves_per_block(MODE))
-__attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? 7 : 8))))) pair_kernel(const SearchParams *__restrict__ Pp,
+__attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? MH_COUNT_WPE : 8))))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
                                                      const uint32_t nslots_arg,  // the host's bound: slots past the real count are empty
                                                      uint32_t *__restrict__ slot_cnt,
@@ -1654,7 +1660,12 @@ __attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE ==
     // (histogram mode over several frames: Pp is an array, one block per frame; the slot record says which.  The histogram's own
     // fields - bins, range, list counter - are the same in all of them and are read from the first.)
     const SearchParams &P0 = *Pp;
+#ifdef MH_SLOT_LOOP
+    uint32_t lane_var = threadIdx.x & 63u;
+    const uint32_t &lane = lane_var;
+#else
     const uint32_t lane = threadIdx.x & 63u;
+#endif
     uint32_t nslots = nslots_arg;
     if (MODE == MODE_HIST && P0.hist_nslots) {        // its own list, written by hist_plan_kernel: the count sits in memory
         const uint32_t real = __builtin_amdgcn_readfirstlane(P0.hist_nslots[0]);
@@ -1773,7 +1784,17 @@ __attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE ==
         // COUNT / FILL: one wave per slot (nothing is live across slots -> fewer registers, more waves)
         // (round 5: two / four consecutive slots per one-wave workgroup in the count pass - half / a quarter of the 2.9e5
         // launches - took 1.21 / 0.93 ms against 0.41: the slot body in a loop loses its register allocation; not kept)
+#ifdef MH_SLOT_LOOP
+        // (experiment: MH_SLOT_LOOP consecutive slots per wave)
+#pragma unroll 1
+        for (uint32_t g = 0; g < (uint32_t)MH_SLOT_LOOP; ++g) {
+            const uint32_t w = w0 + g * (gridDim.x * gridDim.y * WAVES_PER_BLOCK);      // (strided: a workgroup's slots keep its XCD)
+            if (w < nslots) process_slot(w);
+            asm volatile("" : "+v"(lane_var));      // nothing derived from the lane id survives an iteration
+        }
+#else
         if (w0 < nslots) process_slot(w0);
+#endif
     } else {
         // histogram mode: capped grid, strided slots, so each workgroup flushes its LDS histogram once
         for (uint32_t w = w0; w < nslots; w += gridDim.x * gridDim.y * WAVES_PER_BLOCK) process_slot(w);
@@ -1803,6 +1824,9 @@ inline void launch_pair_kernel(unsigned nblocks, size_t dyn_lds, hipStream_t str
                                const unsigned long long *slot_base, uint2 *pairs, float *dist, uint32_t *ids) {
     // (count / fill: `nblocks` counts slots = waves; the histogram mode passes workgroups)
     if (MODE != MODE_HIST) nblocks = (nblocks + (unsigned)waves_per_block(MODE) - 1u) / (unsigned)waves_per_block(MODE);
+#ifdef MH_SLOT_LOOP
+    if (MODE != MODE_HIST) nblocks = (nblocks + (unsigned)MH_SLOT_LOOP - 1u) / (unsigned)MH_SLOT_LOOP;
+#endif
     hipLaunchKernelGGL((pair_kernel<KIND, MODE, WPE>), pair_grid(nblocks), dim3(64 * waves_per_block(MODE)), dyn_lds, stream, dP, slot_desc, nslots,
                        slot_cnt, slot_base, pairs, dist, ids);
 }
