@@ -503,18 +503,31 @@ static void membrane_frames_tests() {
         // ---- chained
         auto none = mem.push(a.data(), pbox);
         EXPECT(!none.has_value());
-        auto v = mem.finish();
-        EXPECT(v.has_value() && v->nlipids == (size_t)K);
-        const size_t E = v->patch_entries, slots = E + 4 * (size_t)K;
-        std::vector<float> head(K * 3), tail(K * 3), n0(K * 3), nrm(K * 3), area(K), order(norder), fitted(E * 3), voro(slots * 3), sh(K * 3);
-        std::vector<uint64_t> poff(K + 1), pids(E), neib(slots);
+        std::vector<float> head(K * 3), tail(K * 3), n0(K * 3), nrm(K * 3), area(K), order(norder), sh(K * 3);
+        std::vector<uint64_t> poff(K + 1);
         std::vector<uint8_t> vout(K);
         std::vector<uint32_t> nvert(K);
         molar_hip_membrane_out O{};
         O.head = head.data(); O.tail = tail.data(); O.initial_normals = n0.data(); O.normals = nrm.data(); O.area = area.data();
-        O.order = order.data(); O.fitted_patch_points = fitted.data(); O.voro_vertexes = voro.data(); O.smoothed_head = sh.data();
-        O.patch_offsets = poff.data(); O.patch_ids = pids.data(); O.neib_ids = neib.data(); O.valid = vout.data(); O.nvert = nvert.data();
-        mem.fetch(O);
+        O.order = order.data(); O.smoothed_head = sh.data(); O.patch_offsets = poff.data(); O.valid = vout.data(); O.nvert = nvert.data();
+        // (the middle frame takes its per-lipid arrays with the end of the frame - molar_hip_membrane_frame_end_fetch -, the others
+        // fetch them afterwards: the same bytes either way)
+        auto v = frame == 1 ? mem.finish(O) : mem.finish();
+        EXPECT(v.has_value() && v->nlipids == (size_t)K);
+        const size_t E = v->patch_entries, slots = E + 4 * (size_t)K;
+        std::vector<float> fitted(E * 3), voro(slots * 3);
+        std::vector<uint64_t> pids(E), neib(slots);
+        if (frame == 1) {
+            molar_hip_membrane_out Oe{};
+            Oe.fitted_patch_points = fitted.data(); Oe.voro_vertexes = voro.data(); Oe.patch_ids = pids.data(); Oe.neib_ids = neib.data();
+            mem.fetch(Oe);
+            bool refused = false;                 // patch-sized arrays cannot come with the end of a frame
+            try { MembraneFrames m2(eng, D); (void)m2.push(a.data(), pbox); (void)m2.finish(Oe); } catch (const MolarError &) { refused = true; }
+            EXPECT(refused);
+        } else {
+            O.fitted_patch_points = fitted.data(); O.voro_vertexes = voro.data(); O.patch_ids = pids.data(); O.neib_ids = neib.data();
+            mem.fetch(O);
+        }
         // ---- stage by stage
         check(molar_hip_unwrap_simple_batch(eng.ctx(), b.data(), natoms, lipid_idx.data(), lipid_off.data(), K, box9, 7));
         EXPECT(std::memcmp(a.data(), b.data(), a.size() * 4) == 0);
