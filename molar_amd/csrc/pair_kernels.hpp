@@ -12,16 +12,20 @@ namespace pairk {
 enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_HIST = 2 };
 
 // (The fill kernel is compiled for 8 waves per SIMD - 64 VGPRs, the few spills fall outside the row loop: -5 % against
-// 7 waves; 32 one-wave workgroups hold 144 KB of the CU's 160 KB LDS.  The count kernel runs 7 waves per SIMD since its
-// plain and same-cell entries go through the matrix cores (run_count_mfma keeps a cell's B records in registers):
-// 0.44 against 0.52 ms.)
+// 7 waves; 32 one-wave workgroups hold 144 KB of the CU's 160 KB LDS; re-measured in round 6: 7 / 6 waves lose 1 / 4 % of the
+// headline.  The count kernel keeps a cell's B records in registers for the matrix cores (run_count_mfma): 8 waves (64
+// registers) 0.41 ms at 0.6 nm, 7 waves (72 registers, 70 spilled, 95 scalars spilled) 0.30, SIX waves (80 registers, 4 and 46
+// spilled) 0.29 - and 0.385 -> 0.365 ms on the headline frame, 5 waves 0.32: since round 6 it runs six.)
 // Waves per workgroup.  Count / fill: ONE wave per workgroup - slots differ a lot in work, and a workgroup's
 // resources are only released when its slowest wave ends (measured: 4 -> 1 waves gives +7 % frames/s).  The fused
 // histogram keeps 4: every workgroup owns an LDS histogram that it flushes with atomics at the end.
 // (round 4, count pass with 2 / 4 waves per workgroup - half / a quarter of the 2.9e5 workgroups, whose bare launch takes
 // 69 us: 0.42 / 0.45 ms against 0.40, three alternations on one box)
 #ifndef MH_COUNT_WPE
-#define MH_COUNT_WPE 7
+#define MH_COUNT_WPE 6
+#endif
+#ifndef MH_FILL_WPE
+#define MH_FILL_WPE 8
 #endif
 #ifndef MH_WPB
 #define MH_WPB 1
@@ -795,7 +799,7 @@ __device__ __forceinline__ uint32_t run_count_sorted(const SearchParams &P, cons
 // to run_count_sorted.  Per block: 16 v_alignbit (sign bits), 8 v_min3 (magnitudes), a popcount - 28 VALU instructions
 // for 1024 candidates instead of 160 (90 after run_count_sorted's bounding-box skips).  All memory a slot needs (rows,
 // origin, <= 10 B records per lane) is requested at once: with one block column prefetched the slot was a chain of ten
-// exposed latencies and the kernel no faster than before.  The count kernel runs 7 waves per SIMD (72 registers) for it.
+// exposed latencies and the kernel no faster than before.  The count kernel runs 6 waves per SIMD (80 registers) for it.
 typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 
@@ -1638,7 +1642,7 @@ __device__ __forceinline__ bool hist_lean_slot(const SearchParams &P, uint32_t f
 // in the sheared box at rc 1.6 nm, 636 atoms per cell: 65 M pairs per ms against 220-240 up to 1.4 nm).  0: the usual budget.
 template <int KIND, int MODE, int WPE = 0>
 __global__ void __launch_bounds__(64 * waves_per_block(MODE))
-__attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? MH_COUNT_WPE : 8))))) pair_kernel(const SearchParams *__restrict__ Pp,
+__attribute__((amdgpu_waves_per_eu(WPE ? WPE : (MODE == MODE_HIST ? 4 : (MODE == MODE_COUNT ? MH_COUNT_WPE : MH_FILL_WPE))))) pair_kernel(const SearchParams *__restrict__ Pp,
                                                      const SlotDesc *__restrict__ slot_desc,
                                                      const uint32_t nslots_arg,  // the host's bound: slots past the real count are empty
                                                      uint32_t *__restrict__ slot_cnt,

@@ -1543,3 +1543,13 @@ def test_fused_histogram_frames_host_inputs(eng, orc32):
         want += orc32.histogram_add(0.0, cutoff, nbins, ref["d"]).astype(np.int64)
     bins = eng.search_histogram_frames(a.SEARCH_SINGLE, cutoff, 0.0, cutoff, nbins, frames_np, box=box, pbc=7)
     assert np.array_equal(bins.astype(np.int64), want)
+    # two sets from host memory: the second set a trajectory of its own
+    m = 2500
+    f2 = np.stack([synth.frame(m, box, 70 + f) for f in range(nframes)])
+    idx1 = np.arange(0, n, 3, dtype=np.uint64)
+    want2 = np.zeros(nbins, np.int64)
+    for f in range(nframes):
+        ref = orc32.search_double_pbc(cutoff, frames_np[f][idx1.astype(int)], f2[f], orc32.box_from_matrix(box), 7, nthreads=4)
+        want2 += orc32.histogram_add(0.0, cutoff, nbins, ref["d"]).astype(np.int64)
+    bins2 = eng.search_histogram_frames(a.SEARCH_DOUBLE, cutoff, 0.0, cutoff, nbins, frames_np, idx1=idx1, box=box, pbc=7, frames2=f2)
+    assert want2.sum() > 0 and np.array_equal(bins2.astype(np.int64), want2)
