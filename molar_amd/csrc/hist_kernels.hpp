@@ -48,6 +48,9 @@ typedef __attribute__((address_space(3))) float lds_f32;
 #define MH_HIST_WAVES 16
 #endif
 constexpr int HIST_WAVES = MH_HIST_WAVES;      // waves per workgroup (one LDS histogram per workgroup)
+#ifndef MH_HIST_WPE
+#define MH_HIST_WPE 8          // waves per SIMD the kernel's registers are budgeted for
+#endif
 #ifndef MH_HIST_CU_WAVES
 #define MH_HIST_CU_WAVES 32
 #endif
@@ -320,7 +323,7 @@ __device__ __forceinline__ uint32_t hist_run_wrapped(const SearchParams &P, cons
 // are found.  The other instance is the kernel as it was (wrapping its slot body in that loop cost the C4 frame 3-5 %) and
 // leaves the odd oversized cell of an ordinary frame to the generic kernel.
 template <int KIND, bool BIG>
-__global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(8)))
+__global__ void __launch_bounds__(64 * HIST_WAVES) __attribute__((amdgpu_waves_per_eu(MH_HIST_WPE)))
 hist_kernel(const SearchParams *__restrict__ Pp, const SlotDesc *__restrict__ slot_desc, uint32_t nslots_bound,
             uint32_t *__restrict__ queue, uint32_t lslot) {
     __shared__ float4 lds_a[HIST_WAVES][64];
