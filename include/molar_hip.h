@@ -217,6 +217,14 @@ int molar_hip_unwrap_connectivity(molar_hip_ctx *ctx, float *xyz, size_t natoms,
                                   uint64_t *group_ids, size_t *ngroups);
 /* Grid dims of the cached search (Grid::get_dims, :212-214). */
 int molar_hip_search_grid_dims(molar_hip_ctx *ctx, uint64_t dims[3]);
+/* Which pair kernels the context's last search of a fixed-cutoff kind ran: *lanes = 16 or 32 for the small-cell kernels (frames of
+ * a few atoms per cell: contact / hydrogen-bond cutoffs), 0 for the regular ones.  The choice follows the atoms per OCCUPIED cell
+ * once a search of the same shape (kind, set sizes, grid dims) has finished on this context - every grid build counts its occupied
+ * cells and the host learns the count with the result sizes - and the atoms per cell until then: a slab or a solute in a mostly
+ * empty periodic box has few atoms per cell on average and many per occupied cell, and moves to the regular kernels from its
+ * second or third frame on.  occupied_cells (may be NULL): the counts that search went by, 0 = not known then.  Diagnostic; the
+ * results do not depend on the choice. */
+int molar_hip_search_cell_kernels(molar_hip_ctx *ctx, int32_t *lanes, uint64_t occupied_cells[2]);
 /* Device-resident result of the cached search: fills ctx-owned buffers (reused across frames)
  * and returns their device addresses; valid until the next search on this ctx. */
 int molar_hip_search_fill_device(molar_hip_ctx *ctx, const uint32_t **d_pairs, const float **d_dist);

@@ -114,6 +114,7 @@ SYMBOLS = {
     "molar_hip_within_fill": (_I, [_P, _P]),
     "molar_hip_within_hold": (_I, [_P, _I]),
     "molar_hip_search_grid_dims": (_I, [_P, _P]),
+    "molar_hip_search_cell_kernels": (_I, [_P, _P, _P]),
     "molar_hip_search_count_f64": (_I, [_P, _P, _P]),
     "molar_hip_search_fill_f64": (_I, [_P, _P, _P, _P]),
     "molar_hip_search_fill_ids_f64": (_I, [_P, _P]),

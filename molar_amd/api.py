@@ -273,6 +273,14 @@ class Engine:
         check(self.lib.molar_hip_search_resident(self.ctx, C.byref(desc), C.byref(cnt), C.byref(p), C.byref(dd)))
         return int(cnt.value), p.value, dd.value
 
+    def search_cell_kernels(self):
+        """molar_hip_search_cell_kernels: (lanes, occupied cells of the two grids) of the context's last fixed-cutoff search -
+        lanes 16 / 32 = small-cell kernels, 0 = regular ones."""
+        lanes = C.c_int32(-1)
+        occ = (C.c_uint64 * 2)()
+        check(self.lib.molar_hip_search_cell_kernels(self.ctx, C.byref(lanes), occ))
+        return int(lanes.value), (int(occ[0]), int(occ[1]))
+
     def search_resident_planes(self, want_dist=True):
         """molar_hip_search_resident_planes: want_dist=False makes the resident searches fill the (i, j) plane only
         (DistanceSearchOutput of (usize, usize)); the distance addresses they return are then None."""

@@ -195,6 +195,7 @@ struct molar_hip_ctx {
         bool pending = false, degenerate = false;
         unsigned long long cap0 = 0, maskcap0 = 0, serial = 0, launched = 0, ntasks = 0;
         int kind = -1;
+        unsigned long long occ_key = 0;
         hipEvent_t done = nullptr;
         molar_hip_search_desc desc{};
     } tickets[2];
@@ -208,7 +209,14 @@ struct molar_hip_ctx {
     unsigned long long trim_real = 0, trim_ntasks = 0;   // slots of the last resident search whose sizes were read, and its plan
     int trim_kind = -1;
     uint32_t slot_launch = 0;               // slots the passes of the resident search being enqueued launch (0: the bound)
-    void *h_sizes = nullptr;                // pinned: 16 bytes of result sizes per ticket
+    void *h_sizes = nullptr;                // pinned: 32 bytes of result sizes per ticket (total, history units, slots, occupied cells)
+    // Occupied cells of the two sets' grids as the last finished search of this shape found them (the grid build counts them, the
+    // offsets kernel hands them to the host with the sizes): small_cell_lanes() judges a frame by its atoms per OCCUPIED cell when it
+    // knows - a slab or a solute in a mostly empty periodic box has a small mean and crowded cells.  occ_use: latched per search.
+    unsigned long long occ_key = 0;
+    uint32_t occ_cells[2] = {0, 0};
+    bool occ_valid = false;
+    uint32_t occ_use[2] = {0, 0};           // 0: not known for the search in hand (the grid's cell count stands in)
     mh::DevBuf out_ids;
     mh::DevBuf wide_i, wide_j; // usize widening
     mh::DevBuf hist;           // u64 bins

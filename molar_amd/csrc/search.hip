@@ -333,15 +333,18 @@ constexpr uint32_t ORDER_MAX = 512;   // = KREG * 64 of the pair kernels
 // The PLACE step and the bounding box alone, 16 lanes per cell: grids of ~1e5 cells of a few atoms (vdW cutoffs, `within` with a
 // short range) that want no spatial order.  A wave per cell spends its time starting up: 98 736 waves took 68 us for a set of
 // 950k atoms and 40 us for one of 50k.  Keys are ranked straight from global memory (a cell's segment is one or two lines).
+constexpr uint32_t OCC_WORDS = 16;      // the occupied-cell count of a grid, spread over this many words behind its cell starts
 __global__ void __launch_bounds__(256) place_small_kernel(BinParams P, uint32_t ncells, int ids_local,
                                                           const uint32_t *__restrict__ cell_start,
                                                           const uint32_t *__restrict__ tmp_key, const float *__restrict__ vdw,
                                                           float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
-                                                          float4 *__restrict__ aabb, float4 *__restrict__ cell_org) {
+                                                          float4 *__restrict__ aabb, float4 *__restrict__ cell_org,
+                                                          uint32_t *__restrict__ occupied) {
     const uint32_t sub = threadIdx.x & 15u;
     const uint32_t c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const bool live = c < ncells;                               // (whole 16-lane groups: the shuffles below stay inside a group)
     const uint32_t s = live ? cell_start[c] : 0u, e = live ? cell_start[c + 1] : 0u, n = e - s;
+    if (occupied && sub == 0 && n) atomicAdd(occupied + (c & (OCC_WORDS - 1u)), 1u);      // cells that hold atoms (small_cell_lanes)
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t t = sub; t < n; t += 16u) {
         const uint32_t mine = tmp_key[s + t];
@@ -544,7 +547,10 @@ __global__ void __launch_bounds__(64) place_order_kernel(BinParams P, uint32_t n
                                                           float4 *__restrict__ sorted, float *__restrict__ sorted_vdw,
                                                           float4 *__restrict__ aabb, float4 *__restrict__ perm,
                                                           float4 *__restrict__ chunk_aabb, uint4 *__restrict__ h16,
-                                                          float4 *__restrict__ cell_org, int want_order, int presorted) {
+                                                          float4 *__restrict__ cell_org, int want_order, int presorted,
+                                                          uint32_t *__restrict__ occupied) {
+    if (occupied && threadIdx.x == 0 && blockIdx.x < ncells && cell_start[blockIdx.x + 1] != cell_start[blockIdx.x])
+        atomicAdd(occupied + (blockIdx.x & (OCC_WORDS - 1u)), 1u);
     place_order_body(P, ncells, ids_local, cell_start, tmp_key, vdw, sorted, sorted_vdw, aabb, perm, chunk_aabb, h16, cell_org, want_order, presorted);
 }
 __global__ void __launch_bounds__(64) place_order_frames_kernel(const GridFrame *__restrict__ G, uint32_t ncells, int ids_local) {
@@ -1008,7 +1014,8 @@ __global__ void __launch_bounds__(256) tile_sums_kernel(const uint32_t *__restri
 __global__ void __launch_bounds__(256) slot_offsets_kernel(const uint32_t *__restrict__ slot_cnt,
                                                            const unsigned long long *__restrict__ tile_sum,
                                                            unsigned long long *__restrict__ slot_base, uint64_t n,
-                                                           unsigned long long *__restrict__ sizes_host) {
+                                                           unsigned long long *__restrict__ sizes_host,
+                                                           const uint32_t *__restrict__ occ0, const uint32_t *__restrict__ occ1) {
     __shared__ unsigned long long part[4];
     unsigned long long pre = 0;
     for (uint32_t t = threadIdx.x; t < blockIdx.x; t += 256u) pre += tile_sum[t];
@@ -1021,19 +1028,34 @@ __global__ void __launch_bounds__(256) slot_offsets_kernel(const uint32_t *__res
     unsigned long long tot;
     const unsigned long long ex = block_exclusive_scan<unsigned long long>(v, &tot);
     if (i < n) slot_base[i] = base + ex;
-    if (i + 1 == n && sizes_host) sizes_host[0] = base + ex;      // slot_cnt[n - 1] is the terminator: its offset is the grand total
+    if (i + 1 == n && sizes_host) {
+        sizes_host[0] = base + ex;      // slot_cnt[n - 1] is the terminator: its offset is the grand total
+        // the occupied cells of the two grids (counted by their placement kernels), for the host's choice of kernels next time
+        uint32_t o0 = 0u, o1 = 0u;
+        for (uint32_t k = 0; k < OCC_WORDS; ++k) {
+            o0 += occ0 ? occ0[k] : 0u;
+            o1 += occ1 ? occ1[k] : 0u;
+        }
+        sizes_host[3] = ((unsigned long long)o1 << 32) | o0;
+    }
 }
 
 // slot counts -> output offsets (n = slots + 1 terminator), the grand total also to `sizes_host` (pinned, may be null)
 int scan_slot_counts(molar_hip_ctx *c, unsigned long long *sizes_host) {
     const uint64_t n = c->nslots_bound + 1;
     const uint64_t ntiles = (n + 255) / 256;
+    const uint32_t *occ[2] = {nullptr, nullptr};
+    if (sizes_host) {
+        const size_t ncells = (size_t)c->dims[0] * c->dims[1] * c->dims[2];
+        for (int s = 0; s < (c->kind == MOLAR_HIP_SEARCH_SINGLE ? 1 : 2); ++s)
+            if (c->set[s].cell_count.cap >= (ncells + 1 + OCC_WORDS) * 4) occ[s] = c->set[s].cell_count.as<uint32_t>() + ncells + 1;
+    }
     if (ntiles <= SLOT_SCAN_MAX_TILES && !c->env_no_tile_sum) {
         MH_TRY(c->tile_sum.reserve(ntiles * 8));
         hipLaunchKernelGGL(tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, c->stream, c->slot_cnt.as<uint32_t>(),
                            c->tile_sum.as<unsigned long long>(), n);
         hipLaunchKernelGGL(slot_offsets_kernel, dim3((unsigned)ntiles), dim3(256), 0, c->stream, c->slot_cnt.as<uint32_t>(),
-                           c->tile_sum.as<unsigned long long>(), c->slot_base.as<unsigned long long>(), n, sizes_host);
+                           c->tile_sum.as<unsigned long long>(), c->slot_base.as<unsigned long long>(), n, sizes_host, occ[0], occ[1]);
         MH_HIP(hipGetLastError());
         return 0;
     }
@@ -1169,10 +1191,42 @@ int dims_from_extents(molar_hip_ctx *c, float cutoff, const float ext[3]) {
 // 0.89 / 1.01 / 0.99 ms per frame against 2.91 / 2.14 / 1.66 / 1.30 / 1.07; at 0.55 nm - 23 atoms per cell - the regular kernels win).
 // Decided from the sets' sizes and the grid alone: the grid build (no spatial order for these) and both passes agree on it.
 int small_cell_lanes(const molar_hip_ctx *c) {
+#ifdef MH_NO_SMALL_CELLS
+    return 0;           // (A/B builds: every frame through the regular kernels)
+#endif
     if (c->kind != MOLAR_HIP_SEARCH_SINGLE && c->kind != MOLAR_HIP_SEARCH_DOUBLE) return 0;
     const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
-    const uint64_t n_max = c->kind == MOLAR_HIP_SEARCH_SINGLE ? c->set[0].n : std::max(c->set[0].n, c->set[1].n);
-    return n_max <= 13ull * ncells ? 16 : (n_max <= 19ull * ncells ? 32 : 0);
+    // atoms per OCCUPIED cell where the last search of this shape has told (prepare_search latches occ_use), per cell otherwise
+    int lanes = 16;
+    const int nsets = c->kind == MOLAR_HIP_SEARCH_SINGLE ? 1 : 2;
+    for (int s = 0; s < nsets; ++s) {
+        const uint64_t cells = c->occ_use[s] ? std::min<uint64_t>(c->occ_use[s], ncells) : ncells;
+        const uint64_t n = c->set[s].n;
+        const int l = n <= 13ull * cells ? 16 : (n <= 19ull * cells ? 32 : 0);
+        lanes = (l == 0 || lanes == 0) ? 0 : std::max(lanes, l);
+    }
+    return lanes;
+}
+
+// the shape a grid's occupancy is remembered for
+static unsigned long long occ_key_of(const molar_hip_ctx *c) {
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](unsigned long long v) { h = (h ^ v) * 1099511628211ull; };
+    mix((unsigned long long)c->kind + 1u); mix(c->set[0].n); mix(c->kind == MOLAR_HIP_SEARCH_SINGLE ? 0u : c->set[1].n);
+    mix(c->dims[0]); mix(c->dims[1]); mix(c->dims[2]); mix(c->use_box ? 1u : 2u);
+    return h ? h : 1ull;
+}
+static void occ_latch(molar_hip_ctx *c) {
+    const bool known = c->occ_valid && c->occ_key == occ_key_of(c);
+    c->occ_use[0] = known ? c->occ_cells[0] : 0u;
+    c->occ_use[1] = known ? c->occ_cells[1] : 0u;
+}
+static void occ_note(molar_hip_ctx *c, unsigned long long key, unsigned long long packed) {
+    if (!key || !(uint32_t)packed) return;          // (a search that did not report: the hint stays as it is)
+    c->occ_key = key;
+    c->occ_cells[0] = (uint32_t)packed;
+    c->occ_cells[1] = (uint32_t)(packed >> 32);
+    c->occ_valid = true;
 }
 
 // Does the count pass of this search record hit history for the fill pass to replay?  The fixed-cutoff kinds do - except on
@@ -1206,7 +1260,7 @@ static uint32_t grid_pad_shift(uint32_t n, uint32_t ncells) { return (n && ncell
 
 static int grid_reserve(GridSet &S, uint32_t ncells) {
     MH_TRY(S.key.reserve((size_t)(S.n ? S.n : 1) * 4));
-    MH_TRY(S.cell_count.reserve((size_t)(ncells + 1) * 4));
+    MH_TRY(S.cell_count.reserve((size_t)(ncells + 1 + OCC_WORDS) * 4));      // cell starts, then the occupied-cell counters
     MH_TRY(S.cursor.reserve((size_t)(S.n ? S.n : 1) * 4));   // arrival order of each atom in its cell
     MH_TRY(S.tmp_key.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.sorted.reserve((size_t)(S.n ? S.n : 1) * sizeof(float4)));
@@ -1226,7 +1280,7 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
     const uint32_t ncells = c->dims[0] * c->dims[1] * c->dims[2];
     const BinParams P = grid_bin_params(c, S);
     MH_TRY(S.key.reserve((size_t)(S.n ? S.n : 1) * 4));
-    MH_TRY(S.cell_count.reserve((size_t)(ncells + 1) * 4));
+    MH_TRY(S.cell_count.reserve((size_t)(ncells + 1 + OCC_WORDS) * 4));      // cell starts, then the occupied-cell counters
     MH_TRY(S.cursor.reserve((size_t)(S.n ? S.n : 1) * 4));   // arrival order of each atom in its cell
     MH_TRY(S.tmp_key.reserve((size_t)(S.n ? S.n : 1) * 4));
     MH_TRY(S.sorted.reserve((size_t)(S.n ? S.n : 1) * sizeof(float4)));
@@ -1245,7 +1299,7 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         // workgroup size: one wave on the side stream (see place_order_kernel), four otherwise
         const unsigned bs = c->on_side ? 64u : 256u;
         const unsigned zb = (unsigned)std::min<size_t>((nz + bs - 1) / bs, 2048u * (256u / bs));
-        hipLaunchKernelGGL(zero2_kernel, dim3(zb), dim3(bs), 0, c->stream, S.cell_count.as<uint32_t>(), (size_t)ncells + 1,
+        hipLaunchKernelGGL(zero2_kernel, dim3(zb), dim3(bs), 0, c->stream, S.cell_count.as<uint32_t>(), (size_t)ncells + 1 + OCC_WORDS,
                            S.cnt_pad.as<uint32_t>(), npad);
     }
     if (S.n) {
@@ -1291,12 +1345,14 @@ int build_grid(molar_hip_ctx *c, GridSet &S, int ids_local) {
         if (!want_order && !by_sort && (uint64_t)S.n < 16ull * ncells)
             hipLaunchKernelGGL(place_small_kernel, dim3((unsigned)(((uint64_t)ncells * 16u + bs - 1u) / bs)), dim3(bs), 0, c->stream, P, ncells,
                                ids_local, S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
-                               S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.cell_org.as<float4>());
+                               S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.cell_org.as<float4>(),
+                               S.cell_count.as<uint32_t>() + ncells + 1);
         else
         hipLaunchKernelGGL(place_order_kernel, dim3(ncells), dim3(64), 0, c->stream, P, ncells, ids_local,
                            S.cell_count.as<uint32_t>(), S.tmp_key.as<uint32_t>(), S.d_vdw, S.sorted.as<float4>(),
                            S.d_vdw ? S.sorted_vdw.as<float>() : nullptr, S.aabb.as<float4>(), S.perm.as<float4>(),
-                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>(), want_order, by_sort ? 1 : 0);
+                           S.chunk_aabb.as<float4>(), S.h16.as<uint4>(), S.cell_org.as<float4>(), want_order, by_sort ? 1 : 0,
+                           S.cell_count.as<uint32_t>() + ncells + 1);
         MH_HIP(hipGetLastError());
     }
     return 0;
@@ -1797,6 +1853,7 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
             MH_TRY(stage_set(c, c->set[0], q->xyz1, q->natoms1, q->idx1, q->n1, q->vdw1, vdw));
         }
     }
+    occ_latch(c);        // kind, set sizes and grid dimensions stand: what small_cell_lanes() answers for this search from here on
     const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
     c->ntasks = ncells * 14ull * (two ? 2ull : 1ull);
     // every set-1 cell is the first cell of at most 14 (two grids: 28) tasks, so
@@ -2221,6 +2278,16 @@ int molar_hip_search_grid_dims(molar_hip_ctx *c, uint64_t dims[3]) {
     return MOLAR_HIP_OK;
 }
 
+int molar_hip_search_cell_kernels(molar_hip_ctx *c, int32_t *lanes, uint64_t occupied_cells[2]) {
+    if (!c || !lanes) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_cell_kernels: null argument");
+    *lanes = small_cell_lanes(c);
+    if (occupied_cells) {
+        occupied_cells[0] = c->occ_use[0];
+        occupied_cells[1] = c->occ_use[1];
+    }
+    return MOLAR_HIP_OK;
+}
+
 static int fill_common(molar_hip_ctx *c, uint2 *d_pairs, float *d_dist, uint32_t *d_ids) {
     if (!c || !c->have_search) return fail(MOLAR_HIP_ERR_NO_SEARCH, "no cached search: call molar_hip_search_count first");
     MH_HIP(hipSetDevice(c->device));
@@ -2416,6 +2483,11 @@ static int resident_run(molar_hip_ctx *c, const molar_hip_search_desc *q, mh::De
         MH_HIP(hipStreamSynchronize(c->stream));
         (void)resident_covered(c, c->h_pinned, L.launched, L.ntasks, c->kind);
     }
+    {
+        unsigned long long occ = 0;
+        std::memcpy(&occ, (const char *)c->h_pinned + 24, 8);
+        occ_note(c, occ_key_of(c), occ);
+    }
     return resident_settle(c, outP, outD, c->h_pinned, L);
 }
 
@@ -2511,6 +2583,7 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     c->side_wait2 = (c->count_done_set && c->env_grid_late) ? c->count_done : nullptr;
     if (c->env_grid_late && !c->count_done) MH_HIP(hipEventCreateWithFlags(&c->count_done, hipEventDisableTiming));
     c->record_count_done = c->env_grid_late;
+    std::memset((char *)c->h_sizes + 32 * slot + 24, 0, 8);      // (occupied cells: zero = not reported)
     const int erc = resident_enqueue(c, q, c->out_pairs_set[slot], c->out_dist_set[slot], (char *)c->h_sizes + 32 * slot, &L);
     c->record_count_done = false;
     c->want_side = false;
@@ -2523,6 +2596,7 @@ int molar_hip_search_resident_begin(molar_hip_ctx *c, const molar_hip_search_des
     T.launched = L.launched;
     T.ntasks = L.ntasks;
     T.kind = q->kind;
+    T.occ_key = occ_key_of(c);
     T.degenerate = L.degenerate;
     T.serial = c->search_serial;
     T.pending = true;
@@ -2544,8 +2618,10 @@ int molar_hip_search_resident_end(molar_hip_ctx *c, int32_t ticket, uint64_t *ou
     if (!T.degenerate) {
         MH_HIP(hipEventSynchronize(T.done));
         const void *sizes = (const char *)c->h_sizes + 32 * ticket;
-        unsigned long long res[2];
+        unsigned long long res[2], occ = 0;
         std::memcpy(res, sizes, 16);
+        std::memcpy(&occ, (const char *)sizes + 24, 8);
+        occ_note(c, T.occ_key, occ);
         const bool fast_kind = T.desc.kind == MOLAR_HIP_SEARCH_SINGLE || T.desc.kind == MOLAR_HIP_SEARCH_DOUBLE;
         total = res[0];
         const bool covered = resident_covered(c, sizes, T.launched, T.ntasks, T.kind);

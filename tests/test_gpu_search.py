@@ -992,6 +992,67 @@ def test_non_finite_coordinates_and_degenerate_inputs(eng, orc32):
     assert cnt == 0
 
 
+@pytest.mark.parametrize("kind", ["single", "double"])
+def test_slab_in_a_mostly_empty_box_switches_kernels_between_frames(orc32, kind):
+    """A slab of liquid density in a periodic box that is mostly empty: few atoms per cell on average, many per OCCUPIED cell.  The
+    first searches of a context judge by the average (small-cell kernels); the grid build counts the occupied cells, the host
+    learns the count with the result sizes, and later searches of the same shape go to the regular kernels (hit history and all).
+    Every frame, before and after the switch, synchronous and pipelined, is the oracle's ordered list bit for bit."""
+    a = api()
+    from molar_amd.api import Engine
+    e = Engine(0)
+    rng = np.random.default_rng(21)
+    L, H, thick, rc = 8.0, 30.0, 3.0, 0.9
+    n = int(L * L * thick * 100)
+    box = np.diag([L, L, H]).astype(np.float32)
+    ob = orc32.box_from_matrix(box)
+    i1 = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.uint64)
+    i2 = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.uint64)
+    frames = [(rng.random((n, 3)) * np.array([L, L, thick]) + np.array([0, 0, 0.5 * (H - thick)])).astype(np.float32) for _ in range(6)]
+
+    def want(pos):
+        if kind == "single":
+            return orc32.search_single_pbc(rc, pos, ob, 7, nthreads=8)
+        return orc32.search_double_pbc(rc, pos[i1.astype(int)], pos[i2.astype(int)], ob, 7, ids1=i1, ids2=i2, nthreads=8)
+
+    def run(pos):
+        if kind == "single":
+            cnt, _, _ = e.search_resident(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+        else:
+            cnt, _, _ = e.search_resident(a.SEARCH_DOUBLE, rc, pos, i1, pos, i2, box=box, pbc=7)
+        return e.search_fill(cnt)
+    lanes = []
+    for f in range(4):
+        ref = want(frames[f])
+        pr, d = run(frames[f])
+        assert len(ref["i"]) > 1e5
+        assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"]), f
+        lanes.append(e.search_cell_kernels()[0])
+    assert lanes[0] in (16, 32) and lanes[-1] == 0, lanes          # the average said small cells; the occupied cells said otherwise
+    if kind == "single":
+        import torch
+        e2 = Engine(0)
+        dev = [torch.from_numpy(f).cuda() for f in frames]
+        descs = [e2.make_search_desc(a.SEARCH_SINGLE, rc, f, box=box, pbc=7) for f in dev]
+        counts, prev = [], None
+        for k in range(len(dev)):
+            t = e2.search_resident_begin(descs[k][0])
+            if prev is not None:
+                counts.append(e2.search_resident_end(prev)[0])
+            prev = t
+        cnt, pp, dp = e2.search_resident_end(prev)
+        counts.append(cnt)
+        assert counts == [len(want(f)["i"]) for f in frames]
+        class Dev:
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+        ref = want(frames[-1])
+        got_pairs = torch.as_tensor(Dev(pp, cnt * 2, "<i4"), device="cuda").cpu().numpy().view(np.uint32).reshape(-1, 2)
+        got_dist = torch.as_tensor(Dev(dp, cnt, "<f4"), device="cuda").cpu().numpy()
+        assert np.array_equal(got_pairs[:, 0], ref["i"]) and np.array_equal(got_pairs[:, 1], ref["j"]) and np.array_equal(got_dist, ref["d"])
+        assert e2.search_cell_kernels()[0] == 0 and e2.search_cell_kernels()[1][0] > 0
+
+
 def test_resident_single_round_trip_matches_count_then_fill():
     """molar_hip_search_resident: same ordered result as count + fill, through the grow-and-repeat logic (fresh
     context: every buffer starts empty; then larger and smaller systems on the same context)."""

@@ -10,6 +10,7 @@ for r in $(seq 1 $N); do
   timeout 600 python tools/fuzz_search.py 1500 $((s + 2)) 2>&1 | tail -1 | tee -a $O/search.log
   timeout 300 python tools/fuzz_pipeline.py 400 $((s + 3)) 2>&1 | tail -1 | tee -a $O/pipeline.log
   timeout 400 python tools/fuzz_hist_frames.py 60 $((s + 12)) 2>&1 | tail -1 | tee -a $O/hist_frames.log
+  timeout 600 python tools/fuzz_slab.py 60 $((s + 13)) 2>&1 | tail -1 | tee -a $O/slab.log
   timeout 300 python tools/fuzz_membrane.py 100 $((s + 4)) 2>&1 | tail -1 | tee -a $O/membrane.log
   timeout 300 python tools/fuzz_membrane_frame.py 40 $((s + 10)) 2>&1 | tail -1 | tee -a $O/membrane_frame.log
   timeout 300 python tools/fuzz_lipid_order.py 300 $((s + 5)) 2>&1 | tail -1 | tee -a $O/lipid.log
