@@ -1992,11 +1992,28 @@ int prepare_search(molar_hip_ctx *c, const molar_hip_search_desc *q, bool size_m
 int finish_count(molar_hip_ctx *c) {
     Prof *prof = new Prof(c, 2);
     // (the look-back scan is slower here: ~140 chained tiles take 43 us against 14 us for the three-kernel scan)
-    int rc = scan_slot_counts(c, nullptr);
+    // the grand total (and the grids' occupied cells, for the next search of this shape) straight into pinned memory where the
+    // block is visible to the device; else one read-back of the total
+    void *sizes_dev = nullptr;
+    if (ensure_pinned(c, 64) == 0 && hipHostGetDevicePointer(&sizes_dev, c->h_pinned, 0) == hipSuccess && sizes_dev) {
+        std::memset(c->h_pinned, 0, 32);
+    } else {
+        (void)hipGetLastError();
+        sizes_dev = nullptr;
+    }
+    int rc = scan_slot_counts(c, (unsigned long long *)sizes_dev);
     delete prof;
     MH_TRY(rc);
     unsigned long long tot = 0;
-    MH_TRY(read_back(c, &tot, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8));
+    if (sizes_dev) {
+        MH_HIP(hipStreamSynchronize(c->stream));
+        unsigned long long occ = 0;
+        std::memcpy(&tot, c->h_pinned, 8);
+        std::memcpy(&occ, (const char *)c->h_pinned + 24, 8);
+        occ_note(c, occ_key_of(c), occ);
+    } else {
+        MH_TRY(read_back(c, &tot, c->slot_base.as<unsigned long long>() + c->nslots_bound, 8));
+    }
     c->total = tot;
     c->have_search = true;
     return 0;

@@ -1029,6 +1029,19 @@ def test_slab_in_a_mostly_empty_box_switches_kernels_between_frames(orc32, kind)
         assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"]), f
         lanes.append(e.search_cell_kernels()[0])
     assert lanes[0] in (16, 32) and lanes[-1] == 0, lanes          # the average said small cells; the occupied cells said otherwise
+    # the stream form (count, then fill) learns the same way
+    e3 = Engine(0)
+    lanes3 = []
+    for f in range(3):
+        ref = want(frames[f])
+        if kind == "single":
+            cnt = e3.search_count(a.SEARCH_SINGLE, rc, frames[f], box=box, pbc=7)
+        else:
+            cnt = e3.search_count(a.SEARCH_DOUBLE, rc, frames[f], i1, frames[f], i2, box=box, pbc=7)
+        pr, d = e3.search_fill(cnt)
+        assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"]), f
+        lanes3.append(e3.search_cell_kernels()[0])
+    assert lanes3[0] in (16, 32) and lanes3[1] == 0 and lanes3[2] == 0, lanes3
     if kind == "single":
         import torch
         e2 = Engine(0)
