@@ -218,7 +218,8 @@ int molar_hip_unwrap_connectivity(molar_hip_ctx *ctx, float *xyz, size_t natoms,
 /* Grid dims of the cached search (Grid::get_dims, :212-214). */
 int molar_hip_search_grid_dims(molar_hip_ctx *ctx, uint64_t dims[3]);
 /* Which pair kernels the context's last search of a fixed-cutoff kind ran: *lanes = 16 or 32 for the small-cell kernels (frames of
- * a few atoms per cell: contact / hydrogen-bond cutoffs), 0 for the regular ones.  The choice follows the atoms per OCCUPIED cell
+ * a few atoms per cell: contact / hydrogen-bond cutoffs), 0 for the regular ones, -1 / -2 for the instances that keep second cells
+ * of up to 1024 / 2048 atoms in registers (frames of more than 448 / 1000 atoms per cell).  The choice follows the atoms per OCCUPIED cell
  * once a search of the same shape (kind, set sizes, grid dims) has finished on this context - every grid build counts its occupied
  * cells and the host learns the count with the result sizes - and the atoms per cell until then: a slab or a solute in a mostly
  * empty periodic box has few atoms per cell on average and many per occupied cell, and moves to the regular kernels from its

@@ -1579,8 +1579,11 @@ int launch_pairs(molar_hip_ctx *c, uint2 *pairs, float *dist, uint32_t *ids, uin
     // frames of large cells (more than 448 atoms per cell of the second set on average, i.e. cells above 512 are common): the
     // instances with 128 registers per lane and up to 16 chunks of the second cell resident
     if (!hist_nbins && !ids && (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE)) {
-        const uint64_t ncells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
-        const uint64_t nb_set = c->kind == MOLAR_HIP_SEARCH_SINGLE ? c->set[0].n : c->set[1].n;
+        // (per occupied cell where the last search of this shape has counted them, like small_cell_lanes: a slab in a mostly empty box)
+        const int sb_set = c->kind == MOLAR_HIP_SEARCH_SINGLE ? 0 : 1;
+        const uint64_t all_cells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
+        const uint64_t ncells = c->occ_use[sb_set] ? std::min<uint64_t>(c->occ_use[sb_set], all_cells) : all_cells;
+        const uint64_t nb_set = c->set[sb_set].n;
         if (nb_set > 1000ull * ncells) {       // cells above 1024 atoms are the rule: 256 registers per lane, up to 2048 atoms resident (pair_k7.hip)
             launch_pair_huge(c->kind, mode, P.nblocks, c->stream, dP, tf, st, sc, sb, pairs, dist);
             MH_HIP(hipGetLastError());
@@ -2298,6 +2301,13 @@ int molar_hip_search_grid_dims(molar_hip_ctx *c, uint64_t dims[3]) {
 int molar_hip_search_cell_kernels(molar_hip_ctx *c, int32_t *lanes, uint64_t occupied_cells[2]) {
     if (!c || !lanes) return fail(MOLAR_HIP_ERR_INVALID_ARGUMENT, "search_cell_kernels: null argument");
     *lanes = small_cell_lanes(c);
+    if (*lanes == 0 && (c->kind == MOLAR_HIP_SEARCH_SINGLE || c->kind == MOLAR_HIP_SEARCH_DOUBLE)) {      // (launch_pairs' rule for large cells)
+        const int sb_set = c->kind == MOLAR_HIP_SEARCH_SINGLE ? 0 : 1;
+        const uint64_t all_cells = (uint64_t)c->dims[0] * c->dims[1] * c->dims[2];
+        const uint64_t ncells = c->occ_use[sb_set] ? std::min<uint64_t>(c->occ_use[sb_set], all_cells) : all_cells;
+        if (c->set[sb_set].n > 1000ull * ncells) *lanes = -2;
+        else if (c->set[sb_set].n > 448ull * ncells) *lanes = -1;
+    }
     if (occupied_cells) {
         occupied_cells[0] = c->occ_use[0];
         occupied_cells[1] = c->occ_use[1];

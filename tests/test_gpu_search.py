@@ -992,6 +992,29 @@ def test_non_finite_coordinates_and_degenerate_inputs(eng, orc32):
     assert cnt == 0
 
 
+def test_slab_with_a_large_cutoff_moves_to_the_large_cell_instances(orc32):
+    """The same for large cells: 160 atoms per cell on average (regular kernels), ~900 per occupied cell - from the second frame on the
+    instances that keep up to 1024 atoms of the second cell in registers; the lists stay the oracle's."""
+    a = api()
+    from molar_amd.api import Engine
+    e = Engine(0)
+    rng = np.random.default_rng(22)
+    L, H, thick, rc = 8.0, 30.0, 3.0, 2.2
+    n = int(L * L * thick * 100)
+    box = np.diag([L, L, H]).astype(np.float32)
+    ob = orc32.box_from_matrix(box)
+    kinds = []
+    for f in range(3):
+        pos = (rng.random((n, 3)) * np.array([L, L, thick]) + np.array([0, 0, 0.5 * (H - thick)])).astype(np.float32)
+        ref = orc32.search_single_pbc(rc, pos, ob, 7, nthreads=8)
+        cnt, _, _ = e.search_resident(a.SEARCH_SINGLE, rc, pos, box=box, pbc=7)
+        pr, d = e.search_fill(cnt)
+        assert cnt == len(ref["i"]) > 1e6
+        assert np.array_equal(pr[:, 0], ref["i"]) and np.array_equal(pr[:, 1], ref["j"]) and np.array_equal(d, ref["d"]), f
+        kinds.append(e.search_cell_kernels()[0])
+    assert kinds[0] == 0 and kinds[-1] in (-1, -2), kinds
+
+
 @pytest.mark.parametrize("kind", ["single", "double"])
 def test_slab_in_a_mostly_empty_box_switches_kernels_between_frames(orc32, kind):
     """A slab of liquid density in a periodic box that is mostly empty: few atoms per cell on average, many per OCCUPIED cell.  The
