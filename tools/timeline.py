@@ -5,7 +5,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 def short(n):
-    n = n.replace("mh::pairk::", "").replace("mh::", "")
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "").replace("mh::pairk::", "").replace("mh::", "")
     for a, b in (("pair_kernel<0, 1, 0>", "FILL"), ("pair_kernel<0, 0, 0>", "COUNT"), ("count_task_kernel<0>", "COUNT_T")):
         if a in n: return b
     return n.split("(")[0].split("<")[0][-28:]
